@@ -1,0 +1,154 @@
+/*
+ * pyradiomics_amd.h -- C ABI of the MI355X (gfx950) texture-matrix engine.
+ *
+ * This is the drop-in boundary for pyradiomics' native operator layer.  It replaces
+ *   - the eight C prototypes of radiomics/src/cmatrices.h:1-8, and
+ *   - the per-voxel driver loops of the CPython wrapper radiomics/src/_cmatrices.c
+ *     (set_bb :1120-1147 and the `for v in Nvox` loops :203-222, :355-377, :552-570, :700-718,
+ *     :850-868), which are folded into the calls below so that a whole voxel batch is ONE launch.
+ * The Python face `radiomics.cMatrices` (radiomics/__init__.py:343-349) is restored on top of this
+ * ABI by pyradiomics_amd/cmatrices.py with ctypes; see INTEGRATION.md for the binding a reference
+ * maintainer would add.
+ *
+ * Conventions (all functions):
+ *   - plain pointers and ints only; no exceptions cross the boundary; thread-safe per device.
+ *   - `image` is int32 [size[0]]...[size[Nd-1]] C-contiguous, `mask` is uint8/bool of the same shape
+ *     (what _cmatrices.c:1023-1085 coerces its inputs to).  1 <= Nd <= PRAD_MAX_ND.
+ *   - voxel mode: `voxels` is int32 [Nd][Nvox] (np.where layout, _cmatrices.c:1087-1118); kernel v covers
+ *     centre +- kernelRadius clamped to the array, collapsed in force2Ddim.  Segment mode: voxels=NULL,
+ *     Nvox=1, box = whole array.  force2Ddim = -1 when force2D is off (_cmatrices.c:126).
+ *   - outputs are caller-allocated float64 arrays in the reference's layouts; they need NOT be
+ *     pre-zeroed (the reference memsets them itself, e.g. _cmatrices.c:185).
+ *   - return value: PRAD_OK (1) on success; PRAD_INDEX_ERROR (0) where the reference's core returns 0
+ *     ("index out of range", surfaced by the wrapper as IndexError, _cmatrices.c:219,566,714,864);
+ *     negative PRAD_E_* for everything else; prad_last_error() gives the message.
+ *   - the `_dev` variants take DEVICE pointers for image/mask/voxels/outputs and a hipStream_t (as
+ *     void*); they enqueue on that stream and synchronise it before returning the status.
+ *     The host variants stage through the library's per-device workspace.
+ */
+#ifndef PYRADIOMICS_AMD_H
+#define PYRADIOMICS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRAD_MAX_ND 8
+
+#define PRAD_OK 1
+#define PRAD_INDEX_ERROR 0
+#define PRAD_E_ARG (-1)         /* bad argument (NULL pointer, Nd out of range, kernelRadius <= 0 with voxels...) */
+#define PRAD_E_HIP (-2)         /* HIP runtime failure; message in prad_last_error() */
+#define PRAD_E_NOMEM (-3)       /* device or host allocation failed */
+#define PRAD_E_UNSUPPORTED (-4) /* valid for the reference but not implemented here (stated in the message) */
+
+/* ---- runtime ---------------------------------------------------------------------------------- */
+const char *prad_version(void);
+const char *prad_last_error(void);       /* thread-local, valid until the next failing call */
+int prad_device_count(void);             /* number of visible HIP devices (0 if none) */
+int prad_set_device(int device);         /* selects the device used by this thread's later calls */
+int prad_get_device(void);
+/* name of the code path taken by this thread's last calculate_* call ("sweep", "generic", ...);
+ * lets tests assert that the fast kernels (not a fallback) produced a result. */
+const char *prad_last_path(void);
+/* Total device time (ms, HIP events on the work stream) of this thread's last calculate_* call, and
+ * the time of its dominant kernel family; used by bench.py for the roofline figure. */
+double prad_last_device_ms(void);
+double prad_last_kernel_ms(const char *kernel_family);
+
+/* ---- angles: cmatrices.h get_angle_count / build_angles (cmatrices.c:756-892) ------------------- */
+/* returns the number of angles, 0 on invalid distance (as the reference) */
+int prad_get_angle_count(const int *size, const int *distances, int Nd, int Ndist, int bidirectional,
+                         int force2Ddim);
+/* returns 0 on success, 1 on invalid distance (as the reference); angles is int32 [Na][Nd] */
+int prad_build_angles(const int *size, const int *distances, int Nd, int Ndist, int force2Ddim, int Na,
+                      int *angles);
+
+/* ---- GLCM: calculate_glcm (cmatrices.c:4-92) ---------------------------------------------------- */
+/* glcm: float64 [Nvox][Ng][Ng][Na] */
+int prad_calculate_glcm(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                        const int *angles, int Na, int Ng,
+                        int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                        double *glcm);
+int prad_calculate_glcm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                            const int *angles, int Na, int Ng,
+                            int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                            double *glcm, void *stream);
+
+/* ---- GLRLM: calculate_glrlm (cmatrices.c:299-541) ----------------------------------------------- */
+/* glrlm: float64 [Nvox][Ng][Nr][Na] */
+int prad_calculate_glrlm(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                         const int *angles, int Na, int Ng, int Nr,
+                         int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                         double *glrlm);
+int prad_calculate_glrlm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                             const int *angles, int Na, int Ng, int Nr,
+                             int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                             double *glrlm, void *stream);
+
+/* ---- GLCM + GLRLM in one call (the headline path: one discretised volume -> both matrices).
+ * Same results as the two calls above with the same `angles`; the volume is packed once and every
+ * angle is swept once for both matrices.  Either output may be NULL to skip it. ------------------- */
+int prad_calculate_glcm_glrlm(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                              const int *angles, int Na, int Ng, int Nr,
+                              int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                              double *glcm, double *glrlm);
+int prad_calculate_glcm_glrlm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                                  const int *angles, int Na, int Ng, int Nr,
+                                  int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                                  double *glcm, double *glrlm, void *stream);
+
+/* ---- GLDM: calculate_gldm (cmatrices.c:660-754) -------------------------------------------------- */
+/* gldm: float64 [Nvox][Ng][2*Na+1] */
+int prad_calculate_gldm(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                        const int *angles, int Na, int Ng, int alpha,
+                        int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                        double *gldm);
+int prad_calculate_gldm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                            const int *angles, int Na, int Ng, int alpha,
+                            int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                            double *gldm, void *stream);
+
+/* ---- NGTDM: calculate_ngtdm (cmatrices.c:543-658) ------------------------------------------------ */
+/* ngtdm: float64 [Nvox][Ng][3].  Column 1 (sum of |i - mean(neighbours)|) is evaluated as
+ * sum_c (sum_p |c*i - s|)/c with exact integer inner sums in segment mode (<= 1e-12 relative from the
+ * reference's raster-order float64 sum) and in raster order -- bit-identical -- in voxel mode. */
+int prad_calculate_ngtdm(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                         const int *angles, int Na, int Ng,
+                         int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                         double *ngtdm);
+int prad_calculate_ngtdm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                             const int *angles, int Na, int Ng,
+                             int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                             double *ngtdm, void *stream);
+
+/* ---- GLSZM: calculate_glszm + fill_glszm (cmatrices.c:94-297) ----------------------------------- */
+/* Phase 1: labels the zones of every kernel on the device and keeps the (level, size) list in the
+ * library's per-thread workspace.  Returns the largest zone size over all Nvox kernels (>= 0), or
+ * PRAD_E_* (< 0); *nzones (optional) receives the total number of zones.  `Ns` is accepted for
+ * signature parity (it only sizes scratch in the reference, _cmatrices.c:298-322). */
+int prad_calculate_glszm(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                         const int *angles, int Na, int Ng, int Ns,
+                         int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                         long long *nzones);
+int prad_calculate_glszm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                             const int *angles, int Na, int Ng, int Ns,
+                             int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                             long long *nzones, void *stream);
+/* Phase 2: histograms the zone list of the preceding phase-1 call into glszm float64
+ * [Nvox][Ng][maxRegion] (host pointer for prad_fill_glszm, device pointer for _dev).
+ * Returns PRAD_OK, or PRAD_INDEX_ERROR when a zone has level <= 0 or falls outside Ng x maxRegion
+ * (cmatrices.c:290-291). */
+int prad_fill_glszm(double *glszm, int Nvox, int Ng, int maxRegion);
+int prad_fill_glszm_dev(double *glszm, int Nvox, int Ng, int maxRegion, void *stream);
+/* Optional: copy the zone list of kernel v to the host in the reference's tempData format
+ * (level,size pairs in raster order of each zone's first voxel, terminated by -1; cmatrices.c:255-276).
+ * tempData must hold 2*nzones_v+1 ints; returns nzones_v or PRAD_E_*. */
+long long prad_glszm_zones(int v, int *tempData, long long capacity_pairs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYRADIOMICS_AMD_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of include/pyradiomics_amd.h.  There is no fallback: if the HIP library is missing the
+import fails loudly, and if no GPU is visible every calculate_* call raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpyradiomics_amd.so")
+
+PRAD_OK = 1
+PRAD_INDEX_ERROR = 0
+PRAD_E_ARG, PRAD_E_HIP, PRAD_E_NOMEM, PRAD_E_UNSUPPORTED = -1, -2, -3, -4
+
+_ip = C.POINTER(C.c_int)
+_vp = C.c_void_p
+
+# every symbol include/pyradiomics_amd.h declares: name -> (restype, argtypes)
+_COMMON = [_vp, _vp, _ip, C.c_int, _ip, C.c_int]          # image, mask, size, Nd, angles, Na
+_VOX = [C.c_int, _vp, C.c_int, C.c_int]                   # Nvox, voxels, kernelRadius, force2Ddim
+SYMBOLS = {
+    "prad_version": (C.c_char_p, []),
+    "prad_last_error": (C.c_char_p, []),
+    "prad_last_path": (C.c_char_p, []),
+    "prad_device_count": (C.c_int, []),
+    "prad_set_device": (C.c_int, [C.c_int]),
+    "prad_get_device": (C.c_int, []),
+    "prad_last_device_ms": (C.c_double, []),
+    "prad_last_kernel_ms": (C.c_double, [C.c_char_p]),
+    "prad_get_angle_count": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "prad_build_angles": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
+    "prad_calculate_glcm": (C.c_int, _COMMON + [C.c_int] + _VOX + [_vp]),
+    "prad_calculate_glcm_dev": (C.c_int, _COMMON + [C.c_int] + _VOX + [_vp, _vp]),
+    "prad_calculate_glrlm": (C.c_int, _COMMON + [C.c_int, C.c_int] + _VOX + [_vp]),
+    "prad_calculate_glrlm_dev": (C.c_int, _COMMON + [C.c_int, C.c_int] + _VOX + [_vp, _vp]),
+    "prad_calculate_glcm_glrlm": (C.c_int, _COMMON + [C.c_int, C.c_int] + _VOX + [_vp, _vp]),
+    "prad_calculate_glcm_glrlm_dev": (C.c_int, _COMMON + [C.c_int, C.c_int] + _VOX + [_vp, _vp, _vp]),
+    "prad_calculate_gldm": (C.c_int, _COMMON + [C.c_int, C.c_int] + _VOX + [_vp]),
+    "prad_calculate_gldm_dev": (C.c_int, _COMMON + [C.c_int, C.c_int] + _VOX + [_vp, _vp]),
+    "prad_calculate_ngtdm": (C.c_int, _COMMON + [C.c_int] + _VOX + [_vp]),
+    "prad_calculate_ngtdm_dev": (C.c_int, _COMMON + [C.c_int] + _VOX + [_vp, _vp]),
+    "prad_calculate_glszm": (C.c_int, _COMMON + [C.c_int, C.c_int] + _VOX + [C.POINTER(C.c_longlong)]),
+    "prad_calculate_glszm_dev": (C.c_int, _COMMON + [C.c_int, C.c_int] + _VOX + [C.POINTER(C.c_longlong), _vp]),
+    "prad_fill_glszm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
+    "prad_fill_glszm_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "prad_glszm_zones": (C.c_longlong, [C.c_int, _ip, C.c_longlong]),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded CDLL (cached).  Raises ImportError when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "pyradiomics_amd: %s is missing. Build it with `python -m pyradiomics_amd._build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError here = header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().prad_last_error().decode("utf-8", "replace")
+
+
+def last_path() -> str:
+    return load().prad_last_path().decode()
+
+
+def raise_for(rc: int, what: str) -> None:
+    """Maps a C status to the exception the reference wrapper raises (_cmatrices.c:219,566,714,864...)."""
+    if rc == PRAD_OK:
+        return
+    if rc == PRAD_INDEX_ERROR:
+        raise IndexError("Calculation of %s Failed." % what)
+    msg = "%s: %s" % (what, last_error())
+    if rc == PRAD_E_NOMEM:
+        raise MemoryError(msg)
+    if rc == PRAD_E_ARG:
+        raise ValueError(msg)
+    if rc == PRAD_E_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)

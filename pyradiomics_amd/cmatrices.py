@@ -1,0 +1,179 @@
+"""Drop-in for the reference's native operator module `radiomics._cmatrices`
+(bound as `radiomics.cMatrices`, radiomics/__init__.py:343-349).
+
+Same six functions, same positional signatures, same dtype coercions, output shapes/dtypes and exception
+types as radiomics/src/_cmatrices.c -- but every matrix is built on the MI355X through the C ABI of
+include/pyradiomics_amd.h (ctypes).  A reference checkout switches over with
+
+    import radiomics, pyradiomics_amd.cmatrices
+    radiomics.cMatrices = pyradiomics_amd.cmatrices          # the one line at radiomics/__init__.py:348
+
+Inputs are numpy arrays (host); the device-resident entry points used by the benchmark and the batch /
+voxel drivers live in pyradiomics_amd.engine.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_ip = C.POINTER(C.c_int)
+
+
+def _iptr(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _vptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+def _parse_arrays(image, mask):
+    """_cmatrices.c:1023-1085 (try_parse_arrays): int32 / bool, C-contiguous, equal rank and shape."""
+    img = np.ascontiguousarray(np.asarray(image).astype(np.intc, copy=False))
+    msk = np.ascontiguousarray(np.asarray(mask).astype(np.bool_, copy=False))
+    if img.ndim != msk.ndim:
+        raise ValueError("Expected image and mask to have equal number of dimensions.")
+    if img.shape != msk.shape:
+        raise ValueError("Dimensions of image and mask do not match.")
+    size = np.array(img.shape, dtype=np.intc)
+    return img, msk, size
+
+
+def _parse_voxels(voxels, Nd, kernelRadius):
+    """_cmatrices.c:1087-1118 (try_parse_voxels_arr)."""
+    if voxels is None:
+        return None, 1
+    if kernelRadius <= 0:
+        raise RuntimeError("Expecting kernelRadius > 0")
+    v = np.ascontiguousarray(np.asarray(voxels).astype(np.intc, copy=False))
+    if v.ndim != 2 or v.shape[0] != Nd:
+        raise RuntimeError("Expecting voxel indices array to be 2-dimensional")
+    return v, int(v.shape[1])
+
+
+def _build_angles(size, distances, bidirectional, force2Ddim):
+    """_cmatrices.c:926-1021 (build_angles_arr) on prad_get_angle_count / prad_build_angles."""
+    lib = _lib.load()
+    if distances is None:
+        dist = np.array([1], dtype=np.intc)
+    else:
+        try:
+            dist = np.ascontiguousarray(np.asarray(distances).astype(np.intc, copy=False))
+        except (TypeError, ValueError):
+            raise RuntimeError("Error parsing distances array.")
+        if dist.ndim != 1:
+            raise ValueError("Expecting distances array to be 1-dimensional.")
+    Nd = int(size.shape[0])
+    Na = lib.prad_get_angle_count(_iptr(size), _iptr(dist), Nd, int(dist.shape[0]), int(bool(bidirectional)),
+                                  int(force2Ddim)) if dist.shape[0] > 0 else 0
+    if Na == 0:
+        raise RuntimeError("Error getting angle count.")
+    angles = np.empty((Na, Nd), dtype=np.intc)
+    if lib.prad_build_angles(_iptr(size), _iptr(dist), Nd, int(dist.shape[0]), int(force2Ddim), Na, _iptr(angles)) > 0:
+        raise RuntimeError("Error building angles.")
+    return angles
+
+
+def _common(image, mask, distances, bidirectional, force2D, force2Ddimension, kernelRadius, voxels):
+    img, msk, size = _parse_arrays(image, mask)
+    vox, Nvox = _parse_voxels(voxels, img.ndim, kernelRadius)
+    f2d = int(force2Ddimension) if force2D else -1
+    angles = _build_angles(size, distances, bidirectional, f2d)
+    return img, msk, size, vox, Nvox, f2d, angles
+
+
+def calculate_glcm(image, mask, distances, Ng, force2D, force2Ddimension, kernelRadius=0, voxels=None):
+    """-> (P float64 [Nvox, Ng, Ng, Na], angles int32 [Na, Nd]);  _cmatrices.c:84-233"""
+    img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, distances, False, force2D, force2Ddimension,
+                                                     kernelRadius, voxels)
+    Na, Nd = angles.shape
+    out = np.empty((Nvox, Ng, Ng, Na), dtype=np.float64)
+    rc = _lib.load().prad_calculate_glcm(_vptr(img), _vptr(msk), _iptr(size), Nd, _iptr(angles), Na, int(Ng),
+                                         Nvox, _vptr(vox), int(kernelRadius), f2d, _vptr(out))
+    _lib.raise_for(rc, "GLCM")
+    return out, angles
+
+
+def calculate_glrlm(image, mask, Ng, Nr, force2D, force2Ddimension, kernelRadius=0, voxels=None):
+    """-> (P float64 [Nvox, Ng, Nr, Na], angles);  _cmatrices.c:432-581 (distances fixed to [1])"""
+    img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, None, False, force2D, force2Ddimension,
+                                                     kernelRadius, voxels)
+    Na, Nd = angles.shape
+    out = np.empty((Nvox, Ng, Nr, Na), dtype=np.float64)
+    rc = _lib.load().prad_calculate_glrlm(_vptr(img), _vptr(msk), _iptr(size), Nd, _iptr(angles), Na, int(Ng),
+                                          int(Nr), Nvox, _vptr(vox), int(kernelRadius), f2d, _vptr(out))
+    _lib.raise_for(rc, "GLRLM")
+    return out, angles
+
+
+def calculate_glcm_glrlm(image, mask, Ng, Nr, force2D, force2Ddimension, kernelRadius=0, voxels=None):
+    """Both matrices for distance 1 from one pack + one sweep per angle (no reference analogue; results equal
+    calculate_glcm(..., [1], ...) and calculate_glrlm(...)).  -> (P_glcm, P_glrlm, angles)"""
+    img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, None, False, force2D, force2Ddimension,
+                                                     kernelRadius, voxels)
+    Na, Nd = angles.shape
+    glcm = np.empty((Nvox, Ng, Ng, Na), dtype=np.float64)
+    glrlm = np.empty((Nvox, Ng, Nr, Na), dtype=np.float64)
+    rc = _lib.load().prad_calculate_glcm_glrlm(_vptr(img), _vptr(msk), _iptr(size), Nd, _iptr(angles), Na, int(Ng),
+                                               int(Nr), Nvox, _vptr(vox), int(kernelRadius), f2d, _vptr(glcm),
+                                               _vptr(glrlm))
+    _lib.raise_for(rc, "GLCM+GLRLM")
+    return glcm, glrlm, angles
+
+
+def calculate_gldm(image, mask, distances, Ng, alpha, force2D, force2Ddimension, kernelRadius=0, voxels=None):
+    """-> P float64 [Nvox, Ng, 2*Na+1] (Na = bidirectional angle count);  _cmatrices.c:731-880"""
+    img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, distances, True, force2D, force2Ddimension,
+                                                     kernelRadius, voxels)
+    Na, Nd = angles.shape
+    out = np.empty((Nvox, Ng, 2 * Na + 1), dtype=np.float64)
+    rc = _lib.load().prad_calculate_gldm(_vptr(img), _vptr(msk), _iptr(size), Nd, _iptr(angles), Na, int(Ng),
+                                         int(alpha), Nvox, _vptr(vox), int(kernelRadius), f2d, _vptr(out))
+    _lib.raise_for(rc, "GLDM")
+    return out
+
+
+def calculate_ngtdm(image, mask, distances, Ng, force2D, force2Ddimension, kernelRadius=0, voxels=None):
+    """-> P float64 [Nvox, Ng, 3];  _cmatrices.c:583-729"""
+    img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, distances, True, force2D, force2Ddimension,
+                                                     kernelRadius, voxels)
+    Na, Nd = angles.shape
+    out = np.empty((Nvox, Ng, 3), dtype=np.float64)
+    rc = _lib.load().prad_calculate_ngtdm(_vptr(img), _vptr(msk), _iptr(size), Nd, _iptr(angles), Na, int(Ng),
+                                          Nvox, _vptr(vox), int(kernelRadius), f2d, _vptr(out))
+    _lib.raise_for(rc, "NGTDM")
+    return out
+
+
+def calculate_glszm(image, mask, Ng, Ns, force2D, force2Ddimension, kernelRadius=0, voxels=None):
+    """-> P float64 [Nvox, Ng, maxRegion], last axis cropped to the largest zone found (>= 1);
+    _cmatrices.c:235-430.  The input mask is not modified (the reference works on a private copy)."""
+    img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, None, True, force2D, force2Ddimension,
+                                                     kernelRadius, voxels)
+    Na, Nd = angles.shape
+    lib = _lib.load()
+    nz = C.c_longlong(0)
+    rc = lib.prad_calculate_glszm(_vptr(img), _vptr(msk), _iptr(size), Nd, _iptr(angles), Na, int(Ng), int(Ns),
+                                  Nvox, _vptr(vox), int(kernelRadius), f2d, C.byref(nz))
+    if rc < 0:
+        if rc == _lib.PRAD_E_ARG or rc == _lib.PRAD_E_UNSUPPORTED or rc == _lib.PRAD_E_HIP or rc == _lib.PRAD_E_NOMEM:
+            _lib.raise_for(rc, "GLSZM")
+        raise IndexError("Calculation of GLSZM Failed.")
+    maxRegion = max(int(rc), 1)   # _cmatrices.c:390
+    out = np.empty((Nvox, Ng, maxRegion), dtype=np.float64)
+    rc = lib.prad_fill_glszm(_vptr(out), Nvox, int(Ng), maxRegion)
+    if rc == _lib.PRAD_INDEX_ERROR:
+        raise IndexError("Error filling GLSZM.")
+    _lib.raise_for(rc, "GLSZM")
+    return out
+
+
+def generate_angles(size, distances, bidirectional, force2D, force2Ddimension):
+    """-> int32 [Na, Nd];  _cmatrices.c:882-924"""
+    size = np.ascontiguousarray(np.asarray(size).astype(np.intc, copy=False))
+    if size.ndim != 1:
+        raise ValueError("Expected a 1D array for size")
+    return _build_angles(size, distances, bidirectional, int(force2Ddimension) if force2D else -1)

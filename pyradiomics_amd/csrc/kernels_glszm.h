@@ -1,0 +1,450 @@
+// kernels_glszm.h -- grey-level size-zone matrix on gfx950 (cmatrices.c:94-297).
+//
+// Segment mode (one box = the whole array): zones are the connected components of equal-level masked voxels
+// under the angle set, found by label-equivalence union-find in HBM:
+//     init     label[i] = i (masked) | -1
+//     merge    for each masked voxel and each "backward" neighbour (linear offset < 0) of equal level:
+//              union by atomicMin on the larger root (the returned old value keeps the structure consistent
+//              when views are stale, so no inter-workgroup fence is needed inside the kernel)
+//     flatten  label[i] = root(i);   count  size[root] += 1;   stats  maxRegion, nzones
+// The root of a zone is its smallest linear index = the voxel where the reference's raster scan discovers the
+// zone, so listing roots in index order reproduces the reference's tempData order exactly (cmatrices.c:255-258).
+//
+// Voxel mode (many small boxes): one lane per kernel runs the reference's raster-order flood fill inside its
+// box with a private visited map / stack (interleaved [slot][kernel] so neighbouring lanes touch neighbouring
+// addresses); the mask itself is never modified, which replaces the reference's processedStack restore
+// (cmatrices.c:264-272).
+//
+// Phase 2 (fill) histograms (level, size) into float64 [Nvox][Ng][maxRegion] once the caller knows maxRegion.
+#pragma once
+#include <algorithm>
+#include "prad_runtime.h"
+#include "kernels_generic.h"
+
+namespace prad {
+
+struct GlszmState {
+  bool valid = false;
+  bool voxel_mode = false;
+  int device = -1;
+  Geo g;
+  int nvox = 0;
+  long long boxmax = 0;
+  long long nzones = 0;
+  int max_region = 0;
+  const int32_t *image = nullptr;  // segment mode: levels are read from the image at fill time
+  int *labels = nullptr;           // segment: [n] root label or -1
+  unsigned *sizes = nullptr;       // segment: [n] zone size at root index
+  int *zones = nullptr;            // voxel: [boxmax][2][nvox] (level,size) interleaved by kernel
+  int *zone_count = nullptr;       // voxel: [nvox]
+};
+inline GlszmState &glszm_state() {
+  static thread_local GlszmState s;
+  return s;
+}
+
+// ---- segment mode --------------------------------------------------------------------------------
+__global__ void glszm_init_kernel(const uint8_t *__restrict__ mask, long long n, int *__restrict__ labels,
+                                  unsigned *__restrict__ sizes) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    labels[i] = mask[i] ? (int)i : -1;
+    sizes[i] = 0;
+  }
+}
+
+__device__ __forceinline__ int uf_find(const int *labels, int i) {
+  int p;
+  while ((p = __builtin_nontemporal_load(labels + i)) != i) i = p;
+  return i;
+}
+
+__device__ __forceinline__ void uf_union(int *labels, int a, int b) {
+  while (true) {
+    a = uf_find(labels, a);
+    b = uf_find(labels, b);
+    if (a == b) return;
+    if (a < b) { int t = a; a = b; b = t; }
+    const int old = atomicMin(labels + a, b);
+    if (old == a) return;  // a was a root and now points to b
+    a = old;               // a had already been linked elsewhere: join that set with b's
+  }
+}
+
+__global__ void __launch_bounds__(256) glszm_merge_kernel(Geo g, const int *__restrict__ angles, int Na,
+                                                          const int *__restrict__ image,
+                                                          const uint8_t *__restrict__ mask,
+                                                          int *__restrict__ labels) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += stride) {
+    if (!mask[i]) continue;
+    int c[PRAD_MAX_ND];
+    long long rem = i;
+    for (int d = 0; d < g.nd; d++) {
+      c[d] = (int)(rem / g.stride[d]);
+      rem -= (long long)c[d] * g.stride[d];
+    }
+    const int gl = image[i];
+    for (int a = 0; a < Na; a++) {
+      long long j = 0;
+      bool in = true;
+      for (int d = 0; d < g.nd; d++) {
+        const int q = c[d] + angles[a * g.nd + d];
+        if (q < 0 || q >= g.size[d]) { in = false; break; }
+        j += (long long)q * g.stride[d];
+      }
+      if (!in || j >= i) continue;  // only backward neighbours: each adjacent pair is united once
+      if (mask[j] && image[j] == gl) uf_union(labels, (int)i, (int)j);
+    }
+  }
+}
+
+__global__ void glszm_flatten_count_kernel(long long n, int *__restrict__ labels, unsigned *__restrict__ sizes) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int l = labels[i];
+    if (l < 0) continue;
+    int r = l;
+    int p;
+    while ((p = labels[r]) != r) r = p;
+    if (r != l) labels[i] = r;
+    atomicAdd(sizes + r, 1u);
+  }
+}
+
+// stats[0] = max zone size, stats64[0] = zone count
+__global__ void glszm_stats_kernel(long long n, const int *__restrict__ labels, const unsigned *__restrict__ sizes,
+                                   int *__restrict__ stats, unsigned long long *__restrict__ stats64) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  unsigned mx = 0;
+  unsigned long long cnt = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (labels[i] == (int)i) {
+      cnt++;
+      mx = max(mx, sizes[i]);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+    cnt += __shfl_xor(cnt, o);
+  }
+  if ((threadIdx.x & 63) == 0 && cnt) {
+    atomicMax(stats, (int)mx);
+    atomicAdd(stats64, cnt);
+  }
+}
+
+__global__ void glszm_fill_segment_kernel(long long n, const int *__restrict__ labels,
+                                          const unsigned *__restrict__ sizes, const int *__restrict__ image, int Ng,
+                                          int maxRegion, double *__restrict__ out, int *__restrict__ err) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const unsigned long long idx_max = (unsigned long long)Ng * maxRegion;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (labels[i] != (int)i) continue;
+    const int gl = image[i];
+    const unsigned long long idx = (unsigned long long)((long long)(gl - 1) * maxRegion + (long long)sizes[i] - 1);
+    if (gl <= 0 || idx >= idx_max) {  // cmatrices.c:290-291
+      *err = 1;
+      continue;
+    }
+    atomicAdd(out + idx, 1.0);
+  }
+}
+
+// ordered zone list (tempData parity): block counts -> scan -> scatter
+#define PRAD_ZL_BLOCK 1024
+__global__ void __launch_bounds__(256) glszm_root_count_kernel(long long n, const int *__restrict__ labels,
+                                                               unsigned *__restrict__ block_counts) {
+  __shared__ unsigned s;
+  if (threadIdx.x == 0) s = 0;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * PRAD_ZL_BLOCK;
+  unsigned c = 0;
+  for (int k = threadIdx.x; k < PRAD_ZL_BLOCK; k += 256) {
+    const long long i = base + k;
+    if (i < n && labels[i] == (int)i) c++;
+  }
+  if (c) atomicAdd(&s, c);
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = s;
+}
+
+// single-workgroup exclusive scan (nblocks is at most n/1024 ~ 2M for a 2^31 array)
+__global__ void __launch_bounds__(1024) glszm_scan_kernel(long long nblocks, const unsigned *__restrict__ counts,
+                                                          unsigned long long *__restrict__ offsets) {
+  __shared__ unsigned long long part[1024];
+  const long long per = (nblocks + 1023) / 1024;
+  const long long lo = (long long)threadIdx.x * per, hi = min(nblocks, lo + per);
+  unsigned long long s = 0;
+  for (long long i = lo; i < hi; i++) s += counts[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long run = 0;
+    for (int t = 0; t < 1024; t++) {
+      unsigned long long v = part[t];
+      part[t] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  unsigned long long run = part[threadIdx.x];
+  for (long long i = lo; i < hi; i++) {
+    offsets[i] = run;
+    run += counts[i];
+  }
+}
+
+__global__ void __launch_bounds__(64) glszm_root_scatter_kernel(long long n, const int *__restrict__ labels,
+                                                                const unsigned *__restrict__ sizes,
+                                                                const int *__restrict__ image,
+                                                                const unsigned long long *__restrict__ offsets,
+                                                                int *__restrict__ pairs) {
+  // one wave per 1024-voxel block, walking it 64 voxels at a time so the output order is the index order
+  const long long base = (long long)blockIdx.x * PRAD_ZL_BLOCK;
+  unsigned long long out = offsets[blockIdx.x];
+  const int lane = threadIdx.x;
+  for (int k = 0; k < PRAD_ZL_BLOCK; k += 64) {
+    const long long i = base + k + lane;
+    const bool root = i < n && labels[i] == (int)i;
+    const unsigned long long m = __ballot(root);
+    if (root) {
+      const unsigned long long rank = __popcll(m & ((1ull << lane) - 1ull));
+      pairs[(out + rank) * 2] = image[i];
+      pairs[(out + rank) * 2 + 1] = (int)sizes[i];
+    }
+    out += __popcll(m);
+  }
+}
+
+// ---- voxel mode ----------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) glszm_voxel_kernel(Geo g, VoxMode vm, const int *__restrict__ image,
+                                                         const uint8_t *__restrict__ mask,
+                                                         const int *__restrict__ angles, int Na,
+                                                         uint8_t *__restrict__ visited, int *__restrict__ stack,
+                                                         int *__restrict__ zones, int *__restrict__ zone_count,
+                                                         int *__restrict__ stats,
+                                                         unsigned long long *__restrict__ stats64) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= vm.nvox) return;
+  const long long NV = vm.nvox;
+  int lo[PRAD_MAX_ND], hi[PRAD_MAX_ND], ext[PRAD_MAX_ND], c[PRAD_MAX_ND];
+  kernel_box(g, vm, v, lo, hi);
+  long long total = 1;
+  for (int d = 0; d < g.nd; d++) {
+    ext[d] = hi[d] - lo[d] + 1;
+    total *= ext[d];
+  }
+  for (long long k = 0; k < total; k++) visited[k * NV + v] = 0;
+  int nz = 0, mx = 0;
+  for (long long k = 0; k < total; k++) {
+    if (visited[k * NV + v]) continue;
+    long long i;
+    box_decode(g, lo, hi, k, c, &i);
+    if (!mask[i]) continue;
+    const int gl = image[i];
+    int region = 0;
+    long long top = 0;
+    stack[(top++) * NV + v] = (int)k;
+    visited[k * NV + v] = 1;
+    while (top > 0) {
+      const long long kk = stack[(--top) * NV + v];
+      region++;
+      long long ii;
+      box_decode(g, lo, hi, kk, c, &ii);
+      for (int a = 0; a < Na; a++) {
+        const int *ang = angles + a * g.nd;
+        long long j = 0, kj = 0;
+        bool in = true;
+        for (int d = 0; d < g.nd; d++) {
+          const int q = c[d] + ang[d];
+          if (q < lo[d] || q > hi[d]) { in = false; break; }
+          j += (long long)q * g.stride[d];
+          kj = kj * ext[d] + (q - lo[d]);
+        }
+        if (!in || visited[kj * NV + v] || !mask[j] || image[j] != gl) continue;
+        visited[kj * NV + v] = 1;
+        stack[(top++) * NV + v] = (int)kj;
+      }
+    }
+    zones[((long long)nz * 2) * NV + v] = gl;
+    zones[((long long)nz * 2 + 1) * NV + v] = region;
+    nz++;
+    mx = max(mx, region);
+  }
+  zone_count[v] = nz;
+  if (nz) {
+    atomicMax(stats, mx);
+    atomicAdd(stats64, (unsigned long long)nz);
+  }
+}
+
+__global__ void glszm_fill_voxel_kernel(int nvox, long long boxmax, const int *__restrict__ zones,
+                                        const int *__restrict__ zone_count, int Ng, int maxRegion,
+                                        double *__restrict__ out, int *__restrict__ err) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long z = gid / nvox;
+  const int v = (int)(gid % nvox);
+  if (z >= boxmax || z >= zone_count[v]) return;
+  const int gl = zones[(z * 2) * nvox + v], sz = zones[(z * 2 + 1) * nvox + v];
+  const unsigned long long idx_max = (unsigned long long)Ng * maxRegion;
+  const unsigned long long idx = (unsigned long long)((long long)(gl - 1) * maxRegion + (long long)sz - 1);
+  if (gl <= 0 || idx >= idx_max) {
+    *err = 1;
+    return;
+  }
+  atomicAdd(out + (size_t)v * idx_max + idx, 1.0);
+}
+
+__global__ void glszm_gather_zones_kernel(int nvox, int v, int count, const int *__restrict__ zones,
+                                          int *__restrict__ pairs) {
+  const int z = blockIdx.x * blockDim.x + threadIdx.x;
+  if (z >= count) return;
+  pairs[z * 2] = zones[((long long)z * 2) * nvox + v];
+  pairs[z * 2 + 1] = zones[((long long)z * 2 + 1) * nvox + v];
+}
+
+// ---- host drivers --------------------------------------------------------------------------------
+inline unsigned glszm_grid(long long n) { return (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 8192)); }
+
+inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *image, const uint8_t *mask,
+                       const int *angles_h, int Na, int Ng, int Nvox, const int *voxels_dev, int kernelRadius,
+                       int force2Ddim, long long *nzones_out) {
+  (void)Ng;
+  GlszmState &st = glszm_state();
+  st.valid = false;
+  int *stats = nullptr;
+  PRAD_TRY(c.get<int>("glszm_stats", 8, &stats));
+  unsigned long long *stats64 = (unsigned long long *)(stats + 2);
+  PRAD_HIP(hipMemsetAsync(stats, 0, sizeof(int) * 8, s));
+  void *hp = nullptr;
+  PRAD_TRY(c.get_pinned("glszm_stats_h", sizeof(int) * 8, &hp));
+  int *stats_h = (int *)hp;
+
+  if (!voxels_dev) {
+    if (Nvox != 1) return fail(PRAD_E_ARG, "Nvox=%d without a voxel list", Nvox);
+    int *angles_d = nullptr;
+    PRAD_TRY(c.get<int>("angles", (size_t)Na * g.nd, &angles_d));
+    PRAD_HIP(hipMemcpyAsync(angles_d, angles_h, sizeof(int) * Na * g.nd, hipMemcpyHostToDevice, s));
+    PRAD_TRY(c.get<int>("glszm_labels", (size_t)g.n, &st.labels));
+    PRAD_TRY(c.get<unsigned>("glszm_sizes", (size_t)g.n, &st.sizes));
+    Timed t(c, "glszm", s);
+    hipLaunchKernelGGL(glszm_init_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, mask, g.n, st.labels, st.sizes);
+    PRAD_TRY(check_launch("glszm_init_kernel"));
+    hipLaunchKernelGGL(glszm_merge_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g, angles_d, Na, image, mask, st.labels);
+    PRAD_TRY(check_launch("glszm_merge_kernel"));
+    hipLaunchKernelGGL(glszm_flatten_count_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g.n, st.labels, st.sizes);
+    PRAD_TRY(check_launch("glszm_flatten_count_kernel"));
+    hipLaunchKernelGGL(glszm_stats_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g.n, st.labels, st.sizes, stats,
+                       stats64);
+    PRAD_TRY(check_launch("glszm_stats_kernel"));
+    st.voxel_mode = false;
+    st.image = image;
+    st.boxmax = g.n;
+  } else {
+    if (kernelRadius <= 0) return fail(PRAD_E_ARG, "Expecting kernelRadius > 0");
+    VoxMode vm;
+    vm.nvox = Nvox;
+    vm.voxels = voxels_dev;
+    vm.radius = kernelRadius;
+    vm.f2d = force2Ddim;
+    long long b = 1;
+    for (int d = 0; d < g.nd; d++)
+      if (d != force2Ddim) b *= std::min<long long>(2LL * kernelRadius + 1, g.size[d]);
+    vm.boxmax = b;
+    int *angles_d = nullptr;
+    PRAD_TRY(c.get<int>("angles", (size_t)Na * g.nd, &angles_d));
+    PRAD_HIP(hipMemcpyAsync(angles_d, angles_h, sizeof(int) * Na * g.nd, hipMemcpyHostToDevice, s));
+    uint8_t *visited = nullptr;
+    int *stack = nullptr;
+    PRAD_TRY(c.get<uint8_t>("glszm_visited", (size_t)b * Nvox, &visited));
+    PRAD_TRY(c.get<int>("glszm_stack", (size_t)b * Nvox, &stack));
+    PRAD_TRY(c.get<int>("glszm_zones", (size_t)b * 2 * Nvox, &st.zones));
+    PRAD_TRY(c.get<int>("glszm_zone_count", (size_t)Nvox, &st.zone_count));
+    Timed t(c, "glszm", s);
+    hipLaunchKernelGGL(glszm_voxel_kernel, dim3((unsigned)((Nvox + 63) / 64)), dim3(64), 0, s, g, vm, image, mask,
+                       angles_d, Na, visited, stack, st.zones, st.zone_count, stats, stats64);
+    PRAD_TRY(check_launch("glszm_voxel_kernel"));
+    st.voxel_mode = true;
+    st.boxmax = b;
+  }
+  PRAD_HIP(hipMemcpyAsync(stats_h, stats, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  st.g = g;
+  st.nvox = Nvox;
+  st.device = c.device;
+  st.max_region = stats_h[0];
+  st.nzones = (long long)*(unsigned long long *)(stats_h + 2);
+  st.valid = true;
+  if (nzones_out) *nzones_out = st.nzones;
+  c.last_path = st.voxel_mode ? "glszm-voxel" : "glszm-unionfind";
+  return st.max_region;
+}
+
+inline int glszm_fill(Context &c, hipStream_t s, double *out_dev, int Nvox, int Ng, int maxRegion) {
+  GlszmState &st = glszm_state();
+  if (!st.valid || st.device != c.device) return fail(PRAD_E_ARG, "prad_fill_glszm without a preceding prad_calculate_glszm");
+  if (Nvox != st.nvox) return fail(PRAD_E_ARG, "fill_glszm: Nvox=%d but the zone list holds %d kernels", Nvox, st.nvox);
+  int *err = nullptr;
+  PRAD_TRY(c.get<int>("glszm_err", 4, &err));
+  PRAD_HIP(hipMemsetAsync(err, 0, sizeof(int) * 4, s));
+  PRAD_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)Nvox * Ng * maxRegion, s));
+  if (!st.voxel_mode) {
+    hipLaunchKernelGGL(glszm_fill_segment_kernel, dim3(glszm_grid(st.g.n)), dim3(256), 0, s, st.g.n, st.labels,
+                       st.sizes, st.image, Ng, maxRegion, out_dev, err);
+    PRAD_TRY(check_launch("glszm_fill_segment_kernel"));
+  } else {
+    const long long threads = (long long)st.nvox * st.boxmax;
+    hipLaunchKernelGGL(glszm_fill_voxel_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, st.nvox,
+                       st.boxmax, st.zones, st.zone_count, Ng, maxRegion, out_dev, err);
+    PRAD_TRY(check_launch("glszm_fill_voxel_kernel"));
+  }
+  void *hp = nullptr;
+  PRAD_TRY(c.get_pinned("glszm_err_h", sizeof(int) * 4, &hp));
+  PRAD_HIP(hipMemcpyAsync(hp, err, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  return ((int *)hp)[0] ? PRAD_INDEX_ERROR : PRAD_OK;
+}
+
+inline long long glszm_copy_zones(Context &c, int v, int *tempData, long long capacity_pairs) {
+  GlszmState &st = glszm_state();
+  if (!st.valid || st.device != c.device) return fail(PRAD_E_ARG, "prad_glszm_zones without a preceding prad_calculate_glszm");
+  if (!tempData || v < 0 || v >= st.nvox) return fail(PRAD_E_ARG, "prad_glszm_zones: bad kernel index or NULL buffer");
+  hipStream_t s = c.own_stream;
+  long long count = 0;
+  int *pairs = nullptr;
+  if (st.voxel_mode) {
+    int cnt = 0;
+    PRAD_HIP(hipMemcpy(&cnt, st.zone_count + v, sizeof(int), hipMemcpyDeviceToHost));
+    count = cnt;
+    if (count > capacity_pairs) return fail(PRAD_E_ARG, "prad_glszm_zones: %lld zones exceed capacity %lld", count, capacity_pairs);
+    PRAD_TRY(c.get<int>("glszm_pairs", (size_t)count * 2 + 2, &pairs));
+    if (count) {
+      hipLaunchKernelGGL(glszm_gather_zones_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, st.nvox, v,
+                         (int)count, st.zones, pairs);
+      PRAD_TRY(check_launch("glszm_gather_zones_kernel"));
+    }
+  } else {
+    count = st.nzones;
+    if (count > capacity_pairs) return fail(PRAD_E_ARG, "prad_glszm_zones: %lld zones exceed capacity %lld", count, capacity_pairs);
+    const long long n = st.g.n, nblocks = (n + PRAD_ZL_BLOCK - 1) / PRAD_ZL_BLOCK;
+    unsigned *counts = nullptr;
+    unsigned long long *offsets = nullptr;
+    PRAD_TRY(c.get<unsigned>("glszm_bcounts", (size_t)nblocks, &counts));
+    PRAD_TRY(c.get<unsigned long long>("glszm_boffsets", (size_t)nblocks, &offsets));
+    PRAD_TRY(c.get<int>("glszm_pairs", (size_t)count * 2 + 2, &pairs));
+    hipLaunchKernelGGL(glszm_root_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, n, st.labels, counts);
+    PRAD_TRY(check_launch("glszm_root_count_kernel"));
+    hipLaunchKernelGGL(glszm_scan_kernel, dim3(1), dim3(1024), 0, s, nblocks, counts, offsets);
+    PRAD_TRY(check_launch("glszm_scan_kernel"));
+    hipLaunchKernelGGL(glszm_root_scatter_kernel, dim3((unsigned)nblocks), dim3(64), 0, s, n, st.labels, st.sizes,
+                       st.image, offsets, pairs);
+    PRAD_TRY(check_launch("glszm_root_scatter_kernel"));
+  }
+  if (count) PRAD_HIP(hipMemcpyAsync(tempData, pairs, sizeof(int) * 2 * count, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  tempData[count * 2] = -1;  // cmatrices.c:276
+  return count;
+}
+
+}  // namespace prad

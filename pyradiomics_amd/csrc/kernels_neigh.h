@@ -1,0 +1,186 @@
+// kernels_neigh.h -- segment-mode GLDM and NGTDM on gfx950: one lane per ROI voxel, the 26 (or 8, or any
+// small set of) neighbours gathered from the packed uint8 level volume, workgroup-private histograms in LDS.
+//
+//   GLDM  (cmatrices.c:660-754)  bins [Ng][Na+1] u32  (dependence counts 0..Na; the reference's row stride
+//                                2*Na+1 only matters for the output layout, columns > Na stay zero)
+//   NGTDM (cmatrices.c:543-658)  bins [Ng][Na+1] u64: slot 0 = voxels of that level,
+//                                slot c = sum over voxels with c valid neighbours of |c*level - sum(neigh)|
+//                                => s_i = sum_c bins[i][c] / c  (exact integers inside, one division per c)
+// Inputs outside [1,Ng] under the mask are detected by pack_levels (flags[0]) and rerouted to the
+// generic kernels by the caller.
+#pragma once
+#include <algorithm>
+#include "prad_runtime.h"
+#include "kernels_sweep.h"
+#include "kernels_generic.h"
+
+namespace prad {
+
+#define PRAD_MAX_NEIGH 128
+struct NeighSet {
+  int na;
+  signed char o[PRAD_MAX_NEIGH][4];  // (dz, dy, dx, unused), volume embedded in 3-D
+};
+
+template <bool NGTDM>
+__global__ void __launch_bounds__(256) neigh_kernel(NeighSet A, const uint8_t *__restrict__ L, int Nz, int Ny,
+                                                    int Nx, int Ng, int alpha, u32 *__restrict__ gldm_acc,
+                                                    u64 *__restrict__ ngtdm_acc, const int *__restrict__ flags) {
+  extern __shared__ u64 lds64[];
+  if (flags[0]) return;
+  const int W = A.na + 1;
+  u32 *h32 = reinterpret_cast<u32 *>(lds64);
+  const int nbins = Ng * W;
+  for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
+    if (NGTDM) lds64[i] = 0;
+    else h32[i] = 0;
+  }
+  __syncthreads();
+  const long long n = (long long)Nz * Ny * Nx;
+  const long long plane = (long long)Ny * Nx;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = L[i];
+    if (!c) continue;
+    const int z = (int)(i / plane);
+    const int r = (int)(i - (long long)z * plane);
+    const int y = r / Nx;
+    const int x = r - y * Nx;
+    int cnt = 0, sum = 0, dep = 0;
+    for (int a = 0; a < A.na; a++) {
+      const int zz = z + A.o[a][0], yy = y + A.o[a][1], xx = x + A.o[a][2];
+      if ((unsigned)zz >= (unsigned)Nz || (unsigned)yy >= (unsigned)Ny || (unsigned)xx >= (unsigned)Nx) continue;
+      const int v = L[(long long)zz * plane + (long long)yy * Nx + xx];
+      if (!v) continue;
+      if (NGTDM) {
+        cnt++;
+        sum += v;
+      } else {
+        int d = c - v;
+        d = d < 0 ? -d : d;
+        dep += (d <= alpha);
+      }
+    }
+    if (NGTDM) {
+      u64 *row = lds64 + (c - 1) * W;
+      atomicAdd(row, 1ull);
+      if (cnt) {
+        int d = cnt * c - sum;
+        d = d < 0 ? -d : d;
+        if (d) atomicAdd(row + cnt, (u64)d);
+      }
+    } else {
+      atomicAdd(&h32[(c - 1) * W + dep], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
+    if (NGTDM) {
+      u64 v = lds64[i];
+      if (v) atomicAdd(ngtdm_acc + i, v);
+    } else {
+      u32 v = h32[i];
+      if (v) atomicAdd(gldm_acc + i, v);
+    }
+  }
+}
+
+__global__ void finalize_gldm_kernel(const u32 *__restrict__ acc, int Ng, int Na, double *__restrict__ out) {
+  const int width = 2 * Na + 1;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)Ng * width) return;
+  const int g = (int)(idx / width), k = (int)(idx % width);
+  out[idx] = k <= Na ? (double)acc[(size_t)g * (Na + 1) + k] : 0.0;
+}
+
+struct NeighPlan {
+  bool ok = false;
+  int Nz = 1, Ny = 1, Nx = 1;
+  NeighSet set;
+};
+
+inline NeighPlan plan_neigh(const Geo &g, const VoxMode &vm, const int *angles_h, int Na, int Ng, size_t bin_bytes) {
+  NeighPlan p;
+  if (vm.voxels || g.nd > 3 || Ng < 1 || Ng > 255 || Na > PRAD_MAX_NEIGH) return p;
+  if ((size_t)Ng * (Na + 1) * bin_bytes > 64 * 1024) return p;
+  int dims[3] = {1, 1, 1};
+  for (int d = 0; d < g.nd; d++) dims[3 - g.nd + d] = g.size[d];
+  p.Nz = dims[0]; p.Ny = dims[1]; p.Nx = dims[2];
+  p.set.na = Na;
+  for (int a = 0; a < Na; a++) {
+    int o[3] = {0, 0, 0};
+    for (int d = 0; d < g.nd; d++) o[3 - g.nd + d] = angles_h[a * g.nd + d];
+    for (int d = 0; d < 3; d++) {
+      if (o[d] < -127 || o[d] > 127) return p;
+      p.set.o[a][d] = (signed char)o[d];
+    }
+    p.set.o[a][3] = 0;
+  }
+  p.ok = true;
+  return p;
+}
+
+inline int neigh_pack(Context *c, hipStream_t s, const Geo &g, const int32_t *image, const uint8_t *mask, int Ng,
+                      int *flags_d, uint8_t **levels) {
+  PRAD_TRY(c->get<uint8_t>("levels", (size_t)g.n + 64, levels));
+  Timed t(*c, "pack", s);
+  const int vec_ok = ((((uintptr_t)image) | ((uintptr_t)mask) | ((uintptr_t)*levels)) & 15) == 0;
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((g.n / 16 + 255) / 256, 4096));
+  hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, s, image, mask, g.n, Ng, *levels, flags_d, vec_ok);
+  return check_launch("pack_levels_kernel");
+}
+
+inline int neigh_try_gldm(Context *c, hipStream_t s, const Geo &g, const VoxMode &vm, const int32_t *image,
+                          const uint8_t *mask, const int *angles_h, int Na, int Ng, int alpha, double *out,
+                          int *flags_d, bool *done) {
+  *done = false;
+  NeighPlan p = plan_neigh(g, vm, angles_h, Na, Ng, sizeof(u32));
+  if (!p.ok) return PRAD_OK;
+  uint8_t *levels = nullptr;
+  PRAD_TRY(neigh_pack(c, s, g, image, mask, Ng, flags_d, &levels));
+  u32 *acc = nullptr;
+  const size_t nacc = (size_t)Ng * (Na + 1);
+  PRAD_TRY(c->get<u32>("gldm_acc", nacc, &acc));
+  PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u32) * nacc, s));
+  {
+    Timed t(*c, "neigh", s);
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((g.n + 255) / 256, 4096));
+    hipLaunchKernelGGL((neigh_kernel<false>), dim3(gx), dim3(256), sizeof(u32) * nacc, s, p.set, levels, p.Nz, p.Ny,
+                       p.Nx, Ng, alpha, acc, (u64 *)nullptr, flags_d);
+    PRAD_TRY(check_launch("neigh_kernel<gldm>"));
+  }
+  Timed t(*c, "finalize", s);
+  const long long total = (long long)Ng * (2 * Na + 1);
+  hipLaunchKernelGGL(finalize_gldm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, acc, Ng, Na, out);
+  PRAD_TRY(check_launch("finalize_gldm_kernel"));
+  *done = true;
+  return PRAD_OK;
+}
+
+inline int neigh_try_ngtdm(Context *c, hipStream_t s, const Geo &g, const VoxMode &vm, const int32_t *image,
+                           const uint8_t *mask, const int *angles_h, int Na, int Ng, double *out, int *flags_d,
+                           bool *done) {
+  *done = false;
+  NeighPlan p = plan_neigh(g, vm, angles_h, Na, Ng, sizeof(u64));
+  if (!p.ok) return PRAD_OK;
+  uint8_t *levels = nullptr;
+  PRAD_TRY(neigh_pack(c, s, g, image, mask, Ng, flags_d, &levels));
+  u64 *acc = nullptr;
+  const size_t nacc = (size_t)Ng * (Na + 1);
+  PRAD_TRY(c->get<u64>("ngtdm_acc", nacc, &acc));
+  PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u64) * nacc, s));
+  {
+    Timed t(*c, "neigh", s);
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((g.n + 255) / 256, 4096));
+    hipLaunchKernelGGL((neigh_kernel<true>), dim3(gx), dim3(256), sizeof(u64) * nacc, s, p.set, levels, p.Nz, p.Ny,
+                       p.Nx, Ng, 0, (u32 *)nullptr, acc, flags_d);
+    PRAD_TRY(check_launch("neigh_kernel<ngtdm>"));
+  }
+  Timed t(*c, "finalize", s);
+  hipLaunchKernelGGL(ngtdm_finalize_kernel, dim3((unsigned)((Ng + 63) / 64)), dim3(64), 0, s, acc, Ng, Na, out);
+  PRAD_TRY(check_launch("ngtdm_finalize_kernel"));
+  *done = true;
+  return PRAD_OK;
+}
+
+}  // namespace prad

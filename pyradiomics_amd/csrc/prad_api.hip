@@ -1,0 +1,685 @@
+// prad_api.hip -- C ABI (include/pyradiomics_amd.h) of the MI355X texture-matrix engine.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC prad_api.hip -o libpyradiomics_amd.so
+//
+// Dispatch policy (per call):
+//   segment mode, Nd <= 3, unit angles, Ng small enough for LDS-private histograms
+//       -> pack_levels + sweep kernels (kernels_sweep.h)            path "sweep"
+//   anything else (voxel mode, Nd > 3, |offset| > 1, large Ng), or a volume whose masked levels fall outside
+//   [1, Ng] (detected on the device by pack_levels)
+//       -> exact generic kernels (kernels_generic.h)                 path "generic"
+// There is no host-side compute path: without a HIP device every calculate_* call fails with PRAD_E_HIP.
+#include "prad_runtime.h"
+#include "kernels_generic.h"
+#include "kernels_sweep.h"
+#include "kernels_neigh.h"
+#include "kernels_glszm.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+using namespace prad;
+
+namespace {
+
+const char *kVersion = "pyradiomics_amd 0.1.0 (gfx950)";
+
+// ------------------------------------------------------------------------------------------------
+// angle enumeration (cmatrices.c:756-892), host side: tiny, integer, runs once per call
+// ------------------------------------------------------------------------------------------------
+int angle_count(const int *size, const int *distances, int Nd, int Ndist, int bidirectional, int f2d) {
+  long long total = 0;
+  for (int k = 0; k < Ndist; k++) {
+    const int dist = distances[k];
+    if (dist < 1) return 0;
+    long long shell_outer = 1, shell_inner = 1;
+    for (int d = 0; d < Nd; d++) {
+      if (d == f2d) continue;
+      if (dist < size[d]) {
+        shell_outer *= 2LL * dist + 1;
+        shell_inner *= 2LL * dist - 1;
+      } else {
+        const long long reach = 2LL * (size[d] - 1) + 1;
+        shell_outer *= reach;
+        shell_inner *= reach;
+      }
+    }
+    total += shell_outer - shell_inner;
+  }
+  if (!bidirectional) total /= 2;
+  return (int)total;
+}
+
+int angle_build(const int *size, const int *distances, int Nd, int Ndist, int f2d, int Na, int *angles) {
+  int maxd = 0;
+  for (int k = 0; k < Ndist; k++) {
+    if (distances[k] < 1) return 1;
+    maxd = std::max(maxd, distances[k]);
+  }
+  // enumerate offset vectors in the reference's order: every component runs +maxd .. -maxd, last
+  // dimension fastest (cmatrices.c:843-860); emit the legal ones whose infinity norm was requested.
+  std::vector<int> off(Nd, maxd);
+  int got = 0;
+  long long guard = 1;
+  for (int d = 0; d < Nd; d++) guard *= (2LL * maxd + 1);
+  for (long long it = 0; it < guard && got < Na; it++) {
+    int norm = 0;
+    bool legal = true;
+    for (int d = 0; d < Nd && legal; d++) {
+      const int o = off[d];
+      if ((d == f2d && o != 0) || o >= size[d] || o <= -size[d]) legal = false;
+      norm = std::max(norm, std::abs(o));
+    }
+    if (legal && norm >= 1) {
+      for (int k = 0; k < Ndist; k++)
+        if (distances[k] == norm) {
+          std::copy(off.begin(), off.end(), angles + (size_t)got * Nd);
+          got++;
+          break;
+        }
+    }
+    for (int d = Nd - 1; d >= 0; d--) {
+      if (off[d] > -maxd) { off[d]--; break; }
+      off[d] = maxd;
+    }
+  }
+  return got == Na ? 0 : 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// call setup shared by all matrices
+// ------------------------------------------------------------------------------------------------
+struct Call {
+  Context *c;
+  hipStream_t s;
+  Geo g;
+  VoxMode vm;
+  const int32_t *image;   // device
+  const uint8_t *mask;    // device
+  const int *angles_h;    // host [Na][Nd]
+  int *angles_d;          // device copy
+  int Na;
+  int *flags_d;           // device int[4]: [0] pack saw irregular level, [1] generic index error
+  int *flags_h;           // pinned
+};
+
+int setup_call(Call &k, const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+               int Na, int Nvox, const int *voxels_dev, int kernelRadius, int force2Ddim, hipStream_t s) {
+  Context &c = ctx();
+  k.c = &c;
+  k.s = s;
+  if (!image || !mask) return fail(PRAD_E_ARG, "image/mask is NULL");
+  if (!angles || Na < 1) return fail(PRAD_E_ARG, "angles is NULL or Na < 1");
+  PRAD_TRY(make_geo(size, Nd, &k.g));
+  if (Nvox < 1) return fail(PRAD_E_ARG, "Nvox=%d < 1", Nvox);
+  k.vm.nvox = Nvox;
+  k.vm.voxels = voxels_dev;
+  k.vm.radius = kernelRadius;
+  k.vm.f2d = force2Ddim;
+  if (voxels_dev) {
+    if (kernelRadius <= 0) return fail(PRAD_E_ARG, "Expecting kernelRadius > 0");  // _cmatrices.c:1091-1095
+    long long b = 1;
+    for (int d = 0; d < Nd; d++)
+      if (d != force2Ddim) b *= std::min<long long>(2LL * kernelRadius + 1, k.g.size[d]);
+    k.vm.boxmax = b;
+  } else {
+    if (Nvox != 1) return fail(PRAD_E_ARG, "Nvox=%d without a voxel list", Nvox);
+    k.vm.boxmax = k.g.n;
+  }
+  k.image = image;
+  k.mask = mask;
+  k.angles_h = angles;
+  k.Na = Na;
+  PRAD_TRY(c.get<int>("angles", (size_t)Na * Nd, &k.angles_d));
+  PRAD_HIP(hipMemcpyAsync(k.angles_d, angles, sizeof(int) * Na * Nd, hipMemcpyHostToDevice, s));
+  PRAD_TRY(c.get<int>("flags", 4, &k.flags_d));
+  PRAD_HIP(hipMemsetAsync(k.flags_d, 0, sizeof(int) * 4, s));
+  void *fh = nullptr;
+  PRAD_TRY(c.get_pinned("flags_h", sizeof(int) * 4, &fh));
+  k.flags_h = (int *)fh;
+  return PRAD_OK;
+}
+
+int read_flags(Call &k) {
+  PRAD_HIP(hipMemcpyAsync(k.flags_h, k.flags_d, sizeof(int) * 4, hipMemcpyDeviceToHost, k.s));
+  PRAD_HIP(hipStreamSynchronize(k.s));
+  return PRAD_OK;
+}
+
+inline unsigned blocks_for(long long threads, int bs = 256) { return (unsigned)((threads + bs - 1) / bs); }
+
+int check_grid(long long threads, const char *what) {
+  if ((threads + 255) / 256 > 2147483647LL)
+    return fail(PRAD_E_UNSUPPORTED, "%s: %lld work items exceed the launch grid; split the voxel batch", what, threads);
+  return PRAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic launches
+// ------------------------------------------------------------------------------------------------
+int generic_glcm(Call &k, int Ng, double *out) {
+  const size_t per = (size_t)Ng * Ng * k.Na;
+  PRAD_HIP(hipMemsetAsync(out, 0, sizeof(double) * per * k.vm.nvox, k.s));
+  const long long threads = (long long)k.vm.nvox * k.vm.boxmax;
+  PRAD_TRY(check_grid(threads, "GLCM"));
+  Timed t(*k.c, "generic", k.s);
+  hipLaunchKernelGGL(gen_glcm_kernel, dim3(blocks_for(threads)), dim3(256), 0, k.s, k.g, k.vm, k.image, k.mask,
+                     k.angles_d, k.Na, Ng, out, k.flags_d + 1);
+  return check_launch("gen_glcm_kernel");
+}
+
+int generic_glrlm(Call &k, int Ng, int Nr, double *out) {
+  const size_t per = (size_t)Ng * Nr * k.Na;
+  PRAD_HIP(hipMemsetAsync(out, 0, sizeof(double) * per * k.vm.nvox, k.s));
+  int *multi = nullptr;
+  PRAD_TRY(k.c->get<int>("multi", (size_t)k.vm.nvox * k.Na, &multi));
+  PRAD_HIP(hipMemsetAsync(multi, 0, sizeof(int) * k.vm.nvox * k.Na, k.s));
+  const long long threads = (long long)k.vm.nvox * k.vm.boxmax * k.Na;
+  PRAD_TRY(check_grid(threads, "GLRLM"));
+  Timed t(*k.c, "generic", k.s);
+  hipLaunchKernelGGL(gen_glrlm_kernel, dim3(blocks_for(threads)), dim3(256), 0, k.s, k.g, k.vm, k.image, k.mask,
+                     k.angles_d, k.Na, Ng, Nr, out, multi, k.flags_d + 1);
+  PRAD_TRY(check_launch("gen_glrlm_kernel"));
+  const long long pthreads = (long long)k.vm.nvox * Ng * k.Na;
+  hipLaunchKernelGGL(glrlm_prune_kernel, dim3(blocks_for(pthreads)), dim3(256), 0, k.s, out, multi, k.vm.nvox, Ng,
+                     Nr, k.Na);
+  return check_launch("glrlm_prune_kernel");
+}
+
+int generic_gldm(Call &k, int Ng, int alpha, double *out) {
+  const size_t per = (size_t)Ng * (2 * (size_t)k.Na + 1);
+  PRAD_HIP(hipMemsetAsync(out, 0, sizeof(double) * per * k.vm.nvox, k.s));
+  const long long threads = (long long)k.vm.nvox * k.vm.boxmax;
+  PRAD_TRY(check_grid(threads, "GLDM"));
+  Timed t(*k.c, "generic", k.s);
+  hipLaunchKernelGGL(gen_gldm_kernel, dim3(blocks_for(threads)), dim3(256), 0, k.s, k.g, k.vm, k.image, k.mask,
+                     k.angles_d, k.Na, Ng, alpha, out, k.flags_d + 1);
+  return check_launch("gen_gldm_kernel");
+}
+
+int generic_ngtdm(Call &k, int Ng, double *out) {
+  Timed t(*k.c, "generic", k.s);
+  if (k.vm.voxels) {
+    hipLaunchKernelGGL(gen_ngtdm_voxel_kernel, dim3(blocks_for(k.vm.nvox, 64)), dim3(64), 0, k.s, k.g, k.vm,
+                       k.image, k.mask, k.angles_d, k.Na, Ng, out, k.flags_d + 1);
+    return check_launch("gen_ngtdm_voxel_kernel");
+  }
+  unsigned long long *acc = nullptr;
+  const size_t nacc = (size_t)Ng * (k.Na + 1);
+  PRAD_TRY(k.c->get<unsigned long long>("ngtdm_acc", nacc, &acc));
+  PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * nacc, k.s));
+  PRAD_TRY(check_grid(k.g.n, "NGTDM"));
+  hipLaunchKernelGGL(gen_ngtdm_segment_kernel, dim3(blocks_for(k.g.n)), dim3(256), 0, k.s, k.g, k.vm, k.image,
+                     k.mask, k.angles_d, k.Na, Ng, acc, k.flags_d + 1);
+  PRAD_TRY(check_launch("gen_ngtdm_segment_kernel"));
+  hipLaunchKernelGGL(ngtdm_finalize_kernel, dim3(blocks_for(Ng, 64)), dim3(64), 0, k.s, acc, Ng, k.Na, out);
+  return check_launch("ngtdm_finalize_kernel");
+}
+
+// ------------------------------------------------------------------------------------------------
+// sweep path (segment mode GLCM / GLRLM)
+// ------------------------------------------------------------------------------------------------
+struct SweepPlan {
+  bool ok = false;
+  int Nz = 1, Ny = 1, Nx = 1;  // volume embedded in 3-D
+  SweepSet lines;              // angles marching along z or y
+  int row_slot = -1;           // slot of the angle along x, or -1
+  int RS = 0;
+  size_t lds_bytes = 0;
+};
+
+// Can this call run on the sweep kernels?  (see the dispatch policy at the top of this file)
+SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_glrlm) {
+  SweepPlan p;
+  if (k.vm.voxels || k.g.nd > 3 || Ng < 1 || Ng > 255 || k.Na > PRAD_MAX_SWEEP) return p;
+  int dims[3] = {1, 1, 1};
+  for (int d = 0; d < k.g.nd; d++) dims[3 - k.g.nd + d] = k.g.size[d];
+  p.Nz = dims[0]; p.Ny = dims[1]; p.Nx = dims[2];
+  if (want_glrlm && Nr < std::max(dims[0], std::max(dims[1], dims[2]))) return p;  // a run could overflow Nr
+  p.RS = want_glrlm ? std::min(Nr, Ng <= 64 ? 64 : 16) : 0;
+  p.lds_bytes = sizeof(u32) * ((want_glcm ? (size_t)Ng * Ng : 0) + (want_glrlm ? (size_t)Ng * p.RS : 0));
+  if (p.lds_bytes > 64 * 1024) return p;
+  p.lines.count = 0;
+  for (int a = 0; a < k.Na; a++) {
+    int o[3] = {0, 0, 0};
+    for (int d = 0; d < k.g.nd; d++) o[3 - k.g.nd + d] = k.angles_h[a * k.g.nd + d];
+    int first = 0;
+    for (int d = 0; d < 3; d++) {
+      if (o[d] < -1 || o[d] > 1) return p;
+      if (!first && o[d]) first = o[d];
+    }
+    if (first != 1) return p;  // sweeps assume the first moving component is +1 (unidirectional list)
+    if (o[0] == 0 && o[1] == 0) {
+      if (p.row_slot >= 0) return p;
+      p.row_slot = a;
+      continue;
+    }
+    SweepDesc &D = p.lines.d[p.lines.count++];
+    D.slot = a;
+    D.NX = p.Nx;
+    D.dx = o[2];
+    if (o[0] == 1) {  // march z, rows = y
+      D.NM = p.Nz; D.NU = p.Ny; D.du = o[1];
+      D.sM = (long long)p.Ny * p.Nx; D.sU = p.Nx;
+    } else {          // march y, rows = z (never moves)
+      D.NM = p.Ny; D.NU = p.Nz; D.du = 0;
+      D.sM = p.Nx; D.sU = (long long)p.Ny * p.Nx;
+    }
+    D.LU = D.NU + (D.du ? D.NM - 1 : 0);
+    D.u0min = D.du > 0 ? -(D.NM - 1) : 0;
+    const int LX = D.NX + (D.dx ? D.NM - 1 : 0);
+    D.x0min = D.dx > 0 ? -(D.NM - 1) : 0;
+    D.LXc = (LX + 63) / 64;
+    D.chunks = (long long)D.LU * D.LXc;
+  }
+  p.ok = true;
+  return p;
+}
+
+template <bool G, bool R>
+int launch_sweeps(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
+                  int *multi) {
+  Timed t(*k.c, "sweep", k.s);
+  if (p.lines.count > 0) {
+    long long maxchunks = 0;
+    for (int i = 0; i < p.lines.count; i++) maxchunks = std::max(maxchunks, p.lines.d[i].chunks);
+    const long long want = (maxchunks + 3) / 4;
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(want, 3072 / p.lines.count));
+    hipLaunchKernelGGL((sweep_lines_kernel<G, R>), dim3(gx, p.lines.count), dim3(256), p.lds_bytes, k.s, p.lines,
+                       levels, Ng, Nr, p.RS, glcm_acc, glrlm_acc, multi, k.flags_d);
+    PRAD_TRY(check_launch("sweep_lines_kernel"));
+  }
+  if (p.row_slot >= 0) {
+    const long long nrows = (long long)p.Nz * p.Ny;
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((nrows + 3) / 4, 2048));
+    hipLaunchKernelGGL((sweep_rows_kernel<G, R>), dim3(gx), dim3(256), p.lds_bytes, k.s, levels, nrows, p.Nx,
+                       p.row_slot, Ng, Nr, p.RS, glcm_acc, glrlm_acc, multi, k.flags_d);
+    PRAD_TRY(check_launch("sweep_rows_kernel"));
+  }
+  return PRAD_OK;
+}
+
+// returns PRAD_OK with *used=false if the device found irregular levels (caller then runs generic)
+int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, double *glrlm, bool *used) {
+  Context &c = *k.c;
+  uint8_t *levels = nullptr;
+  PRAD_TRY(c.get<uint8_t>("levels", (size_t)k.g.n + 64, &levels));
+  u32 *glcm_acc = nullptr, *glrlm_acc = nullptr;
+  int *multi = nullptr;
+  const size_t nglcm = glcm ? (size_t)k.Na * Ng * Ng : 0, nglrlm = glrlm ? (size_t)k.Na * Ng * Nr : 0;
+  u32 *acc = nullptr;
+  PRAD_TRY(c.get<u32>("sweep_acc", nglcm + nglrlm + PRAD_MAX_SWEEP, &acc));
+  glcm_acc = acc;
+  glrlm_acc = acc + nglcm;
+  multi = (int *)(acc + nglcm + nglrlm);
+  PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u32) * (nglcm + nglrlm + PRAD_MAX_SWEEP), k.s));
+  {
+    Timed t(c, "pack", k.s);
+    const int vec_ok = ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)levels)) & 15) == 0;
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n / 16 + 255) / 256, 4096));
+    hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, k.s, k.image, k.mask, k.g.n, Ng, levels,
+                       k.flags_d, vec_ok);
+    PRAD_TRY(check_launch("pack_levels_kernel"));
+  }
+  if (glcm && glrlm) PRAD_TRY((launch_sweeps<true, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+  else if (glcm) PRAD_TRY((launch_sweeps<true, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+  else PRAD_TRY((launch_sweeps<false, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+  {
+    Timed t(c, "finalize", k.s);
+    if (glcm) {
+      hipLaunchKernelGGL(finalize_glcm_kernel, dim3(blocks_for((long long)Ng * Ng * k.Na)), dim3(256), 0, k.s,
+                         glcm_acc, Ng, k.Na, glcm);
+      PRAD_TRY(check_launch("finalize_glcm_kernel"));
+    }
+    if (glrlm) {
+      hipLaunchKernelGGL(finalize_glrlm_kernel, dim3(blocks_for((long long)Ng * Nr * k.Na)), dim3(256), 0, k.s,
+                         glrlm_acc, multi, Ng, Nr, k.Na, glrlm);
+      PRAD_TRY(check_launch("finalize_glrlm_kernel"));
+    }
+  }
+  PRAD_TRY(read_flags(k));
+  *used = (k.flags_h[0] == 0);
+  return PRAD_OK;
+}
+
+// GLCM and/or GLRLM, device pointers
+int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                       int Na, int Ng, int Nr, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                       double *glcm, double *glrlm, hipStream_t s) {
+  if (!glcm && !glrlm) return fail(PRAD_E_ARG, "both outputs are NULL");
+  if (Ng < 1 || (glrlm && Nr < 1)) return fail(PRAD_E_ARG, "Ng/Nr must be >= 1");
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Call k;
+  PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, Nvox, voxels, kernelRadius, force2Ddim, s));
+  PRAD_TRY(c.begin_call(s));
+  SweepPlan p = plan_sweep(k, Ng, Nr, glcm != nullptr, glrlm != nullptr);
+  bool done = false;
+  if (p.ok) {
+    PRAD_TRY(sweep_glcm_glrlm(k, p, Ng, Nr, glcm, glrlm, &done));
+    if (done) c.last_path = "sweep";
+  }
+  if (!done) {
+    if (glcm) PRAD_TRY(generic_glcm(k, Ng, glcm));
+    if (glrlm) PRAD_TRY(generic_glrlm(k, Ng, Nr, glrlm));
+    PRAD_TRY(read_flags(k));
+    c.last_path = "generic";
+  }
+  PRAD_TRY(c.end_call(s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  return k.flags_h[1] ? PRAD_INDEX_ERROR : PRAD_OK;
+}
+
+int texture_gldm(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                 int Ng, int alpha, int Nvox, const int *voxels, int kernelRadius, int force2Ddim, double *out,
+                 hipStream_t s) {
+  if (!out) return fail(PRAD_E_ARG, "gldm is NULL");
+  if (Ng < 1) return fail(PRAD_E_ARG, "Ng must be >= 1");
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Call k;
+  PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, Nvox, voxels, kernelRadius, force2Ddim, s));
+  PRAD_TRY(c.begin_call(s));
+  bool done = false;
+  PRAD_TRY(neigh_try_gldm(k.c, k.s, k.g, k.vm, k.image, k.mask, k.angles_h, k.Na, Ng, alpha, out, k.flags_d, &done));
+  if (done) {
+    PRAD_TRY(read_flags(k));
+    done = (k.flags_h[0] == 0);
+  }
+  if (done) c.last_path = "neigh";
+  else {
+    PRAD_TRY(generic_gldm(k, Ng, alpha, out));
+    PRAD_TRY(read_flags(k));
+    c.last_path = "generic";
+  }
+  PRAD_TRY(c.end_call(s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  return k.flags_h[1] ? PRAD_INDEX_ERROR : PRAD_OK;
+}
+
+int texture_ngtdm(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                  int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim, double *out,
+                  hipStream_t s) {
+  if (!out) return fail(PRAD_E_ARG, "ngtdm is NULL");
+  if (Ng < 1) return fail(PRAD_E_ARG, "Ng must be >= 1");
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Call k;
+  PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, Nvox, voxels, kernelRadius, force2Ddim, s));
+  PRAD_TRY(c.begin_call(s));
+  bool done = false;
+  PRAD_TRY(neigh_try_ngtdm(k.c, k.s, k.g, k.vm, k.image, k.mask, k.angles_h, k.Na, Ng, out, k.flags_d, &done));
+  if (done) {
+    PRAD_TRY(read_flags(k));
+    done = (k.flags_h[0] == 0);
+  }
+  if (done) c.last_path = "neigh";
+  else {
+    PRAD_TRY(generic_ngtdm(k, Ng, out));
+    PRAD_TRY(read_flags(k));
+    c.last_path = "generic";
+  }
+  PRAD_TRY(c.end_call(s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  return k.flags_h[1] ? PRAD_INDEX_ERROR : PRAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-pointer staging
+// ------------------------------------------------------------------------------------------------
+struct Staged {
+  int32_t *image = nullptr;
+  uint8_t *mask = nullptr;
+  int *voxels = nullptr;
+};
+
+int stage_inputs(Context &c, const int32_t *image, const uint8_t *mask, const int *size, int Nd, int Nvox,
+                 const int *voxels, Staged *st) {
+  PRAD_TRY(c.ensure_device());
+  if (!image || !mask) return fail(PRAD_E_ARG, "image/mask is NULL");
+  Geo g;
+  PRAD_TRY(make_geo(size, Nd, &g));
+  // 16-byte aligned slots so the vectorised pack path applies
+  PRAD_TRY(c.get<int32_t>("h_image", (size_t)g.n + 16, &st->image));
+  PRAD_TRY(c.get<uint8_t>("h_mask", (size_t)g.n + 64, &st->mask));
+  PRAD_HIP(hipMemcpyAsync(st->image, image, sizeof(int32_t) * g.n, hipMemcpyHostToDevice, c.own_stream));
+  PRAD_HIP(hipMemcpyAsync(st->mask, mask, g.n, hipMemcpyHostToDevice, c.own_stream));
+  if (voxels) {
+    if (Nvox < 1) return fail(PRAD_E_ARG, "Nvox=%d < 1", Nvox);
+    PRAD_TRY(c.get<int>("h_voxels", (size_t)Nd * Nvox, &st->voxels));
+    PRAD_HIP(hipMemcpyAsync(st->voxels, voxels, sizeof(int) * Nd * Nvox, hipMemcpyHostToDevice, c.own_stream));
+  }
+  return PRAD_OK;
+}
+
+int fetch_output(Context &c, const char *slot, double *host, size_t count, double **dev) {
+  (void)host;
+  return c.get<double>(slot, count, dev);
+}
+
+int copy_back(Context &c, double *host, const double *dev, size_t count) {
+  PRAD_HIP(hipMemcpyAsync(host, dev, sizeof(double) * count, hipMemcpyDeviceToHost, c.own_stream));
+  PRAD_HIP(hipStreamSynchronize(c.own_stream));
+  return PRAD_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+// extern "C"
+// =================================================================================================
+extern "C" {
+
+const char *prad_version(void) { return kVersion; }
+const char *prad_last_error(void) { return err_state().msg; }
+const char *prad_last_path(void) { return ctx().last_path; }
+
+int prad_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int prad_set_device(int device) {
+  int n = prad_device_count();
+  if (device < 0 || device >= n) return fail(PRAD_E_ARG, "device %d not in [0,%d)", device, n);
+  Context &c = ctx();
+  if (c.device != device) {
+    c.own_stream = nullptr;  // streams belong to a device; a new one is created lazily
+    c.event_pool.clear();
+    c.events_used = 0;
+  }
+  c.device = device;
+  c.device_set = true;
+  PRAD_HIP(hipSetDevice(device));
+  return PRAD_OK;
+}
+int prad_get_device(void) { return ctx().device; }
+
+double prad_last_device_ms(void) {
+  Context &c = ctx();
+  if (!c.call_timed) return -1.0;
+  float ms = 0;
+  if (hipEventElapsedTime(&ms, c.call_a, c.call_b) != hipSuccess) return -1.0;
+  return ms;
+}
+
+double prad_last_kernel_ms(const char *family) {
+  Context &c = ctx();
+  double total = 0;
+  bool any = false;
+  for (auto &t : c.times) {
+    if (family && t.family != family) continue;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) return -1.0;
+    total += ms;
+    any = true;
+  }
+  return any ? total : -1.0;
+}
+
+int prad_get_angle_count(const int *size, const int *distances, int Nd, int Ndist, int bidirectional,
+                         int force2Ddim) {
+  if (!size || !distances || Nd < 1 || Ndist < 1) return 0;
+  return angle_count(size, distances, Nd, Ndist, bidirectional, force2Ddim);
+}
+
+int prad_build_angles(const int *size, const int *distances, int Nd, int Ndist, int force2Ddim, int Na,
+                      int *angles) {
+  if (!size || !distances || !angles || Nd < 1 || Ndist < 1) return 1;
+  return angle_build(size, distances, Nd, Ndist, force2Ddim, Na, angles);
+}
+
+// ---- GLCM / GLRLM ---------------------------------------------------------------------------
+int prad_calculate_glcm_glrlm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                                  const int *angles, int Na, int Ng, int Nr, int Nvox, const int *voxels,
+                                  int kernelRadius, int force2Ddim, double *glcm, double *glrlm, void *stream) {
+  return texture_pairs_runs(image, mask, size, Nd, angles, Na, Ng, Nr, Nvox, voxels, kernelRadius, force2Ddim, glcm,
+                            glrlm, (hipStream_t)stream);
+}
+int prad_calculate_glcm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                            int Na, int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                            double *glcm, void *stream) {
+  if (!glcm) return fail(PRAD_E_ARG, "glcm is NULL");
+  return texture_pairs_runs(image, mask, size, Nd, angles, Na, Ng, 1, Nvox, voxels, kernelRadius, force2Ddim, glcm,
+                            nullptr, (hipStream_t)stream);
+}
+int prad_calculate_glrlm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                             int Na, int Ng, int Nr, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                             double *glrlm, void *stream) {
+  if (!glrlm) return fail(PRAD_E_ARG, "glrlm is NULL");
+  return texture_pairs_runs(image, mask, size, Nd, angles, Na, Ng, Nr, Nvox, voxels, kernelRadius, force2Ddim,
+                            nullptr, glrlm, (hipStream_t)stream);
+}
+
+int prad_calculate_glcm_glrlm(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                              int Na, int Ng, int Nr, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                              double *glcm, double *glrlm) {
+  Context &c = ctx();
+  Staged st;
+  PRAD_TRY(stage_inputs(c, image, mask, size, Nd, Nvox, voxels, &st));
+  if (Ng < 1 || Nvox < 1 || Na < 1) return fail(PRAD_E_ARG, "Ng/Nvox/Na must be >= 1");
+  const size_t nglcm = glcm ? (size_t)Nvox * Ng * Ng * Na : 0;
+  const size_t nglrlm = glrlm ? (size_t)Nvox * Ng * (size_t)std::max(Nr, 1) * Na : 0;
+  double *d_glcm = nullptr, *d_glrlm = nullptr;
+  if (glcm) PRAD_TRY(fetch_output(c, "o_glcm", glcm, nglcm, &d_glcm));
+  if (glrlm) PRAD_TRY(fetch_output(c, "o_glrlm", glrlm, nglrlm, &d_glrlm));
+  int rc = texture_pairs_runs(st.image, st.mask, size, Nd, angles, Na, Ng, Nr, Nvox, st.voxels, kernelRadius,
+                              force2Ddim, d_glcm, d_glrlm, c.own_stream);
+  if (rc != PRAD_OK) return rc;
+  if (glcm) PRAD_TRY(copy_back(c, glcm, d_glcm, nglcm));
+  if (glrlm) PRAD_TRY(copy_back(c, glrlm, d_glrlm, nglrlm));
+  return PRAD_OK;
+}
+int prad_calculate_glcm(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                        int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim, double *glcm) {
+  if (!glcm) return fail(PRAD_E_ARG, "glcm is NULL");
+  return prad_calculate_glcm_glrlm(image, mask, size, Nd, angles, Na, Ng, 1, Nvox, voxels, kernelRadius, force2Ddim,
+                                   glcm, nullptr);
+}
+int prad_calculate_glrlm(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                         int Na, int Ng, int Nr, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                         double *glrlm) {
+  if (!glrlm) return fail(PRAD_E_ARG, "glrlm is NULL");
+  return prad_calculate_glcm_glrlm(image, mask, size, Nd, angles, Na, Ng, Nr, Nvox, voxels, kernelRadius, force2Ddim,
+                                   nullptr, glrlm);
+}
+
+// ---- GLDM -----------------------------------------------------------------------------------
+int prad_calculate_gldm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                            int Na, int Ng, int alpha, int Nvox, const int *voxels, int kernelRadius,
+                            int force2Ddim, double *gldm, void *stream) {
+  return texture_gldm(image, mask, size, Nd, angles, Na, Ng, alpha, Nvox, voxels, kernelRadius, force2Ddim, gldm,
+                      (hipStream_t)stream);
+}
+int prad_calculate_gldm(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                        int Ng, int alpha, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                        double *gldm) {
+  if (!gldm) return fail(PRAD_E_ARG, "gldm is NULL");
+  Context &c = ctx();
+  Staged st;
+  PRAD_TRY(stage_inputs(c, image, mask, size, Nd, Nvox, voxels, &st));
+  if (Ng < 1 || Nvox < 1 || Na < 1) return fail(PRAD_E_ARG, "Ng/Nvox/Na must be >= 1");
+  const size_t n = (size_t)Nvox * Ng * (2 * (size_t)Na + 1);
+  double *d = nullptr;
+  PRAD_TRY(fetch_output(c, "o_gldm", gldm, n, &d));
+  int rc = texture_gldm(st.image, st.mask, size, Nd, angles, Na, Ng, alpha, Nvox, st.voxels, kernelRadius,
+                        force2Ddim, d, c.own_stream);
+  if (rc != PRAD_OK) return rc;
+  return copy_back(c, gldm, d, n);
+}
+
+// ---- NGTDM ----------------------------------------------------------------------------------
+int prad_calculate_ngtdm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                             int Na, int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                             double *ngtdm, void *stream) {
+  return texture_ngtdm(image, mask, size, Nd, angles, Na, Ng, Nvox, voxels, kernelRadius, force2Ddim, ngtdm,
+                       (hipStream_t)stream);
+}
+int prad_calculate_ngtdm(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                         int Na, int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                         double *ngtdm) {
+  if (!ngtdm) return fail(PRAD_E_ARG, "ngtdm is NULL");
+  Context &c = ctx();
+  Staged st;
+  PRAD_TRY(stage_inputs(c, image, mask, size, Nd, Nvox, voxels, &st));
+  if (Ng < 1 || Nvox < 1 || Na < 1) return fail(PRAD_E_ARG, "Ng/Nvox/Na must be >= 1");
+  const size_t n = (size_t)Nvox * Ng * 3;
+  double *d = nullptr;
+  PRAD_TRY(fetch_output(c, "o_ngtdm", ngtdm, n, &d));
+  int rc = texture_ngtdm(st.image, st.mask, size, Nd, angles, Na, Ng, Nvox, st.voxels, kernelRadius, force2Ddim, d,
+                         c.own_stream);
+  if (rc != PRAD_OK) return rc;
+  return copy_back(c, ngtdm, d, n);
+}
+
+// ---- GLSZM ----------------------------------------------------------------------------------
+int prad_calculate_glszm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                             int Na, int Ng, int Ns, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                             long long *nzones, void *stream) {
+  (void)Ns;
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Geo g;
+  PRAD_TRY(make_geo(size, Nd, &g));
+  if (!image || !mask || !angles || Na < 1 || Ng < 1 || Nvox < 1) return fail(PRAD_E_ARG, "bad GLSZM arguments");
+  hipStream_t s = (hipStream_t)stream;
+  PRAD_TRY(c.begin_call(s));
+  int rc = glszm_zones(c, s, g, image, mask, angles, Na, Ng, Nvox, voxels, kernelRadius, force2Ddim, nzones);
+  PRAD_TRY(c.end_call(s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  return rc;
+}
+int prad_calculate_glszm(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                         int Na, int Ng, int Ns, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                         long long *nzones) {
+  Context &c = ctx();
+  Staged st;
+  PRAD_TRY(stage_inputs(c, image, mask, size, Nd, Nvox, voxels, &st));
+  return prad_calculate_glszm_dev(st.image, st.mask, size, Nd, angles, Na, Ng, Ns, Nvox, st.voxels, kernelRadius,
+                                  force2Ddim, nzones, c.own_stream);
+}
+int prad_fill_glszm_dev(double *glszm, int Nvox, int Ng, int maxRegion, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!glszm || Ng < 1 || maxRegion < 1) return fail(PRAD_E_ARG, "bad fill_glszm arguments");
+  return glszm_fill(c, (hipStream_t)stream, glszm, Nvox, Ng, maxRegion);
+}
+int prad_fill_glszm(double *glszm, int Nvox, int Ng, int maxRegion) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!glszm || Ng < 1 || maxRegion < 1 || Nvox < 1) return fail(PRAD_E_ARG, "bad fill_glszm arguments");
+  const size_t n = (size_t)Nvox * Ng * maxRegion;
+  double *d = nullptr;
+  PRAD_TRY(c.get<double>("o_glszm", n, &d));
+  int rc = glszm_fill(c, c.own_stream, d, Nvox, Ng, maxRegion);
+  if (rc != PRAD_OK) return rc;
+  return copy_back(c, glszm, d, n);
+}
+long long prad_glszm_zones(int v, int *tempData, long long capacity_pairs) {
+  Context &c = ctx();
+  int rc = c.ensure_device();
+  if (rc != PRAD_OK) return rc;
+  return glszm_copy_zones(c, v, tempData, capacity_pairs);
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// prad_runtime.h -- per-thread device context, workspace cache, error plumbing and kernel timing
+// for the MI355X texture-matrix engine.  gfx950 only; no CPU fallback lives here or anywhere in csrc/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+
+#include "../../include/pyradiomics_amd.h"
+
+namespace prad {
+
+// ---------------------------------------------------------------------------------------------
+// error state (thread local; no exceptions cross the C ABI)
+// ---------------------------------------------------------------------------------------------
+struct ErrorState {
+  char msg[512];
+  ErrorState() { msg[0] = 0; }
+};
+inline ErrorState &err_state() {
+  static thread_local ErrorState e;
+  return e;
+}
+inline int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_state().msg, sizeof(err_state().msg), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define PRAD_HIP(call)                                                                              \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return ::prad::fail(e_ == hipErrorOutOfMemory ? PRAD_E_NOMEM : PRAD_E_HIP, "%s failed: %s (%s:%d)", \
+                          #call, hipGetErrorString(e_), __FILE__, __LINE__);                        \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// A named, grow-only device buffer cache.  Texture builds are called repeatedly with the same
+// shapes (one per derived image / per voxel batch / per bench step); hipMalloc per call would
+// dominate small cases and serialise the device, so buffers are kept and reused.
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct KernelTime {
+  std::string family;
+  hipEvent_t a, b;
+};
+
+struct Context {
+  int device = 0;
+  bool device_set = false;
+  hipStream_t own_stream = nullptr;   // used by the host-pointer entry points
+  std::map<std::string, DevBuf> bufs;
+  std::map<std::string, DevBuf> pinned;
+  // timing of the last call
+  std::vector<KernelTime> times;
+  std::vector<hipEvent_t> event_pool;
+  size_t events_used = 0;
+  hipEvent_t call_a = nullptr, call_b = nullptr;
+  bool call_timed = false;
+  const char *last_path = "none";
+  // GLSZM phase-1 -> phase-2 state
+  long long glszm_nzones = 0;
+  int glszm_nvox = 0;
+  int glszm_max_region = 0;
+  std::vector<long long> glszm_zone_offsets;  // per kernel, into the device zone list (size nvox+1)
+
+  int ensure_device() {
+    if (!device_set) {
+      int n = 0;
+      hipError_t e = hipGetDeviceCount(&n);
+      if (e != hipSuccess || n <= 0)
+        return fail(PRAD_E_HIP, "no HIP device visible (hipGetDeviceCount: %s) -- this library has no CPU fallback",
+                    hipGetErrorString(e));
+      device_set = true;
+    }
+    PRAD_HIP(hipSetDevice(device));
+    if (!own_stream) PRAD_HIP(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+    return PRAD_OK;
+  }
+
+  // returns device pointer of at least `bytes` (contents undefined)
+  int get(const char *name, size_t bytes, void **out) {
+    DevBuf &b = bufs[std::string(name) + "@" + std::to_string(device)];
+    if (b.cap < bytes) {
+      if (b.p) (void)hipFree(b.p);
+      b.p = nullptr;
+      b.cap = 0;
+      size_t want = bytes + bytes / 8 + 256;
+      hipError_t e = hipMalloc(&b.p, want);
+      if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(PRAD_E_NOMEM, "hipMalloc(%zu) for workspace '%s' failed: %s", want, name, hipGetErrorString(e));
+      }
+      b.cap = want;
+    }
+    *out = b.p;
+    return PRAD_OK;
+  }
+  template <typename T>
+  int get(const char *name, size_t count, T **out) {
+    void *p = nullptr;
+    int rc = get(name, count * sizeof(T), &p);
+    *out = (T *)p;
+    return rc;
+  }
+  int get_pinned(const char *name, size_t bytes, void **out) {
+    DevBuf &b = pinned[name];
+    if (b.cap < bytes) {
+      if (b.p) (void)hipHostFree(b.p);
+      b.p = nullptr;
+      b.cap = 0;
+      hipError_t e = hipHostMalloc(&b.p, bytes + 256, hipHostMallocDefault);
+      if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(PRAD_E_NOMEM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      }
+      b.cap = bytes + 256;
+    }
+    *out = b.p;
+    return PRAD_OK;
+  }
+
+  // ---- timing ------------------------------------------------------------------------------
+  int new_event(hipEvent_t *ev) {
+    if (events_used == event_pool.size()) {
+      hipEvent_t e;
+      PRAD_HIP(hipEventCreate(&e));
+      event_pool.push_back(e);
+    }
+    *ev = event_pool[events_used++];
+    return PRAD_OK;
+  }
+  int begin_call(hipStream_t s) {
+    times.clear();
+    events_used = 0;
+    call_timed = false;
+    int rc;
+    if ((rc = new_event(&call_a)) != PRAD_OK) return rc;
+    if ((rc = new_event(&call_b)) != PRAD_OK) return rc;
+    PRAD_HIP(hipEventRecord(call_a, s));
+    return PRAD_OK;
+  }
+  int end_call(hipStream_t s) {
+    PRAD_HIP(hipEventRecord(call_b, s));
+    call_timed = true;
+    return PRAD_OK;
+  }
+  int tic(const char *family, hipStream_t s) {
+    KernelTime t;
+    t.family = family;
+    int rc;
+    if ((rc = new_event(&t.a)) != PRAD_OK) return rc;
+    if ((rc = new_event(&t.b)) != PRAD_OK) return rc;
+    PRAD_HIP(hipEventRecord(t.a, s));
+    times.push_back(t);
+    return PRAD_OK;
+  }
+  int toc(hipStream_t s) {
+    PRAD_HIP(hipEventRecord(times.back().b, s));
+    return PRAD_OK;
+  }
+};
+
+inline Context &ctx() {
+  static thread_local Context c;
+  return c;
+}
+
+// RAII helper so every launch group is bracketed by events on the stream it runs on.
+struct Timed {
+  Context &c;
+  hipStream_t s;
+  bool ok;
+  Timed(Context &c_, const char *family, hipStream_t s_) : c(c_), s(s_) { ok = c.tic(family, s) == PRAD_OK; }
+  ~Timed() {
+    if (ok) (void)c.toc(s);
+  }
+};
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PRAD_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return PRAD_OK;
+}
+
+#define PRAD_TRY(expr)              \
+  do {                              \
+    int rc_ = (expr);               \
+    if (rc_ != PRAD_OK) return rc_; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// geometry shared by host and device code
+// ---------------------------------------------------------------------------------------------
+struct Geo {
+  int nd;
+  int size[PRAD_MAX_ND];
+  long long stride[PRAD_MAX_ND];  // C-contiguous element strides
+  long long n;                    // total voxels
+};
+
+struct VoxMode {
+  int nvox;           // number of kernels (1 in segment mode)
+  const int *voxels;  // device int32 [nd][nvox] or nullptr (segment mode: box = whole array)
+  int radius;
+  int f2d;            // collapsed dimension or -1
+  long long boxmax;   // upper bound on voxels per box
+};
+
+inline int make_geo(const int *size, int Nd, Geo *g) {
+  if (!size) return fail(PRAD_E_ARG, "size is NULL");
+  if (Nd < 1 || Nd > PRAD_MAX_ND) return fail(PRAD_E_ARG, "Nd=%d outside [1,%d]", Nd, PRAD_MAX_ND);
+  g->nd = Nd;
+  long long n = 1;
+  for (int d = Nd - 1; d >= 0; d--) {
+    if (size[d] < 1) return fail(PRAD_E_ARG, "size[%d]=%d < 1", d, size[d]);
+    g->size[d] = size[d];
+    g->stride[d] = n;
+    n *= size[d];
+  }
+  for (int d = Nd; d < PRAD_MAX_ND; d++) {
+    g->size[d] = 1;
+    g->stride[d] = 0;
+  }
+  if (n > 2147483647LL)
+    return fail(PRAD_E_UNSUPPORTED, "arrays above 2^31-1 elements are not supported (the reference's int strides overflow too, _cmatrices.c:1082)");
+  g->n = n;
+  return PRAD_OK;
+}
+
+}  // namespace prad

@@ -1,0 +1,196 @@
+"""GPU parity: the HIP path (through the C ABI / pyradiomics_amd.cmatrices) against the CPU oracle on the same
+seeded inputs.  Integer matrices must be bit-exact; the NGTDM float column within 1e-12 relative in segment
+mode (exact-integer formulation, see include/pyradiomics_amd.h) and bit-exact in voxel mode."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cm():
+    from pyradiomics_amd import cmatrices
+    return cmatrices
+
+
+def _vol(seed, shape, Ng, frac, smooth=False):
+    rng = np.random.default_rng(seed)
+    if smooth:
+        from scipy import ndimage
+        f = ndimage.gaussian_filter(rng.standard_normal(shape), 2.0)
+        f = (f - f.min()) / (f.max() - f.min() + 1e-12)
+        img = np.minimum((f * Ng).astype(np.int32) + 1, Ng)
+    else:
+        img = rng.integers(1, Ng + 1, size=shape).astype(np.int32)
+    mask = np.ones(shape, bool) if frac >= 1.0 else rng.random(shape) < frac
+    return img, mask
+
+
+def _check_all(cm, oracle, img, mask, Ng, force2D=False, f2d=0, dist=(1,), alpha=0, vox=None, radius=0,
+               expect_path=None):
+    from pyradiomics_amd import _lib
+    kw = {} if vox is None else dict(kernelRadius=radius, voxels=vox)
+    dist = list(dist)
+    Nr = max(img.shape)
+    a, ang = cm.calculate_glcm(img, mask, dist, Ng, force2D, f2d, **kw)
+    if expect_path:
+        assert _lib.last_path() == expect_path
+    b, bng = oracle.calculate_glcm(img, mask, dist, Ng, force2D, f2d, **kw)
+    assert np.array_equal(ang, bng)
+    assert a.dtype == np.float64 and a.shape == b.shape and np.array_equal(a, b), "GLCM"
+    a, ang = cm.calculate_glrlm(img, mask, Ng, Nr, force2D, f2d, **kw)
+    if expect_path:
+        assert _lib.last_path() == expect_path
+    b, bng = oracle.calculate_glrlm(img, mask, Ng, Nr, force2D, f2d, **kw)
+    assert np.array_equal(ang, bng) and a.shape == b.shape and np.array_equal(a, b), "GLRLM"
+    if vox is None:
+        g, r, _ = cm.calculate_glcm_glrlm(img, mask, Ng, Nr, force2D, f2d)
+        assert np.array_equal(r, b), "fused GLRLM"
+        assert np.array_equal(g, oracle.calculate_glcm(img, mask, [1], Ng, force2D, f2d)[0]), "fused GLCM"
+    a = cm.calculate_gldm(img, mask, dist, Ng, alpha, force2D, f2d, **kw)
+    b = oracle.calculate_gldm(img, mask, dist, Ng, alpha, force2D, f2d, **kw)
+    assert a.shape == b.shape and np.array_equal(a, b), "GLDM"
+    a = cm.calculate_ngtdm(img, mask, dist, Ng, force2D, f2d, **kw)
+    b = oracle.calculate_ngtdm(img, mask, dist, Ng, force2D, f2d, **kw)
+    assert a.shape == b.shape
+    assert np.array_equal(a[..., 0], b[..., 0]) and np.array_equal(a[..., 2], b[..., 2]), "NGTDM counts"
+    if vox is None:
+        np.testing.assert_allclose(a[..., 1], b[..., 1], rtol=1e-12, atol=0)
+    else:
+        assert np.array_equal(a[..., 1], b[..., 1]), "NGTDM voxel mode must be bit-exact"
+    Ns = int(mask.sum())
+    a = cm.calculate_glszm(img, mask, Ng, Ns, force2D, f2d, **kw)
+    b = oracle.calculate_glszm(img, mask, Ng, Ns, force2D, f2d, **kw)
+    assert a.shape == b.shape and np.array_equal(a, b), "GLSZM"
+
+
+SHAPES = [(5, 6, 7), (1, 9, 9), (9, 1, 5), (4, 4, 1), (12, 10, 8), (3, 70, 65), (33, 17, 130), (16, 16, 16)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("Ng", [3, 32])
+@pytest.mark.parametrize("frac", [1.0, 0.6])
+def test_segment_3d(cm, oracle_port, shape, Ng, frac):
+    img, mask = _vol(hash((shape, Ng)) % 1000, shape, Ng, frac)
+    _check_all(cm, oracle_port, img, mask, Ng, expect_path="sweep")
+
+
+@pytest.mark.parametrize("shape", [(12, 10, 8), (3, 70, 65)])
+@pytest.mark.parametrize("f2d", [0, 1, 2])
+def test_segment_force2d(cm, oracle_port, shape, f2d):
+    img, mask = _vol(7, shape, 8, 0.7)
+    _check_all(cm, oracle_port, img, mask, 8, True, f2d, expect_path="sweep")
+
+
+@pytest.mark.parametrize("shape", [(40, 50), (1, 64), (7,), (2, 3, 4, 3)])
+def test_other_ranks(cm, oracle_port, shape):
+    img, mask = _vol(3, shape, 5, 0.8)
+    _check_all(cm, oracle_port, img, mask, 5)
+
+
+def test_smooth_volume_long_runs(cm, oracle_port):
+    img, mask = _vol(11, (40, 48, 150), 16, 1.0, smooth=True)
+    _check_all(cm, oracle_port, img, mask, 16, expect_path="sweep")
+    img[:] = 4   # one level everywhere: runs as long as the volume, GLSZM is a single zone
+    _check_all(cm, oracle_port, img, mask, 16, expect_path="sweep")
+
+
+def test_distances_two(cm, oracle_port):
+    img, mask = _vol(5, (9, 10, 11), 6, 0.8)
+    _check_all(cm, oracle_port, img, mask, 6, dist=(1, 2), alpha=1)
+    _check_all(cm, oracle_port, img, mask, 6, dist=(2,), alpha=2)
+
+
+def test_large_ng_generic(cm, oracle_port):
+    img, mask = _vol(6, (8, 9, 10), 300, 0.9)
+    _check_all(cm, oracle_port, img, mask, 300)
+
+
+@pytest.mark.parametrize("force2D", [False, True])
+def test_voxel_mode(cm, oracle_port, force2D):
+    img, mask = _vol(9, (10, 14, 12), 7, 0.7)
+    rng = np.random.default_rng(0)
+    co = np.array(np.where(mask))
+    sel = rng.choice(co.shape[1], 200, replace=False)
+    _check_all(cm, oracle_port, img, mask, 7, force2D, 0, vox=co[:, sel], radius=2, expect_path=None)
+    _check_all(cm, oracle_port, img, mask, 7, force2D, 0, vox=co[:, sel[:5]], radius=1)
+
+
+def test_irregular_levels_match_reference_semantics(cm, oracle_port):
+    """Levels <= 0 or > Ng under the mask: IndexError where the reference raises, aliased bins where it doesn't."""
+    img, mask = _vol(2, (6, 7, 8), 5, 1.0)
+    bad = img.copy()
+    bad[2, 3, 4] = 0
+    for fn, args in (("calculate_glcm", ([1], 5, False, 0)), ("calculate_glrlm", (5, 8, False, 0)),
+                     ("calculate_gldm", ([1], 5, 0, False, 0)), ("calculate_ngtdm", ([1], 5, False, 0))):
+        with pytest.raises(IndexError):
+            getattr(oracle_port, fn)(bad, mask, *args)
+        with pytest.raises(IndexError):
+            getattr(cm, fn)(bad, mask, *args)
+    big = img.copy()
+    big[1, 1, 1] = 6      # one level above Ng: the reference aliases / raises depending on the flat index
+    for fn, args in (("calculate_glcm", ([1], 5, False, 0)), ("calculate_glrlm", (5, 8, False, 0))):
+        try:
+            want = getattr(oracle_port, fn)(big, mask, *args)[0]
+        except IndexError:
+            with pytest.raises(IndexError):
+                getattr(cm, fn)(big, mask, *args)
+        else:
+            assert np.array_equal(getattr(cm, fn)(big, mask, *args)[0], want)
+
+
+def test_empty_mask_and_single_voxel(cm, oracle_port):
+    img, _ = _vol(1, (5, 5, 5), 4, 1.0)
+    none = np.zeros(img.shape, bool)
+    one = none.copy()
+    one[2, 2, 2] = True
+    for m in (none, one):
+        _check_all(cm, oracle_port, img, m, 4)
+
+
+def test_argument_errors(cm):
+    img, mask = _vol(1, (5, 5, 5), 4, 1.0)
+    with pytest.raises(ValueError):
+        cm.calculate_glcm(img, mask[0], [1], 4, False, 0)
+    with pytest.raises(ValueError):
+        cm.calculate_glcm(img, mask[:4], [1], 4, False, 0)
+    with pytest.raises(RuntimeError):
+        cm.calculate_glcm(img, mask, [0], 4, False, 0)
+    with pytest.raises(RuntimeError):
+        cm.calculate_glcm(img, mask, [1], 4, False, 0, 0, np.zeros((3, 2), int))
+    with pytest.raises(RuntimeError):
+        cm.calculate_glcm(img, mask, [1], 4, False, 0, 1, np.zeros((2, 2), int))
+
+
+def test_glszm_zone_list_order(cm, oracle_port):
+    """tempData parity: zones listed in raster order of their first voxel (cmatrices.c:255-258)."""
+    import ctypes as C
+    from pyradiomics_amd import _lib
+    img, mask = _vol(4, (9, 12, 20), 4, 0.8)
+    cm.calculate_glszm(img, mask, 4, int(mask.sum()), False, 0)
+    lib = _lib.load()
+    cap = int(mask.sum())
+    buf = np.empty(2 * cap + 1, dtype=np.intc)
+    n = lib.prad_glszm_zones(0, buf.ctypes.data_as(C.POINTER(C.c_int)), cap)
+    assert n > 0 and buf[2 * n] == -1
+    # reference order from the oracle's calculate_glszm
+    L = oracle_port.L
+    m2 = mask.copy()
+    size = np.array(img.shape, dtype=np.intc)
+    strides = np.array([s // 4 for s in img.strides], dtype=np.intc)
+    bb = np.concatenate([np.zeros(3, np.intc), size - 1]).astype(np.intc)
+    ang = oracle_port.generate_angles(size, [1], 1, 0, 0)
+    temp = np.empty(2 * cap + 1, dtype=np.intc)
+    ip = C.POINTER(C.c_int)
+    L.calculate_glszm(img.ctypes.data_as(ip), m2.ctypes.data_as(C.c_char_p), size.ctypes.data_as(ip),
+                      bb.ctypes.data_as(ip), strides.ctypes.data_as(ip), ang.ctypes.data_as(ip), len(ang), 3,
+                      temp.ctypes.data_as(ip), 4, cap, 1)
+    assert np.array_equal(buf[:2 * n + 1], temp[:2 * n + 1])
+
+
+def test_medium_volume_vs_oracle(cm, oracle_port):
+    """128^3 at 32 levels: large enough to exercise the persistent-grid paths, seconds for the oracle."""
+    img, mask = _vol(0, (128, 128, 128), 32, 1.0)
+    g, r, _ = cm.calculate_glcm_glrlm(img, mask, 32, 128, False, 0)
+    assert np.array_equal(g, oracle_port.calculate_glcm(img, mask, [1], 32, False, 0)[0])
+    assert np.array_equal(r, oracle_port.calculate_glrlm(img, mask, 32, 128, False, 0)[0])
