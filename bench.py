@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X: Mvoxels/s for the GLCM+GLRLM matrix build of a 512^3 volume at
+32 grey levels (full mask, distance 1, 13 angles), 1..8 GPUs.
+
+One "step" = one pass of the hot path over one volume that is already resident in HBM as the boundary dtypes
+(int32 levels + uint8 mask, 5 B/voxel): pack -> 13 angle sweeps -> float64 GLCM [32,32,13] + GLRLM [32,512,13]
+in HBM.  With N > 1 GPUs every rank builds the matrices of its own volume (batch mode shards cases, no collective:
+SURVEY.md section 8e), so scaling is "weak" and value = N * voxels * steps / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--dist uniform|smooth]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (plus `roofline` and, at N=1, `cpu_baseline`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+ALG_BYTES_PER_VOXEL = 5.0       # int32 level + uint8 mask, read once
+
+
+def make_volume(size: int, levels: int, dist: str, seed: int, device) -> tuple[torch.Tensor, torch.Tensor]:
+    """Synthetic uint16-range volume discretised to `levels` grey levels (binWidth 25 on [0, 25*levels)),
+    full mask.  `uniform`: iid levels (worst case for histogram locality); `smooth`: low-pass noise (diagonal-heavy
+    GLCM, long runs) -- SURVEY.md section 8d, inputs C2(i)/(ii)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    shape = (size, size, size)
+    if dist == "uniform":
+        raw = torch.randint(0, 25 * levels, shape, generator=g, device=device, dtype=torch.int32)
+    else:
+        f = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+        k = torch.tensor([1, 4, 6, 4, 1], device=device, dtype=torch.float32)
+        k = k / k.sum()
+        for _ in range(3):                       # separable binomial blur, applied 3x (sigma ~ 1.7 voxels)
+            for ax in range(3):
+                f = torch.movedim(f, ax, -1)
+                f = torch.nn.functional.conv1d(f.reshape(-1, 1, size), k.view(1, 1, 5), padding=2).reshape(
+                    *([size] * 3))
+                f = torch.movedim(f, -1, ax)
+        lo, hi = f.min(), f.max()
+        raw = ((f - lo) / (hi - lo) * (25 * levels - 1)).to(torch.int32)
+    image = (raw // 25 + 1).to(torch.int32).contiguous()       # binImage with binWidth 25, min 0
+    mask = torch.ones(shape, dtype=torch.uint8, device=device)
+    return image, mask
+
+
+def cpu_baseline(image: torch.Tensor, mask: torch.Tensor, levels: int, target_voxels: int, gpu_glcm=None):
+    """Times the reference's own C (oracle/_ref, kind 'reference') or, if that prebuilt file is absent, our C
+    restatement (kind 'port') on a z-slab of the same volume, single-threaded like the reference."""
+    from oracle import binding
+    if not os.path.exists(binding.PORT_SO):
+        binding.build()
+    kind = "reference" if binding.have_ref() else "port"
+    cpu = binding.ref() if kind == "reference" else binding.port()
+    nz = max(2, min(image.shape[0], target_voxels // (image.shape[1] * image.shape[2])))
+    img = image[:nz].cpu().numpy()
+    msk = mask[:nz].cpu().numpy().astype(bool)
+    Nr = int(max(img.shape))
+    t0 = time.perf_counter()
+    g = cpu.calculate_glcm(img, msk, [1], levels, False, 0)[0]
+    r = cpu.calculate_glrlm(img, msk, levels, Nr, False, 0)[0]
+    dt = time.perf_counter() - t0
+    out = {"value": round(img.size / dt / 1e6, 3), "unit": "Mvoxels/s", "cores": 1, "kind": kind,
+           "sample": "z-slab %dx%dx%d of the bench volume, calculate_glcm + calculate_glrlm, %.1f s"
+                     % (img.shape[0], img.shape[1], img.shape[2], dt)}
+    return out, (img, msk, g[0], r[0], Nr)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--levels", type=int, default=32)
+    ap.add_argument("--dist", choices=["uniform", "smooth"], default="uniform")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-voxels", type=int, default=48 * 512 * 512, help="size of the CPU baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    from pyradiomics_amd import engine
+
+    image, mask = make_volume(args.size, args.levels, args.dist, seed=rank, device=device)
+    Ng, Nr = args.levels, args.size
+    nvox = image.numel()
+    glcm = glrlm = None
+
+    def step():
+        nonlocal glcm, glrlm
+        glcm, glrlm, _ = engine.glcm_glrlm(image, mask, Ng, Nr, out_glcm=glcm, out_glrlm=glrlm)
+
+    for _ in range(args.warmup):
+        step()
+    assert engine.last_path() == "sweep", "bench must run the sweep kernels, got %s" % engine.last_path()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    kernel_ms = {"pack": 0.0, "sweep": 0.0, "finalize": 0.0}
+    device_ms = 0.0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # per-family device time from HIP events recorded on the launch stream inside the library
+        for fam in kernel_ms:
+            kernel_ms[fam] += engine.last_kernel_ms(fam)
+        device_ms += engine.last_device_ms()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # size-independent property checks on the full-size result (every ordered neighbour pair / every voxel counted)
+    gl = glcm.sum(dim=(0, 1)).cpu().numpy()
+    n = args.size
+    expect_pairs = {0: n * n * (n - 1), 1: n * (n - 1) * (n - 1), 2: (n - 1) ** 3}
+    ang = engine._build_angles(np.array(image.shape, dtype=np.intc), None, False, -1)
+    for a in range(ang.shape[0]):
+        assert int(gl[a]) == expect_pairs[int(np.count_nonzero(ang[a])) - 1], "GLCM pair count of angle %d" % a
+    rl_vox = (glrlm * torch.arange(1, Nr + 1, device=device, dtype=torch.float64).view(1, Nr, 1)).sum(dim=(0, 1))
+    assert torch.all(rl_vox == float(nvox)), "GLRLM runs do not tile the volume"
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * nvox * args.steps / elapsed / 1e6
+        sweep_ms = kernel_ms["sweep"] / args.steps
+        pipe_ms = device_ms / args.steps
+        alg_bytes = ALG_BYTES_PER_VOXEL * nvox
+        achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mvoxels/s for GLCM+GLRLM build, 512^3 vol @32 bins",
+            "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 levels / u32 counts / f64 out", "data": "synthetic",
+            "config": {"workload": "GLCM+GLRLM matrix build, %d^3 int32+uint8 volume resident in HBM, %d grey levels, "
+                                   "full mask, 13 angles, %s levels; one volume per GPU (batch sharding, no collective)"
+                                   % (args.size, args.levels, args.dist),
+                       "size": args.size, "levels": args.levels, "dist": args.dist},
+            "roofline": {
+                "bound": "hbm", "kernel": "sweep_lines_kernel+sweep_rows_kernel (13 angle sweeps)",
+                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "algorithmic_bytes": alg_bytes, "kernel_ms": round(sweep_ms, 4),
+                "pipeline_ms": round(pipe_ms, 4), "pack_ms": round(kernel_ms["pack"] / args.steps, 4),
+                "finalize_ms": round(kernel_ms["finalize"] / args.steps, 4),
+                "pipeline_achieved": round(alg_bytes / (pipe_ms * 1e-3) / 1e9, 2),
+                "note": "achieved = 5 B/voxel x voxels / sweep time (HIP events on the launch stream); "
+                        "pipeline_* uses pack+sweeps+finalize",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, (img, msk, g_cpu, r_cpu, Nr_s) = cpu_baseline(image, mask, Ng, args.cpu_voxels)
+            # same slab through the GPU path: the CPU run doubles as a bit-exact parity check
+            gg, rr, _ = engine.glcm_glrlm(image[:img.shape[0]].contiguous(), mask[:img.shape[0]].contiguous(), Ng, Nr_s)
+            cb["parity"] = bool(np.array_equal(gg.cpu().numpy(), g_cpu) and np.array_equal(rr.cpu().numpy(), r_cpu))
+            assert cb["parity"], "GPU matrices differ from the CPU baseline on the sample"
+            out["cpu_baseline"] = cb
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

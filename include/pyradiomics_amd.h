@@ -43,6 +43,8 @@ extern "C" {
 #define PRAD_E_HIP (-2)         /* HIP runtime failure; message in prad_last_error() */
 #define PRAD_E_NOMEM (-3)       /* device or host allocation failed */
 #define PRAD_E_UNSUPPORTED (-4) /* valid for the reference but not implemented here (stated in the message) */
+#define PRAD_E_INDEX (-5)       /* GLSZM phase 1 only: the reference's calculate_glszm would return -1 (scratch sized by
+                                   Ns exhausted, cmatrices.c:174,226,245,274) -> IndexError in the wrapper */
 
 /* ---- runtime ---------------------------------------------------------------------------------- */
 const char *prad_version(void);
@@ -127,8 +129,10 @@ int prad_calculate_ngtdm_dev(const int32_t *image, const uint8_t *mask, const in
 /* ---- GLSZM: calculate_glszm + fill_glszm (cmatrices.c:94-297) ----------------------------------- */
 /* Phase 1: labels the zones of every kernel on the device and keeps the (level, size) list in the
  * library's per-thread workspace.  Returns the largest zone size over all Nvox kernels (>= 0), or
- * PRAD_E_* (< 0); *nzones (optional) receives the total number of zones.  `Ns` is accepted for
- * signature parity (it only sizes scratch in the reference, _cmatrices.c:298-322). */
+ * PRAD_E_* (< 0); *nzones (optional) receives the total number of zones.  `Ns` only sizes scratch in the
+ * reference (_cmatrices.c:298-322) but its exhaustion is observable: a kernel with >= 2*Ns zones, or (voxel mode)
+ * more than Ns masked voxels, makes the reference fail -- reproduced here as PRAD_E_INDEX (so an empty mask with
+ * Ns = 0 raises IndexError exactly like the reference). */
 int prad_calculate_glszm(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
                          const int *angles, int Na, int Ng, int Ns,
                          int Nvox, const int *voxels, int kernelRadius, int force2Ddim,

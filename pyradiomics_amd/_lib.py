@@ -4,13 +4,14 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpyradiomics_amd.so")
 
 PRAD_OK = 1
 PRAD_INDEX_ERROR = 0
-PRAD_E_ARG, PRAD_E_HIP, PRAD_E_NOMEM, PRAD_E_UNSUPPORTED = -1, -2, -3, -4
+PRAD_E_ARG, PRAD_E_HIP, PRAD_E_NOMEM, PRAD_E_UNSUPPORTED, PRAD_E_INDEX = -1, -2, -3, -4, -5
 
 _ip = C.POINTER(C.c_int)
 _vp = C.c_void_p
@@ -58,6 +59,14 @@ def load():
         raise ImportError(
             "pyradiomics_amd: %s is missing. Build it with `python -m pyradiomics_amd._build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever is loaded first serves the whole
+    # process, and two copies cannot both own the GPU, so when torch is installed it is imported BEFORE the
+    # engine so that torch tensors and the engine share one HIP runtime (set PRAD_NO_TORCH=1 to skip).
+    if "torch" not in sys.modules and not os.environ.get("PRAD_NO_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch absent: the engine runs on /opt/rocm's runtime alone
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError here = header and library out of sync

@@ -158,10 +158,10 @@ def calculate_glszm(image, mask, Ng, Ns, force2D, force2Ddimension, kernelRadius
     nz = C.c_longlong(0)
     rc = lib.prad_calculate_glszm(_vptr(img), _vptr(msk), _iptr(size), Nd, _iptr(angles), Na, int(Ng), int(Ns),
                                   Nvox, _vptr(vox), int(kernelRadius), f2d, C.byref(nz))
+    if rc == _lib.PRAD_E_INDEX:
+        raise IndexError("Calculation of GLSZM Failed.")   # _cmatrices.c:372
     if rc < 0:
-        if rc == _lib.PRAD_E_ARG or rc == _lib.PRAD_E_UNSUPPORTED or rc == _lib.PRAD_E_HIP or rc == _lib.PRAD_E_NOMEM:
-            _lib.raise_for(rc, "GLSZM")
-        raise IndexError("Calculation of GLSZM Failed.")
+        _lib.raise_for(rc, "GLSZM")
     maxRegion = max(int(rc), 1)   # _cmatrices.c:390
     out = np.empty((Nvox, Ng, maxRegion), dtype=np.float64)
     rc = lib.prad_fill_glszm(_vptr(out), Nvox, int(Ng), maxRegion)

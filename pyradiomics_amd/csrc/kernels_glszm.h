@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(64) glszm_voxel_kernel(Geo g, VoxMode vm, cons
                                                          uint8_t *__restrict__ visited, int *__restrict__ stack,
                                                          int *__restrict__ zones, int *__restrict__ zone_count,
                                                          int *__restrict__ stats,
-                                                         unsigned long long *__restrict__ stats64) {
+                                                         unsigned long long *__restrict__ stats64, int Ns_eff) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= vm.nvox) return;
   const long long NV = vm.nvox;
@@ -236,12 +236,13 @@ __global__ void __launch_bounds__(64) glszm_voxel_kernel(Geo g, VoxMode vm, cons
     total *= ext[d];
   }
   for (long long k = 0; k < total; k++) visited[k * NV + v] = 0;
-  int nz = 0, mx = 0;
+  int nz = 0, mx = 0, nproc = 0;
   for (long long k = 0; k < total; k++) {
     if (visited[k * NV + v]) continue;
     long long i;
     box_decode(g, lo, hi, k, c, &i);
     if (!mask[i]) continue;
+    if (nz >= 2 * Ns_eff) { stats[1] = 1; break; }  // cmatrices.c:245 (tempData full)
     const int gl = image[i];
     int region = 0;
     long long top = 0;
@@ -250,6 +251,7 @@ __global__ void __launch_bounds__(64) glszm_voxel_kernel(Geo g, VoxMode vm, cons
     while (top > 0) {
       const long long kk = stack[(--top) * NV + v];
       region++;
+      nproc++;
       long long ii;
       box_decode(g, lo, hi, kk, c, &ii);
       for (int a = 0; a < Na; a++) {
@@ -272,6 +274,7 @@ __global__ void __launch_bounds__(64) glszm_voxel_kernel(Geo g, VoxMode vm, cons
     nz++;
     mx = max(mx, region);
   }
+  if (nproc > Ns_eff || nz >= 2 * Ns_eff) stats[1] = 1;  // cmatrices.c:174,226 (processedStack) and :274
   zone_count[v] = nz;
   if (nz) {
     atomicMax(stats, mx);
@@ -308,7 +311,7 @@ __global__ void glszm_gather_zones_kernel(int nvox, int v, int count, const int 
 inline unsigned glszm_grid(long long n) { return (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 8192)); }
 
 inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *image, const uint8_t *mask,
-                       const int *angles_h, int Na, int Ng, int Nvox, const int *voxels_dev, int kernelRadius,
+                       const int *angles_h, int Na, int Ng, int Ns, int Nvox, const int *voxels_dev, int kernelRadius,
                        int force2Ddim, long long *nzones_out) {
   (void)Ng;
   GlszmState &st = glszm_state();
@@ -355,6 +358,10 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
     int *angles_d = nullptr;
     PRAD_TRY(c.get<int>("angles", (size_t)Na * g.nd, &angles_d));
     PRAD_HIP(hipMemcpyAsync(angles_d, angles_h, sizeof(int) * Na * g.nd, hipMemcpyHostToDevice, s));
+    // _cmatrices.c:298-314: Ns is clipped to the nominal kernel volume (2r+1)^(Nd or Nd-1)
+    long long nominal = 1;
+    for (int d = 0; d < (force2Ddim >= 0 ? g.nd - 1 : g.nd); d++) nominal *= (2LL * kernelRadius + 1);
+    const int Ns_eff = (int)std::min<long long>(Ns, nominal);
     uint8_t *visited = nullptr;
     int *stack = nullptr;
     PRAD_TRY(c.get<uint8_t>("glszm_visited", (size_t)b * Nvox, &visited));
@@ -363,7 +370,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
     PRAD_TRY(c.get<int>("glszm_zone_count", (size_t)Nvox, &st.zone_count));
     Timed t(c, "glszm", s);
     hipLaunchKernelGGL(glszm_voxel_kernel, dim3((unsigned)((Nvox + 63) / 64)), dim3(64), 0, s, g, vm, image, mask,
-                       angles_d, Na, visited, stack, st.zones, st.zone_count, stats, stats64);
+                       angles_d, Na, visited, stack, st.zones, st.zone_count, stats, stats64, Ns_eff);
     PRAD_TRY(check_launch("glszm_voxel_kernel"));
     st.voxel_mode = true;
     st.boxmax = b;
@@ -377,6 +384,9 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
   st.nzones = (long long)*(unsigned long long *)(stats_h + 2);
   st.valid = true;
   if (nzones_out) *nzones_out = st.nzones;
+  // scratch-exhaustion rule of the reference (see include/pyradiomics_amd.h)
+  if (!st.voxel_mode ? st.nzones >= 2LL * Ns : stats_h[1] != 0)
+    return fail(PRAD_E_INDEX, "GLSZM: zone list would overflow the reference's Ns-sized scratch (Ns=%d)", Ns);
   c.last_path = st.voxel_mode ? "glszm-voxel" : "glszm-unionfind";
   return st.max_region;
 }

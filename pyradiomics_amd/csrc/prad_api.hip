@@ -223,9 +223,29 @@ struct SweepPlan {
   int Nz = 1, Ny = 1, Nx = 1;  // volume embedded in 3-D
   SweepSet lines;              // angles marching along z or y
   int row_slot = -1;           // slot of the angle along x, or -1
-  int RS = 0;
+  // lines kernel configuration
+  int RS = 0;                  // GLRLM run lengths kept in LDS (== Nr: whole table, no long-run path)
+  bool LONG = false;
+  int threads = 256;
   size_t lds_bytes = 0;
+  // rows kernel configuration
+  int RSr = 0;
+  bool LONGr = false;
+  size_t lds_bytes_rows = 0;
 };
+
+constexpr size_t kHistBudget = 72 * 1024;  // LDS bytes one workgroup may spend on histograms
+
+int cu_count() {
+  static thread_local int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
 
 // Can this call run on the sweep kernels?  (see the dispatch policy at the top of this file)
 SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_glrlm) {
@@ -235,9 +255,20 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
   for (int d = 0; d < k.g.nd; d++) dims[3 - k.g.nd + d] = k.g.size[d];
   p.Nz = dims[0]; p.Ny = dims[1]; p.Nx = dims[2];
   if (want_glrlm && Nr < std::max(dims[0], std::max(dims[1], dims[2]))) return p;  // a run could overflow Nr
-  p.RS = want_glrlm ? std::min(Nr, Ng <= 64 ? 64 : 16) : 0;
-  p.lds_bytes = sizeof(u32) * ((want_glcm ? (size_t)Ng * Ng : 0) + (want_glrlm ? (size_t)Ng * p.RS : 0));
-  if (p.lds_bytes > 64 * 1024) return p;
+  // lines kernel: whole GLRLM in LDS when it fits, else short runs only
+  const int RS_short = want_glrlm ? std::min(Nr, Ng <= 64 ? 64 : 16) : 0;
+  p.RS = want_glrlm ? Nr : 0;
+  if (sizeof(u32) * (size_t)hist_layout(want_glcm, want_glrlm, Ng, p.RS).words > kHistBudget) p.RS = RS_short;
+  p.LONG = want_glrlm && p.RS < Nr;
+  p.lds_bytes = sizeof(u32) * (size_t)hist_layout(want_glcm, want_glrlm, Ng, p.RS).words;
+  if (p.lds_bytes > kHistBudget) return p;
+  p.threads = p.lds_bytes <= 20 * 1024 ? 256 : (p.lds_bytes <= 40 * 1024 ? 512 : 1024);
+  // rows kernel: 256 threads, 4 staging tiles of 64 x PRAD_ROW_PITCH bytes behind the histograms
+  p.RSr = RS_short;
+  p.LONGr = want_glrlm && p.RSr < Nr;
+  const size_t hw = (size_t)hist_layout(want_glcm, want_glrlm, Ng, p.RSr).words;
+  p.lds_bytes_rows = sizeof(u32) * ((hw + 3) & ~(size_t)3) + 4 * 64 * PRAD_ROW_PITCH;
+  if (p.lds_bytes_rows > 150 * 1024) return p;
   p.lines.count = 0;
   for (int a = 0; a < k.Na; a++) {
     int o[3] = {0, 0, 0};
@@ -275,25 +306,48 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
   return p;
 }
 
+template <bool G, bool R, bool LNG>
+int launch_lines(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
+                 int *multi) {
+  long long maxchunks = 0;
+  for (int i = 0; i < p.lines.count; i++) maxchunks = std::max(maxchunks, p.lines.d[i].chunks);
+  const int wpb = p.threads / 64;
+  const long long want = (maxchunks + wpb - 1) / wpb;
+  const int per_cu = std::max(1, std::min(2048 / p.threads, (int)(160 * 1024 / std::max<size_t>(p.lds_bytes, 1))));
+  const long long resident = (long long)cu_count() * per_cu;
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(want, resident / p.lines.count));
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_lines_kernel<G, R, LNG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+  hipLaunchKernelGGL((sweep_lines_kernel<G, R, LNG>), dim3(gx, p.lines.count), dim3(p.threads), p.lds_bytes, k.s,
+                     p.lines, levels, Ng, Nr, p.RS, glcm_acc, glrlm_acc, multi, k.flags_d);
+  return check_launch("sweep_lines_kernel");
+}
+
+template <bool G, bool R, bool LNG>
+int launch_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
+                int *multi) {
+  const long long nrows = (long long)p.Nz * p.Ny;
+  const long long groups = (nrows + 63) / 64;
+  const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / p.lds_bytes_rows)));
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + 3) / 4, (long long)cu_count() * per_cu));
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_rows_kernel<G, R, LNG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_rows));
+  hipLaunchKernelGGL((sweep_rows_kernel<G, R, LNG>), dim3(gx), dim3(256), p.lds_bytes_rows, k.s, levels, nrows, p.Nx,
+                     p.row_slot, Ng, Nr, p.RSr, glcm_acc, glrlm_acc, multi, k.flags_d);
+  return check_launch("sweep_rows_kernel");
+}
+
 template <bool G, bool R>
 int launch_sweeps(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
                   int *multi) {
   Timed t(*k.c, "sweep", k.s);
   if (p.lines.count > 0) {
-    long long maxchunks = 0;
-    for (int i = 0; i < p.lines.count; i++) maxchunks = std::max(maxchunks, p.lines.d[i].chunks);
-    const long long want = (maxchunks + 3) / 4;
-    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(want, 3072 / p.lines.count));
-    hipLaunchKernelGGL((sweep_lines_kernel<G, R>), dim3(gx, p.lines.count), dim3(256), p.lds_bytes, k.s, p.lines,
-                       levels, Ng, Nr, p.RS, glcm_acc, glrlm_acc, multi, k.flags_d);
-    PRAD_TRY(check_launch("sweep_lines_kernel"));
+    if (R && p.LONG) PRAD_TRY((launch_lines<G, R, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+    else PRAD_TRY((launch_lines<G, R, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   }
   if (p.row_slot >= 0) {
-    const long long nrows = (long long)p.Nz * p.Ny;
-    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((nrows + 3) / 4, 2048));
-    hipLaunchKernelGGL((sweep_rows_kernel<G, R>), dim3(gx), dim3(256), p.lds_bytes, k.s, levels, nrows, p.Nx,
-                       p.row_slot, Ng, Nr, p.RS, glcm_acc, glrlm_acc, multi, k.flags_d);
-    PRAD_TRY(check_launch("sweep_rows_kernel"));
+    if (R && p.LONGr) PRAD_TRY((launch_rows<G, R, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+    else PRAD_TRY((launch_rows<G, R, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   }
   return PRAD_OK;
 }
@@ -636,7 +690,6 @@ int prad_calculate_ngtdm(const int32_t *image, const uint8_t *mask, const int *s
 int prad_calculate_glszm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
                              int Na, int Ng, int Ns, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
                              long long *nzones, void *stream) {
-  (void)Ns;
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
   Geo g;
@@ -644,7 +697,7 @@ int prad_calculate_glszm_dev(const int32_t *image, const uint8_t *mask, const in
   if (!image || !mask || !angles || Na < 1 || Ng < 1 || Nvox < 1) return fail(PRAD_E_ARG, "bad GLSZM arguments");
   hipStream_t s = (hipStream_t)stream;
   PRAD_TRY(c.begin_call(s));
-  int rc = glszm_zones(c, s, g, image, mask, angles, Na, Ng, Nvox, voxels, kernelRadius, force2Ddim, nzones);
+  int rc = glszm_zones(c, s, g, image, mask, angles, Na, Ng, Ns, Nvox, voxels, kernelRadius, force2Ddim, nzones);
   PRAD_TRY(c.end_call(s));
   PRAD_HIP(hipStreamSynchronize(s));
   return rc;

@@ -1,0 +1,76 @@
+"""Device-resident entry points: torch tensors that already live in HBM go straight to the `_dev` functions of
+the C ABI (include/pyradiomics_amd.h); nothing is staged through the host.  torch is used only for device
+memory and streams.  Used by bench.py, the batch driver and the voxel-map driver."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch  # imported before the HIP library so both share one libamdhip64 instance
+
+from . import _lib
+from .cmatrices import _build_angles, _iptr
+
+
+def _stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _prep(image: torch.Tensor, mask: torch.Tensor):
+    if not image.is_cuda or not mask.is_cuda:
+        raise ValueError("engine.* expects CUDA/HIP tensors; use pyradiomics_amd.cmatrices for numpy input")
+    if image.dtype != torch.int32:
+        image = image.to(torch.int32)
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    elif mask.dtype != torch.uint8:
+        mask = (mask != 0).view(torch.uint8)
+    image = image.contiguous()
+    mask = mask.contiguous()
+    if image.shape != mask.shape:
+        raise ValueError("Dimensions of image and mask do not match.")
+    lib = _lib.load()
+    dev = image.device.index if image.device.index is not None else torch.cuda.current_device()
+    if lib.prad_get_device() != dev or True:
+        rc = lib.prad_set_device(dev)
+        if rc != _lib.PRAD_OK:
+            _lib.raise_for(rc, "set_device")
+    size = np.array(image.shape, dtype=np.intc)
+    return lib, image, mask, size
+
+
+def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None = None, force2D: bool = False,
+               force2Ddimension: int = 0, want_glcm: bool = True, want_glrlm: bool = True,
+               out_glcm: torch.Tensor | None = None, out_glrlm: torch.Tensor | None = None):
+    """GLCM [Ng,Ng,Na] and GLRLM [Ng,Nr,Na] (float64, on the device) of one discretised volume in segment
+    mode, distance 1.  Returns (glcm, glrlm, angles)."""
+    lib, image, mask, size = _prep(image, mask)
+    f2d = int(force2Ddimension) if force2D else -1
+    angles = _build_angles(size, None, False, f2d)
+    Na, Nd = angles.shape
+    if Nr is None:
+        Nr = int(max(image.shape))
+    dev = image.device
+    if want_glcm and out_glcm is None:
+        out_glcm = torch.empty((Ng, Ng, Na), dtype=torch.float64, device=dev)
+    if want_glrlm and out_glrlm is None:
+        out_glrlm = torch.empty((Ng, Nr, Na), dtype=torch.float64, device=dev)
+    rc = lib.prad_calculate_glcm_glrlm_dev(
+        C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd, _iptr(angles), Na, int(Ng),
+        int(Nr), 1, None, 0, f2d,
+        C.c_void_p(out_glcm.data_ptr()) if want_glcm else None,
+        C.c_void_p(out_glrlm.data_ptr()) if want_glrlm else None, _stream_ptr())
+    _lib.raise_for(rc, "GLCM+GLRLM")
+    return out_glcm, out_glrlm, angles
+
+
+def last_device_ms() -> float:
+    return float(_lib.load().prad_last_device_ms())
+
+
+def last_kernel_ms(family: str | None = None) -> float:
+    return float(_lib.load().prad_last_kernel_ms(family.encode() if family else None))
+
+
+def last_path() -> str:
+    return _lib.last_path()

@@ -59,9 +59,14 @@ def _check_all(cm, oracle, img, mask, Ng, force2D=False, f2d=0, dist=(1,), alpha
     else:
         assert np.array_equal(a[..., 1], b[..., 1]), "NGTDM voxel mode must be bit-exact"
     Ns = int(mask.sum())
-    a = cm.calculate_glszm(img, mask, Ng, Ns, force2D, f2d, **kw)
-    b = oracle.calculate_glszm(img, mask, Ng, Ns, force2D, f2d, **kw)
-    assert a.shape == b.shape and np.array_equal(a, b), "GLSZM"
+    try:
+        b = oracle.calculate_glszm(img, mask, Ng, Ns, force2D, f2d, **kw)
+    except IndexError:   # e.g. empty mask: Ns = 0 exhausts the reference's scratch (cmatrices.c:274)
+        with pytest.raises(IndexError):
+            cm.calculate_glszm(img, mask, Ng, Ns, force2D, f2d, **kw)
+    else:
+        a = cm.calculate_glszm(img, mask, Ng, Ns, force2D, f2d, **kw)
+        assert a.shape == b.shape and np.array_equal(a, b), "GLSZM"
 
 
 SHAPES = [(5, 6, 7), (1, 9, 9), (9, 1, 5), (4, 4, 1), (12, 10, 8), (3, 70, 65), (33, 17, 130), (16, 16, 16)]
