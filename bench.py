@@ -153,10 +153,13 @@ def main() -> None:
     n = args.size
     expect_pairs = {0: n * n * (n - 1), 1: n * (n - 1) * (n - 1), 2: (n - 1) ** 3}
     ang = engine._build_angles(np.array(image.shape, dtype=np.intc), None, False, -1)
+    nocheck = bool(os.environ.get("PRAD_BENCH_NOCHECK"))   # ablation libraries (scripts/ablate.sh) are wrong by design
     for a in range(ang.shape[0]):
+        if nocheck:
+            break
         assert int(gl[a]) == expect_pairs[int(np.count_nonzero(ang[a])) - 1], "GLCM pair count of angle %d" % a
     rl_vox = (glrlm * torch.arange(1, Nr + 1, device=device, dtype=torch.float64).view(1, Nr, 1)).sum(dim=(0, 1))
-    assert torch.all(rl_vox == float(nvox)), "GLRLM runs do not tile the volume"
+    assert nocheck or torch.all(rl_vox == float(nvox)), "GLRLM runs do not tile the volume"
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

@@ -7,7 +7,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpyradiomics_amd.so")
+LIB_PATH = os.environ.get("PRAD_LIB") or os.path.join(_HERE, "csrc", "libpyradiomics_amd.so")  # PRAD_LIB: ablation builds
 
 PRAD_OK = 1
 PRAD_INDEX_ERROR = 0

@@ -126,7 +126,9 @@ inline int neigh_pack(Context *c, hipStream_t s, const Geo &g, const int32_t *im
   Timed t(*c, "pack", s);
   const int vec_ok = ((((uintptr_t)image) | ((uintptr_t)mask) | ((uintptr_t)*levels)) & 15) == 0;
   const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((g.n / 16 + 255) / 256, 4096));
-  hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, s, image, mask, g.n, Ng, *levels, flags_d, vec_ok);
+  const int NX = g.size[g.nd - 1];
+  hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, s, image, mask, g.n, NX, NX, 0, Ng, *levels, flags_d,
+                     vec_ok);
   return check_launch("pack_levels_kernel");
 }
 

@@ -2,30 +2,30 @@
 //
 // Data layout in HBM
 //   image  int32 [Nz][Ny][Nx]  + mask uint8 [Nz][Ny][Nx]     (boundary dtypes, 5 B/voxel, read ONCE)
-//   levels uint8 [Nz][Ny][Nx]   level | 0 = outside the ROI     (1 B/voxel, written once by pack_levels,
-//                                                              then L2/Infinity-Cache resident for the sweeps)
+//   levels uint8 [Nz*Ny][pitch]  level | 0 = outside the ROI; pitch = Nx + padw and the first padw bytes of
+//                                every row are repeated behind it (periodic pad), written once by pack_levels,
+//                                then L2 / Infinity-Cache resident for the 13 sweeps
 //   acc    uint32 GLCM [Na][Ng][Ng], GLRLM [Na][Ng][Nr]        (angle-major while accumulating)
 //   out    float64 GLCM [Ng][Ng][Na], GLRLM [Ng][Nr][Na]       (reference layout, written by finalize)
 //
 // Why sweeps.  For a unit angle d the ordered neighbour pairs (p, p+d) of the GLCM are exactly the
 // consecutive voxels of the lines the GLRLM walks (cmatrices.c:61-85 vs :448-510), so one walk along every
 // line of an angle yields both matrices for that angle: a lane keeps (previous level, current run length)
-// in registers, consumes ONE byte per step and issues one GLCM and one GLRLM LDS increment.
-//   * lines kernel (angles marching along z or y): lanes of a wavefront are 64 x-adjacent lines, so every
-//     step is one coalesced 64-byte read from a wave-uniform (SGPR) base + lane offset, even for diagonal
-//     angles (the whole wave shifts by one voxel per step).  Lines are indexed by their virtual position at
-//     march coordinate 0, which turns the line set of a skewed angle into a rectangle; the steps during
-//     which every lane of the wave is inside the volume run a predicate-free body.
-//   * rows kernel (the angle along x): a wave owns 64 consecutive rows; 64x64-voxel tiles are read coalesced,
-//     transposed through LDS, and every lane then walks its own row with the same per-step logic.
+// in registers and consumes one byte per step.
 //
-// Per step and lane the state machine is branch-free: invalid increments are steered to a per-lane dummy
-// LDS word instead of being branched around (about a dozen VALU ops per step instead of ~90 with branches).
-// Histograms are privatised per workgroup in LDS (ds_add_u32, no return).  The GLRLM table is laid out
-// [run length][level] so that the 32 levels of one run length -- the common case, short runs -- fall into 32
-// different banks.  When Ng*(Ng+Nr) words fit, the whole GLRLM lives in LDS; otherwise only run lengths
-// <= RS do and longer runs (rare) go to L2 atomics.  Workgroups are persistent and merge with one global
-// atomic per non-zero bin.  This is integer histogramming: MFMA has no role; the bound is LDS-atomic issue.
+//   * lines kernel (angles marching along z or y).  Lines are walked WRAPPED: at march step t the lines of a
+//     wave sit at row (u0 + t*du) mod NU and columns (x0 + t*dx) mod NX.  Every lane is therefore busy for all
+//     NM steps (no skew triangles, no predicates), a step is one contiguous 64*LPL-byte read per wave from a
+//     wave-uniform (SGPR) base -- the periodic row pad makes the read contiguous across the wrap -- and a wrap
+//     is simply a line break (close the run, start a new line).  Row wraps are wave-uniform; at most one of a
+//     wave's lines wraps in x per step, and groups of 8 steps without any wrap run a check-free fast path.
+//     Each lane owns LPL (1/2/4) adjacent lines = one (possibly unaligned) byte/short/dword load per step.
+//   * rows kernel (the angle along x): a wave owns 64 consecutive rows; 64x64-voxel tiles are read coalesced
+//     (16 B per lane), transposed through LDS, and every lane walks its own row with the same walker.
+//
+// The per-step state machine is branch-free: non-events are steered to a per-lane dummy LDS word.
+// Histograms are privatised per workgroup in LDS (ds_add_u32, no return); workgroups are persistent and
+// merge with one global atomic per non-zero bin.  Integer histogramming: MFMA has no role here.
 #pragma once
 #include "prad_runtime.h"
 
@@ -34,23 +34,28 @@ namespace prad {
 typedef unsigned int u32;
 typedef unsigned long long u64;
 
-// flags[0]: set when a masked voxel has a level outside [1, Ng] (=> the exact generic path must run)
+// ---------------------------------------------------------------------------------------------------
+// pack: (int32 level, uint8 mask) -> padded uint8 rows.  flags[0] is set when a masked voxel has a level
+// outside [1, Ng] (=> the exact generic path must run instead).  padw == 0: plain linear layout.
+// ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) pack_levels_kernel(const int *__restrict__ image,
-                                                          const uint8_t *__restrict__ mask, long long n, int Ng,
+                                                          const uint8_t *__restrict__ mask, long long n, int NX,
+                                                          int pitch, int padw, int Ng,
                                                           uint8_t *__restrict__ levels, int *__restrict__ flags,
                                                           int vec_ok) {
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long nthreads = (long long)gridDim.x * blockDim.x;
+  const bool linear = (padw == 0 && pitch == NX);
   int bad = 0;
   long long done = 0;
-  if (vec_ok) {
+  if (vec_ok) {  // 16 voxels per lane; with a pad, NX / pitch / padw are multiples of 16
     const long long n16 = n >> 4;
+    const int upr = NX >> 4;  // 16-voxel units per row (pad layout only)
     const int4 *im4 = reinterpret_cast<const int4 *>(image);
     const uint4 *mk4 = reinterpret_cast<const uint4 *>(mask);
-    uint4 *out4 = reinterpret_cast<uint4 *>(levels);
     for (long long t = tid; t < n16; t += nthreads) {
-      uint4 m = mk4[t];
-      int4 q0 = im4[4 * t], q1 = im4[4 * t + 1], q2 = im4[4 * t + 2], q3 = im4[4 * t + 3];
+      const uint4 m = mk4[t];
+      const int4 q0 = im4[4 * t], q1 = im4[4 * t + 1], q2 = im4[4 * t + 2], q3 = im4[4 * t + 3];
       const int lv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                           q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
       const u32 mw[4] = {m.x, m.y, m.z, m.w};
@@ -67,28 +72,44 @@ __global__ void __launch_bounds__(256) pack_levels_kernel(const int *__restrict_
         }
         ow[w] = o;
       }
-      out4[t] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+      const uint4 o4 = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+      if (linear) {
+        reinterpret_cast<uint4 *>(levels)[t] = o4;
+      } else {
+        const long long row = t / upr;
+        const int x = (int)(t - row * upr) << 4;
+        uint8_t *dst = levels + row * pitch + x;
+        *reinterpret_cast<uint4 *>(dst) = o4;
+        if (x < padw) *reinterpret_cast<uint4 *>(dst + NX) = o4;
+      }
     }
-    done = n16 << 4;
+    done = n16 << 4;  // (n is a multiple of 16 whenever a pad layout takes this path)
   }
   for (long long i = done + tid; i < n; i += nthreads) {
     const bool in = mask[i] != 0;
     const int l = image[i];
     bad |= in && (l < 1 || l > Ng);
-    levels[i] = in ? (uint8_t)l : (uint8_t)0;
+    const uint8_t v = in ? (uint8_t)l : (uint8_t)0;
+    if (linear) {
+      levels[i] = v;
+    } else {
+      const long long row = i / NX;
+      const int x = (int)(i - row * NX);
+      levels[row * pitch + x] = v;
+      if (x < padw) levels[row * pitch + NX + x] = v;
+    }
   }
   if (bad) flags[0] = 1;
 }
 
-// One sweepable angle, expressed in (march, row, lane) coordinates.
+// One sweepable angle in (march, row, lane) coordinates; strides are in bytes of the padded level volume.
 struct SweepDesc {
   int slot;          // index of the angle in the caller's list (output column)
   int NM, NU, NX;    // extents: march dim, row dim, lane dim (lane dim is always the contiguous x axis)
   int du, dx;        // motion per march step in the row / lane dims (-1, 0, +1)
-  long long sM, sU;  // element strides of march and row dims
-  int LU, LXc;       // virtual rows, 64-lane chunks per virtual row
-  int u0min, x0min;  // first virtual row / lane coordinate
-  long long chunks;  // LU * LXc
+  long long sM, sU;  // strides of march and row dims
+  int LXc;           // chunks (of 64*LPL lines) per row
+  long long chunks;  // NU * LXc
 };
 #define PRAD_MAX_SWEEP 16
 struct SweepSet {
@@ -96,49 +117,62 @@ struct SweepSet {
   SweepDesc d[PRAD_MAX_SWEEP];
 };
 
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
-}
-
-// ---- LDS histogram layout (u32 words) ----------------------------------------------------------------
+// ---- LDS histogram layouts (u32 words) -----------------------------------------------------------------
+// separate tables (GLCM only / GLRLM only / both when the fused table does not fit):
 //   [0, Ng*Ng)                 GLCM  [prev-1][cur-1]                  (only when DO_GLCM)
 //   [.., +RS*Ng)               GLRLM [len-1][level-1], len <= RS      (only when DO_GLRLM)
 //   [.., +64)                  per-lane dummy words (targets of masked-out increments)
+// fused table (GLCM and GLRLM together, FUSED):
+//   [0, (Ng+1)*(RS+1)*(Ng+1))  H [prev][min(len,RS+1)-1][cur]         cur = 0: the run ended at an unmasked
+//   [.., +64)                  dummies                                voxel / line end;  row prev = 0 collects
+//                                                                     the "events" that follow unmasked voxels
+//                                                                     and is ignored (saves a compare per step)
+//   One event per RUN END carries everything both matrices need:
+//     GLRLM[prev][len]      = sum_cur H[prev][len][cur]          (len <= RS; longer runs go to L2 atomics)
+//     GLCM[prev][cur!=prev] = sum_len H[prev][len][cur]          (a pair of different levels IS a run boundary)
+//     GLCM[g][g]            = sum_len (len-1) * GLRLM[g][len]    (pairs inside runs; evaluated in finalize)
+//   so the walk issues ONE ds_add per step instead of two, and none of them hits the hot diagonal bins.
 struct HistLayout {
   int Ng, RS;
-  int glrlm0;  // first GLRLM word
+  bool fused;
+  int glrlm0;  // first GLRLM word (separate tables)
   int dummy0;  // first dummy word
   int words;   // total
 };
-__host__ __device__ inline HistLayout hist_layout(bool glcm, bool glrlm, int Ng, int RS) {
+__host__ __device__ inline HistLayout hist_layout(bool glcm, bool glrlm, bool fused, int Ng, int RS) {
   HistLayout h;
   h.Ng = Ng;
   h.RS = RS;
-  h.glrlm0 = glcm ? Ng * Ng : 0;
-  h.dummy0 = h.glrlm0 + (glrlm ? RS * Ng : 0);
+  h.fused = fused;
+  if (fused) {
+    h.glrlm0 = 0;
+    h.dummy0 = (Ng + 1) * (RS + 1) * (Ng + 1);
+  } else {
+    h.glrlm0 = glcm ? Ng * Ng : 0;
+    h.dummy0 = h.glrlm0 + (glrlm ? RS * Ng : 0);
+  }
   h.words = h.dummy0 + 64;
   return h;
 }
 
-// Per-lane walk state + the branch-free step.  All LDS positions are kept as BYTE offsets so that a step
-// needs no index->address shift:  GLCM byte = prev*4Ng + cur*4 + cG,  GLRLM byte = len*4Ng + prev*4 + cR.
 typedef __attribute__((address_space(3))) u32 lds_u32;
+__device__ __forceinline__ void lds_bump(int lds_addr) {  // bare ds_add_u32 on a 32-bit LDS byte address
+#ifdef PRAD_DBG_NOBUMP  // ablation build: keep the address computation alive, drop the LDS atomic
+  asm volatile("" ::"v"(lds_addr));
+  return;
+#endif
+  __hip_atomic_fetch_add((lds_u32 *)(size_t)(unsigned)lds_addr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
-template <bool DO_GLCM, bool DO_GLRLM, bool LONG>
+// Per-line walk state + the branch-free step, separate-table flavour.  All LDS positions are absolute LDS
+// BYTE addresses:  GLCM byte = prev*4Ng + cur*4 + cG,  GLRLM byte = len*4Ng + prev*4 + cR.
+template <bool DO_GLCM, bool DO_GLRLM, bool LONG, bool FUSED>
 struct Walker {
   u32 *rl_long;  // global GLRLM rows of this angle (long runs only)
   int Ng4, Nr;   // Ng4 = 4*Ng
-  int cG;        // see above (both include the absolute LDS address of the histogram block, so that a
-  int cR;        //            bump is a bare ds_add_u32 on a computed 32-bit LDS address)
+  int cG, cR;    // see above
   int rl_limit;  // len*4Ng + cR beyond which the run is "long" (LONG only)
-  int dummy;     // byte offset of this lane's dummy word
+  int dummy;     // LDS address of this lane's dummy word
   // state
   int prev;   // level of the previous voxel on the line (0 = none / unmasked)
   int prowG;  // prev*4Ng + cG
@@ -146,7 +180,7 @@ struct Walker {
   int nmask;  // masked voxels seen on this line
 
   __device__ __forceinline__ void init(u32 *lds_, const HistLayout &h, int Nr_, u32 *rl_long_, int lane) {
-    const int base = (int)(unsigned)(size_t)((lds_u32 *)lds_);  // 32-bit LDS address
+    const int base = (int)(unsigned)(size_t)((lds_u32 *)lds_);
     rl_long = rl_long_;
     Ng4 = 4 * h.Ng;
     Nr = Nr_;
@@ -161,70 +195,205 @@ struct Walker {
     rlN = Ng4 + cR;
     nmask = 0;
   }
-  __device__ __forceinline__ void bump(int lds_addr) {
-    __hip_atomic_fetch_add((lds_u32 *)(size_t)(unsigned)lds_addr, 1u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
+  // true if a run of this line could be emitted as "long" within the next `steps` steps
+  __device__ __forceinline__ bool risky(int steps) const { return LONG && DO_GLRLM && rlN + steps * Ng4 > rl_limit; }
+  template <bool CHECK = true>
   __device__ __forceinline__ void step(int cur) {
     const bool pnz = prev != 0, cnz = cur != 0;
     if (DO_GLCM) {
-      bump((pnz && cnz) ? prowG + (cur << 2) : dummy);
+      lds_bump((pnz && cnz) ? prowG + (cur << 2) : dummy);
       prowG = __mul24(cur, Ng4) + cG;
     }
     if (DO_GLRLM) {
       const bool chg = cur != prev;
       const bool emit = chg && pnz;
-      if (LONG) {
+      if (LONG && CHECK) {
         const bool lng = rlN > rl_limit;
-        bump((emit && !lng) ? rlN + (prev << 2) : dummy);
+        lds_bump((emit && !lng) ? rlN + (prev << 2) : dummy);
         if (emit && lng) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + ((rlN - cR) / Ng4 - 1)], 1u);
       } else {
-        bump(emit ? rlN + (prev << 2) : dummy);
+        lds_bump(emit ? rlN + (prev << 2) : dummy);
       }
       rlN = chg ? Ng4 + cR : rlN + Ng4;
       nmask += cnz;
     }
     prev = cur;
   }
-  // closes the run that is open at the end of a line; returns "line held >= 2 masked voxels"
+  // closes the run that is open at the end of a line; returns "the line held >= 2 masked voxels"
   __device__ __forceinline__ bool end_line() {
-    step(0);
+    step<true>(0);
     return nmask > 1;
+  }
+  // a step that may first break the line (wrapped sweeps); returns end_line()'s verdict for the closed line
+  __device__ __forceinline__ bool step_brk(int cur, bool brk) {
+    bool m = false;
+    if (brk) {
+      m = end_line();
+      begin_line();
+    }
+    step<true>(cur);
+    return m;
   }
 };
 
-template <bool DO_GLCM, bool DO_GLRLM>
+// Fused flavour: H byte = prev*P + min(len-1, RS)*Q + cur*4 with Q = 4(Ng+1), P = (RS+1)*Q.
+// Whether a line held >= 2 masked voxels is NOT tracked here (it would cost mask logic on every step); it is
+// recovered after the sweeps by resolve_multi_kernel / multi_check_kernel.
+template <bool LONG>
+struct Walker<true, true, LONG, true> {
+  u32 *rl_long;
+  int Nr, P, Q;
+  int cB;      // LDS address of H
+  int lenmax;  // RS*Q: byte offset of the "long" slot
+  int dummy;
+  // state
+  int prev;
+  int prowB;  // prev*P + cB
+  int lenb;   // (len-1)*Q of the stretch of equal values ending at prev (unclamped)
+
+  __device__ __forceinline__ void init(u32 *lds_, const HistLayout &h, int Nr_, u32 *rl_long_, int lane) {
+    const int base = (int)(unsigned)(size_t)((lds_u32 *)lds_);
+    rl_long = rl_long_;
+    Nr = Nr_;
+    Q = 4 * (h.Ng + 1);
+    P = (h.RS + 1) * Q;
+    cB = base;
+    lenmax = h.RS * Q;
+    dummy = base + 4 * (h.dummy0 + lane);
+  }
+  __device__ __forceinline__ void begin_line() {
+    prev = 0;
+    prowB = cB;
+    lenb = 0;
+  }
+  // stretches of unmasked voxels count too: their events land in row 0, but an unclamped slot must stay in range
+  __device__ __forceinline__ bool risky(int steps) const { return LONG && lenb + steps * Q > lenmax; }
+  template <bool CHECK = true>
+  __device__ __forceinline__ void step(int cur) {
+    const bool chg = cur != prev;
+    const int slot = (LONG && CHECK) ? min(lenb, lenmax) : lenb;
+    lds_bump(chg ? prowB + slot + (cur << 2) : dummy);
+    if (LONG && CHECK) {
+      if (chg && prev != 0 && lenb >= lenmax) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + lenb / Q], 1u);
+    }
+    lenb = chg ? 0 : lenb + Q;
+    prowB = __mul24(cur, P) + cB;
+    prev = cur;
+  }
+  __device__ __forceinline__ bool end_line() {
+    step<true>(0);
+    return false;
+  }
+  // branch-free line break: the event of the closed run records cur = 0 (no pair across the break)
+  __device__ __forceinline__ bool step_brk(int cur, bool brk) {
+    const bool chg = (cur != prev) || brk;
+    const int evt = brk ? 0 : cur;
+    const int slot = LONG ? min(lenb, lenmax) : lenb;
+    lds_bump(chg ? prowB + slot + (evt << 2) : dummy);
+    if (LONG) {
+      if (chg && prev != 0 && lenb >= lenmax) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + lenb / Q], 1u);
+    }
+    lenb = chg ? 0 : lenb + Q;
+    prowB = __mul24(cur, P) + cB;
+    prev = cur;
+    return false;
+  }
+};
+
+template <bool DO_GLCM, bool DO_GLRLM, bool FUSED>
 __device__ __forceinline__ void flush_block_hist(const u32 *lds, const HistLayout &h, int Nr, int slot,
                                                  u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc) {
   __syncthreads();
+  const int Ng = h.Ng;
+  if (FUSED) {
+    const int Q = Ng + 1, P = (h.RS + 1) * Q;  // word strides
+    u32 *gd = glcm_acc + (size_t)slot * Ng * Ng;
+    for (int i = threadIdx.x; i < Ng * Ng; i += blockDim.x) {
+      const int p = i / Ng, c = i - p * Ng;
+      if (p == c) continue;  // diagonal comes from the GLRLM in finalize
+      u32 v = 0;
+      for (int l = 0; l <= h.RS; l++) v += lds[(p + 1) * P + l * Q + c + 1];
+      if (v) atomicAdd(gd + i, v);
+    }
+    u32 *rd = glrlm_acc + (size_t)slot * Ng * Nr;
+    for (int i = threadIdx.x; i < Ng * h.RS; i += blockDim.x) {  // the "long" slot RS is not a GLRLM bin
+      const int p = i / h.RS, l = i - p * h.RS;
+      u32 v = 0;
+      for (int c = 0; c <= Ng; c++) v += lds[(p + 1) * P + l * Q + c];
+      if (v) atomicAdd(rd + (size_t)p * Nr + l, v);
+    }
+    return;
+  }
   if (DO_GLCM) {
-    u32 *dst = glcm_acc + (size_t)slot * h.Ng * h.Ng;
-    for (int i = threadIdx.x; i < h.Ng * h.Ng; i += blockDim.x) {
+    u32 *dst = glcm_acc + (size_t)slot * Ng * Ng;
+    for (int i = threadIdx.x; i < Ng * Ng; i += blockDim.x) {
       const u32 v = lds[i];
       if (v) atomicAdd(dst + i, v);
     }
   }
   if (DO_GLRLM) {
     const u32 *hr = lds + h.glrlm0;
-    u32 *dst = glrlm_acc + (size_t)slot * h.Ng * Nr;
-    for (int i = threadIdx.x; i < h.RS * h.Ng; i += blockDim.x) {
+    u32 *dst = glrlm_acc + (size_t)slot * Ng * Nr;
+    for (int i = threadIdx.x; i < h.RS * Ng; i += blockDim.x) {
       const u32 v = hr[i];
-      if (v) atomicAdd(dst + (size_t)(i % h.Ng) * Nr + (i / h.Ng), v);
+      if (v) atomicAdd(dst + (size_t)(i % Ng) * Nr + (i / Ng), v);
     }
   }
 }
 
 #define PRAD_SWEEP_UNROLL 8
 
-// Angles whose march dimension is NOT the contiguous axis: one lane per line.
-template <bool DO_GLCM, bool DO_GLRLM, bool LONG>
-__global__ void __launch_bounds__(1024) sweep_lines_kernel(SweepSet set, const uint8_t *__restrict__ L, int Ng,
-                                                           int Nr, int RS, u32 *__restrict__ glcm_acc,
-                                                           u32 *__restrict__ glrlm_acc, int *__restrict__ multi,
-                                                           const int *__restrict__ flags) {
+struct __attribute__((packed)) u32_unaligned { u32 v; };
+struct __attribute__((packed)) u16_unaligned { unsigned short v; };
+// LPL adjacent level bytes as one (possibly unaligned) global load
+template <int LPL>
+__device__ __forceinline__ u32 load_lines(const uint8_t *p) {
+#ifdef PRAD_DBG_NOLOAD  // ablation build: synthetic levels, no memory traffic
+  const u32 x = (u32)(size_t)p * 2654435761u;
+  return ((x >> 7) & 0x1f1f1f1fu) + 0x01010101u;
+#else
+  if (LPL == 4) return reinterpret_cast<const u32_unaligned *>(p)->v;
+  if (LPL == 2) return reinterpret_cast<const u16_unaligned *>(p)->v;
+  return *p;
+#endif
+}
+
+// wave-uniform position of a wave of wrapped lines: row u, first column b, plus the breaks that take effect
+// when ENTERING the current step: ent_uw = the row wrapped (every line breaks), ent_sb = x-offset within the wave
+// of the one line that wrapped in x (or -1)
+struct WrapPos {
+  int u, b, ent_sb;
+  bool ent_uw;
+};
+template <int CW>
+__device__ __forceinline__ void wrap_advance(WrapPos &p, int du, int dx, int NU, int NX) {
+  int un = p.u + du, bn = p.b + dx;
+  bool uw = false;
+  if (un < 0) { un = NU - 1; uw = true; }
+  else if (un >= NU) { un = 0; uw = true; }
+  if (bn < 0) bn += NX;
+  else if (bn >= NX) bn -= NX;
+  int sb = -1;
+  if (dx > 0) { sb = NX - bn; if (sb == NX) sb = 0; }  // the line at offset sb now sits at column 0
+  else if (dx < 0) sb = NX - 1 - bn;                   // the line at offset sb now sits at column NX-1
+  if (sb >= CW) sb = -1;
+  p.u = un;
+  p.b = bn;
+  p.ent_sb = sb;
+  p.ent_uw = uw;
+}
+
+// Angles whose march dimension is NOT the contiguous axis (see the header comment).
+template <bool DO_GLCM, bool DO_GLRLM, bool LONG, bool FUSED, int LPL>
+__global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, const uint8_t *__restrict__ L, int Ng,
+                                                              int Nr, int RS, u32 *__restrict__ glcm_acc,
+                                                              u32 *__restrict__ glrlm_acc, int *__restrict__ multi,
+                                                              const int *__restrict__ flags) {
+  constexpr int CW = 64 * LPL;  // lines per wave
+  constexpr int U = PRAD_SWEEP_UNROLL;
   extern __shared__ u32 lds[];
   if (flags[0]) return;  // irregular levels: the generic path will redo this call
-  const HistLayout h = hist_layout(DO_GLCM, DO_GLRLM, Ng, RS);
+  const HistLayout h = hist_layout(DO_GLCM, DO_GLRLM, FUSED, Ng, RS);
   for (int i = threadIdx.x; i < h.words; i += blockDim.x) lds[i] = 0;
   __syncthreads();
 
@@ -232,90 +401,104 @@ __global__ void __launch_bounds__(1024) sweep_lines_kernel(SweepSet set, const u
   const int lane = threadIdx.x & 63;
   const int wpb = blockDim.x >> 6;
   const long long nwaves = (long long)gridDim.x * wpb;
-  const long long step = D.sM + (long long)D.du * D.sU + D.dx;  // address increment per march step
-  Walker<DO_GLCM, DO_GLRLM, LONG> w;
-  w.init(lds, h, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr, lane);
+  Walker<DO_GLCM, DO_GLRLM, LONG, FUSED> w[LPL];
+#pragma unroll
+  for (int j = 0; j < LPL; j++) w[j].init(lds, h, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr, lane);
   bool seen_multi = false;
+  const int lane4 = lane * LPL;
+  const int NM = D.NM, NU = D.NU, NX = D.NX, du = D.du, dx = D.dx;
+  const long long sM = D.sM, sU = D.sU;
 
   const long long chunk0 = (long long)blockIdx.x * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (long long chunk = chunk0; chunk < D.chunks; chunk += nwaves) {
-    const int ui = (int)(chunk / D.LXc);
-    const int xc = (int)(chunk - (long long)ui * D.LXc);
-    // (wave-uniform; the 64-bit division above is done in VALU, readfirstlane moves the results to SGPRs so
-    // that the line base below is a scalar address)
-    const int u0 = __builtin_amdgcn_readfirstlane(D.u0min + ui);
-    const int xfirst = __builtin_amdgcn_readfirstlane(D.x0min + xc * 64);
-    const int x0 = xfirst + lane;
-    // march interval during which this lane's line is inside the volume
-    int lo = 0, hi = D.NM - 1;
-    if (D.du > 0) { lo = max(lo, -u0); hi = min(hi, D.NU - 1 - u0); }
-    else if (D.du < 0) { lo = max(lo, u0 - (D.NU - 1)); hi = min(hi, u0); }
-    if (D.dx > 0) { lo = max(lo, -x0); hi = min(hi, D.NX - 1 - x0); }
-    else if (D.dx < 0) { lo = max(lo, x0 - (D.NX - 1)); hi = min(hi, x0); }
-    else if (x0 < 0 || x0 >= D.NX) { lo = 1; hi = 0; }
-    const bool live = lo <= hi;
-    // readfirstlane: the reductions are wave-uniform by construction; telling the compiler keeps the loop
-    // counters, the loop branches and the load base in SGPRs
-    const int wlo = __builtin_amdgcn_readfirstlane(wave_min_i32(live ? lo : 0x7fffffff));
-    const int whi = __builtin_amdgcn_readfirstlane(wave_max_i32(live ? hi : -1));
-    if (wlo > whi) continue;
-    // [blo, bhi]: steps at which EVERY lane of the wave is inside (empty if some lane is dead)
-    const int blo = __builtin_amdgcn_readfirstlane(wave_max_i32(live ? lo : 0x7fffffff));
-    const int bhi = __builtin_amdgcn_readfirstlane(wave_min_i32(live ? hi : -1));
-    // wave-uniform base of the 64 lines at march coordinate 0 (may point outside L for dead lanes: never
-    // dereferenced there)
-    const uint8_t *base = L + ((long long)u0 * D.sU + xfirst);
-    const unsigned ulane = (unsigned)lane;  // zero-extended lane offset => global_load ... saddr form
-    w.begin_line();
-    int t = wlo;
-    // head: some lanes have not entered yet
-    const int head_end = min(whi, (blo <= bhi ? blo - 1 : whi));
-    for (; t <= head_end; t++) {
-      const uint8_t *pt = base + (long long)t * step;
-      const int cur = (t >= lo && t <= hi) ? (int)pt[ulane] : 0;
-      w.step(cur);
-    }
-    // body: predicate-free, unrolled, loads issued ahead of use
-    if (blo <= bhi) {
-      for (; t + PRAD_SWEEP_UNROLL - 1 <= bhi; t += PRAD_SWEEP_UNROLL) {
-        int v[PRAD_SWEEP_UNROLL];
-        const uint8_t *p = base + (long long)t * step;
+    // wave-uniform chunk coordinates (the 64-bit division runs in VALU; readfirstlane moves results to SGPRs)
+    const int u0 = __builtin_amdgcn_readfirstlane((int)(chunk / D.LXc));
+    const int xfirst = __builtin_amdgcn_readfirstlane((int)(chunk % D.LXc)) * CW;
+    bool dead[LPL];
+    bool anydead_l = false;
 #pragma unroll
-        for (int k = 0; k < PRAD_SWEEP_UNROLL; k++) {
-          v[k] = (int)p[ulane];
-          p += step;
+    for (int j = 0; j < LPL; j++) {
+      dead[j] = xfirst + lane4 + j >= NX;  // lines beyond the row end (partial last chunk)
+      anydead_l = anydead_l || dead[j];
+    }
+    const bool anydead = __ballot(anydead_l) != 0;
+#pragma unroll
+    for (int j = 0; j < LPL; j++) w[j].begin_line();
+
+    WrapPos pos;
+    pos.u = u0;
+    pos.b = xfirst;
+    pos.ent_sb = -1;
+    pos.ent_uw = false;
+    int t0 = 0;
+    for (; t0 + U <= NM; t0 += U) {
+      // ---- scalar pre-pass: load offsets and break flags of the group's U steps ----
+      long long off[U];
+      int sb[U];
+      bool uw[U];
+      bool anybrk = false;
+#pragma unroll
+      for (int k = 0; k < U; k++) {
+        off[k] = (long long)(t0 + k) * sM + (long long)pos.u * sU + pos.b;
+        sb[k] = pos.ent_sb;
+        uw[k] = pos.ent_uw;
+        anybrk = anybrk || pos.ent_uw || pos.ent_sb >= 0;
+        wrap_advance<CW>(pos, du, dx, NU, NX);
+      }
+      // ---- loads issued ahead of use ----
+      u32 v[U];
+#pragma unroll
+      for (int k = 0; k < U; k++) v[k] = load_lines<LPL>(L + off[k] + lane4);
+      bool risky_l = false;
+#pragma unroll
+      for (int j = 0; j < LPL; j++) risky_l = risky_l || w[j].risky(U);
+      if (!anybrk && !anydead && !(LONG && __ballot(risky_l) != 0)) {
+        // no line break, no dead line, no run can exceed RS inside this group: bare steps
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+#pragma unroll
+          for (int j = 0; j < LPL; j++) w[j].template step<false>((int)((v[k] >> (8 * j)) & 0xffu));
         }
+      } else {
 #pragma unroll
-        for (int k = 0; k < PRAD_SWEEP_UNROLL; k++) w.step(v[k]);
-      }
-      for (; t <= bhi; t++) {
-        const uint8_t *pt = base + (long long)t * step;
-        w.step((int)pt[ulane]);
+        for (int k = 0; k < U; k++) {
+#pragma unroll
+          for (int j = 0; j < LPL; j++) {
+            const bool brk = uw[k] || (sb[k] == lane4 + j);
+            const int cur = dead[j] ? 0 : (int)((v[k] >> (8 * j)) & 0xffu);
+            seen_multi |= w[j].step_brk(cur, brk);
+          }
+        }
       }
     }
-    // tail: some lanes have already left
-    for (; t <= whi; t++) {
-      const uint8_t *pt = base + (long long)t * step;
-      const int cur = (t >= lo && t <= hi) ? (int)pt[ulane] : 0;
-      w.step(cur);
+    for (int t = t0; t < NM; t++) {  // remainder steps
+      const u32 v = load_lines<LPL>(L + ((long long)t * sM + (long long)pos.u * sU + pos.b) + lane4);
+#pragma unroll
+      for (int j = 0; j < LPL; j++) {
+        const bool brk = pos.ent_uw || (pos.ent_sb == lane4 + j);
+        const int cur = dead[j] ? 0 : (int)((v >> (8 * j)) & 0xffu);
+        seen_multi |= w[j].step_brk(cur, brk);
+      }
+      wrap_advance<CW>(pos, du, dx, NU, NX);
     }
-    seen_multi |= w.end_line();
+#pragma unroll
+    for (int j = 0; j < LPL; j++) seen_multi |= w[j].end_line();
   }
-  if (DO_GLRLM && seen_multi) multi[D.slot] = 1;
-  flush_block_hist<DO_GLCM, DO_GLRLM>(lds, h, Nr, D.slot, glcm_acc, glrlm_acc);
+  if (DO_GLRLM && !FUSED && seen_multi) multi[D.slot] = 1;
+  flush_block_hist<DO_GLCM, DO_GLRLM, FUSED>(lds, h, Nr, D.slot, glcm_acc, glrlm_acc);
 }
 
 // The angle along the contiguous axis.  A wave owns 64 consecutive rows (row = flattened (z,y)); it stages
 // 64 rows x 64 voxels through LDS (coalesced in, one row per lane out) and walks them with the same Walker.
 #define PRAD_ROW_PITCH 80  // bytes per staged row: 64 data + 16 pad => conflict-free ds_read_b128 per lane
-template <bool DO_GLCM, bool DO_GLRLM, bool LONG>
-__global__ void __launch_bounds__(256) sweep_rows_kernel(const uint8_t *__restrict__ L, long long nrows, int NX,
-                                                         int slot, int Ng, int Nr, int RS,
+template <bool DO_GLCM, bool DO_GLRLM, bool LONG, bool FUSED>
+__global__ void __launch_bounds__(512) sweep_rows_kernel(const uint8_t *__restrict__ L, long long nrows, int NX,
+                                                         int pitch, int slot, int Ng, int Nr, int RS,
                                                          u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
                                                          int *__restrict__ multi, const int *__restrict__ flags) {
   extern __shared__ u32 lds[];
   if (flags[0]) return;
-  const HistLayout h = hist_layout(DO_GLCM, DO_GLRLM, Ng, RS);
+  const HistLayout h = hist_layout(DO_GLCM, DO_GLRLM, FUSED, Ng, RS);
   for (int i = threadIdx.x; i < h.words; i += blockDim.x) lds[i] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;
@@ -325,10 +508,10 @@ __global__ void __launch_bounds__(256) sweep_rows_kernel(const uint8_t *__restri
   uint8_t *tile = reinterpret_cast<uint8_t *>(lds + ((h.words + 3) & ~3)) + (size_t)wave * 64 * PRAD_ROW_PITCH;
   const long long ngroups = (nrows + 63) / 64;
   const long long nwaves = (long long)gridDim.x * wpb;
-  Walker<DO_GLCM, DO_GLRLM, LONG> w;
+  Walker<DO_GLCM, DO_GLRLM, LONG, FUSED> w;
   w.init(lds, h, Nr, glrlm_acc + (size_t)slot * Ng * Nr, lane);
   bool seen_multi = false;
-  const bool vec16 = (NX & 15) == 0 && ((uintptr_t)L & 15) == 0;
+  const bool vec16 = (NX & 15) == 0 && (pitch & 15) == 0 && ((uintptr_t)L & 15) == 0;
 
   for (long long grp = (long long)blockIdx.x * wpb + wave; grp < ngroups; grp += nwaves) {
     const long long r0 = grp * 64;
@@ -342,7 +525,7 @@ __global__ void __launch_bounds__(256) sweep_rows_kernel(const uint8_t *__restri
           const int rr = j * 16 + (lane >> 2);
           const int cx = xc + (lane & 3) * 16;
           uint4 q = make_uint4(0, 0, 0, 0);
-          if (r0 + rr < nrows && cx < NX) q = *reinterpret_cast<const uint4 *>(L + (r0 + rr) * NX + cx);
+          if (r0 + rr < nrows && cx < NX) q = *reinterpret_cast<const uint4 *>(L + (r0 + rr) * pitch + cx);
           *reinterpret_cast<uint4 *>(tile + rr * PRAD_ROW_PITCH + (lane & 3) * 16) = q;
         }
       } else {
@@ -350,7 +533,7 @@ __global__ void __launch_bounds__(256) sweep_rows_kernel(const uint8_t *__restri
 #pragma unroll 8
         for (int rr = 0; rr < 64; rr++) {
           uint8_t b = 0;
-          if (xin && r0 + rr < nrows) b = L[(r0 + rr) * NX + xc + lane];
+          if (xin && r0 + rr < nrows) b = L[(r0 + rr) * pitch + xc + lane];
           tile[rr * PRAD_ROW_PITCH + lane] = b;
         }
       }
@@ -363,25 +546,86 @@ __global__ void __launch_bounds__(256) sweep_rows_kernel(const uint8_t *__restri
         const u32 wds[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
+          if (LONG && __ballot(w.risky(4)) != 0) {
 #pragma unroll
-          for (int b = 0; b < 4; b++) w.step((int)((wds[k] >> (8 * b)) & 0xffu));
+            for (int b = 0; b < 4; b++) w.template step<true>((int)((wds[k] >> (8 * b)) & 0xffu));
+          } else {
+#pragma unroll
+            for (int b = 0; b < 4; b++) w.template step<false>((int)((wds[k] >> (8 * b)) & 0xffu));
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
     seen_multi |= w.end_line();
   }
-  if (DO_GLRLM && seen_multi) multi[slot] = 1;
-  flush_block_hist<DO_GLCM, DO_GLRLM>(lds, h, Nr, slot, glcm_acc, glrlm_acc);
+  if (DO_GLRLM && !FUSED && seen_multi) multi[slot] = 1;
+  flush_block_hist<DO_GLCM, DO_GLRLM, FUSED>(lds, h, Nr, slot, glcm_acc, glrlm_acc);
 }
 
-// acc (angle-major u32) -> reference layout float64
-__global__ void finalize_glcm_kernel(const u32 *__restrict__ acc, int Ng, int Na, double *__restrict__ out) {
+// ---- "does some line of angle a hold >= 2 masked voxels?" for the fused walker (cmatrices.c:524-534) -------
+// Cheap sufficient conditions from the finished histograms: a run longer than 1, or a pair of different levels.
+__global__ void __launch_bounds__(256) resolve_multi_kernel(const u32 *__restrict__ glcm_acc,
+                                                            const u32 *__restrict__ glrlm_acc, int Ng, int Nr,
+                                                            int *__restrict__ multi) {
+  const int a = blockIdx.x;
+  const u32 *racc = glrlm_acc + (size_t)a * Ng * Nr;
+  const u32 *gacc = glcm_acc + (size_t)a * Ng * Ng;
+  int found = 0;
+  for (int i = threadIdx.x; i < Ng * Nr; i += blockDim.x)
+    if ((i % Nr) != 0 && racc[i]) found = 1;
+  for (int i = threadIdx.x; i < Ng * Ng; i += blockDim.x)
+    if (gacc[i]) found = 1;  // fused accumulators hold off-diagonal pairs only
+  if (found) multi[a] = 1;
+}
+
+// Exact test for the angles the conditions above leave open (every masked voxel isolated along the angle):
+// one lane per line start, early exit once the flag is known.  Rarely does any work.
+struct AngleSet {
+  int count;
+  int off[PRAD_MAX_SWEEP][3];
+};
+__global__ void __launch_bounds__(256) multi_check_kernel(AngleSet A, const uint8_t *__restrict__ L, int Nz, int Ny,
+                                                          int Nx, int pitch, int *__restrict__ multi) {
+  const int a = blockIdx.y;
+  if (multi[a]) return;
+  const int dz = A.off[a][0], dy = A.off[a][1], dx = A.off[a][2];
+  const long long n = (long long)Nz * Ny * Nx, plane = (long long)Ny * Nx;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int z = (int)(i / plane);
+    const int r = (int)(i - (long long)z * plane);
+    int y = r / Nx, x = r - y * Nx;
+    const int pz = z - dz, py = y - dy, px = x - dx;
+    if ((unsigned)pz < (unsigned)Nz && (unsigned)py < (unsigned)Ny && (unsigned)px < (unsigned)Nx) continue;
+    int cnt = 0;
+    while ((unsigned)z < (unsigned)Nz && (unsigned)y < (unsigned)Ny && (unsigned)x < (unsigned)Nx) {
+      cnt += L[((long long)z * Ny + y) * pitch + x] != 0;
+      if (cnt > 1) {
+        multi[a] = 1;
+        return;
+      }
+      z += dz; y += dy; x += dx;
+    }
+  }
+}
+
+// acc (angle-major u32) -> reference layout float64.  diag_from_runs: GLCM[g][g] = sum_len (len-1)*GLRLM[g][len].
+__global__ void finalize_glcm_kernel(const u32 *__restrict__ acc, const u32 *__restrict__ glrlm_acc, int Ng, int Nr,
+                                     int Na, int diag_from_runs, double *__restrict__ out) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)Ng * Ng * Na;
   if (idx >= total) return;
   const int a = (int)(idx % Na);
   const long long ij = idx / Na;
+  const int i = (int)(ij / Ng), j = (int)(ij - (long long)i * Ng);
+  if (diag_from_runs && i == j) {
+    const u32 *row = glrlm_acc + ((size_t)a * Ng + i) * Nr;
+    unsigned long long pairs = 0;
+    for (int r = 1; r < Nr; r++) pairs += (unsigned long long)r * row[r];
+    out[idx] = (double)pairs;
+    return;
+  }
   out[idx] = (double)acc[(size_t)a * Ng * Ng + ij];
 }
 

@@ -223,18 +223,25 @@ struct SweepPlan {
   int Nz = 1, Ny = 1, Nx = 1;  // volume embedded in 3-D
   SweepSet lines;              // angles marching along z or y
   int row_slot = -1;           // slot of the angle along x, or -1
+  bool fused = false;          // one [prev][len][cur] table instead of separate GLCM / GLRLM tables
+  int LPL = 1;                 // lines per lane of the lines kernel (1, 2, 4)
+  int pitch = 0, padw = 0;     // row pitch / periodic pad of the packed level volume
+  bool vec_rows = false;       // Nx multiple of 16: vector pack and vector row staging
+  AngleSet aset;               // all angles embedded in 3-D (for multi_check_kernel)
   // lines kernel configuration
-  int RS = 0;                  // GLRLM run lengths kept in LDS (== Nr: whole table, no long-run path)
+  int RS = 0;                  // GLRLM run lengths kept in LDS (>= Nr: every length, no long-run path)
   bool LONG = false;
   int threads = 256;
   size_t lds_bytes = 0;
-  // rows kernel configuration
+  // rows kernel configuration (512 threads, 8 staging tiles behind the histograms)
   int RSr = 0;
   bool LONGr = false;
   size_t lds_bytes_rows = 0;
 };
 
-constexpr size_t kHistBudget = 72 * 1024;  // LDS bytes one workgroup may spend on histograms
+constexpr size_t kHistBudget = 72 * 1024;      // LDS bytes a lines workgroup may spend on histograms
+constexpr size_t kHistBudgetRows = 36 * 1024;  // same for a rows workgroup (which also holds staging tiles)
+constexpr int kRowsThreads = 512;
 
 int cu_count() {
   static thread_local int cus = 0;
@@ -247,6 +254,19 @@ int cu_count() {
   return cus;
 }
 
+// largest RS (<= Nr) whose table fits `budget` bytes; -1 if not even RS = 1 fits
+int fit_rs(bool glcm, bool glrlm, bool fused, int Ng, int Nr, size_t budget) {
+  int lo = 0, hi = Nr;
+  if (sizeof(u32) * (size_t)hist_layout(glcm, glrlm, fused, Ng, 1).words > budget) return -1;
+  lo = 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) / 2;
+    if (sizeof(u32) * (size_t)hist_layout(glcm, glrlm, fused, Ng, mid).words <= budget) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
 // Can this call run on the sweep kernels?  (see the dispatch policy at the top of this file)
 SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_glrlm) {
   SweepPlan p;
@@ -254,22 +274,38 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
   int dims[3] = {1, 1, 1};
   for (int d = 0; d < k.g.nd; d++) dims[3 - k.g.nd + d] = k.g.size[d];
   p.Nz = dims[0]; p.Ny = dims[1]; p.Nx = dims[2];
-  if (want_glrlm && Nr < std::max(dims[0], std::max(dims[1], dims[2]))) return p;  // a run could overflow Nr
-  // lines kernel: whole GLRLM in LDS when it fits, else short runs only
-  const int RS_short = want_glrlm ? std::min(Nr, Ng <= 64 ? 64 : 16) : 0;
-  p.RS = want_glrlm ? Nr : 0;
-  if (sizeof(u32) * (size_t)hist_layout(want_glcm, want_glrlm, Ng, p.RS).words > kHistBudget) p.RS = RS_short;
+  const int longest = std::max(dims[0], std::max(dims[1], dims[2]));
+  if (want_glrlm && Nr < longest) return p;  // a run could overflow Nr
+  if (!want_glrlm) Nr = 1;
+  // fused table when both matrices are wanted and it holds run lengths up to at least min(Nr, 8)
+  if (want_glcm && want_glrlm) {
+    const int rs = fit_rs(true, true, true, Ng, Nr, kHistBudget);
+    const int rsr = fit_rs(true, true, true, Ng, Nr, kHistBudgetRows);
+    if (rs >= std::min(Nr, 8) && rsr >= std::min(Nr, 4)) {
+      p.fused = true;
+      p.RS = rs;
+      p.RSr = rsr;
+    }
+  }
+  if (!p.fused) {
+    p.RS = want_glrlm ? fit_rs(want_glcm, true, false, Ng, Nr, kHistBudget) : 0;
+    p.RSr = want_glrlm ? fit_rs(want_glcm, true, false, Ng, Nr, kHistBudgetRows) : 0;
+    if (p.RS < 0 || p.RSr < 0) return p;
+    if (!want_glrlm && sizeof(u32) * (size_t)hist_layout(true, false, false, Ng, 0).words > kHistBudgetRows) return p;
+  }
   p.LONG = want_glrlm && p.RS < Nr;
-  p.lds_bytes = sizeof(u32) * (size_t)hist_layout(want_glcm, want_glrlm, Ng, p.RS).words;
-  if (p.lds_bytes > kHistBudget) return p;
-  p.threads = p.lds_bytes <= 20 * 1024 ? 256 : (p.lds_bytes <= 40 * 1024 ? 512 : 1024);
-  // rows kernel: 256 threads, 4 staging tiles of 64 x PRAD_ROW_PITCH bytes behind the histograms
-  p.RSr = RS_short;
   p.LONGr = want_glrlm && p.RSr < Nr;
-  const size_t hw = (size_t)hist_layout(want_glcm, want_glrlm, Ng, p.RSr).words;
-  p.lds_bytes_rows = sizeof(u32) * ((hw + 3) & ~(size_t)3) + 4 * 64 * PRAD_ROW_PITCH;
-  if (p.lds_bytes_rows > 150 * 1024) return p;
+  p.lds_bytes = sizeof(u32) * (size_t)hist_layout(want_glcm, want_glrlm, p.fused, Ng, p.RS).words;
+  p.threads = p.lds_bytes <= 20 * 1024 ? 256 : (p.lds_bytes <= 40 * 1024 ? 512 : 1024);
+  const size_t hw = (size_t)hist_layout(want_glcm, want_glrlm, p.fused, Ng, p.RSr).words;
+  p.lds_bytes_rows = sizeof(u32) * ((hw + 3) & ~(size_t)3) + (kRowsThreads / 64) * 64 * PRAD_ROW_PITCH;
+  // packed layout: each lane of the lines kernel owns LPL adjacent lines; rows get a periodic pad of one wave width
+  p.LPL = p.Nx >= 192 ? 4 : (p.Nx >= 96 ? 2 : 1);
+  p.vec_rows = (p.Nx % 16) == 0;
+  p.padw = std::min(64 * p.LPL, p.Nx);
+  p.pitch = p.Nx + p.padw;
   p.lines.count = 0;
+  p.aset.count = k.Na;
   for (int a = 0; a < k.Na; a++) {
     int o[3] = {0, 0, 0};
     for (int d = 0; d < k.g.nd; d++) o[3 - k.g.nd + d] = k.angles_h[a * k.g.nd + d];
@@ -277,6 +313,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     for (int d = 0; d < 3; d++) {
       if (o[d] < -1 || o[d] > 1) return p;
       if (!first && o[d]) first = o[d];
+      p.aset.off[a][d] = o[d];
     }
     if (first != 1) return p;  // sweeps assume the first moving component is +1 (unidirectional list)
     if (o[0] == 0 && o[1] == 0) {
@@ -290,64 +327,72 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     D.dx = o[2];
     if (o[0] == 1) {  // march z, rows = y
       D.NM = p.Nz; D.NU = p.Ny; D.du = o[1];
-      D.sM = (long long)p.Ny * p.Nx; D.sU = p.Nx;
+      D.sM = (long long)p.Ny * p.pitch; D.sU = p.pitch;
     } else {          // march y, rows = z (never moves)
       D.NM = p.Ny; D.NU = p.Nz; D.du = 0;
-      D.sM = p.Nx; D.sU = (long long)p.Ny * p.Nx;
+      D.sM = p.pitch; D.sU = (long long)p.Ny * p.pitch;
     }
-    D.LU = D.NU + (D.du ? D.NM - 1 : 0);
-    D.u0min = D.du > 0 ? -(D.NM - 1) : 0;
-    const int LX = D.NX + (D.dx ? D.NM - 1 : 0);
-    D.x0min = D.dx > 0 ? -(D.NM - 1) : 0;
-    D.LXc = (LX + 63) / 64;
-    D.chunks = (long long)D.LU * D.LXc;
+    D.LXc = (p.Nx + 64 * p.LPL - 1) / (64 * p.LPL);
+    D.chunks = (long long)D.NU * D.LXc;
   }
   p.ok = true;
   return p;
 }
 
-template <bool G, bool R, bool LNG>
-int launch_lines(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
-                 int *multi) {
+template <bool G, bool R, bool LNG, bool F, int LPL>
+int launch_lines_lpl(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc,
+                     u32 *glrlm_acc, int *multi) {
   long long maxchunks = 0;
   for (int i = 0; i < p.lines.count; i++) maxchunks = std::max(maxchunks, p.lines.d[i].chunks);
   const int wpb = p.threads / 64;
-  const long long want = (maxchunks + wpb - 1) / wpb;
   const int per_cu = std::max(1, std::min(2048 / p.threads, (int)(160 * 1024 / std::max<size_t>(p.lds_bytes, 1))));
-  const long long resident = (long long)cu_count() * per_cu;
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(want, resident / p.lines.count));
-  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_lines_kernel<G, R, LNG>),
+  // waves available to one angle when all angles are resident together; give every wave the same number of
+  // chunks (a chunk is one NM-step serial walk, so an uneven split costs a whole extra walk)
+  const long long waves_avail = std::max<long long>(wpb, (long long)cu_count() * per_cu * wpb / p.lines.count);
+  const long long per_wave = (maxchunks + waves_avail - 1) / waves_avail;
+  const long long waves_used = (maxchunks + per_wave - 1) / per_wave;
+  const unsigned gx = (unsigned)std::max<long long>(1, (waves_used + wpb - 1) / wpb);
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_lines_kernel<G, R, LNG, F, LPL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-  hipLaunchKernelGGL((sweep_lines_kernel<G, R, LNG>), dim3(gx, p.lines.count), dim3(p.threads), p.lds_bytes, k.s,
-                     p.lines, levels, Ng, Nr, p.RS, glcm_acc, glrlm_acc, multi, k.flags_d);
+  hipLaunchKernelGGL((sweep_lines_kernel<G, R, LNG, F, LPL>), dim3(gx, p.lines.count), dim3(p.threads), p.lds_bytes,
+                     k.s, p.lines, levels, Ng, Nr, p.RS, glcm_acc, glrlm_acc, multi, k.flags_d);
   return check_launch("sweep_lines_kernel");
 }
 
-template <bool G, bool R, bool LNG>
+template <bool G, bool R, bool LNG, bool F>
+int launch_lines(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
+                 int *multi) {
+  if (p.LPL == 4) return launch_lines_lpl<G, R, LNG, F, 4>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
+  if (p.LPL == 2) return launch_lines_lpl<G, R, LNG, F, 2>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
+  return launch_lines_lpl<G, R, LNG, F, 1>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
+}
+
+template <bool G, bool R, bool LNG, bool F>
 int launch_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
                 int *multi) {
   const long long nrows = (long long)p.Nz * p.Ny;
   const long long groups = (nrows + 63) / 64;
-  const int per_cu = std::max(1, std::min(8, (int)(160 * 1024 / p.lds_bytes_rows)));
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + 3) / 4, (long long)cu_count() * per_cu));
-  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_rows_kernel<G, R, LNG>),
+  const int wpb = kRowsThreads / 64;
+  const int per_cu = std::max(1, std::min(2048 / kRowsThreads, (int)(160 * 1024 / p.lds_bytes_rows)));
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + wpb - 1) / wpb, (long long)cu_count() * per_cu));
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_rows_kernel<G, R, LNG, F>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes_rows));
-  hipLaunchKernelGGL((sweep_rows_kernel<G, R, LNG>), dim3(gx), dim3(256), p.lds_bytes_rows, k.s, levels, nrows, p.Nx,
-                     p.row_slot, Ng, Nr, p.RSr, glcm_acc, glrlm_acc, multi, k.flags_d);
+  hipLaunchKernelGGL((sweep_rows_kernel<G, R, LNG, F>), dim3(gx), dim3(kRowsThreads), p.lds_bytes_rows, k.s, levels,
+                     nrows, p.Nx, p.pitch, p.row_slot, Ng, Nr, p.RSr, glcm_acc, glrlm_acc, multi, k.flags_d);
   return check_launch("sweep_rows_kernel");
 }
 
-template <bool G, bool R>
+template <bool G, bool R, bool F>
 int launch_sweeps(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
                   int *multi) {
   Timed t(*k.c, "sweep", k.s);
   if (p.lines.count > 0) {
-    if (R && p.LONG) PRAD_TRY((launch_lines<G, R, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
-    else PRAD_TRY((launch_lines<G, R, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+    if (R && p.LONG) PRAD_TRY((launch_lines<G, R, true, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+    else PRAD_TRY((launch_lines<G, R, false, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   }
   if (p.row_slot >= 0) {
-    if (R && p.LONGr) PRAD_TRY((launch_rows<G, R, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
-    else PRAD_TRY((launch_rows<G, R, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+    if (R && p.LONGr) PRAD_TRY((launch_rows<G, R, true, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+    else PRAD_TRY((launch_rows<G, R, false, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   }
   return PRAD_OK;
 }
@@ -356,7 +401,8 @@ int launch_sweeps(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, in
 int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, double *glrlm, bool *used) {
   Context &c = *k.c;
   uint8_t *levels = nullptr;
-  PRAD_TRY(c.get<uint8_t>("levels", (size_t)k.g.n + 64, &levels));
+  const long long nrows = (long long)p.Nz * p.Ny;
+  PRAD_TRY(c.get<uint8_t>("levels", (size_t)nrows * p.pitch + 512, &levels));
   u32 *glcm_acc = nullptr, *glrlm_acc = nullptr;
   int *multi = nullptr;
   const size_t nglcm = glcm ? (size_t)k.Na * Ng * Ng : 0, nglrlm = glrlm ? (size_t)k.Na * Ng * Nr : 0;
@@ -368,21 +414,29 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
   PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u32) * (nglcm + nglrlm + PRAD_MAX_SWEEP), k.s));
   {
     Timed t(c, "pack", k.s);
-    const int vec_ok = ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)levels)) & 15) == 0;
+    const int vec_ok = p.vec_rows && ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)levels)) & 15) == 0;
     const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n / 16 + 255) / 256, 4096));
-    hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, k.s, k.image, k.mask, k.g.n, Ng, levels,
-                       k.flags_d, vec_ok);
+    hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, k.s, k.image, k.mask, k.g.n, p.Nx, p.pitch, p.padw,
+                       Ng, levels, k.flags_d, vec_ok);
     PRAD_TRY(check_launch("pack_levels_kernel"));
   }
-  if (glcm && glrlm) PRAD_TRY((launch_sweeps<true, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
-  else if (glcm) PRAD_TRY((launch_sweeps<true, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
-  else PRAD_TRY((launch_sweeps<false, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+  if (glcm && glrlm && p.fused) PRAD_TRY((launch_sweeps<true, true, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+  else if (glcm && glrlm) PRAD_TRY((launch_sweeps<true, true, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+  else if (glcm) PRAD_TRY((launch_sweeps<true, false, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+  else PRAD_TRY((launch_sweeps<false, true, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   {
     Timed t(c, "finalize", k.s);
     if (glcm) {
       hipLaunchKernelGGL(finalize_glcm_kernel, dim3(blocks_for((long long)Ng * Ng * k.Na)), dim3(256), 0, k.s,
-                         glcm_acc, Ng, k.Na, glcm);
+                         glcm_acc, glrlm_acc, Ng, Nr, k.Na, p.fused ? 1 : 0, glcm);
       PRAD_TRY(check_launch("finalize_glcm_kernel"));
+    }
+    if (glrlm && p.fused) {
+      hipLaunchKernelGGL(resolve_multi_kernel, dim3(k.Na), dim3(256), 0, k.s, glcm_acc, glrlm_acc, Ng, Nr, multi);
+      PRAD_TRY(check_launch("resolve_multi_kernel"));
+      hipLaunchKernelGGL(multi_check_kernel, dim3(256, k.Na), dim3(256), 0, k.s, p.aset, levels, p.Nz, p.Ny, p.Nx,
+                         p.pitch, multi);
+      PRAD_TRY(check_launch("multi_check_kernel"));
     }
     if (glrlm) {
       hipLaunchKernelGGL(finalize_glrlm_kernel, dim3(blocks_for((long long)Ng * Nr * k.Na)), dim3(256), 0, k.s,
