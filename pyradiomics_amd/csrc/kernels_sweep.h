@@ -358,29 +358,52 @@ __device__ __forceinline__ u32 load_lines(const uint8_t *p) {
 #endif
 }
 
-// wave-uniform position of a wave of wrapped lines: row u, first column b, plus the breaks that take effect
-// when ENTERING the current step: ent_uw = the row wrapped (every line breaks), ent_sb = x-offset within the wave
-// of the one line that wrapped in x (or -1)
+// Wave-uniform position of a wave of wrapped lines, kept entirely in SGPRs and advanced incrementally:
+//   off     byte offset of (march t, row u, column b) in the padded level volume
+//   u, b    current row / first column of the wave
+//   ent_uw  the row wrapped when entering the current step (every line of the wave breaks)
+//   ent_sb  x-offset (0..CW-1) of the one line that wrapped in x when entering the current step, or -1
 struct WrapPos {
+  long long off;
   int u, b, ent_sb;
   bool ent_uw;
 };
+struct WrapGeo {
+  int du, dx, NU, NX;
+  long long delta;    // sM + du*sU + dx: offset change of a step without wraps
+  long long uwrapfix; // -du*NU*sU: correction when the row wraps
+};
 template <int CW>
-__device__ __forceinline__ void wrap_advance(WrapPos &p, int du, int dx, int NU, int NX) {
-  int un = p.u + du, bn = p.b + dx;
-  bool uw = false;
-  if (un < 0) { un = NU - 1; uw = true; }
-  else if (un >= NU) { un = 0; uw = true; }
-  if (bn < 0) bn += NX;
-  else if (bn >= NX) bn -= NX;
-  int sb = -1;
-  if (dx > 0) { sb = NX - bn; if (sb == NX) sb = 0; }  // the line at offset sb now sits at column 0
-  else if (dx < 0) sb = NX - 1 - bn;                   // the line at offset sb now sits at column NX-1
-  if (sb >= CW) sb = -1;
-  p.u = un;
-  p.b = bn;
-  p.ent_sb = sb;
-  p.ent_uw = uw;
+__device__ __forceinline__ void wrap_advance(WrapPos &p, const WrapGeo &g) {
+  p.off += g.delta;
+  p.u += g.du;
+  p.ent_uw = false;
+  if (p.u < 0 || p.u >= g.NU) {
+    p.u -= g.du * g.NU;
+    p.off += g.uwrapfix;
+    p.ent_uw = true;
+  }
+  p.ent_sb = -1;
+  if (g.dx != 0) {
+    p.b += g.dx;
+    if (p.b < 0 || p.b >= g.NX) {
+      p.b -= g.dx * g.NX;
+      p.off -= (long long)g.dx * g.NX;
+    }
+    // dx > 0: the line at offset NX - b now sits at column 0 (b = 0: offset 0);  dx < 0: offset NX-1-b sits at NX-1
+    int sb = g.dx > 0 ? (p.b == 0 ? 0 : g.NX - p.b) : g.NX - 1 - p.b;
+    p.ent_sb = sb < CW ? sb : -1;
+  }
+}
+// true if the next `steps` advances cause no row wrap, no base wrap and no line of the wave to wrap in x
+template <int CW>
+__device__ __forceinline__ bool wrap_quiet(const WrapPos &p, const WrapGeo &g, int steps) {
+  bool q = true;
+  if (g.du > 0) q = q && (p.u + steps < g.NU);
+  else if (g.du < 0) q = q && (p.u - steps >= 0);
+  if (g.dx > 0) q = q && (p.b + steps <= g.NX - CW);       // all offsets NX - b_k stay >= CW
+  else if (g.dx < 0) q = q && (p.b - steps >= 0) && (p.b <= g.NX - 1 - CW);
+  return q;
 }
 
 // Angles whose march dimension is NOT the contiguous axis (see the header comment).
@@ -407,7 +430,11 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
   bool seen_multi = false;
   const int lane4 = lane * LPL;
   const int NM = D.NM, NU = D.NU, NX = D.NX, du = D.du, dx = D.dx;
-  const long long sM = D.sM, sU = D.sU;
+  const long long sU = D.sU;
+  WrapGeo geo;
+  geo.du = du; geo.dx = dx; geo.NU = NU; geo.NX = NX;
+  geo.delta = D.sM + (long long)du * D.sU + dx;
+  geo.uwrapfix = -(long long)du * NU * D.sU;
 
   const long long chunk0 = (long long)blockIdx.x * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (long long chunk = chunk0; chunk < D.chunks; chunk += nwaves) {
@@ -426,40 +453,45 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
     for (int j = 0; j < LPL; j++) w[j].begin_line();
 
     WrapPos pos;
+    pos.off = (long long)u0 * sU + xfirst;
     pos.u = u0;
     pos.b = xfirst;
     pos.ent_sb = -1;
     pos.ent_uw = false;
     int t0 = 0;
     for (; t0 + U <= NM; t0 += U) {
-      // ---- scalar pre-pass: load offsets and break flags of the group's U steps ----
-      long long off[U];
-      int sb[U];
-      bool uw[U];
-      bool anybrk = false;
-#pragma unroll
-      for (int k = 0; k < U; k++) {
-        off[k] = (long long)(t0 + k) * sM + (long long)pos.u * sU + pos.b;
-        sb[k] = pos.ent_sb;
-        uw[k] = pos.ent_uw;
-        anybrk = anybrk || pos.ent_uw || pos.ent_sb >= 0;
-        wrap_advance<CW>(pos, du, dx, NU, NX);
-      }
-      // ---- loads issued ahead of use ----
       u32 v[U];
-#pragma unroll
-      for (int k = 0; k < U; k++) v[k] = load_lines<LPL>(L + off[k] + lane4);
       bool risky_l = false;
 #pragma unroll
       for (int j = 0; j < LPL; j++) risky_l = risky_l || w[j].risky(U);
-      if (!anybrk && !anydead && !(LONG && __ballot(risky_l) != 0)) {
-        // no line break, no dead line, no run can exceed RS inside this group: bare steps
+      const bool calm = !pos.ent_uw && pos.ent_sb < 0 && wrap_quiet<CW>(pos, geo, U) && !anydead &&
+                        !(LONG && __ballot(risky_l) != 0);
+      if (calm) {
+        // no line break, no dead line, no run can exceed RS inside this group: constant stride, bare steps
+        const uint8_t *pl = L + pos.off + lane4;
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+          v[k] = load_lines<LPL>(pl);
+          pl += geo.delta;
+        }
+        pos.off += (long long)U * geo.delta;
+        pos.u += U * du;
+        pos.b += U * dx;
 #pragma unroll
         for (int k = 0; k < U; k++) {
 #pragma unroll
           for (int j = 0; j < LPL; j++) w[j].template step<false>((int)((v[k] >> (8 * j)) & 0xffu));
         }
       } else {
+        int sb[U];
+        bool uw[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+          v[k] = load_lines<LPL>(L + pos.off + lane4);
+          sb[k] = pos.ent_sb;
+          uw[k] = pos.ent_uw;
+          wrap_advance<CW>(pos, geo);
+        }
 #pragma unroll
         for (int k = 0; k < U; k++) {
 #pragma unroll
@@ -472,14 +504,14 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
       }
     }
     for (int t = t0; t < NM; t++) {  // remainder steps
-      const u32 v = load_lines<LPL>(L + ((long long)t * sM + (long long)pos.u * sU + pos.b) + lane4);
+      const u32 v = load_lines<LPL>(L + pos.off + lane4);
 #pragma unroll
       for (int j = 0; j < LPL; j++) {
         const bool brk = pos.ent_uw || (pos.ent_sb == lane4 + j);
         const int cur = dead[j] ? 0 : (int)((v >> (8 * j)) & 0xffu);
         seen_multi |= w[j].step_brk(cur, brk);
       }
-      wrap_advance<CW>(pos, du, dx, NU, NX);
+      wrap_advance<CW>(pos, geo);
     }
 #pragma unroll
     for (int j = 0; j < LPL; j++) seen_multi |= w[j].end_line();
