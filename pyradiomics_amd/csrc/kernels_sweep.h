@@ -237,6 +237,7 @@ struct Walker {
 };
 
 // Fused flavour: H byte = prev*P + min(len-1, RS)*Q + cur*4 with Q = 4(Ng+1), P = (RS+1)*Q.
+// State is ONE running LDS address pl = cB + prev*P + (len-1)*Q (the bin row of the open run) plus prev.
 // Whether a line held >= 2 masked voxels is NOT tracked here (it would cost mask logic on every step); it is
 // recovered after the sweeps by resolve_multi_kernel / multi_check_kernel.
 template <bool LONG>
@@ -248,8 +249,7 @@ struct Walker<true, true, LONG, true> {
   int dummy;
   // state
   int prev;
-  int prowB;  // prev*P + cB
-  int lenb;   // (len-1)*Q of the stretch of equal values ending at prev (unclamped)
+  int pl;  // cB + prev*P + (len-1)*Q, unclamped
 
   __device__ __forceinline__ void init(u32 *lds_, const HistLayout &h, int Nr_, u32 *rl_long_, int lane) {
     const int base = (int)(unsigned)(size_t)((lds_u32 *)lds_);
@@ -263,21 +263,22 @@ struct Walker<true, true, LONG, true> {
   }
   __device__ __forceinline__ void begin_line() {
     prev = 0;
-    prowB = cB;
-    lenb = 0;
+    pl = cB;
   }
+  __device__ __forceinline__ int lenb() const { return pl - (__mul24(prev, P) + cB); }
   // stretches of unmasked voxels count too: their events land in row 0, but an unclamped slot must stay in range
-  __device__ __forceinline__ bool risky(int steps) const { return LONG && lenb + steps * Q > lenmax; }
+  __device__ __forceinline__ bool risky(int steps) const { return LONG && lenb() + steps * Q > lenmax; }
   template <bool CHECK = true>
   __device__ __forceinline__ void step(int cur) {
     const bool chg = cur != prev;
-    const int slot = (LONG && CHECK) ? min(lenb, lenmax) : lenb;
-    lds_bump(chg ? prowB + slot + (cur << 2) : dummy);
+    int bin = pl;
     if (LONG && CHECK) {
-      if (chg && prev != 0 && lenb >= lenmax) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + lenb / Q], 1u);
+      const int lb = lenb();
+      bin = pl - lb + min(lb, lenmax);
+      if (chg && prev != 0 && lb >= lenmax) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + lb / Q], 1u);
     }
-    lenb = chg ? 0 : lenb + Q;
-    prowB = __mul24(cur, P) + cB;
+    lds_bump(chg ? bin + (cur << 2) : dummy);
+    pl = chg ? __mul24(cur, P) + cB : pl + Q;
     prev = cur;
   }
   __device__ __forceinline__ bool end_line() {
@@ -288,13 +289,14 @@ struct Walker<true, true, LONG, true> {
   __device__ __forceinline__ bool step_brk(int cur, bool brk) {
     const bool chg = (cur != prev) || brk;
     const int evt = brk ? 0 : cur;
-    const int slot = LONG ? min(lenb, lenmax) : lenb;
-    lds_bump(chg ? prowB + slot + (evt << 2) : dummy);
+    int bin = pl;
     if (LONG) {
-      if (chg && prev != 0 && lenb >= lenmax) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + lenb / Q], 1u);
+      const int lb = lenb();
+      bin = pl - lb + min(lb, lenmax);
+      if (chg && prev != 0 && lb >= lenmax) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + lb / Q], 1u);
     }
-    lenb = chg ? 0 : lenb + Q;
-    prowB = __mul24(cur, P) + cB;
+    lds_bump(chg ? bin + (evt << 2) : dummy);
+    pl = chg ? __mul24(cur, P) + cB : pl + Q;
     prev = cur;
     return false;
   }
@@ -411,7 +413,7 @@ template <bool DO_GLCM, bool DO_GLRLM, bool LONG, bool FUSED, int LPL>
 __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, const uint8_t *__restrict__ L, int Ng,
                                                               int Nr, int RS, u32 *__restrict__ glcm_acc,
                                                               u32 *__restrict__ glrlm_acc, int *__restrict__ multi,
-                                                              const int *__restrict__ flags) {
+                                                              int *__restrict__ work, const int *__restrict__ flags) {
   constexpr int CW = 64 * LPL;  // lines per wave
   constexpr int U = PRAD_SWEEP_UNROLL;
   extern __shared__ u32 lds[];
@@ -436,11 +438,17 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
   geo.delta = D.sM + (long long)du * D.sU + dx;
   geo.uwrapfix = -(long long)du * NU * D.sU;
 
-  const long long chunk0 = (long long)blockIdx.x * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (long long chunk = chunk0; chunk < D.chunks; chunk += nwaves) {
-    // wave-uniform chunk coordinates (the 64-bit division runs in VALU; readfirstlane moves results to SGPRs)
-    const int u0 = __builtin_amdgcn_readfirstlane((int)(chunk / D.LXc));
-    const int xfirst = __builtin_amdgcn_readfirstlane((int)(chunk % D.LXc)) * CW;
+  // Chunks (one NM-step walk of 64*LPL lines) are handed out dynamically, one atomic per chunk: a chunk is a long
+  // serial walk, so a static split leaves whole walks of imbalance between CUs that host 1 vs 2 workgroups.
+  (void)nwaves;
+  for (;;) {
+    int grabbed = 0;
+    if (lane == 0) grabbed = atomicAdd(&work[blockIdx.y], 1);
+    const int chunk = __builtin_amdgcn_readfirstlane(grabbed);
+    if (chunk >= D.chunks) break;
+    // wave-uniform chunk coordinates
+    const int u0 = chunk / D.LXc;
+    const int xfirst = (chunk - u0 * D.LXc) * CW;
     bool dead[LPL];
     bool anydead_l = false;
 #pragma unroll
@@ -464,10 +472,9 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
       bool risky_l = false;
 #pragma unroll
       for (int j = 0; j < LPL; j++) risky_l = risky_l || w[j].risky(U);
-      const bool calm = !pos.ent_uw && pos.ent_sb < 0 && wrap_quiet<CW>(pos, geo, U) && !anydead &&
-                        !(LONG && __ballot(risky_l) != 0);
-      if (calm) {
-        // no line break, no dead line, no run can exceed RS inside this group: constant stride, bare steps
+      const bool quiet = !pos.ent_uw && pos.ent_sb < 0 && wrap_quiet<CW>(pos, geo, U) && !anydead;
+      if (quiet) {
+        // no line break and no dead line inside this group: constant stride
         const uint8_t *pl = L + pos.off + lane4;
 #pragma unroll
         for (int k = 0; k < U; k++) {
@@ -477,10 +484,18 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
         pos.off += (long long)U * geo.delta;
         pos.u += U * du;
         pos.b += U * dx;
+        if (LONG && __ballot(risky_l) != 0) {  // some run may exceed RS: clamp + long-run test per step
 #pragma unroll
-        for (int k = 0; k < U; k++) {
+          for (int k = 0; k < U; k++) {
 #pragma unroll
-          for (int j = 0; j < LPL; j++) w[j].template step<false>((int)((v[k] >> (8 * j)) & 0xffu));
+            for (int j = 0; j < LPL; j++) w[j].template step<true>((int)((v[k] >> (8 * j)) & 0xffu));
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < U; k++) {
+#pragma unroll
+            for (int j = 0; j < LPL; j++) w[j].template step<false>((int)((v[k] >> (8 * j)) & 0xffu));
+          }
         }
       } else {
         int sb[U];

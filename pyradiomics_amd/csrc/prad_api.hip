@@ -297,10 +297,18 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
   p.LONGr = want_glrlm && p.RSr < Nr;
   p.lds_bytes = sizeof(u32) * (size_t)hist_layout(want_glcm, want_glrlm, p.fused, Ng, p.RS).words;
   p.threads = p.lds_bytes <= 20 * 1024 ? 256 : (p.lds_bytes <= 40 * 1024 ? 512 : 1024);
+  if (const char *e = getenv("PRAD_THREADS")) {  // tuning/ablation override
+    const int v = atoi(e);
+    if (v == 256 || v == 512 || v == 1024) p.threads = v;
+  }
   const size_t hw = (size_t)hist_layout(want_glcm, want_glrlm, p.fused, Ng, p.RSr).words;
   p.lds_bytes_rows = sizeof(u32) * ((hw + 3) & ~(size_t)3) + (kRowsThreads / 64) * 64 * PRAD_ROW_PITCH;
   // packed layout: each lane of the lines kernel owns LPL adjacent lines; rows get a periodic pad of one wave width
   p.LPL = p.Nx >= 192 ? 4 : (p.Nx >= 96 ? 2 : 1);
+  if (const char *e = getenv("PRAD_LPL")) {  // tuning/ablation override
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) p.LPL = v;
+  }
   p.vec_rows = (p.Nx % 16) == 0;
   p.padw = std::min(64 * p.LPL, p.Nx);
   p.pitch = p.Nx + p.padw;
@@ -348,14 +356,15 @@ int launch_lines_lpl(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng,
   const int per_cu = std::max(1, std::min(2048 / p.threads, (int)(160 * 1024 / std::max<size_t>(p.lds_bytes, 1))));
   // waves available to one angle when all angles are resident together; give every wave the same number of
   // chunks (a chunk is one NM-step serial walk, so an uneven split costs a whole extra walk)
-  const long long waves_avail = std::max<long long>(wpb, (long long)cu_count() * per_cu * wpb / p.lines.count);
-  const long long per_wave = (maxchunks + waves_avail - 1) / waves_avail;
-  const long long waves_used = (maxchunks + per_wave - 1) / per_wave;
-  const unsigned gx = (unsigned)std::max<long long>(1, (waves_used + wpb - 1) / wpb);
+  // chunks are grabbed dynamically, so simply fill the machine: every angle gets an equal share of the resident
+  // workgroup slots (never more waves than chunks)
+  const long long blocks_avail = std::max<long long>(1, (long long)cu_count() * per_cu / p.lines.count);
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(blocks_avail, (maxchunks + wpb - 1) / wpb));
   PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_lines_kernel<G, R, LNG, F, LPL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
   hipLaunchKernelGGL((sweep_lines_kernel<G, R, LNG, F, LPL>), dim3(gx, p.lines.count), dim3(p.threads), p.lds_bytes,
-                     k.s, p.lines, levels, Ng, Nr, p.RS, glcm_acc, glrlm_acc, multi, k.flags_d);
+                     k.s, p.lines, levels, Ng, Nr, p.RS, glcm_acc, glrlm_acc, multi, multi + PRAD_MAX_SWEEP,
+                     k.flags_d);
   return check_launch("sweep_lines_kernel");
 }
 
@@ -407,11 +416,12 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
   int *multi = nullptr;
   const size_t nglcm = glcm ? (size_t)k.Na * Ng * Ng : 0, nglrlm = glrlm ? (size_t)k.Na * Ng * Nr : 0;
   u32 *acc = nullptr;
-  PRAD_TRY(c.get<u32>("sweep_acc", nglcm + nglrlm + PRAD_MAX_SWEEP, &acc));
+  // accumulators, then per-angle "multi-element" flags, then per-angle work counters of the lines kernel
+  PRAD_TRY(c.get<u32>("sweep_acc", nglcm + nglrlm + 2 * PRAD_MAX_SWEEP, &acc));
   glcm_acc = acc;
   glrlm_acc = acc + nglcm;
   multi = (int *)(acc + nglcm + nglrlm);
-  PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u32) * (nglcm + nglrlm + PRAD_MAX_SWEEP), k.s));
+  PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u32) * (nglcm + nglrlm + 2 * PRAD_MAX_SWEEP), k.s));
   {
     Timed t(c, "pack", k.s);
     const int vec_ok = p.vec_rows && ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)levels)) & 15) == 0;
