@@ -225,13 +225,14 @@ struct Walker {
     return nmask > 1;
   }
   // a step that may first break the line (wrapped sweeps); returns end_line()'s verdict for the closed line
+  template <bool CHECK = true>
   __device__ __forceinline__ bool step_brk(int cur, bool brk) {
     bool m = false;
     if (brk) {
       m = end_line();
       begin_line();
     }
-    step<true>(cur);
+    step<CHECK>(cur);
     return m;
   }
 };
@@ -286,11 +287,12 @@ struct Walker<true, true, LONG, true> {
     return false;
   }
   // branch-free line break: the event of the closed run records cur = 0 (no pair across the break)
+  template <bool CHECK = true>
   __device__ __forceinline__ bool step_brk(int cur, bool brk) {
     const bool chg = (cur != prev) || brk;
     const int evt = brk ? 0 : cur;
     int bin = pl;
-    if (LONG) {
+    if (LONG && CHECK) {
       const int lb = lenb();
       bin = pl - lb + min(lb, lenmax);
       if (chg && prev != 0 && lb >= lenmax) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + lb / Q], 1u);
@@ -507,13 +509,24 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
           uw[k] = pos.ent_uw;
           wrap_advance<CW>(pos, geo);
         }
+        if (anydead || (LONG && __ballot(risky_l) != 0)) {
 #pragma unroll
-        for (int k = 0; k < U; k++) {
+          for (int k = 0; k < U; k++) {
 #pragma unroll
-          for (int j = 0; j < LPL; j++) {
-            const bool brk = uw[k] || (sb[k] == lane4 + j);
-            const int cur = dead[j] ? 0 : (int)((v[k] >> (8 * j)) & 0xffu);
-            seen_multi |= w[j].step_brk(cur, brk);
+            for (int j = 0; j < LPL; j++) {
+              const bool brk = uw[k] || (sb[k] == lane4 + j);
+              const int cur = dead[j] ? 0 : (int)((v[k] >> (8 * j)) & 0xffu);
+              seen_multi |= w[j].template step_brk<true>(cur, brk);
+            }
+          }
+        } else {  // line breaks only: no dead line, no run can exceed RS inside this group
+#pragma unroll
+          for (int k = 0; k < U; k++) {
+#pragma unroll
+            for (int j = 0; j < LPL; j++) {
+              const bool brk = uw[k] || (sb[k] == lane4 + j);
+              seen_multi |= w[j].template step_brk<false>((int)((v[k] >> (8 * j)) & 0xffu), brk);
+            }
           }
         }
       }
@@ -610,20 +623,29 @@ __global__ void __launch_bounds__(512) sweep_rows_kernel(const uint8_t *__restri
   flush_block_hist<DO_GLCM, DO_GLRLM, FUSED>(lds, h, Nr, slot, glcm_acc, glrlm_acc);
 }
 
-// ---- "does some line of angle a hold >= 2 masked voxels?" for the fused walker (cmatrices.c:524-534) -------
-// Cheap sufficient conditions from the finished histograms: a run longer than 1, or a pair of different levels.
-__global__ void __launch_bounds__(256) resolve_multi_kernel(const u32 *__restrict__ glcm_acc,
-                                                            const u32 *__restrict__ glrlm_acc, int Ng, int Nr,
-                                                            int *__restrict__ multi) {
-  const int a = blockIdx.x;
-  const u32 *racc = glrlm_acc + (size_t)a * Ng * Nr;
-  const u32 *gacc = glcm_acc + (size_t)a * Ng * Ng;
+// ---- fused mode post-pass: one wave per (level i, angle a) --------------------------------------------------
+//   GLCM diagonal  out[i][i][a] = sum_len (len-1) * GLRLM[a][i][len]     (pairs inside runs)
+//   multi[a]      |= some run of level i is longer than 1, or row i of the (off-diagonal) GLCM is not empty:
+//                    cheap sufficient conditions for "some line of angle a holds >= 2 masked voxels"
+//                    (cmatrices.c:524-534); multi_check_kernel settles the angles they leave open.
+__global__ void __launch_bounds__(64) glcm_diag_resolve_kernel(const u32 *__restrict__ glcm_acc,
+                                                               const u32 *__restrict__ glrlm_acc, int Ng, int Nr,
+                                                               int Na, double *__restrict__ glcm_out,
+                                                               int *__restrict__ multi) {
+  const int i = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
+  const u32 *row = glrlm_acc + ((size_t)a * Ng + i) * Nr;
+  unsigned long long pairs = 0;
   int found = 0;
-  for (int i = threadIdx.x; i < Ng * Nr; i += blockDim.x)
-    if ((i % Nr) != 0 && racc[i]) found = 1;
-  for (int i = threadIdx.x; i < Ng * Ng; i += blockDim.x)
-    if (gacc[i]) found = 1;  // fused accumulators hold off-diagonal pairs only
-  if (found) multi[a] = 1;
+  for (int r = lane; r < Nr; r += 64) {
+    const u32 v = row[r];
+    pairs += (unsigned long long)r * v;
+    found |= (r > 0 && v != 0);
+  }
+  const u32 *grow = glcm_acc + ((size_t)a * Ng + i) * Ng;
+  for (int j = lane; j < Ng; j += 64) found |= (grow[j] != 0);
+  for (int o = 32; o > 0; o >>= 1) pairs += __shfl_xor(pairs, o);
+  if (lane == 0) glcm_out[((size_t)i * Ng + i) * Na + a] = (double)pairs;
+  if (__ballot(found) != 0 && lane == 0) multi[a] = 1;
 }
 
 // Exact test for the angles the conditions above leave open (every masked voxel isolated along the angle):
@@ -657,7 +679,7 @@ __global__ void __launch_bounds__(256) multi_check_kernel(AngleSet A, const uint
   }
 }
 
-// acc (angle-major u32) -> reference layout float64.  diag_from_runs: GLCM[g][g] = sum_len (len-1)*GLRLM[g][len].
+// acc (angle-major u32) -> reference layout float64 (fused mode: off-diagonal entries only)
 __global__ void finalize_glcm_kernel(const u32 *__restrict__ acc, const u32 *__restrict__ glrlm_acc, int Ng, int Nr,
                                      int Na, int diag_from_runs, double *__restrict__ out) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -666,13 +688,7 @@ __global__ void finalize_glcm_kernel(const u32 *__restrict__ acc, const u32 *__r
   const int a = (int)(idx % Na);
   const long long ij = idx / Na;
   const int i = (int)(ij / Ng), j = (int)(ij - (long long)i * Ng);
-  if (diag_from_runs && i == j) {
-    const u32 *row = glrlm_acc + ((size_t)a * Ng + i) * Nr;
-    unsigned long long pairs = 0;
-    for (int r = 1; r < Nr; r++) pairs += (unsigned long long)r * row[r];
-    out[idx] = (double)pairs;
-    return;
-  }
+  if (diag_from_runs && i == j) return;  // written by glcm_diag_resolve_kernel
   out[idx] = (double)acc[(size_t)a * Ng * Ng + ij];
 }
 

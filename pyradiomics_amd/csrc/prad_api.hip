@@ -442,9 +442,10 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
       PRAD_TRY(check_launch("finalize_glcm_kernel"));
     }
     if (glrlm && p.fused) {
-      hipLaunchKernelGGL(resolve_multi_kernel, dim3(k.Na), dim3(256), 0, k.s, glcm_acc, glrlm_acc, Ng, Nr, multi);
-      PRAD_TRY(check_launch("resolve_multi_kernel"));
-      hipLaunchKernelGGL(multi_check_kernel, dim3(256, k.Na), dim3(256), 0, k.s, p.aset, levels, p.Nz, p.Ny, p.Nx,
+      hipLaunchKernelGGL(glcm_diag_resolve_kernel, dim3(Ng, k.Na), dim3(64), 0, k.s, glcm_acc, glrlm_acc, Ng, Nr, k.Na,
+                         glcm, multi);
+      PRAD_TRY(check_launch("glcm_diag_resolve_kernel"));
+      hipLaunchKernelGGL(multi_check_kernel, dim3(128, k.Na), dim3(256), 0, k.s, p.aset, levels, p.Nz, p.Ny, p.Nx,
                          p.pitch, multi);
       PRAD_TRY(check_launch("multi_check_kernel"));
     }

@@ -1,0 +1,238 @@
+"""Grey Level Co-occurrence Matrix features: interface and feature-name surface of the reference's
+radiomics/glcm.py (RadiomicsGLCM), with the matrix built on the MI355X through cMatrices.calculate_glcm.
+
+Conventions (glcm.py:113-258): P has shape (Nvox, Ngp, Ngp, Na) after dropping grey levels absent from the ROI
+(:149-152), adding the transpose when symmetricalGLCM (:155-157), optional distance weighting that collapses the
+angle axis (:160-182), dropping all-empty angles (:186-198) and per-angle normalisation (:201-203).  Every feature
+is evaluated per angle and averaged with nanmean (:260-887).  i / j are the ACTUAL level values of the kept rows;
+the sum / difference axes use the maximum level Ng, not the pruned count (:217-224)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .base import RadiomicsFeaturesBase, deprecated
+
+_EPS = np.spacing(1)
+
+
+def _weights(angles, spacing_zyx, norm, kind, logger):
+    """per-angle weights: GLCM uses exp(-d^2) (glcm.py:160-182), GLRLM uses the distance d itself
+    (glrlm.py:127-148), with d the infinity / euclidean / manhattan norm of the angle in mm"""
+    out = np.empty(len(angles))
+    for n, a in enumerate(angles):
+        step = np.abs(a) * spacing_zyx
+        if norm == "infinity":
+            d, d2 = max(step), max(step) ** 2
+        elif norm == "euclidean":
+            d2 = np.sum(step ** 2)
+            d = np.sqrt(d2)
+        elif norm == "manhattan":
+            d = np.sum(step)
+            d2 = d ** 2
+        elif norm == "no_weighting":
+            out[n] = 1
+            continue
+        else:
+            logger.warning('weigthing norm "%s" is unknown, W is set to 1', norm)
+            out[n] = 1
+            continue
+        out[n] = np.exp(-d2) if kind == "glcm" else d
+    return out
+
+
+class RadiomicsGLCM(RadiomicsFeaturesBase):
+    def __init__(self, inputImage, inputMask, **kwargs):
+        super().__init__(inputImage, inputMask, **kwargs)
+        self.symmetricalGLCM = kwargs.get("symmetricalGLCM", True)
+        self.weightingNorm = kwargs.get("weightingNorm")
+        self.P_glcm = None
+        self.imageArray = self._applyBinning(self.imageArray)
+
+    def _initCalculation(self, voxelCoordinates=None):
+        self.P_glcm = self._calculateMatrix(voxelCoordinates)
+        self._calculateCoefficients()
+
+    def _calculateMatrix(self, voxelCoordinates=None):
+        Ng = self.coefficients["Ng"]
+        args = [self.imageArray, self.maskArray, np.array(self.settings.get("distances", [1])), Ng,
+                self.settings.get("force2D", False), self.settings.get("force2Ddimension", 0)]
+        P, angles = self.cMatrices.calculate_glcm(*(args + self._matrix_tail(voxelCoordinates)))
+        keep = self.coefficients["grayLevels"] - 1
+        P = P[:, keep][:, :, keep]
+        if self.symmetricalGLCM:
+            P = P + P.transpose((0, 2, 1, 3))
+        if self.weightingNorm is not None:
+            w = _weights(angles, np.array(self.inputImage.GetSpacing()[::-1]), self.weightingNorm, "glcm",
+                         self.logger)
+            P = np.sum(P * w[None, None, None, :], 3, keepdims=True)
+        total = np.sum(P, (1, 2))
+        if P.shape[3] > 1:
+            empty = np.where(np.sum(total, 0) == 0)
+            if len(empty[0]) > 0:
+                P = np.delete(P, empty, 3)
+                total = np.delete(total, empty, 1)
+        total[total == 0] = np.nan
+        P /= total[:, None, None, :]
+        return P
+
+    def _calculateCoefficients(self):
+        P = self.P_glcm
+        Ng = self.coefficients["Ng"]
+        levels = self.coefficients["grayLevels"].astype("float")
+        i, j = np.meshgrid(levels, levels, indexing="ij", sparse=True)
+        kSum = np.arange(2, 2 * Ng + 1, dtype="float")
+        kDiff = np.arange(0, Ng, dtype="float")
+        c = self.coefficients
+        c["eps"] = _EPS
+        c["i"], c["j"] = i, j
+        c["kValuesSum"], c["kValuesDiff"] = kSum, kDiff
+        c["px"] = P.sum(2, keepdims=True)
+        c["py"] = P.sum(1, keepdims=True)
+        c["ux"] = np.sum(i[None, :, :, None] * P, (1, 2), keepdims=True)
+        c["uy"] = np.sum(j[None, :, :, None] * P, (1, 2), keepdims=True)
+        c["pxAddy"] = np.array([np.sum(P[:, i + j == k, :], 1) for k in kSum]).transpose((1, 0, 2))
+        c["pxSuby"] = np.array([np.sum(P[:, np.abs(i - j) == k, :], 1) for k in kDiff]).transpose((1, 0, 2))
+        c["HXY"] = (-1) * np.sum(P * np.log2(P + _EPS), (1, 2))
+
+    # -- helpers ---------------------------------------------------------------------------------------
+    def _centred(self, power):
+        c = self.coefficients
+        dev = (c["i"] + c["j"])[None, :, :, None] - c["ux"] - c["uy"]
+        return np.nanmean(np.sum(self.P_glcm * dev ** power, (1, 2)), 1)
+
+    def _diff_weighted(self, denom):
+        return np.nanmean(np.sum(self.coefficients["pxSuby"] / denom[None, :, None], 1), 1)
+
+    # -- features (glcm.py:260-887) --------------------------------------------------------------------
+    def getAutocorrelationFeatureValue(self):
+        c = self.coefficients
+        return np.nanmean(np.sum(self.P_glcm * (c["i"] * c["j"])[None, :, :, None], (1, 2)), 1)
+
+    def getJointAverageFeatureValue(self):
+        return self.coefficients["ux"].mean((1, 2, 3))
+
+    def getClusterProminenceFeatureValue(self):
+        return self._centred(4)
+
+    def getClusterShadeFeatureValue(self):
+        return self._centred(3)
+
+    def getClusterTendencyFeatureValue(self):
+        return self._centred(2)
+
+    def getContrastFeatureValue(self):
+        c = self.coefficients
+        return np.nanmean(np.sum(self.P_glcm * (np.abs(c["i"] - c["j"]))[None, :, :, None] ** 2, (1, 2)), 1)
+
+    def getCorrelationFeatureValue(self):
+        c = self.coefficients
+        P = self.P_glcm
+        di = c["i"][None, :, :, None] - c["ux"]
+        dj = c["j"][None, :, :, None] - c["uy"]
+        sigx = np.sum(P * di ** 2, (1, 2), keepdims=True) ** 0.5
+        sigy = np.sum(P * dj ** 2, (1, 2), keepdims=True) ** 0.5
+        corr = np.sum(P * di * dj, (1, 2), keepdims=True) / (sigx * sigy + _EPS)
+        corr[sigx * sigy == 0] = 1
+        return np.nanmean(corr, (1, 2, 3))
+
+    def getDifferenceAverageFeatureValue(self):
+        c = self.coefficients
+        return np.nanmean(np.sum(c["kValuesDiff"][None, :, None] * c["pxSuby"], 1), 1)
+
+    def getDifferenceEntropyFeatureValue(self):
+        p = self.coefficients["pxSuby"]
+        return np.nanmean((-1) * np.sum(p * np.log2(p + _EPS), 1), 1)
+
+    def getDifferenceVarianceFeatureValue(self):
+        c = self.coefficients
+        k = c["kValuesDiff"][None, :, None]
+        mean = np.sum(k * c["pxSuby"], 1, keepdims=True)
+        return np.nanmean(np.sum(c["pxSuby"] * (k - mean) ** 2, 1), 1)
+
+    @deprecated
+    def getDissimilarityFeatureValue(self):
+        raise DeprecationWarning("GLCM - Dissimilarity is mathematically equal to GLCM - Difference Average")
+
+    def getJointEnergyFeatureValue(self):
+        return np.nanmean(np.sum(self.P_glcm ** 2, (1, 2)), 1)
+
+    def getJointEntropyFeatureValue(self):
+        return np.nanmean(self.coefficients["HXY"], 1)
+
+    @deprecated
+    def getHomogeneity1FeatureValue(self):
+        raise DeprecationWarning("GLCM - Homogeneity 1 is mathematically equal to GLCM - Inverse Difference")
+
+    @deprecated
+    def getHomogeneity2FeatureValue(self):
+        raise DeprecationWarning("GLCM - Homogeneity 2 is mathematically equal to GLCM - Inverse Difference Moment")
+
+    def getImc1FeatureValue(self):
+        c = self.coefficients
+        px, py = c["px"], c["py"]
+        HX = (-1) * np.sum(px * np.log2(px + _EPS), (1, 2))
+        HY = (-1) * np.sum(py * np.log2(py + _EPS), (1, 2))
+        HXY1 = (-1) * np.sum(self.P_glcm * np.log2(px * py + _EPS), (1, 2))
+        div = np.fmax(HX, HY)
+        imc1 = c["HXY"] - HXY1
+        imc1[div != 0] /= div[div != 0]
+        imc1[div == 0] = 0
+        return np.nanmean(imc1, 1)
+
+    def getImc2FeatureValue(self):
+        c = self.coefficients
+        pxy = c["px"] * c["py"]
+        HXY2 = (-1) * np.sum(pxy * np.log2(pxy + _EPS), (1, 2))
+        imc2 = (1 - np.e ** (-2 * (HXY2 - c["HXY"]))) ** 0.5
+        imc2[HXY2 == c["HXY"]] = 0
+        return np.nanmean(imc2, 1)
+
+    def getIdmFeatureValue(self):
+        return self._diff_weighted(1 + self.coefficients["kValuesDiff"] ** 2)
+
+    def getMCCFeatureValue(self):
+        # Q(i,j) = sum_k P(i,k) P(j,k) / (px(i) py(k) + eps); second largest eigenvalue (glcm.py:665-707)
+        c = self.coefficients
+        P, px, py = self.P_glcm, c["px"], c["py"]
+        Q = np.zeros((P.shape[0], P.shape[1], P.shape[1], P.shape[3]))
+        for k in range(P.shape[1]):
+            Q += (P[:, :, None, k, :] * P[:, None, :, k, :]) / (px[:, :, None, 0, :] * py[:, None, :, k, :] + _EPS)
+        ev = np.linalg.eigvals(Q.transpose((0, 3, 1, 2)))
+        ev.sort()
+        if ev.shape[2] < 2:
+            return 1
+        return np.nanmean(np.sqrt(ev[:, :, -2]), 1).real
+
+    def getIdmnFeatureValue(self):
+        c = self.coefficients
+        return self._diff_weighted(1 + (c["kValuesDiff"] ** 2) / (c["Ng"] ** 2))
+
+    def getIdFeatureValue(self):
+        return self._diff_weighted(1 + self.coefficients["kValuesDiff"])
+
+    def getIdnFeatureValue(self):
+        c = self.coefficients
+        return self._diff_weighted(1 + c["kValuesDiff"] / c["Ng"])
+
+    def getInverseVarianceFeatureValue(self):
+        c = self.coefficients
+        return np.nanmean(np.sum(c["pxSuby"][:, 1:, :] / c["kValuesDiff"][None, 1:, None] ** 2, 1), 1)
+
+    def getMaximumProbabilityFeatureValue(self):
+        return np.nanmean(np.amax(self.P_glcm, (1, 2)), 1)
+
+    def getSumAverageFeatureValue(self):
+        c = self.coefficients
+        return np.nanmean(np.sum(c["kValuesSum"][None, :, None] * c["pxAddy"], 1), 1)
+
+    @deprecated
+    def getSumVarianceFeatureValue(self):
+        raise DeprecationWarning("GLCM - Sum Variance is mathematically equal to GLCM - Cluster Tendency")
+
+    def getSumEntropyFeatureValue(self):
+        p = self.coefficients["pxAddy"]
+        return np.nanmean((-1) * np.sum(p * np.log2(p + _EPS), 1), 1)
+
+    def getSumSquaresFeatureValue(self):
+        c = self.coefficients
+        return np.nanmean(np.sum(self.P_glcm * (c["i"][None, :, :, None] - c["ux"]) ** 2, (1, 2)), 1)

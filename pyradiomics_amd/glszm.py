@@ -1,0 +1,146 @@
+"""Grey Level Size Zone Matrix features: interface and feature-name surface of the reference's radiomics/glszm.py
+(RadiomicsGLSZM), matrix built on the MI355X through cMatrices.calculate_glszm.
+
+P has shape (Nvox, Ngp, Ns'): absent grey levels dropped (glszm.py:99-106), zone sizes that never occur dropped
+(:123-126).  Nz = zones, Np = voxels in zones, both forced to 1 when empty (:117-121).  No angle axis."""
+from __future__ import annotations
+
+import numpy as np
+
+from .base import RadiomicsFeaturesBase
+
+_EPS = np.spacing(1)
+
+
+class _ZoneLikeFeatures(RadiomicsFeaturesBase):
+    """the feature pattern shared by GLSZM and GLDM: a (Nvox, level, size) count matrix P with marginals
+    pg (per level) and ps (per size / dependence), Nz = sum(P)"""
+
+    def _P(self):
+        raise NotImplementedError
+
+    def _iw(self):
+        return self.coefficients["ivector"][None, :, None]
+
+    def _jw(self):
+        return self.coefficients["jvector"][None, None, :]
+
+    def _over_sizes(self, weight):      # sum_j ps * weight / Nz
+        c = self.coefficients
+        return np.sum(c["ps"] * weight[None, :], 1) / c["Nz"]
+
+    def _over_levels(self, weight):
+        c = self.coefficients
+        return np.sum(c["pg"] * weight[None, :], 1) / c["Nz"]
+
+    def _level_variance(self):
+        c = self.coefficients
+        i = c["ivector"][None, :]
+        pg = c["pg"] / c["Nz"][:, None]
+        u = np.sum(pg * i, 1, keepdims=True)
+        return np.sum(pg * (i - u) ** 2, 1)
+
+    def _size_variance(self):
+        c = self.coefficients
+        j = c["jvector"][None, :]
+        ps = c["ps"] / c["Nz"][:, None]
+        u = np.sum(ps * j, 1, keepdims=True)
+        return np.sum(ps * (j - u) ** 2, 1)
+
+    def _entropy(self):
+        p = self._P() / self.coefficients["Nz"][:, None, None]
+        return -np.sum(p * np.log2(p + _EPS), (1, 2))
+
+
+class RadiomicsGLSZM(_ZoneLikeFeatures):
+    def __init__(self, inputImage, inputMask, **kwargs):
+        super().__init__(inputImage, inputMask, **kwargs)
+        self.P_glszm = None
+        self.imageArray = self._applyBinning(self.imageArray)
+
+    def _P(self):
+        return self.P_glszm
+
+    def _initCalculation(self, voxelCoordinates=None):
+        self.P_glszm = self._calculateMatrix(voxelCoordinates)
+        self._calculateCoefficients()
+
+    def _calculateMatrix(self, voxelCoordinates=None):
+        Ng = self.coefficients["Ng"]
+        Ns = np.sum(self.maskArray)
+        args = [self.imageArray, self.maskArray, Ng, Ns, self.settings.get("force2D", False),
+                self.settings.get("force2Ddimension", 0)]
+        P = self.cMatrices.calculate_glszm(*(args + self._matrix_tail(voxelCoordinates)))
+        return np.delete(P, self._absent_levels(), 1)
+
+    def _calculateCoefficients(self):
+        P = self.P_glszm
+        ps = np.sum(P, 1)
+        pg = np.sum(P, 2)
+        j = np.arange(1, P.shape[2] + 1, dtype=np.float64)
+        Nz = np.sum(P, (1, 2))
+        Nz[Nz == 0] = 1
+        Np = np.sum(ps * j[None, :], 1)
+        Np[Np == 0] = 1
+        unused = np.where(np.sum(ps, 0) == 0)
+        self.P_glszm = np.delete(P, unused, 2)
+        c = self.coefficients
+        c["Np"], c["Nz"] = Np, Nz
+        c["ps"] = np.delete(ps, unused, 1)
+        c["pg"] = pg
+        c["ivector"] = c["grayLevels"].astype(float)
+        c["jvector"] = np.delete(j, unused)
+
+    def getSmallAreaEmphasisFeatureValue(self):
+        c = self.coefficients
+        return np.sum(c["ps"] / (c["jvector"][None, :] ** 2), 1) / c["Nz"]
+
+    def getLargeAreaEmphasisFeatureValue(self):
+        return self._over_sizes(self.coefficients["jvector"] ** 2)
+
+    def getGrayLevelNonUniformityFeatureValue(self):
+        c = self.coefficients
+        return np.sum(c["pg"] ** 2, 1) / c["Nz"]
+
+    def getGrayLevelNonUniformityNormalizedFeatureValue(self):
+        c = self.coefficients
+        return np.sum(c["pg"] ** 2, 1) / c["Nz"] ** 2
+
+    def getSizeZoneNonUniformityFeatureValue(self):
+        c = self.coefficients
+        return np.sum(c["ps"] ** 2, 1) / c["Nz"]
+
+    def getSizeZoneNonUniformityNormalizedFeatureValue(self):
+        c = self.coefficients
+        return np.sum(c["ps"] ** 2, 1) / c["Nz"] ** 2
+
+    def getZonePercentageFeatureValue(self):
+        return self.coefficients["Nz"] / self.coefficients["Np"]
+
+    def getGrayLevelVarianceFeatureValue(self):
+        return self._level_variance()
+
+    def getZoneVarianceFeatureValue(self):
+        return self._size_variance()
+
+    def getZoneEntropyFeatureValue(self):
+        return self._entropy()
+
+    def getLowGrayLevelZoneEmphasisFeatureValue(self):
+        c = self.coefficients
+        return np.sum(c["pg"] / (c["ivector"][None, :] ** 2), 1) / c["Nz"]
+
+    def getHighGrayLevelZoneEmphasisFeatureValue(self):
+        return self._over_levels(self.coefficients["ivector"] ** 2)
+
+    def getSmallAreaLowGrayLevelEmphasisFeatureValue(self):
+        return np.sum(self.P_glszm / ((self._iw() ** 2) * (self._jw() ** 2)), (1, 2)) / self.coefficients["Nz"]
+
+    def getSmallAreaHighGrayLevelEmphasisFeatureValue(self):
+        return np.sum(self.P_glszm * (self._iw() ** 2) / (self._jw() ** 2), (1, 2)) / self.coefficients["Nz"]
+
+    def getLargeAreaLowGrayLevelEmphasisFeatureValue(self):
+        return np.sum(self.P_glszm * (self._jw() ** 2) / (self._iw() ** 2), (1, 2)) / self.coefficients["Nz"]
+
+    def getLargeAreaHighGrayLevelEmphasisFeatureValue(self):
+        return np.sum(self.P_glszm * (self._iw() ** 2) * (self._jw() ** 2), (1, 2)) / self.coefficients["Nz"]
