@@ -76,3 +76,37 @@ def cropToTumorMask(image, mask, label=1, padDistance=0):
     origin = tuple(np.array(img.origin) + shift)
     return (Image(img.array[sl], img.spacing, origin, img.direction),
             Image(msk.array[sl], msk.spacing, origin, msk.direction))
+
+
+def resegmentMask(image, mask, **kwargs):
+    """Restricts the ROI to voxels whose intensity lies in `resegmentRange` (1 threshold: >= T; 2: closed range),
+    with the thresholds absolute, relative to the ROI maximum, or in standard deviations around the ROI mean
+    (imageoperations.py:533-640).  Returns a new mask Image holding `label` inside the kept ROI."""
+    rng = kwargs["resegmentRange"]
+    mode = kwargs.get("resegmentMode", "absolute")
+    label = kwargs.get("label", 1)
+    if rng is None:
+        raise ValueError("resegmentRange is None.")
+    if len(rng) == 0 or len(rng) > 2:
+        raise ValueError("Length %d is not allowed for resegmentRange" % len(rng))
+    im = as_array(image)
+    roi = as_array(mask) == label
+    if mode == "absolute":
+        thr = sorted(rng)
+    elif mode == "relative":
+        top = np.max(im[roi])
+        thr = [top * t for t in sorted(rng)]
+    elif mode == "sigma":
+        mu, sd = np.mean(im[roi]), np.std(im[roi])
+        thr = [mu + sd * t for t in sorted(rng)]
+    else:
+        raise ValueError("Resegment mode %s not recognized." % mode)
+    roi[roi] = im[roi] >= thr[0]
+    if len(thr) == 2:
+        roi[roi] = im[roi] <= thr[1]
+    if np.sum(roi) <= 1:
+        raise ValueError("Resegmentation excluded too many voxels with label %s (retained %d voxel(s))! "
+                         "Cannot extract features" % (label, np.sum(roi)))
+    out = np.zeros(roi.shape, dtype="int")
+    out[roi] = label
+    return mask.like(out) if isinstance(mask, Image) else Image(out)
