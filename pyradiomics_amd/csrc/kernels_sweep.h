@@ -155,6 +155,14 @@ __host__ __device__ inline HistLayout hist_layout(bool glcm, bool glrlm, bool fu
   return h;
 }
 
+// cond ? a : b as ONE v_cndmask: both operands are pinned in VGPRs first, otherwise hipcc sinks their computation
+// into a divergent if/else (s_and_saveexec / s_xor / s_andn2_saveexec / s_or: 4 scalar ops + a second compare per
+// voxel-step, which made the scalar unit the bottleneck of the sweeps)
+__device__ __forceinline__ int select_i32(bool cond, int a, int b) {
+  asm volatile("" : "+v"(a), "+v"(b));
+  return cond ? a : b;
+}
+
 typedef __attribute__((address_space(3))) u32 lds_u32;
 __device__ __forceinline__ void lds_bump(int lds_addr) {  // bare ds_add_u32 on a 32-bit LDS byte address
 #ifdef PRAD_DBG_NOBUMP  // ablation build: keep the address computation alive, drop the LDS atomic
@@ -214,7 +222,7 @@ struct Walker {
       } else {
         lds_bump(emit ? rlN + (prev << 2) : dummy);
       }
-      rlN = chg ? Ng4 + cR : rlN + Ng4;
+      rlN = select_i32(chg, Ng4 + cR, rlN + Ng4);
       nmask += cnz;
     }
     prev = cur;
@@ -279,7 +287,7 @@ struct Walker<true, true, LONG, true> {
       if (chg && prev != 0 && lb >= lenmax) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + lb / Q], 1u);
     }
     lds_bump(chg ? bin + (cur << 2) : dummy);
-    pl = chg ? __mul24(cur, P) + cB : pl + Q;
+    pl = select_i32(chg, __mul24(cur, P) + cB, pl + Q);
     prev = cur;
   }
   __device__ __forceinline__ bool end_line() {
@@ -298,7 +306,7 @@ struct Walker<true, true, LONG, true> {
       if (chg && prev != 0 && lb >= lenmax) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + lb / Q], 1u);
     }
     lds_bump(chg ? bin + (evt << 2) : dummy);
-    pl = chg ? __mul24(cur, P) + cB : pl + Q;
+    pl = select_i32(chg, __mul24(cur, P) + cB, pl + Q);
     prev = cur;
     return false;
   }
