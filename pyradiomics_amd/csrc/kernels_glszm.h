@@ -53,9 +53,16 @@ __global__ void glszm_init_kernel(const uint8_t *__restrict__ mask, long long n,
   }
 }
 
-__device__ __forceinline__ int uf_find(const int *labels, int i) {
-  int p;
-  while ((p = __builtin_nontemporal_load(labels + i)) != i) i = p;
+// find with path halving.  Labels only ever decrease towards the root, so a racing / stale view at worst repeats
+// a hop; writing the grandparent is always a valid shortcut (it is an ancestor).
+__device__ __forceinline__ int uf_find(int *labels, int i) {
+  int p = __builtin_nontemporal_load(labels + i);
+  while (p != i) {
+    const int g = __builtin_nontemporal_load(labels + p);
+    if (g != p) labels[i] = g;
+    i = p;
+    p = g;
+  }
   return i;
 }
 
@@ -99,16 +106,34 @@ __global__ void __launch_bounds__(256) glszm_merge_kernel(Geo g, const int *__re
   }
 }
 
-__global__ void glszm_flatten_count_kernel(long long n, int *__restrict__ labels, unsigned *__restrict__ sizes) {
+// label[i] = root(i) and size[root] += 1.  x-adjacent voxels usually share a root, so each wave first collapses
+// runs of equal roots among its lanes and issues one atomic per run instead of one per voxel.
+__global__ void __launch_bounds__(256) glszm_flatten_count_kernel(long long n, int *__restrict__ labels,
+                                                                   unsigned *__restrict__ sizes) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    int l = labels[i];
-    if (l < 0) continue;
-    int r = l;
-    int p;
-    while ((p = labels[r]) != r) r = p;
-    if (r != l) labels[i] = r;
-    atomicAdd(sizes + r, 1u);
+  const int lane = threadIdx.x & 63;
+  const long long nround = ((n + stride - 1) / stride) * stride;  // keep whole waves in the loop for the shuffles
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
+    int r = -1;
+    if (i < n) {
+      const int l = labels[i];
+      if (l >= 0) {
+        r = l;
+        int p;
+        while ((p = labels[r]) != r) r = p;
+        if (r != l) labels[i] = r;
+      }
+    }
+    int left = __shfl_up(r, 1);
+    if (lane == 0) left = -2;
+    const bool head = (r >= 0) && (r != left);
+    const bool brk = (r != left) || lane == 0;          // a run (of any value) starts here
+    const unsigned long long B = __ballot(brk);
+    if (head) {
+      const unsigned long long above = lane == 63 ? 0ull : (B >> (lane + 1));
+      const int len = above ? __ffsll((long long)above) : 64 - lane;  // distance to the next run start
+      atomicAdd(sizes + r, (unsigned)len);
+    }
   }
 }
 

@@ -74,3 +74,60 @@ def last_kernel_ms(family: str | None = None) -> float:
 
 def last_path() -> str:
     return _lib.last_path()
+
+
+def _neigh_common(image, mask, distances, force2D, force2Ddimension):
+    lib, image, mask, size = _prep(image, mask)
+    f2d = int(force2Ddimension) if force2D else -1
+    angles = _build_angles(size, distances, True, f2d)
+    return lib, image, mask, size, f2d, angles
+
+
+def gldm(image: torch.Tensor, mask: torch.Tensor, Ng: int, alpha: int = 0, distances=(1,), force2D: bool = False,
+         force2Ddimension: int = 0) -> torch.Tensor:
+    """GLDM [Ng, 2*Na+1] float64 on the device (segment mode)."""
+    lib, image, mask, size, f2d, angles = _neigh_common(image, mask, list(distances), force2D, force2Ddimension)
+    Na, Nd = angles.shape
+    out = torch.empty((Ng, 2 * Na + 1), dtype=torch.float64, device=image.device)
+    rc = lib.prad_calculate_gldm_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
+                                     _iptr(angles), Na, int(Ng), int(alpha), 1, None, 0, f2d,
+                                     C.c_void_p(out.data_ptr()), _stream_ptr())
+    _lib.raise_for(rc, "GLDM")
+    return out
+
+
+def ngtdm(image: torch.Tensor, mask: torch.Tensor, Ng: int, distances=(1,), force2D: bool = False,
+          force2Ddimension: int = 0) -> torch.Tensor:
+    """NGTDM [Ng, 3] float64 on the device (segment mode)."""
+    lib, image, mask, size, f2d, angles = _neigh_common(image, mask, list(distances), force2D, force2Ddimension)
+    Na, Nd = angles.shape
+    out = torch.empty((Ng, 3), dtype=torch.float64, device=image.device)
+    rc = lib.prad_calculate_ngtdm_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
+                                      _iptr(angles), Na, int(Ng), 1, None, 0, f2d, C.c_void_p(out.data_ptr()),
+                                      _stream_ptr())
+    _lib.raise_for(rc, "NGTDM")
+    return out
+
+
+def glszm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Ns: int | None = None, force2D: bool = False,
+          force2Ddimension: int = 0) -> torch.Tensor:
+    """GLSZM [Ng, maxRegion] float64 on the device (segment mode); Ns defaults to the number of masked voxels."""
+    lib, image, mask, size, f2d, angles = _neigh_common(image, mask, None, force2D, force2Ddimension)
+    Na, Nd = angles.shape
+    if Ns is None:
+        Ns = int(mask.sum().item())
+    nz = C.c_longlong(0)
+    rc = lib.prad_calculate_glszm_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
+                                      _iptr(angles), Na, int(Ng), int(Ns), 1, None, 0, f2d, C.byref(nz),
+                                      _stream_ptr())
+    if rc == _lib.PRAD_E_INDEX:
+        raise IndexError("Calculation of GLSZM Failed.")
+    if rc < 0:
+        _lib.raise_for(rc, "GLSZM")
+    maxRegion = max(int(rc), 1)
+    out = torch.empty((Ng, maxRegion), dtype=torch.float64, device=image.device)
+    rc = lib.prad_fill_glszm_dev(C.c_void_p(out.data_ptr()), 1, int(Ng), maxRegion, _stream_ptr())
+    if rc == _lib.PRAD_INDEX_ERROR:
+        raise IndexError("Error filling GLSZM.")
+    _lib.raise_for(rc, "GLSZM")
+    return out
