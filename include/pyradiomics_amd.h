@@ -152,6 +152,28 @@ int prad_fill_glszm_dev(double *glszm, int Nvox, int Ng, int maxRegion, void *st
  * tempData must hold 2*nzones_v+1 ints; returns nzones_v or PRAD_E_*. */
 long long prad_glszm_zones(int v, int *tempData, long long capacity_pairs);
 
+/* ---- filter stack in front of the matrices (radiomics/imageoperations.py:756-970) ---------------------------
+ * The arithmetic of both filters lives in third-party wheels (PyWavelets, SimpleITK/ITK) that are not part of
+ * the reference tree; these entry points implement their published algorithms (see oracle/filters_oracle.py):
+ * parity with those wheels is UNPINNED.
+ *
+ * prad_swt_level1: one level of the undecimated (stationary) wavelet transform with periodisation along `axes`
+ * (in that order), i.e. pywt.swtn(data, wavelet, level=1, start_level=0, axes) (imageoperations.py:928,935).
+ *   in   float64 [size[0]]..[size[Nd-1]], every transformed axis of even length
+ *   out  float64 [2^naxes][...]: sub-bands in PyWavelets' key order ('a' = dec_lo before 'd' = dec_hi, the first
+ *        axis of `axes` is the most significant letter): aaa, aad, ada, add, daa, dad, dda, ddd for 3 axes.
+ * prad_log: ITK LaplacianRecursiveGaussianImageFilter (imageoperations.py:824-830): float32 in / out,
+ *   `spacing` per ARRAY axis (i.e. SimpleITK spacing reversed), sigma in the units of spacing,
+ *   normalize != 0 multiplies by sigma^2 (NormalizeAcrossScale).  Every axis needs >= 4 samples. */
+int prad_swt_level1(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi, int flen,
+                    const int *axes, int naxes, double *out);
+int prad_swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi,
+                        int flen, const int *axes, int naxes, double *out, void *stream);
+int prad_log(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
+             float *out);
+int prad_log_dev(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
+                 float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,130 @@
+// kernels_filters.h -- the filter stack in front of the texture matrices,
+// HBM-bound separable 1-D passes.
+//
+//   swt_axis_kernel      one level-1 undecimated, periodised analysis step along one axis:
+//                        lo[o] = sum_k dec_lo[k] * x[(o + F/2 - k) mod N],  hi likewise   (float64, taps in
+//                        ascending k, unfused multiply/add so that rounding follows the CPU restatement of
+//                        PyWavelets' downsampling_convolution_periodization; imageoperations.py:921-935)
+//   rgauss_line_kernel   ITK RecursiveGaussianImageFilter along one axis: one lane per line, 4th-order causal +
+//                        anti-causal recursion with edge-replicating boundary initialisation, float64 inside the
+//                        line, float32 images between passes (imageoperations.py:824-830)
+//   log_accumulate_kernel  Laplacian accumulation  acc += d2 / spacing^2
+// Arithmetic of both filters lives in third-party wheels absent from the reference tree: parity unpinned.
+#pragma once
+#include "prad_runtime.h"
+
+namespace prad {
+
+#define PRAD_MAX_TAPS 32
+struct FilterTaps {
+  int F;
+  double lo[PRAD_MAX_TAPS];
+  double hi[PRAD_MAX_TAPS];
+};
+
+// x viewed as [outer][N][inner] (inner = stride of the filtered axis); one lane per element
+__global__ void __launch_bounds__(256) swt_axis_kernel(const double *__restrict__ x, long long outer, int N,
+                                                       long long inner, FilterTaps T, double *__restrict__ lo,
+                                                       double *__restrict__ hi) {
+  const long long total = outer * N * inner;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int half = T.F / 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long long in_ = i % inner;
+    const long long r = i / inner;
+    const int o = (int)(r % N);
+    const long long base = (r / N) * N * inner + in_;
+    double sl = 0.0, sh = 0.0;
+    for (int k = 0; k < T.F; k++) {
+      int p = o + half - k;
+      p %= N;
+      if (p < 0) p += N;
+      const double v = x[base + (long long)p * inner];
+      sl = __dadd_rn(sl, __dmul_rn(T.lo[k], v));
+      sh = __dadd_rn(sh, __dmul_rn(T.hi[k], v));
+    }
+    lo[i] = sl;
+    hi[i] = sh;
+  }
+}
+
+struct RGaussCoef {
+  double N0, N1, N2, N3, D1, D2, D3, D4, M1, M2, M3, M4, BN1, BN2, BN3, BN4, BM1, BM2, BM3, BM4;
+};
+
+// data viewed as [outer][ln][inner]; lane = (outer index, inner index); scratch holds the causal pass in float64
+__global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restrict__ in, long long outer, int ln,
+                                                          long long inner, RGaussCoef c,
+                                                          double *__restrict__ scratch, float *__restrict__ out) {
+#pragma clang fp contract(off)  // ITK's line arithmetic is plain multiply / add; keep the same roundings
+  const long long lines = outer * inner;
+  const long long line = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (line >= lines) return;
+  const long long base = (line / inner) * ln * inner + (line % inner);
+  const float *d = in + base;
+  double *s = scratch + base;
+  float *o = out + base;
+  const long long st = inner;
+  // causal pass (itkRecursiveSeparableImageFilter.hxx FilterDataArray)
+  const double v1 = d[0];
+  double x1 = d[1 * st], x2 = d[2 * st], x3 = d[3 * st];
+  double s0 = v1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+  double s1 = x1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+  double s2 = x2 * c.N0 + x1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+  double s3 = x3 * c.N0 + x2 * c.N1 + x1 * c.N2 + v1 * c.N3;
+  s0 -= v1 * c.BN1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
+  s1 -= s0 * c.D1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
+  s2 -= s1 * c.D1 + s0 * c.D2 + v1 * c.BN3 + v1 * c.BN4;
+  s3 -= s2 * c.D1 + s1 * c.D2 + s0 * c.D3 + v1 * c.BN4;
+  s[0] = s0; s[st] = s1; s[2 * st] = s2; s[3 * st] = s3;
+  {
+    double dm1 = x3, dm2 = x2, dm3 = x1;       // data[i-1], [i-2], [i-3]
+    double p1 = s3, p2 = s2, p3 = s1, p4 = s0; // scratch[i-1..i-4]
+    for (int i = 4; i < ln; i++) {
+      const double di = d[(long long)i * st];
+      double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
+      v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
+      s[(long long)i * st] = v;
+      dm3 = dm2; dm2 = dm1; dm1 = di;
+      p4 = p3; p3 = p2; p2 = p1; p1 = v;
+    }
+  }
+  // anti-causal pass
+  const double v2 = d[(long long)(ln - 1) * st];
+  const double y1 = d[(long long)(ln - 2) * st], y2 = d[(long long)(ln - 3) * st];
+  double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-1
+  double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-2: data[ln-1] = v2
+  double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-3
+  double a4 = y2 * c.M1 + y1 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-4
+  a1 -= v2 * c.BM1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+  a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+  a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
+  a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
+  o[(long long)(ln - 1) * st] = (float)(s[(long long)(ln - 1) * st] + a1);
+  o[(long long)(ln - 2) * st] = (float)(s[(long long)(ln - 2) * st] + a2);
+  o[(long long)(ln - 3) * st] = (float)(s[(long long)(ln - 3) * st] + a3);
+  o[(long long)(ln - 4) * st] = (float)(s[(long long)(ln - 4) * st] + a4);
+  {
+    // scratch[i-1] = data[i]*M1 + data[i+1]*M2 + data[i+2]*M3 + data[i+3]*M4 - (scratch[i]*D1 + ... + scratch[i+3]*D4)
+    double dp0 = d[(long long)(ln - 4) * st], dp1 = y2, dp2 = y1, dp3 = v2;  // data[i], [i+1], [i+2], [i+3] at i = ln-4
+    double q0 = a4, q1 = a3, q2 = a2, q3 = a1;                              // scratch[i], [i+1], [i+2], [i+3]
+    for (int i = ln - 4; i > 0; i--) {
+      double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
+      v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
+      o[(long long)(i - 1) * st] = (float)(s[(long long)(i - 1) * st] + v);
+      dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = d[(long long)(i - 1) * st];
+      q3 = q2; q2 = q1; q1 = q0; q0 = v;
+    }
+  }
+}
+
+__global__ void log_accumulate_kernel(float *__restrict__ acc, const float *__restrict__ cur, long long n,
+                                      double spacing2, int first) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const double a = first ? 0.0 : (double)acc[i];
+    acc[i] = (float)(a + (double)cur[i] / spacing2);
+  }
+}
+
+}  // namespace prad

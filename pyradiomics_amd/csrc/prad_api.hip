@@ -13,8 +13,10 @@
 #include "kernels_sweep.h"
 #include "kernels_neigh.h"
 #include "kernels_glszm.h"
+#include "kernels_filters.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 using namespace prad;
@@ -581,6 +583,173 @@ int copy_back(Context &c, double *host, const double *dev, size_t count) {
   return PRAD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// filters
+// ------------------------------------------------------------------------------------------------
+int swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi, int flen,
+                   const int *axes, int naxes, double *out, hipStream_t s) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Geo g;
+  PRAD_TRY(make_geo(size, Nd, &g));
+  if (!in || !out || !dec_lo || !dec_hi || !axes) return fail(PRAD_E_ARG, "swt: NULL pointer");
+  if (flen < 2 || flen > PRAD_MAX_TAPS) return fail(PRAD_E_ARG, "swt: filter length %d outside [2,%d]", flen, PRAD_MAX_TAPS);
+  if (naxes < 1 || naxes > Nd) return fail(PRAD_E_ARG, "swt: naxes=%d", naxes);
+  FilterTaps T;
+  T.F = flen;
+  for (int k = 0; k < flen; k++) { T.lo[k] = dec_lo[k]; T.hi[k] = dec_hi[k]; }
+  for (int a = 0; a < naxes; a++) {
+    if (axes[a] < 0 || axes[a] >= Nd) return fail(PRAD_E_ARG, "swt: axis %d out of range", axes[a]);
+    if (g.size[axes[a]] % 2) return fail(PRAD_E_ARG, "swt: axis %d has odd length %d (pad first, imageoperations.py:914-919)", axes[a], g.size[axes[a]]);
+  }
+  PRAD_TRY(c.begin_call(s));
+  // stage k holds 2^k arrays; stages alternate between two workspaces, the last stage writes `out`
+  double *ws[2] = {nullptr, nullptr};
+  const size_t n = (size_t)g.n;
+  if (naxes >= 2) PRAD_TRY(c.get<double>("swt_a", n * ((size_t)1 << (naxes - 1)), &ws[0]));
+  if (naxes >= 3) PRAD_TRY(c.get<double>("swt_b", n * ((size_t)1 << (naxes - 2)), &ws[1]));
+  const double *src = in;
+  {
+    Timed t(c, "swt", s);
+    for (int a = 0; a < naxes; a++) {
+      const int count = 1 << a;
+      double *dst = (a == naxes - 1) ? out : ws[(naxes - 2 - a) & 1];
+      const int ax = axes[a];
+      long long outer = 1;
+      for (int d = 0; d < ax; d++) outer *= g.size[d];
+      const long long inner = g.stride[ax];
+      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((g.n + 255) / 256, 8192));
+      for (int j = 0; j < count; j++) {
+        hipLaunchKernelGGL(swt_axis_kernel, dim3(gx), dim3(256), 0, s, src + (size_t)j * n, outer, g.size[ax], inner, T,
+                           dst + (size_t)(2 * j) * n, dst + (size_t)(2 * j + 1) * n);
+        PRAD_TRY(check_launch("swt_axis_kernel"));
+      }
+      src = dst;
+    }
+  }
+  PRAD_TRY(c.end_call(s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  c.last_path = "swt";
+  return PRAD_OK;
+}
+
+// ITK itkRecursiveGaussianImageFilter.hxx SetUp / ComputeNCoefficients / ComputeDCoefficients /
+// ComputeRemainingCoefficients (symmetric orders 0 and 2)
+void rgauss_n(double sigmad, double A1, double B1, double A2, double B2, double N[4], double &SN, double &DN, double &EN) {
+  const double W1 = 0.6681, L1 = -1.3932, W2 = 2.0787, L2 = -1.3732;
+  const double s1 = sin(W1 / sigmad), s2 = sin(W2 / sigmad), c1 = cos(W1 / sigmad), c2 = cos(W2 / sigmad);
+  const double e1 = exp(L1 / sigmad), e2 = exp(L2 / sigmad);
+  N[0] = A1 + A2;
+  N[1] = e2 * (B2 * s2 - (A2 + 2 * A1) * c2);
+  N[1] += e1 * (B1 * s1 - (A1 + 2 * A2) * c1);
+  N[2] = (A1 + A2) * c2 * c1;
+  N[2] -= B1 * c2 * s1 + B2 * c1 * s2;
+  N[2] *= 2 * e1 * e2;
+  N[2] += A2 * e1 * e1 + A1 * e2 * e2;
+  N[3] = e2 * e1 * e1 * (B2 * s2 - A2 * c2);
+  N[3] += e1 * e2 * e2 * (B1 * s1 - A1 * c1);
+  SN = N[0] + N[1] + N[2] + N[3];
+  DN = N[1] + 2 * N[2] + 3 * N[3];
+  EN = N[1] + 4 * N[2] + 9 * N[3];
+}
+
+RGaussCoef rgauss_coefficients(double sigma, double spacing, int order, bool normalize) {
+  const double W1 = 0.6681, L1 = -1.3932, W2 = 2.0787, L2 = -1.3732;
+  const double A1[3] = {1.3530, -0.6724, -1.3563}, B1[3] = {1.8151, -3.4327, 5.2318};
+  const double A2[3] = {-0.3531, 0.6724, 0.3446}, B2[3] = {0.0902, 0.6100, -2.2355};
+  const double sigmad = sigma / fabs(spacing);
+  const double c1 = cos(W1 / sigmad), c2 = cos(W2 / sigmad), e1 = exp(L1 / sigmad), e2 = exp(L2 / sigmad);
+  double D[4];
+  D[3] = e1 * e1 * e2 * e2;
+  D[2] = -2 * c1 * e1 * e2 * e2;
+  D[2] += -2 * c2 * e2 * e1 * e1;
+  D[1] = 4 * c2 * c1 * e1 * e2;
+  D[1] += e1 * e1 + e2 * e2;
+  D[0] = -2 * (e2 * c2 + e1 * c1);
+  const double SD = 1.0 + D[0] + D[1] + D[2] + D[3];
+  const double DD = D[0] + 2 * D[1] + 3 * D[2] + 4 * D[3];
+  const double ED = D[0] + 4 * D[1] + 9 * D[2] + 16 * D[3];
+  double N[4], SN, DN, EN;
+  if (order == 0) {
+    rgauss_n(sigmad, A1[0], B1[0], A2[0], B2[0], N, SN, DN, EN);
+    const double alpha0 = 2 * SN / SD - N[0];
+    for (int i = 0; i < 4; i++) N[i] /= alpha0;
+  } else {
+    const double scale = normalize ? sigma * sigma : 1.0;
+    double N0s[4], N2s[4], SN0, DN0, EN0, SN2, DN2, EN2;
+    rgauss_n(sigmad, A1[0], B1[0], A2[0], B2[0], N0s, SN0, DN0, EN0);
+    rgauss_n(sigmad, A1[2], B1[2], A2[2], B2[2], N2s, SN2, DN2, EN2);
+    const double beta = -(2 * SN2 - SD * N2s[0]) / (2 * SN0 - SD * N0s[0]);
+    for (int i = 0; i < 4; i++) N[i] = N2s[i] + beta * N0s[i];
+    SN = SN2 + beta * SN0; DN = DN2 + beta * DN0; EN = EN2 + beta * EN0;
+    const double alpha2 = (EN * SD * SD - ED * SN * SD - 2 * DN * DD * SD + 2 * DD * DD * SN) / (SD * SD * SD);
+    for (int i = 0; i < 4; i++) N[i] = N[i] * scale / alpha2;
+  }
+  RGaussCoef c;
+  c.N0 = N[0]; c.N1 = N[1]; c.N2 = N[2]; c.N3 = N[3];
+  c.D1 = D[0]; c.D2 = D[1]; c.D3 = D[2]; c.D4 = D[3];
+  c.M1 = N[1] - D[0] * N[0]; c.M2 = N[2] - D[1] * N[0]; c.M3 = N[3] - D[2] * N[0]; c.M4 = -D[3] * N[0];
+  const double SNn = c.N0 + c.N1 + c.N2 + c.N3, SM = c.M1 + c.M2 + c.M3 + c.M4, SDd = 1.0 + D[0] + D[1] + D[2] + D[3];
+  c.BN1 = D[0] * SNn / SDd; c.BN2 = D[1] * SNn / SDd; c.BN3 = D[2] * SNn / SDd; c.BN4 = D[3] * SNn / SDd;
+  c.BM1 = D[0] * SM / SDd; c.BM2 = D[1] * SM / SDd; c.BM3 = D[2] * SM / SDd; c.BM4 = D[3] * SM / SDd;
+  return c;
+}
+
+int log_dev(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize, float *out,
+            hipStream_t s) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Geo g;
+  PRAD_TRY(make_geo(size, Nd, &g));
+  if (!in || !out || !spacing) return fail(PRAD_E_ARG, "log: NULL pointer");
+  if (!(sigma > 0.0)) return fail(PRAD_E_ARG, "log: sigma must be > 0");
+  for (int d = 0; d < Nd; d++)
+    if (g.size[d] < 4) return fail(PRAD_E_ARG, "log: axis %d has %d < 4 samples (imageoperations.py:811)", d, g.size[d]);
+  PRAD_TRY(c.begin_call(s));
+  const size_t n = (size_t)g.n;
+  float *bufA = nullptr, *bufB = nullptr;
+  double *scratch = nullptr;
+  PRAD_TRY(c.get<float>("log_a", n, &bufA));
+  PRAD_TRY(c.get<float>("log_b", n, &bufB));
+  PRAD_TRY(c.get<double>("log_scratch", n, &scratch));
+  {
+    Timed t(c, "log", s);
+    const unsigned ge = (unsigned)std::max<long long>(1, std::min<long long>((g.n + 255) / 256, 8192));
+    // ITK dimension order x, y, z = array axes Nd-1 .. 0
+    bool first = true;
+    for (int dim = Nd - 1; dim >= 0; dim--) {
+      const float *cur = in;
+      float *pp[2] = {bufA, bufB};
+      int flip = 0;
+      auto pass = [&](int ax, int order) -> int {
+        const RGaussCoef k = rgauss_coefficients(sigma, spacing[ax], order, normalize != 0);
+        long long outer = 1;
+        for (int d = 0; d < ax; d++) outer *= g.size[d];
+        const long long inner = g.stride[ax];
+        const long long lines = outer * inner;
+        float *dst = pp[flip];
+        hipLaunchKernelGGL(rgauss_line_kernel, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, cur, outer,
+                           g.size[ax], inner, k, scratch, dst);
+        PRAD_TRY(check_launch("rgauss_line_kernel"));
+        cur = dst;
+        flip ^= 1;
+        return PRAD_OK;
+      };
+      for (int other = Nd - 1; other >= 0; other--)
+        if (other != dim) PRAD_TRY(pass(other, 0));
+      PRAD_TRY(pass(dim, 2));
+      hipLaunchKernelGGL(log_accumulate_kernel, dim3(ge), dim3(256), 0, s, out, cur, g.n, spacing[dim] * spacing[dim],
+                         first ? 1 : 0);
+      PRAD_TRY(check_launch("log_accumulate_kernel"));
+      first = false;
+    }
+  }
+  PRAD_TRY(c.end_call(s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  c.last_path = "log";
+  return PRAD_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -793,6 +962,50 @@ int prad_fill_glszm(double *glszm, int Nvox, int Ng, int maxRegion) {
   if (rc != PRAD_OK) return rc;
   return copy_back(c, glszm, d, n);
 }
+// ---- filters ---------------------------------------------------------------------------------
+int prad_swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi,
+                        int flen, const int *axes, int naxes, double *out, void *stream) {
+  return swt_level1_dev(in, size, Nd, dec_lo, dec_hi, flen, axes, naxes, out, (hipStream_t)stream);
+}
+int prad_swt_level1(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi, int flen,
+                    const int *axes, int naxes, double *out) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Geo g;
+  PRAD_TRY(make_geo(size, Nd, &g));
+  if (!in || !out || naxes < 1 || naxes > Nd) return fail(PRAD_E_ARG, "swt: bad arguments");
+  const size_t n = (size_t)g.n, nout = n << naxes;
+  double *d_in = nullptr, *d_out = nullptr;
+  PRAD_TRY(c.get<double>("swt_in", n, &d_in));
+  PRAD_TRY(c.get<double>("swt_out", nout, &d_out));
+  PRAD_HIP(hipMemcpyAsync(d_in, in, sizeof(double) * n, hipMemcpyHostToDevice, c.own_stream));
+  int rc = swt_level1_dev(d_in, size, Nd, dec_lo, dec_hi, flen, axes, naxes, d_out, c.own_stream);
+  if (rc != PRAD_OK) return rc;
+  return copy_back(c, out, d_out, nout);
+}
+int prad_log_dev(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
+                 float *out, void *stream) {
+  return log_dev(in, size, Nd, spacing, sigma, normalize, out, (hipStream_t)stream);
+}
+int prad_log(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
+             float *out) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Geo g;
+  PRAD_TRY(make_geo(size, Nd, &g));
+  if (!in || !out) return fail(PRAD_E_ARG, "log: NULL pointer");
+  const size_t n = (size_t)g.n;
+  float *d_in = nullptr, *d_out = nullptr;
+  PRAD_TRY(c.get<float>("log_in", n, &d_in));
+  PRAD_TRY(c.get<float>("log_out", n, &d_out));
+  PRAD_HIP(hipMemcpyAsync(d_in, in, sizeof(float) * n, hipMemcpyHostToDevice, c.own_stream));
+  int rc = log_dev(d_in, size, Nd, spacing, sigma, normalize, d_out, c.own_stream);
+  if (rc != PRAD_OK) return rc;
+  PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * n, hipMemcpyDeviceToHost, c.own_stream));
+  PRAD_HIP(hipStreamSynchronize(c.own_stream));
+  return PRAD_OK;
+}
+
 long long prad_glszm_zones(int v, int *tempData, long long capacity_pairs) {
   Context &c = ctx();
   int rc = c.ensure_device();

@@ -1,0 +1,137 @@
+"""Wavelet and Laplacian-of-Gaussian image types: the generator protocol of the reference's
+radiomics/imageoperations.py (`get<Type>Image(inputImage, inputMask, **kwargs)` yielding
+(image, imageTypeName, kwargs); featureextractor.py:371-379) with the filtering done on the MI355X through
+prad_swt_level1 / prad_log (include/pyradiomics_amd.h).
+
+Names follow the reference exactly: "wavelet-LLH" ... "wavelet-LLL" / "wavelet<k>-XYZ" (imageoperations.py:882-893)
+with the first letter belonging to the x axis, and "log-sigma-<sigma with '.'->'-'>-mm-3D" (:827).
+The third-party arithmetic behind both filters is restated from its published algorithms: parity with PyWavelets /
+SimpleITK is unpinned (oracle/filters_oracle.py)."""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+
+import numpy as np
+
+from . import _lib
+from .image import Image, as_array
+
+logger = logging.getLogger(__name__)
+
+# decomposition low-pass filters as tabulated by PyWavelets; dec_hi[k] = (-1)^(k+1) dec_lo[F-1-k]
+_DEC_LO = {
+    "coif1": [-0.01565572813546454, -0.0727326195128539, 0.38486484686420286, 0.8525720202122554,
+              0.3378976624578092, -0.0727326195128539],
+    "haar": [0.7071067811865476, 0.7071067811865476],
+    "db1": [0.7071067811865476, 0.7071067811865476],
+    "db2": [-0.12940952255092145, 0.22414386804185735, 0.836516303737469, 0.48296291314469025],
+    "sym2": [-0.12940952255092145, 0.22414386804185735, 0.836516303737469, 0.48296291314469025],
+}
+
+
+def wavelet_filters(wavelet):
+    """(dec_lo, dec_hi) float64 arrays for a wavelet name, or pass-through of a (dec_lo, dec_hi) pair"""
+    if isinstance(wavelet, (tuple, list)) and len(wavelet) == 2:
+        return np.asarray(wavelet[0], dtype=np.float64), np.asarray(wavelet[1], dtype=np.float64)
+    if hasattr(wavelet, "dec_lo"):           # a pywt.Wavelet object
+        return np.asarray(wavelet.dec_lo, dtype=np.float64), np.asarray(wavelet.dec_hi, dtype=np.float64)
+    if wavelet not in _DEC_LO:
+        raise NotImplementedError("wavelet %r is not tabulated here (known: %s); pass (dec_lo, dec_hi) instead"
+                                  % (wavelet, ", ".join(sorted(_DEC_LO))))
+    lo = np.array(_DEC_LO[wavelet], dtype=np.float64)
+    F = len(lo)
+    hi = np.array([(-1) ** (k + 1) * lo[F - 1 - k] for k in range(F)], dtype=np.float64)
+    return lo, hi
+
+
+def swtn_level1(data, lo, hi, axes):
+    """pywt.swtn(data, wavelet, level=1, start_level=0, axes=axes)[0] on the device: dict key -> float64 array,
+    keys in PyWavelets' order ('aaa', 'aad', ..., 'ddd')"""
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    size = np.array(data.shape, dtype=np.intc)
+    ax = np.array(axes, dtype=np.intc)
+    out = np.empty((1 << len(ax),) + data.shape, dtype=np.float64)
+    ip = C.POINTER(C.c_int)
+    rc = _lib.load().prad_swt_level1(C.c_void_p(data.ctypes.data), size.ctypes.data_as(ip), data.ndim,
+                                     C.c_void_p(lo.ctypes.data), C.c_void_p(hi.ctypes.data), len(lo),
+                                     ax.ctypes.data_as(ip), len(ax), C.c_void_p(out.ctypes.data))
+    _lib.raise_for(rc, "swt")
+    keys = [""]
+    for _ in ax:
+        keys = [k + c for k in keys for c in "ad"]
+    return {k: out[i] for i, k in enumerate(keys)}
+
+
+def _swt3(array, axes, **kwargs):
+    """imageoperations.py:899-970: pad odd dimensions by one wrapped sample, `level` single-level undecimated
+    transforms (the un-dilated transform is re-applied to the previous approximation), crop the pad"""
+    lo, hi = wavelet_filters(kwargs.get("wavelet", "coif1"))
+    level = kwargs.get("level", 1)
+    start_level = kwargs.get("start_level", 0)
+    shape = array.shape
+    data = np.pad(np.asarray(array).copy(), tuple((0, 1 if d % 2 else 0) for d in shape), "wrap")
+    crop = tuple(slice(None, -1 if d % 2 else None) for d in shape)
+    approx_key = "a" * len(axes)
+    for _ in range(start_level):
+        data = swtn_level1(data, lo, hi, axes)[approx_key].copy()
+    ret = []
+    for _ in range(start_level, start_level + level):
+        dec = swtn_level1(data, lo, hi, axes)
+        data = dec[approx_key].copy()
+        ret.append({k.replace("a", "L").replace("d", "H"): v[crop].copy() for k, v in dec.items() if k != approx_key})
+    return data[crop], ret
+
+
+def getWaveletImage(inputImage, inputMask, **kwargs):
+    """imageoperations.py:839-896"""
+    arr = as_array(inputImage)
+    ref = inputImage if isinstance(inputImage, Image) else Image(arr)
+    axes = list(range(arr.ndim - 1, -1, -1))
+    if kwargs.get("force2D", False):
+        axes.remove(kwargs.get("force2Ddimension", 0))
+    approx, ret = _swt3(arr, tuple(axes), **kwargs)
+    for idx, wl in enumerate(ret, start=1):
+        for name, dec in wl.items():
+            yield ref.like(dec), ("wavelet-%s" % name if idx == 1 else "wavelet%d-%s" % (idx, name)), kwargs
+    tail = "L" * len(axes)
+    yield ref.like(approx), ("wavelet-%s" % tail if len(ret) == 1 else "wavelet%d-%s" % (len(ret), tail)), kwargs
+
+
+def laplacian_recursive_gaussian(array, spacing_xyz, sigma, normalize=True):
+    """sitk.LaplacianRecursiveGaussianImageFilter (NormalizeAcrossScale) on the device: float32 array"""
+    a = np.ascontiguousarray(array, dtype=np.float32)
+    size = np.array(a.shape, dtype=np.intc)
+    sp = np.array([float(s) for s in spacing_xyz][::-1], dtype=np.float64)
+    out = np.empty(a.shape, dtype=np.float32)
+    rc = _lib.load().prad_log(C.c_void_p(a.ctypes.data), size.ctypes.data_as(C.POINTER(C.c_int)), a.ndim,
+                              C.c_void_p(sp.ctypes.data), float(sigma), 1 if normalize else 0,
+                              C.c_void_p(out.ctypes.data))
+    _lib.raise_for(rc, "LoG")
+    return out
+
+
+def getLoGImage(inputImage, inputMask, **kwargs):
+    """imageoperations.py:756-836"""
+    arr = as_array(inputImage)
+    ref = inputImage if isinstance(inputImage, Image) else Image(arr)
+    size = np.array(ref.GetSize())
+    spacing = np.array(ref.GetSpacing())
+    if np.min(size) < 4:
+        logger.warning("Image too small to apply LoG filter, size: %s", size)
+        return
+    for sigma in kwargs.get("sigma", []):
+        if sigma > 0.0:
+            if np.all(size >= np.ceil(sigma / spacing) + 1):
+                name = "log-sigma-%s-mm-3D" % str(sigma).replace(".", "-")
+                yield ref.like(laplacian_recursive_gaussian(arr, spacing, sigma, True)), name, kwargs
+            else:
+                logger.warning("applyLoG: sigma(%s)/spacing(%s) + 1 must be greater than the size(%s) of the inputImage",
+                               sigma, spacing, size)
+        else:
+            logger.warning("applyLoG: sigma must be greater than 0.0: %s", sigma)
+
+
+def getOriginalImage(inputImage, inputMask, **kwargs):
+    """imageoperations.py:745-753"""
+    yield inputImage, "original", kwargs

@@ -1,0 +1,75 @@
+"""GPU: wavelet / LoG kernels against the CPU restatement (oracle/filters_oracle.py; parity with PyWavelets / ITK
+itself is unpinned, see its header), plus properties that hold for any correct implementation."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(6, 8, 10), (5, 7, 9), (16, 12, 20), (1, 16, 16)])
+@pytest.mark.parametrize("wavelet", ["coif1", "haar", "db2"])
+def test_wavelet_matches_restatement(shape, wavelet):
+    from oracle import filters_oracle as fo
+    from pyradiomics_amd import filters
+    rng = np.random.default_rng(1)
+    x = rng.integers(-500, 1500, size=shape).astype(np.int16)
+    kw = dict(wavelet=wavelet)
+    if shape[0] == 1:
+        kw.update(force2D=True, force2Ddimension=0)
+    got = {name: im.array for im, name, _ in filters.getWaveletImage(x, None, **kw)}
+    axes = tuple(a for a in range(x.ndim - 1, -1, -1) if not (kw.get("force2D") and a == 0))
+    ap, ret = fo.swt3(x, wavelet, axes=axes)
+    want = {"wavelet-" + k: v for k, v in ret[0].items()}
+    want["wavelet-" + "L" * len(axes)] = ap
+    assert list(got) == list(want)                      # names AND yield order (LLH ... HHH, then LLL)
+    for k in want:
+        assert got[k].dtype == np.float64 and got[k].shape == x.shape
+        np.testing.assert_allclose(got[k], want[k], rtol=1e-13, atol=1e-10)
+    # energy identity of an orthogonal undecimated transform: sum of sub-band energies = 2^naxes * ||x||^2
+    if all(s % 2 == 0 for s in np.array(shape)[list(axes)]):
+        e = sum(float((v.astype(np.float64) ** 2).sum()) for v in got.values())
+        assert abs(e / ((x.astype(np.float64) ** 2).sum() * 2 ** len(axes)) - 1) < 1e-9
+
+
+def test_wavelet_two_levels():
+    from oracle import filters_oracle as fo
+    from pyradiomics_amd import filters
+    x = np.random.default_rng(2).standard_normal((8, 10, 12))
+    got = {n: im.array for im, n, _ in filters.getWaveletImage(x, None, level=2)}
+    ap, ret = fo.swt3(x, "coif1", level=2)
+    assert "wavelet2-HHL" in got and "wavelet-HHL" in got and "wavelet2-LLL" in got and len(got) == 15
+    np.testing.assert_allclose(got["wavelet2-LLL"], ap, rtol=1e-13, atol=1e-12)
+    np.testing.assert_allclose(got["wavelet2-LHL"], ret[1]["LHL"], rtol=1e-13, atol=1e-12)
+
+
+@pytest.mark.parametrize("spacing", [(1.0, 1.0, 1.0), (0.78125, 0.78125, 6.5), (0.5, 1.0, 2.0)])
+@pytest.mark.parametrize("sigma", [1.0, 3.0])
+def test_log_matches_restatement(spacing, sigma):
+    from oracle import filters_oracle as fo
+    from pyradiomics_amd import filters
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 800, size=(12, 40, 36)).astype(np.int16)
+    out = list(filters.getLoGImage(Image(x, spacing), None, sigma=[sigma]))
+    want = fo.laplacian_recursive_gaussian(x, spacing, sigma)
+    if not out:      # the reference skips sigmas that do not fit the image (imageoperations.py:823)
+        assert not np.all(np.array(x.shape[::-1]) >= np.ceil(sigma / np.array(spacing)) + 1)
+        return
+    im, name, _ = out[0]
+    assert name == "log-sigma-%s-mm-3D" % str(sigma).replace(".", "-") and im.array.dtype == np.float32
+    scale = np.abs(want).max()
+    assert np.abs(im.array - want).max() <= 2e-6 * scale     # float32 images, identical operation order
+
+
+def test_log_properties():
+    from pyradiomics_amd import filters
+    z, y, x = np.meshgrid(np.arange(24.0), np.arange(28.0), np.arange(32.0), indexing="ij")
+    const = filters.laplacian_recursive_gaussian(np.full((8, 9, 10), 7.0), (1, 1, 1), 1.5)
+    assert np.abs(const).max() < 1e-4
+    quad = filters.laplacian_recursive_gaussian(0.5 * (x - 16) ** 2, (1, 1, 1), 2.0)      # Laplacian 1 -> sigma^2
+    assert abs(quad[8:-8, 8:-8, 10:-10].mean() - 4.0) < 0.05
+    lin = filters.laplacian_recursive_gaussian(3 * x + 2 * y - z, (1, 1, 1), 2.0)
+    assert np.abs(lin[8:-8, 8:-8, 8:-8]).max() < 5e-2      # |ramp| ~ 100: the edge-replicating start decays inwards
+    a = np.random.default_rng(0).standard_normal((16, 16, 16)).astype(np.float32)
+    two = filters.laplacian_recursive_gaussian(2 * a, (1, 1, 1), 1.0)
+    np.testing.assert_allclose(two, 2 * filters.laplacian_recursive_gaussian(a, (1, 1, 1), 1.0), rtol=1e-5, atol=1e-5)
