@@ -1,0 +1,218 @@
+"""`RadiomicsFeatureExtractor`: the orchestration API of the reference's radiomics/featureextractor.py for the
+path this package accelerates -- image types Original / Wavelet / LoG, feature classes glcm / glrlm / glszm / gldm /
+ngtdm, segment-based and voxel-based extraction -- without SimpleITK / pykwalify (not installed on the build and
+GPU hosts).  Same constructor forms (parameter file, dict, or keyword settings), the same enable*/disable* methods,
+the same `execute(image, mask, label=None, voxelBased=False)` returning an OrderedDict keyed
+`<imageType>_<featureClass>_<featureName>` (featureextractor.py:241-396, 560-604).
+
+Not provided (out of scope): shape / firstorder classes, resampling, normalisation,
+the remaining image types, parameter-file schema validation.  Enabling them raises/ warns instead of silently
+computing something else."""
+from __future__ import annotations
+
+import collections
+import json
+import logging
+import os
+from itertools import chain
+
+import numpy as np
+
+from . import __version__, filters, imageoperations
+from .image import Image, as_array, read_nrrd
+
+logger = logging.getLogger(__name__)
+
+_FEATURE_CLASSES = ("glcm", "glrlm", "glszm", "gldm", "ngtdm")
+_IMAGE_TYPES = {"Original": filters.getOriginalImage, "Wavelet": filters.getWaveletImage, "LoG": filters.getLoGImage}
+
+
+def getFeatureClasses():
+    """name -> class (radiomics/__init__.py:64-117), restricted to the texture classes on the accelerated path"""
+    import importlib
+    return {n: getattr(importlib.import_module("pyradiomics_amd." + n), "Radiomics" + n.upper())
+            for n in _FEATURE_CLASSES}
+
+
+def getImageTypes():
+    return list(_IMAGE_TYPES)
+
+
+class RadiomicsFeatureExtractor:
+    def __init__(self, *args, **kwargs):
+        self.settings = {}
+        self.enabledImagetypes = {}
+        self.enabledFeatures = {}
+        self.featureClassNames = list(_FEATURE_CLASSES)
+        if len(args) == 1 and isinstance(args[0], dict):
+            self._applyParams(paramsDict=args[0])
+        elif len(args) == 1 and isinstance(args[0], (str, os.PathLike)):
+            self._applyParams(paramsFile=args[0])
+        else:
+            self.settings = self._getDefaultSettings()
+            self.settings.update(kwargs)
+            self.enabledImagetypes = {"Original": {}}
+            self.enabledFeatures = {n: [] for n in self.featureClassNames}
+
+    @staticmethod
+    def _getDefaultSettings():
+        # featureextractor.py:139-163 (keys that reach the accelerated path keep their defaults)
+        return {"minimumROIDimensions": 2, "minimumROISize": None, "normalize": False, "normalizeScale": 1,
+                "removeOutliers": None, "resampledPixelSpacing": None, "interpolator": "sitkBSpline", "preCrop": False,
+                "padDistance": 5, "distances": [1], "force2D": False, "force2Ddimension": 0, "resegmentRange": None,
+                "label": 1, "additionalInfo": True}
+
+    # -- configuration (featureextractor.py:165-239, 606-763) ----------------------------------------------
+    def loadParams(self, paramsFile):
+        self._applyParams(paramsFile=paramsFile)
+
+    def loadJSONParams(self, jsonString):
+        self._applyParams(paramsDict=json.loads(jsonString))
+
+    def _applyParams(self, paramsFile=None, paramsDict=None):
+        if paramsFile is not None:
+            import yaml
+            with open(paramsFile) as f:
+                params = yaml.safe_load(f)
+        else:
+            params = paramsDict
+        params = params or {}
+        unknown = set(params) - {"setting", "voxelSetting", "imageType", "featureClass"}
+        if unknown:
+            raise ValueError("unknown top-level parameter key(s): %s" % ", ".join(sorted(unknown)))
+        self.settings = self._getDefaultSettings()
+        self.settings.update(params.get("setting") or {})
+        self.settings.update(params.get("voxelSetting") or {})
+        types = params.get("imageType")
+        self.enabledImagetypes = {"Original": {}} if not types else {k: (v or {}) for k, v in types.items()}
+        for t in self.enabledImagetypes:
+            if t not in _IMAGE_TYPES:
+                raise NotImplementedError("image type %r is outside the accelerated path (available: %s)"
+                                          % (t, ", ".join(_IMAGE_TYPES)))
+        classes = params.get("featureClass")
+        if not classes:
+            self.enabledFeatures = {n: [] for n in self.featureClassNames}
+        else:
+            self.enabledFeatures = {}
+            for k, v in classes.items():
+                if k not in self.featureClassNames:
+                    logger.warning("feature class %r is outside the accelerated path and is skipped", k)
+                    continue
+                self.enabledFeatures[k] = list(v) if v else []
+
+    def addProvenance(self, provenance_on=True):
+        self.settings["additionalInfo"] = provenance_on
+
+    def enableAllImageTypes(self):
+        self.enabledImagetypes = {t: {} for t in _IMAGE_TYPES}
+
+    def disableAllImageTypes(self):
+        self.enabledImagetypes = {}
+
+    def enableImageTypeByName(self, imageType, enabled=True, customArgs=None):
+        if imageType not in _IMAGE_TYPES:
+            raise NotImplementedError("image type %r is outside the accelerated path" % imageType)
+        if enabled:
+            self.enabledImagetypes[imageType] = customArgs or {}
+        else:
+            self.enabledImagetypes.pop(imageType, None)
+
+    def enableImageTypes(self, **enabledImagetypes):
+        for k, v in enabledImagetypes.items():
+            self.enableImageTypeByName(k, True, v)
+
+    def enableAllFeatures(self):
+        self.enabledFeatures = {n: [] for n in self.featureClassNames}
+
+    def disableAllFeatures(self):
+        self.enabledFeatures = {}
+
+    def enableFeatureClassByName(self, featureClass, enabled=True):
+        if featureClass not in self.featureClassNames:
+            logger.warning("Feature class %s is not recognized", featureClass)
+            return
+        if enabled:
+            self.enabledFeatures[featureClass] = []
+        else:
+            self.enabledFeatures.pop(featureClass, None)
+
+    def enableFeaturesByName(self, **enabledFeatures):
+        for k, v in enabledFeatures.items():
+            if k in self.featureClassNames:
+                self.enabledFeatures[k] = list(v) if v else []
+            else:
+                logger.warning("Feature class %s is not recognized", k)
+
+    # -- execution ---------------------------------------------------------------------------------------
+    @staticmethod
+    def loadImage(imageFilepath, maskFilepath, **kwargs):
+        """paths to NRRD files, pyradiomics_amd.image.Image objects, or numpy arrays (z, y, x)"""
+        def load(x):
+            if isinstance(x, (str, os.PathLike)):
+                return read_nrrd(os.fspath(x))
+            return x if isinstance(x, Image) else Image(as_array(x))
+        image, mask = load(imageFilepath), load(maskFilepath)
+        if image.array.shape != mask.array.shape:
+            raise ValueError("Image/Mask geometry mismatch: %s vs %s" % (image.array.shape, mask.array.shape))
+        return image, mask
+
+    def execute(self, imageFilepath, maskFilepath, label=None, label_channel=None, voxelBased=False):
+        s = self.settings.copy()
+        if label is not None:
+            s["label"] = label
+        label = s.get("label", 1)
+        for k in ("normalize", "resampledPixelSpacing"):
+            if s.get(k):
+                raise NotImplementedError("setting %r needs SimpleITK preprocessing that is outside the accelerated path" % k)
+        kernelRadius = 0
+        if voxelBased:
+            s["voxelBased"] = True
+            kernelRadius = s.get("kernelRadius", 1)
+        out = collections.OrderedDict()
+        image, mask = self.loadImage(imageFilepath, maskFilepath, **s)
+        roi = mask.array == label
+        if not roi.any():
+            raise ValueError("Label (%g) not present in mask" % label)
+        if s.get("resegmentRange") is not None:
+            mask = imageoperations.resegmentMask(image, mask, **s)
+            roi = mask.array == label
+        lo, hi = imageoperations.boundingBox(roi)
+        ndims = int(np.sum(hi - lo + 1 > 1))
+        if ndims < s.get("minimumROIDimensions", 2):
+            raise ValueError("mask has too few dimensions (number of dimensions %d, minimum required %d)"
+                             % (ndims, s.get("minimumROIDimensions", 2)))
+        if s.get("minimumROISize") is not None and roi.sum() <= s["minimumROISize"]:
+            raise ValueError("Size of the ROI is too small (minimum size: %g)" % s["minimumROISize"])
+        if s.get("additionalInfo", True):
+            out["diagnostics_Versions_PyRadiomicsAMD"] = __version__
+            out["diagnostics_Versions_Numpy"] = np.__version__
+            out["diagnostics_Configuration_Settings"] = {k: v for k, v in s.items()}
+            out["diagnostics_Configuration_EnabledImageTypes"] = dict(self.enabledImagetypes)
+            out["diagnostics_Image-original_Spacing"] = image.GetSpacing()
+            out["diagnostics_Image-original_Size"] = image.GetSize()
+            out["diagnostics_Mask-original_BoundingBox"] = tuple(int(v) for v in lo[::-1]) + \
+                tuple(int(v) for v in (hi - lo + 1)[::-1])
+            out["diagnostics_Mask-original_VoxelNum"] = int(roi.sum())
+        gens = []
+        for imageType, custom in self.enabledImagetypes.items():
+            args = s.copy()
+            args.update(custom)
+            gens = chain(gens, _IMAGE_TYPES[imageType](image, mask, **args))
+        for derived, typeName, kw in gens:
+            cimg, cmask = imageoperations.cropToTumorMask(derived, mask, label, padDistance=kernelRadius)
+            out.update(self.computeFeatures(cimg, cmask, typeName, **kw))
+        return out
+
+    def computeFeatures(self, image, mask, imageTypeName, **kwargs):
+        """featureextractor.py:560-604"""
+        out = collections.OrderedDict()
+        classes = getFeatureClasses()
+        for cname, fnames in self.enabledFeatures.items():
+            if cname not in classes:
+                continue
+            fc = classes[cname](image, mask, **kwargs)
+            for f in fnames or []:
+                fc.enableFeatureByName(f)
+            for fname, value in fc.execute().items():
+                out["%s_%s_%s" % (imageTypeName, cname, fname)] = value
+        return out
