@@ -152,6 +152,30 @@ int prad_fill_glszm_dev(double *glszm, int Nvox, int Ng, int maxRegion, void *st
  * tempData must hold 2*nzones_v+1 ints; returns nzones_v or PRAD_E_*. */
 long long prad_glszm_zones(int v, int *tempData, long long capacity_pairs);
 
+/* ---- fused voxel-based GLCM feature maps (no reference analogue at this boundary) ---------------------------
+ * For every centre voxel the GLCM of its kernel window is built and reduced to the requested features on the
+ * device; the P[Nvox][Ng][Ng][Na] intermediate of the reference (glcm.py:145, base.py:200-245) is never
+ * materialised.  Semantics follow glcm.py:149-887 with weightingNorm = None: per-angle normalisation, nanmean over
+ * the angles that are non-empty for the voxel.  feature_ids: 0 Autocorrelation, 1 JointAverage, 2 ClusterProminence,
+ * 3 ClusterShade, 4 ClusterTendency, 5 Contrast, 6 Correlation, 7 DifferenceAverage, 8 DifferenceEntropy,
+ * 9 DifferenceVariance, 10 JointEnergy, 11 JointEntropy, 12 Imc1, 13 Imc2, 14 Idm, 15 Idmn, 16 Id, 17 Idn,
+ * 18 InverseVariance, 19 MaximumProbability, 20 SumAverage, 21 SumEntropy, 22 SumSquares (MCC is not offered).
+ *   out         float64 [nfeat][Nvox]
+ *   empty_mask  uint32 [Nvox] (optional): bit a set <=> angle a has no voxel pair in kernel v
+ *   any_nonempty uint32 [1] (optional): OR of the non-empty angle bits over all kernels (JointAverage, which the
+ *               reference averages with a plain mean, is NaN for kernels whose empty angles are not empty
+ *               everywhere -- glcm.py:292; the Python layer applies that rule)
+ * Requirements: Nd <= 3, Ng <= 64, Na <= 32, masked levels in [1, Ng]; otherwise PRAD_E_UNSUPPORTED and the
+ * caller uses prad_calculate_glcm + host features.  All pointers of the _dev variant are device pointers. */
+int prad_voxel_glcm_features(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                             int Na, int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                             int symmetric, const int *feature_ids, int nfeat, double *out, uint32_t *empty_mask,
+                             uint32_t *any_nonempty);
+int prad_voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                                 const int *angles, int Na, int Ng, int Nvox, const int *voxels, int kernelRadius,
+                                 int force2Ddim, int symmetric, const int *feature_ids, int nfeat, double *out,
+                                 uint32_t *empty_mask, uint32_t *any_nonempty, void *stream);
+
 /* ---- filter stack in front of the matrices (radiomics/imageoperations.py:756-970) ---------------------------
  * The arithmetic of both filters lives in third-party wheels (PyWavelets, SimpleITK/ITK) that are not part of
  * the reference tree; these entry points implement their published algorithms (see oracle/filters_oracle.py):

@@ -177,3 +177,40 @@ def generate_angles(size, distances, bidirectional, force2D, force2Ddimension):
     if size.ndim != 1:
         raise ValueError("Expected a 1D array for size")
     return _build_angles(size, distances, bidirectional, int(force2Ddimension) if force2D else -1)
+
+
+# ---- fused voxel-based GLCM features (no reference analogue: replaces calculate_glcm + numpy feature math in
+# ---- voxel mode, see include/pyradiomics_amd.h) -------------------------------------------------------------
+VOXEL_GLCM_FEATURES = ["Autocorrelation", "JointAverage", "ClusterProminence", "ClusterShade", "ClusterTendency",
+                       "Contrast", "Correlation", "DifferenceAverage", "DifferenceEntropy", "DifferenceVariance",
+                       "JointEnergy", "JointEntropy", "Imc1", "Imc2", "Idm", "Idmn", "Id", "Idn", "InverseVariance",
+                       "MaximumProbability", "SumAverage", "SumEntropy", "SumSquares"]
+
+
+def voxel_glcm_features(image, mask, distances, Ng, force2D, force2Ddimension, kernelRadius, voxels, features,
+                        symmetrical=True):
+    """-> {feature name: float64 [Nvox]} for the kernels centred on `voxels` (int [Nd, Nvox]).
+    Raises NotImplementedError when the fused kernel does not cover the request (Ng > 64, MCC, ...): the caller
+    then uses calculate_glcm and the numpy feature formulas."""
+    unknown = [f for f in features if f not in VOXEL_GLCM_FEATURES]
+    if unknown:
+        raise NotImplementedError("not available in the fused voxel kernel: %s" % ", ".join(unknown))
+    img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, distances, False, force2D, force2Ddimension,
+                                                     kernelRadius, voxels)
+    if vox is None:
+        raise RuntimeError("voxel_glcm_features needs a voxel list")
+    Na, Nd = angles.shape
+    ids = np.array([VOXEL_GLCM_FEATURES.index(f) for f in features], dtype=np.intc)
+    out = np.empty((len(ids), Nvox), dtype=np.float64)
+    empty = np.empty(Nvox, dtype=np.uint32)
+    anyne = np.zeros(1, dtype=np.uint32)
+    rc = _lib.load().prad_voxel_glcm_features(_vptr(img), _vptr(msk), _iptr(size), Nd, _iptr(angles), Na, int(Ng),
+                                              Nvox, _vptr(vox), int(kernelRadius), f2d, 1 if symmetrical else 0,
+                                              _iptr(ids), len(ids), _vptr(out), _vptr(empty), _vptr(anyne))
+    _lib.raise_for(rc, "voxel GLCM features")
+    res = {f: out[i] for i, f in enumerate(features)}
+    if "JointAverage" in res:
+        # glcm.py:292 takes a plain mean over the angles kept for the batch: NaN wherever a kernel lacks an angle
+        # that some other kernel of the batch has
+        res["JointAverage"] = np.where((empty & anyne[0]) != 0, np.nan, res["JointAverage"])
+    return res

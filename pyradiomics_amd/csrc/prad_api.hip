@@ -14,6 +14,7 @@
 #include "kernels_neigh.h"
 #include "kernels_glszm.h"
 #include "kernels_filters.h"
+#include "kernels_voxel.h"
 
 #include <algorithm>
 #include <cmath>
@@ -584,6 +585,78 @@ int copy_back(Context &c, double *host, const double *dev, size_t count) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// fused voxel-based GLCM features
+// ------------------------------------------------------------------------------------------------
+int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                            int Na, int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                            int symmetric, const int *feature_ids, int nfeat, double *out, uint32_t *empty_mask,
+                            uint32_t *any_nonempty, hipStream_t s) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Geo g;
+  PRAD_TRY(make_geo(size, Nd, &g));
+  if (!image || !mask || !angles || !voxels || !feature_ids || !out) return fail(PRAD_E_ARG, "voxel_glcm: NULL pointer");
+  if (Nvox < 1 || nfeat < 1 || kernelRadius <= 0) return fail(PRAD_E_ARG, "voxel_glcm: Nvox/nfeat/kernelRadius must be >= 1");
+  if (Nd > 3 || Ng < 1 || Ng > 64 || Na < 1 || Na > PRAD_VOX_MAX_ANGLES)
+    return fail(PRAD_E_UNSUPPORTED, "voxel_glcm: needs Nd <= 3, Ng <= 64, Na <= %d (got Nd=%d Ng=%d Na=%d)",
+                PRAD_VOX_MAX_ANGLES, Nd, Ng, Na);
+  VoxAngles A;
+  A.na = Na;
+  for (int a = 0; a < Na; a++) {
+    for (int d = 0; d < 4; d++) A.o[a][d] = 0;
+    for (int d = 0; d < Nd; d++) {
+      const int o = angles[a * Nd + d];
+      if (o < -127 || o > 127) return fail(PRAD_E_UNSUPPORTED, "voxel_glcm: angle offset %d", o);
+      A.o[a][3 - Nd + d] = (signed char)o;
+    }
+  }
+  unsigned fmask = 0;
+  int slot[VF_COUNT];
+  for (int f = 0; f < VF_COUNT; f++) slot[f] = 0;
+  for (int i = 0; i < nfeat; i++) {
+    if (feature_ids[i] < 0 || feature_ids[i] >= VF_COUNT) return fail(PRAD_E_ARG, "voxel_glcm: feature id %d", feature_ids[i]);
+    if (fmask & (1u << feature_ids[i])) return fail(PRAD_E_ARG, "voxel_glcm: duplicate feature id %d", feature_ids[i]);
+    fmask |= 1u << feature_ids[i];
+    slot[feature_ids[i]] = i;
+  }
+  int dims[3] = {1, 1, 1};
+  for (int d = 0; d < Nd; d++) dims[3 - Nd + d] = g.size[d];
+  const int f2d3 = force2Ddim >= 0 ? 3 - Nd + force2Ddim : -1;
+  PRAD_TRY(c.begin_call(s));
+  int *flags = nullptr, *slot_d = nullptr;
+  PRAD_TRY(c.get<int>("flags", 4, &flags));
+  PRAD_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, s));
+  PRAD_TRY(c.get<int>("vox_slots", VF_COUNT, &slot_d));
+  PRAD_HIP(hipMemcpyAsync(slot_d, slot, sizeof(int) * VF_COUNT, hipMemcpyHostToDevice, s));
+  unsigned *scratch_mask = nullptr;
+  PRAD_TRY(c.get<unsigned>("vox_masks", (size_t)Nvox + 4, &scratch_mask));
+  unsigned *em = empty_mask ? empty_mask : scratch_mask + 4;
+  unsigned *an = any_nonempty ? any_nonempty : scratch_mask;
+  PRAD_HIP(hipMemsetAsync(an, 0, sizeof(unsigned), s));
+  uint8_t *levels = nullptr;
+  PRAD_TRY(neigh_pack(&c, s, g, image, mask, Ng, flags, &levels));
+  {
+    Timed t(c, "voxel", s);
+    const size_t lds = sizeof(u32) * PRAD_VOX_WAVES * ((size_t)Ng * Ng + 5 * (size_t)Ng + 1);
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((long long)Nvox + PRAD_VOX_WAVES - 1) / PRAD_VOX_WAVES,
+                                                                           (long long)cu_count() * 8));
+    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(voxel_glcm_kernel, dim3(gx), dim3(64 * PRAD_VOX_WAVES), lds, s, levels, dims[0], dims[1], dims[2],
+                       A, Ng, Nvox, voxels, Nd, kernelRadius, f2d3, symmetric, fmask, slot_d, out, em, an, flags);
+    PRAD_TRY(check_launch("voxel_glcm_kernel"));
+  }
+  void *fh = nullptr;
+  PRAD_TRY(c.get_pinned("flags_h", sizeof(int) * 4, &fh));
+  PRAD_HIP(hipMemcpyAsync(fh, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  PRAD_TRY(c.end_call(s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  if (((int *)fh)[0]) return fail(PRAD_E_UNSUPPORTED, "voxel_glcm: masked levels outside [1, Ng]; use the matrix path");
+  c.last_path = "voxel-fused";
+  return PRAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // filters
 // ------------------------------------------------------------------------------------------------
 int swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi, int flen,
@@ -962,6 +1035,35 @@ int prad_fill_glszm(double *glszm, int Nvox, int Ng, int maxRegion) {
   if (rc != PRAD_OK) return rc;
   return copy_back(c, glszm, d, n);
 }
+// ---- fused voxel-based GLCM features -----------------------------------------------------------
+int prad_voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                                 const int *angles, int Na, int Ng, int Nvox, const int *voxels, int kernelRadius,
+                                 int force2Ddim, int symmetric, const int *feature_ids, int nfeat, double *out,
+                                 uint32_t *empty_mask, uint32_t *any_nonempty, void *stream) {
+  return voxel_glcm_features_dev(image, mask, size, Nd, angles, Na, Ng, Nvox, voxels, kernelRadius, force2Ddim,
+                                 symmetric, feature_ids, nfeat, out, empty_mask, any_nonempty, (hipStream_t)stream);
+}
+int prad_voxel_glcm_features(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                             int Na, int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
+                             int symmetric, const int *feature_ids, int nfeat, double *out, uint32_t *empty_mask,
+                             uint32_t *any_nonempty) {
+  Context &c = ctx();
+  Staged st;
+  PRAD_TRY(stage_inputs(c, image, mask, size, Nd, Nvox, voxels, &st));
+  if (!voxels || !out || nfeat < 1) return fail(PRAD_E_ARG, "voxel_glcm: bad arguments");
+  double *d_out = nullptr;
+  unsigned *d_masks = nullptr;
+  PRAD_TRY(c.get<double>("o_vox", (size_t)nfeat * Nvox, &d_out));
+  PRAD_TRY(c.get<unsigned>("o_voxmask", (size_t)Nvox + 1, &d_masks));
+  int rc = voxel_glcm_features_dev(st.image, st.mask, size, Nd, angles, Na, Ng, Nvox, st.voxels, kernelRadius,
+                                   force2Ddim, symmetric, feature_ids, nfeat, d_out, d_masks + 1, d_masks, c.own_stream);
+  if (rc != PRAD_OK) return rc;
+  PRAD_TRY(copy_back(c, out, d_out, (size_t)nfeat * Nvox));
+  if (empty_mask) PRAD_HIP(hipMemcpy(empty_mask, d_masks + 1, sizeof(unsigned) * Nvox, hipMemcpyDeviceToHost));
+  if (any_nonempty) PRAD_HIP(hipMemcpy(any_nonempty, d_masks, sizeof(unsigned), hipMemcpyDeviceToHost));
+  return PRAD_OK;
+}
+
 // ---- filters ---------------------------------------------------------------------------------
 int prad_swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi,
                         int flen, const int *axes, int naxes, double *out, void *stream) {

@@ -52,6 +52,27 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
         self.P_glcm = self._calculateMatrix(voxelCoordinates)
         self._calculateCoefficients()
 
+    def _calculateFeatures(self, voxelCoordinates=None):
+        """voxel mode: when the operator backend offers the fused kernel and it covers the request, feature maps
+        come straight from the device (no (Nvox, Ng, Ng, Na) intermediate); otherwise the reference's route
+        (matrix + numpy formulas, base.py:253-273) is taken.  `fusedVoxel: False` in the settings forces the latter."""
+        fused = getattr(self.cMatrices, "voxel_glcm_features", None)
+        names = [n for n, on in self.enabledFeatures.items() if on]
+        if (self.voxelBased and voxelCoordinates is not None and fused is not None and names
+                and self.settings.get("fusedVoxel", True) and self.weightingNorm is None):
+            try:
+                vals = fused(self.imageArray, self.maskArray, np.array(self.settings.get("distances", [1])),
+                             self.coefficients["Ng"], self.settings.get("force2D", False),
+                             self.settings.get("force2Ddimension", 0), self.settings.get("kernelRadius", 1),
+                             voxelCoordinates, names, self.symmetricalGLCM)
+            except NotImplementedError:
+                vals = None
+            if vals is not None:
+                for n in names:
+                    yield True, n, vals[n]
+                return
+        yield from super()._calculateFeatures(voxelCoordinates)
+
     def _calculateMatrix(self, voxelCoordinates=None):
         Ng = self.coefficients["Ng"]
         args = [self.imageArray, self.maskArray, np.array(self.settings.get("distances", [1])), Ng,
