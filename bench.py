@@ -28,6 +28,11 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
+# Fabric (HBM + Infinity Cache) bytes per engine call at the default workload, from the committed PMC profile
+# profiles/r01g_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 correction applied to
+# the 16 B/lane streams): pack 679 MB + 201 MB, sweep_lines 1002 MB + 3 MB, sweep_rows 191 MB + 3 MB.
+# rocprof cannot run inside bench.py; the figure is only reported when the workload matches the profiled one.
+PROFILED_TRAFFIC = {"workload": (512, 32, "uniform"), "bytes": 2.08e9, "source": "profiles/r01g_pmc.md"}
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 ALG_BYTES_PER_VOXEL = 5.0       # int32 level + uint8 mask, read once
 
@@ -104,7 +109,7 @@ def main() -> None:
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist_on = world > 1
+    dist_on = world > 1 or "RANK" in os.environ      # any torch.distributed launch (also a 1-rank one) takes the N>1 path
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -180,7 +185,9 @@ def main() -> None:
             "roofline": {
                 "bound": "hbm", "kernel": "sweep_lines_kernel+sweep_rows_kernel (13 angle sweeps)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "traffic": PROFILED_TRAFFIC["bytes"] if (args.size, args.levels, args.dist) == PROFILED_TRAFFIC["workload"] else None,
+                "traffic_source": PROFILED_TRAFFIC["source"],
                 "algorithmic_bytes": alg_bytes, "kernel_ms": round(sweep_ms, 4),
                 "pipeline_ms": round(pipe_ms, 4), "pack_ms": round(kernel_ms["pack"] / args.steps, 4),
                 "finalize_ms": round(kernel_ms["finalize"] / args.steps, 4),

@@ -131,3 +131,34 @@ def glszm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Ns: int | None = Non
         raise IndexError("Error filling GLSZM.")
     _lib.raise_for(rc, "GLSZM")
     return out
+
+
+def voxel_glcm_features(image: torch.Tensor, mask: torch.Tensor, Ng: int, voxels: torch.Tensor, features,
+                        kernelRadius: int = 1, force2D: bool = False, force2Ddimension: int = 0,
+                        symmetrical: bool = True, distances=(1,)):
+    """Fused voxel-based GLCM feature maps, everything device-resident.
+    voxels: int32 [Nd, Nvox] centre coordinates (np.where layout) on the device.
+    Returns {name: float64 tensor [Nvox]} (JointAverage with the reference's plain-mean NaN rule applied)."""
+    from .cmatrices import VOXEL_GLCM_FEATURES
+    lib, image, mask, size = _prep(image, mask)
+    f2d = int(force2Ddimension) if force2D else -1
+    angles = _build_angles(size, list(distances), False, f2d)
+    Na, Nd = angles.shape
+    vox = voxels.to(torch.int32).contiguous()
+    if vox.dim() != 2 or vox.shape[0] != Nd:
+        raise RuntimeError("Expecting voxel indices array to be 2-dimensional")
+    Nvox = int(vox.shape[1])
+    ids = np.array([VOXEL_GLCM_FEATURES.index(f) for f in features], dtype=np.intc)
+    out = torch.empty((len(ids), Nvox), dtype=torch.float64, device=image.device)
+    empty = torch.empty(Nvox, dtype=torch.int32, device=image.device)
+    anyne = torch.zeros(1, dtype=torch.int32, device=image.device)
+    rc = lib.prad_voxel_glcm_features_dev(
+        C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd, _iptr(angles), Na, int(Ng), Nvox,
+        C.c_void_p(vox.data_ptr()), int(kernelRadius), f2d, 1 if symmetrical else 0, _iptr(ids), len(ids),
+        C.c_void_p(out.data_ptr()), C.c_void_p(empty.data_ptr()), C.c_void_p(anyne.data_ptr()), _stream_ptr())
+    _lib.raise_for(rc, "voxel GLCM features")
+    res = {f: out[i] for i, f in enumerate(features)}
+    if "JointAverage" in res:
+        bad = (empty & anyne[0]) != 0
+        res["JointAverage"] = torch.where(bad, torch.full_like(res["JointAverage"], float("nan")), res["JointAverage"])
+    return res
