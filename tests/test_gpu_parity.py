@@ -199,3 +199,24 @@ def test_medium_volume_vs_oracle(cm, oracle_port):
     g, r, _ = cm.calculate_glcm_glrlm(img, mask, 32, 128, False, 0)
     assert np.array_equal(g, oracle_port.calculate_glcm(img, mask, [1], 32, False, 0)[0])
     assert np.array_equal(r, oracle_port.calculate_glrlm(img, mask, 32, 128, False, 0)[0])
+
+
+@pytest.mark.parametrize("shape", [(9, 12, 16), (1, 20, 64), (6, 1, 8), (20, 24, 132), (4, 4, 4)])
+@pytest.mark.parametrize("frac", [1.0, 0.55])
+def test_gldm_ngtdm_packed_byte_path(cm, oracle_port, shape, frac):
+    """Nx % 4 == 0 takes the 4-voxels-per-lane packed-byte kernels (neigh4_kernel); all force2D variants, levels up
+    to 255, alpha = 0 (packed) and alpha = 2 (per-neighbour kernel)"""
+    for Ng in (5, 255):
+        img, mask = _vol(sum(shape) + Ng, shape, Ng, frac)
+        for force2D, f2d in ((False, 0), (True, 0), (True, 1), (True, 2)):
+            try:
+                want = oracle_port.calculate_gldm(img, mask, [1], Ng, 0, force2D, f2d)
+            except RuntimeError:
+                continue        # no angle left for this shape / force2D combination
+            assert np.array_equal(cm.calculate_gldm(img, mask, [1], Ng, 0, force2D, f2d), want)
+            assert np.array_equal(cm.calculate_gldm(img, mask, [1], Ng, 2, force2D, f2d),
+                                  oracle_port.calculate_gldm(img, mask, [1], Ng, 2, force2D, f2d))
+            a = cm.calculate_ngtdm(img, mask, [1], Ng, force2D, f2d)
+            b = oracle_port.calculate_ngtdm(img, mask, [1], Ng, force2D, f2d)
+            assert np.array_equal(a[..., 0], b[..., 0]) and np.array_equal(a[..., 2], b[..., 2])
+            np.testing.assert_allclose(a[..., 1], b[..., 1], rtol=1e-12, atol=0)
