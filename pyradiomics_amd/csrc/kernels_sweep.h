@@ -312,6 +312,37 @@ struct Walker<true, true, LONG, true> {
   }
 };
 
+// One march step of LPL independent lines with the work of the lines interleaved (all compares first, then all
+// address selects / bumps, then all state updates): the hardware needs a wait state between a VALU compare and the
+// v_cndmask that consumes it, and hipcc otherwise walks the lines one after the other and fills it with s_nop.
+template <int LPL, typename W>
+__device__ __forceinline__ void step_lines_plain(W (&w)[LPL], unsigned v) {
+#pragma unroll
+  for (int j = 0; j < LPL; j++) w[j].template step<false>((int)((v >> (8 * j)) & 0xffu));
+}
+template <int LPL, bool LONG>
+__device__ __forceinline__ void step_lines_plain(Walker<true, true, LONG, true> (&w)[LPL], unsigned v) {
+  int cur[LPL], addr[LPL], fresh[LPL], grown[LPL];
+  bool chg[LPL];
+#pragma unroll
+  for (int j = 0; j < LPL; j++) cur[j] = (int)((v >> (8 * j)) & 0xffu);
+#pragma unroll
+  for (int j = 0; j < LPL; j++) chg[j] = cur[j] != w[j].prev;
+#pragma unroll
+  for (int j = 0; j < LPL; j++) {
+    addr[j] = w[j].pl + (cur[j] << 2);
+    fresh[j] = __mul24(cur[j], w[j].P) + w[j].cB;
+    grown[j] = w[j].pl + w[j].Q;
+  }
+#pragma unroll
+  for (int j = 0; j < LPL; j++) lds_bump(chg[j] ? addr[j] : w[j].dummy);
+#pragma unroll
+  for (int j = 0; j < LPL; j++) {
+    w[j].pl = select_i32(chg[j], fresh[j], grown[j]);
+    w[j].prev = cur[j];
+  }
+}
+
 template <bool DO_GLCM, bool DO_GLRLM, bool FUSED>
 __device__ __forceinline__ void flush_block_hist(const u32 *lds, const HistLayout &h, int Nr, int slot,
                                                  u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc) {
@@ -502,10 +533,7 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
           }
         } else {
 #pragma unroll
-          for (int k = 0; k < U; k++) {
-#pragma unroll
-            for (int j = 0; j < LPL; j++) w[j].template step<false>((int)((v[k] >> (8 * j)) & 0xffu));
-          }
+          for (int k = 0; k < U; k++) step_lines_plain<LPL>(w, v[k]);
         }
       } else {
         int sb[U];
