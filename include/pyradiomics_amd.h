@@ -176,6 +176,16 @@ int prad_voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, cons
                                  int force2Ddim, int symmetric, const int *feature_ids, int nfeat, double *out,
                                  uint32_t *empty_mask, uint32_t *any_nonempty, void *stream);
 
+/* ---- on-device discretisation (radiomics/imageoperations.py:67-174; device pointers only) ----------------------
+ * dtype: 0 = float32, 1 = float64, 2 = int32, 3 = int16 image.
+ * prad_roi_minmax_dev: minmax[0..1] (HOST doubles) = min / max of image over mask != 0; PRAD_E_ARG if the ROI is empty.
+ * prad_digitize_dev:   levels[i] = number of edges <= image[i] (np.digitize) where mask != 0, else 0;
+ *                      `edges` is a HOST array of nedges ascending float64 values (getBinEdges output);
+ *                      *max_level (HOST int) receives the largest level written (= Ng of base.py:121-124). */
+int prad_roi_minmax_dev(const void *image, int dtype, const uint8_t *mask, long long n, double *minmax, void *stream);
+int prad_digitize_dev(const void *image, int dtype, const uint8_t *mask, long long n, const double *edges, int nedges,
+                      int32_t *levels, int *max_level, void *stream);
+
 /* ---- filter stack in front of the matrices (radiomics/imageoperations.py:756-970) ---------------------------
  * The arithmetic of both filters lives in third-party wheels (PyWavelets, SimpleITK/ITK) that are not part of
  * the reference tree; these entry points implement their published algorithms (see oracle/filters_oracle.py):

@@ -15,6 +15,7 @@
 #include "kernels_glszm.h"
 #include "kernels_filters.h"
 #include "kernels_voxel.h"
+#include "kernels_binning.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1061,6 +1062,64 @@ int prad_voxel_glcm_features(const int32_t *image, const uint8_t *mask, const in
   PRAD_TRY(copy_back(c, out, d_out, (size_t)nfeat * Nvox));
   if (empty_mask) PRAD_HIP(hipMemcpy(empty_mask, d_masks + 1, sizeof(unsigned) * Nvox, hipMemcpyDeviceToHost));
   if (any_nonempty) PRAD_HIP(hipMemcpy(any_nonempty, d_masks, sizeof(unsigned), hipMemcpyDeviceToHost));
+  return PRAD_OK;
+}
+
+// ---- on-device discretisation ----------------------------------------------------------------
+int prad_roi_minmax_dev(const void *image, int dtype, const uint8_t *mask, long long n, double *minmax, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!image || !mask || !minmax || n < 1) return fail(PRAD_E_ARG, "roi_minmax: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long *keys = nullptr;
+  PRAD_TRY(c.get<unsigned long long>("minmax_keys", 2, &keys));
+  const unsigned long long init[2] = {~0ull, 0ull};
+  PRAD_HIP(hipMemcpyAsync(keys, init, sizeof(init), hipMemcpyHostToDevice, s));
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(roi_minmax_kernel<float>, dim3(gx), dim3(256), 0, s, (const float *)image, mask, n, keys); break;
+    case 1: hipLaunchKernelGGL(roi_minmax_kernel<double>, dim3(gx), dim3(256), 0, s, (const double *)image, mask, n, keys); break;
+    case 2: hipLaunchKernelGGL(roi_minmax_kernel<int>, dim3(gx), dim3(256), 0, s, (const int *)image, mask, n, keys); break;
+    case 3: hipLaunchKernelGGL(roi_minmax_kernel<short>, dim3(gx), dim3(256), 0, s, (const short *)image, mask, n, keys); break;
+    default: return fail(PRAD_E_ARG, "roi_minmax: dtype %d", dtype);
+  }
+  PRAD_TRY(check_launch("roi_minmax_kernel"));
+  unsigned long long out[2];
+  PRAD_HIP(hipMemcpyAsync(out, keys, sizeof(out), hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  if (out[1] == 0ull) return fail(PRAD_E_ARG, "roi_minmax: empty ROI");
+  minmax[0] = f64_unkey(out[0]);
+  minmax[1] = f64_unkey(out[1]);
+  return PRAD_OK;
+}
+
+int prad_digitize_dev(const void *image, int dtype, const uint8_t *mask, long long n, const double *edges, int nedges,
+                      int32_t *levels, int *max_level, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!image || !mask || !edges || !levels || n < 1 || nedges < 1) return fail(PRAD_E_ARG, "digitize: bad arguments");
+  if ((size_t)nedges * sizeof(double) > 60 * 1024) return fail(PRAD_E_UNSUPPORTED, "digitize: %d edges exceed the LDS table", nedges);
+  hipStream_t s = (hipStream_t)stream;
+  double *e_d = nullptr;
+  int *top = nullptr;
+  PRAD_TRY(c.get<double>("bin_edges", (size_t)nedges, &e_d));
+  PRAD_TRY(c.get<int>("bin_top", 1, &top));
+  PRAD_HIP(hipMemcpyAsync(e_d, edges, sizeof(double) * nedges, hipMemcpyHostToDevice, s));
+  PRAD_HIP(hipMemsetAsync(top, 0, sizeof(int), s));
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+  const size_t lds = sizeof(double) * nedges;
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(digitize_kernel<float>, dim3(gx), dim3(256), lds, s, (const float *)image, mask, n, e_d, nedges, levels, top); break;
+    case 1: hipLaunchKernelGGL(digitize_kernel<double>, dim3(gx), dim3(256), lds, s, (const double *)image, mask, n, e_d, nedges, levels, top); break;
+    case 2: hipLaunchKernelGGL(digitize_kernel<int>, dim3(gx), dim3(256), lds, s, (const int *)image, mask, n, e_d, nedges, levels, top); break;
+    case 3: hipLaunchKernelGGL(digitize_kernel<short>, dim3(gx), dim3(256), lds, s, (const short *)image, mask, n, e_d, nedges, levels, top); break;
+    default: return fail(PRAD_E_ARG, "digitize: dtype %d", dtype);
+  }
+  PRAD_TRY(check_launch("digitize_kernel"));
+  int t = 0;
+  PRAD_HIP(hipMemcpyAsync(&t, top, sizeof(int), hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  if (max_level) *max_level = t;
   return PRAD_OK;
 }
 

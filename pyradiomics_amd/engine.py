@@ -162,3 +162,98 @@ def voxel_glcm_features(image: torch.Tensor, mask: torch.Tensor, Ng: int, voxels
         bad = (empty & anyne[0]) != 0
         res["JointAverage"] = torch.where(bad, torch.full_like(res["JointAverage"], float("nan")), res["JointAverage"])
     return res
+
+
+# ---- device-resident discretisation and filters (config 3: filter stack -> re-binning -> matrices, all in HBM) ---
+_DTYPE_CODES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int16: 3}
+
+
+def _mask_u8(mask: torch.Tensor) -> torch.Tensor:
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
+    return mask.contiguous() if mask.dtype == torch.uint8 else (mask != 0).view(torch.uint8)
+
+
+def bin_image(image: torch.Tensor, mask: torch.Tensor, **kwargs):
+    """imageoperations.binImage + base._applyBinning on the device: returns (levels int32 tensor, Ng, edges).
+    The edges come from pyradiomics_amd.imageoperations.getBinEdges fed with the ROI's (min, max), which is all
+    that function depends on, so levels are identical to the host route."""
+    from . import imageoperations
+    lib = _lib.load()
+    if image.dtype not in _DTYPE_CODES:
+        image = image.to(torch.float64)
+    image = image.contiguous()
+    mask = _mask_u8(mask)
+    rc = lib.prad_set_device(image.device.index or 0)
+    mm = (C.c_double * 2)()
+    n = image.numel()
+    rc = lib.prad_roi_minmax_dev(C.c_void_p(image.data_ptr()), _DTYPE_CODES[image.dtype], C.c_void_p(mask.data_ptr()),
+                                 n, mm, _stream_ptr())
+    _lib.raise_for(rc, "roi_minmax")
+    np_dtype = {torch.float32: np.float32, torch.float64: np.float64, torch.int32: np.int32, torch.int16: np.int16}[image.dtype]
+    edges = np.asarray(imageoperations.getBinEdges(np.array([mm[0], mm[1]], dtype=np_dtype), **kwargs), dtype=np.float64)
+    levels = torch.empty(image.shape, dtype=torch.int32, device=image.device)
+    top = C.c_int(0)
+    rc = lib.prad_digitize_dev(C.c_void_p(image.data_ptr()), _DTYPE_CODES[image.dtype], C.c_void_p(mask.data_ptr()), n,
+                               edges.ctypes.data_as(C.POINTER(C.c_double)), len(edges), C.c_void_p(levels.data_ptr()),
+                               C.byref(top), _stream_ptr())
+    _lib.raise_for(rc, "digitize")
+    return levels, int(top.value), edges
+
+
+def swt_level1(data: torch.Tensor, lo: np.ndarray, hi: np.ndarray, axes) -> torch.Tensor:
+    """pywt.swtn(level=1) on the device: float64 tensor [2^len(axes), *data.shape], sub-bands in key order"""
+    lib = _lib.load()
+    data = data.to(torch.float64).contiguous()
+    lib.prad_set_device(data.device.index or 0)
+    size = np.array(data.shape, dtype=np.intc)
+    ax = np.array(axes, dtype=np.intc)
+    lo = np.ascontiguousarray(lo, dtype=np.float64)
+    hi = np.ascontiguousarray(hi, dtype=np.float64)
+    out = torch.empty((1 << len(ax),) + tuple(data.shape), dtype=torch.float64, device=data.device)
+    rc = lib.prad_swt_level1_dev(C.c_void_p(data.data_ptr()), _iptr(size), data.dim(), C.c_void_p(lo.ctypes.data),
+                                 C.c_void_p(hi.ctypes.data), len(lo), _iptr(ax), len(ax), C.c_void_p(out.data_ptr()),
+                                 _stream_ptr())
+    _lib.raise_for(rc, "swt")
+    return out
+
+
+def wavelet_images(image: torch.Tensor, wavelet="coif1"):
+    """the 8 (2^Nd) level-1 sub-bands of getWaveletImage as {name: float64 tensor}, yield order of the reference"""
+    from .filters import wavelet_filters
+    lo, hi = wavelet_filters(wavelet)
+    x = image.to(torch.float64)
+    shape = x.shape
+    for d, s in enumerate(shape):          # np.pad(..., 'wrap') by one sample on odd axes
+        if s % 2:
+            x = torch.cat([x, x.narrow(d, 0, 1)], dim=d)
+    axes = tuple(range(x.dim() - 1, -1, -1))
+    sub = swt_level1(x, lo, hi, axes)
+    crop = tuple(slice(0, s) for s in shape)
+    keys = [""]
+    for _ in axes:
+        keys = [k + c for k in keys for c in "ad"]
+    out = {}
+    approx = None
+    for i, k in enumerate(keys):
+        name = "wavelet-" + k.replace("a", "L").replace("d", "H")
+        if k == "a" * len(axes):
+            approx = (name, sub[i][crop])
+        else:
+            out[name] = sub[i][crop]
+    out[approx[0]] = approx[1]
+    return out
+
+
+def log_image(image: torch.Tensor, spacing_xyz, sigma: float, normalize: bool = True) -> torch.Tensor:
+    """sitk.LaplacianRecursiveGaussianImageFilter on the device: float32 tensor"""
+    lib = _lib.load()
+    x = image.to(torch.float32).contiguous()
+    lib.prad_set_device(x.device.index or 0)
+    size = np.array(x.shape, dtype=np.intc)
+    sp = np.array([float(s) for s in spacing_xyz][::-1], dtype=np.float64)
+    out = torch.empty_like(x)
+    rc = lib.prad_log_dev(C.c_void_p(x.data_ptr()), _iptr(size), x.dim(), C.c_void_p(sp.ctypes.data), float(sigma),
+                          1 if normalize else 0, C.c_void_p(out.data_ptr()), _stream_ptr())
+    _lib.raise_for(rc, "LoG")
+    return out

@@ -73,3 +73,33 @@ def test_log_properties():
     a = np.random.default_rng(0).standard_normal((16, 16, 16)).astype(np.float32)
     two = filters.laplacian_recursive_gaussian(2 * a, (1, 1, 1), 1.0)
     np.testing.assert_allclose(two, 2 * filters.laplacian_recursive_gaussian(a, (1, 1, 1), 1.0), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("kw", [dict(binWidth=25), dict(binCount=16), dict(binWidth=0.37)])
+@pytest.mark.parametrize("dtype", ["int16", "float32", "float64"])
+def test_device_binning_equals_host(kw, dtype):
+    """engine.bin_image (ROI min/max + digitize on the device) == imageoperations.binImage (numpy), level for level"""
+    import torch
+    from pyradiomics_amd import engine, imageoperations
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((9, 20, 33)) * 300).astype(dtype)
+    if "binWidth" in kw and kw["binWidth"] < 1 and dtype == "int16":
+        pytest.skip("fractional width on an integer image is not a reference use case")
+    m = rng.random(x.shape) < 0.7
+    want, edges = imageoperations.binImage(x, m, **kw)
+    got, Ng, e2 = engine.bin_image(torch.from_numpy(x).cuda(), torch.from_numpy(m).cuda(), **kw)
+    assert np.array_equal(got.cpu().numpy(), want) and Ng == int(want[m].max())
+    assert np.array_equal(np.asarray(edges, dtype=np.float64), e2)
+
+
+def test_device_resident_filters_equal_host_route():
+    import torch
+    from pyradiomics_amd import engine, filters
+    x = np.random.default_rng(6).integers(0, 900, size=(9, 14, 16)).astype(np.int16)
+    host = {n: im.array for im, n, _ in filters.getWaveletImage(x, None)}
+    dev = engine.wavelet_images(torch.from_numpy(x).cuda())
+    assert list(dev) == list(host)
+    for k in host:
+        assert np.array_equal(dev[k].cpu().numpy(), host[k])
+    a = engine.log_image(torch.from_numpy(x).cuda(), (1.0, 1.0, 2.5), 2.0).cpu().numpy()
+    assert np.array_equal(a, filters.laplacian_recursive_gaussian(x, (1.0, 1.0, 2.5), 2.0))
