@@ -106,6 +106,105 @@ __global__ void __launch_bounds__(256) glszm_merge_kernel(Geo g, const int *__re
   }
 }
 
+// ---- tiled variant (Nd <= 3): zones are first labelled inside 4 x 8 x 64 tiles entirely in LDS, then only voxel
+// pairs that straddle a tile boundary are united in HBM.  Most unions (and all of their retries on large zones)
+// never leave the CU; the global forest starts from one root per (zone, tile) instead of one per voxel.
+#define PRAD_TZ 4
+#define PRAD_TY 8
+#define PRAD_TX 64
+#define PRAD_TVOX (PRAD_TZ * PRAD_TY * PRAD_TX)
+struct Offsets3 {
+  int na;
+  signed char o[32][4];   // backward neighbours only (linear offset < 0), embedded in 3-D
+};
+
+__device__ __forceinline__ int lds_find(volatile int *lab, int i) {
+  int p;
+  while ((p = lab[i]) != i) i = p;
+  return i;
+}
+__device__ __forceinline__ void lds_union(int *lab, int a, int b) {
+  while (true) {
+    a = lds_find(lab, a);
+    b = lds_find(lab, b);
+    if (a == b) return;
+    if (a < b) { int t = a; a = b; b = t; }
+    const int old = atomicMin(lab + a, b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+__global__ void __launch_bounds__(256) glszm_tile_kernel(Offsets3 A, const int *__restrict__ image,
+                                                         const uint8_t *__restrict__ mask, int Nz, int Ny, int Nx,
+                                                         int *__restrict__ labels, unsigned *__restrict__ sizes) {
+  __shared__ int img[PRAD_TVOX];
+  __shared__ int lab[PRAD_TVOX];
+  __shared__ uint8_t msk[PRAD_TVOX];
+  const int tx = (Nx + PRAD_TX - 1) / PRAD_TX, ty = (Ny + PRAD_TY - 1) / PRAD_TY;
+  const int bz = blockIdx.x / (ty * tx), br = blockIdx.x % (ty * tx);
+  const int z0 = bz * PRAD_TZ, y0 = (br / tx) * PRAD_TY, x0 = (br % tx) * PRAD_TX;
+  for (int k = threadIdx.x; k < PRAD_TVOX; k += blockDim.x) {
+    const int lx = k % PRAD_TX, ly = (k / PRAD_TX) % PRAD_TY, lz = k / (PRAD_TX * PRAD_TY);
+    const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
+    const bool in = z < Nz && y < Ny && x < Nx;
+    const long long gi = ((long long)z * Ny + y) * Nx + x;
+    const bool m = in && mask[gi] != 0;
+    msk[k] = m;
+    img[k] = m ? image[gi] : 0;
+    lab[k] = k;
+    if (in) sizes[gi] = 0;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < PRAD_TVOX; k += blockDim.x) {
+    if (!msk[k]) continue;
+    const int lx = k % PRAD_TX, ly = (k / PRAD_TX) % PRAD_TY, lz = k / (PRAD_TX * PRAD_TY);
+    const int gl = img[k];
+    for (int a = 0; a < A.na; a++) {
+      const int qz = lz + A.o[a][0], qy = ly + A.o[a][1], qx = lx + A.o[a][2];
+      if ((unsigned)qz >= PRAD_TZ || (unsigned)qy >= PRAD_TY || (unsigned)qx >= PRAD_TX) continue;
+      const int j = (qz * PRAD_TY + qy) * PRAD_TX + qx;
+      if (msk[j] && img[j] == gl) lds_union(lab, k, j);
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < PRAD_TVOX; k += blockDim.x) {
+    const int lx = k % PRAD_TX, ly = (k / PRAD_TX) % PRAD_TY, lz = k / (PRAD_TX * PRAD_TY);
+    const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
+    if (z >= Nz || y >= Ny || x >= Nx) continue;
+    const long long gi = ((long long)z * Ny + y) * Nx + x;
+    if (!msk[k]) { labels[gi] = -1; continue; }
+    const int r = lds_find(lab, k);
+    const int rx = r % PRAD_TX, ry = (r / PRAD_TX) % PRAD_TY, rz = r / (PRAD_TX * PRAD_TY);
+    labels[gi] = (int)(((long long)(z0 + rz) * Ny + (y0 + ry)) * Nx + (x0 + rx));   // local raster order == global order
+  }
+}
+
+// unions across tile boundaries only
+__global__ void __launch_bounds__(256) glszm_border_kernel(Offsets3 A, const int *__restrict__ image,
+                                                           const uint8_t *__restrict__ mask, int Nz, int Ny, int Nx,
+                                                           int *__restrict__ labels) {
+  const long long n = (long long)Nz * Ny * Nx, plane = (long long)Ny * Nx;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int z = (int)(i / plane);
+    const int r = (int)(i - (long long)z * plane);
+    const int y = r / Nx, x = r - y * Nx;
+    // interior voxels of a tile have all their backward neighbours inside the tile
+    const bool edge = (z % PRAD_TZ == 0) || (y % PRAD_TY == 0) || (y % PRAD_TY == PRAD_TY - 1) ||
+                      (x % PRAD_TX == 0) || (x % PRAD_TX == PRAD_TX - 1);
+    if (!edge || !mask[i]) continue;
+    const int gl = image[i];
+    for (int a = 0; a < A.na; a++) {
+      const int qz = z + A.o[a][0], qy = y + A.o[a][1], qx = x + A.o[a][2];
+      if ((unsigned)qz >= (unsigned)Nz || (unsigned)qy >= (unsigned)Ny || (unsigned)qx >= (unsigned)Nx) continue;
+      if (qz / PRAD_TZ == z / PRAD_TZ && qy / PRAD_TY == y / PRAD_TY && qx / PRAD_TX == x / PRAD_TX) continue;
+      const long long j = ((long long)qz * Ny + qy) * Nx + qx;
+      if (mask[j] && image[j] == gl) uf_union(labels, (int)i, (int)j);
+    }
+  }
+}
+
 // label[i] = root(i) and size[root] += 1.  x-adjacent voxels usually share a root, so each wave first collapses
 // runs of equal roots among its lanes and issues one atomic per run instead of one per voxel.
 __global__ void __launch_bounds__(256) glszm_flatten_count_kernel(long long n, int *__restrict__ labels,
@@ -357,10 +456,38 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
     PRAD_TRY(c.get<int>("glszm_labels", (size_t)g.n, &st.labels));
     PRAD_TRY(c.get<unsigned>("glszm_sizes", (size_t)g.n, &st.sizes));
     Timed t(c, "glszm", s);
-    hipLaunchKernelGGL(glszm_init_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, mask, g.n, st.labels, st.sizes);
-    PRAD_TRY(check_launch("glszm_init_kernel"));
-    hipLaunchKernelGGL(glszm_merge_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g, angles_d, Na, image, mask, st.labels);
-    PRAD_TRY(check_launch("glszm_merge_kernel"));
+    // tiled path for <= 3-D volumes whose neighbour offsets are unit steps; generic union-find otherwise
+    Offsets3 A3;
+    A3.na = 0;
+    bool tiled = g.nd <= 3 && Na <= 64;
+    int dims3[3] = {1, 1, 1};
+    for (int d = 0; d < g.nd && tiled; d++) dims3[3 - g.nd + d] = g.size[d];
+    for (int a = 0; a < Na && tiled; a++) {
+      int o[3] = {0, 0, 0};
+      for (int d = 0; d < g.nd; d++) o[3 - g.nd + d] = angles_h[a * g.nd + d];
+      if (o[0] < -1 || o[0] > 1 || o[1] < -1 || o[1] > 1 || o[2] < -1 || o[2] > 1) { tiled = false; break; }
+      const long long lin = ((long long)o[0] * dims3[1] + o[1]) * dims3[2] + o[2];
+      if (lin >= 0) continue;                 // forward neighbour: its pair is handled from the other end
+      if (A3.na >= 32) { tiled = false; break; }
+      for (int d = 0; d < 3; d++) A3.o[A3.na][d] = (signed char)o[d];
+      A3.o[A3.na][3] = 0;
+      A3.na++;
+    }
+    if (tiled) {
+      const long long tiles = (long long)((dims3[0] + PRAD_TZ - 1) / PRAD_TZ) * ((dims3[1] + PRAD_TY - 1) / PRAD_TY) *
+                              ((dims3[2] + PRAD_TX - 1) / PRAD_TX);
+      hipLaunchKernelGGL(glszm_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, s, A3, image, mask, dims3[0], dims3[1],
+                         dims3[2], st.labels, st.sizes);
+      PRAD_TRY(check_launch("glszm_tile_kernel"));
+      hipLaunchKernelGGL(glszm_border_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, A3, image, mask, dims3[0],
+                         dims3[1], dims3[2], st.labels);
+      PRAD_TRY(check_launch("glszm_border_kernel"));
+    } else {
+      hipLaunchKernelGGL(glszm_init_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, mask, g.n, st.labels, st.sizes);
+      PRAD_TRY(check_launch("glszm_init_kernel"));
+      hipLaunchKernelGGL(glszm_merge_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g, angles_d, Na, image, mask, st.labels);
+      PRAD_TRY(check_launch("glszm_merge_kernel"));
+    }
     hipLaunchKernelGGL(glszm_flatten_count_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g.n, st.labels, st.sizes);
     PRAD_TRY(check_launch("glszm_flatten_count_kernel"));
     hipLaunchKernelGGL(glszm_stats_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g.n, st.labels, st.sizes, stats,
