@@ -151,6 +151,15 @@ int prad_fill_glszm_dev(double *glszm, int Nvox, int Ng, int maxRegion, void *st
  * (level,size pairs in raster order of each zone's first voxel, terminated by -1; cmatrices.c:255-276).
  * tempData must hold 2*nzones_v+1 ints; returns nzones_v or PRAD_E_*. */
 long long prad_glszm_zones(int v, int *tempData, long long capacity_pairs);
+/* Optional, segment mode: the matrix with its empty size columns already removed -- what glszm.py:118-131 keeps
+ * (`jvector`, `np.delete(P_glszm, emptyZoneSizes, 2)`).  The reference layout [Ng][maxRegion] is almost all
+ * zeros once zones are large (maxRegion in the millions for a smooth 256^3 volume, a few thousand distinct sizes).
+ * prad_glszm_sizes: the distinct zone sizes of the preceding phase-1 call, ascending, into the HOST array `sizes`
+ *   (capacity entries; at most min(maxRegion, sqrt(2 Nvoxels) + 1) are needed); returns their number k or PRAD_E_*.
+ * prad_fill_glszm_compact_dev: glszm float64 [Ng][k] (DEVICE pointer), column c counting the zones of size
+ *   sizes[c]; PRAD_OK / PRAD_INDEX_ERROR as prad_fill_glszm. */
+int prad_glszm_sizes(int *sizes, int capacity);
+int prad_fill_glszm_compact_dev(double *glszm, int Ng, int nsizes, void *stream);
 
 /* ---- fused voxel-based GLCM feature maps (no reference analogue at this boundary) ---------------------------
  * For every centre voxel the GLCM of its kernel window is built and reduced to the requested features on the
@@ -181,10 +190,15 @@ int prad_voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, cons
  * prad_roi_minmax_dev: minmax[0..1] (HOST doubles) = min / max of image over mask != 0; PRAD_E_ARG if the ROI is empty.
  * prad_digitize_dev:   levels[i] = number of edges <= image[i] (np.digitize) where mask != 0, else 0;
  *                      `edges` is a HOST array of nedges ascending float64 values (getBinEdges output);
- *                      *max_level (HOST int) receives the largest level written (= Ng of base.py:121-124). */
+ *                      *max_level (HOST int) receives the largest level written (= Ng of base.py:121-124).
+ * prad_level_counts_dev: counts[g] (HOST int64, Ng + 1 entries) = number of ROI voxels with level g for g in 1..Ng
+ *                      (which levels are present = `grayLevels` of base.py:120-122, their sum = Ns of glszm.py:84);
+ *                      counts[0] = ROI voxels whose level is outside 1..Ng. */
 int prad_roi_minmax_dev(const void *image, int dtype, const uint8_t *mask, long long n, double *minmax, void *stream);
 int prad_digitize_dev(const void *image, int dtype, const uint8_t *mask, long long n, const double *edges, int nedges,
                       int32_t *levels, int *max_level, void *stream);
+int prad_level_counts_dev(const int32_t *levels, const uint8_t *mask, long long n, int Ng, long long *counts,
+                          void *stream);
 
 /* ---- filter stack in front of the matrices (radiomics/imageoperations.py:756-970) ---------------------------
  * The arithmetic of both filters lives in third-party wheels (PyWavelets, SimpleITK/ITK) that are not part of

@@ -10,7 +10,7 @@ import traceback
 import numpy as np
 
 from . import backend, imageoperations
-from .image import Image, as_array
+from .image import Image, as_array, as_image
 
 
 def deprecated(func):
@@ -31,9 +31,14 @@ class RadiomicsFeaturesBase:
         self.enabledFeatures = {}
         self.featureValues = {}
         self.featureNames = self.getFeatureNames()
-        self.inputImage = inputImage if hasattr(inputImage, "GetSpacing") else Image(as_array(inputImage))
-        self.inputMask = inputMask if hasattr(inputMask, "GetSpacing") else Image(as_array(inputMask))
-        self.imageArray = as_array(self.inputImage)
+        self.inputImage = as_image(inputImage)
+        self.inputMask = as_image(inputMask)
+        # Segment mode keeps the volume in HBM from here on (upload once, bin on the device, matrices through the
+        # _dev entry points); only the finished matrices come back.  `deviceResident: False` takes the host-array
+        # route of the reference (numpy binning, host pointers handed to the operator module).
+        self.deviceResident = (not self.voxelBased and bool(kwargs.get("deviceResident", True))
+                               and getattr(self.cMatrices, "DEVICE_TENSORS", False))
+        self.imageArray = self.inputImage.device_tensor() if self.deviceResident else as_array(self.inputImage)
         if self.voxelBased:
             self._initVoxelBasedCalculation()
         else:
@@ -41,7 +46,10 @@ class RadiomicsFeaturesBase:
 
     # -- initialisation (base.py:93-125) -------------------------------------------------------------
     def _initSegmentBasedCalculation(self):
-        self.maskArray = as_array(self.inputMask) == self.label
+        if self.deviceResident:
+            self.maskArray = imageoperations.roiTensor(self.inputMask, self.label)
+        else:
+            self.maskArray = as_array(self.inputMask) == self.label
 
     def _initVoxelBasedCalculation(self):
         self.masked = self.settings.get("maskedKernel", True)
@@ -54,10 +62,29 @@ class RadiomicsFeaturesBase:
         pass
 
     def _applyBinning(self, matrix):
+        if self.deviceResident:
+            return self._applyBinningDevice(matrix)
         matrix, _ = imageoperations.binImage(matrix, self.maskArray, **self.settings)
         self.coefficients["grayLevels"] = np.unique(matrix[self.maskArray])
         self.coefficients["Ng"] = int(np.max(self.coefficients["grayLevels"]))
         return matrix
+
+    def _applyBinningDevice(self, tensor):
+        """binImage + grey-level bookkeeping in HBM (prad_roi_minmax_dev / prad_digitize_dev / prad_level_counts_dev).
+        All feature classes of one derived image share the result: the reference re-bins per class (base.py:119-125)."""
+        from . import engine
+        key = ("levels", self.settings.get("binWidth", 25), self.settings.get("binCount"), id(self.maskArray))
+        memo = self.inputImage._derived
+        if key not in memo:
+            levels, top, edges = engine.bin_image(tensor, self.maskArray, **self.settings)
+            counts = engine.level_counts(levels, self.maskArray, top)
+            levels._prad_memo = {"mask": self.maskArray}      # lets cMatrices serve GLCM and GLRLM from one sweep
+            memo[key] = (levels, np.flatnonzero(counts[1:]) + 1, int(counts[1:].sum()), self.maskArray)
+        levels, grayLevels, Ns, _ = memo[key]
+        self.coefficients["grayLevels"] = grayLevels
+        self.coefficients["Ng"] = int(grayLevels.max())
+        self.coefficients["Ns"] = Ns
+        return levels
 
     @property
     def cMatrices(self):

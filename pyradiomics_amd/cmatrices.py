@@ -8,8 +8,10 @@ include/pyradiomics_amd.h (ctypes).  A reference checkout sw
     import radiomics, pyradiomics_amd.cmatrices
     radiomics.cMatrices = pyradiomics_amd.cmatrices          # the one line at radiomics/__init__.py:348
 
-Inputs are numpy arrays (host); the device-resident entry points used by the benchmark and the batch /
-voxel drivers live in pyradiomics_amd.engine.
+Inputs are numpy arrays (host) as in the reference.  In segment mode the same functions also accept torch tensors
+that already live in HBM (`DEVICE_TENSORS`): nothing is staged through the host and only the finished matrix comes
+back as numpy, which is how pyradiomics_amd's own feature classes call them (pyradiomics_amd/base.py).  The
+lower-level device-resident entry points live in pyradiomics_amd.engine.
 """
 from __future__ import annotations
 
@@ -20,6 +22,40 @@ import numpy as np
 from . import _lib
 
 _ip = C.POINTER(C.c_int)
+
+DEVICE_TENSORS = True     # calculate_* accept device tensors in segment mode (checked by pyradiomics_amd.base)
+
+
+def _on_device(x):
+    return hasattr(x, "data_ptr") and getattr(x, "is_cuda", False)
+
+
+def _memo(image, mask):
+    """per-levels-tensor memo used to serve GLCM and GLRLM from one fused sweep; only active on tensors that
+    pyradiomics_amd.base tagged (`_prad_memo`), keyed by the mask they were tagged with"""
+    memo = getattr(image, "_prad_memo", None)
+    if memo is None or memo.get("mask") is not mask:
+        return None
+    return memo
+
+
+def _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, want):
+    """distance-1 GLCM / GLRLM of device tensors through the fused sweep"""
+    from . import engine
+    f2d = int(force2Ddimension) if force2D else -1
+    Nr = int(max(image.shape))
+    memo = _memo(image, mask)
+    key = ("pairs_runs", int(Ng), f2d)
+    if memo is not None and key in memo:
+        return memo[key]
+    both = memo is not None
+    g, r, angles = engine.glcm_glrlm(image, mask, int(Ng), Nr, force2D, force2Ddimension,
+                                     want_glcm=both or want == "glcm", want_glrlm=both or want == "glrlm")
+    res = {"glcm": None if g is None else g.cpu().numpy()[None], "glrlm": None if r is None else r.cpu().numpy()[None],
+           "angles": angles}
+    if memo is not None:
+        memo[key] = res
+    return res
 
 
 def _iptr(a):
@@ -87,6 +123,14 @@ def _common(image, mask, distances, bidirectional, force2D, force2Ddimension, ke
 
 def calculate_glcm(image, mask, distances, Ng, force2D, force2Ddimension, kernelRadius=0, voxels=None):
     """-> (P float64 [Nvox, Ng, Ng, Na], angles int32 [Na, Nd]);  _cmatrices.c:84-233"""
+    if _on_device(image) and voxels is None:
+        from . import engine
+        dist = [int(d) for d in np.asarray(distances).ravel()]
+        if dist == [1]:
+            res = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glcm")
+            return res["glcm"], res["angles"]
+        P, angles = engine.glcm(image, mask, int(Ng), dist, force2D, force2Ddimension)
+        return P.cpu().numpy()[None], angles
     img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, distances, False, force2D, force2Ddimension,
                                                      kernelRadius, voxels)
     Na, Nd = angles.shape
@@ -99,6 +143,13 @@ def calculate_glcm(image, mask, distances, Ng, force2D, force2Ddimension, kernel
 
 def calculate_glrlm(image, mask, Ng, Nr, force2D, force2Ddimension, kernelRadius=0, voxels=None):
     """-> (P float64 [Nvox, Ng, Nr, Na], angles);  _cmatrices.c:432-581 (distances fixed to [1])"""
+    if _on_device(image) and voxels is None:
+        if int(Nr) == int(max(image.shape)):
+            res = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glrlm")
+            return res["glrlm"], res["angles"]
+        from . import engine
+        _, r, angles = engine.glcm_glrlm(image, mask, int(Ng), int(Nr), force2D, force2Ddimension, want_glcm=False)
+        return r.cpu().numpy()[None], angles
     img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, None, False, force2D, force2Ddimension,
                                                      kernelRadius, voxels)
     Na, Nd = angles.shape
@@ -126,6 +177,10 @@ def calculate_glcm_glrlm(image, mask, Ng, Nr, force2D, force2Ddimension, kernelR
 
 def calculate_gldm(image, mask, distances, Ng, alpha, force2D, force2Ddimension, kernelRadius=0, voxels=None):
     """-> P float64 [Nvox, Ng, 2*Na+1] (Na = bidirectional angle count);  _cmatrices.c:731-880"""
+    if _on_device(image) and voxels is None:
+        from . import engine
+        return engine.gldm(image, mask, int(Ng), int(alpha), [int(d) for d in np.asarray(distances).ravel()], force2D,
+                           force2Ddimension).cpu().numpy()[None]
     img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, distances, True, force2D, force2Ddimension,
                                                      kernelRadius, voxels)
     Na, Nd = angles.shape
@@ -138,6 +193,10 @@ def calculate_gldm(image, mask, distances, Ng, alpha, force2D, force2Ddimension,
 
 def calculate_ngtdm(image, mask, distances, Ng, force2D, force2Ddimension, kernelRadius=0, voxels=None):
     """-> P float64 [Nvox, Ng, 3];  _cmatrices.c:583-729"""
+    if _on_device(image) and voxels is None:
+        from . import engine
+        return engine.ngtdm(image, mask, int(Ng), [int(d) for d in np.asarray(distances).ravel()], force2D,
+                            force2Ddimension).cpu().numpy()[None]
     img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, distances, True, force2D, force2Ddimension,
                                                      kernelRadius, voxels)
     Na, Nd = angles.shape
@@ -151,6 +210,9 @@ def calculate_ngtdm(image, mask, distances, Ng, force2D, force2Ddimension, kerne
 def calculate_glszm(image, mask, Ng, Ns, force2D, force2Ddimension, kernelRadius=0, voxels=None):
     """-> P float64 [Nvox, Ng, maxRegion], last axis cropped to the largest zone found (>= 1);
     _cmatrices.c:235-430.  The input mask is not modified (the reference works on a private copy)."""
+    if _on_device(image) and voxels is None:
+        from . import engine
+        return engine.glszm(image, mask, int(Ng), int(Ns), force2D, force2Ddimension).cpu().numpy()[None]
     img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, None, True, force2D, force2Ddimension,
                                                      kernelRadius, voxels)
     Na, Nd = angles.shape
@@ -169,6 +231,20 @@ def calculate_glszm(image, mask, Ng, Ns, force2D, force2Ddimension, kernelRadius
         raise IndexError("Error filling GLSZM.")
     _lib.raise_for(rc, "GLSZM")
     return out
+
+
+def calculate_glszm_compact(image, mask, Ng, Ns, force2D, force2Ddimension):
+    """Segment-mode GLSZM with the all-zero size columns left out (no reference analogue at this boundary; it is
+    the matrix glszm.py:118-131 ends up with).  -> (P float64 [1, Ng, k], sizes int32 [k] ascending).
+    Host arrays are uploaded; device tensors are used in place."""
+    import torch
+    from . import engine
+    if not _on_device(image):
+        img, msk, _ = _parse_arrays(image, mask)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        image, mask = torch.from_numpy(img).to(dev), torch.from_numpy(msk).to(dev)
+    P, sizes = engine.glszm_compact(image, mask, int(Ng), int(Ns), force2D, force2Ddimension)
+    return P.cpu().numpy()[None], sizes
 
 
 def generate_angles(size, distances, bidirectional, force2D, force2Ddimension):

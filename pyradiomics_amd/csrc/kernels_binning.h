@@ -70,4 +70,32 @@ __global__ void __launch_bounds__(256) digitize_kernel(const T *__restrict__ x, 
   if ((threadIdx.x & 63) == 0 && top) atomicMax(maxlevel, top);
 }
 
+// ROI voxel count per level: per-wave private LDS tables when Ng fits (the common case), global atomics otherwise
+__global__ void __launch_bounds__(256) level_counts_kernel(const int *__restrict__ levels,
+                                                           const uint8_t *__restrict__ mask, long long n, int Ng,
+                                                           int use_lds, unsigned long long *__restrict__ counts) {
+  extern __shared__ unsigned int sh[];
+  const int nb = Ng + 1;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < 4 * nb; i += blockDim.x) sh[i] = 0u;
+    __syncthreads();
+  }
+  unsigned int *mine = sh + (threadIdx.x >> 6) * nb;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (!mask[i]) continue;
+    const int lv = levels[i];
+    const int b = (lv >= 1 && lv <= Ng) ? lv : 0;
+    if (use_lds) atomicAdd(mine + b, 1u);
+    else atomicAdd(counts + b, 1ull);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+      const unsigned int v = sh[i] + sh[nb + i] + sh[2 * nb + i] + sh[3 * nb + i];
+      if (v) atomicAdd(counts + i, (unsigned long long)v);
+    }
+  }
+}
+
 }  // namespace prad

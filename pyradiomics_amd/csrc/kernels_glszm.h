@@ -32,6 +32,7 @@ struct GlszmState {
   long long boxmax = 0;
   long long nzones = 0;
   int max_region = 0;
+  int nsizes = -1;                 // segment: distinct zone sizes found by glszm_distinct_sizes (-1 = not run)
   const int32_t *image = nullptr;  // segment mode: levels are read from the image at fill time
   int *labels = nullptr;           // segment: [n] root label or -1
   unsigned *sizes = nullptr;       // segment: [n] zone size at root index
@@ -272,6 +273,44 @@ __global__ void glszm_fill_segment_kernel(long long n, const int *__restrict__ l
       continue;
     }
     atomicAdd(out + idx, 1.0);
+  }
+}
+
+// compact fill (segment mode): the reference's [Ng][maxRegion] layout is almost entirely zero columns when zones are
+// large (a smooth 256^3 volume has maxRegion in the millions but only a few thousand distinct sizes -- at most
+// sqrt(2 n) since distinct sizes sum to <= n).  mark: collect the distinct sizes; rank: size -> column; fill.
+__global__ void glszm_mark_sizes_kernel(long long n, const int *__restrict__ labels, const unsigned *__restrict__ sizes,
+                                        unsigned *__restrict__ flags, int *__restrict__ uniq, int cap,
+                                        int *__restrict__ nuniq) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (labels[i] != (int)i) continue;
+    const unsigned sz = sizes[i];
+    if (__builtin_nontemporal_load(flags + sz)) continue;
+    if (atomicExch(flags + sz, 1u) == 0u) {
+      const int pos = atomicAdd(nuniq, 1);
+      if (pos < cap) uniq[pos] = (int)sz;
+    }
+  }
+}
+__global__ void glszm_rank_sizes_kernel(int k, const int *__restrict__ sorted, unsigned *__restrict__ flags) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < k) flags[sorted[r]] = (unsigned)r;
+}
+__global__ void glszm_fill_compact_kernel(long long n, const int *__restrict__ labels,
+                                          const unsigned *__restrict__ sizes, const int *__restrict__ image, int Ng,
+                                          int k, const unsigned *__restrict__ rank, double *__restrict__ out,
+                                          int *__restrict__ err) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (labels[i] != (int)i) continue;
+    const int gl = image[i];
+    const unsigned r = rank[sizes[i]];
+    if (gl <= 0 || gl > Ng || r >= (unsigned)k) {
+      *err = 1;
+      continue;
+    }
+    atomicAdd(out + (size_t)(gl - 1) * k + r, 1.0);
   }
 }
 
@@ -533,6 +572,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
   st.nvox = Nvox;
   st.device = c.device;
   st.max_region = stats_h[0];
+  st.nsizes = -1;
   st.nzones = (long long)*(unsigned long long *)(stats_h + 2);
   st.valid = true;
   if (nzones_out) *nzones_out = st.nzones;
@@ -560,6 +600,65 @@ inline int glszm_fill(Context &c, hipStream_t s, double *out_dev, int Nvox, int 
     hipLaunchKernelGGL(glszm_fill_voxel_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, st.nvox,
                        st.boxmax, st.zones, st.zone_count, Ng, maxRegion, out_dev, err);
     PRAD_TRY(check_launch("glszm_fill_voxel_kernel"));
+  }
+  void *hp = nullptr;
+  PRAD_TRY(c.get_pinned("glszm_err_h", sizeof(int) * 4, &hp));
+  PRAD_HIP(hipMemcpyAsync(hp, err, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  return ((int *)hp)[0] ? PRAD_INDEX_ERROR : PRAD_OK;
+}
+
+// distinct zone sizes of the preceding segment-mode phase-1 call, ascending, to the host; the size -> column map
+// stays on the device for glszm_fill_compact
+inline int glszm_distinct_sizes(Context &c, int *sizes_host, int cap) {
+  GlszmState &st = glszm_state();
+  if (!st.valid || st.device != c.device) return fail(PRAD_E_ARG, "prad_glszm_sizes without a preceding prad_calculate_glszm");
+  if (st.voxel_mode) return fail(PRAD_E_UNSUPPORTED, "prad_glszm_sizes: segment mode only");
+  if (!sizes_host || cap < 1) return fail(PRAD_E_ARG, "prad_glszm_sizes: bad buffer");
+  hipStream_t s = c.own_stream;
+  unsigned *flags = nullptr;
+  int *uniq = nullptr, *nuniq = nullptr;
+  const size_t nf = (size_t)st.max_region + 2;
+  PRAD_TRY(c.get<unsigned>("glszm_flags", nf, &flags));
+  PRAD_TRY(c.get<int>("glszm_uniq", (size_t)cap, &uniq));
+  PRAD_TRY(c.get<int>("glszm_nuniq", 1, &nuniq));
+  PRAD_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * nf, s));
+  PRAD_HIP(hipMemsetAsync(nuniq, 0, sizeof(int), s));
+  hipLaunchKernelGGL(glszm_mark_sizes_kernel, dim3(glszm_grid(st.g.n)), dim3(256), 0, s, st.g.n, st.labels, st.sizes,
+                     flags, uniq, cap, nuniq);
+  PRAD_TRY(check_launch("glszm_mark_sizes_kernel"));
+  int k = 0;
+  PRAD_HIP(hipMemcpyAsync(&k, nuniq, sizeof(int), hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  if (k > cap) return fail(PRAD_E_ARG, "prad_glszm_sizes: %d distinct sizes exceed capacity %d", k, cap);
+  if (k) {
+    PRAD_HIP(hipMemcpyAsync(sizes_host, uniq, sizeof(int) * k, hipMemcpyDeviceToHost, s));
+    PRAD_HIP(hipStreamSynchronize(s));
+    std::sort(sizes_host, sizes_host + k);
+    PRAD_HIP(hipMemcpyAsync(uniq, sizes_host, sizeof(int) * k, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(glszm_rank_sizes_kernel, dim3((k + 255) / 256), dim3(256), 0, s, k, uniq, flags);
+    PRAD_TRY(check_launch("glszm_rank_sizes_kernel"));
+    PRAD_HIP(hipStreamSynchronize(s));
+  }
+  st.nsizes = k;
+  return k;
+}
+
+inline int glszm_fill_compact(Context &c, hipStream_t s, double *out_dev, int Ng, int k) {
+  GlszmState &st = glszm_state();
+  if (!st.valid || st.device != c.device || st.voxel_mode || st.nsizes < 0)
+    return fail(PRAD_E_ARG, "prad_fill_glszm_compact without a preceding prad_glszm_sizes");
+  if (k != st.nsizes) return fail(PRAD_E_ARG, "fill_glszm_compact: k=%d but %d distinct sizes were found", k, st.nsizes);
+  int *err = nullptr;
+  unsigned *flags = nullptr;
+  PRAD_TRY(c.get<int>("glszm_err", 4, &err));
+  PRAD_TRY(c.get<unsigned>("glszm_flags", (size_t)st.max_region + 2, &flags));
+  PRAD_HIP(hipMemsetAsync(err, 0, sizeof(int) * 4, s));
+  PRAD_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)Ng * std::max(k, 1), s));
+  if (k) {
+    hipLaunchKernelGGL(glszm_fill_compact_kernel, dim3(glszm_grid(st.g.n)), dim3(256), 0, s, st.g.n, st.labels, st.sizes,
+                       st.image, Ng, k, flags, out_dev, err);
+    PRAD_TRY(check_launch("glszm_fill_compact_kernel"));
   }
   void *hp = nullptr;
   PRAD_TRY(c.get_pinned("glszm_err_h", sizeof(int) * 4, &hp));

@@ -1123,6 +1123,27 @@ int prad_digitize_dev(const void *image, int dtype, const uint8_t *mask, long lo
   return PRAD_OK;
 }
 
+int prad_level_counts_dev(const int32_t *levels, const uint8_t *mask, long long n, int Ng, long long *counts,
+                          void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!levels || !mask || !counts || n < 1 || Ng < 1) return fail(PRAD_E_ARG, "level_counts: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long *d = nullptr;
+  const size_t nb = (size_t)Ng + 1;
+  PRAD_TRY(c.get<unsigned long long>("level_counts", nb, &d));
+  PRAD_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long) * nb, s));
+  // per-block partial sums are 32-bit: a block sees at most n / grid voxels, bounded below 2^32 by the grid size
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+  const int use_lds = 4 * nb * sizeof(unsigned) <= 48 * 1024;
+  hipLaunchKernelGGL(level_counts_kernel, dim3(gx), dim3(256), use_lds ? 4 * nb * sizeof(unsigned) : 0, s, levels, mask,
+                     n, Ng, use_lds, d);
+  PRAD_TRY(check_launch("level_counts_kernel"));
+  PRAD_HIP(hipMemcpyAsync(counts, d, sizeof(long long) * nb, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  return PRAD_OK;
+}
+
 // ---- filters ---------------------------------------------------------------------------------
 int prad_swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi,
                         int flen, const int *axes, int naxes, double *out, void *stream) {
@@ -1165,6 +1186,18 @@ int prad_log(const float *in, const int *size, int Nd, const double *spacing, do
   PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * n, hipMemcpyDeviceToHost, c.own_stream));
   PRAD_HIP(hipStreamSynchronize(c.own_stream));
   return PRAD_OK;
+}
+
+int prad_glszm_sizes(int *sizes, int capacity) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  return glszm_distinct_sizes(c, sizes, capacity);
+}
+int prad_fill_glszm_compact_dev(double *glszm, int Ng, int nsizes, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!glszm || Ng < 1 || nsizes < 0) return fail(PRAD_E_ARG, "bad fill_glszm_compact arguments");
+  return glszm_fill_compact(c, (hipStream_t)stream, glszm, Ng, nsizes);
 }
 
 long long prad_glszm_zones(int v, int *tempData, long long capacity_pairs) {

@@ -64,6 +64,21 @@ def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None 
     return out_glcm, out_glrlm, angles
 
 
+def glcm(image: torch.Tensor, mask: torch.Tensor, Ng: int, distances=(1,), force2D: bool = False,
+         force2Ddimension: int = 0):
+    """GLCM [Ng, Ng, Na] float64 on the device for arbitrary distances (segment mode).  Returns (glcm, angles)."""
+    lib, image, mask, size = _prep(image, mask)
+    f2d = int(force2Ddimension) if force2D else -1
+    angles = _build_angles(size, list(distances), False, f2d)
+    Na, Nd = angles.shape
+    out = torch.empty((Ng, Ng, Na), dtype=torch.float64, device=image.device)
+    rc = lib.prad_calculate_glcm_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
+                                     _iptr(angles), Na, int(Ng), 1, None, 0, f2d, C.c_void_p(out.data_ptr()),
+                                     _stream_ptr())
+    _lib.raise_for(rc, "GLCM")
+    return out, angles
+
+
 def last_device_ms() -> float:
     return float(_lib.load().prad_last_device_ms())
 
@@ -133,6 +148,37 @@ def glszm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Ns: int | None = Non
     return out
 
 
+def glszm_compact(image: torch.Tensor, mask: torch.Tensor, Ng: int, Ns: int | None = None, force2D: bool = False,
+                  force2Ddimension: int = 0):
+    """GLSZM without its empty size columns: (P float64 [Ng, k] on the device, sizes int32 numpy [k] ascending),
+    P[:, c] counting the zones of sizes[c].  Equals glszm(...)[:, sizes - 1]; this is what the feature class keeps
+    after glszm.py:118-131, without ever materialising the [Ng, maxRegion] layout."""
+    lib, image, mask, size, f2d, angles = _neigh_common(image, mask, None, force2D, force2Ddimension)
+    Na, Nd = angles.shape
+    if Ns is None:
+        Ns = int(mask.sum().item())
+    nz = C.c_longlong(0)
+    rc = lib.prad_calculate_glszm_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
+                                      _iptr(angles), Na, int(Ng), int(Ns), 1, None, 0, f2d, C.byref(nz),
+                                      _stream_ptr())
+    if rc == _lib.PRAD_E_INDEX:
+        raise IndexError("Calculation of GLSZM Failed.")
+    if rc < 0:
+        _lib.raise_for(rc, "GLSZM")
+    maxRegion = max(int(rc), 1)
+    cap = int(min(maxRegion, int(np.sqrt(2.0 * image.numel())) + 2))
+    sizes = np.empty(cap, dtype=np.intc)
+    k = lib.prad_glszm_sizes(_iptr(sizes), cap)
+    if k < 0:
+        _lib.raise_for(k, "GLSZM sizes")
+    out = torch.empty((Ng, max(k, 1)), dtype=torch.float64, device=image.device)
+    rc = lib.prad_fill_glszm_compact_dev(C.c_void_p(out.data_ptr()), int(Ng), int(k), _stream_ptr())
+    if rc == _lib.PRAD_INDEX_ERROR:
+        raise IndexError("Error filling GLSZM.")
+    _lib.raise_for(rc, "GLSZM")
+    return out[:, :k], sizes[:k].copy()
+
+
 def voxel_glcm_features(image: torch.Tensor, mask: torch.Tensor, Ng: int, voxels: torch.Tensor, features,
                         kernelRadius: int = 1, force2D: bool = False, force2Ddimension: int = 0,
                         symmetrical: bool = True, distances=(1,)):
@@ -199,6 +245,19 @@ def bin_image(image: torch.Tensor, mask: torch.Tensor, **kwargs):
                                C.byref(top), _stream_ptr())
     _lib.raise_for(rc, "digitize")
     return levels, int(top.value), edges
+
+
+def level_counts(levels: torch.Tensor, mask: torch.Tensor, Ng: int) -> np.ndarray:
+    """int64 [Ng + 1]: ROI voxels per grey level 1..Ng ([0] = ROI voxels with a level outside that range)"""
+    lib = _lib.load()
+    levels = levels.contiguous()
+    mask = _mask_u8(mask)
+    lib.prad_set_device(levels.device.index or 0)
+    counts = np.zeros(int(Ng) + 1, dtype=np.int64)
+    rc = lib.prad_level_counts_dev(C.c_void_p(levels.data_ptr()), C.c_void_p(mask.data_ptr()), levels.numel(), int(Ng),
+                                   counts.ctypes.data_as(C.POINTER(C.c_longlong)), _stream_ptr())
+    _lib.raise_for(rc, "level_counts")
+    return counts
 
 
 def swt_level1(data: torch.Tensor, lo: np.ndarray, hi: np.ndarray, axes) -> torch.Tensor:

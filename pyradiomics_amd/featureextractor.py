@@ -18,8 +18,8 @@ from itertools import chain
 
 import numpy as np
 
-from . import __version__, filters, imageoperations
-from .image import Image, as_array, read_nrrd
+from . import __version__, backend, filters, imageoperations
+from .image import Image, as_array, as_image, read_nrrd
 
 logger = logging.getLogger(__name__)
 
@@ -150,10 +150,10 @@ class RadiomicsFeatureExtractor:
         def load(x):
             if isinstance(x, (str, os.PathLike)):
                 return read_nrrd(os.fspath(x))
-            return x if isinstance(x, Image) else Image(as_array(x))
+            return as_image(x)
         image, mask = load(imageFilepath), load(maskFilepath)
-        if image.array.shape != mask.array.shape:
-            raise ValueError("Image/Mask geometry mismatch: %s vs %s" % (image.array.shape, mask.array.shape))
+        if image.shape != mask.shape:
+            raise ValueError("Image/Mask geometry mismatch: %s vs %s" % (image.shape, mask.shape))
         return image, mask
 
     def execute(self, imageFilepath, maskFilepath, label=None, label_channel=None, voxelBased=False):
@@ -170,18 +170,28 @@ class RadiomicsFeatureExtractor:
             kernelRadius = s.get("kernelRadius", 1)
         out = collections.OrderedDict()
         image, mask = self.loadImage(imageFilepath, maskFilepath, **s)
-        roi = mask.array == label
-        if not roi.any():
-            raise ValueError("Label (%g) not present in mask" % label)
+        # Segment-based extraction keeps the case in HBM: one upload of image + mask, then filters, crop,
+        # discretisation and the matrices all work on device tensors (`deviceResident: False` restores the
+        # host-array route of the reference; voxel-based extraction batches host coordinates and uses it too).
+        on_dev = (bool(s.get("deviceResident", True)) and not voxelBased
+                  and getattr(backend.get(), "DEVICE_TENSORS", False))
+        s["deviceResident"] = on_dev
         if s.get("resegmentRange") is not None:
+            if not np.any(mask.array == label):
+                raise ValueError("Label (%g) not present in mask" % label)
             mask = imageoperations.resegmentMask(image, mask, **s)
-            roi = mask.array == label
-        lo, hi = imageoperations.boundingBox(roi)
+        roi = imageoperations.roiTensor(mask, label) if on_dev else (mask.array == label)
+        try:
+            lo, hi = imageoperations.boundingBox(roi)
+        except ValueError:
+            raise ValueError("Label (%g) not present in mask" % label)
+        mask._derived[("bbox", label)] = (lo, hi)
+        nroi = int(roi.sum())
         ndims = int(np.sum(hi - lo + 1 > 1))
         if ndims < s.get("minimumROIDimensions", 2):
             raise ValueError("mask has too few dimensions (number of dimensions %d, minimum required %d)"
                              % (ndims, s.get("minimumROIDimensions", 2)))
-        if s.get("minimumROISize") is not None and roi.sum() <= s["minimumROISize"]:
+        if s.get("minimumROISize") is not None and nroi <= s["minimumROISize"]:
             raise ValueError("Size of the ROI is too small (minimum size: %g)" % s["minimumROISize"])
         if s.get("additionalInfo", True):
             out["diagnostics_Versions_PyRadiomicsAMD"] = __version__
@@ -192,14 +202,15 @@ class RadiomicsFeatureExtractor:
             out["diagnostics_Image-original_Size"] = image.GetSize()
             out["diagnostics_Mask-original_BoundingBox"] = tuple(int(v) for v in lo[::-1]) + \
                 tuple(int(v) for v in (hi - lo + 1)[::-1])
-            out["diagnostics_Mask-original_VoxelNum"] = int(roi.sum())
+            out["diagnostics_Mask-original_VoxelNum"] = nroi
         gens = []
         for imageType, custom in self.enabledImagetypes.items():
             args = s.copy()
             args.update(custom)
             gens = chain(gens, _IMAGE_TYPES[imageType](image, mask, **args))
         for derived, typeName, kw in gens:
-            cimg, cmask = imageoperations.cropToTumorMask(derived, mask, label, padDistance=kernelRadius)
+            cimg, cmask = imageoperations.cropToTumorMask(derived, mask, label, padDistance=kernelRadius,
+                                                          deviceResident=on_dev)
             out.update(self.computeFeatures(cimg, cmask, typeName, **kw))
         return out
 

@@ -15,7 +15,7 @@ import logging
 import numpy as np
 
 from . import _lib
-from .image import Image, as_array
+from .image import Image, as_array, as_image
 
 logger = logging.getLogger(__name__)
 
@@ -83,19 +83,54 @@ def _swt3(array, axes, **kwargs):
     return data[crop], ret
 
 
+def _swt3_device(x, axes, **kwargs):
+    """_swt3 with every intermediate in HBM: x and all results are torch tensors on the device"""
+    import torch
+    from . import engine
+    lo, hi = wavelet_filters(kwargs.get("wavelet", "coif1"))
+    level = kwargs.get("level", 1)
+    start_level = kwargs.get("start_level", 0)
+    shape = tuple(x.shape)
+    data = x.to(torch.float64)
+    for d, n in enumerate(shape):                      # np.pad(..., 'wrap') by one sample on odd axes
+        if n % 2:
+            data = torch.cat([data, data.narrow(d, 0, 1)], dim=d)
+    crop = tuple(slice(0, n) for n in shape)
+    keys = [""]
+    for _ in axes:
+        keys = [k + c for k in keys for c in "ad"]
+    approx_idx = keys.index("a" * len(axes))
+    for _ in range(start_level):
+        data = engine.swt_level1(data, lo, hi, axes)[approx_idx]
+    ret = []
+    for _ in range(start_level, start_level + level):
+        sub = engine.swt_level1(data, lo, hi, axes)
+        data = sub[approx_idx]
+        ret.append({k.replace("a", "L").replace("d", "H"): sub[i][crop] for i, k in enumerate(keys) if i != approx_idx})
+    return data[crop], ret
+
+
 def getWaveletImage(inputImage, inputMask, **kwargs):
-    """imageoperations.py:839-896"""
-    arr = as_array(inputImage)
-    ref = inputImage if isinstance(inputImage, Image) else Image(arr)
-    axes = list(range(arr.ndim - 1, -1, -1))
+    """imageoperations.py:839-896.  By default the sub-bands stay in HBM (Images backed by device tensors; `.array`
+    downloads on demand); `deviceResident=False` hands host arrays through prad_swt_level1 instead."""
+    ref = as_image(inputImage)
+    nd = len(ref.shape)
+    axes = list(range(nd - 1, -1, -1))
     if kwargs.get("force2D", False):
         axes.remove(kwargs.get("force2Ddimension", 0))
-    approx, ret = _swt3(arr, tuple(axes), **kwargs)
+    on_dev = kwargs.get("deviceResident", True)
+    if on_dev:
+        approx, ret = _swt3_device(ref.device_tensor(), tuple(axes), **kwargs)
+    else:
+        approx, ret = _swt3(ref.array, tuple(axes), **kwargs)
+
+    def wrap(a):
+        return ref.like(tensor=a) if on_dev else ref.like(a)
     for idx, wl in enumerate(ret, start=1):
         for name, dec in wl.items():
-            yield ref.like(dec), ("wavelet-%s" % name if idx == 1 else "wavelet%d-%s" % (idx, name)), kwargs
+            yield wrap(dec), ("wavelet-%s" % name if idx == 1 else "wavelet%d-%s" % (idx, name)), kwargs
     tail = "L" * len(axes)
-    yield ref.like(approx), ("wavelet-%s" % tail if len(ret) == 1 else "wavelet%d-%s" % (len(ret), tail)), kwargs
+    yield wrap(approx), ("wavelet-%s" % tail if len(ret) == 1 else "wavelet%d-%s" % (len(ret), tail)), kwargs
 
 
 def laplacian_recursive_gaussian(array, spacing_xyz, sigma, normalize=True):
@@ -113,8 +148,8 @@ def laplacian_recursive_gaussian(array, spacing_xyz, sigma, normalize=True):
 
 def getLoGImage(inputImage, inputMask, **kwargs):
     """imageoperations.py:756-836"""
-    arr = as_array(inputImage)
-    ref = inputImage if isinstance(inputImage, Image) else Image(arr)
+    ref = as_image(inputImage)
+    on_dev = kwargs.get("deviceResident", True)
     size = np.array(ref.GetSize())
     spacing = np.array(ref.GetSpacing())
     if np.min(size) < 4:
@@ -124,7 +159,11 @@ def getLoGImage(inputImage, inputMask, **kwargs):
         if sigma > 0.0:
             if np.all(size >= np.ceil(sigma / spacing) + 1):
                 name = "log-sigma-%s-mm-3D" % str(sigma).replace(".", "-")
-                yield ref.like(laplacian_recursive_gaussian(arr, spacing, sigma, True)), name, kwargs
+                if on_dev:
+                    from . import engine
+                    yield ref.like(tensor=engine.log_image(ref.device_tensor(), spacing, sigma, True)), name, kwargs
+                else:
+                    yield ref.like(laplacian_recursive_gaussian(ref.array, spacing, sigma, True)), name, kwargs
             else:
                 logger.warning("applyLoG: sigma(%s)/spacing(%s) + 1 must be greater than the size(%s) of the inputImage",
                                sigma, spacing, size)

@@ -67,17 +67,23 @@ class RadiomicsGLSZM(_ZoneLikeFeatures):
 
     def _calculateMatrix(self, voxelCoordinates=None):
         Ng = self.coefficients["Ng"]
-        Ns = np.sum(self.maskArray)
+        Ns = self.coefficients["Ns"] if self.deviceResident else np.sum(self.maskArray)
         args = [self.imageArray, self.maskArray, Ng, Ns, self.settings.get("force2D", False),
                 self.settings.get("force2Ddimension", 0)]
-        P = self.cMatrices.calculate_glszm(*(args + self._matrix_tail(voxelCoordinates)))
+        self._sizes = None
+        compact = getattr(self.cMatrices, "calculate_glszm_compact", None)
+        if compact is not None and not self.voxelBased and self.settings.get("compactGLSZM", True):
+            # only the non-empty size columns (what _calculateCoefficients keeps anyway), straight from the device
+            P, self._sizes = compact(*args)
+        else:
+            P = self.cMatrices.calculate_glszm(*(args + self._matrix_tail(voxelCoordinates)))
         return np.delete(P, self._absent_levels(), 1)
 
     def _calculateCoefficients(self):
         P = self.P_glszm
         ps = np.sum(P, 1)
         pg = np.sum(P, 2)
-        j = np.arange(1, P.shape[2] + 1, dtype=np.float64)
+        j = np.arange(1, P.shape[2] + 1, dtype=np.float64) if self._sizes is None else self._sizes.astype(np.float64)
         Nz = np.sum(P, (1, 2))
         Nz[Nz == 0] = 1
         Np = np.sum(ps * j[None, :], 1)

@@ -19,14 +19,49 @@ _NRRD_TYPES = {
 
 
 class Image:
-    """array: numpy (z, y, x); spacing/origin: (x, y, z) tuples; direction: 9 floats row-major."""
+    """A volume with SimpleITK-style geometry.  Storage is a numpy array (z, y, x) on the host, a torch tensor in
+    HBM, or both: `array` downloads on first use, `device_tensor()` uploads on first use, so a derived image made
+    on the device (filter output, crop) never touches the host unless somebody asks for `.array`.
+    spacing/origin: (x, y, z) tuples; direction: Nd*Nd floats row-major."""
 
-    def __init__(self, array, spacing=None, origin=None, direction=None):
-        self.array = np.asarray(array)
-        nd = self.array.ndim
+    def __init__(self, array=None, spacing=None, origin=None, direction=None, tensor=None):
+        if array is None and tensor is None:
+            raise ValueError("Image needs an array or a device tensor")
+        self._array = None if array is None else np.asarray(array)
+        self._tensor = tensor
+        nd = len(self.shape)
         self.spacing = tuple(float(s) for s in (spacing if spacing is not None else (1.0,) * nd))
         self.origin = tuple(float(s) for s in (origin if origin is not None else (0.0,) * nd))
         self.direction = tuple(direction) if direction is not None else tuple(np.eye(nd).ravel())
+        self._derived = {}           # per-image memo of device-side products (ROI, bounding box, levels)
+
+    @property
+    def array(self):
+        if self._array is None:
+            self._array = self._tensor.cpu().numpy()
+        return self._array
+
+    @property
+    def shape(self):
+        return tuple(self._array.shape) if self._array is not None else tuple(self._tensor.shape)
+
+    @property
+    def on_device(self):
+        return self._tensor is not None
+
+    def device_tensor(self, device=None):
+        """the volume as a torch tensor in HBM (uploaded once, original dtype; 64-bit integers narrow to int32
+        as the operator boundary does, _cmatrices.c:1027)"""
+        import torch
+        if self._tensor is None:
+            a = np.ascontiguousarray(self._array)
+            if a.dtype in (np.uint16, np.uint32, np.uint64, np.int64):
+                a = a.astype(np.int32) if (a.size == 0 or (a.min() >= -2**31 and a.max() < 2**31)) else a.astype(np.float64)
+            elif a.dtype == np.uint8 or a.dtype == np.int8:
+                a = a.astype(np.int16)
+            dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+            self._tensor = torch.from_numpy(a).to(dev, non_blocking=False)
+        return self._tensor
 
     # the SimpleITK-style accessors the feature classes call
     def GetSpacing(self):
@@ -39,14 +74,25 @@ class Image:
         return self.direction
 
     def GetSize(self):
-        return tuple(int(s) for s in self.array.shape[::-1])
+        return tuple(int(s) for s in self.shape[::-1])
 
     def GetDimension(self):
-        return self.array.ndim
+        return len(self.shape)
 
-    def like(self, array):
+    def like(self, array=None, tensor=None):
         """new Image with this one's geometry (sitk CopyInformation, base.py:240-245)"""
-        return Image(array, self.spacing, self.origin, self.direction)
+        return Image(array, self.spacing, self.origin, self.direction, tensor=tensor)
+
+
+def as_image(obj):
+    """Image view of an Image / array-like / SimpleITK-like object (geometry kept where available)"""
+    if isinstance(obj, Image):
+        return obj
+    if hasattr(obj, "GetSpacing") and not isinstance(obj, np.ndarray):
+        return Image(as_array(obj), obj.GetSpacing(), obj.GetOrigin(), obj.GetDirection())
+    if hasattr(obj, "data_ptr"):
+        return Image(tensor=obj)
+    return Image(np.asarray(obj))
 
 
 def as_array(obj):
@@ -56,6 +102,8 @@ def as_array(obj):
     if hasattr(obj, "GetSpacing") and not isinstance(obj, np.ndarray):   # a real SimpleITK image
         import SimpleITK as sitk  # pragma: no cover - optional
         return sitk.GetArrayFromImage(obj)
+    if hasattr(obj, "data_ptr"):
+        return obj.cpu().numpy()
     return np.asarray(obj)
 
 

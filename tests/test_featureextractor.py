@@ -73,3 +73,37 @@ def test_extractor_filters_feed_matrices_on_gpu():
     assert len(keys) == (8 + 2) * 3
     assert "wavelet-LLH_glcm_JointEntropy" in res and "log-sigma-3-0-mm-3D_glrlm_RunEntropy" in res
     assert all(np.isfinite(float(res[k])) for k in keys)
+
+
+@pytest.mark.gpu
+def test_device_resident_route_equals_host_array_route():
+    """The default route (case kept in HBM: filters -> crop -> binning -> matrices on device tensors) must give
+    exactly the numbers of the reference-shaped route (numpy binning, host arrays through the operator module)."""
+    from pyradiomics_amd import backend, cmatrices
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    backend.set(cmatrices)
+    params = {"setting": {"binWidth": 25}, "imageType": {"Original": {}, "Wavelet": {}, "LoG": {"sigma": [2.0]}}}
+    dev = RadiomicsFeatureExtractor(params).execute(IMG, LBL)
+    params["setting"]["deviceResident"] = False
+    host = RadiomicsFeatureExtractor(params).execute(IMG, LBL)
+    keys = [k for k in host if not k.startswith("diagnostics")]
+    assert len(keys) == (1 + 8 + 1) * (24 + 16 + 16 + 14 + 5) and set(keys) <= set(dev)
+    for k in keys:
+        a, b = float(dev[k]), float(host[k])
+        assert a == b or (np.isnan(a) and np.isnan(b)), (k, a, b)
+    assert dev["diagnostics_Mask-original_BoundingBox"] == host["diagnostics_Mask-original_BoundingBox"]
+
+
+@pytest.mark.gpu
+def test_device_resident_binning_modes_and_resegmentation():
+    from pyradiomics_amd import backend, cmatrices
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    backend.set(cmatrices)
+    for setting in ({"binCount": 16}, {"binWidth": 10, "force2D": True},
+                    {"binWidth": 25, "resegmentRange": [-1, 1], "resegmentMode": "sigma"}, {"binWidth": 25, "distances": [1, 2]}):
+        dev = RadiomicsFeatureExtractor({"setting": dict(setting)}).execute(IMG, LBL)
+        host = RadiomicsFeatureExtractor({"setting": dict(setting, deviceResident=False)}).execute(IMG, LBL)
+        for k in host:
+            if not k.startswith("diagnostics"):
+                a, b = float(dev[k]), float(host[k])
+                assert a == b or (np.isnan(a) and np.isnan(b)), (setting, k, a, b)

@@ -220,3 +220,51 @@ def test_gldm_ngtdm_packed_byte_path(cm, oracle_port, shape, frac):
             b = oracle_port.calculate_ngtdm(img, mask, [1], Ng, force2D, f2d)
             assert np.array_equal(a[..., 0], b[..., 0]) and np.array_equal(a[..., 2], b[..., 2])
             np.testing.assert_allclose(a[..., 1], b[..., 1], rtol=1e-12, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,smooth", [((24, 40, 33), False), ((48, 64, 80), True), ((1, 50, 70), True)])
+def test_glszm_compact_equals_dense(shape, smooth):
+    """prad_glszm_sizes + prad_fill_glszm_compact_dev == the non-empty columns of the reference-layout matrix"""
+    import torch
+    from pyradiomics_amd import engine, cmatrices
+    rng = np.random.default_rng(11)
+    if smooth:
+        import scipy.ndimage as ndi
+        f = ndi.gaussian_filter(rng.standard_normal(shape), 2.0)
+        img = (1 + np.floor((f - f.min()) / (np.ptp(f) + 1e-9) * 6)).astype(np.int32)
+    else:
+        img = rng.integers(1, 6, shape).astype(np.int32)
+    mask = rng.random(shape) < 0.9
+    dense = cmatrices.calculate_glszm(img, mask, 8, int(mask.sum()), False, 0)[0]
+    P, sizes = engine.glszm_compact(torch.from_numpy(img).cuda(), torch.from_numpy(mask).cuda(), 8, int(mask.sum()))
+    cols = np.flatnonzero(dense.sum(0))
+    assert np.array_equal(sizes, cols + 1)
+    assert np.array_equal(P.cpu().numpy(), dense[:, cols])
+    P2, sizes2 = cmatrices.calculate_glszm_compact(img, mask, 8, int(mask.sum()), False, 0)
+    assert np.array_equal(P2[0], dense[:, cols]) and np.array_equal(sizes2, sizes)
+
+
+@pytest.mark.gpu
+def test_level_counts_and_tensor_inputs_of_the_operator_module():
+    import torch
+    from pyradiomics_amd import engine, cmatrices
+    rng = np.random.default_rng(5)
+    shape = (20, 31, 45)
+    img = rng.integers(0, 12, shape).astype(np.int32)          # level 0 and levels > Ng under the mask -> counts[0]
+    mask = rng.random(shape) < 0.7
+    ti, tm = torch.from_numpy(img).cuda(), torch.from_numpy(mask).cuda()
+    counts = engine.level_counts(ti, tm, 9)
+    want = np.bincount(np.where((img >= 1) & (img <= 9), img, 0)[mask], minlength=10)
+    assert np.array_equal(counts, want)
+    img = np.maximum(img, 1)
+    ti = torch.from_numpy(img).cuda()
+    for d in ([1], [1, 2]):
+        a, ang_a = cmatrices.calculate_glcm(ti, tm, np.array(d), 11, False, 0)
+        b, ang_b = cmatrices.calculate_glcm(img, mask, np.array(d), 11, False, 0)
+        assert np.array_equal(a, b) and np.array_equal(ang_a, ang_b)
+    assert np.array_equal(cmatrices.calculate_glrlm(ti, tm, 11, 45, True, 0)[0], cmatrices.calculate_glrlm(img, mask, 11, 45, True, 0)[0])
+    assert np.array_equal(cmatrices.calculate_glrlm(ti, tm, 11, 60, False, 0)[0], cmatrices.calculate_glrlm(img, mask, 11, 60, False, 0)[0])
+    assert np.array_equal(cmatrices.calculate_gldm(ti, tm, np.array([1]), 11, 1, False, 0), cmatrices.calculate_gldm(img, mask, np.array([1]), 11, 1, False, 0))
+    assert np.array_equal(cmatrices.calculate_ngtdm(ti, tm, np.array([1]), 11, False, 0), cmatrices.calculate_ngtdm(img, mask, np.array([1]), 11, False, 0))
+    assert np.array_equal(cmatrices.calculate_glszm(ti, tm, 11, int(mask.sum()), False, 0), cmatrices.calculate_glszm(img, mask, 11, int(mask.sum()), False, 0))
