@@ -33,6 +33,12 @@ struct GlszmState {
   long long nzones = 0;
   int max_region = 0;
   int nsizes = -1;                 // segment: distinct zone sizes found by glszm_distinct_sizes (-1 = not run)
+  int nsmall = 0, nlarge = 0;      //   ... of which below / at or above PRAD_SMALL_SIZES
+  unsigned *small_bits = nullptr;  // segment: bitmap of the zone sizes < PRAD_SMALL_SIZES that occur
+  int *large_list = nullptr;       // segment: every zone size >= PRAD_SMALL_SIZES (unsorted, with repeats)
+  int *large_count = nullptr;
+  int large_cap = 0;
+  int *small_rank = nullptr;       // segment, after glszm_distinct_sizes: size -> compact column
   const int32_t *image = nullptr;  // segment mode: levels are read from the image at fill time
   int *labels = nullptr;           // segment: [n] root label or -1
   unsigned *sizes = nullptr;       // segment: [n] zone size at root index
@@ -110,7 +116,7 @@ __global__ void __launch_bounds__(256) glszm_merge_kernel(Geo g, const int *__re
 // ---- tiled variant (Nd <= 3): zones are first labelled inside 4 x 8 x 64 tiles entirely in LDS, then only voxel
 // pairs that straddle a tile boundary are united in HBM.  Most unions (and all of their retries on large zones)
 // never leave the CU; the global forest starts from one root per (zone, tile) instead of one per voxel.
-#define PRAD_TZ 4
+#define PRAD_TZ 8
 #define PRAD_TY 8
 #define PRAD_TX 64
 #define PRAD_TVOX (PRAD_TZ * PRAD_TY * PRAD_TX)
@@ -154,7 +160,6 @@ __global__ void __launch_bounds__(256) glszm_tile_kernel(Offsets3 A, const int *
     msk[k] = m;
     img[k] = m ? image[gi] : 0;
     lab[k] = k;
-    if (in) sizes[gi] = 0;
   }
   __syncthreads();
   for (int k = threadIdx.x; k < PRAD_TVOX; k += blockDim.x) {
@@ -169,40 +174,101 @@ __global__ void __launch_bounds__(256) glszm_tile_kernel(Offsets3 A, const int *
     }
   }
   __syncthreads();
-  for (int k = threadIdx.x; k < PRAD_TVOX; k += blockDim.x) {
+  // flatten inside the tile and count each local component: img[] is reused for the counts (its levels are no
+  // longer needed), runs of equal roots among the lanes of a wave issue one LDS atomic
+  int root[PRAD_TVOX / 256];
+#pragma unroll
+  for (int q = 0; q < PRAD_TVOX / 256; q++) {
+    const int k = threadIdx.x + q * 256;
+    root[q] = msk[k] ? lds_find(lab, k) : -1;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < PRAD_TVOX; k += blockDim.x) img[k] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < PRAD_TVOX / 256; q++) {
+    const int r = root[q];
+    int left = __shfl_up(r, 1);
+    if (lane == 0) left = -2;
+    const unsigned long long B = __ballot(r != left || lane == 0);
+    if (r >= 0 && r != left) {
+      const unsigned long long above = lane == 63 ? 0ull : (B >> (lane + 1));
+      atomicAdd((unsigned *)img + r, (unsigned)(above ? __ffsll((long long)above) : 64 - lane));
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PRAD_TVOX / 256; q++) {
+    const int k = threadIdx.x + q * 256;
     const int lx = k % PRAD_TX, ly = (k / PRAD_TX) % PRAD_TY, lz = k / (PRAD_TX * PRAD_TY);
     const int z = z0 + lz, y = y0 + ly, x = x0 + lx;
     if (z >= Nz || y >= Ny || x >= Nx) continue;
     const long long gi = ((long long)z * Ny + y) * Nx + x;
-    if (!msk[k]) { labels[gi] = -1; continue; }
-    const int r = lds_find(lab, k);
+    const int r = root[q];
+    if (r < 0) { labels[gi] = -1; sizes[gi] = 0; continue; }
     const int rx = r % PRAD_TX, ry = (r / PRAD_TX) % PRAD_TY, rz = r / (PRAD_TX * PRAD_TY);
     labels[gi] = (int)(((long long)(z0 + rz) * Ny + (y0 + ry)) * Nx + (x0 + rx));   // local raster order == global order
+    sizes[gi] = r == k ? (unsigned)img[k] : 0u;     // voxels of the local component, kept at its (tile) root
   }
 }
 
-// unions across tile boundaries only
+// unions across tile boundaries only.  The union runs between the two tile roots (labels[] of a non-root voxel is
+// one hop from its tile root and is never rewritten), and a lane whose (root, root) pair repeats its left
+// neighbour's -- the usual case along a face shared by two large components -- skips the union altogether.
 __global__ void __launch_bounds__(256) glszm_border_kernel(Offsets3 A, const int *__restrict__ image,
                                                            const uint8_t *__restrict__ mask, int Nz, int Ny, int Nx,
                                                            int *__restrict__ labels) {
   const long long n = (long long)Nz * Ny * Nx, plane = (long long)Ny * Nx;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int z = (int)(i / plane);
-    const int r = (int)(i - (long long)z * plane);
-    const int y = r / Nx, x = r - y * Nx;
-    // interior voxels of a tile have all their backward neighbours inside the tile
-    const bool edge = (z % PRAD_TZ == 0) || (y % PRAD_TY == 0) || (y % PRAD_TY == PRAD_TY - 1) ||
-                      (x % PRAD_TX == 0) || (x % PRAD_TX == PRAD_TX - 1);
-    if (!edge || !mask[i]) continue;
-    const int gl = image[i];
-    for (int a = 0; a < A.na; a++) {
-      const int qz = z + A.o[a][0], qy = y + A.o[a][1], qx = x + A.o[a][2];
-      if ((unsigned)qz >= (unsigned)Nz || (unsigned)qy >= (unsigned)Ny || (unsigned)qx >= (unsigned)Nx) continue;
-      if (qz / PRAD_TZ == z / PRAD_TZ && qy / PRAD_TY == y / PRAD_TY && qx / PRAD_TX == x / PRAD_TX) continue;
-      const long long j = ((long long)qz * Ny + qy) * Nx + qx;
-      if (mask[j] && image[j] == gl) uf_union(labels, (int)i, (int)j);
+  const long long nround = ((n + stride - 1) / stride) * stride;      // whole waves stay in the loop for the shuffles
+  const int lane = threadIdx.x & 63;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
+    int z = 0, y = 0, x = 0, gl = 0, li = -1;
+    if (i < n) {
+      z = (int)(i / plane);
+      const int r = (int)(i - (long long)z * plane);
+      y = r / Nx;
+      x = r - y * Nx;
+      // interior voxels of a tile have all their backward neighbours inside the tile
+      const bool edge = (z % PRAD_TZ == 0) || (y % PRAD_TY == 0) || (y % PRAD_TY == PRAD_TY - 1) ||
+                        (x % PRAD_TX == 0) || (x % PRAD_TX == PRAD_TX - 1);
+      if (edge && mask[i]) {
+        gl = image[i];
+        li = labels[i];
+      }
     }
+    if (__ballot(li >= 0) == 0ull) continue;
+    for (int a = 0; a < A.na; a++) {
+      int lj = -1;
+      if (li >= 0) {
+        const int qz = z + A.o[a][0], qy = y + A.o[a][1], qx = x + A.o[a][2];
+        const bool in = (unsigned)qz < (unsigned)Nz && (unsigned)qy < (unsigned)Ny && (unsigned)qx < (unsigned)Nx;
+        const bool same_tile = qz / PRAD_TZ == z / PRAD_TZ && qy / PRAD_TY == y / PRAD_TY && qx / PRAD_TX == x / PRAD_TX;
+        if (in && !same_tile) {
+          const long long j = ((long long)qz * Ny + qy) * Nx + qx;
+          if (mask[j] && image[j] == gl) lj = labels[j];
+        }
+      }
+      const int pi = __shfl_up(li, 1), pj = __shfl_up(lj, 1);
+      if (lj >= 0 && !(lane > 0 && pi == li && pj == lj)) uf_union(labels, li, lj);
+    }
+  }
+}
+
+// tiled path: sizes[] holds the voxel count of every tile-local component at its tile root; fold the counts of
+// tile roots that were linked elsewhere into their global root.  One find per (zone, tile) instead of per voxel.
+__global__ void __launch_bounds__(256) glszm_rootsum_kernel(long long n, int *__restrict__ labels,
+                                                            unsigned *__restrict__ sizes) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const unsigned sz = sizes[i];
+    if (sz == 0u) continue;
+    const int l = labels[i];
+    if (l == (int)i) continue;
+    const int r = uf_find(labels, l);
+    labels[i] = r;
+    atomicAdd(sizes + r, sz);
   }
 }
 
@@ -237,16 +303,36 @@ __global__ void __launch_bounds__(256) glszm_flatten_count_kernel(long long n, i
   }
 }
 
-// stats[0] = max zone size, stats64[0] = zone count
-__global__ void glszm_stats_kernel(long long n, const int *__restrict__ labels, const unsigned *__restrict__ sizes,
-                                   int *__restrict__ stats, unsigned long long *__restrict__ stats64) {
+// stats[0] = max zone size, stats64[0] = zone count.  Also records which zone sizes occur, for the compact fill:
+// sizes below PRAD_SMALL_SIZES in a bitmap (LDS per block, OR-ed out once), the few larger ones (at most
+// n / PRAD_SMALL_SIZES zones) appended to a list.
+#define PRAD_SMALL_SIZES 8192
+__global__ void __launch_bounds__(256) glszm_stats_kernel(long long n, const int *__restrict__ labels,
+                                                          const unsigned *__restrict__ sizes, int *__restrict__ stats,
+                                                          unsigned long long *__restrict__ stats64,
+                                                          unsigned *__restrict__ small_bits, int *__restrict__ large_list,
+                                                          int large_cap, int *__restrict__ large_count) {
+  __shared__ unsigned bits[PRAD_SMALL_SIZES / 32];
+  __shared__ unsigned smx;
+  __shared__ unsigned long long scnt;
+  for (int k = threadIdx.x; k < PRAD_SMALL_SIZES / 32; k += blockDim.x) bits[k] = 0u;
+  if (threadIdx.x == 0) { smx = 0u; scnt = 0ull; }
+  __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
   unsigned mx = 0;
   unsigned long long cnt = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     if (labels[i] == (int)i) {
+      const unsigned sz = sizes[i];
       cnt++;
-      mx = max(mx, sizes[i]);
+      mx = max(mx, sz);
+      if (sz < PRAD_SMALL_SIZES) {
+        const unsigned bit = 1u << (sz & 31);
+        if (!(bits[sz >> 5] & bit)) atomicOr(bits + (sz >> 5), bit);
+      } else {
+        const int pos = atomicAdd(large_count, 1);
+        if (pos < large_cap) large_list[pos] = (int)sz;
+      }
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -254,64 +340,87 @@ __global__ void glszm_stats_kernel(long long n, const int *__restrict__ labels, 
     cnt += __shfl_xor(cnt, o);
   }
   if ((threadIdx.x & 63) == 0 && cnt) {
-    atomicMax(stats, (int)mx);
-    atomicAdd(stats64, cnt);
+    atomicMax(&smx, mx);
+    atomicAdd(&scnt, cnt);
   }
+  __syncthreads();
+  if (threadIdx.x == 0 && scnt) {
+    atomicMax(stats, (int)smx);
+    atomicAdd(stats64, scnt);
+  }
+  for (int k = threadIdx.x; k < PRAD_SMALL_SIZES / 32; k += blockDim.x)
+    if (bits[k]) atomicOr(small_bits + k, bits[k]);
 }
 
-__global__ void glszm_fill_segment_kernel(long long n, const int *__restrict__ labels,
-                                          const unsigned *__restrict__ sizes, const int *__restrict__ image, int Ng,
-                                          int maxRegion, double *__restrict__ out, int *__restrict__ err) {
+// column of a zone size in the compact matrix: table lookup below PRAD_SMALL_SIZES, binary search above
+__device__ __forceinline__ int glszm_rank(unsigned sz, const int *__restrict__ small_rank, int nsmall,
+                                          const int *__restrict__ large_sorted, int nlarge) {
+  if (sz < PRAD_SMALL_SIZES) return small_rank[sz];
+  int lo = 0, hi = nlarge;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((unsigned)large_sorted[mid] < sz) lo = mid + 1;
+    else hi = mid;
+  }
+  return (lo < nlarge && (unsigned)large_sorted[lo] == sz) ? nsmall + lo : -1;
+}
+
+// Zone counts concentrate on the smallest sizes (noise-like volumes have millions of 1..10-voxel zones), so the
+// first RL size columns of every level are accumulated in LDS per block and flushed once; the rest go to HBM.
+__global__ void __launch_bounds__(256) glszm_fill_segment_kernel(long long n, const int *__restrict__ labels,
+                                                                 const unsigned *__restrict__ sizes,
+                                                                 const int *__restrict__ image, int Ng, int maxRegion,
+                                                                 int RL, double *__restrict__ out,
+                                                                 int *__restrict__ err) {
+  extern __shared__ unsigned fh[];
+  for (int k = threadIdx.x; k < Ng * RL; k += blockDim.x) fh[k] = 0u;
+  __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
   const unsigned long long idx_max = (unsigned long long)Ng * maxRegion;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     if (labels[i] != (int)i) continue;
     const int gl = image[i];
-    const unsigned long long idx = (unsigned long long)((long long)(gl - 1) * maxRegion + (long long)sizes[i] - 1);
+    const unsigned sz = sizes[i];
+    const unsigned long long idx = (unsigned long long)((long long)(gl - 1) * maxRegion + (long long)sz - 1);
     if (gl <= 0 || idx >= idx_max) {  // cmatrices.c:290-291
       *err = 1;
       continue;
     }
-    atomicAdd(out + idx, 1.0);
+    if (gl <= Ng && sz >= 1u && sz <= (unsigned)RL) atomicAdd(fh + (gl - 1) * RL + (sz - 1), 1u);
+    else atomicAdd(out + idx, 1.0);
   }
+  __syncthreads();
+  for (int k = threadIdx.x; k < Ng * RL; k += blockDim.x)
+    if (fh[k]) atomicAdd(out + (size_t)(k / RL) * maxRegion + (k % RL), (double)fh[k]);
 }
 
 // compact fill (segment mode): the reference's [Ng][maxRegion] layout is almost entirely zero columns when zones are
 // large (a smooth 256^3 volume has maxRegion in the millions but only a few thousand distinct sizes -- at most
-// sqrt(2 n) since distinct sizes sum to <= n).  mark: collect the distinct sizes; rank: size -> column; fill.
-__global__ void glszm_mark_sizes_kernel(long long n, const int *__restrict__ labels, const unsigned *__restrict__ sizes,
-                                        unsigned *__restrict__ flags, int *__restrict__ uniq, int cap,
-                                        int *__restrict__ nuniq) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (labels[i] != (int)i) continue;
-    const unsigned sz = sizes[i];
-    if (__builtin_nontemporal_load(flags + sz)) continue;
-    if (atomicExch(flags + sz, 1u) == 0u) {
-      const int pos = atomicAdd(nuniq, 1);
-      if (pos < cap) uniq[pos] = (int)sz;
-    }
-  }
-}
-__global__ void glszm_rank_sizes_kernel(int k, const int *__restrict__ sorted, unsigned *__restrict__ flags) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < k) flags[sorted[r]] = (unsigned)r;
-}
-__global__ void glszm_fill_compact_kernel(long long n, const int *__restrict__ labels,
-                                          const unsigned *__restrict__ sizes, const int *__restrict__ image, int Ng,
-                                          int k, const unsigned *__restrict__ rank, double *__restrict__ out,
-                                          int *__restrict__ err) {
+// sqrt(2 n) since distinct sizes sum to <= n).  The distinct sizes come from glszm_stats_kernel's bookkeeping.
+__global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, const int *__restrict__ labels,
+                                                                 const unsigned *__restrict__ sizes,
+                                                                 const int *__restrict__ image, int Ng, int k, int RL,
+                                                                 const int *__restrict__ small_rank, int nsmall,
+                                                                 const int *__restrict__ large_sorted, int nlarge,
+                                                                 double *__restrict__ out, int *__restrict__ err) {
+  extern __shared__ unsigned fh[];
+  for (int q = threadIdx.x; q < Ng * RL; q += blockDim.x) fh[q] = 0u;
+  __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     if (labels[i] != (int)i) continue;
     const int gl = image[i];
-    const unsigned r = rank[sizes[i]];
-    if (gl <= 0 || gl > Ng || r >= (unsigned)k) {
+    const int r = glszm_rank(sizes[i], small_rank, nsmall, large_sorted, nlarge);
+    if (gl <= 0 || gl > Ng || r < 0 || r >= k) {
       *err = 1;
       continue;
     }
-    atomicAdd(out + (size_t)(gl - 1) * k + r, 1.0);
+    if (r < RL) atomicAdd(fh + (gl - 1) * RL + r, 1u);
+    else atomicAdd(out + (size_t)(gl - 1) * k + r, 1.0);
   }
+  __syncthreads();
+  for (int q = threadIdx.x; q < Ng * RL; q += blockDim.x)
+    if (fh[q]) atomicAdd(out + (size_t)(q / RL) * k + (q % RL), (double)fh[q]);
 }
 
 // ordered zone list (tempData parity): block counts -> scan -> scatter
@@ -494,6 +603,12 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
     PRAD_HIP(hipMemcpyAsync(angles_d, angles_h, sizeof(int) * Na * g.nd, hipMemcpyHostToDevice, s));
     PRAD_TRY(c.get<int>("glszm_labels", (size_t)g.n, &st.labels));
     PRAD_TRY(c.get<unsigned>("glszm_sizes", (size_t)g.n, &st.sizes));
+    st.large_cap = (int)(g.n / PRAD_SMALL_SIZES + 2);
+    PRAD_TRY(c.get<unsigned>("glszm_small_bits", PRAD_SMALL_SIZES / 32, &st.small_bits));
+    PRAD_TRY(c.get<int>("glszm_large_list", (size_t)st.large_cap, &st.large_list));
+    PRAD_TRY(c.get<int>("glszm_large_count", 1, &st.large_count));
+    PRAD_HIP(hipMemsetAsync(st.small_bits, 0, PRAD_SMALL_SIZES / 8, s));
+    PRAD_HIP(hipMemsetAsync(st.large_count, 0, sizeof(int), s));
     Timed t(c, "glszm", s);
     // tiled path for <= 3-D volumes whose neighbour offsets are unit steps; generic union-find otherwise
     Offsets3 A3;
@@ -521,16 +636,18 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
       hipLaunchKernelGGL(glszm_border_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, A3, image, mask, dims3[0],
                          dims3[1], dims3[2], st.labels);
       PRAD_TRY(check_launch("glszm_border_kernel"));
+      hipLaunchKernelGGL(glszm_rootsum_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g.n, st.labels, st.sizes);
+      PRAD_TRY(check_launch("glszm_rootsum_kernel"));
     } else {
       hipLaunchKernelGGL(glszm_init_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, mask, g.n, st.labels, st.sizes);
       PRAD_TRY(check_launch("glszm_init_kernel"));
       hipLaunchKernelGGL(glszm_merge_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g, angles_d, Na, image, mask, st.labels);
       PRAD_TRY(check_launch("glszm_merge_kernel"));
+      hipLaunchKernelGGL(glszm_flatten_count_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g.n, st.labels, st.sizes);
+      PRAD_TRY(check_launch("glszm_flatten_count_kernel"));
     }
-    hipLaunchKernelGGL(glszm_flatten_count_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g.n, st.labels, st.sizes);
-    PRAD_TRY(check_launch("glszm_flatten_count_kernel"));
-    hipLaunchKernelGGL(glszm_stats_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g.n, st.labels, st.sizes, stats,
-                       stats64);
+    hipLaunchKernelGGL(glszm_stats_kernel, dim3(std::min(glszm_grid(g.n), 1024u)), dim3(256), 0, s, g.n, st.labels,
+                       st.sizes, stats, stats64, st.small_bits, st.large_list, st.large_cap, st.large_count);
     PRAD_TRY(check_launch("glszm_stats_kernel"));
     st.voxel_mode = false;
     st.image = image;
@@ -592,8 +709,10 @@ inline int glszm_fill(Context &c, hipStream_t s, double *out_dev, int Nvox, int 
   PRAD_HIP(hipMemsetAsync(err, 0, sizeof(int) * 4, s));
   PRAD_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)Nvox * Ng * maxRegion, s));
   if (!st.voxel_mode) {
-    hipLaunchKernelGGL(glszm_fill_segment_kernel, dim3(glszm_grid(st.g.n)), dim3(256), 0, s, st.g.n, st.labels,
-                       st.sizes, st.image, Ng, maxRegion, out_dev, err);
+    const int RL = Ng <= 8192 ? std::max(1, std::min(maxRegion, 8192 / Ng)) : 0;
+    hipLaunchKernelGGL(glszm_fill_segment_kernel, dim3(std::min(glszm_grid(st.g.n), 2048u)), dim3(256),
+                       sizeof(unsigned) * Ng * RL, s, st.g.n, st.labels, st.sizes, st.image, Ng, maxRegion, RL, out_dev,
+                       err);
     PRAD_TRY(check_launch("glszm_fill_segment_kernel"));
   } else {
     const long long threads = (long long)st.nvox * st.boxmax;
@@ -616,31 +735,42 @@ inline int glszm_distinct_sizes(Context &c, int *sizes_host, int cap) {
   if (st.voxel_mode) return fail(PRAD_E_UNSUPPORTED, "prad_glszm_sizes: segment mode only");
   if (!sizes_host || cap < 1) return fail(PRAD_E_ARG, "prad_glszm_sizes: bad buffer");
   hipStream_t s = c.own_stream;
-  unsigned *flags = nullptr;
-  int *uniq = nullptr, *nuniq = nullptr;
-  const size_t nf = (size_t)st.max_region + 2;
-  PRAD_TRY(c.get<unsigned>("glszm_flags", nf, &flags));
-  PRAD_TRY(c.get<int>("glszm_uniq", (size_t)cap, &uniq));
-  PRAD_TRY(c.get<int>("glszm_nuniq", 1, &nuniq));
-  PRAD_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * nf, s));
-  PRAD_HIP(hipMemsetAsync(nuniq, 0, sizeof(int), s));
-  hipLaunchKernelGGL(glszm_mark_sizes_kernel, dim3(glszm_grid(st.g.n)), dim3(256), 0, s, st.g.n, st.labels, st.sizes,
-                     flags, uniq, cap, nuniq);
-  PRAD_TRY(check_launch("glszm_mark_sizes_kernel"));
-  int k = 0;
-  PRAD_HIP(hipMemcpyAsync(&k, nuniq, sizeof(int), hipMemcpyDeviceToHost, s));
+  std::vector<unsigned> bits(PRAD_SMALL_SIZES / 32);
+  int nl = 0;
+  PRAD_HIP(hipMemcpyAsync(bits.data(), st.small_bits, PRAD_SMALL_SIZES / 8, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipMemcpyAsync(&nl, st.large_count, sizeof(int), hipMemcpyDeviceToHost, s));
   PRAD_HIP(hipStreamSynchronize(s));
-  if (k > cap) return fail(PRAD_E_ARG, "prad_glszm_sizes: %d distinct sizes exceed capacity %d", k, cap);
-  if (k) {
-    PRAD_HIP(hipMemcpyAsync(sizes_host, uniq, sizeof(int) * k, hipMemcpyDeviceToHost, s));
+  if (nl > st.large_cap) return fail(PRAD_E_ARG, "prad_glszm_sizes: internal list overflow (%d > %d)", nl, st.large_cap);
+  std::vector<int> large((size_t)nl);
+  if (nl) {
+    PRAD_HIP(hipMemcpyAsync(large.data(), st.large_list, sizeof(int) * nl, hipMemcpyDeviceToHost, s));
     PRAD_HIP(hipStreamSynchronize(s));
-    std::sort(sizes_host, sizes_host + k);
-    PRAD_HIP(hipMemcpyAsync(uniq, sizes_host, sizeof(int) * k, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(glszm_rank_sizes_kernel, dim3((k + 255) / 256), dim3(256), 0, s, k, uniq, flags);
-    PRAD_TRY(check_launch("glszm_rank_sizes_kernel"));
-    PRAD_HIP(hipStreamSynchronize(s));
+    std::sort(large.begin(), large.end());
+    large.erase(std::unique(large.begin(), large.end()), large.end());
   }
+  std::vector<int> rank(PRAD_SMALL_SIZES, -1);
+  int k = 0;
+  for (int sz = 0; sz < PRAD_SMALL_SIZES; sz++)
+    if (bits[sz >> 5] & (1u << (sz & 31))) {
+      if (k < cap) sizes_host[k] = sz;
+      rank[sz] = k++;
+    }
+  const int nsmall = k;
+  for (int v : large) {
+    if (k < cap) sizes_host[k] = v;
+    k++;
+  }
+  if (k > cap) return fail(PRAD_E_ARG, "prad_glszm_sizes: %d distinct sizes exceed capacity %d", k, cap);
+  int *large_d = nullptr;
+  PRAD_TRY(c.get<int>("glszm_small_rank", PRAD_SMALL_SIZES, &st.small_rank));
+  PRAD_TRY(c.get<int>("glszm_large_sorted", large.size() + 1, &large_d));
+  PRAD_HIP(hipMemcpyAsync(st.small_rank, rank.data(), sizeof(int) * PRAD_SMALL_SIZES, hipMemcpyHostToDevice, s));
+  if (!large.empty())
+    PRAD_HIP(hipMemcpyAsync(large_d, large.data(), sizeof(int) * large.size(), hipMemcpyHostToDevice, s));
+  PRAD_HIP(hipStreamSynchronize(s));
   st.nsizes = k;
+  st.nsmall = nsmall;
+  st.nlarge = (int)large.size();
   return k;
 }
 
@@ -649,15 +779,16 @@ inline int glszm_fill_compact(Context &c, hipStream_t s, double *out_dev, int Ng
   if (!st.valid || st.device != c.device || st.voxel_mode || st.nsizes < 0)
     return fail(PRAD_E_ARG, "prad_fill_glszm_compact without a preceding prad_glszm_sizes");
   if (k != st.nsizes) return fail(PRAD_E_ARG, "fill_glszm_compact: k=%d but %d distinct sizes were found", k, st.nsizes);
-  int *err = nullptr;
-  unsigned *flags = nullptr;
+  int *err = nullptr, *large_d = nullptr;
   PRAD_TRY(c.get<int>("glszm_err", 4, &err));
-  PRAD_TRY(c.get<unsigned>("glszm_flags", (size_t)st.max_region + 2, &flags));
+  PRAD_TRY(c.get<int>("glszm_large_sorted", (size_t)st.nlarge + 1, &large_d));
   PRAD_HIP(hipMemsetAsync(err, 0, sizeof(int) * 4, s));
   PRAD_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)Ng * std::max(k, 1), s));
   if (k) {
-    hipLaunchKernelGGL(glszm_fill_compact_kernel, dim3(glszm_grid(st.g.n)), dim3(256), 0, s, st.g.n, st.labels, st.sizes,
-                       st.image, Ng, k, flags, out_dev, err);
+    const int RL = Ng <= 8192 ? std::max(1, std::min(k, 8192 / Ng)) : 0;
+    hipLaunchKernelGGL(glszm_fill_compact_kernel, dim3(std::min(glszm_grid(st.g.n), 2048u)), dim3(256),
+                       sizeof(unsigned) * Ng * RL, s, st.g.n, st.labels, st.sizes, st.image, Ng, k, RL, st.small_rank,
+                       st.nsmall, large_d, st.nlarge, out_dev, err);
     PRAD_TRY(check_launch("glszm_fill_compact_kernel"));
   }
   void *hp = nullptr;
