@@ -200,6 +200,30 @@ int prad_digitize_dev(const void *image, int dtype, const uint8_t *mask, long lo
 int prad_level_counts_dev(const int32_t *levels, const uint8_t *mask, long long n, int Ng, long long *counts,
                           void *stream);
 
+/* ---- first-order statistics of the ROI intensities (radiomics/firstorder.py:33-474; device pointers) -----------
+ * Segment mode.  The reference computes these with numpy on image[mask] (firstorder.py:96-101); here the ROI is
+ * compacted, sorted and reduced on the device and `out` (HOST, PRAD_FO_COUNT doubles) receives the statistics every
+ * feature of the class derives from:
+ *   Np; Energy = sum (x + voxelArrayShift)^2 (:151); Minimum / Maximum (:207,:244); the 10 / 25 / 75 / 90-th
+ *   percentiles and the median with numpy's linear interpolation (:218-231,:268,:282); Mean (:256); mean absolute
+ *   deviation (:308); robust mean absolute deviation over p10 <= x <= p90 (:323-342); central moments m2, m3, m4
+ *   (:136-145, Variance / Skewness / Kurtosis :381-446).
+ * dtype as for prad_digitize_dev.  Entropy / Uniformity come from prad_level_counts_dev on the discretised image. */
+enum { PRAD_FO_NP = 0, PRAD_FO_ENERGY, PRAD_FO_MINIMUM, PRAD_FO_P10, PRAD_FO_P25, PRAD_FO_MEDIAN, PRAD_FO_P75, PRAD_FO_P90,
+       PRAD_FO_MAXIMUM, PRAD_FO_MEAN, PRAD_FO_MAD, PRAD_FO_RMAD, PRAD_FO_M2, PRAD_FO_M3, PRAD_FO_M4, PRAD_FO_COUNT };
+int prad_firstorder_dev(const void *image, int dtype, const uint8_t *mask, long long n, double voxelArrayShift,
+                        double *out, void *stream);
+/* Voxel mode (firstorder.py:37-118,104-118): for each of the Nvox centres (`voxels` DEVICE int32 [Nd][Nvox]) the
+ * window centre + {offsets of infinity-norm <= kernelRadius} -- per dimension limited to |offset| < bbsize[d] (HOST,
+ * the `boundingBoxSize` of firstorder.py:45-58; NULL = no limit) and 0 in the force2D dimension -- is reduced over
+ * its voxels with mask != 0 (the reference's NaN padding / NaN outside the ROI).  levels (discretised image, may
+ * be NULL) feeds Entropy / Uniformity.  feature_ids (HOST) index the feature list in the order of
+ * pyradiomics_amd.firstorder.FEATURES; out is DEVICE float64 [nfeat][Nvox]. */
+int prad_voxel_firstorder_dev(const void *image, int dtype, const uint8_t *mask, const int32_t *levels, const int *size,
+                              int Nd, int Nvox, const int *voxels, int kernelRadius, int force2Ddim, const int *bbsize,
+                              double voxelArrayShift, double voxelVolume, const int *feature_ids, int nfeat, double *out,
+                              void *stream);
+
 /* ---- filter stack in front of the matrices (radiomics/imageoperations.py:756-970) ---------------------------
  * The arithmetic of both filters lives in third-party wheels (PyWavelets, SimpleITK/ITK) that are not part of
  * the reference tree; these entry points implement their published algorithms (see oracle/filters_oracle.py):

@@ -66,6 +66,19 @@ class CMatricesCPU:
             getattr(L, f).restype = C.c_int
         self.L = L
 
+    # -- first-order statistics: the reference computes these in numpy, so does this CPU backend ---------
+    @staticmethod
+    def firstorder_stats(image, mask, voxelArrayShift=0.0):
+        from . import firstorder_oracle
+        return firstorder_oracle.firstorder_stats(image, mask, voxelArrayShift)
+
+    @staticmethod
+    def voxel_firstorder(image, mask, levels, voxels, kernelRadius, bbsize, force2D, force2Ddimension,
+                         voxelArrayShift, voxelVolume, features):
+        from . import firstorder_oracle
+        return firstorder_oracle.voxel_firstorder(image, mask, levels, voxels, kernelRadius, bbsize, force2D,
+                                                  force2Ddimension, voxelArrayShift, voxelVolume, features)
+
     # -- helpers ---------------------------------------------------------------------------
     @staticmethod
     def _arrays(image, mask, copy_mask=False):

@@ -65,7 +65,8 @@ class RadiomicsFeaturesBase:
         if self.deviceResident:
             return self._applyBinningDevice(matrix)
         matrix, _ = imageoperations.binImage(matrix, self.maskArray, **self.settings)
-        self.coefficients["grayLevels"] = np.unique(matrix[self.maskArray])
+        self.coefficients["grayLevels"], self.coefficients["levelCounts"] = np.unique(matrix[self.maskArray],
+                                                                                       return_counts=True)
         self.coefficients["Ng"] = int(np.max(self.coefficients["grayLevels"]))
         return matrix
 
@@ -79,9 +80,11 @@ class RadiomicsFeaturesBase:
             levels, top, edges = engine.bin_image(tensor, self.maskArray, **self.settings)
             counts = engine.level_counts(levels, self.maskArray, top)
             levels._prad_memo = {"mask": self.maskArray}      # lets cMatrices serve GLCM and GLRLM from one sweep
-            memo[key] = (levels, np.flatnonzero(counts[1:]) + 1, int(counts[1:].sum()), self.maskArray)
-        levels, grayLevels, Ns, _ = memo[key]
+            memo[key] = (levels, np.flatnonzero(counts[1:]) + 1, int(counts[1:].sum()), self.maskArray,
+                         counts[1:][counts[1:] > 0])
+        levels, grayLevels, Ns, _, levelCounts = memo[key]
         self.coefficients["grayLevels"] = grayLevels
+        self.coefficients["levelCounts"] = levelCounts
         self.coefficients["Ng"] = int(grayLevels.max())
         self.coefficients["Ns"] = Ns
         return levels

@@ -247,6 +247,47 @@ def calculate_glszm_compact(image, mask, Ng, Ns, force2D, force2Ddimension):
     return P.cpu().numpy()[None], sizes
 
 
+# ---- first-order statistics (no native code in the reference: radiomics/firstorder.py is numpy; here the ROI /
+# ---- the kernels are reduced on the device, see include/pyradiomics_amd.h) ----------------------------------
+FIRSTORDER_FEATURES = ["Energy", "TotalEnergy", "Entropy", "Minimum", "10Percentile", "90Percentile", "Maximum", "Mean",
+                       "Median", "InterquartileRange", "Range", "MeanAbsoluteDeviation",
+                       "RobustMeanAbsoluteDeviation", "RootMeanSquared", "StandardDeviation", "Skewness", "Kurtosis",
+                       "Variance", "Uniformity"]
+
+
+def _to_device(a, integer=False):
+    import torch
+    if _on_device(a):
+        return a
+    a = np.ascontiguousarray(a)
+    if a.dtype == np.bool_:
+        a = a.view(np.uint8)
+    elif integer:
+        a = a.astype(np.intc, copy=False)
+    elif a.dtype not in (np.float32, np.float64, np.int32, np.int16):
+        a = a.astype(np.float64)
+    return torch.from_numpy(a).to(torch.device("cuda", torch.cuda.current_device()))
+
+
+def firstorder_stats(image, mask, voxelArrayShift=0.0):
+    """-> {Np, Energy, Minimum, P10, P25, Median, P75, P90, Maximum, Mean, MAD, rMAD, m2, m3, m4} of image[mask]
+    (numpy arrays are uploaded, device tensors used in place)"""
+    from . import engine
+    return engine.firstorder_stats(_to_device(image), _to_device(mask), voxelArrayShift)
+
+
+def voxel_firstorder(image, mask, levels, voxels, kernelRadius, bbsize, force2D, force2Ddimension, voxelArrayShift,
+                     voxelVolume, features):
+    """-> {feature name: float64 [Nvox]} for the kernels centred on `voxels` (int [Nd, Nvox])"""
+    from . import engine
+    ids = [FIRSTORDER_FEATURES.index(f) for f in features]
+    vox = _to_device(np.ascontiguousarray(np.asarray(voxels).astype(np.intc, copy=False))) if not _on_device(voxels) else voxels
+    out = engine.voxel_firstorder(_to_device(image), _to_device(mask), _to_device(levels, integer=True), vox, ids,
+                                  kernelRadius, force2D, force2Ddimension, bbsize, voxelArrayShift, voxelVolume)
+    out = out.cpu().numpy()
+    return {f: out[i] for i, f in enumerate(features)}
+
+
 def generate_angles(size, distances, bidirectional, force2D, force2Ddimension):
     """-> int32 [Na, Nd];  _cmatrices.c:882-924"""
     size = np.ascontiguousarray(np.asarray(size).astype(np.intc, copy=False))

@@ -1,0 +1,286 @@
+// kernels_firstorder.h -- first-order statistics of the ROI intensities (radiomics/firstorder.py:33-474), segment mode.
+//   fo_compact_kernel   ROI voxels -> dense float64 array (order irrelevant: it is sorted next)
+//   (rocPRIM radix sort of the float64 keys: the order statistics behind the percentile / median / IQR features)
+//   fo_sums_kernel      per-block partial sums of x and (x + c)^2
+//   fo_central_kernel   per-block partial sums of |x - mu|, (x - mu)^2..4 and count / sum of the 10-90 percentile band
+//   fo_band_kernel      per-block partial sums of |x - mu_band| over the band (robust mean absolute deviation)
+// Partials are summed on the host in block order, so results are reproducible run to run.  HBM-bound: 9 B/voxel for
+// the compaction, 8 B per ROI voxel for each of the three reductions, plus the sort.
+#pragma once
+#include "prad_runtime.h"
+
+namespace prad {
+
+#define PRAD_FO_BLOCKS 1024
+
+template <typename T>
+__global__ void __launch_bounds__(256) fo_compact_kernel(const T *__restrict__ x, const uint8_t *__restrict__ mask,
+                                                         long long n, double *__restrict__ vals,
+                                                         unsigned long long *__restrict__ count) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long nround = ((n + stride - 1) / stride) * stride;
+  const int lane = threadIdx.x & 63;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
+    const bool m = i < n && mask[i] != 0;
+    const unsigned long long B = __ballot(m);
+    if (!B) continue;
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(B));
+    base = __shfl(base, 0);
+    if (m) vals[base + __popcll(B & ((1ull << lane) - 1ull))] = (double)x[i];
+  }
+}
+
+__device__ __forceinline__ double fo_block_sum(double v, double *sh) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// partial[b][0] = sum x, partial[b][1] = sum (x + c)^2
+__global__ void __launch_bounds__(256) fo_sums_kernel(const double *__restrict__ v, long long m, double shift,
+                                                      double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double s1 = 0, s2 = 0;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    const double x = v[i], y = x + shift;
+    s1 += x;
+    s2 += y * y;
+  }
+  s1 = fo_block_sum(s1, sh);
+  s2 = fo_block_sum(s2, sh);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 2 + 0] = s1;
+    partial[blockIdx.x * 2 + 1] = s2;
+  }
+}
+
+// partial[b][0..3] = sum |d|, d^2, d^3, d^4 with d = x - mu; [4] = count, [5] = sum of x with lo <= x <= hi
+__global__ void __launch_bounds__(256) fo_central_kernel(const double *__restrict__ v, long long m, double mu, double lo,
+                                                         double hi, double *__restrict__ partial) {
+#pragma clang fp contract(off)
+  __shared__ double sh[4];
+  double a1 = 0, a2 = 0, a3 = 0, a4 = 0, bc = 0, bs = 0;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    const double x = v[i], d = x - mu, d2 = d * d;
+    a1 += fabs(d);
+    a2 += d2;
+    a3 += d2 * d;
+    a4 += d2 * d2;
+    if (x >= lo && x <= hi) {
+      bc += 1.0;
+      bs += x;
+    }
+  }
+  a1 = fo_block_sum(a1, sh);
+  a2 = fo_block_sum(a2, sh);
+  a3 = fo_block_sum(a3, sh);
+  a4 = fo_block_sum(a4, sh);
+  bc = fo_block_sum(bc, sh);
+  bs = fo_block_sum(bs, sh);
+  if (threadIdx.x == 0) {
+    double *p = partial + blockIdx.x * 6;
+    p[0] = a1; p[1] = a2; p[2] = a3; p[3] = a4; p[4] = bc; p[5] = bs;
+  }
+}
+
+__global__ void __launch_bounds__(256) fo_band_kernel(const double *__restrict__ v, long long m, double mu, double lo,
+                                                      double hi, double *__restrict__ partial) {
+  __shared__ double sh[4];
+  double a = 0;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
+    const double x = v[i];
+    if (x >= lo && x <= hi) a += fabs(x - mu);
+  }
+  a = fo_block_sum(a, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+
+// ---- voxel mode (firstorder.py:37-118): one wave per centre voxel ------------------------------------------------
+// The reference gathers, for every centre, the intensities at centre + kernelOffsets from a NaN-padded copy of the
+// image in which non-ROI voxels are NaN, then applies the nan-aware numpy reductions row by row.  Here a 64-lane
+// block loads the window into LDS (invalid slots = +inf, level 0), reduces it with wave shuffles, sorts it with a
+// bitonic network for the order statistics and writes only the requested feature values: no (Nvox, Nk) intermediate.
+struct FoWindow {
+  int nd;
+  int half[PRAD_MAX_ND];     // per-dimension half width: min(kernelRadius, boundingBoxSize - 1), 0 in the force2D dimension
+  int nk;                    // prod(2 half + 1)
+  int P;                     // power of two >= nk (LDS slots)
+};
+
+enum { PRAD_FOF_ENERGY = 0, PRAD_FOF_TOTALENERGY, PRAD_FOF_ENTROPY, PRAD_FOF_MINIMUM, PRAD_FOF_P10, PRAD_FOF_P90,
+       PRAD_FOF_MAXIMUM, PRAD_FOF_MEAN, PRAD_FOF_MEDIAN, PRAD_FOF_IQR, PRAD_FOF_RANGE, PRAD_FOF_MAD, PRAD_FOF_RMAD,
+       PRAD_FOF_RMS, PRAD_FOF_STD, PRAD_FOF_SKEWNESS, PRAD_FOF_KURTOSIS, PRAD_FOF_VARIANCE, PRAD_FOF_UNIFORMITY,
+       PRAD_FOF_COUNT };
+
+__device__ __forceinline__ double fo_wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double fo_quantile(const double *sorted, int m, double q) {
+#pragma clang fp contract(off)
+  const double virt = (double)(m - 1) * q;
+  int prev = (int)floor(virt);
+  const double t = virt - (double)prev;
+  prev = min(max(prev, 0), m - 1);
+  const int next = min(prev + 1, m - 1);
+  const double a = sorted[prev], b = sorted[next], d = b - a;
+  return t >= 0.5 ? b - d * (1 - t) : a + d * t;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) voxel_firstorder_kernel(const T *__restrict__ image,
+                                                              const uint8_t *__restrict__ mask,
+                                                              const int *__restrict__ levels, Geo g, FoWindow w,
+                                                              int nvox, const int *__restrict__ voxels, double shift,
+                                                              double voxel_volume, const int *__restrict__ feature_ids,
+                                                              int nfeat, double *__restrict__ out) {
+#pragma clang fp contract(off)
+  extern __shared__ double fo_lds[];
+  double *val = fo_lds;                 // [P]
+  int *lev = (int *)(fo_lds + w.P);     // [P]
+  const int lane = threadIdx.x;
+  const double INF = __builtin_huge_val();
+  for (int v = blockIdx.x; v < nvox; v += gridDim.x) {
+    __syncthreads();
+    int c[PRAD_MAX_ND];
+    for (int d = 0; d < g.nd; d++) c[d] = voxels[(long long)d * nvox + v];
+    // load the window
+    double s1 = 0, s2 = 0, mn = INF, mx = -INF, cnt = 0;
+    for (int k = lane; k < w.P; k += 64) {
+      double x = INF;
+      int lv = 0;
+      if (k < w.nk) {
+        int rem = k;
+        long long idx = 0;
+        bool in = true;
+        for (int d = g.nd - 1; d >= 0; d--) {
+          const int ext = 2 * w.half[d] + 1;
+          const int q = c[d] + (rem % ext) - w.half[d];
+          rem /= ext;
+          in = in && q >= 0 && q < g.size[d];
+          idx += (long long)q * g.stride[d];
+        }
+        if (in && mask[idx]) {
+          x = (double)image[idx];
+          lv = levels ? levels[idx] : 0;
+          const double y = x + shift;
+          s1 += x;
+          s2 += y * y;
+          mn = fmin(mn, x);
+          mx = fmax(mx, x);
+          cnt += 1.0;
+        }
+      }
+      val[k] = x;
+      lev[k] = lv;
+    }
+    s1 = fo_wave_sum(s1);
+    s2 = fo_wave_sum(s2);
+    cnt = fo_wave_sum(cnt);
+    for (int o = 32; o > 0; o >>= 1) {
+      mn = fmin(mn, __shfl_xor(mn, o));
+      mx = fmax(mx, __shfl_xor(mx, o));
+    }
+    const int m = (int)cnt;
+    const double mu = s1 / cnt;
+    __syncthreads();
+    // central moments, and per-voxel multiplicity of its grey level (entropy / uniformity without a histogram)
+    double a1 = 0, a2 = 0, a3 = 0, a4 = 0, ent = 0, uni = 0;
+    for (int k = lane; k < w.nk; k += 64) {
+      const double x = val[k];
+      if (x == INF) continue;
+      const double d = x - mu, d2 = d * d;
+      a1 += fabs(d);
+      a2 += d2;
+      a3 += d2 * d;
+      a4 += d2 * d2;
+      const int lv = lev[k];
+      int same = 0;
+      for (int j = 0; j < w.nk; j++) same += (lev[j] == lv && val[j] != INF) ? 1 : 0;
+      const double p = (double)same / cnt;
+      ent += log2(p + 2.220446049250313e-16) / cnt;
+      uni += p / cnt;
+    }
+    a1 = fo_wave_sum(a1);
+    a2 = fo_wave_sum(a2);
+    a3 = fo_wave_sum(a3);
+    a4 = fo_wave_sum(a4);
+    ent = -fo_wave_sum(ent);
+    uni = fo_wave_sum(uni);
+    // bitonic sort of val[0..P) ascending (+inf padding ends up last)
+    for (int size = 2; size <= w.P; size <<= 1) {
+      for (int str = size >> 1; str > 0; str >>= 1) {
+        __syncthreads();
+        for (int t = lane; t < (w.P >> 1); t += 64) {
+          const int i = ((t / str) * str << 1) + (t % str), j = i + str;
+          const bool up = ((i & size) == 0);
+          const double a = val[i], b = val[j];
+          if ((a > b) == up) {
+            val[i] = b;
+            val[j] = a;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const double p10 = fo_quantile(val, m, 0.1), p25 = fo_quantile(val, m, 0.25), p75 = fo_quantile(val, m, 0.75),
+                 p90 = fo_quantile(val, m, 0.9);
+    const double med = (m & 1) ? val[m >> 1] : (val[(m >> 1) - 1] + val[m >> 1]) / 2.0;
+    double bc = 0, bs = 0;
+    for (int k = lane; k < m; k += 64) {
+      const double x = val[k];
+      if (x >= p10 && x <= p90) {
+        bc += 1.0;
+        bs += x;
+      }
+    }
+    bc = fo_wave_sum(bc);
+    bs = fo_wave_sum(bs);
+    const double mub = bs / bc;
+    double ba = 0;
+    for (int k = lane; k < m; k += 64) {
+      const double x = val[k];
+      if (x >= p10 && x <= p90) ba += fabs(x - mub);
+    }
+    ba = fo_wave_sum(ba);
+    if (lane == 0) {
+      const double m2 = a2 / cnt, m3 = a3 / cnt, m4 = a4 / cnt;
+      const double m2s = m2 == 0 ? 1.0 : m2;            // firstorder.py:403-405,441-443: flat regions give 0
+      for (int f = 0; f < nfeat; f++) {
+        double r;
+        switch (feature_ids[f]) {
+          case PRAD_FOF_ENERGY: r = s2; break;
+          case PRAD_FOF_TOTALENERGY: r = s2 * voxel_volume; break;
+          case PRAD_FOF_ENTROPY: r = ent; break;
+          case PRAD_FOF_MINIMUM: r = mn; break;
+          case PRAD_FOF_P10: r = p10; break;
+          case PRAD_FOF_P90: r = p90; break;
+          case PRAD_FOF_MAXIMUM: r = mx; break;
+          case PRAD_FOF_MEAN: r = mu; break;
+          case PRAD_FOF_MEDIAN: r = med; break;
+          case PRAD_FOF_IQR: r = p75 - p25; break;
+          case PRAD_FOF_RANGE: r = mx - mn; break;
+          case PRAD_FOF_MAD: r = a1 / cnt; break;
+          case PRAD_FOF_RMAD: r = ba / bc; break;
+          case PRAD_FOF_RMS: r = sqrt(s2 / cnt); break;
+          case PRAD_FOF_STD: r = sqrt(m2); break;
+          case PRAD_FOF_SKEWNESS: r = m3 / pow(m2s, 1.5); break;
+          case PRAD_FOF_KURTOSIS: r = m4 / (m2s * m2s); break;
+          case PRAD_FOF_VARIANCE: { const double sd = sqrt(m2); r = sd * sd; } break;
+          case PRAD_FOF_UNIFORMITY: r = uni; break;
+          default: r = __builtin_nan("");
+        }
+        out[(long long)f * nvox + v] = r;
+      }
+    }
+  }
+}
+
+}  // namespace prad

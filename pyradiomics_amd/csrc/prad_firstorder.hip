@@ -1,0 +1,195 @@
+// prad_firstorder.hip -- C ABI of the first-order statistics (include/pyradiomics_amd.h); second translation unit of
+// libpyradiomics_amd.so so that the rocPRIM sort templates do not slow down rebuilding the texture kernels.
+#include <hipcub/hipcub.hpp>
+#include <math.h>
+#include "kernels_firstorder.h"
+
+using namespace prad;
+
+namespace {
+
+// numpy's linear-interpolation quantile (numpy/lib/_function_base_impl.py: _compute_virtual_index with
+// alpha = beta = 1, _get_gamma, _lerp): the statistic np.nanpercentile / np.nanmedian return for finite data
+struct Quantile {
+  long long prev, next;
+  double gamma;
+};
+Quantile quantile_pos(long long m, double q) {
+  const double virt = (double)(m - 1) * q;
+  Quantile r;
+  r.prev = (long long)floor(virt);
+  r.gamma = virt - (double)r.prev;
+  if (r.prev < 0) r.prev = 0;
+  if (r.prev > m - 1) r.prev = m - 1;
+  r.next = r.prev + 1 > m - 1 ? m - 1 : r.prev + 1;
+  return r;
+}
+double lerp_np(double a, double b, double t) {
+  const double d = b - a;
+  return t >= 0.5 ? b - d * (1 - t) : a + d * t;
+}
+
+int sum_partials(Context &c, hipStream_t s, const double *partial_d, int blocks, int width, double *out) {
+  void *hp = nullptr;
+  PRAD_TRY(c.get_pinned("fo_partials_h", sizeof(double) * PRAD_FO_BLOCKS * 8, &hp));
+  double *h = (double *)hp;
+  PRAD_HIP(hipMemcpyAsync(h, partial_d, sizeof(double) * blocks * width, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  for (int k = 0; k < width; k++) {
+    double acc = 0;
+    for (int b = 0; b < blocks; b++) acc += h[b * width + k];
+    out[k] = acc;
+  }
+  return PRAD_OK;
+}
+
+}  // namespace
+
+extern "C" int prad_firstorder_dev(const void *image, int dtype, const uint8_t *mask, long long n,
+                                   double voxelArrayShift, double *out, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!image || !mask || !out || n < 1) return fail(PRAD_E_ARG, "firstorder: bad arguments");
+  if (n > 2147483647LL) return fail(PRAD_E_UNSUPPORTED, "firstorder: more than 2^31-1 voxels");
+  hipStream_t s = (hipStream_t)stream;
+  double *vals = nullptr, *sorted = nullptr, *partial = nullptr;
+  unsigned long long *count = nullptr;
+  PRAD_TRY(c.get<double>("fo_vals", (size_t)n, &vals));
+  PRAD_TRY(c.get<double>("fo_sorted", (size_t)n, &sorted));
+  PRAD_TRY(c.get<double>("fo_partial", (size_t)PRAD_FO_BLOCKS * 8, &partial));
+  PRAD_TRY(c.get<unsigned long long>("fo_count", 1, &count));
+  PRAD_HIP(hipMemsetAsync(count, 0, sizeof(unsigned long long), s));
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+  {
+    Timed t(c, "firstorder", s);
+    switch (dtype) {
+      case 0: hipLaunchKernelGGL(fo_compact_kernel<float>, dim3(gx), dim3(256), 0, s, (const float *)image, mask, n, vals, count); break;
+      case 1: hipLaunchKernelGGL(fo_compact_kernel<double>, dim3(gx), dim3(256), 0, s, (const double *)image, mask, n, vals, count); break;
+      case 2: hipLaunchKernelGGL(fo_compact_kernel<int>, dim3(gx), dim3(256), 0, s, (const int *)image, mask, n, vals, count); break;
+      case 3: hipLaunchKernelGGL(fo_compact_kernel<short>, dim3(gx), dim3(256), 0, s, (const short *)image, mask, n, vals, count); break;
+      default: return fail(PRAD_E_ARG, "firstorder: dtype %d", dtype);
+    }
+    PRAD_TRY(check_launch("fo_compact_kernel"));
+  }
+  unsigned long long m64 = 0;
+  PRAD_HIP(hipMemcpyAsync(&m64, count, sizeof(m64), hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  const long long m = (long long)m64;
+  if (m < 1) return fail(PRAD_E_ARG, "firstorder: empty ROI");
+
+  size_t tmp_bytes = 0;
+  PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, vals, sorted, (int)m, 0, 64, s));
+  uint8_t *tmp = nullptr;
+  PRAD_TRY(c.get<uint8_t>("fo_sort_tmp", tmp_bytes + 16, &tmp));
+  const int blocks = (int)std::max<long long>(1, std::min<long long>((m + 255) / 256, PRAD_FO_BLOCKS));
+  {
+    Timed t(c, "firstorder", s);
+    PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, vals, sorted, (int)m, 0, 64, s));
+    hipLaunchKernelGGL(fo_sums_kernel, dim3(blocks), dim3(256), 0, s, sorted, m, voxelArrayShift, partial);
+    PRAD_TRY(check_launch("fo_sums_kernel"));
+  }
+  double sums[2];
+  PRAD_TRY(sum_partials(c, s, partial, blocks, 2, sums));
+  const double mu = sums[0] / (double)m;
+
+  // order statistics: minimum, maximum and the two neighbours of each requested quantile
+  const double qs[5] = {0.1, 0.25, 0.5, 0.75, 0.9};
+  Quantile qp[5];
+  double os[12];
+  for (int k = 0; k < 5; k++) {
+    qp[k] = quantile_pos(m, qs[k]);
+    PRAD_HIP(hipMemcpyAsync(os + 2 * k, sorted + qp[k].prev, sizeof(double), hipMemcpyDeviceToHost, s));
+    PRAD_HIP(hipMemcpyAsync(os + 2 * k + 1, sorted + qp[k].next, sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  PRAD_HIP(hipMemcpyAsync(os + 10, sorted, sizeof(double), hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipMemcpyAsync(os + 11, sorted + (m - 1), sizeof(double), hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  double pq[5];
+  for (int k = 0; k < 5; k++) pq[k] = lerp_np(os[2 * k], os[2 * k + 1], qp[k].gamma);
+  // np.median averages the two middle elements for even counts (np.mean of the pair), middle element otherwise
+  const double median = (m % 2) ? os[4] : (os[4] + os[5]) / 2.0;
+
+  {
+    Timed t(c, "firstorder", s);
+    hipLaunchKernelGGL(fo_central_kernel, dim3(blocks), dim3(256), 0, s, sorted, m, mu, pq[0], pq[4], partial);
+    PRAD_TRY(check_launch("fo_central_kernel"));
+  }
+  double cen[6];
+  PRAD_TRY(sum_partials(c, s, partial, blocks, 6, cen));
+  double rmad = NAN;
+  if (cen[4] > 0) {
+    const double mu_band = cen[5] / cen[4];
+    {
+      Timed t(c, "firstorder", s);
+      hipLaunchKernelGGL(fo_band_kernel, dim3(blocks), dim3(256), 0, s, sorted, m, mu_band, pq[0], pq[4], partial);
+      PRAD_TRY(check_launch("fo_band_kernel"));
+    }
+    double band;
+    PRAD_TRY(sum_partials(c, s, partial, blocks, 1, &band));
+    rmad = band / cen[4];
+  }
+  const double dm = (double)m;
+  out[PRAD_FO_NP] = dm;
+  out[PRAD_FO_ENERGY] = sums[1];
+  out[PRAD_FO_MINIMUM] = os[10];
+  out[PRAD_FO_P10] = pq[0];
+  out[PRAD_FO_P25] = pq[1];
+  out[PRAD_FO_MEDIAN] = median;
+  out[PRAD_FO_P75] = pq[3];
+  out[PRAD_FO_P90] = pq[4];
+  out[PRAD_FO_MAXIMUM] = os[11];
+  out[PRAD_FO_MEAN] = mu;
+  out[PRAD_FO_MAD] = cen[0] / dm;
+  out[PRAD_FO_RMAD] = rmad;
+  out[PRAD_FO_M2] = cen[1] / dm;
+  out[PRAD_FO_M3] = cen[2] / dm;
+  out[PRAD_FO_M4] = cen[3] / dm;
+  c.last_path = "firstorder-sort";
+  return PRAD_OK;
+}
+
+extern "C" int prad_voxel_firstorder_dev(const void *image, int dtype, const uint8_t *mask, const int32_t *levels,
+                                         const int *size, int Nd, int Nvox, const int *voxels, int kernelRadius,
+                                         int force2Ddim, const int *bbsize, double voxelArrayShift, double voxelVolume,
+                                         const int *feature_ids, int nfeat, double *out, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Geo g;
+  PRAD_TRY(make_geo(size, Nd, &g));
+  if (!image || !mask || !voxels || !out || !feature_ids || Nvox < 1 || nfeat < 1 || kernelRadius < 1)
+    return fail(PRAD_E_ARG, "voxel_firstorder: bad arguments");
+  for (int f = 0; f < nfeat; f++)
+    if (feature_ids[f] < 0 || feature_ids[f] >= PRAD_FOF_COUNT) return fail(PRAD_E_ARG, "voxel_firstorder: feature id %d", feature_ids[f]);
+  hipStream_t s = (hipStream_t)stream;
+  FoWindow w;
+  w.nd = Nd;
+  long long nk = 1;
+  for (int d = 0; d < Nd; d++) {
+    int h = kernelRadius;
+    if (bbsize) h = std::min(h, std::max(bbsize[d] - 1, 0));
+    h = std::min(h, g.size[d] - 1);
+    if (d == force2Ddim) h = 0;
+    w.half[d] = h;
+    nk *= 2 * h + 1;
+  }
+  if (nk > 4096) return fail(PRAD_E_UNSUPPORTED, "voxel_firstorder: %lld voxels per kernel exceed the 4096-slot window", nk);
+  w.nk = (int)nk;
+  w.P = 2;
+  while (w.P < w.nk) w.P <<= 1;
+  int *ids_d = nullptr;
+  PRAD_TRY(c.get<int>("fo_ids", (size_t)nfeat, &ids_d));
+  PRAD_HIP(hipMemcpyAsync(ids_d, feature_ids, sizeof(int) * nfeat, hipMemcpyHostToDevice, s));
+  const size_t lds = (size_t)w.P * (sizeof(double) + sizeof(int));
+  const unsigned gx = (unsigned)std::min<long long>(Nvox, 1 << 20);
+  Timed t(c, "voxel_firstorder", s);
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(voxel_firstorder_kernel<float>, dim3(gx), dim3(64), lds, s, (const float *)image, mask, levels, g, w, Nvox, voxels, voxelArrayShift, voxelVolume, ids_d, nfeat, out); break;
+    case 1: hipLaunchKernelGGL(voxel_firstorder_kernel<double>, dim3(gx), dim3(64), lds, s, (const double *)image, mask, levels, g, w, Nvox, voxels, voxelArrayShift, voxelVolume, ids_d, nfeat, out); break;
+    case 2: hipLaunchKernelGGL(voxel_firstorder_kernel<int>, dim3(gx), dim3(64), lds, s, (const int *)image, mask, levels, g, w, Nvox, voxels, voxelArrayShift, voxelVolume, ids_d, nfeat, out); break;
+    case 3: hipLaunchKernelGGL(voxel_firstorder_kernel<short>, dim3(gx), dim3(64), lds, s, (const short *)image, mask, levels, g, w, Nvox, voxels, voxelArrayShift, voxelVolume, ids_d, nfeat, out); break;
+    default: return fail(PRAD_E_ARG, "voxel_firstorder: dtype %d", dtype);
+  }
+  PRAD_TRY(check_launch("voxel_firstorder_kernel"));
+  c.last_path = "voxel-firstorder";
+  return PRAD_OK;
+}

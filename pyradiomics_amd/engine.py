@@ -260,6 +260,55 @@ def level_counts(levels: torch.Tensor, mask: torch.Tensor, Ng: int) -> np.ndarra
     return counts
 
 
+FIRSTORDER_FIELDS = ("Np", "Energy", "Minimum", "P10", "P25", "Median", "P75", "P90", "Maximum", "Mean", "MAD", "rMAD",
+                     "m2", "m3", "m4")
+
+
+def firstorder_stats(image: torch.Tensor, mask: torch.Tensor, voxelArrayShift: float = 0.0) -> dict:
+    """the ROI statistics behind the first-order feature class (prad_firstorder_dev): {field: float}"""
+    lib = _lib.load()
+    if image.dtype not in _DTYPE_CODES:
+        image = image.to(torch.float64)
+    image = image.contiguous()
+    mask = _mask_u8(mask)
+    lib.prad_set_device(image.device.index or 0)
+    out = (C.c_double * len(FIRSTORDER_FIELDS))()
+    rc = lib.prad_firstorder_dev(C.c_void_p(image.data_ptr()), _DTYPE_CODES[image.dtype], C.c_void_p(mask.data_ptr()),
+                                 image.numel(), float(voxelArrayShift), out, _stream_ptr())
+    _lib.raise_for(rc, "firstorder")
+    return dict(zip(FIRSTORDER_FIELDS, (float(v) for v in out)))
+
+
+def voxel_firstorder(image: torch.Tensor, mask: torch.Tensor, levels, voxels: torch.Tensor, feature_ids,
+                     kernelRadius: int = 1, force2D: bool = False, force2Ddimension: int = 0, bbsize=None,
+                     voxelArrayShift: float = 0.0, voxelVolume: float = 1.0) -> torch.Tensor:
+    """Voxel-based first-order feature maps (prad_voxel_firstorder_dev): float64 tensor [nfeat, Nvox] on the device.
+    voxels: int32 [Nd, Nvox] centre coordinates on the device; levels: discretised image (or None)."""
+    lib = _lib.load()
+    if image.dtype not in _DTYPE_CODES:
+        image = image.to(torch.float64)
+    image = image.contiguous()
+    mask = _mask_u8(mask)
+    lib.prad_set_device(image.device.index or 0)
+    size = np.array(image.shape, dtype=np.intc)
+    vox = voxels.to(torch.int32).contiguous()
+    if vox.dim() != 2 or vox.shape[0] != image.dim():
+        raise RuntimeError("Expecting voxel indices array to be 2-dimensional")
+    ids = np.ascontiguousarray(feature_ids, dtype=np.intc)
+    bb = None if bbsize is None else np.ascontiguousarray(bbsize, dtype=np.intc)
+    if levels is not None:
+        levels = levels.to(torch.int32).contiguous()
+    out = torch.empty((len(ids), int(vox.shape[1])), dtype=torch.float64, device=image.device)
+    rc = lib.prad_voxel_firstorder_dev(
+        C.c_void_p(image.data_ptr()), _DTYPE_CODES[image.dtype], C.c_void_p(mask.data_ptr()),
+        C.c_void_p(levels.data_ptr()) if levels is not None else None, _iptr(size), image.dim(), int(vox.shape[1]),
+        C.c_void_p(vox.data_ptr()), int(kernelRadius), int(force2Ddimension) if force2D else -1,
+        _iptr(bb) if bb is not None else None, float(voxelArrayShift), float(voxelVolume), _iptr(ids), len(ids),
+        C.c_void_p(out.data_ptr()), _stream_ptr())
+    _lib.raise_for(rc, "voxel firstorder")
+    return out
+
+
 def swt_level1(data: torch.Tensor, lo: np.ndarray, hi: np.ndarray, axes) -> torch.Tensor:
     """pywt.swtn(level=1) on the device: float64 tensor [2^len(axes), *data.shape], sub-bands in key order"""
     lib = _lib.load()

@@ -1,11 +1,11 @@
 """`RadiomicsFeatureExtractor`: the orchestration API of the reference's radiomics/featureextractor.py for the
-path this package accelerates -- image types Original / Wavelet / LoG, feature classes glcm / glrlm / glszm / gldm /
-ngtdm, segment-based and voxel-based extraction -- without SimpleITK / pykwalify (not installed on the build and
+path this package accelerates -- image types Original / Wavelet / LoG, feature classes firstorder / glcm / glrlm /
+glszm / gldm / ngtdm, segment-based and voxel-based extraction -- without SimpleITK / pykwalify (not installed on the build and
 GPU hosts).  Same constructor forms (parameter file, dict, or keyword settings), the same enable*/disable* methods,
 the same `execute(image, mask, label=None, voxelBased=False)` returning an OrderedDict keyed
 `<imageType>_<featureClass>_<featureName>` (featureextractor.py:241-396, 560-604).
 
-Not provided (out of scope): shape / firstorder classes, resampling, normalisation,
+Not provided (out of scope): the shape classes, resampling, normalisation,
 the remaining image types, parameter-file schema validation.  Enabling them raises/ warns instead of silently
 computing something else."""
 from __future__ import annotations
@@ -23,14 +23,15 @@ from .image import Image, as_array, as_image, read_nrrd
 
 logger = logging.getLogger(__name__)
 
-_FEATURE_CLASSES = ("glcm", "glrlm", "glszm", "gldm", "ngtdm")
+_FEATURE_CLASSES = ("firstorder", "glcm", "gldm", "glrlm", "glszm", "ngtdm")     # the reference's (alphabetical) order
 _IMAGE_TYPES = {"Original": filters.getOriginalImage, "Wavelet": filters.getWaveletImage, "LoG": filters.getLoGImage}
 
 
 def getFeatureClasses():
-    """name -> class (radiomics/__init__.py:64-117), restricted to the texture classes on the accelerated path"""
+    """name -> class (radiomics/__init__.py:64-117), restricted to the classes on the accelerated path"""
     import importlib
-    return {n: getattr(importlib.import_module("pyradiomics_amd." + n), "Radiomics" + n.upper())
+    names = {"firstorder": "RadiomicsFirstOrder"}
+    return {n: getattr(importlib.import_module("pyradiomics_amd." + n), names.get(n, "Radiomics" + n.upper()))
             for n in _FEATURE_CLASSES}
 
 

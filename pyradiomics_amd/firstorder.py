@@ -1,0 +1,124 @@
+"""First-order statistics: interface and feature-name surface of the reference's radiomics/firstorder.py
+(RadiomicsFirstOrder).  The reference evaluates these with nan-aware numpy reductions over the ROI intensities
+(segment mode, firstorder.py:96-101) or over every kernel window (voxel mode, :104-118); here the reductions run on
+the MI355X -- prad_firstorder_dev (compaction, rocPRIM sort, block reductions) and prad_voxel_firstorder_dev (one
+wave per kernel) -- and this class only derives the 19 feature values from the returned statistics.
+
+Settings as in the reference: voxelArrayShift [0] is added to the intensities in Energy, TotalEnergy and
+RootMeanSquared (:151,:166,:364)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .base import RadiomicsFeaturesBase, deprecated
+from .image import as_array
+
+
+class RadiomicsFirstOrder(RadiomicsFeaturesBase):
+    def __init__(self, inputImage, inputMask, **kwargs):
+        super().__init__(inputImage, inputMask, **kwargs)
+        self.pixelSpacing = self.inputImage.GetSpacing()
+        self.voxelArrayShift = kwargs.get("voxelArrayShift", 0)
+        self.rawImageArray = self.imageArray
+        self.discretizedImageArray = self._applyBinning(self.imageArray)
+        self.st = None
+
+    def _initVoxelBasedCalculation(self):
+        super()._initVoxelBasedCalculation()
+        kernelRadius = self.settings.get("kernelRadius", 1)
+        # firstorder.py:45-58: kernel offsets are limited by the ROI (masked kernels) or image extent
+        if self.masked:
+            size = np.max(self.labelledVoxelCoordinates, 1) - np.min(self.labelledVoxelCoordinates, 1) + 1
+        else:
+            size = np.array(self.imageArray.shape)
+        self.boundingBoxSize = np.minimum(size, kernelRadius * 2 + 1)
+
+    def _calculateFeatures(self, voxelCoordinates=None):
+        if not self.voxelBased:
+            yield from super()._calculateFeatures(voxelCoordinates)
+            return
+        # voxel mode: the operator backend evaluates the enabled features kernel by kernel
+        names = [n for n, on in self.enabledFeatures.items() if on]
+        vals = self.cMatrices.voxel_firstorder(
+            self.rawImageArray, self.maskArray, self.discretizedImageArray, voxelCoordinates,
+            self.settings.get("kernelRadius", 1), self.boundingBoxSize, self.settings.get("force2D", False),
+            self.settings.get("force2Ddimension", 0), self.voxelArrayShift, float(np.multiply.reduce(self.pixelSpacing)),
+            names)
+        for n in names:
+            yield True, n, vals[n]
+
+    def _initCalculation(self, voxelCoordinates=None):
+        st = self.cMatrices.firstorder_stats(self.rawImageArray, self.maskArray, self.voxelArrayShift)
+        self.st = {k: np.array([v], dtype=np.float64) for k, v in st.items()}
+        counts = self.coefficients["levelCounts"]           # ROI voxels per present grey level, ascending (:99-101)
+        p_i = counts.reshape((1, -1)).astype("float")
+        total = np.sum(p_i, 1, keepdims=True)
+        total[total == 0] = 1
+        self.coefficients["p_i"] = p_i / total
+
+    # -- the 19 features (firstorder.py:147-474) -----------------------------------------------------------
+    def getEnergyFeatureValue(self):
+        return self.st["Energy"]
+
+    def getTotalEnergyFeatureValue(self):
+        return self.st["Energy"] * np.multiply.reduce(self.pixelSpacing)
+
+    def getEntropyFeatureValue(self):
+        p_i = self.coefficients["p_i"]
+        return -1.0 * np.sum(p_i * np.log2(p_i + np.spacing(1)), 1)
+
+    def getMinimumFeatureValue(self):
+        return self.st["Minimum"]
+
+    def get10PercentileFeatureValue(self):
+        return self.st["P10"]
+
+    def get90PercentileFeatureValue(self):
+        return self.st["P90"]
+
+    def getMaximumFeatureValue(self):
+        return self.st["Maximum"]
+
+    def getMeanFeatureValue(self):
+        return self.st["Mean"]
+
+    def getMedianFeatureValue(self):
+        return self.st["Median"]
+
+    def getInterquartileRangeFeatureValue(self):
+        return self.st["P75"] - self.st["P25"]
+
+    def getRangeFeatureValue(self):
+        return self.st["Maximum"] - self.st["Minimum"]
+
+    def getMeanAbsoluteDeviationFeatureValue(self):
+        return self.st["MAD"]
+
+    def getRobustMeanAbsoluteDeviationFeatureValue(self):
+        return self.st["rMAD"]
+
+    def getRootMeanSquaredFeatureValue(self):
+        if self.st["Np"][0] == 0:       # firstorder.py:360-362
+            return 0
+        return np.sqrt(self.st["Energy"] / self.st["Np"])
+
+    @deprecated
+    def getStandardDeviationFeatureValue(self):
+        return np.sqrt(self.st["m2"])
+
+    def _m2_safe(self):
+        m2 = self.st["m2"].copy()
+        m2[m2 == 0] = 1                 # flat region: the moment ratio is returned as 0 (:403-405, :441-443)
+        return m2
+
+    def getSkewnessFeatureValue(self):
+        return self.st["m3"] / self._m2_safe() ** 1.5
+
+    def getKurtosisFeatureValue(self):
+        return self.st["m4"] / self._m2_safe() ** 2.0
+
+    def getVarianceFeatureValue(self):
+        return np.sqrt(self.st["m2"]) ** 2      # np.nanstd(x) ** 2 (:462)
+
+    def getUniformityFeatureValue(self):
+        return np.nansum(self.coefficients["p_i"] ** 2, 1)

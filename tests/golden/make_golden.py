@@ -29,8 +29,9 @@ REF = os.environ.get("REFERENCE", "/root/reference")
 CASES = ["brain1", "brain2", "breast1"]
 CLASSES = ["glcm", "glrlm", "glszm", "gldm", "ngtdm"]
 CONFIG_SUFFIXES = ["", "_2d", "_FBN", "_combined", "_flatRegion", "_resegmentation"]
+FEATURE_CLASSES = CLASSES + ["firstorder"]      # golden feature values only (first order has no matrix)
 KEEP = ("binWidth", "binCount", "force2D", "force2Ddimension", "distances", "weightingNorm", "symmetricalGLCM",
-        "gldm_a", "label", "resegmentRange", "resegmentMode")
+        "gldm_a", "label", "resegmentRange", "resegmentMode", "voxelArrayShift")
 
 
 def main():
@@ -46,7 +47,7 @@ def main():
             out["P_" + cls] = np.load(os.path.join(REF, "data", "baseline", "%s_%s.npy" % (case, cls)))
         np.savez_compressed(os.path.join(HERE, case + ".npz"), **out)
         print(case, out["image"].shape, out["image"].dtype, int(m.sum()), "voxels")
-    for cls in CLASSES:
+    for cls in FEATURE_CLASSES:
         rows = list(csv.reader(open(os.path.join(REF, "data", "baseline", "baseline_%s.csv" % cls))))
         hdr = rows[0]
         byname = {r[0]: r for r in rows}
@@ -58,6 +59,7 @@ def main():
             settings = ast.literal_eval(byname["diagnostics_Configuration_Settings"][col])
             entry = feats.setdefault(cfg, {"case": case, "settings": {k: v for k, v in settings.items() if k in KEEP},
                                            "features": {}})
+            entry["settings"].update({k: v for k, v in settings.items() if k in KEEP})
             prefix = "original_%s_" % cls
             entry["features"][cls] = {r[0][len(prefix):]: float(r[col]) for r in rows
                                       if r[0].startswith(prefix) and r[col] != ""}

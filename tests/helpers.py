@@ -5,13 +5,14 @@ import os
 import numpy as np
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CLASSES = ["glcm", "glrlm", "glszm", "gldm", "ngtdm"]
+CLASSES = ["glcm", "glrlm", "glszm", "gldm", "ngtdm"]          # the matrix-building classes
+FEATURE_CLASSES = ["firstorder"] + CLASSES                      # everything with golden feature values
 
 
 def feature_class(name):
     import importlib
     mod = importlib.import_module("pyradiomics_amd." + name)
-    return getattr(mod, "Radiomics" + name.upper())
+    return getattr(mod, "RadiomicsFirstOrder" if name == "firstorder" else "Radiomics" + name.upper())
 
 
 def load_case(case):

@@ -87,7 +87,7 @@ def test_device_resident_route_equals_host_array_route():
     params["setting"]["deviceResident"] = False
     host = RadiomicsFeatureExtractor(params).execute(IMG, LBL)
     keys = [k for k in host if not k.startswith("diagnostics")]
-    assert len(keys) == (1 + 8 + 1) * (24 + 16 + 16 + 14 + 5) and set(keys) <= set(dev)
+    assert len(keys) == (1 + 8 + 1) * (18 + 24 + 16 + 16 + 14 + 5) and set(keys) <= set(dev)
     for k in keys:
         a, b = float(dev[k]), float(host[k])
         assert a == b or (np.isnan(a) and np.isnan(b)), (k, a, b)

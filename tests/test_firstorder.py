@@ -1,0 +1,113 @@
+"""First-order statistics: the device reductions (prad_firstorder_dev, prad_voxel_firstorder_dev) against the numpy
+restatement of radiomics/firstorder.py in oracle/firstorder_oracle.py, which tests/test_oracle.py::test_golden_features
+pins to the reference's baseline_firstorder.csv.  Tolerances: order statistics (min / max / percentiles / median) must
+be identical; sums differ only by summation order (numpy pairwise vs. block tree), bounded here by 1e-11 relative."""
+import numpy as np
+import pytest
+
+from helpers import load_baseline_features, prepared_case
+
+EXACT = ("Np", "Minimum", "Maximum", "P10", "P25", "Median", "P75", "P90")
+
+
+def _volume(dtype, shape, seed, frac=0.6):
+    rng = np.random.default_rng(seed)
+    if np.issubdtype(dtype, np.integer):
+        img = rng.integers(-900, 1500, shape).astype(dtype)
+    else:
+        img = (rng.standard_normal(shape) * 37.5 + 11).astype(dtype)
+    return img, rng.random(shape) < frac
+
+
+def test_oracle_kernel_offsets_follow_the_operator_angles(oracle_port):
+    """firstorder.py:57-67 builds the kernel from cMatrices.generate_angles(bbsize, 1..r, bidirectional) + centre"""
+    from oracle import firstorder_oracle
+    for bb, r, f2d in (((5, 5, 5), 2, None), ((3, 5, 2), 2, None), ((5, 5, 5), 1, 0), ((1, 4, 5), 2, None)):
+        want = oracle_port.generate_angles(np.array(bb), np.arange(1, r + 1), True, f2d is not None, f2d or 0)
+        want = {tuple(a) for a in want} | {(0, 0, 0)}
+        got = {tuple(a) for a in firstorder_oracle.kernel_offsets(bb, r, f2d is not None, f2d or 0)}
+        assert got == want, (bb, r, f2d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.int16, np.int32, np.float32, np.float64])
+@pytest.mark.parametrize("shape,frac", [((9, 30, 41), 0.6), ((1, 1, 7), 1.0), ((64, 64, 65), 0.05)])
+def test_segment_statistics_vs_oracle(dtype, shape, frac):
+    from oracle import firstorder_oracle
+    from pyradiomics_amd import cmatrices
+    img, mask = _volume(dtype, shape, 3, frac)
+    mask.flat[0] = True
+    for shift in (0.0, 2000.0):
+        got = cmatrices.firstorder_stats(img, mask, shift)
+        want = firstorder_oracle.firstorder_stats(img, mask, shift)
+        assert set(got) == set(want)
+        for k in want:
+            if k in EXACT:
+                assert got[k] == want[k], (k, got[k], want[k])
+            elif np.isnan(want[k]):
+                assert np.isnan(got[k]), k
+            else:
+                assert abs(got[k] - want[k]) <= 1e-11 * max(abs(want[k]), 1e-300) + 1e-9 * (k in ("m3",)) * abs(want["m2"]) ** 1.5, (k, got[k], want[k])
+
+
+@pytest.mark.gpu
+def test_segment_flat_region_and_single_voxel():
+    from pyradiomics_amd import firstorder
+    img = np.full((4, 5, 6), 7, dtype=np.int16)
+    mask = np.ones(img.shape, dtype=np.int32)
+    vals = firstorder.RadiomicsFirstOrder(img, mask, binWidth=25).execute()
+    assert float(vals["Skewness"]) == 0 and float(vals["Kurtosis"]) == 0 and float(vals["Variance"]) == 0
+    assert float(vals["Entropy"]) == pytest.approx(0, abs=1e-12) and float(vals["Uniformity"]) == 1
+    assert float(vals["Median"]) == 7 and float(vals["RobustMeanAbsoluteDeviation"]) == 0
+    one = np.zeros(img.shape, dtype=np.int32)
+    one[1, 2, 3] = 1
+    vals = firstorder.RadiomicsFirstOrder(img, one, binWidth=25, voxelArrayShift=3).execute()
+    assert float(vals["Energy"]) == 100 and float(vals["RootMeanSquared"]) == 10 and float(vals["Range"]) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfgname", ["brain1", "brain2_resegmentation", "breast1"])
+def test_golden_firstorder_host_and_device_routes(cfgname):
+    """both call routes of the class (device tensors / host arrays uploaded by the operator module) on the GPU"""
+    from pyradiomics_amd import backend, cmatrices, firstorder
+    backend.set(cmatrices)
+    cfg = load_baseline_features()[cfgname]
+    image, mask, settings = prepared_case(cfg)
+    for route in (True, False):
+        got = firstorder.RadiomicsFirstOrder(image, mask, deviceResident=route, **settings).execute()
+        for name, ref in cfg["features"]["firstorder"].items():
+            assert abs(float(got[name]) - ref) <= 1e-9 * abs(ref) + 1e-12, (route, name, float(got[name]), ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,radius,force2D,masked", [((7, 12, 11), 1, False, True), ((6, 9, 10), 2, False, True),
+                                                          ((5, 14, 13), 2, True, True), ((6, 8, 9), 1, False, False),
+                                                          ((2, 9, 9), 2, False, True)])
+@pytest.mark.parametrize("dtype", [np.int16, np.float64])
+def test_voxel_mode_vs_oracle(shape, radius, force2D, masked, dtype, oracle_port):
+    from pyradiomics_amd import backend, cmatrices, firstorder
+    img, roi = _volume(dtype, shape, 8, 0.7)
+    mask = roi.astype(np.int32)
+    kw = dict(binWidth=40, voxelBased=True, kernelRadius=radius, force2D=force2D, force2Ddimension=0,
+              maskedKernel=masked, voxelArrayShift=17, voxelBatch=97, initValue=np.nan)
+    res = {}
+    for name, be in (("gpu", cmatrices), ("cpu", oracle_port)):
+        backend.set(be)
+        try:
+            fc = firstorder.RadiomicsFirstOrder(img, mask, **kw)
+            fc.enableAllFeatures()
+            fc.enableFeatureByName("StandardDeviation")
+            res[name] = {k: v.array for k, v in fc.execute().items()}
+        finally:
+            backend.set(cmatrices)
+    assert set(res["gpu"]) == set(res["cpu"]) and len(res["gpu"]) == 19
+    for k, want in res["cpu"].items():
+        got = res["gpu"][k]
+        assert np.array_equal(np.isnan(got), np.isnan(want)), k
+        ok = ~np.isnan(want)
+        assert ok.sum() == roi.sum()
+        if k in ("Minimum", "Maximum", "Median", "10Percentile", "90Percentile", "InterquartileRange", "Range"):
+            assert np.array_equal(got[ok], want[ok]), k
+        else:
+            scale = np.maximum(np.abs(want[ok]), 1e-9 if k in ("Skewness",) else 1e-300)
+            assert np.all(np.abs(got[ok] - want[ok]) <= 1e-9 * scale + 1e-12), (k, np.abs(got[ok] - want[ok]).max())

@@ -4,7 +4,7 @@ relative), plus raw-matrix bit-exactness against the oracle on the real brain1 /
 import numpy as np
 import pytest
 
-from helpers import CLASSES, feature_class, load_baseline_features, load_case, prepared_case
+from helpers import CLASSES, FEATURE_CLASSES, feature_class, load_baseline_features, load_case, prepared_case
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +37,7 @@ def test_golden_matrices_on_gpu(case, cls):
 def test_golden_features_on_gpu(cfgname):
     cfg = load_baseline_features()[cfgname]
     image, mask, settings = prepared_case(cfg)
-    for cls in CLASSES:
+    for cls in FEATURE_CLASSES:
         if cls not in cfg["features"]:
             continue
         got = feature_class(cls)(image, mask, **settings).execute()

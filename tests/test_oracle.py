@@ -10,7 +10,7 @@ No GPU involved."""
 import numpy as np
 import pytest
 
-from helpers import CLASSES, feature_class, load_baseline_features, load_case, prepared_case
+from helpers import CLASSES, FEATURE_CLASSES, feature_class, load_baseline_features, load_case, prepared_case
 
 SHAPES = [(5, 6, 7), (1, 9, 9), (9, 1, 5), (4, 4, 1), (12, 10, 8), (3, 3), (7,), (2, 3, 4, 3), (1, 1, 6)]
 
@@ -104,7 +104,7 @@ def test_golden_matrices(oracle_backend, case, cls):
 def test_golden_features(oracle_backend, cfgname):
     cfg = load_baseline_features()[cfgname]
     image, mask, settings = prepared_case(cfg)
-    for cls in CLASSES:
+    for cls in FEATURE_CLASSES:
         if cls not in cfg["features"]:     # e.g. the weighting-norm config only exists for GLCM / GLRLM
             continue
         fc = feature_class(cls)(image, mask, **settings)
