@@ -47,8 +47,10 @@ class RadiomicsFeatureExtractor:
         self.featureClassNames = list(_FEATURE_CLASSES)
         if len(args) == 1 and isinstance(args[0], dict):
             self._applyParams(paramsDict=args[0])
+            self.settings.update(kwargs)          # keyword settings override the parameter set (featureextractor.py:117-137)
         elif len(args) == 1 and isinstance(args[0], (str, os.PathLike)):
             self._applyParams(paramsFile=args[0])
+            self.settings.update(kwargs)
         else:
             self.settings = self._getDefaultSettings()
             self.settings.update(kwargs)
