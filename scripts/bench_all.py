@@ -25,6 +25,8 @@ jobs = {
     "gldm": lambda: engine.gldm(img, msk, a.levels),
     "ngtdm": lambda: engine.ngtdm(img, msk, a.levels),
     "glszm": lambda: engine.glszm(img, msk, a.levels, n),
+    "glszm-compact": lambda: engine.glszm_compact(img, msk, a.levels, n),
+    "firstorder": lambda: engine.firstorder_stats(img, msk, 0.0),
 }
 for name, fn in jobs.items():
     fn()
