@@ -185,6 +185,17 @@ int prad_voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, cons
                                  int force2Ddim, int symmetric, const int *feature_ids, int nfeat, double *out,
                                  uint32_t *empty_mask, uint32_t *any_nonempty, void *stream);
 
+/* Fused voxel-based feature maps of the other four texture classes (same idea, same window rule as above).
+ * family: 1 = GLDM (alpha = gldm_a; angles bidirectional), 2 = NGTDM (bidirectional), 3 = GLRLM (unidirectional, mean
+ * over the non-empty angles as np.nanmean does), 4 = GLSZM (bidirectional).  feature_ids (HOST) follow the lists
+ * VOXEL_*_FEATURES of pyradiomics_amd/cmatrices.py; out is DEVICE float64 [nfeat][Nvox]; image / mask / voxels are
+ * DEVICE pointers.  PRAD_E_UNSUPPORTED (Nd > 3, Ng > 255, > 32 angles, > 512 voxels per kernel, levels outside
+ * [1, Ng]) means: build the matrices with prad_calculate_* and evaluate the formulas on the host. */
+int prad_voxel_texture_features_dev(int family, const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                                    const int *angles, int Na, int Ng, int alpha, int Nvox, const int *voxels,
+                                    int kernelRadius, int force2Ddim, const int *feature_ids, int nfeat, double *out,
+                                    void *stream);
+
 /* ---- on-device discretisation (radiomics/imageoperations.py:67-174; device pointers only) ----------------------
  * dtype: 0 = float32, 1 = float64, 2 = int32, 3 = int16 image.
  * prad_roi_minmax_dev: minmax[0..1] (HOST doubles) = min / max of image over mask != 0; PRAD_E_ARG if the ROI is empty.

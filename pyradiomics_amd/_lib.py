@@ -51,6 +51,8 @@ SYMBOLS = {
     "prad_voxel_glcm_features_dev": (C.c_int, _COMMON + [C.c_int] + _VOX + [C.c_int, _ip, C.c_int, _vp, _vp, _vp, _vp]),
     "prad_roi_minmax_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.POINTER(C.c_double), _vp]),
     "prad_digitize_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.POINTER(C.c_double), C.c_int, _vp, _ip, _vp]),
+    "prad_voxel_texture_features_dev": (C.c_int, [C.c_int, _vp, _vp, _ip, C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                  _vp, C.c_int, C.c_int, _ip, C.c_int, _vp, _vp]),
     "prad_firstorder_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_double, C.POINTER(C.c_double), _vp]),
     "prad_voxel_firstorder_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _ip, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _ip,
                                             C.c_double, C.c_double, _ip, C.c_int, _vp, _vp]),

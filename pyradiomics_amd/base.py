@@ -166,6 +166,27 @@ class RadiomicsFeaturesBase:
                 self.featureValues[name] = ref.like(self.featureValues[name]) if isinstance(ref, Image) \
                     else Image(self.featureValues[name])
 
+    def _fusedVoxelFeatures(self, cls, voxelCoordinates, alpha=0):
+        """voxel mode: feature maps of class `cls` straight from the device when the operator backend offers the
+        fused kernels and they cover the request (no (Nvox, Ng, ...) intermediate); None otherwise.
+        `fusedVoxel: False` in the settings forces the reference's route (matrix + numpy formulas, base.py:253-273)."""
+        fused = getattr(self.cMatrices, "voxel_texture_features", None)
+        names = [n for n, on in self.enabledFeatures.items() if on]
+        if not (self.voxelBased and voxelCoordinates is not None and fused is not None and names
+                and self.settings.get("fusedVoxel", True)):
+            return None
+        if getattr(self, "_fusedInputs", None) is None:           # upload the discretised volume once, not per batch
+            up = getattr(self.cMatrices, "_to_device", lambda a, **kw: a)
+            self._fusedInputs = (up(self.imageArray, integer=True), up(self.maskArray))
+        try:
+            vals = fused(cls, self._fusedInputs[0], self._fusedInputs[1], np.array(self.settings.get("distances", [1])),
+                         self.coefficients["Ng"], self.settings.get("force2D", False),
+                         self.settings.get("force2Ddimension", 0), self.settings.get("kernelRadius", 1),
+                         voxelCoordinates, names, alpha)
+        except NotImplementedError:
+            return None
+        return [(True, n, vals[n]) for n in names]
+
     def _calculateFeatures(self, voxelCoordinates=None):
         self._initCalculation(voxelCoordinates)
         for name, enabled in self.enabledFeatures.items():

@@ -247,6 +247,55 @@ def calculate_glszm_compact(image, mask, Ng, Ns, force2D, force2Ddimension):
     return P.cpu().numpy()[None], sizes
 
 
+# ---- fused voxel-based features of the other four texture classes (prad_voxel_texture_features_dev) ---------
+_ZONE_LIKE = {
+    "glrlm": (3, ["ShortRunEmphasis", "LongRunEmphasis", "GrayLevelNonUniformity", "GrayLevelNonUniformityNormalized",
+                  "RunLengthNonUniformity", "RunLengthNonUniformityNormalized", "RunPercentage", "GrayLevelVariance",
+                  "RunVariance", "RunEntropy", "LowGrayLevelRunEmphasis", "HighGrayLevelRunEmphasis",
+                  "ShortRunLowGrayLevelEmphasis", "ShortRunHighGrayLevelEmphasis", "LongRunLowGrayLevelEmphasis",
+                  "LongRunHighGrayLevelEmphasis"]),
+    "glszm": (4, ["SmallAreaEmphasis", "LargeAreaEmphasis", "GrayLevelNonUniformity", "GrayLevelNonUniformityNormalized",
+                  "SizeZoneNonUniformity", "SizeZoneNonUniformityNormalized", "ZonePercentage", "GrayLevelVariance",
+                  "ZoneVariance", "ZoneEntropy", "LowGrayLevelZoneEmphasis", "HighGrayLevelZoneEmphasis",
+                  "SmallAreaLowGrayLevelEmphasis", "SmallAreaHighGrayLevelEmphasis", "LargeAreaLowGrayLevelEmphasis",
+                  "LargeAreaHighGrayLevelEmphasis"]),
+    # None = slot of the shared numbering that is a deprecated feature in this class (gldm.py:228,311)
+    "gldm": (1, ["SmallDependenceEmphasis", "LargeDependenceEmphasis", "GrayLevelNonUniformity", None,
+                 "DependenceNonUniformity", "DependenceNonUniformityNormalized", None, "GrayLevelVariance",
+                 "DependenceVariance", "DependenceEntropy", "LowGrayLevelEmphasis", "HighGrayLevelEmphasis",
+                 "SmallDependenceLowGrayLevelEmphasis", "SmallDependenceHighGrayLevelEmphasis",
+                 "LargeDependenceLowGrayLevelEmphasis", "LargeDependenceHighGrayLevelEmphasis"]),
+    "ngtdm": (2, ["Coarseness", "Contrast", "Busyness", "Complexity", "Strength"]),
+}
+VOXEL_GLRLM_FEATURES = _ZONE_LIKE["glrlm"][1]
+VOXEL_GLSZM_FEATURES = _ZONE_LIKE["glszm"][1]
+VOXEL_GLDM_FEATURES = [f for f in _ZONE_LIKE["gldm"][1] if f]
+VOXEL_NGTDM_FEATURES = _ZONE_LIKE["ngtdm"][1]
+
+
+def voxel_texture_features(cls, image, mask, distances, Ng, force2D, force2Ddimension, kernelRadius, voxels, features,
+                           alpha=0):
+    """-> {feature name: float64 [Nvox]} of feature class `cls` ("glrlm" | "glszm" | "gldm" | "ngtdm") for the kernels
+    centred on `voxels` (int [Nd, Nvox]).  Raises NotImplementedError when the fused kernels do not cover the request
+    (unknown / deprecated feature, Ng > 255, more than 32 angles, kernels above 512 voxels): the caller then builds
+    the matrices with calculate_* and uses the numpy formulas."""
+    from . import engine
+    family, table = _ZONE_LIKE[cls]
+    missing = [f for f in features if f not in table]
+    if missing:
+        raise NotImplementedError("not available in the fused voxel kernel: %s" % ", ".join(missing))
+    ids = [table.index(f) for f in features]
+    vox = voxels if _on_device(voxels) else _to_device(np.ascontiguousarray(np.asarray(voxels).astype(np.intc, copy=False)))
+    try:
+        out = engine.voxel_texture_features(family, _to_device(image, integer=True), _to_device(mask), Ng, vox, ids,
+                                            kernelRadius, force2D, force2Ddimension,
+                                            [int(d) for d in np.asarray(distances).ravel()], alpha)
+    except NotImplementedError:
+        raise
+    out = out.cpu().numpy()
+    return {f: out[i] for i, f in enumerate(features)}
+
+
 # ---- first-order statistics (no native code in the reference: radiomics/firstorder.py is numpy; here the ROI /
 # ---- the kernels are reduced on the device, see include/pyradiomics_amd.h) ----------------------------------
 FIRSTORDER_FEATURES = ["Energy", "TotalEnergy", "Entropy", "Minimum", "10Percentile", "90Percentile", "Maximum", "Mean",

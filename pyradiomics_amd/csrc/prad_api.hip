@@ -15,6 +15,7 @@
 #include "kernels_glszm.h"
 #include "kernels_filters.h"
 #include "kernels_voxel.h"
+#include "kernels_voxtex.h"
 #include "kernels_binning.h"
 
 #include <algorithm>
@@ -657,6 +658,70 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
   return PRAD_OK;
 }
 
+int voxel_texture_features_dev(int family, const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                               const int *angles, int Na, int Ng, int alpha, int Nvox, const int *voxels, int kernelRadius,
+                               int force2Ddim, const int *feature_ids, int nfeat, double *out, hipStream_t s) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Geo g;
+  PRAD_TRY(make_geo(size, Nd, &g));
+  if (!image || !mask || !angles || !voxels || !feature_ids || !out) return fail(PRAD_E_ARG, "voxel_texture: NULL pointer");
+  if (Nvox < 1 || nfeat < 1 || kernelRadius <= 0) return fail(PRAD_E_ARG, "voxel_texture: Nvox/nfeat/kernelRadius must be >= 1");
+  if (family < PRAD_VT_GLDM || family > PRAD_VT_GLSZM) return fail(PRAD_E_ARG, "voxel_texture: family %d", family);
+  long long W = 1;
+  for (int d = 0; d < Nd; d++)
+    if (d != force2Ddim) W *= std::min(2 * kernelRadius + 1, g.size[d]);
+  if (Nd > 3 || Ng < 1 || Ng > 255 || Na < 1 || Na > PRAD_VOX_MAX_ANGLES || W > PRAD_VT_MAXW)
+    return fail(PRAD_E_UNSUPPORTED, "voxel_texture: needs Nd <= 3, Ng <= 255, Na <= %d, <= %d voxels per kernel "
+                "(got Nd=%d Ng=%d Na=%d W=%lld)", PRAD_VOX_MAX_ANGLES, PRAD_VT_MAXW, Nd, Ng, Na, W);
+  const int fcount = family == PRAD_VT_NGTDM ? (int)NF_COUNT : (int)ZF_COUNT;
+  for (int i = 0; i < nfeat; i++)
+    if (feature_ids[i] < 0 || feature_ids[i] >= fcount) return fail(PRAD_E_ARG, "voxel_texture: feature id %d", feature_ids[i]);
+  VoxAngles A;
+  A.na = Na;
+  for (int a = 0; a < Na; a++) {
+    for (int d = 0; d < 4; d++) A.o[a][d] = 0;
+    for (int d = 0; d < Nd; d++) {
+      const int o = angles[a * Nd + d];
+      if (o < -127 || o > 127) return fail(PRAD_E_UNSUPPORTED, "voxel_texture: angle offset %d", o);
+      A.o[a][3 - Nd + d] = (signed char)o;
+    }
+  }
+  int dims[3] = {1, 1, 1};
+  for (int d = 0; d < Nd; d++) dims[3 - Nd + d] = g.size[d];
+  const int f2d3 = force2Ddim >= 0 ? 3 - Nd + force2Ddim : -1;
+  PRAD_TRY(c.begin_call(s));
+  int *flags = nullptr, *ids_d = nullptr;
+  PRAD_TRY(c.get<int>("flags", 4, &flags));
+  PRAD_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, s));
+  PRAD_TRY(c.get<int>("vt_ids", (size_t)nfeat, &ids_d));
+  PRAD_HIP(hipMemcpyAsync(ids_d, feature_ids, sizeof(int) * nfeat, hipMemcpyHostToDevice, s));
+  uint8_t *levels = nullptr;
+  PRAD_TRY(neigh_pack(&c, s, g, image, mask, Ng, flags, &levels));
+  {
+    Timed t(c, "voxel", s);
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((long long)Nvox + PRAD_VT_WAVES - 1) / PRAD_VT_WAVES,
+                                                                           (long long)cu_count() * 16));
+    if (family == PRAD_VT_NGTDM) {
+      hipLaunchKernelGGL(voxel_ngtdm_kernel, dim3(gx), dim3(64 * PRAD_VT_WAVES), 0, s, levels, dims[0], dims[1], dims[2], A,
+                         Ng, Nvox, voxels, Nd, kernelRadius, f2d3, ids_d, nfeat, out, flags);
+      PRAD_TRY(check_launch("voxel_ngtdm_kernel"));
+    } else {
+      hipLaunchKernelGGL(voxel_zonelike_kernel, dim3(gx), dim3(64 * PRAD_VT_WAVES), 0, s, family, levels, dims[0], dims[1],
+                         dims[2], A, alpha, Nvox, voxels, Nd, kernelRadius, f2d3, ids_d, nfeat, out, flags);
+      PRAD_TRY(check_launch("voxel_zonelike_kernel"));
+    }
+  }
+  void *fh = nullptr;
+  PRAD_TRY(c.get_pinned("flags_h", sizeof(int) * 4, &fh));
+  PRAD_HIP(hipMemcpyAsync(fh, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  PRAD_TRY(c.end_call(s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  if (((int *)fh)[0]) return fail(PRAD_E_UNSUPPORTED, "voxel_texture: masked levels outside [1, Ng]; use the matrix path");
+  c.last_path = "voxel-fused";
+  return PRAD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // filters
 // ------------------------------------------------------------------------------------------------
@@ -1063,6 +1128,14 @@ int prad_voxel_glcm_features(const int32_t *image, const uint8_t *mask, const in
   if (empty_mask) PRAD_HIP(hipMemcpy(empty_mask, d_masks + 1, sizeof(unsigned) * Nvox, hipMemcpyDeviceToHost));
   if (any_nonempty) PRAD_HIP(hipMemcpy(any_nonempty, d_masks, sizeof(unsigned), hipMemcpyDeviceToHost));
   return PRAD_OK;
+}
+
+int prad_voxel_texture_features_dev(int family, const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                                    const int *angles, int Na, int Ng, int alpha, int Nvox, const int *voxels,
+                                    int kernelRadius, int force2Ddim, const int *feature_ids, int nfeat, double *out,
+                                    void *stream) {
+  return voxel_texture_features_dev(family, image, mask, size, Nd, angles, Na, Ng, alpha, Nvox, voxels, kernelRadius,
+                                    force2Ddim, feature_ids, nfeat, out, (hipStream_t)stream);
 }
 
 // ---- on-device discretisation ----------------------------------------------------------------

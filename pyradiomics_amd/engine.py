@@ -210,6 +210,30 @@ def voxel_glcm_features(image: torch.Tensor, mask: torch.Tensor, Ng: int, voxels
     return res
 
 
+def voxel_texture_features(family: int, image: torch.Tensor, mask: torch.Tensor, Ng: int, voxels: torch.Tensor,
+                           feature_ids, kernelRadius: int = 1, force2D: bool = False, force2Ddimension: int = 0,
+                           distances=(1,), alpha: int = 0) -> torch.Tensor:
+    """Fused voxel-based GLDM (family 1) / NGTDM (2) / GLRLM (3) / GLSZM (4) feature maps: float64 tensor
+    [nfeat, Nvox] on the device.  voxels: int32 [Nd, Nvox] centre coordinates on the device."""
+    lib, image, mask, size = _prep(image, mask)
+    f2d = int(force2Ddimension) if force2D else -1
+    # GLRLM walks one direction per line, the other three look at the full neighbourhood; GLRLM / GLSZM ignore
+    # `distances` (_cmatrices.c:283,475)
+    angles = _build_angles(size, list(distances) if family in (1, 2) else None, family != 3, f2d)
+    Na, Nd = angles.shape
+    vox = voxels.to(torch.int32).contiguous()
+    if vox.dim() != 2 or vox.shape[0] != Nd:
+        raise RuntimeError("Expecting voxel indices array to be 2-dimensional")
+    ids = np.ascontiguousarray(feature_ids, dtype=np.intc)
+    out = torch.empty((len(ids), int(vox.shape[1])), dtype=torch.float64, device=image.device)
+    rc = lib.prad_voxel_texture_features_dev(
+        int(family), C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd, _iptr(angles), Na,
+        int(Ng), int(alpha), int(vox.shape[1]), C.c_void_p(vox.data_ptr()), int(kernelRadius), f2d, _iptr(ids), len(ids),
+        C.c_void_p(out.data_ptr()), _stream_ptr())
+    _lib.raise_for(rc, "voxel texture features")
+    return out
+
+
 # ---- device-resident discretisation and filters (config 3: filter stack -> re-binning -> matrices, all in HBM) ---
 _DTYPE_CODES = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int16: 3}
 

@@ -21,6 +21,13 @@ class RadiomicsGLDM(_ZoneLikeFeatures):
     def _P(self):
         return self.P_gldm
 
+    def _calculateFeatures(self, voxelCoordinates=None):
+        fused = self._fusedVoxelFeatures("gldm", voxelCoordinates, self.gldm_a)
+        if fused is not None:
+            yield from fused
+            return
+        yield from super()._calculateFeatures(voxelCoordinates)
+
     def _initCalculation(self, voxelCoordinates=None):
         self.P_gldm = self._calculateMatrix(voxelCoordinates)
 

@@ -21,6 +21,13 @@ class RadiomicsGLRLM(RadiomicsFeaturesBase):
         self.P_glrlm = None
         self.imageArray = self._applyBinning(self.imageArray)
 
+    def _calculateFeatures(self, voxelCoordinates=None):
+        fused = self._fusedVoxelFeatures("glrlm", voxelCoordinates) if self.weightingNorm is None else None
+        if fused is not None:
+            yield from fused
+            return
+        yield from super()._calculateFeatures(voxelCoordinates)
+
     def _initCalculation(self, voxelCoordinates=None):
         self.P_glrlm = self._calculateMatrix(voxelCoordinates)
         self._calculateCoefficients()

@@ -61,6 +61,13 @@ class RadiomicsGLSZM(_ZoneLikeFeatures):
     def _P(self):
         return self.P_glszm
 
+    def _calculateFeatures(self, voxelCoordinates=None):
+        fused = self._fusedVoxelFeatures("glszm", voxelCoordinates)
+        if fused is not None:
+            yield from fused
+            return
+        yield from super()._calculateFeatures(voxelCoordinates)
+
     def _initCalculation(self, voxelCoordinates=None):
         self.P_glszm = self._calculateMatrix(voxelCoordinates)
         self._calculateCoefficients()

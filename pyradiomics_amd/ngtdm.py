@@ -16,6 +16,13 @@ class RadiomicsNGTDM(RadiomicsFeaturesBase):
         self.P_ngtdm = None
         self.imageArray = self._applyBinning(self.imageArray)
 
+    def _calculateFeatures(self, voxelCoordinates=None):
+        fused = self._fusedVoxelFeatures("ngtdm", voxelCoordinates)
+        if fused is not None:
+            yield from fused
+            return
+        yield from super()._calculateFeatures(voxelCoordinates)
+
     def _initCalculation(self, voxelCoordinates=None):
         self.P_ngtdm = self._calculateMatrix(voxelCoordinates)
         self._calculateCoefficients()

@@ -136,3 +136,32 @@ def test_fused_voxel_glcm_unmasked_kernel_and_3d_radius1():
             assert (~np.isclose(out[True][n], out[False][n], rtol=1e-9, atol=1e-12, equal_nan=True)).mean() < 0.01
             continue
         np.testing.assert_allclose(out[True][n], out[False][n], rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=n)
+
+
+@pytest.mark.parametrize("cls", ["glrlm", "glszm", "gldm", "ngtdm"])
+@pytest.mark.parametrize("case,force2D,radius,masked", [("brain2", True, 2, True), ("brain2", False, 1, True),
+                                                        ("breast1", False, 2, True), ("breast1", False, 1, False),
+                                                        ("brain2", True, 3, False)])
+def test_fused_voxel_texture_equals_matrix_route(cls, case, force2D, radius, masked):
+    """fused voxel kernels of GLRLM / GLSZM / GLDM / NGTDM against the reference's route (per-kernel matrices from the
+    generic kernels + numpy formulas): every non-deprecated feature, kernels at the ROI border (clamped windows, empty
+    GLRLM angles) and unmasked kernels included"""
+    from pyradiomics_amd import cmatrices
+    image, mask, _ = load_case(case)
+    kw = dict(binWidth=25, force2D=force2D, force2Ddimension=0, kernelRadius=radius, maskedKernel=masked,
+              initValue=np.nan, voxelBased=True, label=1, voxelBatch=173)
+    if cls == "gldm":
+        kw["gldm_a"] = 1
+    maps = {}
+    for fused in (True, False):
+        fc = feature_class(cls)(image, mask, fusedVoxel=fused, **kw)
+        maps[fused] = {k: v.array for k, v in fc.execute().items()}
+        if fused:
+            assert cmatrices._lib.last_path() == "voxel-fused"
+    assert set(maps[True]) == set(maps[False]) and len(maps[True]) >= 5
+    for n in maps[True]:
+        a, b = maps[True][n], maps[False][n]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), n
+        ok = ~np.isnan(a)
+        assert ok.sum() > 0
+        np.testing.assert_allclose(a[ok], b[ok], rtol=1e-9, atol=1e-12, err_msg="%s %s" % (cls, n))
