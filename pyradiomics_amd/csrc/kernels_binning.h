@@ -36,9 +36,22 @@ __global__ void __launch_bounds__(256) roi_minmax_kernel(const T *__restrict__ x
     lo = l2 < lo ? l2 : lo;
     hi = h2 > hi ? h2 : hi;
   }
-  if ((threadIdx.x & 63) == 0 && hi != 0ull) {
-    atomicMin(keys, lo);
-    atomicMax(keys + 1, hi);
+  // one pair of global atomics per block: thousands of waves hitting the same two addresses serialise in L2
+  __shared__ unsigned long long slo[4], shi[4];
+  if ((threadIdx.x & 63) == 0) {
+    slo[threadIdx.x >> 6] = lo;
+    shi[threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; w++) {
+      lo = slo[w] < lo ? slo[w] : lo;
+      hi = shi[w] > hi ? shi[w] : hi;
+    }
+    if (hi != 0ull) {
+      atomicMin(keys, lo);
+      atomicMax(keys + 1, hi);
+    }
   }
 }
 
@@ -67,7 +80,13 @@ __global__ void __launch_bounds__(256) digitize_kernel(const T *__restrict__ x, 
     levels[i] = lv;
   }
   for (int o = 32; o > 0; o >>= 1) top = max(top, __shfl_xor(top, o));
-  if ((threadIdx.x & 63) == 0 && top) atomicMax(maxlevel, top);
+  __shared__ int stop[4];
+  if ((threadIdx.x & 63) == 0) stop[threadIdx.x >> 6] = top;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    top = max(max(stop[0], stop[1]), max(stop[2], stop[3]));
+    if (top) atomicMax(maxlevel, top);
+  }
 }
 
 // ROI voxel count per level: per-wave private LDS tables when Ng fits (the common case), global atomics otherwise

@@ -118,6 +118,103 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
   }
 }
 
+// The same recursion for the contiguous axis (inner == 1): a lane-per-line walk would read 64 different cache lines
+// per step.  One wave owns 64 consecutive lines and moves them through LDS in 64-sample tiles: every global access is
+// a 256-byte row segment, the lane then walks its own line inside the tile (pitch 65: conflict-free).  Causal tiles
+// run from the start of the line, anti-causal tiles from its end, so each direction's 4 boundary samples sit in
+// its first tile.
+#define PRAD_RG_T 64
+__global__ void __launch_bounds__(64) rgauss_xline_kernel(const float *__restrict__ in, long long lines, int ln,
+                                                          RGaussCoef c, double *__restrict__ scratch,
+                                                          float *__restrict__ out) {
+#pragma clang fp contract(off)
+  __shared__ float tin[PRAD_RG_T][PRAD_RG_T + 1];
+  __shared__ double tsc[PRAD_RG_T][PRAD_RG_T + 1];
+  const int lane = threadIdx.x;
+  const long long l0 = (long long)blockIdx.x * PRAD_RG_T;
+  const int nl = (int)min((long long)PRAD_RG_T, lines - l0);
+  const bool mine = lane < nl;
+  // ---- causal ----
+  double dm1 = 0, dm2 = 0, dm3 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, v1 = 0;
+  for (int c0 = 0; c0 < ln; c0 += PRAD_RG_T) {
+    const int w = min(PRAD_RG_T, ln - c0);
+    __syncthreads();
+    for (int t = 0; t < nl; t++)
+      if (lane < w) tin[t][lane] = in[(l0 + t) * ln + c0 + lane];
+    __syncthreads();
+    if (mine) {
+      int j = 0;
+      if (c0 == 0) {
+        v1 = tin[lane][0];
+        const double x1 = tin[lane][1], x2 = tin[lane][2], x3 = tin[lane][3];
+        double s0 = v1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+        double s1 = x1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+        double s2 = x2 * c.N0 + x1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+        double s3 = x3 * c.N0 + x2 * c.N1 + x1 * c.N2 + v1 * c.N3;
+        s0 -= v1 * c.BN1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
+        s1 -= s0 * c.D1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
+        s2 -= s1 * c.D1 + s0 * c.D2 + v1 * c.BN3 + v1 * c.BN4;
+        s3 -= s2 * c.D1 + s1 * c.D2 + s0 * c.D3 + v1 * c.BN4;
+        tsc[lane][0] = s0; tsc[lane][1] = s1; tsc[lane][2] = s2; tsc[lane][3] = s3;
+        dm1 = x3; dm2 = x2; dm3 = x1;
+        p1 = s3; p2 = s2; p3 = s1; p4 = s0;
+        j = 4;
+      }
+      for (; j < w; j++) {
+        const double di = tin[lane][j];
+        double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
+        v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
+        tsc[lane][j] = v;
+        dm3 = dm2; dm2 = dm1; dm1 = di;
+        p4 = p3; p3 = p2; p2 = p1; p1 = v;
+      }
+    }
+    __syncthreads();
+    for (int t = 0; t < nl; t++)
+      if (lane < w) scratch[(l0 + t) * ln + c0 + lane] = tsc[t][lane];
+  }
+  // ---- anti-causal: tiles [e - w, e) walking down from e = ln ----
+  double dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+  for (int e = ln; e > 0; e -= PRAD_RG_T) {
+    const int b = max(e - PRAD_RG_T, 0), w = e - b;
+    __syncthreads();
+    for (int t = 0; t < nl; t++)
+      if (lane < w) {
+        tin[t][lane] = in[(l0 + t) * ln + b + lane];
+        tsc[t][lane] = scratch[(l0 + t) * ln + b + lane];
+      }
+    __syncthreads();
+    if (mine) {
+      int j = w - 1;                         // tile-local index of the sample being produced
+      if (e == ln) {
+        const double v2 = tin[lane][w - 1], y1 = tin[lane][w - 2], y2 = tin[lane][w - 3];
+        double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+        double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+        double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+        double a4 = y2 * c.M1 + y1 * c.M2 + v2 * c.M3 + v2 * c.M4;
+        a1 -= v2 * c.BM1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+        a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+        a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
+        a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
+        tsc[lane][w - 1] += a1; tsc[lane][w - 2] += a2; tsc[lane][w - 3] += a3; tsc[lane][w - 4] += a4;
+        dp0 = tin[lane][w - 4]; dp1 = y2; dp2 = y1; dp3 = v2;
+        q0 = a4; q1 = a3; q2 = a2; q3 = a1;
+        j = w - 5;
+      }
+      for (; j >= 0; j--) {
+        double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
+        v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
+        dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = tin[lane][j];
+        tsc[lane][j] += v;
+        q3 = q2; q2 = q1; q1 = q0; q0 = v;
+      }
+    }
+    __syncthreads();
+    for (int t = 0; t < nl; t++)
+      if (lane < w) out[(l0 + t) * ln + b + lane] = (float)tsc[t][lane];
+  }
+}
+
 __global__ void log_accumulate_kernel(float *__restrict__ acc, const float *__restrict__ cur, long long n,
                                       double spacing2, int first) {
   const long long stride = (long long)gridDim.x * blockDim.x;

@@ -867,9 +867,15 @@ int log_dev(const float *in, const int *size, int Nd, const double *spacing, dou
         const long long inner = g.stride[ax];
         const long long lines = outer * inner;
         float *dst = pp[flip];
-        hipLaunchKernelGGL(rgauss_line_kernel, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, cur, outer,
-                           g.size[ax], inner, k, scratch, dst);
-        PRAD_TRY(check_launch("rgauss_line_kernel"));
+        if (inner == 1 && g.size[ax] >= 8) {      // contiguous axis: LDS-tiled walk (see kernels_filters.h)
+          hipLaunchKernelGGL(rgauss_xline_kernel, dim3((unsigned)((lines + PRAD_RG_T - 1) / PRAD_RG_T)), dim3(64), 0, s, cur,
+                             lines, g.size[ax], k, scratch, dst);
+          PRAD_TRY(check_launch("rgauss_xline_kernel"));
+        } else {
+          hipLaunchKernelGGL(rgauss_line_kernel, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, cur, outer,
+                             g.size[ax], inner, k, scratch, dst);
+          PRAD_TRY(check_launch("rgauss_line_kernel"));
+        }
         cur = dst;
         flip ^= 1;
         return PRAD_OK;
@@ -1148,7 +1154,7 @@ int prad_roi_minmax_dev(const void *image, int dtype, const uint8_t *mask, long 
   PRAD_TRY(c.get<unsigned long long>("minmax_keys", 2, &keys));
   const unsigned long long init[2] = {~0ull, 0ull};
   PRAD_HIP(hipMemcpyAsync(keys, init, sizeof(init), hipMemcpyHostToDevice, s));
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 2048));
   switch (dtype) {
     case 0: hipLaunchKernelGGL(roi_minmax_kernel<float>, dim3(gx), dim3(256), 0, s, (const float *)image, mask, n, keys); break;
     case 1: hipLaunchKernelGGL(roi_minmax_kernel<double>, dim3(gx), dim3(256), 0, s, (const double *)image, mask, n, keys); break;
