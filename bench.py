@@ -85,6 +85,57 @@ def cpu_baseline(image: torch.Tensor, mask: torch.Tensor, levels: int, target_vo
     return out, (img, msk, g[0], r[0], Nr)
 
 
+def usable_cores() -> int:
+    """cores this process may really use: the affinity mask, capped by the cgroup CPU quota of the container"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota|max> <period>"
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:     # cgroup v1
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_baseline_all_cores(levels: int, size: int, nz: int = 24):
+    """The only way the reference uses more than one core: one process per case (scripts/__init__.py:387-416).
+    nproc single-threaded workers, each on its own nz x size x size slab, started together; aggregate Mvoxels/s."""
+    import subprocess
+    import sys
+    nproc = usable_cores()
+    root = os.path.dirname(os.path.abspath(__file__))
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", str(nz), str(size), str(size), str(levels), str(i)],
+                              cwd=root, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for i in range(nproc)]
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("cpu worker failed to start")
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write("go\n")
+            p.stdin.flush()
+        vox = 0
+        for p in procs:
+            v, _ = p.stdout.readline().split()
+            vox += int(v)
+        dt = time.perf_counter() - t0
+    finally:
+        for p in procs:
+            p.kill() if p.poll() is None else None
+            p.wait()
+    return {"value": round(vox / dt / 1e6, 2), "unit": "Mvoxels/s", "nproc": nproc,
+            "sample": "%d processes x %dx%dx%d slab each, %.1f s wall" % (nproc, nz, size, size, dt)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,6 +254,10 @@ def main() -> None:
             gg, rr, _ = engine.glcm_glrlm(image[:img.shape[0]].contiguous(), mask[:img.shape[0]].contiguous(), Ng, Nr_s)
             cb["parity"] = bool(np.array_equal(gg.cpu().numpy(), g_cpu) and np.array_equal(rr.cpu().numpy(), r_cpu))
             assert cb["parity"], "GPU matrices differ from the CPU baseline on the sample"
+            try:                                   # informational: every host core busy, one process per volume
+                cb["all_cores"] = cpu_baseline_all_cores(Ng, args.size)
+            except Exception as e:                 # never let the side figure break the bench line
+                cb["all_cores"] = {"error": str(e)[:200]}
             out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if dist_on:

@@ -31,10 +31,9 @@ def _prep(image: torch.Tensor, mask: torch.Tensor):
         raise ValueError("Dimensions of image and mask do not match.")
     lib = _lib.load()
     dev = image.device.index if image.device.index is not None else torch.cuda.current_device()
-    if lib.prad_get_device() != dev or True:
-        rc = lib.prad_set_device(dev)
-        if rc != _lib.PRAD_OK:
-            _lib.raise_for(rc, "set_device")
+    rc = lib.prad_set_device(dev)          # the library context is per thread: follow the tensor's device
+    if rc != _lib.PRAD_OK:
+        _lib.raise_for(rc, "set_device")
     size = np.array(image.shape, dtype=np.intc)
     return lib, image, mask, size
 
