@@ -55,6 +55,14 @@ class RadiomicsFeaturesBase:
         self.masked = self.settings.get("maskedKernel", True)
         maskArray = as_array(self.inputMask) == self.label
         self.labelledVoxelCoordinates = np.array(np.where(maskArray))
+        self.allLabelledVoxelCoordinates = self.labelledVoxelCoordinates
+        shard = self.settings.get("voxelShard")
+        if shard is not None:
+            # multi-GPU voxel maps (pyradiomics_amd.batch.voxel_maps_sharded): this process computes only its
+            # contiguous slice of the centre list (raster order => a z-slab); kernels still see the whole volume
+            rank, world = shard
+            n = self.labelledVoxelCoordinates.shape[1]
+            self.labelledVoxelCoordinates = self.labelledVoxelCoordinates[:, (n * rank) // world:(n * (rank + 1)) // world]
         # unmasked kernels discretise (and later count) over the whole image
         self.maskArray = maskArray if self.masked else np.ones(self.imageArray.shape, dtype=bool)
 

@@ -53,3 +53,33 @@ def run_batch(cases: Sequence, worker: Callable, gather: bool = True):
     for part in bucket:
         merged.update(part)
     return [merged[i] for i in range(len(cases))]
+
+
+def voxel_maps_sharded(feature_class, image, mask, features=None, **settings):
+    """Voxel-based feature maps of one case on all ranks of the job: the centre-voxel list is cut into `world`
+    contiguous slices (z-slabs in raster order), every rank evaluates its slice on its own GPU against the whole
+    (replicated) volume, and rank 0 assembles the maps.  No data-path collective -- the per-rank results travel
+    as Python objects on the control plane.  Returns {feature name: Image} on rank 0, None elsewhere.
+    `feature_class` is one of the Radiomics* classes; `features` the names to enable (default: all)."""
+    import numpy as np
+    rank, world = rank_world()
+    fc = feature_class(image, mask, voxelBased=True, voxelShard=(rank, world), **settings)
+    for f in features or []:
+        fc.enableFeatureByName(f)
+    maps = fc.execute()
+    coords = tuple(fc.labelledVoxelCoordinates)
+    mine = {name: np.asarray(img.array)[coords] for name, img in maps.items()}
+    if world == 1:
+        return maps
+    import torch.distributed as dist
+    bucket = [None] * world if rank == 0 else None
+    dist.gather_object((fc.labelledVoxelCoordinates, mine), bucket, dst=0)
+    if rank != 0:
+        return None
+    out = {}
+    for name, img in maps.items():
+        full = np.array(img.array, copy=True)
+        for c, vals in bucket:
+            full[tuple(c)] = vals[name]
+        out[name] = img.like(full)
+    return out

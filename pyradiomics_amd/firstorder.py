@@ -28,7 +28,7 @@ class RadiomicsFirstOrder(RadiomicsFeaturesBase):
         kernelRadius = self.settings.get("kernelRadius", 1)
         # firstorder.py:45-58: kernel offsets are limited by the ROI (masked kernels) or image extent
         if self.masked:
-            size = np.max(self.labelledVoxelCoordinates, 1) - np.min(self.labelledVoxelCoordinates, 1) + 1
+            size = np.max(self.allLabelledVoxelCoordinates, 1) - np.min(self.allLabelledVoxelCoordinates, 1) + 1
         else:
             size = np.array(self.imageArray.shape)
         self.boundingBoxSize = np.minimum(size, kernelRadius * 2 + 1)
