@@ -124,18 +124,22 @@ struct SweepSet {
 //   [.., +64)                  per-lane dummy words (targets of masked-out increments)
 // fused table (GLCM and GLRLM together, FUSED):
 //   [0, (Ng+1)*(RS+1)*(Ng+1))  H [prev][min(len,RS+1)-1][cur]         cur = 0: the run ended at an unmasked
-//   [.., +64)                  dummies                                voxel / line end;  row prev = 0 collects
-//                                                                     the "events" that follow unmasked voxels
+//   [.., +Ng*RL)               G [prev-1][len-1-RS], RS < len <= RS+RL voxel / line end;  row prev = 0 collects
+//   [.., +64)                  dummies                                the "events" that follow unmasked voxels
 //                                                                     and is ignored (saves a compare per step)
 //   One event per RUN END carries everything both matrices need:
-//     GLRLM[prev][len]      = sum_cur H[prev][len][cur]          (len <= RS; longer runs go to L2 atomics)
+//     GLRLM[prev][len]      = sum_cur H[prev][len][cur]          (len <= RS; a longer run puts its pair into the
+//                                                                 len slot RS and its length into G, or, beyond
+//                                                                 RS+RL, into a wave-aggregated L2 atomic)
 //     GLCM[prev][cur!=prev] = sum_len H[prev][len][cur]          (a pair of different levels IS a run boundary)
 //     GLCM[g][g]            = sum_len (len-1) * GLRLM[g][len]    (pairs inside runs; evaluated in finalize)
 //   so the walk issues ONE ds_add per step instead of two, and none of them hits the hot diagonal bins.
+#define PRAD_LONG_BINS 64
 struct HistLayout {
   int Ng, RS;
   bool fused;
   int glrlm0;  // first GLRLM word (separate tables)
+  int g0, RL;  // fused: first word / bins per level of the long-run table G
   int dummy0;  // first dummy word
   int words;   // total
 };
@@ -144,9 +148,13 @@ __host__ __device__ inline HistLayout hist_layout(bool glcm, bool glrlm, bool fu
   h.Ng = Ng;
   h.RS = RS;
   h.fused = fused;
+  h.g0 = 0;
+  h.RL = 0;
   if (fused) {
     h.glrlm0 = 0;
-    h.dummy0 = (Ng + 1) * (RS + 1) * (Ng + 1);
+    h.g0 = (Ng + 1) * (RS + 1) * (Ng + 1);
+    h.RL = PRAD_LONG_BINS;
+    h.dummy0 = h.g0 + Ng * h.RL;
   } else {
     h.glrlm0 = glcm ? Ng * Ng : 0;
     h.dummy0 = h.glrlm0 + (glrlm ? RS * Ng : 0);
@@ -255,6 +263,10 @@ struct Walker<true, true, LONG, true> {
   int Nr, P, Q;
   int cB;      // LDS address of H
   int lenmax;  // RS*Q: byte offset of the "long" slot
+  int gB;      // LDS address of G minus the offset of its first bin (len-1 = RS, prev = 1)
+  int RL4;     // bytes per level row of G
+  unsigned Qinv;  // ceil(2^32 / Q): (len-1) = umulhi((len-1)*Q, Qinv)
+  int RS, RL;
   int dummy;
   // state
   int prev;
@@ -268,11 +280,37 @@ struct Walker<true, true, LONG, true> {
     P = (h.RS + 1) * Q;
     cB = base;
     lenmax = h.RS * Q;
+    RS = h.RS;
+    RL = h.RL;
+    RL4 = 4 * h.RL;
+    gB = base + 4 * h.g0 - RL4 - 4 * h.RS;       // + prev*RL4 + (len-1)*4 addresses G[prev-1][len-1-RS]
+    Qinv = (unsigned)((0x100000000ull + (unsigned)Q - 1) / (unsigned)Q);
     dummy = base + 4 * (h.dummy0 + lane);
   }
   __device__ __forceinline__ void begin_line() {
     prev = 0;
     pl = cB;
+  }
+  // the run of level `pv` (!= 0) that just ended was longer than RS: record its length.  Rare, divergent.
+  __device__ __forceinline__ void long_event(int pv, int lb) {
+    const int idx = (int)__umulhi((unsigned)lb, Qinv);            // len - 1
+    if (idx < RS + RL) {
+      lds_bump(gB + __mul24(pv, RL4) + (idx << 2));
+      return;
+    }
+    // very long runs (flat regions): lanes of the wave that close the same (level, length) share one L2 atomic
+    const unsigned key = ((unsigned)pv << 20) | (unsigned)idx;
+    bool pending = true;
+    while (pending) {
+      const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)key);
+      const bool same = key == first;
+      const unsigned long long m = __ballot(same);       // evaluated by every still-pending lane
+      if (same) {
+        if ((int)(__ffsll((long long)m) - 1) == (int)(threadIdx.x & 63))
+          atomicAdd(&rl_long[(size_t)(pv - 1) * Nr + idx], (u32)__popcll(m));
+        pending = false;
+      }
+    }
   }
   __device__ __forceinline__ int lenb() const { return pl - (__mul24(prev, P) + cB); }
   // stretches of unmasked voxels count too: their events land in row 0, but an unclamped slot must stay in range
@@ -284,7 +322,7 @@ struct Walker<true, true, LONG, true> {
     if (LONG && CHECK) {
       const int lb = lenb();
       bin = pl - lb + min(lb, lenmax);
-      if (chg && prev != 0 && lb >= lenmax) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + lb / Q], 1u);
+      if (chg && prev != 0 && lb >= lenmax) long_event(prev, lb);
     }
     lds_bump(chg ? bin + (cur << 2) : dummy);
     pl = select_i32(chg, __mul24(cur, P) + cB, pl + Q);
@@ -303,7 +341,7 @@ struct Walker<true, true, LONG, true> {
     if (LONG && CHECK) {
       const int lb = lenb();
       bin = pl - lb + min(lb, lenmax);
-      if (chg && prev != 0 && lb >= lenmax) atomicAdd(&rl_long[(size_t)(prev - 1) * Nr + lb / Q], 1u);
+      if (chg && prev != 0 && lb >= lenmax) long_event(prev, lb);
     }
     lds_bump(chg ? bin + (evt << 2) : dummy);
     pl = select_i32(chg, __mul24(cur, P) + cB, pl + Q);
@@ -364,6 +402,11 @@ __device__ __forceinline__ void flush_block_hist(const u32 *lds, const HistLayou
       u32 v = 0;
       for (int c = 0; c <= Ng; c++) v += lds[(p + 1) * P + l * Q + c];
       if (v) atomicAdd(rd + (size_t)p * Nr + l, v);
+    }
+    for (int i = threadIdx.x; i < Ng * h.RL; i += blockDim.x) {  // lengths RS+1 .. RS+RL
+      const int p = i / h.RL, l = h.RS + (i - p * h.RL);
+      const u32 v = lds[h.g0 + i];
+      if (v && l < Nr) atomicAdd(rd + (size_t)p * Nr + l, v);
     }
     return;
   }

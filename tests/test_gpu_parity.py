@@ -268,3 +268,23 @@ def test_level_counts_and_tensor_inputs_of_the_operator_module():
     assert np.array_equal(cmatrices.calculate_gldm(ti, tm, np.array([1]), 11, 1, False, 0), cmatrices.calculate_gldm(img, mask, np.array([1]), 11, 1, False, 0))
     assert np.array_equal(cmatrices.calculate_ngtdm(ti, tm, np.array([1]), 11, False, 0), cmatrices.calculate_ngtdm(img, mask, np.array([1]), 11, False, 0))
     assert np.array_equal(cmatrices.calculate_glszm(ti, tm, 11, int(mask.sum()), False, 0), cmatrices.calculate_glszm(img, mask, 11, int(mask.sum()), False, 0))
+
+
+@pytest.mark.parametrize("shape", [(6, 40, 300), (40, 6, 200), (150, 130, 8)])
+def test_long_runs_all_three_mechanisms(cm, oracle_port, shape):
+    """runs longer than the LDS table's run-length slots: lengths just above RS go to the LDS long-run table,
+    full-row / full-column runs of flat regions to the wave-aggregated L2 atomics -- along every axis"""
+    rng = np.random.default_rng(21)
+    Ng = 32
+    img = rng.integers(1, Ng + 1, size=shape).astype(np.int32)
+    img[: shape[0] // 2] = 7                                  # a flat half: runs as long as the axes
+    img[:, : shape[1] // 3, :] = np.where(rng.random((shape[0], shape[1] // 3, shape[2])) < 0.02, 3, 9)   # 20..100-voxel runs
+    mask = np.ones(shape, bool)
+    mask[rng.random(shape) < 0.001] = False
+    from pyradiomics_amd import _lib
+    Nr = max(shape)
+    g, r, ang = cm.calculate_glcm_glrlm(img, mask, Ng, Nr, False, 0)
+    assert _lib.last_path() == "sweep"
+    assert np.array_equal(r, oracle_port.calculate_glrlm(img, mask, Ng, Nr, False, 0)[0])
+    assert np.array_equal(g, oracle_port.calculate_glcm(img, mask, [1], Ng, False, 0)[0])
+    assert r[0, :, 80:, :].sum() > 0 and r[0, :, 20:78, :].sum() > 0      # both long-run paths were exercised
