@@ -142,7 +142,9 @@ __device__ __forceinline__ void lds_union(int *lab, int a, int b) {
   }
 }
 
-__global__ void __launch_bounds__(256) glszm_tile_kernel(Offsets3 A, const int *__restrict__ image,
+// mode: 0 = any offset list, 1 = the full 26-neighbourhood (13 backward offsets), 2 = the full in-plane
+// 8-neighbourhood (4 backward offsets, dz = 0)
+__global__ void __launch_bounds__(256) glszm_tile_kernel(Offsets3 A, int mode, const int *__restrict__ image,
                                                          const uint8_t *__restrict__ mask, int Nz, int Ny, int Nx,
                                                          int *__restrict__ labels, unsigned *__restrict__ sizes) {
   __shared__ int img[PRAD_TVOX];
@@ -166,11 +168,46 @@ __global__ void __launch_bounds__(256) glszm_tile_kernel(Offsets3 A, const int *
     if (!msk[k]) continue;
     const int lx = k % PRAD_TX, ly = (k / PRAD_TX) % PRAD_TY, lz = k / (PRAD_TX * PRAD_TY);
     const int gl = img[k];
-    for (int a = 0; a < A.na; a++) {
-      const int qz = lz + A.o[a][0], qy = ly + A.o[a][1], qx = lx + A.o[a][2];
-      if ((unsigned)qz >= PRAD_TZ || (unsigned)qy >= PRAD_TY || (unsigned)qx >= PRAD_TX) continue;
+    // in-tile index of the neighbour at (dz, dy, dx) if it lies in the tile and continues the zone, else -1
+    auto same = [&](int dz, int dy, int dx) -> int {
+      const int qz = lz + dz, qy = ly + dy, qx = lx + dx;
+      if ((unsigned)qz >= PRAD_TZ || (unsigned)qy >= PRAD_TY || (unsigned)qx >= PRAD_TX) return -1;
       const int j = (qz * PRAD_TY + qy) * PRAD_TX + qx;
-      if (msk[j] && img[j] == gl) lds_union(lab, k, j);
+      return (msk[j] && img[j] == gl) ? j : -1;
+    };
+    if (mode == 0) {
+      for (int a = 0; a < A.na; a++) {
+        const int j = same(A.o[a][0], A.o[a][1], A.o[a][2]);
+        if (j >= 0) lds_union(lab, k, j);
+      }
+      continue;
+    }
+    // Full 8- / 26-neighbourhoods: a neighbour that is itself adjacent (within its plane) to one already united
+    // with k belongs to the same zone through that plane's own unions, so its union is redundant.  On smooth data
+    // this leaves ~2 unions per voxel instead of ~10.
+    const int b = same(0, -1, 0);                    // in-plane: b is adjacent to a, c and d
+    if (b >= 0) lds_union(lab, k, b);
+    else {
+      const int a = same(0, -1, -1), c = same(0, -1, 1), d = same(0, 0, -1);
+      if (c >= 0) lds_union(lab, k, c);
+      if (a >= 0) lds_union(lab, k, a);              // a and d are adjacent to each other
+      else if (d >= 0) lds_union(lab, k, d);
+    }
+    if (mode == 1) {                                 // plane above: its centre is adjacent to the other eight
+      const int m = same(-1, 0, 0);
+      if (m >= 0) lds_union(lab, k, m);
+      else {
+        const int e1 = same(-1, -1, 0), e2 = same(-1, 1, 0), e3 = same(-1, 0, -1), e4 = same(-1, 0, 1);
+        if (e1 >= 0) lds_union(lab, k, e1);
+        if (e2 >= 0) lds_union(lab, k, e2);
+        if (e3 >= 0) lds_union(lab, k, e3);
+        if (e4 >= 0) lds_union(lab, k, e4);
+        int q;                                       // a corner is adjacent to the two edges next to it
+        if (e1 < 0 && e3 < 0 && (q = same(-1, -1, -1)) >= 0) lds_union(lab, k, q);
+        if (e1 < 0 && e4 < 0 && (q = same(-1, -1, 1)) >= 0) lds_union(lab, k, q);
+        if (e2 < 0 && e3 < 0 && (q = same(-1, 1, -1)) >= 0) lds_union(lab, k, q);
+        if (e2 < 0 && e4 < 0 && (q = same(-1, 1, 1)) >= 0) lds_union(lab, k, q);
+      }
     }
   }
   __syncthreads();
@@ -219,57 +256,84 @@ __global__ void __launch_bounds__(256) glszm_tile_kernel(Offsets3 A, const int *
 __global__ void __launch_bounds__(256) glszm_border_kernel(Offsets3 A, const int *__restrict__ image,
                                                            const uint8_t *__restrict__ mask, int Nz, int Ny, int Nx,
                                                            int *__restrict__ labels) {
-  const long long n = (long long)Nz * Ny * Nx, plane = (long long)Ny * Nx;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  const long long nround = ((n + stride - 1) / stride) * stride;      // whole waves stay in the loop for the shuffles
+  // One wave per row (z, y).  Rows on a z- or y-face of their tile are scanned completely; in all other rows only
+  // the two x-faces of every tile (x mod 64 in {0, 63}) can have a backward neighbour in another tile, so the wave
+  // visits just those.  No per-voxel index decoding: z, y are wave-uniform, x comes from the lane.
   const int lane = threadIdx.x & 63;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
-    int z = 0, y = 0, x = 0, gl = 0, li = -1;
-    if (i < n) {
-      z = (int)(i / plane);
-      const int r = (int)(i - (long long)z * plane);
-      y = r / Nx;
-      x = r - y * Nx;
-      // interior voxels of a tile have all their backward neighbours inside the tile
-      const bool edge = (z % PRAD_TZ == 0) || (y % PRAD_TY == 0) || (y % PRAD_TY == PRAD_TY - 1) ||
-                        (x % PRAD_TX == 0) || (x % PRAD_TX == PRAD_TX - 1);
-      if (edge && mask[i]) {
-        gl = image[i];
-        li = labels[i];
+  const long long nrows = (long long)Nz * Ny;
+  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  const int xtiles = (Nx + PRAD_TX - 1) / PRAD_TX;
+  for (long long row = wave0; row < nrows; row += nwaves) {
+    const int z = (int)(row / Ny), y = (int)(row - (long long)z * Ny);
+    const bool row_edge = (z % PRAD_TZ == 0) || (y % PRAD_TY == 0) || (y % PRAD_TY == PRAD_TY - 1);
+    const int count = row_edge ? Nx : 2 * xtiles;            // candidates in this row
+    const long long rbase = row * Nx;
+    for (int c0 = 0; c0 < count; c0 += 64) {
+      const int c = c0 + lane;
+      int x = -1;
+      if (c < count) x = row_edge ? c : (c >> 1) * PRAD_TX + ((c & 1) ? PRAD_TX - 1 : 0);
+      int gl = 0, li = -1;
+      if (x >= 0 && x < Nx && mask[rbase + x]) {
+        gl = image[rbase + x];
+        li = labels[rbase + x];
       }
-    }
-    if (__ballot(li >= 0) == 0ull) continue;
-    for (int a = 0; a < A.na; a++) {
-      int lj = -1;
-      if (li >= 0) {
-        const int qz = z + A.o[a][0], qy = y + A.o[a][1], qx = x + A.o[a][2];
-        const bool in = (unsigned)qz < (unsigned)Nz && (unsigned)qy < (unsigned)Ny && (unsigned)qx < (unsigned)Nx;
-        const bool same_tile = qz / PRAD_TZ == z / PRAD_TZ && qy / PRAD_TY == y / PRAD_TY && qx / PRAD_TX == x / PRAD_TX;
-        if (in && !same_tile) {
-          const long long j = ((long long)qz * Ny + qy) * Nx + qx;
-          if (mask[j] && image[j] == gl) lj = labels[j];
+      if (__ballot(li >= 0) == 0ull) continue;
+      for (int a = 0; a < A.na; a++) {
+        int lj = -1;
+        if (li >= 0) {
+          const int qz = z + A.o[a][0], qy = y + A.o[a][1], qx = x + A.o[a][2];
+          const bool in = (unsigned)qz < (unsigned)Nz && (unsigned)qy < (unsigned)Ny && (unsigned)qx < (unsigned)Nx;
+          const bool same_tile = qz / PRAD_TZ == z / PRAD_TZ && qy / PRAD_TY == y / PRAD_TY && qx / PRAD_TX == x / PRAD_TX;
+          if (in && !same_tile) {
+            const long long j = ((long long)qz * Ny + qy) * Nx + qx;
+            if (mask[j] && image[j] == gl) lj = labels[j];
+          }
         }
+        const int pi = __shfl_up(li, 1), pj = __shfl_up(lj, 1);
+        if (lj >= 0 && !(lane > 0 && pi == li && pj == lj)) uf_union(labels, li, lj);
       }
-      const int pi = __shfl_up(li, 1), pj = __shfl_up(lj, 1);
-      if (lj >= 0 && !(lane > 0 && pi == li && pj == lj)) uf_union(labels, li, lj);
     }
   }
 }
 
 // tiled path: sizes[] holds the voxel count of every tile-local component at its tile root; fold the counts of
 // tile roots that were linked elsewhere into their global root.  One find per (zone, tile) instead of per voxel.
+// A zone that spans thousands of tiles would otherwise receive thousands of atomics on one address, so every block
+// owns a CONTIGUOUS slab of voxels and first combines contributions to the same root in an LDS hash table.
+#define PRAD_RS_SLOTS 1024
+#define PRAD_RS_CHUNK (256 * 256)      // voxels per block
 __global__ void __launch_bounds__(256) glszm_rootsum_kernel(long long n, int *__restrict__ labels,
                                                             unsigned *__restrict__ sizes) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  __shared__ int hkey[PRAD_RS_SLOTS];
+  __shared__ unsigned hval[PRAD_RS_SLOTS];
+  for (int k = threadIdx.x; k < PRAD_RS_SLOTS; k += blockDim.x) {
+    hkey[k] = -1;
+    hval[k] = 0u;
+  }
+  __syncthreads();
+  const long long lo = (long long)blockIdx.x * PRAD_RS_CHUNK, hi = min(n, lo + PRAD_RS_CHUNK);
+  for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const unsigned sz = sizes[i];
     if (sz == 0u) continue;
     const int l = labels[i];
     if (l == (int)i) continue;
     const int r = uf_find(labels, l);
     labels[i] = r;
-    atomicAdd(sizes + r, sz);
+    unsigned slot = ((unsigned)r * 2654435761u) >> 22;          // 10 bits
+    bool done = false;
+    for (int probe = 0; probe < 8 && !done; probe++, slot = (slot + 1) & (PRAD_RS_SLOTS - 1)) {
+      const int old = atomicCAS(hkey + slot, -1, r);
+      if (old == -1 || old == r) {
+        atomicAdd(hval + slot, sz);
+        done = true;
+      }
+    }
+    if (!done) atomicAdd(sizes + r, sz);
   }
+  __syncthreads();
+  for (int k = threadIdx.x; k < PRAD_RS_SLOTS; k += blockDim.x)
+    if (hkey[k] >= 0 && hval[k]) atomicAdd(sizes + hkey[k], hval[k]);
 }
 
 // label[i] = root(i) and size[root] += 1.  x-adjacent voxels usually share a root, so each wave first collapses
@@ -630,13 +694,22 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
     if (tiled) {
       const long long tiles = (long long)((dims3[0] + PRAD_TZ - 1) / PRAD_TZ) * ((dims3[1] + PRAD_TY - 1) / PRAD_TY) *
                               ((dims3[2] + PRAD_TX - 1) / PRAD_TX);
-      hipLaunchKernelGGL(glszm_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, s, A3, image, mask, dims3[0], dims3[1],
-                         dims3[2], st.labels, st.sizes);
+      // all 13 (all 4 in-plane) backward unit offsets present => the redundancy rules of the tile kernel apply
+      int mode = 0;
+      if (A3.na == 13) mode = 1;
+      else if (A3.na == 4) {
+        mode = 2;
+        for (int a = 0; a < 4; a++)
+          if (A3.o[a][0] != 0) mode = 0;
+      }
+      hipLaunchKernelGGL(glszm_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, s, A3, mode, image, mask, dims3[0],
+                         dims3[1], dims3[2], st.labels, st.sizes);
       PRAD_TRY(check_launch("glszm_tile_kernel"));
-      hipLaunchKernelGGL(glszm_border_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, A3, image, mask, dims3[0],
-                         dims3[1], dims3[2], st.labels);
+      hipLaunchKernelGGL(glszm_border_kernel, dim3((unsigned)std::min<long long>(((long long)dims3[0] * dims3[1] + 3) / 4, 16384)),
+                         dim3(256), 0, s, A3, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
       PRAD_TRY(check_launch("glszm_border_kernel"));
-      hipLaunchKernelGGL(glszm_rootsum_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g.n, st.labels, st.sizes);
+      hipLaunchKernelGGL(glszm_rootsum_kernel, dim3((unsigned)((g.n + PRAD_RS_CHUNK - 1) / PRAD_RS_CHUNK)), dim3(256), 0, s,
+                         g.n, st.labels, st.sizes);
       PRAD_TRY(check_launch("glszm_rootsum_kernel"));
     } else {
       hipLaunchKernelGGL(glszm_init_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, mask, g.n, st.labels, st.sizes);
