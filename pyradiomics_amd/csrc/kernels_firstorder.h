@@ -13,21 +13,38 @@ namespace prad {
 
 #define PRAD_FO_BLOCKS 1024
 
+// Every block owns a contiguous slab: it counts its ROI voxels, reserves their output range with ONE global atomic
+// (a per-wave atomic on the shared cursor serialises ~n/64 same-address operations in L2), then scatters with an LDS
+// cursor.  The output order is irrelevant: the values are sorted next.
 template <typename T>
 __global__ void __launch_bounds__(256) fo_compact_kernel(const T *__restrict__ x, const uint8_t *__restrict__ mask,
                                                          long long n, double *__restrict__ vals,
                                                          unsigned long long *__restrict__ count) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  const long long nround = ((n + stride - 1) / stride) * stride;
+  __shared__ unsigned cursor, total;
+  __shared__ unsigned long long base;
+  if (threadIdx.x == 0) { cursor = 0u; total = 0u; }
+  __syncthreads();
+  const long long per = (n + gridDim.x - 1) / gridDim.x;
+  const long long lo = (long long)blockIdx.x * per, hi = min(n, lo + per);
   const int lane = threadIdx.x & 63;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nround; i += stride) {
-    const bool m = i < n && mask[i] != 0;
+  unsigned mine = 0;
+  for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) mine += mask[i] != 0;
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+  if (lane == 0 && mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) base = total ? atomicAdd(count, (unsigned long long)total) : 0ull;
+  __syncthreads();
+  if (!total) return;
+  const long long span = hi - lo;
+  const long long rounds = (span + blockDim.x - 1) / blockDim.x;
+  for (long long r = 0; r < rounds; r++) {
+    const long long i = lo + r * blockDim.x + threadIdx.x;
+    const bool m = i < hi && mask[i] != 0;
     const unsigned long long B = __ballot(m);
-    if (!B) continue;
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(B));
-    base = __shfl(base, 0);
-    if (m) vals[base + __popcll(B & ((1ull << lane) - 1ull))] = (double)x[i];
+    unsigned wbase = 0;
+    if (lane == 0 && B) wbase = atomicAdd(&cursor, (unsigned)__popcll(B));
+    wbase = __shfl(wbase, 0);
+    if (m) vals[base + wbase + __popcll(B & ((1ull << lane) - 1ull))] = (double)x[i];
   }
 }
 
