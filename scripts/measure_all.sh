@@ -15,6 +15,8 @@ L=$R/gpurun_out/measure_$tag.log
   python $R/scripts/bench_firstorder.py 256
   echo "## voxel-based GLCM maps (scripts/bench_voxel.py)"
   python $R/scripts/bench_voxel.py
+  echo "## fused voxel-based maps of the other texture classes (scripts/bench_voxel_texture.py)"
+  python $R/scripts/bench_voxel_texture.py 256
   echo "## whole cases: device-resident vs host-array route (scripts/bench_cases.py)"
   python $R/scripts/bench_cases.py 256 3 smooth
   echo "## config 5: 64 cases through the batch front end (scripts/bench_batch.py)"
