@@ -427,7 +427,9 @@ __device__ __forceinline__ void flush_block_hist(const u32 *lds, const HistLayou
   }
 }
 
+#ifndef PRAD_SWEEP_UNROLL
 #define PRAD_SWEEP_UNROLL 8
+#endif
 
 struct __attribute__((packed)) u32_unaligned { u32 v; };
 struct __attribute__((packed)) u16_unaligned { unsigned short v; };
