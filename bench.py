@@ -85,6 +85,23 @@ def cpu_baseline(image: torch.Tensor, mask: torch.Tensor, levels: int, target_vo
     return out, (img, msk, g[0], r[0], Nr)
 
 
+def measured_copy_bandwidth(device) -> float:
+    """device-to-device copy of 1 GiB (read + write = 2 GiB moved), GB/s: the bandwidth a pure streaming kernel
+    achieves on this GPU, reported next to the 8 TB/s datasheet peak"""
+    n = 1 << 28
+    src = torch.empty(n, dtype=torch.int32, device=device).fill_(1)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(5):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * n * 4 / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def usable_cores() -> int:
     """cores this process may really use: the affinity mask, capped by the cgroup CPU quota of the container"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -225,6 +242,7 @@ def main() -> None:
         pipe_ms = device_ms / args.steps
         alg_bytes = ALG_BYTES_PER_VOXEL * nvox
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+        copy_gbps = measured_copy_bandwidth(device)
         out = {
             "metric": "Mvoxels/s for GLCM+GLRLM build, 512^3 vol @32 bins",
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
@@ -244,6 +262,7 @@ def main() -> None:
                 "pipeline_ms": round(pipe_ms, 4), "pack_ms": round(kernel_ms["pack"] / args.steps, 4),
                 "finalize_ms": round(kernel_ms["finalize"] / args.steps, 4),
                 "pipeline_achieved": round(alg_bytes / (pipe_ms * 1e-3) / 1e9, 2),
+                "measured_copy_GBps": round(copy_gbps, 1), "frac_of_measured_copy": round(achieved / copy_gbps, 5),
                 "note": "achieved = 5 B/voxel x voxels / sweep time (HIP events on the launch stream); "
                         "pipeline_* uses pack+sweeps+finalize",
             },
