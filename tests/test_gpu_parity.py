@@ -288,3 +288,54 @@ def test_long_runs_all_three_mechanisms(cm, oracle_port, shape):
     assert np.array_equal(r, oracle_port.calculate_glrlm(img, mask, Ng, Nr, False, 0)[0])
     assert np.array_equal(g, oracle_port.calculate_glcm(img, mask, [1], Ng, False, 0)[0])
     assert r[0, :, 80:, :].sum() > 0 and r[0, :, 20:78, :].sum() > 0      # both long-run paths were exercised
+
+
+def test_full_size_512_properties():
+    """BASELINE's headline size (512^3, 32 levels) is beyond what the CPU oracle finishes in seconds: check the
+    size-independent identities every exact result must satisfy, on device-resident inputs, for all five matrices."""
+    import torch
+    from pyradiomics_amd import engine
+    dev = torch.device("cuda", 0)
+    N, Ng = 512, 32
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    img = torch.randint(1, Ng + 1, (N, N, N), generator=g, device=dev, dtype=torch.int32)
+    img[:, :, : N // 4] = torch.div(img[:, :, : N // 4], 8, rounding_mode="floor") + 1      # a quarter with long runs
+    mask = torch.rand((N, N, N), generator=g, device=dev) < 0.9
+    counts = torch.bincount(img[mask], minlength=Ng + 1)[1:].to(torch.float64)
+    nroi = int(mask.sum())
+    glcm, glrlm, ang = engine.glcm_glrlm(img, mask, Ng, N)
+    assert engine.last_path() == "sweep"
+    lens = torch.arange(1, N + 1, device=dev, dtype=torch.float64)
+    for a in range(ang.shape[0]):
+        dz, dy, dx = (int(v) for v in ang[a])
+        def sl(d):
+            return (slice(0, N - d), slice(d, N)) if d >= 0 else (slice(-d, N), slice(0, N + d))
+        (z0, z1), (y0, y1), (x0, x1) = sl(dz), sl(dy), sl(dx)
+        both = mask[z0, y0, x0] & mask[z1, y1, x1]
+        assert int(glcm[:, :, a].sum()) == int(both.sum()), "every ordered ROI pair is counted once"
+        same = both & (img[z0, y0, x0] == img[z1, y1, x1])
+        assert int(torch.diagonal(glcm[:, :, a]).sum()) == int(same.sum())
+        # runs tile the ROI, level by level; pairs inside runs are the GLCM diagonal
+        assert torch.equal((glrlm[:, :, a] * lens[None, :]).sum(1), counts)
+        assert torch.equal((glrlm[:, :, a] * (lens - 1)[None, :]).sum(1), torch.diagonal(glcm[:, :, a]))
+    # an x-angle sees each z-slab independently: additivity over a split of the volume
+    half = engine.glcm_glrlm(img[: N // 2].contiguous(), mask[: N // 2].contiguous(), Ng, N)
+    rest = engine.glcm_glrlm(img[N // 2:].contiguous(), mask[N // 2:].contiguous(), Ng, N)
+    xa = [a for a in range(ang.shape[0]) if tuple(ang[a]) == (0, 0, 1)][0]
+    assert torch.equal(half[0][:, :, xa] + rest[0][:, :, xa], glcm[:, :, xa])
+    assert torch.equal(half[1][:, :, xa] + rest[1][:, :, xa], glrlm[:, :, xa])
+    gldm = engine.gldm(img, mask, Ng, 0)
+    assert torch.equal(gldm.sum(1), counts) and float(gldm[:, 27:].sum()) == 0
+    ngtdm = engine.ngtdm(img, mask, Ng)
+    assert torch.equal(ngtdm[:, 0], counts) and torch.equal(ngtdm[:, 2], torch.arange(1, Ng + 1, device=dev, dtype=torch.float64))
+    P, sizes = engine.glszm_compact(img, mask, Ng, nroi)
+    assert torch.equal((P * torch.from_numpy(sizes).to(dev, torch.float64)[None, :]).sum(1), counts), "zones tile the ROI"
+    dense = engine.glszm(img, mask, Ng, nroi)
+    assert torch.equal(dense[:, torch.from_numpy(sizes.astype(np.int64) - 1).to(dev)], P) and float(dense.sum()) == float(P.sum())
+    st = engine.firstorder_stats(img, mask)
+    assert st["Np"] == nroi and st["Minimum"] == float(img[mask].min()) and st["Maximum"] == float(img[mask].max())
+    assert st["Energy"] == float((img[mask].to(torch.float64) ** 2).sum())
+    cum = torch.cumsum(counts, 0).cpu().numpy()                      # order statistics of integer data from the histogram
+    lvl = lambda k: float(np.searchsorted(cum, k + 1) + 1)           # k-th smallest ROI value (0-based)
+    assert st["Median"] == (lvl((nroi - 1) // 2) + lvl(nroi // 2)) / 2 and st["P10"] >= 1 and st["P90"] <= Ng
