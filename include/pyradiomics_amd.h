@@ -52,6 +52,12 @@ const char *prad_last_error(void);       /* thread-local, valid until the next f
 int prad_device_count(void);             /* number of visible HIP devices (0 if none) */
 int prad_set_device(int device);         /* selects the device used by this thread's later calls */
 int prad_get_device(void);
+/* The library keeps grow-only scratch buffers per calling thread and device (packed levels, accumulators, union-find
+ * labels, staging copies of host inputs ...) so that repeated calls of the same shape allocate nothing.
+ * prad_workspace_bytes: device bytes currently held by the calling thread; prad_release_workspace: free them (and
+ * the pinned host buffers); any pending two-phase GLSZM state is dropped. */
+long long prad_workspace_bytes(void);
+int prad_release_workspace(void);
 /* name of the code path taken by this thread's last calculate_* call ("sweep", "generic", ...);
  * lets tests assert that the fast kernels (not a fallback) produced a result. */
 const char *prad_last_path(void);

@@ -26,6 +26,8 @@ SYMBOLS = {
     "prad_device_count": (C.c_int, []),
     "prad_set_device": (C.c_int, [C.c_int]),
     "prad_get_device": (C.c_int, []),
+    "prad_workspace_bytes": (C.c_longlong, []),
+    "prad_release_workspace": (C.c_int, []),
     "prad_last_device_ms": (C.c_double, []),
     "prad_last_kernel_ms": (C.c_double, [C.c_char_p]),
     "prad_get_angle_count": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),

@@ -928,6 +928,27 @@ int prad_set_device(int device) {
 }
 int prad_get_device(void) { return ctx().device; }
 
+long long prad_workspace_bytes(void) {
+  long long total = 0;
+  for (const auto &kv : ctx().bufs) total += (long long)kv.second.cap;
+  return total;
+}
+int prad_release_workspace(void) {
+  Context &c = ctx();
+  glszm_state().valid = false;            // its zone list lives in the workspace
+  for (auto &kv : c.bufs) {
+    if (kv.second.p) (void)hipFree(kv.second.p);
+    kv.second.p = nullptr;
+    kv.second.cap = 0;
+  }
+  for (auto &kv : c.pinned) {
+    if (kv.second.p) (void)hipHostFree(kv.second.p);
+    kv.second.p = nullptr;
+    kv.second.cap = 0;
+  }
+  return PRAD_OK;
+}
+
 double prad_last_device_ms(void) {
   Context &c = ctx();
   if (!c.call_timed) return -1.0;

@@ -78,6 +78,16 @@ def glcm(image: torch.Tensor, mask: torch.Tensor, Ng: int, distances=(1,), force
     return out, angles
 
 
+def workspace_bytes() -> int:
+    """device bytes of scratch the library currently holds for this thread"""
+    return int(_lib.load().prad_workspace_bytes())
+
+
+def release_workspace() -> None:
+    """free the library's cached scratch buffers (they are re-created on demand)"""
+    _lib.raise_for(_lib.load().prad_release_workspace(), "release_workspace")
+
+
 def last_device_ms() -> float:
     return float(_lib.load().prad_last_device_ms())
 

@@ -339,3 +339,17 @@ def test_full_size_512_properties():
     cum = torch.cumsum(counts, 0).cpu().numpy()                      # order statistics of integer data from the histogram
     lvl = lambda k: float(np.searchsorted(cum, k + 1) + 1)           # k-th smallest ROI value (0-based)
     assert st["Median"] == (lvl((nroi - 1) // 2) + lvl(nroi // 2)) / 2 and st["P10"] >= 1 and st["P90"] <= Ng
+
+
+def test_workspace_query_and_release(cm, oracle_port):
+    from pyradiomics_amd import engine
+    img, mask = _vol(3, (20, 24, 28), 8, 0.8)
+    want = oracle_port.calculate_glszm(img, mask, 8, int(mask.sum()), False, 0)
+    assert np.array_equal(cm.calculate_glszm(img, mask, 8, int(mask.sum()), False, 0), want)
+    assert engine.workspace_bytes() > 0
+    engine.release_workspace()
+    assert engine.workspace_bytes() == 0
+    with pytest.raises(ValueError):            # phase 2 without phase 1: the zone list went with the workspace
+        _ = cm._lib.raise_for(cm._lib.load().prad_fill_glszm(np.zeros(8).ctypes.data, 1, 8, 1), "fill")
+    assert np.array_equal(cm.calculate_glszm(img, mask, 8, int(mask.sum()), False, 0), want)
+    _check_all(cm, oracle_port, img, mask, 8)
