@@ -202,6 +202,19 @@ int prad_voxel_texture_features_dev(int family, const int32_t *image, const uint
                                     int kernelRadius, int force2Ddim, const int *feature_ids, int nfeat, double *out,
                                     void *stream);
 
+/* ---- segment-mode feature formulas on the device matrices (no reference analogue: numpy in glcm.py:208-887,
+ * glrlm.py:174-523, glszm.py:108-434, gldm.py:103-430) ------------------------------------------------------------
+ * prad_glcm_features_dev: glcm = DEVICE float64 [Ng][Ng][Na] raw counts as prad_calculate_glcm[_glrlm]_dev leave
+ *   them; per angle the matrix is symmetrised (symmetric != 0), normalised, and reduced to the 23 features that are
+ *   plain sums (ids = VOXEL_GLCM_FEATURES order; MCC excluded).  out: HOST float64 [Na][23]; empty: HOST int [Na],
+ *   1 where the angle holds no pair (its row of `out` is NaN; glcm.py:186-198 drops such angles).
+ * prad_zone_matrix_features_dev: P(i, j, a) = P[i*stride_i + j*stride_j + a*stride_a] DEVICE float64 counts with level
+ *   value i + 1 and size value jvals[j] (HOST float64 [Nj]: run lengths / zone sizes / dependence counts + 1);
+ *   out: HOST float64 [Na][16] in the shared numbering of prad_voxel_texture_features_dev; empty as above. */
+int prad_glcm_features_dev(const double *glcm, int Ng, int Na, int symmetric, double *out, int *empty, void *stream);
+int prad_zone_matrix_features_dev(const double *P, int Ni, int Nj, int Na, long long stride_i, long long stride_j,
+                                  long long stride_a, const double *jvals, double *out, int *empty, void *stream);
+
 /* ---- on-device discretisation (radiomics/imageoperations.py:67-174; device pointers only) ----------------------
  * dtype: 0 = float32, 1 = float64, 2 = int32, 3 = int16 image.
  * prad_roi_minmax_dev: minmax[0..1] (HOST doubles) = min / max of image over mask != 0; PRAD_E_ARG if the ROI is empty.

@@ -195,6 +195,39 @@ class RadiomicsFeaturesBase:
             return None
         return [(True, n, vals[n]) for n in names]
 
+    def _fusedSegmentFeatures(self, cls, host_only=(), **extra):
+        """segment mode on the device-resident route: matrix AND feature formulas on the device when the operator
+        backend offers it (only the feature values come back); None otherwise.  Features named in `host_only` (GLCM's
+        MCC) are evaluated from the host matrix in addition.  `fusedSegment: False` forces the reference's route
+        (matrix to the host, numpy formulas)."""
+        fused = getattr(self.cMatrices, "segment_features", None)
+        names = [n for n, on in self.enabledFeatures.items() if on]
+        if (self.voxelBased or not self.deviceResident or fused is None or not names
+                or not self.settings.get("fusedSegment", True)):
+            return None
+        dev_names = [n for n in names if n not in host_only]
+        try:
+            vals = fused(cls, self.imageArray, self.maskArray, self.coefficients["Ng"], dev_names,
+                         distances=self.settings.get("distances", [1]), force2D=self.settings.get("force2D", False),
+                         force2Ddimension=self.settings.get("force2Ddimension", 0), Ns=self.coefficients.get("Ns"),
+                         **extra) if dev_names else {}
+        except NotImplementedError:
+            return None
+        out = []
+        rest = [n for n in names if n in host_only]
+        if rest:
+            getattr(self, "_initHostOnly", self._initCalculation)(None)
+        for n in names:
+            if n in vals:
+                out.append((True, n, np.array(vals[n])))
+            else:
+                try:
+                    out.append((True, n, getattr(self, "get%sFeatureValue" % n)()))
+                except Exception:
+                    self.logger.error("FAILED: %s", traceback.format_exc())
+                    out.append((False, n, np.nan))
+        return out
+
     def _calculateFeatures(self, voxelCoordinates=None):
         self._initCalculation(voxelCoordinates)
         for name, enabled in self.enabledFeatures.items():

@@ -52,7 +52,7 @@ def _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, want):
     g, r, angles = engine.glcm_glrlm(image, mask, int(Ng), Nr, force2D, force2Ddimension,
                                      want_glcm=both or want == "glcm", want_glrlm=both or want == "glrlm")
     res = {"glcm": None if g is None else g.cpu().numpy()[None], "glrlm": None if r is None else r.cpu().numpy()[None],
-           "angles": angles}
+           "angles": angles, "glcm_dev": g, "glrlm_dev": r}
     if memo is not None:
         memo[key] = res
     return res
@@ -294,6 +294,54 @@ def voxel_texture_features(cls, image, mask, distances, Ng, force2D, force2Ddime
         raise
     out = out.cpu().numpy()
     return {f: out[i] for i, f in enumerate(features)}
+
+
+# ---- segment-mode features evaluated on the device matrices (prad_glcm_features_dev / prad_zone_matrix_features_dev)
+def _angle_mean(per_angle, empty):
+    """np.nanmean over the angles the reference keeps (all-empty angles are deleted, e.g. glcm.py:186-198)"""
+    kept = per_angle[~empty]
+    if kept.shape[0] == 0:
+        return np.full(per_angle.shape[1], np.nan)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        return np.nanmean(kept, 0)
+
+
+def segment_features(cls, image, mask, Ng, features, distances=(1,), force2D=False, force2Ddimension=0, alpha=0,
+                     symmetrical=True, Ns=None):
+    """-> {feature name: float} of feature class `cls` ("glcm" | "glrlm" | "glszm" | "gldm") in segment mode with the
+    matrix AND the formulas on the device; image / mask are device tensors (discretised levels, ROI).
+    Raises NotImplementedError for features outside the fused set (MCC, deprecated ones)."""
+    from . import engine
+    dist = [int(d) for d in np.asarray(distances).ravel()]
+    if cls == "glcm":
+        table = VOXEL_GLCM_FEATURES
+    else:
+        table = _ZONE_LIKE[cls][1]
+    missing = [f for f in features if f not in table]
+    if missing:
+        raise NotImplementedError("not available in the fused segment kernels: %s" % ", ".join(missing))
+    if cls == "glcm":
+        if dist == [1]:
+            g = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glcm")["glcm_dev"]
+        else:
+            g, _ = engine.glcm(image, mask, int(Ng), dist, force2D, force2Ddimension)
+        vals = _angle_mean(*engine.glcm_features(g, symmetrical))
+    elif cls == "glrlm":
+        r = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glrlm")["glrlm_dev"]
+        vals = _angle_mean(*engine.zone_matrix_features(r, np.arange(1, r.shape[1] + 1)))
+    elif cls == "gldm":
+        P = engine.gldm(image, mask, int(Ng), int(alpha), dist, force2D, force2Ddimension)
+        vals = _angle_mean(*engine.zone_matrix_features(P, np.arange(1, P.shape[1] + 1)))
+    elif cls == "glszm":
+        P, sizes = engine.glszm_compact(image, mask, int(Ng), Ns, force2D, force2Ddimension)
+        if len(sizes) == 0:
+            raise NotImplementedError("no zones")
+        vals = _angle_mean(*engine.zone_matrix_features(P, sizes))
+    else:
+        raise NotImplementedError(cls)
+    return {f: float(vals[table.index(f)]) for f in features}
 
 
 # ---- first-order statistics (no native code in the reference: radiomics/firstorder.py is numpy; here the ROI /

@@ -1,0 +1,316 @@
+// kernels_features.h -- segment-mode feature formulas evaluated on the device matrices (SURVEY.md section 8f rank 1:
+// "fused on-device feature evaluation ... not only in voxel mode").
+//
+//   glcm_matrix_features_kernel      one block per angle: the raw co-occurrence counts [Ng][Ng][Na] the sweeps produce
+//                                    -> symmetrised, normalised p(i,j) and the 23 features of glcm.py:260-887 that are
+//                                    plain sums (everything but MCC).  Marginals are built one row / column /
+//                                    diagonal per thread, so the result does not depend on scheduling.
+//   zone_matrix_features_kernel      one block per angle: a count matrix P[Ni][Nj] with level values i and size values
+//                                    j (run lengths, zone sizes, dependence counts) -> the 16 features GLRLM
+//                                    (glrlm.py:196-523), GLSZM (glszm.py:140-434) and GLDM (gldm.py:138-430) share.
+// Both kernels read matrices of at most a few hundred KB that are L2-resident; they are latency-, not bandwidth-bound,
+// and exist to keep the host out of the per-image loop (9 derived images x 5 classes per case).
+#pragma once
+#include "prad_runtime.h"
+
+namespace prad {
+
+enum { GF_Autocorrelation = 0, GF_JointAverage, GF_ClusterProminence, GF_ClusterShade, GF_ClusterTendency, GF_Contrast,
+       GF_Correlation, GF_DifferenceAverage, GF_DifferenceEntropy, GF_DifferenceVariance, GF_JointEnergy,
+       GF_JointEntropy, GF_Imc1, GF_Imc2, GF_Idm, GF_Idmn, GF_Id, GF_Idn, GF_InverseVariance, GF_MaximumProbability,
+       GF_SumAverage, GF_SumEntropy, GF_SumSquares, GF_COUNT };
+
+#define PRAD_FEAT_THREADS 256
+#define PRAD_FEAT_EPS 2.220446049250313e-16
+
+// deterministic block sum: per-wave shuffle tree, then the 4 wave results in lane order
+__device__ __forceinline__ double feat_block_sum(double v, double *sh4) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+}
+__device__ __forceinline__ double feat_block_max(double v, double *sh4) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmax(fmax(sh4[0], sh4[1]), fmax(sh4[2], sh4[3]));
+}
+
+// counts: [Ng][Ng][Na] float64 (reference layout).  out: [Na][GF_COUNT]; empty[a] = 1 when the angle has no pair.
+__global__ void __launch_bounds__(PRAD_FEAT_THREADS) glcm_matrix_features_kernel(const double *__restrict__ counts,
+                                                                                 int Ng, int Na, int symmetric,
+                                                                                 double *__restrict__ out,
+                                                                                 int *__restrict__ empty) {
+#pragma clang fp contract(off)
+  extern __shared__ double fs[];
+  double *px = fs, *py = px + Ng, *psum = py + Ng, *pdif = psum + 2 * Ng, *sh4 = pdif + Ng;   // sizes Ng, Ng, 2Ng, Ng, 4
+  const int a = blockIdx.x, t = threadIdx.x;
+  const double eps = PRAD_FEAT_EPS;
+  auto C = [&](int i, int j) -> double {
+    const double v = counts[((size_t)i * Ng + j) * Na + a];
+    return symmetric ? v + counts[((size_t)j * Ng + i) * Na + a] : v;
+  };
+  const int n2 = Ng * Ng;
+  double tot = 0;
+  for (int e = t; e < n2; e += PRAD_FEAT_THREADS) tot += C(e / Ng, e % Ng);
+  tot = feat_block_sum(tot, sh4);
+  if (tot == 0) {
+    if (t == 0) empty[a] = 1;
+    for (int f = t; f < GF_COUNT; f += PRAD_FEAT_THREADS) out[(size_t)a * GF_COUNT + f] = __builtin_nan("");
+    return;
+  }
+  if (t == 0) empty[a] = 0;
+  // marginals: one row / column / (anti-)diagonal per thread, in index order
+  for (int i = t; i < Ng; i += PRAD_FEAT_THREADS) {
+    double r = 0, c = 0;
+    for (int j = 0; j < Ng; j++) {
+      r += C(i, j) / tot;
+      c += C(j, i) / tot;
+    }
+    px[i] = r;
+    py[i] = c;
+  }
+  for (int k = t; k < 2 * Ng - 1; k += PRAD_FEAT_THREADS) {       // i + j = k + 2 (levels are 1-based)
+    double s = 0;
+    for (int i = max(0, k - (Ng - 1)); i <= min(k, Ng - 1); i++) s += C(i, k - i) / tot;
+    psum[k] = s;
+  }
+  for (int k = t; k < Ng; k += PRAD_FEAT_THREADS) {               // |i - j| = k
+    double s = 0;
+    for (int i = 0; i + k < Ng; i++) s += (k == 0 ? C(i, i) : C(i, i + k) + C(i + k, i)) / tot;
+    pdif[k] = s;
+  }
+  __syncthreads();
+  // pass 1 over the entries: means, entropy, energy, maximum, autocorrelation, contrast
+  double ux = 0, uy = 0, hxy = 0, energy = 0, pmax = 0, autoc = 0, contrast = 0;
+  for (int e = t; e < n2; e += PRAD_FEAT_THREADS) {
+    const int i0 = e / Ng, j0 = e % Ng;
+    const double p = C(i0, j0) / tot, i = i0 + 1, j = j0 + 1;
+    ux += i * p;
+    uy += j * p;
+    hxy += p * log2(p + eps);
+    energy += p * p;
+    pmax = fmax(pmax, p);
+    autoc += p * (i * j);
+    const double d = fabs(i - j);
+    contrast += p * (d * d);
+  }
+  ux = feat_block_sum(ux, sh4);
+  uy = feat_block_sum(uy, sh4);
+  hxy = -feat_block_sum(hxy, sh4);
+  energy = feat_block_sum(energy, sh4);
+  pmax = feat_block_max(pmax, sh4);
+  autoc = feat_block_sum(autoc, sh4);
+  contrast = feat_block_sum(contrast, sh4);
+  // pass 2: moments about the means, information measures
+  double cp = 0, cs = 0, ct = 0, vx = 0, vy = 0, cov = 0, hxy1 = 0, hxy2 = 0;
+  for (int e = t; e < n2; e += PRAD_FEAT_THREADS) {
+    const int i0 = e / Ng, j0 = e % Ng;
+    const double p = C(i0, j0) / tot, i = i0 + 1, j = j0 + 1;
+    const double s = (i + j) - ux - uy, s2 = s * s;
+    ct += p * s2;
+    cs += p * (s2 * s);
+    cp += p * (s2 * s2);
+    const double di = i - ux, dj = j - uy;
+    vx += p * (di * di);
+    vy += p * (dj * dj);
+    cov += p * di * dj;
+    const double q = px[i0] * py[j0];
+    hxy1 += p * log2(q + eps);
+    hxy2 += q * log2(q + eps);
+  }
+  cp = feat_block_sum(cp, sh4);
+  cs = feat_block_sum(cs, sh4);
+  ct = feat_block_sum(ct, sh4);
+  vx = feat_block_sum(vx, sh4);
+  vy = feat_block_sum(vy, sh4);
+  cov = feat_block_sum(cov, sh4);
+  hxy1 = -feat_block_sum(hxy1, sh4);
+  hxy2 = -feat_block_sum(hxy2, sh4);
+  // marginal-based sums
+  double hx = 0, hy = 0;
+  for (int i = t; i < Ng; i += PRAD_FEAT_THREADS) {
+    hx += px[i] * log2(px[i] + eps);
+    hy += py[i] * log2(py[i] + eps);
+  }
+  hx = -feat_block_sum(hx, sh4);
+  hy = -feat_block_sum(hy, sh4);
+  double da = 0, de = 0, idm = 0, idmn = 0, id = 0, idn = 0, iv = 0;
+  const double Ngd = (double)Ng;
+  for (int k = t; k < Ng; k += PRAD_FEAT_THREADS) {
+    const double p = pdif[k], kd = (double)k;
+    da += kd * p;
+    de += p * log2(p + eps);
+    idm += p / (1 + kd * kd);
+    idmn += p / (1 + (kd * kd) / (Ngd * Ngd));
+    id += p / (1 + kd);
+    idn += p / (1 + kd / Ngd);
+    if (k >= 1) iv += p / (kd * kd);
+  }
+  da = feat_block_sum(da, sh4);
+  de = -feat_block_sum(de, sh4);
+  idm = feat_block_sum(idm, sh4);
+  idmn = feat_block_sum(idmn, sh4);
+  id = feat_block_sum(id, sh4);
+  idn = feat_block_sum(idn, sh4);
+  iv = feat_block_sum(iv, sh4);
+  double dv = 0;
+  for (int k = t; k < Ng; k += PRAD_FEAT_THREADS) {
+    const double d = (double)k - da;
+    dv += pdif[k] * (d * d);
+  }
+  dv = feat_block_sum(dv, sh4);
+  double sa = 0, se = 0;
+  for (int k = t; k < 2 * Ng - 1; k += PRAD_FEAT_THREADS) {
+    const double p = psum[k];
+    sa += (double)(k + 2) * p;
+    se += p * log2(p + eps);
+  }
+  sa = feat_block_sum(sa, sh4);
+  se = -feat_block_sum(se, sh4);
+  if (t == 0) {
+    double *o = out + (size_t)a * GF_COUNT;
+    const double sigx = sqrt(vx), sigy = sqrt(vy);
+    o[GF_Autocorrelation] = autoc;
+    o[GF_JointAverage] = ux;
+    o[GF_ClusterProminence] = cp;
+    o[GF_ClusterShade] = cs;
+    o[GF_ClusterTendency] = ct;
+    o[GF_Contrast] = contrast;
+    o[GF_Correlation] = (sigx * sigy == 0) ? 1.0 : cov / (sigx * sigy + eps);       // glcm.py:409-410
+    o[GF_DifferenceAverage] = da;
+    o[GF_DifferenceEntropy] = de;
+    o[GF_DifferenceVariance] = dv;
+    o[GF_JointEnergy] = energy;
+    o[GF_JointEntropy] = hxy;
+    const double div = fmax(hx, hy);
+    o[GF_Imc1] = div != 0 ? (hxy - hxy1) / div : 0.0;                                // :605-610
+    o[GF_Imc2] = (hxy2 == hxy) ? 0.0 : sqrt(1 - exp(-2 * (hxy2 - hxy)));            // :641-647 (NaN when negative)
+    o[GF_Idm] = idm;
+    o[GF_Idmn] = idmn;
+    o[GF_Id] = id;
+    o[GF_Idn] = idn;
+    o[GF_InverseVariance] = iv;
+    o[GF_MaximumProbability] = pmax;
+    o[GF_SumAverage] = sa;
+    o[GF_SumEntropy] = se;
+    o[GF_SumSquares] = vx;
+  }
+}
+
+// ---- GLRLM / GLSZM / GLDM ------------------------------------------------------------------------------------
+enum { ZM_SmallEmphasis = 0, ZM_LargeEmphasis, ZM_GrayLevelNonUniformity, ZM_GrayLevelNonUniformityNormalized,
+       ZM_SizeNonUniformity, ZM_SizeNonUniformityNormalized, ZM_Percentage, ZM_GrayLevelVariance, ZM_SizeVariance,
+       ZM_Entropy, ZM_LowGrayLevelEmphasis, ZM_HighGrayLevelEmphasis, ZM_SmallLowGrayLevelEmphasis,
+       ZM_SmallHighGrayLevelEmphasis, ZM_LargeLowGrayLevelEmphasis, ZM_LargeHighGrayLevelEmphasis, ZM_COUNT };
+
+// P(i, j, a) = counts[i * si + j * sj + a * sa]; level value = i + 1; size value = jvals[j].
+// scratch: [Na][Ni + Nj] float64 (marginals).  out: [Na][ZM_COUNT]; empty[a] = 1 when the matrix of angle a is all zero.
+__global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel(
+    const double *__restrict__ counts, int Ni, int Nj, int Na, long long si, long long sj, long long sa,
+    const double *__restrict__ jvals, double *__restrict__ scratch, double *__restrict__ out, int *__restrict__ empty) {
+#pragma clang fp contract(off)
+  __shared__ double sh4[4];
+  const int a = blockIdx.x, t = threadIdx.x;
+  const double eps = PRAD_FEAT_EPS;
+  double *pg = scratch + (size_t)a * (Ni + Nj), *pj = pg + Ni;
+  auto P = [&](int i, int j) -> double { return counts[i * si + j * sj + a * sa]; };
+  for (int i = t; i < Ni; i += PRAD_FEAT_THREADS) {
+    double s = 0;
+    for (int j = 0; j < Nj; j++) s += P(i, j);
+    pg[i] = s;
+  }
+  for (int j = t; j < Nj; j += PRAD_FEAT_THREADS) {
+    double s = 0;
+    for (int i = 0; i < Ni; i++) s += P(i, j);
+    pj[j] = s;
+  }
+  __syncthreads();
+  double n = 0;
+  for (int i = t; i < Ni; i += PRAD_FEAT_THREADS) n += pg[i];
+  n = feat_block_sum(n, sh4);
+  if (n == 0) {
+    if (t == 0) empty[a] = 1;
+    for (int f = t; f < ZM_COUNT; f += PRAD_FEAT_THREADS) out[(size_t)a * ZM_COUNT + f] = __builtin_nan("");
+    return;
+  }
+  if (t == 0) empty[a] = 0;
+  double i1 = 0, i2 = 0, inv_i2 = 0, mg = 0;
+  for (int i = t; i < Ni; i += PRAD_FEAT_THREADS) {
+    const double g = pg[i], iv = i + 1;
+    i1 += g * iv;
+    i2 += g * (iv * iv);
+    inv_i2 += g / (iv * iv);
+    mg += g * g;
+  }
+  i1 = feat_block_sum(i1, sh4);
+  i2 = feat_block_sum(i2, sh4);
+  inv_i2 = feat_block_sum(inv_i2, sh4);
+  mg = feat_block_sum(mg, sh4);
+  double j1 = 0, j2 = 0, inv_j2 = 0, mj = 0;
+  for (int j = t; j < Nj; j += PRAD_FEAT_THREADS) {
+    const double s = pj[j], jv = jvals[j];
+    j1 += s * jv;
+    j2 += s * (jv * jv);
+    inv_j2 += s / (jv * jv);
+    mj += s * s;
+  }
+  j1 = feat_block_sum(j1, sh4);
+  j2 = feat_block_sum(j2, sh4);
+  inv_j2 = feat_block_sum(inv_j2, sh4);
+  mj = feat_block_sum(mj, sh4);
+  const double ui = i1 / n, uj = j1 / n;
+  double vi = 0, vj = 0;
+  for (int i = t; i < Ni; i += PRAD_FEAT_THREADS) {
+    const double d = (double)(i + 1) - ui;
+    vi += (pg[i] / n) * (d * d);
+  }
+  for (int j = t; j < Nj; j += PRAD_FEAT_THREADS) {
+    const double d = jvals[j] - uj;
+    vj += (pj[j] / n) * (d * d);
+  }
+  vi = feat_block_sum(vi, sh4);
+  vj = feat_block_sum(vj, sh4);
+  double ent = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+  const long long nij = (long long)Ni * Nj;
+  for (long long e = t; e < nij; e += PRAD_FEAT_THREADS) {
+    const int i = (int)(e / Nj), j = (int)(e - (long long)i * Nj);
+    const double v = P(i, j);
+    if (v == 0) continue;
+    const double iv = i + 1, jv = jvals[j], i2v = iv * iv, j2v = jv * jv, p = v / n;
+    ent += p * log2(p + eps);
+    c1 += v / (i2v * j2v);
+    c2 += v * i2v / j2v;
+    c3 += v * j2v / i2v;
+    c4 += v * (i2v * j2v);
+  }
+  ent = -feat_block_sum(ent, sh4);
+  c1 = feat_block_sum(c1, sh4);
+  c2 = feat_block_sum(c2, sh4);
+  c3 = feat_block_sum(c3, sh4);
+  c4 = feat_block_sum(c4, sh4);
+  if (t == 0) {
+    double *o = out + (size_t)a * ZM_COUNT;
+    o[ZM_SmallEmphasis] = inv_j2 / n;
+    o[ZM_LargeEmphasis] = j2 / n;
+    o[ZM_GrayLevelNonUniformity] = mg / n;
+    o[ZM_GrayLevelNonUniformityNormalized] = mg / (n * n);
+    o[ZM_SizeNonUniformity] = mj / n;
+    o[ZM_SizeNonUniformityNormalized] = mj / (n * n);
+    o[ZM_Percentage] = n / j1;
+    o[ZM_GrayLevelVariance] = vi;
+    o[ZM_SizeVariance] = vj;
+    o[ZM_Entropy] = ent;
+    o[ZM_LowGrayLevelEmphasis] = inv_i2 / n;
+    o[ZM_HighGrayLevelEmphasis] = i2 / n;
+    o[ZM_SmallLowGrayLevelEmphasis] = c1 / n;
+    o[ZM_SmallHighGrayLevelEmphasis] = c2 / n;
+    o[ZM_LargeLowGrayLevelEmphasis] = c3 / n;
+    o[ZM_LargeHighGrayLevelEmphasis] = c4 / n;
+  }
+}
+
+}  // namespace prad

@@ -78,6 +78,42 @@ def glcm(image: torch.Tensor, mask: torch.Tensor, Ng: int, distances=(1,), force
     return out, angles
 
 
+def glcm_features(glcm: torch.Tensor, symmetric: bool = True):
+    """the 23 sum-type GLCM features (order of cmatrices.VOXEL_GLCM_FEATURES) per angle from the raw device matrix
+    [Ng, Ng, Na]: (float64 numpy [Na, 23], bool numpy [Na] = angle empty)"""
+    lib = _lib.load()
+    glcm = glcm.contiguous()
+    Ng, _, Na = glcm.shape
+    lib.prad_set_device(glcm.device.index or 0)
+    out = np.empty((Na, 23), dtype=np.float64)
+    empty = np.empty(Na, dtype=np.intc)
+    rc = lib.prad_glcm_features_dev(C.c_void_p(glcm.data_ptr()), int(Ng), int(Na), 1 if symmetric else 0,
+                                    out.ctypes.data_as(C.POINTER(C.c_double)), _iptr(empty), _stream_ptr())
+    _lib.raise_for(rc, "GLCM features")
+    return out, empty != 0
+
+
+def zone_matrix_features(P: torch.Tensor, jvals):
+    """the 16 features GLRLM / GLSZM / GLDM share, per angle, from a device count matrix [Ni, Nj] or [Ni, Nj, Na] with
+    level values 1..Ni and size values `jvals` [Nj]: (float64 numpy [Na, 16], bool numpy [Na] = matrix empty)"""
+    lib = _lib.load()
+    if P.dim() == 2:
+        P = P.unsqueeze(2)
+    Ni, Nj, Na = P.shape
+    si, sj, sa = P.stride()
+    lib.prad_set_device(P.device.index or 0)
+    jv = np.ascontiguousarray(jvals, dtype=np.float64)
+    if jv.shape != (Nj,):
+        raise ValueError("jvals must have one entry per column")
+    out = np.empty((Na, 16), dtype=np.float64)
+    empty = np.empty(Na, dtype=np.intc)
+    rc = lib.prad_zone_matrix_features_dev(C.c_void_p(P.data_ptr()), int(Ni), int(Nj), int(Na), int(si), int(sj), int(sa),
+                                           jv.ctypes.data_as(C.POINTER(C.c_double)),
+                                           out.ctypes.data_as(C.POINTER(C.c_double)), _iptr(empty), _stream_ptr())
+    _lib.raise_for(rc, "zone matrix features")
+    return out, empty != 0
+
+
 def workspace_bytes() -> int:
     """device bytes of scratch the library currently holds for this thread"""
     return int(_lib.load().prad_workspace_bytes())

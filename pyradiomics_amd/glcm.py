@@ -52,10 +52,21 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
         self.P_glcm = self._calculateMatrix(voxelCoordinates)
         self._calculateCoefficients()
 
+    def _initHostOnly(self, voxelCoordinates=None):
+        """what MCC needs when every other feature came from the device: the normalised matrix and its marginals"""
+        self.P_glcm = self._calculateMatrix(voxelCoordinates)
+        self.coefficients["px"] = self.P_glcm.sum(2, keepdims=True)
+        self.coefficients["py"] = self.P_glcm.sum(1, keepdims=True)
+
     def _calculateFeatures(self, voxelCoordinates=None):
         """voxel mode: when the operator backend offers the fused kernel and it covers the request, feature maps
         come straight from the device (no (Nvox, Ng, Ng, Na) intermediate); otherwise the reference's route
         (matrix + numpy formulas, base.py:253-273) is taken.  `fusedVoxel: False` in the settings forces the latter."""
+        if self.weightingNorm is None:
+            seg = self._fusedSegmentFeatures("glcm", host_only=("MCC",), symmetrical=self.symmetricalGLCM)
+            if seg is not None:
+                yield from seg
+                return
         fused = getattr(self.cMatrices, "voxel_glcm_features", None)
         names = [n for n, on in self.enabledFeatures.items() if on]
         if (self.voxelBased and voxelCoordinates is not None and fused is not None and names

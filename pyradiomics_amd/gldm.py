@@ -23,6 +23,8 @@ class RadiomicsGLDM(_ZoneLikeFeatures):
 
     def _calculateFeatures(self, voxelCoordinates=None):
         fused = self._fusedVoxelFeatures("gldm", voxelCoordinates, self.gldm_a)
+        if fused is None:
+            fused = self._fusedSegmentFeatures("gldm", alpha=self.gldm_a)
         if fused is not None:
             yield from fused
             return

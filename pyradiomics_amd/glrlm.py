@@ -23,6 +23,8 @@ class RadiomicsGLRLM(RadiomicsFeaturesBase):
 
     def _calculateFeatures(self, voxelCoordinates=None):
         fused = self._fusedVoxelFeatures("glrlm", voxelCoordinates) if self.weightingNorm is None else None
+        if fused is None:
+            fused = self._fusedSegmentFeatures("glrlm") if self.weightingNorm is None else None
         if fused is not None:
             yield from fused
             return

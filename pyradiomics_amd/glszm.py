@@ -63,6 +63,8 @@ class RadiomicsGLSZM(_ZoneLikeFeatures):
 
     def _calculateFeatures(self, voxelCoordinates=None):
         fused = self._fusedVoxelFeatures("glszm", voxelCoordinates)
+        if fused is None:
+            fused = self._fusedSegmentFeatures("glszm")
         if fused is not None:
             yield from fused
             return

@@ -26,7 +26,7 @@ for route in ("device", "host"):
     p["setting"]["deviceResident"] = route == "device"
     ex = RadiomicsFeatureExtractor(p)
     times = []
-    for c in range(cases + 1):
+    for c in range((cases if route == "device" else 1) + 1):      # the host route takes ~10 s per case: one timed run
         vol = (make_volume(N, 32, kind, c, torch.device("cuda", 0))[0] * 25).cpu().numpy().astype(np.int16)
         torch.cuda.synchronize()
         t = time.perf_counter()
@@ -37,6 +37,7 @@ for route in ("device", "host"):
     print("%-6s route: %d^3 %s, %d features/case, median %.1f ms/case (%.2f cases/s, %.1f Mvox/s of ROI x 9 images)"
           % (route, N, kind, len(out), res[route][0] * 1e3, 1 / res[route][0],
              9 * int(mask.sum()) / res[route][0] / 1e6), flush=True)
-same = all(float(res["device"][1][k]) == float(res["host"][1][k]) or
-           (np.isnan(float(res["device"][1][k])) and np.isnan(float(res["host"][1][k]))) for k in res["host"][1])
-print("routes agree bit-for-bit:", same)
+def close(a, b):
+    return a == b or (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-10 * abs(b)
+same = all(close(float(res["device"][1][k]), float(res["host"][1][k])) for k in res["host"][1])
+print("routes agree within 1e-10 relative (device-side formulas reorder float sums; matrices are bit-identical):", same)
