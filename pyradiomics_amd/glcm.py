@@ -223,17 +223,21 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
         return self._diff_weighted(1 + self.coefficients["kValuesDiff"] ** 2)
 
     def getMCCFeatureValue(self):
-        # Q(i,j) = sum_k P(i,k) P(j,k) / (px(i) py(k) + eps); second largest eigenvalue (glcm.py:665-707)
+        """sqrt of the second largest eigenvalue of Q(i,j) = sum_k P(i,k) P(j,k) / (px(i) py(k)) (glcm.py:665-707).
+        The reference hands the non-symmetric Q to np.linalg.eigvals.  Q = Dx^-1 P Dy^-1 P^T is similar to A A^T with
+        A(i,k) = P(i,k) / sqrt(px(i) py(k)), so its eigenvalues are the squared singular values of A: MCC is the second
+        largest singular value of A (batched SVD; the eps guard of the reference's denominator is kept in A)."""
         c = self.coefficients
         P, px, py = self.P_glcm, c["px"], c["py"]
-        Q = np.zeros((P.shape[0], P.shape[1], P.shape[1], P.shape[3]))
-        for k in range(P.shape[1]):
-            Q += (P[:, :, None, k, :] * P[:, None, :, k, :]) / (px[:, :, None, 0, :] * py[:, None, :, k, :] + _EPS)
-        ev = np.linalg.eigvals(Q.transpose((0, 3, 1, 2)))
-        ev.sort()
-        if ev.shape[2] < 2:
-            return 1
-        return np.nanmean(np.sqrt(ev[:, :, -2]), 1).real
+        if P.shape[1] < 2:
+            return 1                    # glcm.py:702-703
+        A = P / np.sqrt(px * py + _EPS)                              # (Nvox, Ng, Ng, Na)
+        A = np.where(np.isnan(A), 0.0, A)                            # kernels with an empty angle (P is NaN there)
+        sv = np.linalg.svd(A.transpose((0, 3, 1, 2)), compute_uv=False)      # (Nvox, Na, Ng), descending
+        mcc = sv[:, :, 1]
+        empty = np.isnan(np.sum(P, (1, 2)))                          # (Nvox, Na): angle absent in this kernel
+        mcc = np.where(empty, np.nan, mcc)
+        return np.nanmean(mcc, 1)
 
     def getIdmnFeatureValue(self):
         c = self.coefficients
