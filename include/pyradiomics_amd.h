@@ -214,6 +214,9 @@ int prad_voxel_texture_features_dev(int family, const int32_t *image, const uint
 int prad_glcm_features_dev(const double *glcm, int Ng, int Na, int symmetric, double *out, int *empty, void *stream);
 int prad_zone_matrix_features_dev(const double *P, int Ni, int Nj, int Na, long long stride_i, long long stride_j,
                                   long long stride_a, const double *jvals, double *out, int *empty, void *stream);
+/* NGTDM (ngtdm.py:133-287): P = DEVICE float64 [Ng][3] as prad_calculate_ngtdm_dev leaves it;
+ * out: HOST float64 [5] = Coarseness, Contrast, Busyness, Complexity, Strength. */
+int prad_ngtdm_features_dev(const double *P, int Ng, double *out, void *stream);
 
 /* ---- on-device discretisation (radiomics/imageoperations.py:67-174; device pointers only) ----------------------
  * dtype: 0 = float32, 1 = float64, 2 = int32, 3 = int16 image.

@@ -310,7 +310,7 @@ def _angle_mean(per_angle, empty):
 
 def segment_features(cls, image, mask, Ng, features, distances=(1,), force2D=False, force2Ddimension=0, alpha=0,
                      symmetrical=True, Ns=None):
-    """-> {feature name: float} of feature class `cls` ("glcm" | "glrlm" | "glszm" | "gldm") in segment mode with the
+    """-> {feature name: float} of feature class `cls` ("glcm" | "glrlm" | "glszm" | "gldm" | "ngtdm") in segment mode with the
     matrix AND the formulas on the device; image / mask are device tensors (discretised levels, ROI).
     Raises NotImplementedError for features outside the fused set (MCC, deprecated ones)."""
     from . import engine
@@ -339,6 +339,8 @@ def segment_features(cls, image, mask, Ng, features, distances=(1,), force2D=Fal
         if len(sizes) == 0:
             raise NotImplementedError("no zones")
         vals = _angle_mean(*engine.zone_matrix_features(P, sizes))
+    elif cls == "ngtdm":
+        vals = engine.ngtdm_features(engine.ngtdm(image, mask, int(Ng), dist, force2D, force2Ddimension))
     else:
         raise NotImplementedError(cls)
     return {f: float(vals[table.index(f)]) for f in features}

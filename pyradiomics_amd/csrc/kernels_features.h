@@ -313,4 +313,60 @@ __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel
   }
 }
 
+// ---- NGTDM (ngtdm.py:133-287): P[Ng][3] = (n_i, s_i, level) -> Coarseness, Contrast, Busyness, Complexity, Strength ----
+__global__ void __launch_bounds__(PRAD_FEAT_THREADS) ngtdm_matrix_features_kernel(const double *__restrict__ P, int Ng,
+                                                                                  double *__restrict__ out) {
+#pragma clang fp contract(off)
+  extern __shared__ double ns[];
+  double *pi = ns, *si = pi + Ng, *lv = si + Ng, *sh4 = lv + Ng;     // present levels, compacted in level order
+  __shared__ int ngp_s;
+  const int t = threadIdx.x;
+  if (t == 0) {                       // compaction in level order (Ng <= a few hundred: serial is fine)
+    int k = 0;
+    for (int g = 0; g < Ng; g++)
+      if (P[g * 3] > 0) {
+        pi[k] = P[g * 3];
+        si[k] = P[g * 3 + 1];
+        lv[k] = P[g * 3 + 2];
+        k++;
+      }
+    ngp_s = k;
+  }
+  __syncthreads();
+  const int ngp = ngp_s;
+  double nvp = 0, stot = 0;
+  for (int k = t; k < ngp; k += PRAD_FEAT_THREADS) {
+    nvp += pi[k];
+    stot += si[k];
+  }
+  nvp = feat_block_sum(nvp, sh4);
+  stot = feat_block_sum(stot, sh4);
+  __syncthreads();
+  for (int k = t; k < ngp; k += PRAD_FEAT_THREADS) pi[k] = pi[k] / nvp;
+  __syncthreads();
+  double coarse = 0, contrast = 0, absdiff = 0, complexity = 0, strength = 0;
+  for (int k = t; k < ngp; k += PRAD_FEAT_THREADS) coarse += pi[k] * si[k];
+  coarse = feat_block_sum(coarse, sh4);
+  for (int e = t; e < ngp * ngp; e += PRAD_FEAT_THREADS) {
+    const int a = e / ngp, b = e % ngp;
+    const double pa = pi[a], pb = pi[b], d = lv[a] - lv[b];
+    contrast += pa * pb * (d * d);
+    absdiff += fabs(lv[a] * pa - lv[b] * pb);
+    complexity += fabs(d) * (pa * si[a] + pb * si[b]) / (pa + pb);
+    strength += (pa + pb) * (d * d);
+  }
+  contrast = feat_block_sum(contrast, sh4);
+  absdiff = feat_block_sum(absdiff, sh4);
+  complexity = feat_block_sum(complexity, sh4);
+  strength = feat_block_sum(strength, sh4);
+  if (t == 0) {
+    const double div = (double)ngp * (double)(ngp - 1);
+    out[0] = coarse != 0 ? 1.0 / coarse : 1e6;                                    // ngtdm.py:148-150
+    out[1] = div != 0 ? contrast * stot / nvp / div : 0.0;                        // :187-188
+    out[2] = absdiff != 0 ? coarse / absdiff : 0.0;                               // :219-220
+    out[3] = nvp != 0 ? complexity / nvp : __builtin_nan("");
+    out[4] = stot != 0 ? strength / stot : 0.0;                                   // :284-285
+  }
+}
+
 }  // namespace prad

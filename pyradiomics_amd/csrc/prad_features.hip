@@ -53,3 +53,22 @@ extern "C" int prad_zone_matrix_features_dev(const double *P, int Ni, int Nj, in
   PRAD_HIP(hipStreamSynchronize(s));
   return PRAD_OK;
 }
+
+extern "C" int prad_ngtdm_features_dev(const double *P, int Ng, double *out, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!P || !out || Ng < 1) return fail(PRAD_E_ARG, "ngtdm_features: bad arguments");
+  const size_t lds = sizeof(double) * ((size_t)3 * Ng + 4);
+  if (lds > 60 * 1024) return fail(PRAD_E_UNSUPPORTED, "ngtdm_features: Ng=%d exceeds the LDS level table", Ng);
+  hipStream_t s = (hipStream_t)stream;
+  double *d_out = nullptr;
+  PRAD_TRY(c.get<double>("nf_out", 8, &d_out));
+  {
+    Timed t(c, "features", s);
+    hipLaunchKernelGGL(ngtdm_matrix_features_kernel, dim3(1), dim3(PRAD_FEAT_THREADS), lds, s, P, Ng, d_out);
+    PRAD_TRY(check_launch("ngtdm_matrix_features_kernel"));
+  }
+  PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * 5, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  return PRAD_OK;
+}

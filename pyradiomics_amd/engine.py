@@ -114,6 +114,18 @@ def zone_matrix_features(P: torch.Tensor, jvals):
     return out, empty != 0
 
 
+def ngtdm_features(P: torch.Tensor) -> np.ndarray:
+    """Coarseness, Contrast, Busyness, Complexity, Strength from the device NGTDM [Ng, 3]"""
+    lib = _lib.load()
+    P = P.contiguous()
+    lib.prad_set_device(P.device.index or 0)
+    out = np.empty(5, dtype=np.float64)
+    rc = lib.prad_ngtdm_features_dev(C.c_void_p(P.data_ptr()), int(P.shape[0]), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                     _stream_ptr())
+    _lib.raise_for(rc, "NGTDM features")
+    return out
+
+
 def workspace_bytes() -> int:
     """device bytes of scratch the library currently holds for this thread"""
     return int(_lib.load().prad_workspace_bytes())

@@ -18,6 +18,8 @@ class RadiomicsNGTDM(RadiomicsFeaturesBase):
 
     def _calculateFeatures(self, voxelCoordinates=None):
         fused = self._fusedVoxelFeatures("ngtdm", voxelCoordinates)
+        if fused is None:
+            fused = self._fusedSegmentFeatures("ngtdm")
         if fused is not None:
             yield from fused
             return

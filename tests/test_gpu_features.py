@@ -173,7 +173,7 @@ def test_segment_features_on_device_equal_numpy_formulas(cfgname):
     numpy formulas applied to the same device-built matrices, every non-deprecated feature, golden configurations"""
     cfg = load_baseline_features()[cfgname]
     image, mask, settings = prepared_case(cfg)
-    for cls in ("glcm", "glrlm", "glszm", "gldm"):
+    for cls in ("glcm", "glrlm", "glszm", "gldm", "ngtdm"):
         if cls not in cfg["features"]:
             continue
         vals = {}
