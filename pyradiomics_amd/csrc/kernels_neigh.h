@@ -238,7 +238,7 @@ inline int neigh_pack(Context *c, hipStream_t s, const Geo &g, const int32_t *im
   const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((g.n / 16 + 255) / 256, 4096));
   const int NX = g.size[g.nd - 1];
   hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, s, image, mask, g.n, NX, NX, 0, Ng, *levels, flags_d,
-                     vec_ok);
+                     vec_ok, 0);
   return check_launch("pack_levels_kernel");
 }
 

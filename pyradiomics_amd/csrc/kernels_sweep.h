@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) pack_levels_kernel(const int *__restrict_
                                                           const uint8_t *__restrict__ mask, long long n, int NX,
                                                           int pitch, int padw, int Ng,
                                                           uint8_t *__restrict__ levels, int *__restrict__ flags,
-                                                          int vec_ok) {
+                                                          int vec_ok, int shift) {
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long nthreads = (long long)gridDim.x * blockDim.x;
   const bool linear = (padw == 0 && pitch == NX);
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) pack_levels_kernel(const int *__restrict_
           const bool in = (mw[w] >> (8 * b)) & 0xffu;
           const int l = lv[w * 4 + b];
           bad |= in && (l < 1 || l > Ng);
-          o |= (in ? ((u32)l & 0xffu) : 0u) << (8 * b);
+          o |= (in ? (((u32)l << shift) & 0xffu) : 0u) << (8 * b);
         }
         ow[w] = o;
       }
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) pack_levels_kernel(const int *__restrict_
     const bool in = mask[i] != 0;
     const int l = image[i];
     bad |= in && (l < 1 || l > Ng);
-    const uint8_t v = in ? (uint8_t)l : (uint8_t)0;
+    const uint8_t v = in ? (uint8_t)(l << shift) : (uint8_t)0;
     if (linear) {
       levels[i] = v;
     } else {
@@ -254,52 +254,56 @@ struct Walker {
 };
 
 // Fused flavour: H byte = prev*P + min(len-1, RS)*Q + cur*4 with Q = 4(Ng+1), P = (RS+1)*Q.
-// State is ONE running LDS address pl = cB + prev*P + (len-1)*Q (the bin row of the open run) plus prev.
+// State is ONE running LDS address pl = prev*P + (len-1)*Q (the bin row of the open run, relative to the table) plus prev.
+// The fused table only fits for Ng <= 44, so the packed volume holds level*4 (PRAD_FUSED_SHIFT) and `prev` / `cur`
+// below are those pre-scaled bytes: the bin offset cur*4 is the byte itself and prev*P = byte * (P/4), which lets
+// the compiler read the byte lanes of the packed word directly in v_add / v_mul_u32_u24 / v_cmp (SDWA) instead of
+// extracting them first.
 // Whether a line held >= 2 masked voxels is NOT tracked here (it would cost mask logic on every step); it is
 // recovered after the sweeps by resolve_multi_kernel / multi_check_kernel.
+#define PRAD_FUSED_SHIFT 2
 template <bool LONG>
 struct Walker<true, true, LONG, true> {
   u32 *rl_long;
-  int Nr, P, Q;
-  int cB;      // LDS address of H
+  int Nr, P4, Q;
+  // H sits at LDS address 0 (the kernels' only LDS object is the dynamic array; they check it and flag an internal
+  // error otherwise), so table offsets ARE LDS addresses and no base has to be carried through the address math
   int lenmax;  // RS*Q: byte offset of the "long" slot
-  int gB;      // LDS address of G minus the offset of its first bin (len-1 = RS, prev = 1)
+  int gB;      // offset of G minus the offset of its first bin (len-1 = RS, prev = 1)
   int RL4;     // bytes per level row of G
   unsigned Qinv;  // ceil(2^32 / Q): (len-1) = umulhi((len-1)*Q, Qinv)
   int RS, RL;
   int dummy;
   // state
-  int prev;
-  int pl;  // cB + prev*P + (len-1)*Q, unclamped
+  int prev;  // level*4 of the previous voxel (0 = none / outside the ROI)
+  int pl;    // level*P + (len-1)*Q, unclamped
 
   __device__ __forceinline__ void init(u32 *lds_, const HistLayout &h, int Nr_, u32 *rl_long_, int lane) {
-    const int base = (int)(unsigned)(size_t)((lds_u32 *)lds_);
     rl_long = rl_long_;
     Nr = Nr_;
     Q = 4 * (h.Ng + 1);
-    P = (h.RS + 1) * Q;
-    cB = base;
+    P4 = (h.RS + 1) * (h.Ng + 1);               // P / 4
     lenmax = h.RS * Q;
     RS = h.RS;
     RL = h.RL;
     RL4 = 4 * h.RL;
-    gB = base + 4 * h.g0 - RL4 - 4 * h.RS;       // + prev*RL4 + (len-1)*4 addresses G[prev-1][len-1-RS]
+    gB = 4 * h.g0 - RL4 - 4 * h.RS;       // + level*RL4 + (len-1)*4 addresses G[level-1][len-1-RS]
     Qinv = (unsigned)((0x100000000ull + (unsigned)Q - 1) / (unsigned)Q);
-    dummy = base + 4 * (h.dummy0 + lane);
+    dummy = 4 * (h.dummy0 + lane);
   }
   __device__ __forceinline__ void begin_line() {
     prev = 0;
-    pl = cB;
+    pl = 0;
   }
-  // the run of level `pv` (!= 0) that just ended was longer than RS: record its length.  Rare, divergent.
-  __device__ __forceinline__ void long_event(int pv, int lb) {
+  // the run of level `lv` (!= 0) that just ended was longer than RS: record its length.  Rare, divergent.
+  __device__ __forceinline__ void long_event(int lv, int lb) {
     const int idx = (int)__umulhi((unsigned)lb, Qinv);            // len - 1
     if (idx < RS + RL) {
-      lds_bump(gB + __mul24(pv, RL4) + (idx << 2));
+      lds_bump(gB + __mul24(lv, RL4) + (idx << 2));
       return;
     }
     // very long runs (flat regions): lanes of the wave that close the same (level, length) share one L2 atomic
-    const unsigned key = ((unsigned)pv << 20) | (unsigned)idx;
+    const unsigned key = ((unsigned)lv << 20) | (unsigned)idx;
     bool pending = true;
     while (pending) {
       const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)key);
@@ -307,12 +311,12 @@ struct Walker<true, true, LONG, true> {
       const unsigned long long m = __ballot(same);       // evaluated by every still-pending lane
       if (same) {
         if ((int)(__ffsll((long long)m) - 1) == (int)(threadIdx.x & 63))
-          atomicAdd(&rl_long[(size_t)(pv - 1) * Nr + idx], (u32)__popcll(m));
+          atomicAdd(&rl_long[(size_t)(lv - 1) * Nr + idx], (u32)__popcll(m));
         pending = false;
       }
     }
   }
-  __device__ __forceinline__ int lenb() const { return pl - (__mul24(prev, P) + cB); }
+  __device__ __forceinline__ int lenb() const { return pl - __mul24(prev, P4); }
   // stretches of unmasked voxels count too: their events land in row 0, but an unclamped slot must stay in range
   __device__ __forceinline__ bool risky(int steps) const { return LONG && lenb() + steps * Q > lenmax; }
   template <bool CHECK = true>
@@ -322,10 +326,10 @@ struct Walker<true, true, LONG, true> {
     if (LONG && CHECK) {
       const int lb = lenb();
       bin = pl - lb + min(lb, lenmax);
-      if (chg && prev != 0 && lb >= lenmax) long_event(prev, lb);
+      if (chg && prev != 0 && lb >= lenmax) long_event(prev >> PRAD_FUSED_SHIFT, lb);
     }
-    lds_bump(chg ? bin + (cur << 2) : dummy);
-    pl = select_i32(chg, __mul24(cur, P) + cB, pl + Q);
+    lds_bump(chg ? bin + cur : dummy);
+    pl = select_i32(chg, __mul24(cur, P4), pl + Q);
     prev = cur;
   }
   __device__ __forceinline__ bool end_line() {
@@ -341,10 +345,10 @@ struct Walker<true, true, LONG, true> {
     if (LONG && CHECK) {
       const int lb = lenb();
       bin = pl - lb + min(lb, lenmax);
-      if (chg && prev != 0 && lb >= lenmax) long_event(prev, lb);
+      if (chg && prev != 0 && lb >= lenmax) long_event(prev >> PRAD_FUSED_SHIFT, lb);
     }
-    lds_bump(chg ? bin + (evt << 2) : dummy);
-    pl = select_i32(chg, __mul24(cur, P) + cB, pl + Q);
+    lds_bump(chg ? bin + evt : dummy);
+    pl = select_i32(chg, __mul24(cur, P4), pl + Q);
     prev = cur;
     return false;
   }
@@ -358,27 +362,55 @@ __device__ __forceinline__ void step_lines_plain(W (&w)[LPL], unsigned v) {
 #pragma unroll
   for (int j = 0; j < LPL; j++) w[j].template step<false>((int)((v >> (8 * j)) & 0xffu));
 }
+// Fused flavour: `pw` is the packed word of the previous step (the prev bytes of the LPL lines).  Every operand that
+// involves a level is a byte lane of v / pw, so compare, bin address and fresh row each cost one SDWA instruction:
+// 6 VALU + 1 ds_add per voxel-step.  The walkers' own `prev` members are NOT maintained here; the caller packs them
+// into pw before a group of plain steps and unpacks the last word afterwards (pack_prev / unpack_prev).
 template <int LPL, bool LONG>
-__device__ __forceinline__ void step_lines_plain(Walker<true, true, LONG, true> (&w)[LPL], unsigned v) {
-  int cur[LPL], addr[LPL], fresh[LPL], grown[LPL];
+__device__ __forceinline__ void step_lines_plain(Walker<true, true, LONG, true> (&w)[LPL], unsigned v, unsigned pw) {
+  int addr[LPL], fresh[LPL], grown[LPL];
   bool chg[LPL];
+  // explicit bit-field extracts: the SDWA peephole folds a byte-aligned v_bfe into each VOP2 / VOPC user, whereas the
+  // shift-and-mask form gets rewritten into (v ^ pw) & mask != 0, which costs two instructions
 #pragma unroll
-  for (int j = 0; j < LPL; j++) cur[j] = (int)((v >> (8 * j)) & 0xffu);
-#pragma unroll
-  for (int j = 0; j < LPL; j++) chg[j] = cur[j] != w[j].prev;
+  for (int j = 0; j < LPL; j++) chg[j] = __builtin_amdgcn_ubfe(v, 8 * j, 8) != __builtin_amdgcn_ubfe(pw, 8 * j, 8);
 #pragma unroll
   for (int j = 0; j < LPL; j++) {
-    addr[j] = w[j].pl + (cur[j] << 2);
-    fresh[j] = __mul24(cur[j], w[j].P) + w[j].cB;
+    addr[j] = w[j].pl + (int)__builtin_amdgcn_ubfe(v, 8 * j, 8);
+    fresh[j] = (int)__umul24(__builtin_amdgcn_ubfe(v, 8 * j, 8), (unsigned)w[j].P4);
     grown[j] = w[j].pl + w[j].Q;
   }
 #pragma unroll
   for (int j = 0; j < LPL; j++) lds_bump(chg[j] ? addr[j] : w[j].dummy);
 #pragma unroll
-  for (int j = 0; j < LPL; j++) {
-    w[j].pl = select_i32(chg[j], fresh[j], grown[j]);
-    w[j].prev = cur[j];
+  for (int j = 0; j < LPL; j++) w[j].pl = select_i32(chg[j], fresh[j], grown[j]);
+}
+template <int LPL, typename W>
+__device__ __forceinline__ unsigned pack_prev(const W (&w)[LPL]) {
+  unsigned pw = 0;
+#pragma unroll
+  for (int j = 0; j < LPL; j++) pw |= (unsigned)w[j].prev << (8 * j);
+  return pw;
+}
+template <int LPL, typename W>
+__device__ __forceinline__ void unpack_prev(W (&w)[LPL], unsigned pw) {
+#pragma unroll
+  for (int j = 0; j < LPL; j++) w[j].prev = (int)((pw >> (8 * j)) & 0xffu);
+}
+template <int LPL, int U, typename W>
+__device__ __forceinline__ void steps_plain_group(W (&w)[LPL], const unsigned (&v)[U]) {
+#pragma unroll
+  for (int k = 0; k < U; k++) step_lines_plain<LPL>(w, v[k]);
+}
+template <int LPL, int U, bool LONG>
+__device__ __forceinline__ void steps_plain_group(Walker<true, true, LONG, true> (&w)[LPL], const unsigned (&v)[U]) {
+  unsigned pw = pack_prev<LPL>(w);
+#pragma unroll
+  for (int k = 0; k < U; k++) {
+    step_lines_plain<LPL, LONG>(w, v[k], pw);
+    pw = v[k];
   }
+  unpack_prev<LPL>(w, pw);
 }
 
 template <bool DO_GLCM, bool DO_GLRLM, bool FUSED>
@@ -499,12 +531,16 @@ template <bool DO_GLCM, bool DO_GLRLM, bool LONG, bool FUSED, int LPL>
 __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, const uint8_t *__restrict__ L, int Ng,
                                                               int Nr, int RS, u32 *__restrict__ glcm_acc,
                                                               u32 *__restrict__ glrlm_acc, int *__restrict__ multi,
-                                                              int *__restrict__ work, const int *__restrict__ flags) {
+                                                              int *__restrict__ work, int *__restrict__ flags) {
   constexpr int CW = 64 * LPL;  // lines per wave
   constexpr int U = PRAD_SWEEP_UNROLL;
   extern __shared__ u32 lds[];
   if (flags[0]) return;  // irregular levels: the generic path will redo this call
   const HistLayout h = hist_layout(DO_GLCM, DO_GLRLM, FUSED, Ng, RS);
+  if (FUSED && (unsigned)(size_t)((lds_u32 *)lds) != 0u) {  // the fused walker addresses its table from LDS address 0
+    if (threadIdx.x == 0) atomicExch(flags + 2, 1);
+    return;
+  }
   for (int i = threadIdx.x; i < h.words; i += blockDim.x) lds[i] = 0;
   __syncthreads();
 
@@ -577,8 +613,7 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
             for (int j = 0; j < LPL; j++) w[j].template step<true>((int)((v[k] >> (8 * j)) & 0xffu));
           }
         } else {
-#pragma unroll
-          for (int k = 0; k < U; k++) step_lines_plain<LPL>(w, v[k]);
+          steps_plain_group<LPL, U>(w, v);
         }
       } else {
         int sb[U];
@@ -636,10 +671,14 @@ template <bool DO_GLCM, bool DO_GLRLM, bool LONG, bool FUSED>
 __global__ void __launch_bounds__(512) sweep_rows_kernel(const uint8_t *__restrict__ L, long long nrows, int NX,
                                                          int pitch, int slot, int Ng, int Nr, int RS,
                                                          u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
-                                                         int *__restrict__ multi, const int *__restrict__ flags) {
+                                                         int *__restrict__ multi, int *__restrict__ flags) {
   extern __shared__ u32 lds[];
   if (flags[0]) return;
   const HistLayout h = hist_layout(DO_GLCM, DO_GLRLM, FUSED, Ng, RS);
+  if (FUSED && (unsigned)(size_t)((lds_u32 *)lds) != 0u) {
+    if (threadIdx.x == 0) atomicExch(flags + 2, 1);
+    return;
+  }
   for (int i = threadIdx.x; i < h.words; i += blockDim.x) lds[i] = 0;
   __syncthreads();
   const int lane = threadIdx.x & 63;

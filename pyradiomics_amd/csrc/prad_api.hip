@@ -103,7 +103,7 @@ struct Call {
   const int *angles_h;    // host [Na][Nd]
   int *angles_d;          // device copy
   int Na;
-  int *flags_d;           // device int[4]: [0] pack saw irregular level, [1] generic index error
+  int *flags_d;           // device int[4]: [0] pack saw irregular level, [1] generic index error, [2] sweep LDS base != 0
   int *flags_h;           // pinned
 };
 
@@ -286,7 +286,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
   if (want_glcm && want_glrlm) {
     const int rs = fit_rs(true, true, true, Ng, Nr, kHistBudget);
     const int rsr = fit_rs(true, true, true, Ng, Nr, kHistBudgetRows);
-    if (rs >= std::min(Nr, 8) && rsr >= std::min(Nr, 4)) {
+    if (Ng <= (255 >> PRAD_FUSED_SHIFT) && rs >= std::min(Nr, 8) && rsr >= std::min(Nr, 4)) {
       p.fused = true;
       p.RS = rs;
       p.RSr = rsr;
@@ -431,8 +431,10 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
     Timed t(c, "pack", k.s);
     const int vec_ok = p.vec_rows && ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)levels)) & 15) == 0;
     const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n / 16 + 255) / 256, 4096));
+    // the fused walker reads level*4 bytes (see Walker<true, true, LONG, true>); it only exists for Ng <= 44
+    const int shift = (glcm && glrlm && p.fused) ? PRAD_FUSED_SHIFT : 0;
     hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, k.s, k.image, k.mask, k.g.n, p.Nx, p.pitch, p.padw,
-                       Ng, levels, k.flags_d, vec_ok);
+                       Ng, levels, k.flags_d, vec_ok, shift);
     PRAD_TRY(check_launch("pack_levels_kernel"));
   }
   if (glcm && glrlm && p.fused) PRAD_TRY((launch_sweeps<true, true, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
@@ -461,6 +463,7 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
     }
   }
   PRAD_TRY(read_flags(k));
+  if (k.flags_h[2]) return fail(PRAD_E_HIP, "internal error: the sweep kernels' dynamic LDS does not start at address 0");
   *used = (k.flags_h[0] == 0);
   return PRAD_OK;
 }
