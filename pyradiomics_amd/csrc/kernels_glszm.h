@@ -297,6 +297,83 @@ __global__ void __launch_bounds__(256) glszm_border_kernel(Offsets3 A, const int
   }
 }
 
+// The same scan for the full 26- (MODE 1) / in-plane 8-neighbourhood (MODE 2) with the redundancy rules of the tile
+// kernel applied to GLOBAL sameness: a backward neighbour whose own (earlier) unions already tie it to a neighbour we
+// unite with is skipped -- and so are its loads.  By induction over raster order every adjacent same-level pair still
+// ends up connected: each voxel is united with one representative of every cluster of mutually adjacent backward
+// neighbours, and the members of a cluster are adjacent voxels that precede it.  Pairs inside one tile are left to
+// the tile kernel (which applies the rules to in-tile sameness and therefore performs a superset of them).
+template <int MODE>
+__global__ void __launch_bounds__(256) glszm_border_full_kernel(const int *__restrict__ image,
+                                                                const uint8_t *__restrict__ mask, int Nz, int Ny,
+                                                                int Nx, int *__restrict__ labels) {
+  const int lane = threadIdx.x & 63;
+  const long long nrows = (long long)Nz * Ny;
+  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  const int xtiles = (Nx + PRAD_TX - 1) / PRAD_TX;
+  for (long long row = wave0; row < nrows; row += nwaves) {
+    const int z = (int)(row / Ny), y = (int)(row - (long long)z * Ny);
+    const bool row_edge = (MODE == 1 && z % PRAD_TZ == 0) || (y % PRAD_TY == 0) || (MODE == 1 && y % PRAD_TY == PRAD_TY - 1);
+    const int count = row_edge ? Nx : 2 * xtiles;
+    const long long rbase = row * Nx;
+    for (int c0 = 0; c0 < count; c0 += 64) {
+      const int c = c0 + lane;
+      int x = -1;
+      if (c < count) x = row_edge ? c : (c >> 1) * PRAD_TX + ((c & 1) ? PRAD_TX - 1 : 0);
+      int gl = 0, li = -1;
+      if (x >= 0 && x < Nx && mask[rbase + x]) {
+        gl = image[rbase + x];
+        li = labels[rbase + x];
+      }
+      if (__ballot(li >= 0) == 0ull) continue;
+      // linear index of the neighbour if it continues the zone, else -1 (only evaluated for live lanes)
+      auto same = [&](int dz, int dy, int dx) -> long long {
+        const int qz = z + dz, qy = y + dy, qx = x + dx;
+        if ((unsigned)qz >= (unsigned)Nz || (unsigned)qy >= (unsigned)Ny || (unsigned)qx >= (unsigned)Nx) return -1;
+        const long long j = ((long long)qz * Ny + qy) * Nx + qx;
+        return (mask[j] && image[j] == gl) ? j : -1;
+      };
+      // unite across the tile boundary; every lane of the wave takes part in the shuffle
+      auto pair = [&](long long j, int dz, int dy, int dx) {
+        int lj = -1;
+        if (j >= 0) {
+          const int qz = z + dz, qy = y + dy, qx = x + dx;
+          const bool same_tile = qz / PRAD_TZ == z / PRAD_TZ && qy / PRAD_TY == y / PRAD_TY && qx / PRAD_TX == x / PRAD_TX;
+          if (!same_tile) lj = labels[j];
+        }
+        const int pi = __shfl_up(li, 1), pj = __shfl_up(lj, 1);
+        if (lj >= 0 && !(lane > 0 && pi == li && pj == lj)) uf_union(labels, li, lj);
+      };
+      const bool live = li >= 0;
+      const long long jb = live ? same(0, -1, 0) : -1;
+      pair(jb, 0, -1, 0);
+      const bool nb = live && jb < 0;
+      const long long jc = nb ? same(0, -1, 1) : -1;
+      pair(jc, 0, -1, 1);
+      const long long ja = nb ? same(0, -1, -1) : -1;
+      pair(ja, 0, -1, -1);
+      const long long jd = (nb && ja < 0) ? same(0, 0, -1) : -1;
+      pair(jd, 0, 0, -1);
+      if (MODE == 1) {
+        const long long jm = live ? same(-1, 0, 0) : -1;
+        pair(jm, -1, 0, 0);
+        const bool nm = live && jm < 0;
+        const long long e1 = nm ? same(-1, -1, 0) : -1, e2 = nm ? same(-1, 1, 0) : -1;
+        const long long e3 = nm ? same(-1, 0, -1) : -1, e4 = nm ? same(-1, 0, 1) : -1;
+        pair(e1, -1, -1, 0);
+        pair(e2, -1, 1, 0);
+        pair(e3, -1, 0, -1);
+        pair(e4, -1, 0, 1);
+        pair((nm && e1 < 0 && e3 < 0) ? same(-1, -1, -1) : -1, -1, -1, -1);
+        pair((nm && e1 < 0 && e4 < 0) ? same(-1, -1, 1) : -1, -1, -1, 1);
+        pair((nm && e2 < 0 && e3 < 0) ? same(-1, 1, -1) : -1, -1, 1, -1);
+        pair((nm && e2 < 0 && e4 < 0) ? same(-1, 1, 1) : -1, -1, 1, 1);
+      }
+    }
+  }
+}
+
 // tiled path: sizes[] holds the voxel count of every tile-local component at its tile root; fold the counts of
 // tile roots that were linked elsewhere into their global root.  One find per (zone, tile) instead of per voxel.
 // A zone that spans thousands of tiles would otherwise receive thousands of atomics on one address, so every block
@@ -705,8 +782,13 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
       hipLaunchKernelGGL(glszm_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, s, A3, mode, image, mask, dims3[0],
                          dims3[1], dims3[2], st.labels, st.sizes);
       PRAD_TRY(check_launch("glszm_tile_kernel"));
-      hipLaunchKernelGGL(glszm_border_kernel, dim3((unsigned)std::min<long long>(((long long)dims3[0] * dims3[1] + 3) / 4, 16384)),
-                         dim3(256), 0, s, A3, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
+      const dim3 bgrid((unsigned)std::min<long long>(((long long)dims3[0] * dims3[1] + 3) / 4, 16384));
+      if (mode == 1)
+        hipLaunchKernelGGL(glszm_border_full_kernel<1>, bgrid, dim3(256), 0, s, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
+      else if (mode == 2)
+        hipLaunchKernelGGL(glszm_border_full_kernel<2>, bgrid, dim3(256), 0, s, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
+      else
+        hipLaunchKernelGGL(glszm_border_kernel, bgrid, dim3(256), 0, s, A3, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
       PRAD_TRY(check_launch("glszm_border_kernel"));
       hipLaunchKernelGGL(glszm_rootsum_kernel, dim3((unsigned)((g.n + PRAD_RS_CHUNK - 1) / PRAD_RS_CHUNK)), dim3(256), 0, s,
                          g.n, st.labels, st.sizes);
