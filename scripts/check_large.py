@@ -40,3 +40,17 @@ for a in range(ang.shape[0]):
     diag = int(torch.diagonal(glcm[:, :, a]).sum().item())
     assert diag == same, ("GLCM diagonal", a, diag, same)
 print("1024x1024x1020: GLCM totals, diagonals and GLRLM coverage of all %d angles verified; ROI %d voxels" % (ang.shape[0], nroi))
+
+# the other matrices and the first-order statistics at the same size: identities that hold for exact results
+Ngl = 32
+counts = torch.bincount(img[mask], minlength=Ngl + 1)[1:].to(torch.float64)
+t = time.perf_counter(); gldm = engine.gldm(img, mask, Ngl, 0); torch.cuda.synchronize(); t_gldm = time.perf_counter() - t
+assert torch.equal(gldm.sum(1), counts)
+t = time.perf_counter(); ngtdm = engine.ngtdm(img, mask, Ngl); torch.cuda.synchronize(); t_ngtdm = time.perf_counter() - t
+assert torch.equal(ngtdm[:, 0], counts)
+t = time.perf_counter(); P, sizes = engine.glszm_compact(img, mask, Ngl, nroi); torch.cuda.synchronize(); t_glszm = time.perf_counter() - t
+assert torch.equal((P * torch.from_numpy(sizes).to(dev, torch.float64)[None, :]).sum(1), counts)
+t = time.perf_counter(); st = engine.firstorder_stats(img, mask); torch.cuda.synchronize(); t_fo = time.perf_counter() - t
+assert st["Np"] == nroi and st["Energy"] == float((counts * torch.arange(1, Ngl + 1, device=dev, dtype=torch.float64) ** 2).sum())
+print("GLDM %.1f ms, NGTDM %.1f ms, GLSZM %.1f ms (%d zones, %d distinct sizes), first order %.1f ms: level totals, zone "
+      "tiling and energy verified" % (t_gldm * 1e3, t_ngtdm * 1e3, t_glszm * 1e3, int(P.sum().item()), len(sizes), t_fo * 1e3))
