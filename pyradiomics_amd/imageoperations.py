@@ -104,6 +104,32 @@ def cropToTumorMask(image, mask, label=1, padDistance=0, deviceResident=False):
             msk._derived[ckey])
 
 
+def normalizeImage(image, **kwargs):
+    """f(x) = scale * (x - mean) / sigma over ALL voxels of the image (imageoperations.py:615-654: sitk.Normalize, i.e.
+    float64 output and the N - 1 standard deviation -- pinned by the reference's `_normalization` golden vectors),
+    values beyond +-removeOutliers standard deviations clipped before the scale is applied.  Works on the device when
+    the image lives there (or `deviceResident` is set), on the host otherwise."""
+    scale = kwargs.get("normalizeScale", 1)
+    outliers = kwargs.get("removeOutliers")
+    img = as_image(image)
+    if img.on_device or kwargs.get("deviceResident", False):
+        import torch
+        x = img.device_tensor().to(torch.float64)
+        mean = x.mean()
+        sigma = torch.sqrt(((x - mean) ** 2).sum() / (x.numel() - 1))
+        out = (x - mean) / sigma
+        if outliers is not None:
+            out = out.clamp(-outliers, outliers)
+        return img.like(tensor=out * float(scale))
+    x = img.array.astype(np.float64)
+    mean = x.mean()
+    sigma = np.sqrt(((x - mean) ** 2).sum() / (x.size - 1))
+    out = (x - mean) / sigma
+    if outliers is not None:
+        out = np.clip(out, -outliers, outliers)
+    return img.like(out * float(scale))
+
+
 def resegmentMask(image, mask, **kwargs):
     """Restricts the ROI to voxels whose intensity lies in `resegmentRange` (1 threshold: >= T; 2: closed range),
     with the thresholds absolute, relative to the ROI maximum, or in standard deviations around the ROI mean

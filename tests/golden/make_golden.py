@@ -9,7 +9,8 @@ missing large blobs) this stores, per case, in tests/golden/<case>.npz:
     P_glcm .. P_ngtdm  the reference's golden matrices data/baseline/<case>_<class>.npy  (tests/test_matrices.py:35-65)
 and in tests/golden/baseline_features.json the reference's golden feature values
 data/baseline/baseline_<class>.csv (tests/test_features.py) for the configurations that need no SimpleITK-only
-preprocessing (default, _2d, _FBN, _combined, _flatRegion, _resegmentation), together with their settings.
+preprocessing (default, _2d, _FBN, _combined, _flatRegion, _resegmentation, _normalization), together with their
+settings.
 
 Nothing here is reference SOURCE; these are its test vectors."""
 import ast
@@ -28,10 +29,11 @@ from pyradiomics_amd.image import read_nrrd  # noqa: E402
 REF = os.environ.get("REFERENCE", "/root/reference")
 CASES = ["brain1", "brain2", "breast1"]
 CLASSES = ["glcm", "glrlm", "glszm", "gldm", "ngtdm"]
-CONFIG_SUFFIXES = ["", "_2d", "_FBN", "_combined", "_flatRegion", "_resegmentation"]
+CONFIG_SUFFIXES = ["", "_2d", "_FBN", "_combined", "_flatRegion", "_resegmentation", "_normalization"]
 FEATURE_CLASSES = CLASSES + ["firstorder"]      # golden feature values only (first order has no matrix)
 KEEP = ("binWidth", "binCount", "force2D", "force2Ddimension", "distances", "weightingNorm", "symmetricalGLCM",
-        "gldm_a", "label", "resegmentRange", "resegmentMode", "voxelArrayShift")
+        "gldm_a", "label", "resegmentRange", "resegmentMode", "voxelArrayShift", "normalize", "normalizeScale",
+        "removeOutliers")
 
 
 def main():
@@ -42,7 +44,13 @@ def main():
         m = lab.array == 1
         idx = np.where(m)
         sl = tuple(slice(int(i.min()), int(i.max()) + 1) for i in idx)
-        out = {"image": img.array[sl], "mask": m[sl].astype(np.uint8), "spacing": np.array(img.spacing)}
+        # whole-image mean / standard deviation (N - 1): what sitk.Normalize uses for the `_normalization` configs
+        # (imageoperations.py:615-654 normalises over ALL voxels, not just the ROI)
+        x = img.array.astype(np.float64)
+        mean = x.mean()
+        sigma = np.sqrt(((x - mean) ** 2).sum() / (x.size - 1))
+        out = {"image": img.array[sl], "mask": m[sl].astype(np.uint8), "spacing": np.array(img.spacing),
+               "image_mean": np.float64(mean), "image_sigma": np.float64(sigma)}
         for cls in CLASSES:
             out["P_" + cls] = np.load(os.path.join(REF, "data", "baseline", "%s_%s.npy" % (case, cls)))
         np.savez_compressed(os.path.join(HERE, case + ".npz"), **out)

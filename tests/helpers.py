@@ -34,6 +34,16 @@ def prepared_case(cfg):
     from pyradiomics_amd import imageoperations
     image, mask, _ = load_case(cfg["case"])
     settings = {k: v for k, v in cfg["settings"].items() if v is not None}
+    if settings.pop("normalize", False):
+        # the reference normalises the WHOLE image before cropping (imageoperations.py:615-654); the fixtures hold the
+        # ROI crop plus the whole-image mean / sigma, which is all normalizeImage depends on
+        d = np.load(os.path.join(GOLDEN, cfg["case"] + ".npz"))
+        arr = (image.array.astype(np.float64) - float(d["image_mean"])) / float(d["image_sigma"])
+        if settings.get("removeOutliers") is not None:
+            arr = np.clip(arr, -settings["removeOutliers"], settings["removeOutliers"])
+        image = image.like(arr * float(settings.get("normalizeScale", 1)))
+    settings.pop("normalizeScale", None)
+    settings.pop("removeOutliers", None)
     if cfg["settings"].get("resegmentRange") is not None:
         mask = imageoperations.resegmentMask(image, mask, **settings)
         image, mask = imageoperations.cropToTumorMask(image, mask, settings.get("label", 1))

@@ -12,8 +12,8 @@ IMG = os.path.join(GOLDEN, "data", "brain1_image.nrrd")
 LBL = os.path.join(GOLDEN, "data", "brain1_label.nrrd")
 
 
-def _check_against_baseline(result, classes):
-    want = load_baseline_features()["brain1"]["features"]
+def _check_against_baseline(result, classes, config="brain1"):
+    want = load_baseline_features()[config]["features"]
     for cls in classes:
         for name, ref in want[cls].items():
             val = float(result["original_%s_%s" % (cls, name)])
@@ -39,6 +39,20 @@ def test_extractor_config1_on_oracle_backend(oracle_port):
         backend.set(old)
 
 
+def test_extractor_normalization_on_oracle_backend(oracle_port):
+    """whole-image normalisation (sitk.Normalize semantics) through the extractor on the full brain1 NRRD pair against
+    the reference's `brain1_normalization` golden vectors (all six classes)"""
+    from pyradiomics_amd import backend
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    old = backend._cmatrices
+    backend.set(oracle_port)
+    try:
+        res = RadiomicsFeatureExtractor(binWidth=5, normalize=True, normalizeScale=100).execute(IMG, LBL)
+        _check_against_baseline(res, ["firstorder", "glcm", "glrlm", "glszm", "gldm", "ngtdm"], "brain1_normalization")
+    finally:
+        backend.set(old)
+
+
 def test_extractor_params_dict_and_names():
     from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
     ex = RadiomicsFeatureExtractor({"setting": {"binWidth": 25, "force2D": True},
@@ -57,6 +71,18 @@ def test_extractor_config1_on_gpu():
     backend.set(cmatrices)
     res = RadiomicsFeatureExtractor(binWidth=25).execute(IMG, LBL)      # all five texture classes
     _check_against_baseline(res, ["glcm", "glrlm", "glszm", "gldm", "ngtdm"])
+
+
+@pytest.mark.gpu
+def test_extractor_normalization_on_gpu():
+    from pyradiomics_amd import backend, cmatrices
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    backend.set(cmatrices)
+    for route in (True, False):
+        res = RadiomicsFeatureExtractor(binWidth=5, normalize=True, normalizeScale=100, deviceResident=route).execute(IMG, LBL)
+        _check_against_baseline(res, ["firstorder", "glcm", "glrlm", "glszm", "gldm", "ngtdm"], "brain1_normalization")
+    clipped = RadiomicsFeatureExtractor(binWidth=5, normalize=True, normalizeScale=100, removeOutliers=1.5).execute(IMG, LBL)
+    assert float(clipped["original_firstorder_Maximum"]) <= 150.0 and float(clipped["original_firstorder_Minimum"]) >= -150.0
 
 
 @pytest.mark.gpu
