@@ -19,7 +19,7 @@ from itertools import chain
 import numpy as np
 
 from . import __version__, backend, filters, imageoperations
-from .image import Image, as_array, as_image, read_nrrd
+from .image import Image, as_array, as_image, read_image
 
 logger = logging.getLogger(__name__)
 
@@ -149,10 +149,10 @@ class RadiomicsFeatureExtractor:
     # -- execution ---------------------------------------------------------------------------------------
     @staticmethod
     def loadImage(imageFilepath, maskFilepath, **kwargs):
-        """paths to NRRD files, pyradiomics_amd.image.Image objects, or numpy arrays (z, y, x)"""
+        """paths to NRRD / NIfTI-1 / MetaImage files, pyradiomics_amd.image.Image objects, or numpy arrays (z, y, x)"""
         def load(x):
             if isinstance(x, (str, os.PathLike)):
-                return read_nrrd(os.fspath(x))
+                return read_image(os.fspath(x))
             return as_image(x)
         image, mask = load(imageFilepath), load(maskFilepath)
         if image.shape != mask.shape:

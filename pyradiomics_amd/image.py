@@ -196,3 +196,119 @@ def write_nrrd(path: str, image: Image, compress: bool = True) -> None:
         f.write(("\n".join(hdr) + "\n\n").encode("ascii"))
         f.write(payload)
     os.replace(tmp, path)
+
+
+# ---- other on-disk formats the reference reads through SimpleITK (featureextractor.py:399-483 ReadImage) ----------
+_NIFTI_TYPES = {2: "u1", 4: "i2", 8: "i4", 16: "f4", 64: "f8", 256: "i1", 512: "u2", 768: "u4", 1024: "i8", 1280: "u8"}
+
+
+def read_nifti(path: str) -> Image:
+    """NIfTI-1 single-file reader (.nii / .nii.gz): voxel array as (z, y, x), spacing from pixdim, origin / direction
+    from the sform or qform converted from NIfTI's RAS to the LPS convention SimpleITK reports; scl_slope / scl_inter
+    applied like ITK does (result float64 when a scaling is present)."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    if raw[:2] == b"\x1f\x8b":
+        raw = gzip.decompress(raw)
+    order = "<" if int(np.frombuffer(raw, "<i4", 1, 0)[0]) == 348 else ">"
+    if int(np.frombuffer(raw, order + "i4", 1, 0)[0]) != 348 or raw[344:347] not in (b"n+1", b"ni1"):
+        raise ValueError("%s: not a NIfTI-1 file" % path)
+    if raw[344:347] == b"ni1":
+        raise NotImplementedError("NIfTI header/image pairs (.hdr/.img) are not supported")
+    dim = np.frombuffer(raw, order + "i2", 8, 40)
+    nd = int(dim[0])
+    if nd < 2 or nd > 3 and any(int(d) > 1 for d in dim[4:nd + 1]):
+        raise NotImplementedError("only 2-D and 3-D NIfTI volumes are supported (dim = %s)" % list(dim))
+    nd = min(nd, 3)
+    sizes = [int(d) for d in dim[1:nd + 1]]
+    datatype = int(np.frombuffer(raw, order + "i2", 1, 70)[0])
+    if datatype not in _NIFTI_TYPES:
+        raise NotImplementedError("NIfTI datatype %d" % datatype)
+    pixdim = np.frombuffer(raw, order + "f4", 8, 76)
+    vox_offset = int(np.frombuffer(raw, order + "f4", 1, 108)[0])
+    slope, inter = (float(v) for v in np.frombuffer(raw, order + "f4", 2, 112))
+    dt = np.dtype(_NIFTI_TYPES[datatype])
+    if dt.itemsize > 1:
+        dt = dt.newbyteorder(order)
+    arr = np.frombuffer(raw, dt, int(np.prod(sizes)), vox_offset).reshape(sizes[::-1])
+    arr = arr.astype(dt.newbyteorder("="), copy=True)
+    if slope not in (0.0, 1.0) or (slope != 0.0 and inter != 0.0):
+        arr = arr.astype(np.float64) * slope + inter
+    spacing = [abs(float(p)) or 1.0 for p in pixdim[1:nd + 1]]
+    origin, direction = [0.0] * nd, list(np.eye(nd).ravel())
+    qform_code, sform_code = (int(v) for v in np.frombuffer(raw, order + "i2", 2, 252))
+    A = None
+    if sform_code > 0:
+        A = np.frombuffer(raw, order + "f4", 12, 280).reshape(3, 4).astype(np.float64)
+    elif qform_code > 0:
+        b, c, d, qx, qy, qz = (float(v) for v in np.frombuffer(raw, order + "f4", 6, 256))
+        a = np.sqrt(max(0.0, 1.0 - b * b - c * c - d * d))
+        R = np.array([[a * a + b * b - c * c - d * d, 2 * (b * c - a * d), 2 * (b * d + a * c)],
+                      [2 * (b * c + a * d), a * a + c * c - b * b - d * d, 2 * (c * d - a * b)],
+                      [2 * (b * d - a * c), 2 * (c * d + a * b), a * a + d * d - b * b - c * c]])
+        qfac = -1.0 if float(pixdim[0]) < 0 else 1.0
+        S = np.diag([float(pixdim[1]), float(pixdim[2]), float(pixdim[3]) * qfac])
+        A = np.concatenate([R @ S, np.array([[qx], [qy], [qz]])], 1)
+    if A is not None and nd == 3:
+        flip = np.diag([-1.0, -1.0, 1.0])                     # RAS -> LPS
+        M = flip @ A[:, :3]
+        sp = np.sqrt((M ** 2).sum(0))
+        sp[sp == 0] = 1.0
+        spacing = [float(v) for v in sp]
+        direction = list((M / sp).ravel())
+        origin = [float(v) for v in flip @ A[:, 3]]
+    return Image(arr, spacing, origin, direction)
+
+
+def read_metaimage(path: str) -> Image:
+    """MetaImage reader (.mha, or .mhd with a raw / zlib-compressed data file next to it)"""
+    with open(path, "rb") as f:
+        raw = f.read()
+    fields, pos = {}, 0
+    while True:
+        end = raw.index(b"\n", pos)
+        line = raw[pos:end].decode("ascii", "replace").strip()
+        pos = end + 1
+        if "=" in line:
+            k, v = (t.strip() for t in line.split("=", 1))
+            fields[k] = v
+            if k == "ElementDataFile":
+                break
+    nd = int(fields.get("NDims", 3))
+    sizes = [int(v) for v in fields["DimSize"].split()]
+    met = {"MET_CHAR": "i1", "MET_UCHAR": "u1", "MET_SHORT": "i2", "MET_USHORT": "u2", "MET_INT": "i4", "MET_UINT": "u4",
+           "MET_LONG_LONG": "i8", "MET_ULONG_LONG": "u8", "MET_FLOAT": "f4", "MET_DOUBLE": "f8"}
+    if fields["ElementType"] not in met:
+        raise NotImplementedError("MetaImage ElementType %r" % fields["ElementType"])
+    if int(fields.get("ElementNumberOfChannels", 1)) != 1:
+        raise NotImplementedError("multi-channel MetaImage")
+    msb = fields.get("BinaryDataByteOrderMSB", fields.get("ElementByteOrderMSB", "False")).lower() == "true"
+    dt = np.dtype(met[fields["ElementType"]])
+    if dt.itemsize > 1:
+        dt = dt.newbyteorder(">" if msb else "<")
+    if fields["ElementDataFile"] == "LOCAL":
+        data = raw[pos:]
+    else:
+        with open(os.path.join(os.path.dirname(os.path.abspath(path)), fields["ElementDataFile"]), "rb") as f:
+            data = f.read()
+    if fields.get("CompressedData", "False").lower() == "true":
+        import zlib
+        data = zlib.decompress(data)
+    arr = np.frombuffer(data, dt, int(np.prod(sizes))).reshape(sizes[::-1]).astype(dt.newbyteorder("="), copy=True)
+    spacing = [float(v) for v in fields.get("ElementSpacing", fields.get("ElementSize", " ".join(["1"] * nd))).split()]
+    origin = [float(v) for v in fields.get("Offset", fields.get("Position", fields.get("Origin", " ".join(["0"] * nd)))).split()]
+    tm = fields.get("TransformMatrix", fields.get("Orientation", fields.get("Rotation")))
+    direction = list(np.eye(nd).ravel())
+    if tm is not None:
+        direction = list(np.array([float(v) for v in tm.split()]).reshape(nd, nd).T.ravel())   # file holds columns
+    return Image(arr, spacing, origin, direction)
+
+
+def read_image(path: str) -> Image:
+    """dispatch on the file name: .nrrd / .nhdr-less NRRD, .nii / .nii.gz, .mha / .mhd"""
+    low = path.lower()
+    if low.endswith((".nii", ".nii.gz")):
+        return read_nifti(path)
+    if low.endswith((".mha", ".mhd")):
+        return read_metaimage(path)
+    return read_nrrd(path)
