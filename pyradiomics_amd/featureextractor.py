@@ -5,7 +5,7 @@ GPU hosts).  Same constructor forms (parameter file, dict, or keyword settings),
 the same `execute(image, mask, label=None, voxelBased=False)` returning an OrderedDict keyed
 `<imageType>_<featureClass>_<featureName>` (featureextractor.py:241-396, 560-604).
 
-Not provided (out of scope): the shape classes, resampling,
+Not provided (out of scope): the shape classes,
 the remaining image types, parameter-file schema validation.  Enabling them raises/ warns instead of silently
 computing something else."""
 from __future__ import annotations
@@ -164,9 +164,7 @@ class RadiomicsFeatureExtractor:
         if label is not None:
             s["label"] = label
         label = s.get("label", 1)
-        if s.get("resampledPixelSpacing"):
-            raise NotImplementedError("setting 'resampledPixelSpacing' needs SimpleITK resampling, which is outside the "
-                                      "accelerated path")
+
         kernelRadius = 0
         if voxelBased:
             s["voxelBased"] = True
@@ -181,6 +179,10 @@ class RadiomicsFeatureExtractor:
         s["deviceResident"] = on_dev
         if s.get("normalize", False):                  # featureextractor.py:432-433: before anything else sees the image
             image = imageoperations.normalizeImage(image, **s)
+        if s.get("resampledPixelSpacing") is not None:  # :436-440 (host-side preprocessing like the file readers)
+            if not np.any(mask.array == label):
+                raise ValueError("Label (%g) not present in mask" % label)
+            image, mask = imageoperations.resampleImage(image, mask, **s)
         if s.get("resegmentRange") is not None:
             if not np.any(mask.array == label):
                 raise ValueError("Label (%g) not present in mask" % label)

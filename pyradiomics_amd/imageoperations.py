@@ -104,6 +104,143 @@ def cropToTumorMask(image, mask, label=1, padDistance=0, deviceResident=False):
             msk._derived[ckey])
 
 
+# ---- resampling (imageoperations.py:448-612 on SimpleITK's ResampleImageFilter) ------------------------------------
+# The arithmetic lives in ITK: BSplineDecompositionImageFilter (recursive prefilter, pole sqrt(3) - 2, mirror boundaries,
+# 1e-10 horizon), BSplineInterpolateImageFunction (cubic weights, mirrored support), ResampleImageFilter (inside-buffer
+# test, clamp + C cast to the input pixel type), NearestNeighborInterpolateImageFunction (round half up) for the
+# mask.  Restated here from the published algorithms and PINNED by the reference's `_resampling` golden vectors
+# (tests/golden/baseline_features.json: every feature of all six classes reproduces within 1e-12).
+_BSPLINE_POLE = np.sqrt(3.0) - 2.0
+
+
+def _bspline_decompose_axis(c, axis, tol=1e-10):
+    """in-place-style 1-D cubic B-spline coefficient filter along `axis` (BSplineDecompositionImageFilter::
+    DataToCoefficients1D with SetInitialCausalCoefficient / SetInitialAntiCausalCoefficient)"""
+    c = np.moveaxis(c, axis, 0).copy()
+    N = c.shape[0]
+    if N == 1:
+        return np.moveaxis(c, 0, axis)
+    z = _BSPLINE_POLE
+    c *= (1.0 - z) * (1.0 - 1.0 / z)
+    horizon = int(np.ceil(np.log(tol) / np.log(abs(z))))
+    if horizon < N:
+        zn, acc = z, c[0].copy()
+        for n in range(1, horizon):
+            acc += zn * c[n]
+            zn *= z
+        c[0] = acc
+    else:
+        iz, z2n, zn = 1.0 / z, z ** (N - 1), z
+        acc = c[0] + z2n * c[N - 1]
+        z2n *= z2n * iz
+        for n in range(1, N - 1):
+            acc += (zn + z2n) * c[n]
+            zn *= z
+            z2n *= iz
+        c[0] = acc / (1.0 - zn * zn)
+    for n in range(1, N):
+        c[n] += z * c[n - 1]
+    c[N - 1] = (z / (z * z - 1.0)) * (z * c[N - 2] + c[N - 1])
+    for n in range(N - 2, -1, -1):
+        c[n] = z * (c[n + 1] - c[n])
+    return np.moveaxis(c, 0, axis)
+
+
+def _bspline_interp_axis(c, axis, pos):
+    """cubic B-spline evaluation of the coefficient array along `axis` at the continuous indices `pos`"""
+    N = c.shape[axis]
+    base = np.floor(pos).astype(np.int64) - 1
+    w = pos - (base + 1)
+    w3 = (1.0 / 6.0) * w * w * w
+    w0 = (1.0 / 6.0) + 0.5 * w * (w - 1.0) - w3
+    w2 = w + w0 - 2.0 * w3
+    w1 = 1.0 - w0 - w2 - w3
+    out = 0
+    shape = [1] * c.ndim
+    shape[axis] = len(pos)
+    for k, wk in enumerate((w0, w1, w2, w3)):
+        idx = base + k
+        if N == 1:
+            idx = np.zeros_like(idx)
+        else:                                               # mirror boundary conditions, period 2N - 2
+            L2 = 2 * N - 2
+            idx = np.where(idx < 0, -idx - L2 * ((-idx) // L2), idx - L2 * (idx // L2))
+            idx = np.where(idx >= N, L2 - idx, idx)
+        out = out + np.take(c, idx, axis=axis) * wk.reshape(shape)
+    return out
+
+
+def resampleImage(image, mask, **kwargs):
+    """Resamples image (cubic B-spline; `interpolator: sitkNearestNeighbor | sitkLinear` also understood) and mask
+    (nearest neighbour) onto the grid of spacing `resampledPixelSpacing` aligned to the input origin, restricted to the
+    ROI bounding box + `padDistance` (imageoperations.py:448-612).  Image and mask must share one grid (the reference
+    additionally accepts differing geometries through ITK's physical-space transforms)."""
+    img, msk = as_image(image), as_image(mask)
+    if img.shape != msk.shape or not np.allclose(img.spacing, msk.spacing) or not np.allclose(img.origin, msk.origin):
+        raise NotImplementedError("resampleImage needs image and mask on the same grid")
+    new = np.array(kwargs["resampledPixelSpacing"], dtype=float)
+    interpolator = kwargs.get("interpolator", "sitkBSpline")
+    pad = kwargs.get("padDistance", 5)
+    label = int(kwargs.get("label", 1))
+    old = np.array(msk.spacing)
+    nd = len(old)
+    if len(new) != nd:
+        raise AssertionError("Wrong dimensionality (%d-D) of resampledPixelSpacing!, %d-D required" % (len(new), nd))
+    new = np.where(new == 0, old, new)
+    lo, hi = boundingBox(msk.array == label)
+    lo, size = lo[::-1], (hi - lo + 1)[::-1]                # (x, y, z) like SimpleITK
+    new = np.where(size != 1, new, old)
+    if np.allclose(old, new):                               # nothing to interpolate: plain crop (:527-546)
+        return cropToTumorMask(img, msk, label)
+    ratio = old / new
+    fullsize = np.array(msk.GetSize())
+    L = np.floor((lo - 0.5) * ratio - pad)
+    U = np.ceil((lo + size - 0.5) * ratio + pad)
+    maxU = np.ceil(fullsize * ratio) - 1
+    L = np.where(L < 0, 0, L)
+    U = np.where(U > maxU, maxU, U)
+    newsize = np.array(U - L + 1, dtype=int)
+    start = 0.5 * (new - old) / old + L / ratio             # continuous input index of output voxel 0
+    pos = [start[d] + np.arange(newsize[d]) * (new[d] / old[d]) for d in range(nd)]
+    inside = None
+    for d in range(nd):                                     # ImageFunction::IsInsideBuffer on the continuous index
+        ok = (pos[d] >= -0.5) & (pos[d] < fullsize[d] - 0.5)
+        shape = [1] * nd
+        shape[nd - 1 - d] = len(ok)
+        inside = ok.reshape(shape) if inside is None else inside & ok.reshape(shape)
+    src = img.array
+    if str(interpolator) in ("sitkBSpline", "3"):
+        c = src.astype(np.float64)
+        for d in range(nd):                                 # ITK filters dimension 0 (x) first
+            c = _bspline_decompose_axis(c, nd - 1 - d)
+        val = c
+        for d in range(nd):
+            val = _bspline_interp_axis(val, nd - 1 - d, pos[d])
+    elif str(interpolator) in ("sitkLinear", "2"):
+        val = src.astype(np.float64)
+        for d in range(nd):
+            ax, N = nd - 1 - d, src.shape[nd - 1 - d]
+            b = np.floor(pos[d]).astype(np.int64)
+            f = pos[d] - b
+            shape = [1] * nd
+            shape[ax] = len(f)
+            val = (np.take(val, np.clip(b, 0, N - 1), axis=ax) * (1 - f).reshape(shape)
+                   + np.take(val, np.clip(b + 1, 0, N - 1), axis=ax) * f.reshape(shape))
+    elif str(interpolator) in ("sitkNearestNeighbor", "1"):
+        val = src[np.ix_(*[np.clip(np.floor(pos[d] + 0.5).astype(int), 0, fullsize[d] - 1) for d in range(nd - 1, -1, -1)])]
+    else:
+        raise NotImplementedError("interpolator %r" % (interpolator,))
+    if np.issubdtype(src.dtype, np.integer):                # CastPixelWithBoundsChecking: clamp, then a C cast
+        info = np.iinfo(src.dtype)
+        val = np.trunc(np.clip(val, info.min, info.max))
+    out = np.where(inside, val, 0).astype(src.dtype)
+    near = [np.clip(np.floor(pos[d] + 0.5).astype(int), 0, fullsize[d] - 1) for d in range(nd)]
+    m = np.where(inside, msk.array[np.ix_(*near[::-1])], 0).astype(msk.array.dtype)
+    dirm = np.array(msk.direction, dtype=float).reshape(nd, nd)
+    origin = tuple(np.array(msk.origin) + dirm @ (old * start))
+    return Image(out, tuple(new), origin, msk.direction), Image(m, tuple(new), origin, msk.direction)
+
+
 def normalizeImage(image, **kwargs):
     """f(x) = scale * (x - mean) / sigma over ALL voxels of the image (imageoperations.py:615-654: sitk.Normalize, i.e.
     float64 output and the N - 1 standard deviation -- pinned by the reference's `_normalization` golden vectors),

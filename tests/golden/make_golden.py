@@ -9,8 +9,9 @@ missing large blobs) this stores, per case, in tests/golden/<case>.npz:
     P_glcm .. P_ngtdm  the reference's golden matrices data/baseline/<case>_<class>.npy  (tests/test_matrices.py:35-65)
 and in tests/golden/baseline_features.json the reference's golden feature values
 data/baseline/baseline_<class>.csv (tests/test_features.py) for the configurations that need no SimpleITK-only
-preprocessing (default, _2d, _FBN, _combined, _flatRegion, _resegmentation, _normalization), together with their
-settings.
+preprocessing (default, _2d, _FBN, _combined, _flatRegion, _resegmentation, _normalization, _resampling), together with
+their settings.  The whole NRRD pairs of brain1 and breast1 are copied to tests/golden/data for the tests that need the
+full grid (resampling, extractor, CLI).
 
 Nothing here is reference SOURCE; these are its test vectors."""
 import ast
@@ -29,11 +30,12 @@ from pyradiomics_amd.image import read_nrrd  # noqa: E402
 REF = os.environ.get("REFERENCE", "/root/reference")
 CASES = ["brain1", "brain2", "breast1"]
 CLASSES = ["glcm", "glrlm", "glszm", "gldm", "ngtdm"]
-CONFIG_SUFFIXES = ["", "_2d", "_FBN", "_combined", "_flatRegion", "_resegmentation", "_normalization"]
+CONFIG_SUFFIXES = ["", "_2d", "_FBN", "_combined", "_flatRegion", "_resegmentation", "_normalization", "_resampling"]
+FULL_IMAGES = ["brain1", "breast1"]      # whole NRRD pairs kept under tests/golden/data (resampling needs the full grid)
 FEATURE_CLASSES = CLASSES + ["firstorder"]      # golden feature values only (first order has no matrix)
 KEEP = ("binWidth", "binCount", "force2D", "force2Ddimension", "distances", "weightingNorm", "symmetricalGLCM",
         "gldm_a", "label", "resegmentRange", "resegmentMode", "voxelArrayShift", "normalize", "normalizeScale",
-        "removeOutliers")
+        "removeOutliers", "resampledPixelSpacing", "interpolator", "padDistance")
 
 
 def main():
@@ -55,6 +57,14 @@ def main():
             out["P_" + cls] = np.load(os.path.join(REF, "data", "baseline", "%s_%s.npy" % (case, cls)))
         np.savez_compressed(os.path.join(HERE, case + ".npz"), **out)
         print(case, out["image"].shape, out["image"].dtype, int(m.sum()), "voxels")
+    import shutil
+    os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
+    for case in FULL_IMAGES:
+        for kind in ("image", "label"):
+            dst = os.path.join(HERE, "data", "%s_%s.nrrd" % (case, kind))
+            if not os.path.exists(dst):
+                shutil.copyfile(os.path.join(REF, "data", "%s_%s.nrrd" % (case, kind)), dst)
+                os.chmod(dst, 0o644)
     for cls in FEATURE_CLASSES:
         rows = list(csv.reader(open(os.path.join(REF, "data", "baseline", "baseline_%s.csv" % cls))))
         hdr = rows[0]

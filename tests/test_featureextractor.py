@@ -53,6 +53,45 @@ def test_extractor_normalization_on_oracle_backend(oracle_port):
         backend.set(old)
 
 
+def test_extractor_resampling_on_oracle_backend(oracle_port):
+    """resampledPixelSpacing [2, 2, 2] with the B-spline interpolator through the extractor on whole NRRD pairs against
+    the reference's `_resampling` golden vectors: pins the restated ITK resampling arithmetic end to end"""
+    from pyradiomics_amd import backend
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    old = backend._cmatrices
+    backend.set(oracle_port)
+    try:
+        for case in ("brain1", "breast1"):
+            img, lbl = os.path.join(GOLDEN, "data", case + "_image.nrrd"), os.path.join(GOLDEN, "data", case + "_label.nrrd")
+            res = RadiomicsFeatureExtractor(resampledPixelSpacing=[2, 2, 2], interpolator="sitkBSpline", padDistance=5).execute(img, lbl)
+            want = load_baseline_features()[case + "_resampling"]["features"]
+            for cls in want:
+                for name, ref in want[cls].items():
+                    val = float(res["original_%s_%s" % (cls, name)])
+                    assert abs(val - ref) <= 1e-6 * abs(ref), (case, cls, name, val, ref)
+    finally:
+        backend.set(old)
+
+
+def test_resample_nearest_linear_and_in_plane_only():
+    from pyradiomics_amd import imageoperations
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(4)
+    arr = rng.integers(0, 1000, (6, 20, 24)).astype(np.int16)
+    msk = np.zeros(arr.shape, dtype=np.int16)
+    msk[2:5, 5:15, 6:20] = 1
+    image, mask = Image(arr, (1.0, 1.0, 3.0)), Image(msk, (1.0, 1.0, 3.0))
+    for interp in ("sitkNearestNeighbor", "sitkLinear", "sitkBSpline"):
+        ri, rm = imageoperations.resampleImage(image, mask, resampledPixelSpacing=[2, 2, 0], interpolator=interp, padDistance=2)
+        assert ri.spacing == (2.0, 2.0, 3.0) and ri.array.shape == rm.array.shape and ri.array.dtype == np.int16
+        assert ri.array.shape[0] == arr.shape[0] or ri.array.shape[0] <= arr.shape[0]      # z is left alone
+        assert rm.array.max() == 1 and ri.array.min() >= -500 and ri.array.max() <= 1500
+    same, samem = imageoperations.resampleImage(image, mask, resampledPixelSpacing=[1, 1, 3])
+    assert same.array.shape == (3, 10, 14) and np.array_equal(same.array, arr[2:5, 5:15, 6:20])   # equal spacing: a crop
+    with pytest.raises(AssertionError):
+        imageoperations.resampleImage(image, mask, resampledPixelSpacing=[2, 2])
+
+
 def test_extractor_params_dict_and_names():
     from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
     ex = RadiomicsFeatureExtractor({"setting": {"binWidth": 25, "force2D": True},
