@@ -1,5 +1,5 @@
 """`RadiomicsFeatureExtractor`: the orchestration API of the reference's radiomics/featureextractor.py for the
-path this package accelerates -- image types Original / Wavelet / LoG, feature classes firstorder / glcm / glrlm /
+path this package accelerates -- image types Original / Wavelet / LoG / Square / SquareRoot / Logarithm / Exponential, feature classes firstorder / glcm / glrlm /
 glszm / gldm / ngtdm, segment-based and voxel-based extraction -- without SimpleITK / pykwalify (not installed on the build and
 GPU hosts).  Same constructor forms (parameter file, dict, or keyword settings), the same enable*/disable* methods,
 the same `execute(image, mask, label=None, voxelBased=False)` returning an OrderedDict keyed
@@ -24,7 +24,9 @@ from .image import Image, as_array, as_image, read_image
 logger = logging.getLogger(__name__)
 
 _FEATURE_CLASSES = ("firstorder", "glcm", "gldm", "glrlm", "glszm", "ngtdm")     # the reference's (alphabetical) order
-_IMAGE_TYPES = {"Original": filters.getOriginalImage, "Wavelet": filters.getWaveletImage, "LoG": filters.getLoGImage}
+_IMAGE_TYPES = {"Original": filters.getOriginalImage, "Wavelet": filters.getWaveletImage, "LoG": filters.getLoGImage,
+                "Square": filters.getSquareImage, "SquareRoot": filters.getSquareRootImage,
+                "Logarithm": filters.getLogarithmImage, "Exponential": filters.getExponentialImage}
 
 
 def getFeatureClasses():

@@ -171,6 +171,50 @@ def getLoGImage(inputImage, inputMask, **kwargs):
             logger.warning("applyLoG: sigma must be greater than 0.0: %s", sigma)
 
 
+# ---- intensity transforms (imageoperations.py:973-1073): explicit numpy formulas in the reference, evaluated here with
+# ---- the same float64 operations on whichever side the image lives ------------------------------------------------
+def _elementwise(inputImage, name, fn, **kwargs):
+    ref = as_image(inputImage)
+    if kwargs.get("deviceResident", True):
+        import torch
+        x = ref.device_tensor().to(torch.float64)
+        return ref.like(tensor=fn(x, torch)), name, kwargs
+    return ref.like(fn(ref.array.astype(np.float64), np)), name, kwargs
+
+
+def getSquareImage(inputImage, inputMask, **kwargs):
+    """f(x) = (c x)^2, c = 1 / sqrt(max |x|)  (imageoperations.py:973-994)"""
+    def fn(x, xp):
+        c = 1 / xp.sqrt(xp.abs(x).max())
+        return (c * x) ** 2
+    yield _elementwise(inputImage, "square", fn, **kwargs)
+
+
+def getSquareRootImage(inputImage, inputMask, **kwargs):
+    """f(x) = sign(x) sqrt(|x| c), c = max |x|  (imageoperations.py:997-1021)"""
+    def fn(x, xp):
+        c = xp.abs(x).max()
+        return xp.sign(x) * xp.sqrt(xp.abs(x) * c)
+    yield _elementwise(inputImage, "squareroot", fn, **kwargs)
+
+
+def getLogarithmImage(inputImage, inputMask, **kwargs):
+    """f(x) = sign(x) c log(|x| + 1), c = max |x| / max |log(|x| + 1)|  (imageoperations.py:1024-1049)"""
+    def fn(x, xp):
+        top = xp.abs(x).max()
+        y = xp.sign(x) * xp.log(xp.abs(x) + 1)
+        return y * (top / xp.abs(y).max())
+    yield _elementwise(inputImage, "logarithm", fn, **kwargs)
+
+
+def getExponentialImage(inputImage, inputMask, **kwargs):
+    """f(x) = exp(c x), c = log(max |x|) / max |x|  (imageoperations.py:1052-1073)"""
+    def fn(x, xp):
+        top = xp.abs(x).max()
+        return xp.exp((xp.log(top) / top) * x)
+    yield _elementwise(inputImage, "exponential", fn, **kwargs)
+
+
 def getOriginalImage(inputImage, inputMask, **kwargs):
     """imageoperations.py:745-753"""
     yield inputImage, "original", kwargs

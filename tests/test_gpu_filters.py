@@ -103,3 +103,27 @@ def test_device_resident_filters_equal_host_route():
         assert np.array_equal(dev[k].cpu().numpy(), host[k])
     a = engine.log_image(torch.from_numpy(x).cuda(), (1.0, 1.0, 2.5), 2.0).cpu().numpy()
     assert np.array_equal(a, filters.laplacian_recursive_gaussian(x, (1.0, 1.0, 2.5), 2.0))
+
+
+@pytest.mark.gpu
+def test_intensity_transform_image_types_follow_the_reference_formulas():
+    """Square / SquareRoot / Logarithm / Exponential (imageoperations.py:973-1073) on the device against the
+    reference's numpy expressions written out literally"""
+    from pyradiomics_amd import filters
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(2)
+    arr = rng.integers(-300, 1200, (6, 9, 11)).astype(np.int16)
+    im = arr.astype("float64")
+    want = {}
+    want["square"] = ((1 / np.sqrt(np.max(np.abs(im)))) * im) ** 2
+    t = im.copy(); c = np.max(np.abs(t)); t[t > 0] = np.sqrt(t[t > 0] * c); t[t < 0] = -np.sqrt(-t[t < 0] * c)
+    want["squareroot"] = t
+    t = im.copy(); top = np.max(np.abs(t)); t[t > 0] = np.log(t[t > 0] + 1); t[t < 0] = -np.log(-(t[t < 0] - 1))
+    want["logarithm"] = t * (top / np.max(np.abs(t)))
+    top = np.max(np.abs(im))
+    want["exponential"] = np.exp((np.log(top) / top) * im)
+    for fn in (filters.getSquareImage, filters.getSquareRootImage, filters.getLogarithmImage, filters.getExponentialImage):
+        for dev in (True, False):
+            (out, name, _kw), = list(fn(Image(arr), None, deviceResident=dev))
+            np.testing.assert_allclose(out.array, want[name], rtol=1e-14, atol=1e-12, err_msg=name)
+            assert out.on_device == dev
