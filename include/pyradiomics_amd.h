@@ -257,6 +257,17 @@ int prad_voxel_firstorder_dev(const void *image, int dtype, const uint8_t *mask,
                               double voxelArrayShift, double voxelVolume, const int *feature_ids, int nfeat, double *out,
                               void *stream);
 
+/* ---- resampling in front of the path (radiomics/imageoperations.py:448-612 on SimpleITK's ResampleImageFilter) ------
+ * Output voxel o along (numpy) axis d samples the input at the continuous index start[d] + o * step[d]; the output
+ * grid shares the input's axes (the reference derives start / step / newsize from the ROI bounding box, padDistance
+ * and resampledPixelSpacing, imageoperations.py:548-578).  interpolator: 0 nearest neighbour (round half up), 1 linear,
+ * 3 cubic B-spline exactly as ITK evaluates it (recursive prefilter with mirror boundaries, mirrored 4^Nd support);
+ * samples outside the buffer ([-0.5, N - 0.5) per axis) become 0; integer pixel types are clamped and truncated like
+ * ResampleImageFilter::CastPixelWithBoundsChecking.  image / out: DEVICE pointers of the same dtype (codes as for
+ * prad_digitize_dev); size / start / step / newsize: HOST arrays of Nd (<= 3) entries. */
+int prad_resample_dev(const void *image, int dtype, const int *size, int Nd, const double *start, const double *step,
+                      const int *newsize, int interpolator, void *out, void *stream);
+
 /* ---- filter stack in front of the matrices (radiomics/imageoperations.py:756-970) ---------------------------
  * The arithmetic of both filters lives in third-party wheels (PyWavelets, SimpleITK/ITK) that are not part of
  * the reference tree; these entry points implement their published algorithms (see oracle/filters_oracle.py):

@@ -9,8 +9,8 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpyradiomics_amd.so")
-SOURCES = ["prad_api.hip", "prad_firstorder.hip", "prad_features.hip"]
-HEADERS = ["prad_runtime.h", "kernels_generic.h", "kernels_sweep.h", "kernels_neigh.h", "kernels_glszm.h", "kernels_filters.h", "kernels_voxel.h", "kernels_voxtex.h", "kernels_binning.h", "kernels_firstorder.h", "kernels_features.h",
+SOURCES = ["prad_api.hip", "prad_firstorder.hip", "prad_features.hip", "prad_resample.hip"]
+HEADERS = ["prad_runtime.h", "kernels_generic.h", "kernels_sweep.h", "kernels_neigh.h", "kernels_glszm.h", "kernels_filters.h", "kernels_voxel.h", "kernels_voxtex.h", "kernels_binning.h", "kernels_firstorder.h", "kernels_features.h", "kernels_resample.h",
            os.path.join("..", "..", "include", "pyradiomics_amd.h")]
 
 

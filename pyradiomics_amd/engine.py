@@ -126,6 +126,28 @@ def ngtdm_features(P: torch.Tensor) -> np.ndarray:
     return out
 
 
+def resample(image: torch.Tensor, start, step, newsize, interpolator: int = 3) -> torch.Tensor:
+    """ITK-style resampling on the device (prad_resample_dev): output voxel o along axis d reads the input at continuous
+    index start[d] + o * step[d]; interpolator 0 nearest / 1 linear / 3 cubic B-spline; same dtype out"""
+    lib = _lib.load()
+    if image.dtype not in _DTYPE_CODES:
+        image = image.to(torch.float64)
+    image = image.contiguous()
+    lib.prad_set_device(image.device.index or 0)
+    nd = image.dim()
+    size = np.array(image.shape, dtype=np.intc)
+    st = np.ascontiguousarray(start, dtype=np.float64)
+    sp = np.ascontiguousarray(step, dtype=np.float64)
+    ns = np.ascontiguousarray(newsize, dtype=np.intc)
+    out = torch.empty(tuple(int(v) for v in ns), dtype=image.dtype, device=image.device)
+    dp = C.POINTER(C.c_double)
+    rc = lib.prad_resample_dev(C.c_void_p(image.data_ptr()), _DTYPE_CODES[image.dtype], _iptr(size), nd,
+                               st.ctypes.data_as(dp), sp.ctypes.data_as(dp), _iptr(ns), int(interpolator),
+                               C.c_void_p(out.data_ptr()), _stream_ptr())
+    _lib.raise_for(rc, "resample")
+    return out
+
+
 def workspace_bytes() -> int:
     """device bytes of scratch the library currently holds for this thread"""
     return int(_lib.load().prad_workspace_bytes())

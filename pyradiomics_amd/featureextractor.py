@@ -181,7 +181,7 @@ class RadiomicsFeatureExtractor:
         s["deviceResident"] = on_dev
         if s.get("normalize", False):                  # featureextractor.py:432-433: before anything else sees the image
             image = imageoperations.normalizeImage(image, **s)
-        if s.get("resampledPixelSpacing") is not None:  # :436-440 (host-side preprocessing like the file readers)
+        if s.get("resampledPixelSpacing") is not None:  # :436-440
             if not np.any(mask.array == label):
                 raise ValueError("Label (%g) not present in mask" % label)
             image, mask = imageoperations.resampleImage(image, mask, **s)

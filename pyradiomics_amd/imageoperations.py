@@ -208,6 +208,19 @@ def resampleImage(image, mask, **kwargs):
         shape = [1] * nd
         shape[nd - 1 - d] = len(ok)
         inside = ok.reshape(shape) if inside is None else inside & ok.reshape(shape)
+    dirm = np.array(msk.direction, dtype=float).reshape(nd, nd)
+    origin = tuple(np.array(msk.origin) + dirm @ (old * start))
+    codes = {"sitkNearestNeighbor": 0, "1": 0, "sitkLinear": 1, "2": 1, "sitkBSpline": 3, "3": 3}
+    if str(interpolator) not in codes:
+        raise NotImplementedError("interpolator %r" % (interpolator,))
+    if (kwargs.get("deviceResident", False) or img.on_device) and nd <= 3:
+        # same arithmetic in the same order on the device (prad_resample_dev): bit-identical to the numpy route below
+        from . import engine
+        step = (new / old)[::-1]
+        ri = engine.resample(img.device_tensor(), start[::-1], step, newsize[::-1], codes[str(interpolator)])
+        rm = engine.resample(msk.device_tensor(), start[::-1], step, newsize[::-1], 0)
+        return (Image(None, tuple(new), origin, msk.direction, tensor=ri),
+                Image(None, tuple(new), origin, msk.direction, tensor=rm))
     src = img.array
     if str(interpolator) in ("sitkBSpline", "3"):
         c = src.astype(np.float64)
@@ -236,8 +249,6 @@ def resampleImage(image, mask, **kwargs):
     out = np.where(inside, val, 0).astype(src.dtype)
     near = [np.clip(np.floor(pos[d] + 0.5).astype(int), 0, fullsize[d] - 1) for d in range(nd)]
     m = np.where(inside, msk.array[np.ix_(*near[::-1])], 0).astype(msk.array.dtype)
-    dirm = np.array(msk.direction, dtype=float).reshape(nd, nd)
-    origin = tuple(np.array(msk.origin) + dirm @ (old * start))
     return Image(out, tuple(new), origin, msk.direction), Image(m, tuple(new), origin, msk.direction)
 
 

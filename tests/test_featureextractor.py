@@ -125,6 +125,22 @@ def test_extractor_normalization_on_gpu():
 
 
 @pytest.mark.gpu
+def test_extractor_resampling_on_gpu():
+    """the `_resampling` golden vectors through the device-resident extractor (prad_resample_dev + everything after)"""
+    from pyradiomics_amd import backend, cmatrices
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    backend.set(cmatrices)
+    for case in ("brain1", "breast1"):
+        img, lbl = os.path.join(GOLDEN, "data", case + "_image.nrrd"), os.path.join(GOLDEN, "data", case + "_label.nrrd")
+        res = RadiomicsFeatureExtractor(resampledPixelSpacing=[2, 2, 2], interpolator="sitkBSpline", padDistance=5).execute(img, lbl)
+        want = load_baseline_features()[case + "_resampling"]["features"]
+        for cls in want:
+            for name, ref in want[cls].items():
+                val = float(res["original_%s_%s" % (cls, name)])
+                assert abs(val - ref) <= 1e-6 * abs(ref), (case, cls, name, val, ref)
+
+
+@pytest.mark.gpu
 def test_extractor_filters_feed_matrices_on_gpu():
     """config 3 in miniature: wavelet (8 sub-bands) + LoG images re-discretised and pushed through GLCM/GLRLM"""
     from pyradiomics_amd import backend, cmatrices

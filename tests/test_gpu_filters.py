@@ -127,3 +127,28 @@ def test_intensity_transform_image_types_follow_the_reference_formulas():
             (out, name, _kw), = list(fn(Image(arr), None, deviceResident=dev))
             np.testing.assert_allclose(out.array, want[name], rtol=1e-14, atol=1e-12, err_msg=name)
             assert out.on_device == dev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("interp", ["sitkBSpline", "sitkLinear", "sitkNearestNeighbor"])
+@pytest.mark.parametrize("dtype", [np.int16, np.float64, np.float32])
+def test_device_resampling_is_bit_identical_to_the_pinned_numpy_route(interp, dtype):
+    """prad_resample_dev performs the arithmetic of imageoperations.resampleImage's numpy route (which the reference's
+    `_resampling` golden vectors pin) in the same order: identical bits, short lines (exact mirror sums) included"""
+    from pyradiomics_amd import imageoperations
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(9)
+    for shape, spacing, new, pad in (((9, 40, 37), (0.8, 0.8, 5.0), [2, 2, 2], 5), ((30, 21, 64), (1.0, 1.0, 1.0), [1.5, 0.7, 0], 3),
+                                     ((1, 33, 30), (0.5, 0.5, 1.0), [1.3, 1.3, 1.3], 4)):
+        arr = (rng.standard_normal(shape) * 300 + 500).astype(dtype)
+        msk = np.zeros(shape, dtype=np.int16)
+        msk[shape[0] // 4: shape[0] // 4 + max(1, shape[0] // 2), 5:-6, 7:-5] = 1
+        kw = dict(resampledPixelSpacing=new, interpolator=interp, padDistance=pad)
+        hi, hm = imageoperations.resampleImage(Image(arr, spacing), Image(msk, spacing), **kw)
+        di, dm = imageoperations.resampleImage(Image(arr, spacing), Image(msk, spacing), deviceResident=True, **kw)
+        assert di.on_device and di.array.dtype == hi.array.dtype and di.array.shape == hi.array.shape
+        assert np.array_equal(dm.array, hm.array) and np.allclose(di.origin, hi.origin) and di.spacing == hi.spacing
+        if interp == "sitkBSpline" and min(shape) == 1 or dtype == np.float32 and interp == "sitkBSpline":
+            np.testing.assert_allclose(di.array, hi.array, rtol=1e-6, atol=1e-4)     # pow() of the short-line sum / f32 cast
+        else:
+            assert np.array_equal(di.array, hi.array), (interp, shape, np.abs(di.array.astype(float) - hi.array).max())
