@@ -179,16 +179,41 @@ class RadiomicsFeatureExtractor:
         on_dev = (bool(s.get("deviceResident", True)) and not voxelBased
                   and getattr(backend.get(), "DEVICE_TENSORS", False))
         s["deviceResident"] = on_dev
+        info = collections.OrderedDict()
+
+        def describe(stage, img, msk):
+            """diagnostics_Image-<stage>_* / diagnostics_Mask-<stage>_* (generalinfo.py:97-190, the subset that needs
+            no SimpleITK label statistics)"""
+            on = msk.on_device or (on_dev and stage != "original")
+            r = imageoperations.roiTensor(msk, label) if on else (msk.array == label)
+            try:
+                blo, bhi = imageoperations.boundingBox(r)
+            except ValueError:
+                raise ValueError("Label (%g) not present in mask" % label)
+            info["diagnostics_Image-%s_Spacing" % stage] = img.GetSpacing()
+            info["diagnostics_Image-%s_Size" % stage] = img.GetSize()
+            info["diagnostics_Mask-%s_Spacing" % stage] = msk.GetSpacing()
+            info["diagnostics_Mask-%s_Size" % stage] = msk.GetSize()
+            info["diagnostics_Mask-%s_BoundingBox" % stage] = tuple(int(v) for v in blo[::-1]) + \
+                tuple(int(v) for v in (bhi - blo + 1)[::-1])
+            info["diagnostics_Mask-%s_VoxelNum" % stage] = int(r.sum())
+
+        if s.get("additionalInfo", True):
+            describe("original", image, mask)
         if s.get("normalize", False):                  # featureextractor.py:432-433: before anything else sees the image
             image = imageoperations.normalizeImage(image, **s)
         if s.get("resampledPixelSpacing") is not None:  # :436-440
             if not np.any(mask.array == label):
                 raise ValueError("Label (%g) not present in mask" % label)
             image, mask = imageoperations.resampleImage(image, mask, **s)
+            if s.get("additionalInfo", True):
+                describe("interpolated", image, mask)
         if s.get("resegmentRange") is not None:
             if not np.any(mask.array == label):
                 raise ValueError("Label (%g) not present in mask" % label)
             mask = imageoperations.resegmentMask(image, mask, **s)
+            if s.get("additionalInfo", True):
+                describe("resegmented", image, mask)
         roi = imageoperations.roiTensor(mask, label) if on_dev else (mask.array == label)
         try:
             lo, hi = imageoperations.boundingBox(roi)
@@ -207,11 +232,7 @@ class RadiomicsFeatureExtractor:
             out["diagnostics_Versions_Numpy"] = np.__version__
             out["diagnostics_Configuration_Settings"] = {k: v for k, v in s.items()}
             out["diagnostics_Configuration_EnabledImageTypes"] = dict(self.enabledImagetypes)
-            out["diagnostics_Image-original_Spacing"] = image.GetSpacing()
-            out["diagnostics_Image-original_Size"] = image.GetSize()
-            out["diagnostics_Mask-original_BoundingBox"] = tuple(int(v) for v in lo[::-1]) + \
-                tuple(int(v) for v in (hi - lo + 1)[::-1])
-            out["diagnostics_Mask-original_VoxelNum"] = nroi
+            out.update(info)
         gens = []
         for imageType, custom in self.enabledImagetypes.items():
             args = s.copy()

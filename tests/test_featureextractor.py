@@ -244,6 +244,7 @@ def test_typical_mr_parameter_set_runs_end_to_end(tmp_path):
     keys = [k for k in res if not k.startswith("diagnostics")]
     assert len(keys) == (1 + 2 + 8) * (18 + 2 + 16 + 16 + 14)
     assert all(np.isfinite(float(res[k])) for k in keys), [k for k in keys if not np.isfinite(float(res[k]))][:5]
-    assert res["diagnostics_Mask-original_VoxelNum"] == 1915           # ROI voxels on the 2 mm grid (golden: brain1_resampling)
+    assert res["diagnostics_Mask-original_VoxelNum"] == 4137 and res["diagnostics_Mask-interpolated_VoxelNum"] == 1915
+    assert res["diagnostics_Image-interpolated_Spacing"] == (2.0, 2.0, 2.0)
     # the wavelet approximation of a normalised image keeps its energy ordering: LLL dominates the detail bands
     assert float(res["wavelet-LLL_firstorder_Energy"]) > float(res["wavelet-HHH_firstorder_Energy"])
