@@ -248,3 +248,20 @@ def test_typical_mr_parameter_set_runs_end_to_end(tmp_path):
     assert res["diagnostics_Image-interpolated_Spacing"] == (2.0, 2.0, 2.0)
     # the wavelet approximation of a normalised image keeps its energy ordering: LLL dominates the detail bands
     assert float(res["wavelet-LLL_firstorder_Energy"]) > float(res["wavelet-HHH_firstorder_Energy"])
+
+
+def test_precrop_leaves_original_image_features_unchanged(oracle_port):
+    """preCrop only changes what filters see: Original-image features are those of the uncropped run"""
+    from pyradiomics_amd import backend
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    old = backend._cmatrices
+    backend.set(oracle_port)
+    try:
+        kw = dict(binWidth=25)
+        a = RadiomicsFeatureExtractor({"setting": dict(kw), "featureClass": {"glcm": None, "firstorder": None}}).execute(IMG, LBL)
+        b = RadiomicsFeatureExtractor({"setting": dict(kw, preCrop=True, padDistance=3), "featureClass": {"glcm": None, "firstorder": None}}).execute(IMG, LBL)
+        for k in a:
+            if not k.startswith("diagnostics"):
+                assert float(a[k]) == float(b[k]), k
+    finally:
+        backend.set(old)
