@@ -22,17 +22,35 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """compiles the translation units concurrently (no device code crosses a unit: no -fgpu-rdc), then links"""
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wall", "-Wno-unused-function"] + SOURCES + ["-o", LIB + ".tmp"]
-    out = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+    objdir = os.path.join(CSRC, ".obj")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        jobs.append((cmd, obj, subprocess.Popen(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    log = []
+    for cmd, obj, proc in jobs:
+        out, _ = proc.communicate()
+        log.append(" ".join(cmd) + "\n" + out)
+        if proc.returncode != 0:
+            for _c, _o, other in jobs:
+                if other.poll() is None:
+                    other.kill()
+            raise RuntimeError("hipcc failed:\n%s" % log[-1])
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [obj for _c, obj, _p in jobs] + ["-o", LIB + ".tmp"]
+    out = subprocess.run(link, cwd=CSRC, capture_output=True, text=True)
     if out.returncode != 0:
-        raise RuntimeError("hipcc failed:\n%s\n%s" % (" ".join(cmd), out.stdout + out.stderr))
+        raise RuntimeError("hipcc link failed:\n%s\n%s" % (" ".join(link), out.stdout + out.stderr))
     os.replace(LIB + ".tmp", LIB)
     if verbose:
-        print(" ".join(cmd))
+        print("\n".join(log))
+        print(" ".join(link))
         print(out.stdout + out.stderr)
     return LIB
 
