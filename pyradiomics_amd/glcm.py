@@ -71,16 +71,28 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
         names = [n for n, on in self.enabledFeatures.items() if on]
         if (self.voxelBased and voxelCoordinates is not None and fused is not None and names
                 and self.settings.get("fusedVoxel", True) and self.weightingNorm is None):
+            covered = getattr(self.cMatrices, "VOXEL_GLCM_FEATURES", names)
+            dev_names = [n for n in names if n in covered]
+            rest = [n for n in names if n not in covered]          # MCC (and deprecated names, which only raise)
             try:
                 vals = fused(self.imageArray, self.maskArray, np.array(self.settings.get("distances", [1])),
                              self.coefficients["Ng"], self.settings.get("force2D", False),
                              self.settings.get("force2Ddimension", 0), self.settings.get("kernelRadius", 1),
-                             voxelCoordinates, names, self.symmetricalGLCM)
+                             voxelCoordinates, dev_names, self.symmetricalGLCM) if dev_names else {}
             except NotImplementedError:
                 vals = None
             if vals is not None:
+                if rest:                                           # only these take the per-kernel matrix route
+                    self._initHostOnly(voxelCoordinates)
                 for n in names:
-                    yield True, n, vals[n]
+                    if n in vals:
+                        yield True, n, vals[n]
+                    else:
+                        try:
+                            yield True, n, getattr(self, "get%sFeatureValue" % n)()
+                        except DeprecationWarning as dw:
+                            self.logger.warning("Feature %s is deprecated: %s", n, dw)
+                            yield False, n, np.nan
                 return
         yield from super()._calculateFeatures(voxelCoordinates)
 

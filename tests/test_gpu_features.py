@@ -203,3 +203,26 @@ def test_segment_features_kernels_on_degenerate_matrices():
     P[1, 2] = 5
     z, e = engine.zone_matrix_features(P, np.arange(1, 7))
     assert not e[0] and z[0, 0] == pytest.approx(1 / 9) and z[0, 6] == pytest.approx(1 / 3) and z[0, 9] == pytest.approx(0, abs=1e-12)
+
+
+def test_voxel_glcm_with_mcc_keeps_the_fused_kernel_for_the_other_features():
+    """MCC is the one GLCM feature without a fused evaluation: requesting it must not push the other 23 onto the
+    per-kernel matrix route"""
+    from pyradiomics_amd import cmatrices, glcm
+    image, mask, _ = load_case("breast1")
+    kw = dict(binWidth=25, kernelRadius=1, maskedKernel=True, initValue=np.nan, voxelBased=True, label=1)
+    out = {}
+    for fused in (True, False):
+        fc = glcm.RadiomicsGLCM(image, mask, fusedVoxel=fused, **kw)
+        for n in ("MCC", "JointEntropy", "Contrast"):
+            fc.enableFeatureByName(n)
+        calls = []
+        orig = cmatrices.voxel_glcm_features
+        cmatrices.voxel_glcm_features = lambda *a, **k: (calls.append(a[8]), orig(*a, **k))[1]
+        try:
+            out[fused] = {k: v.array for k, v in fc.execute().items()}
+        finally:
+            cmatrices.voxel_glcm_features = orig
+        assert (calls == [["JointEntropy", "Contrast"]]) == fused
+    for n in out[True]:
+        np.testing.assert_allclose(out[True][n], out[False][n], rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=n)
