@@ -26,7 +26,8 @@ logger = logging.getLogger(__name__)
 _FEATURE_CLASSES = ("firstorder", "glcm", "gldm", "glrlm", "glszm", "ngtdm")     # the reference's (alphabetical) order
 _IMAGE_TYPES = {"Original": filters.getOriginalImage, "Wavelet": filters.getWaveletImage, "LoG": filters.getLoGImage,
                 "Square": filters.getSquareImage, "SquareRoot": filters.getSquareRootImage,
-                "Logarithm": filters.getLogarithmImage, "Exponential": filters.getExponentialImage}
+                "Logarithm": filters.getLogarithmImage, "Exponential": filters.getExponentialImage,
+                "Gradient": filters.getGradientImage}
 
 
 def getFeatureClasses():

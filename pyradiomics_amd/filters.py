@@ -215,6 +215,43 @@ def getExponentialImage(inputImage, inputMask, **kwargs):
     yield _elementwise(inputImage, "exponential", fn, **kwargs)
 
 
+def getGradientImage(inputImage, inputMask, **kwargs):
+    """Gradient magnitude (imageoperations.py:1076-1091 on sitk.GradientMagnitudeImageFilter): central differences
+    0.5 * (x[i+1] - x[i-1]) per axis with edge replication (ITK's ZeroFluxNeumann boundary), divided by the spacing
+    unless `gradientUseSpacing` is false, root of the sum of squares in float64, float32 output.  ITK arithmetic
+    restated from its documentation; no golden vector exists for this image type (parity unpinned)."""
+    ref = as_image(inputImage)
+    use_spacing = kwargs.get("gradientUseSpacing", True)
+    spacing = ref.GetSpacing()[::-1]                       # numpy axis order
+    if kwargs.get("deviceResident", True):
+        import torch
+        x = ref.device_tensor().to(torch.float64)
+        acc = torch.zeros_like(x)
+        for ax in range(x.dim()):
+            n = x.shape[ax]
+            if n == 1:
+                continue
+            idx = torch.arange(n, device=x.device)
+            d = 0.5 * (x.index_select(ax, (idx + 1).clamp(max=n - 1)) - x.index_select(ax, (idx - 1).clamp(min=0)))
+            if use_spacing:
+                d = d / spacing[ax]
+            acc += d * d
+        yield ref.like(tensor=torch.sqrt(acc).to(torch.float32)), "gradient", kwargs
+        return
+    x = ref.array.astype(np.float64)
+    acc = np.zeros_like(x)
+    for ax in range(x.ndim):
+        n = x.shape[ax]
+        if n == 1:
+            continue
+        idx = np.arange(n)
+        d = 0.5 * (np.take(x, np.minimum(idx + 1, n - 1), axis=ax) - np.take(x, np.maximum(idx - 1, 0), axis=ax))
+        if use_spacing:
+            d = d / spacing[ax]
+        acc += d * d
+    yield ref.like(np.sqrt(acc).astype(np.float32)), "gradient", kwargs
+
+
 def getOriginalImage(inputImage, inputMask, **kwargs):
     """imageoperations.py:745-753"""
     yield inputImage, "original", kwargs

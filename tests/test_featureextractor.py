@@ -100,7 +100,7 @@ def test_extractor_params_dict_and_names():
     assert ex.settings["force2D"] is True and ex.settings["padDistance"] == 5
     assert list(ex.enabledImagetypes) == ["Original", "LoG", "Wavelet"] and ex.enabledFeatures == {"glcm": ["JointEntropy"]}
     with pytest.raises(NotImplementedError):
-        RadiomicsFeatureExtractor({"imageType": {"Gradient": {}}})
+        RadiomicsFeatureExtractor({"imageType": {"LBP3D": {}}})
 
 
 @pytest.mark.gpu

@@ -152,3 +152,24 @@ def test_device_resampling_is_bit_identical_to_the_pinned_numpy_route(interp, dt
             np.testing.assert_allclose(di.array, hi.array, rtol=1e-6, atol=1e-4)     # pow() of the short-line sum / f32 cast
         else:
             assert np.array_equal(di.array, hi.array), (interp, shape, np.abs(di.array.astype(float) - hi.array).max())
+
+
+@pytest.mark.gpu
+def test_gradient_image_type():
+    from pyradiomics_amd import filters
+    from pyradiomics_amd.image import Image
+    z, y, x = np.meshgrid(np.arange(5.0), np.arange(7.0), np.arange(9.0), indexing="ij")
+    ramp = 2 * x - 3 * y + 0.5 * z                            # constant gradient (2, -3, 0.5) in index units
+    for dev in (True, False):
+        (g, name, _), = list(filters.getGradientImage(Image(ramp, (1.0, 1.0, 1.0)), None, deviceResident=dev))
+        assert name == "gradient" and g.array.dtype == np.float32
+        inner = g.array[1:-1, 1:-1, 1:-1]
+        np.testing.assert_allclose(inner, np.sqrt(4 + 9 + 0.25), rtol=1e-6)
+        assert g.array[0, 3, 4] == pytest.approx(np.sqrt(4 + 9 + 0.0625), rel=1e-6)      # replicated edge halves dz
+        (gs, _, _), = list(filters.getGradientImage(Image(ramp, (2.0, 1.0, 1.0)), None, deviceResident=dev))
+        np.testing.assert_allclose(gs.array[1:-1, 1:-1, 1:-1], np.sqrt(1 + 9 + 0.25), rtol=1e-6)   # x spacing 2 mm
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((4, 6, 8))
+    (d1, _, _), = list(filters.getGradientImage(Image(a, (0.7, 1.1, 2.0)), None, deviceResident=True))
+    (d2, _, _), = list(filters.getGradientImage(Image(a, (0.7, 1.1, 2.0)), None, deviceResident=False))
+    np.testing.assert_allclose(d1.array, d2.array, rtol=1e-6)
