@@ -463,8 +463,9 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
     }
   }
   PRAD_TRY(read_flags(k));
-  if (k.flags_h[2]) return fail(PRAD_E_HIP, "internal error: the sweep kernels' dynamic LDS does not start at address 0");
-  *used = (k.flags_h[0] == 0);
+  // flags[2]: the fused walker found its table away from LDS address 0 and did nothing (cannot happen with the current
+  // toolchain: the dynamic array is the kernels' only LDS object) -- let the generic kernels redo the call
+  *used = (k.flags_h[0] == 0 && k.flags_h[2] == 0);
   return PRAD_OK;
 }
 
