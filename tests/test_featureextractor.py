@@ -265,3 +265,31 @@ def test_precrop_leaves_original_image_features_unchanged(oracle_port):
                 assert float(a[k]) == float(b[k]), k
     finally:
         backend.set(old)
+
+
+@pytest.mark.gpu
+def test_two_dimensional_image_through_the_extractor():
+    """a 2-D slice (Nd = 2) as input: Original + Wavelet (4 sub-bands) + LoG, all six classes, device and host routes"""
+    from pyradiomics_amd import backend, cmatrices
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    from pyradiomics_amd.image import Image, read_nrrd
+    backend.set(cmatrices)
+    vol, lab = read_nrrd(IMG), read_nrrd(LBL)
+    sl = int(np.argmax((lab.array == 1).sum((1, 2))))
+    image, mask = Image(vol.array[sl], vol.spacing[:2]), Image(lab.array[sl], lab.spacing[:2])
+    params = {"setting": {"binWidth": 25}, "imageType": {"Original": {}, "Wavelet": {}, "LoG": {"sigma": [2.0]}}}
+    dev = RadiomicsFeatureExtractor(params).execute(image, mask)
+    keys = [k for k in dev if not k.startswith("diagnostics")]
+    assert sorted({k.split("_")[0] for k in keys}) == ["log-sigma-2-0-mm-3D", "original", "wavelet-HH", "wavelet-HL", "wavelet-LH", "wavelet-LL"]
+    assert len(keys) == 6 * (18 + 24 + 16 + 16 + 14 + 5) and all(np.isfinite(float(dev[k])) for k in keys)
+    params["setting"]["deviceResident"] = False
+    host = RadiomicsFeatureExtractor(params).execute(image, mask)
+    for k in keys:
+        a, b = float(dev[k]), float(host[k])
+        assert a == b or abs(a - b) <= 1e-10 * abs(b), (k, a, b)
+    # the same slice embedded as a 1 x Ny x Nx volume with force2D gives the same texture features
+    vol3 = RadiomicsFeatureExtractor({"setting": {"binWidth": 25, "force2D": True}}).execute(
+        Image(vol.array[sl][None], vol.spacing), Image(lab.array[sl][None], lab.spacing))
+    for key in ("original_glcm_JointEntropy", "original_glrlm_RunEntropy", "original_glszm_ZoneEntropy",
+                "original_gldm_DependenceEntropy", "original_ngtdm_Coarseness", "original_firstorder_Mean"):
+        assert float(vol3[key]) == pytest.approx(float(dev[key]), rel=1e-12), key
