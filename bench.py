@@ -29,10 +29,10 @@ import numpy as np
 import torch
 
 # Fabric (HBM + Infinity Cache) bytes per engine call at the default workload, from the committed PMC profile
-# profiles/r01i_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 correction applied to
+# profiles/r01j_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 correction applied to
 # the 16 B/lane streams): pack 679 MB + 201 MB, sweep_lines 1002 MB + 3 MB, sweep_rows 191 MB + 3 MB.
 # rocprof cannot run inside bench.py; the figure is only reported when the workload matches the profiled one.
-PROFILED_TRAFFIC = {"workload": (512, 32, "uniform"), "bytes": 2.08e9, "source": "profiles/r01i_pmc.md"}
+PROFILED_TRAFFIC = {"workload": (512, 32, "uniform"), "bytes": 2.08e9, "source": "profiles/r01j_pmc.md"}
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 ALG_BYTES_PER_VOXEL = 5.0       # int32 level + uint8 mask, read once
 
