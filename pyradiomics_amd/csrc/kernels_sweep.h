@@ -413,6 +413,24 @@ __device__ __forceinline__ void steps_plain_group(Walker<true, true, LONG, true>
   unpack_prev<LPL>(w, pw);
 }
 
+// A group of U steps in which lines break (wrapped sweeps).  sb[k] (wave-uniform) is the one line of the wave that
+// wrapped in x when entering step k, or -1; uw[k] says the row wrapped (every line breaks).  Every line tests for its
+// break on every step, branch-free.  (Letting only the lane that owns the breaking line close its run with an extra
+// step(0) under a divergent branch, then taking the plain step wave-wide, measured 20 % SLOWER at 256^3 / 512^3.)
+template <int LPL, int U, bool CHECK, typename W>
+__device__ __forceinline__ bool steps_break_group(W (&w)[LPL], const unsigned (&v)[U], const int (&sb)[U],
+                                                  const bool (&uw)[U], int lane4) {
+  bool m = false;
+#pragma unroll
+  for (int k = 0; k < U; k++) {
+#pragma unroll
+    for (int j = 0; j < LPL; j++) {
+      const bool brk = uw[k] || (sb[k] == lane4 + j);
+      m |= w[j].template step_brk<CHECK>((int)((v[k] >> (8 * j)) & 0xffu), brk);
+    }
+  }
+  return m;
+}
 template <bool DO_GLCM, bool DO_GLRLM, bool FUSED>
 __device__ __forceinline__ void flush_block_hist(const u32 *lds, const HistLayout &h, int Nr, int slot,
                                                  u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc) {
@@ -579,6 +597,11 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
       anydead_l = anydead_l || dead[j];
     }
     const bool anydead = __ballot(anydead_l) != 0;
+    // lines beyond the row end read zeros (= voxels outside the ROI: their events land in the ignored row 0), so a
+    // partial last chunk runs on the same fast paths as a full one
+    u32 livemask = 0;
+#pragma unroll
+    for (int j = 0; j < LPL; j++) livemask |= dead[j] ? 0u : (0xffu << (8 * j));
 #pragma unroll
     for (int j = 0; j < LPL; j++) w[j].begin_line();
 
@@ -594,7 +617,7 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
       bool risky_l = false;
 #pragma unroll
       for (int j = 0; j < LPL; j++) risky_l = risky_l || w[j].risky(U);
-      const bool quiet = !pos.ent_uw && pos.ent_sb < 0 && wrap_quiet<CW>(pos, geo, U) && !anydead;
+      const bool quiet = !pos.ent_uw && pos.ent_sb < 0 && wrap_quiet<CW>(pos, geo, U);
       if (quiet) {
         // no line break and no dead line inside this group: constant stride
         const uint8_t *pl = L + pos.off + lane4;
@@ -602,6 +625,10 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
         for (int k = 0; k < U; k++) {
           v[k] = load_lines<LPL>(pl);
           pl += geo.delta;
+        }
+        if (anydead) {
+#pragma unroll
+          for (int k = 0; k < U; k++) v[k] &= livemask;
         }
         pos.off += (long long)U * geo.delta;
         pos.u += U * du;
@@ -620,39 +647,21 @@ __global__ void __launch_bounds__(1024, 8) sweep_lines_kernel(SweepSet set, cons
         bool uw[U];
 #pragma unroll
         for (int k = 0; k < U; k++) {
-          v[k] = load_lines<LPL>(L + pos.off + lane4);
+          v[k] = load_lines<LPL>(L + pos.off + lane4) & livemask;
           sb[k] = pos.ent_sb;
           uw[k] = pos.ent_uw;
           wrap_advance<CW>(pos, geo);
         }
-        if (anydead || (LONG && __ballot(risky_l) != 0)) {
-#pragma unroll
-          for (int k = 0; k < U; k++) {
-#pragma unroll
-            for (int j = 0; j < LPL; j++) {
-              const bool brk = uw[k] || (sb[k] == lane4 + j);
-              const int cur = dead[j] ? 0 : (int)((v[k] >> (8 * j)) & 0xffu);
-              seen_multi |= w[j].template step_brk<true>(cur, brk);
-            }
-          }
-        } else {  // line breaks only: no dead line, no run can exceed RS inside this group
-#pragma unroll
-          for (int k = 0; k < U; k++) {
-#pragma unroll
-            for (int j = 0; j < LPL; j++) {
-              const bool brk = uw[k] || (sb[k] == lane4 + j);
-              seen_multi |= w[j].template step_brk<false>((int)((v[k] >> (8 * j)) & 0xffu), brk);
-            }
-          }
-        }
+        if (LONG && __ballot(risky_l) != 0) seen_multi |= steps_break_group<LPL, U, true>(w, v, sb, uw, lane4);
+        else seen_multi |= steps_break_group<LPL, U, false>(w, v, sb, uw, lane4);   // no run can exceed RS in this group
       }
     }
     for (int t = t0; t < NM; t++) {  // remainder steps
-      const u32 v = load_lines<LPL>(L + pos.off + lane4);
+      const u32 v = load_lines<LPL>(L + pos.off + lane4) & livemask;
 #pragma unroll
       for (int j = 0; j < LPL; j++) {
         const bool brk = pos.ent_uw || (pos.ent_sb == lane4 + j);
-        const int cur = dead[j] ? 0 : (int)((v >> (8 * j)) & 0xffu);
+        const int cur = (int)((v >> (8 * j)) & 0xffu);
         seen_multi |= w[j].step_brk(cur, brk);
       }
       wrap_advance<CW>(pos, geo);
@@ -691,7 +700,7 @@ __global__ void __launch_bounds__(512) sweep_rows_kernel(const uint8_t *__restri
   Walker<DO_GLCM, DO_GLRLM, LONG, FUSED> w;
   w.init(lds, h, Nr, glrlm_acc + (size_t)slot * Ng * Nr, lane);
   bool seen_multi = false;
-  const bool vec16 = (NX & 15) == 0 && (pitch & 15) == 0 && ((uintptr_t)L & 15) == 0;
+  const bool vec16 = (pitch & 15) == 0 && ((uintptr_t)L & 15) == 0;   // any NX: the piece that straddles NX is masked
 
   for (long long grp = (long long)blockIdx.x * wpb + wave; grp < ngroups; grp += nwaves) {
     const long long r0 = grp * 64;
@@ -705,7 +714,18 @@ __global__ void __launch_bounds__(512) sweep_rows_kernel(const uint8_t *__restri
           const int rr = j * 16 + (lane >> 2);
           const int cx = xc + (lane & 3) * 16;
           uint4 q = make_uint4(0, 0, 0, 0);
-          if (r0 + rr < nrows && cx < NX) q = *reinterpret_cast<const uint4 *>(L + (r0 + rr) * pitch + cx);
+          if (r0 + rr < nrows && cx < NX) {
+            q = *reinterpret_cast<const uint4 *>(L + (r0 + rr) * pitch + cx);
+            const int valid = NX - cx;             // bytes of this piece that belong to the row (the rest is the pad)
+            if (valid < 16) {
+              u32 *qw = reinterpret_cast<u32 *>(&q);
+#pragma unroll
+              for (int wd = 0; wd < 4; wd++) {
+                const int keep = valid - 4 * wd;
+                qw[wd] = keep >= 4 ? qw[wd] : (keep <= 0 ? 0u : (qw[wd] & ((1u << (8 * keep)) - 1u)));
+              }
+            }
+          }
           *reinterpret_cast<uint4 *>(tile + rr * PRAD_ROW_PITCH + (lane & 3) * 16) = q;
         }
       } else {

@@ -309,14 +309,32 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
   const size_t hw = (size_t)hist_layout(want_glcm, want_glrlm, p.fused, Ng, p.RSr).words;
   p.lds_bytes_rows = sizeof(u32) * ((hw + 3) & ~(size_t)3) + (kRowsThreads / 64) * 64 * PRAD_ROW_PITCH;
   // packed layout: each lane of the lines kernel owns LPL adjacent lines; rows get a periodic pad of one wave width
-  p.LPL = p.Nx >= 192 ? 4 : (p.Nx >= 96 ? 2 : 1);
+  // Lines per lane: more lines amortise the per-step overhead (a chunk of 256 / 128 / 64 lines costs about
+  // 1.0 / 0.575 / 0.33 per step), fewer lines waste less of a partial last chunk and give the dynamic hand-out more,
+  // smaller chunks.  Estimate the walk time of one angle as (chunks per wave + half a chunk of tail) x chunk cost.
+  {
+    const double waves = std::max(1.0, (double)(cu_count() / std::max(1, std::min(k.Na, 12))) * 16.0);
+    const double cost[3] = {1.0, 0.575, 0.33};
+    const int cand[3] = {4, 2, 1};
+    double best = 1e300;
+    p.LPL = 1;
+    for (int i = 0; i < 3; i++) {
+      if (cand[i] > 1 && p.Nx < 48 * cand[i]) continue;        // lanes would mostly idle
+      const double chunks = (double)std::max(p.Ny, 1) * ((p.Nx + 64 * cand[i] - 1) / (64 * cand[i]));
+      const double t = (chunks <= waves ? 1.0 : chunks / waves + 0.5) * cost[i];
+      if (t < best) {
+        best = t;
+        p.LPL = cand[i];
+      }
+    }
+  }
   if (const char *e = getenv("PRAD_LPL")) {  // tuning/ablation override
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) p.LPL = v;
   }
   p.vec_rows = (p.Nx % 16) == 0;
   p.padw = std::min(64 * p.LPL, p.Nx);
-  p.pitch = p.Nx + p.padw;
+  p.pitch = (p.Nx + p.padw + 15) & ~15;   // 16-byte aligned rows: vector staging in the rows kernel for any Nx
   p.lines.count = 0;
   p.aset.count = k.Na;
   for (int a = 0; a < k.Na; a++) {
@@ -358,13 +376,16 @@ int launch_lines_lpl(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng,
   long long maxchunks = 0;
   for (int i = 0; i < p.lines.count; i++) maxchunks = std::max(maxchunks, p.lines.d[i].chunks);
   const int wpb = p.threads / 64;
-  const int per_cu = std::max(1, std::min(2048 / p.threads, (int)(160 * 1024 / std::max<size_t>(p.lds_bytes, 1))));
-  // waves available to one angle when all angles are resident together; give every wave the same number of
-  // chunks (a chunk is one NM-step serial walk, so an uneven split costs a whole extra walk)
-  // chunks are grabbed dynamically, so simply fill the machine: every angle gets an equal share of the resident
-  // workgroup slots (never more waves than chunks)
-  const long long blocks_avail = std::max<long long>(1, (long long)cu_count() * per_cu / p.lines.count);
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(blocks_avail, (maxchunks + wpb - 1) / wpb));
+  // Chunks (one NM-step serial walk of 64*LPL lines) are grabbed dynamically.  ONE workgroup per CU across all angles
+  // measured best at 512^3 (20-21 workgroups per angle on 256 CUs: 0.64 ms; 42, i.e. two per CU: 0.66 ms; anything
+  // between makes some CUs host two workgroups while others host one: 0.75-0.93 ms): with ~3 chunks per wave the
+  // tail is short, and a lone workgroup has the CU's LDS bandwidth to itself.
+  const long long blocks_avail = std::max<long long>(1, (long long)cu_count() / p.lines.count);
+  unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(blocks_avail, (maxchunks + wpb - 1) / wpb));
+  if (const char *e = getenv("PRAD_LINES_BLOCKS")) {  // tuning override: workgroups per angle
+    const int v = atoi(e);
+    if (v >= 1) gx = (unsigned)v;
+  }
   PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_lines_kernel<G, R, LNG, F, LPL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
   hipLaunchKernelGGL((sweep_lines_kernel<G, R, LNG, F, LPL>), dim3(gx, p.lines.count), dim3(p.threads), p.lds_bytes,
