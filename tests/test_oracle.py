@@ -117,3 +117,54 @@ def test_golden_features(oracle_backend, cfgname):
                 assert val == ref or (np.isnan(val) and np.isnan(ref)) or abs(val) < 1e-12, (cls, name, val, ref)
             else:
                 assert abs(val - ref) <= 1e-6 * abs(ref), (cls, name, val, ref)
+
+
+# ---- filter restatements (parity with PyWavelets / SimpleITK is UNPINNED: neither wheel exists here and the reference
+# ---- holds no usable golden vector) against independent scipy implementations, as sanity bounds ----------------------
+def test_swt_restatement_is_a_periodic_convolution_with_the_tabulated_filters():
+    """every level-1 sub-band must equal the separable periodic (wrap) convolution of the image with dec_lo / dec_hi,
+    up to ONE circular shift per axis that is the same for all sub-bands (the alignment is the unpinned part)"""
+    from scipy import ndimage
+    from oracle import filters_oracle as fo
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((8, 10, 12))
+    lo, hi = fo.wavelet_filters("coif1") if hasattr(fo, "wavelet_filters") else (None, None)
+    if lo is None:
+        from pyradiomics_amd.filters import wavelet_filters
+        lo, hi = wavelet_filters("coif1")
+    assert abs(lo.sum() - np.sqrt(2)) < 1e-12 and abs(hi.sum()) < 1e-12 and abs((lo ** 2).sum() - 1) < 1e-12
+    assert abs(np.dot(lo[2:], lo[:-2])) < 1e-12 and abs(np.dot(lo[4:], lo[:-4])) < 1e-12     # orthogonal to even shifts
+    ap, ret = fo.swt3(x, "coif1")
+    bands = dict(ret[0], LLL=ap)
+    shifts = None
+    for name, got in bands.items():
+        y = x
+        for ax, letter in zip((2, 1, 0), name):              # first letter = x axis (imageoperations.py:882-893)
+            y = ndimage.convolve1d(y, lo if letter == "L" else hi, axis=ax, mode="wrap")
+        found = [(sz, sy, sx) for sz in range(-3, 4) for sy in range(-3, 4) for sx in range(-3, 4)
+                 if np.allclose(np.roll(y, (sz, sy, sx), (0, 1, 2)), got, rtol=1e-12, atol=1e-12)]
+        assert len(found) == 1, name
+        shifts = shifts or found[0]
+        assert found[0] == shifts and len(set(shifts)) == 1, (name, found, shifts)     # one alignment for every band / axis
+
+
+def test_log_restatement_tracks_the_true_laplacian_of_gaussian():
+    """ITK's recursive (Deriche) Gaussian approximates the sampled Gaussian: against scipy's FIR gaussian_laplace, scaled
+    by sigma^2 (NormalizeAcrossScale), the restatement must agree to about a percent away from the borders"""
+    from scipy import ndimage
+    from oracle import filters_oracle as fo
+    rng = np.random.default_rng(8)
+    x = ndimage.gaussian_filter(rng.standard_normal((40, 44, 48)), 1.5) * 100
+    for sigma in (2.0, 3.5):
+        got = fo.laplacian_recursive_gaussian(x, (1.0, 1.0, 1.0), sigma).astype(np.float64)
+        want = ndimage.gaussian_laplace(x, sigma, mode="nearest") * sigma ** 2
+        c = tuple(slice(12, -12) for _ in range(3))
+        err = np.sqrt(((got[c] - want[c]) ** 2).mean()) / np.sqrt((want[c] ** 2).mean())
+        assert err < 0.02, (sigma, err)
+        assert np.corrcoef(got[c].ravel(), want[c].ravel())[0, 1] > 0.9995
+    # anisotropic spacing: sigma is in mm
+    got = fo.laplacian_recursive_gaussian(x, (1.0, 1.0, 2.0), 3.0).astype(np.float64)          # spacing (x, y, z)
+    want = sum(ndimage.gaussian_filter(x, (1.5, 3.0, 3.0), order=o, mode="nearest") / s2
+               for o, s2 in (((2, 0, 0), 4.0), ((0, 2, 0), 1.0), ((0, 0, 2), 1.0))) * 9.0
+    c = tuple(slice(12, -12) for _ in range(3))
+    assert np.sqrt(((got[c] - want[c]) ** 2).mean()) / np.sqrt((want[c] ** 2).mean()) < 0.03
