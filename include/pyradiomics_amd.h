@@ -132,6 +132,23 @@ int prad_calculate_ngtdm_dev(const int32_t *image, const uint8_t *mask, const in
                              int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
                              double *ngtdm, void *stream);
 
+/* ---- one large segment over several GPUs: plane-range accumulators of GLDM / NGTDM ------------------
+ * (no reference analogue; SURVEY 8e "one exchange step": GLDM / NGTDM histograms are additive over centre
+ * voxels.)  acc: DEVICE int64 [Ng][Na+1] for the centre voxels in planes z_lo <= z < z_hi of dim 0 of a 3-D
+ * volume, neighbours taken from the whole volume (only planes z_lo-1 .. z_hi are read for distance 1):
+ *   family 0, GLDM :  acc[g][k] = voxels of level g+1 with dependence k            (cmatrices.c:737-748)
+ *   family 1, NGTDM:  acc[g][0] = voxels of level g+1;  acc[g][c] = sum over those with c valid neighbours
+ *                     of |c*level - sum(neighbour levels)|                          (cmatrices.c:637-652)
+ * The accumulators of disjoint plane ranges add up (exactly, they are integers) to those of the whole
+ * volume; prad_neigh_finalize_dev turns the sum into the matrix prad_calculate_gldm / _ngtdm return
+ * (gldm float64 [Ng][2*Na+1], ngtdm float64 [Ng][3]), bit-identical to the single-device call.
+ * `alpha` is used by GLDM only.  PRAD_E_UNSUPPORTED when Nd != 3, Ng > 255 or the bins exceed 64 KiB of LDS;
+ * PRAD_INDEX_ERROR when a masked level is outside 1..Ng. */
+int prad_neigh_accumulate_dev(int family, const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                              const int *angles, int Na, int Ng, int alpha, int z_lo, int z_hi, long long *acc,
+                              void *stream);
+int prad_neigh_finalize_dev(int family, const long long *acc, int Ng, int Na, double *out, void *stream);
+
 /* ---- GLSZM: calculate_glszm + fill_glszm (cmatrices.c:94-297) ----------------------------------- */
 /* Phase 1: labels the zones of every kernel on the device and keeps the (level, size) list in the
  * library's per-thread workspace.  Returns the largest zone size over all Nvox kernels (>= 0), or

@@ -199,6 +199,21 @@ class CMatricesCPU:
                 raise IndexError("Error filling GLSZM.")
         return out
 
+    def pairs_or_runs_for_angles(self, what, image, mask, Ng, Nr, angles):
+        """calculate_glcm ("glcm") / calculate_glrlm ("glrlm") of the reference's core for an explicit angle list
+        (the core takes the angle table as an argument, cmatrices.h:1-8) -> [Ng, Ng|Nr, na]"""
+        img, msk, size, strides = self._arrays(image, mask)
+        ang = np.ascontiguousarray(np.asarray(angles, dtype=np.intc))
+        Na, Nd = ang.shape
+        bb = self._bb(0, size, None, 0, -1)
+        out = np.zeros((Ng, Ng if what == "glcm" else Nr, Na), dtype=np.float64)
+        fn = self.L.calculate_glcm if what == "glcm" else self.L.calculate_glrlm
+        extra = (Ng,) if what == "glcm" else (Ng, Nr)
+        if not fn(_i(img), msk.ctypes.data_as(C.c_char_p), _i(size), _i(bb), _i(strides), _i(ang), Na, Nd,
+                  out.ctypes.data_as(_dp), *extra):
+            raise IndexError("Calculation of %s Failed." % what.upper())
+        return out
+
     def generate_angles(self, size, distances, bidirectional, force2D, force2Ddimension):
         size = np.ascontiguousarray(np.asarray(size).astype(np.intc, copy=False))
         if size.ndim != 1:

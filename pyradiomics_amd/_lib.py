@@ -42,6 +42,8 @@ SYMBOLS = {
     "prad_calculate_gldm_dev": (C.c_int, _COMMON + [C.c_int, C.c_int] + _VOX + [_vp, _vp]),
     "prad_calculate_ngtdm": (C.c_int, _COMMON + [C.c_int] + _VOX + [_vp]),
     "prad_calculate_ngtdm_dev": (C.c_int, _COMMON + [C.c_int] + _VOX + [_vp, _vp]),
+    "prad_neigh_accumulate_dev": (C.c_int, [C.c_int] + _COMMON + [C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "prad_neigh_finalize_dev": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),
     "prad_calculate_glszm": (C.c_int, _COMMON + [C.c_int, C.c_int] + _VOX + [C.POINTER(C.c_longlong)]),
     "prad_calculate_glszm_dev": (C.c_int, _COMMON + [C.c_int, C.c_int] + _VOX + [C.POINTER(C.c_longlong), _vp]),
     "prad_fill_glszm": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),

@@ -83,3 +83,205 @@ def voxel_maps_sharded(feature_class, image, mask, features=None, **settings):
             full[tuple(c)] = vals[name]
         out[name] = img.like(full)
     return out
+
+
+# ---- one large segment over all ranks -------------------------------------------------------------------------
+# The five matrices of ONE discretised volume, each split the way its arithmetic allows (third row):
+#   GLCM, GLRLM   by ANGLE   the matrices are [.., .., Na] with independent angle columns; every rank sweeps its
+#                            angles over the whole (replicated) volume -- runs never cross a rank boundary
+#   GLDM, NGTDM   by z-SLAB  per-voxel histograms are additive: a rank accumulates the centre voxels of its planes
+#                            (neighbours read from the planes around them) into integer accumulators
+#   GLSZM         by LEVEL   a zone is a connected set of voxels of ONE level, so the zones of level g are those of
+#                            the mask restricted to level g; rank r labels the levels g with g % world == r
+# followed by ONE exchange step: all-reduce(sum) of the float64 count tensors (exact: integers and zeros) and of the
+# int64 accumulators, and a gather of the compact zone tables.  The result is bit-identical to the single-GPU
+# calls for every class.  The volume must be resident on every rank (replicate_volume broadcasts it over xGMI).
+
+SEGMENT_CLASSES = ("glcm", "glrlm", "gldm", "ngtdm", "glszm")
+
+
+class HipSegmentOps:
+    """the rank-local pieces on this rank's GPU (pyradiomics_amd.engine; device tensors in, device tensors out)"""
+
+    @staticmethod
+    def pair_angles(shape, distances, force2D, force2Ddimension):
+        from . import engine
+        return engine.pair_angles(shape, distances, force2D, force2Ddimension)
+
+    @staticmethod
+    def neigh_angles(shape, distances, force2D, force2Ddimension):
+        from . import engine
+        return engine.neigh_angles(shape, distances, force2D, force2Ddimension)
+
+    @staticmethod
+    def pairs(image, mask, Ng, angles, force2D, force2Ddimension, fused_ok):
+        """GLCM [Ng, Ng, na] of the given angles"""
+        from . import engine
+        if fused_ok:
+            return engine.glcm_glrlm(image, mask, Ng, None, force2D, force2Ddimension, want_glrlm=False,
+                                     angles=angles)[0]
+        return engine.glcm(image, mask, Ng, (1,), force2D, force2Ddimension, angles=angles)[0]
+
+    @staticmethod
+    def runs(image, mask, Ng, Nr, angles, force2D, force2Ddimension):
+        """GLRLM [Ng, Nr, na] of the given angles"""
+        from . import engine
+        return engine.glcm_glrlm(image, mask, Ng, Nr, force2D, force2Ddimension, want_glcm=False, angles=angles)[1]
+
+    @staticmethod
+    def pairs_runs(image, mask, Ng, Nr, angles, force2D, force2Ddimension):
+        """both, one sweep per angle"""
+        from . import engine
+        g, r, _ = engine.glcm_glrlm(image, mask, Ng, Nr, force2D, force2Ddimension, angles=angles)
+        return g, r
+
+    @staticmethod
+    def neigh_accumulate(family, image, mask, Ng, z_lo, z_hi, alpha, distances, force2D, force2Ddimension):
+        from . import engine
+        return engine.neigh_accumulate(family, image, mask, Ng, z_lo, z_hi, alpha, distances, force2D,
+                                       force2Ddimension)
+
+    @staticmethod
+    def neigh_finalize(family, acc):
+        from . import engine
+        return engine.neigh_finalize(family, acc)
+
+    @staticmethod
+    def zones(image, mask, Ng, Ns, force2D, force2Ddimension):
+        """compact GLSZM (P float64 numpy [Ng, k], sizes int numpy [k] ascending)"""
+        from . import engine
+        P, sizes = engine.glszm_compact(image, mask, Ng, Ns, force2D, force2Ddimension)
+        return P.cpu().numpy(), sizes
+
+
+def replicate_volume(image, mask, src: int = 0, device=None):
+    """Broadcasts a discretised volume from rank `src` to every rank (one RCCL broadcast over xGMI): levels
+    travel as ONE byte per voxel (0 = outside the mask) when they fit, int32 otherwise.  `image` / `mask` are
+    tensors on `src` and ignored (may be None) elsewhere.  Returns (image int32, mask uint8) on this rank."""
+    import torch
+    import torch.distributed as dist
+    rank, world = rank_world()
+    if world == 1:
+        return image.to(torch.int32), mask.to(torch.uint8)
+    head = [None]
+    if rank == src:
+        device = image.device
+        levels = torch.where(mask.bool(), image, torch.zeros_like(image))
+        lo, hi = int(levels.min()), int(levels.max())
+        narrow = lo >= 0 and hi <= 255
+        head = [(tuple(image.shape), narrow)]
+    dist.broadcast_object_list(head, src=src)
+    shape, narrow = head[0]
+    dtype = torch.uint8 if narrow else torch.int32
+    if rank == src:
+        packed = levels.to(dtype).contiguous()
+        # a voxel inside the mask with level 0 is an input error the matrix calls must still see (IndexError):
+        # it cannot be told apart from "outside" in the packed form, so it is refused here
+        if bool(((levels == 0) & mask.bool()).any()):
+            raise IndexError("level 0 under the mask")
+    else:
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu"
+        packed = torch.empty(shape, dtype=dtype, device=device)
+    dist.broadcast(packed, src=src)
+    return packed.to(torch.int32), (packed != 0).to(torch.uint8)
+
+
+def segment_partials(image, mask, Ng, rank, world, classes=SEGMENT_CLASSES, Nr=None, alpha=0, distances=(1,),
+                     force2D=False, force2Ddimension=0, ops=HipSegmentOps):
+    """Rank `rank`'s additive share of the matrices of one segment (no communication).  Returns a dict:
+    "glcm" [Ng,Ng,Na] / "glrlm" [Ng,Nr,Na] float64 with only this rank's angle columns non-zero, "gldm_acc" /
+    "ngtdm_acc" int64 [Ng, Na+1] of this rank's planes, "glszm" (P numpy [Ng,k], sizes numpy [k]) of this rank's
+    levels, plus the angle tables."""
+    import numpy as np
+    import torch
+    shape = tuple(image.shape)
+    dist1 = [int(d) for d in distances] == [1]
+    out = {}
+    if "glcm" in classes or "glrlm" in classes:
+        run_angles = ops.pair_angles(shape, (1,), force2D, force2Ddimension)
+        pair_angles = run_angles if dist1 else ops.pair_angles(shape, distances, force2D, force2Ddimension)
+        if Nr is None:
+            Nr = int(max(shape))
+        mine_r = list(range(rank, len(run_angles), world))
+        mine_p = list(range(rank, len(pair_angles), world))
+        if "glcm" in classes:
+            out["glcm"] = torch.zeros((Ng, Ng, len(pair_angles)), dtype=torch.float64, device=image.device)
+            out["glcm_angles"] = pair_angles
+        if "glrlm" in classes:
+            out["glrlm"] = torch.zeros((Ng, Nr, len(run_angles)), dtype=torch.float64, device=image.device)
+            out["glrlm_angles"] = run_angles
+        if "glcm" in classes and "glrlm" in classes and dist1:
+            if mine_r:
+                g, r = ops.pairs_runs(image, mask, Ng, Nr, run_angles[mine_r], force2D, force2Ddimension)
+                out["glcm"][:, :, mine_r] = g
+                out["glrlm"][:, :, mine_r] = r
+        else:
+            if "glcm" in classes and mine_p:
+                out["glcm"][:, :, mine_p] = ops.pairs(image, mask, Ng, pair_angles[mine_p], force2D,
+                                                      force2Ddimension, dist1)
+            if "glrlm" in classes and mine_r:
+                out["glrlm"][:, :, mine_r] = ops.runs(image, mask, Ng, Nr, run_angles[mine_r], force2D,
+                                                      force2Ddimension)
+    if "gldm" in classes or "ngtdm" in classes:
+        if image.dim() != 3:
+            raise NotImplementedError("the z-slab split of GLDM / NGTDM needs a 3-D volume")
+        lo, hi, _, _ = split_slabs(shape[0], world)[rank]
+        out["neigh_angles"] = ops.neigh_angles(shape, distances, force2D, force2Ddimension)
+        if "gldm" in classes:
+            out["gldm_acc"] = ops.neigh_accumulate(0, image, mask, Ng, lo, hi, alpha, distances, force2D,
+                                                   force2Ddimension)
+        if "ngtdm" in classes:
+            out["ngtdm_acc"] = ops.neigh_accumulate(1, image, mask, Ng, lo, hi, 0, distances, force2D,
+                                                    force2Ddimension)
+    if "glszm" in classes:
+        own = mask.bool() & ((image % world) == rank)
+        Ns = int(own.sum())
+        if Ns:
+            out["glszm"] = ops.zones(image, own.to(mask.dtype), Ng, Ns, force2D, force2Ddimension)
+        else:
+            out["glszm"] = (np.zeros((Ng, 0)), np.zeros(0, dtype=np.intc))
+    return out
+
+
+def merge_zone_tables(tables, Ng):
+    """compact GLSZM tables of disjoint level sets -> one table over the union of their zone sizes"""
+    import numpy as np
+    sizes = np.unique(np.concatenate([np.asarray(s, dtype=np.int64) for _, s in tables])) if tables else np.zeros(0)
+    P = np.zeros((Ng, len(sizes)), dtype=np.float64)
+    for Pr, sr in tables:
+        if len(sr):
+            P[:, np.searchsorted(sizes, sr)] += Pr
+    return P, sizes.astype(np.intc)
+
+
+def segment_matrices_sharded(image, mask, Ng, classes=SEGMENT_CLASSES, Nr=None, alpha=0, distances=(1,),
+                             force2D=False, force2Ddimension=0, ops=HipSegmentOps):
+    """The matrices of ONE segment computed by all ranks of the job (see the table above): every rank passes the
+    same discretised volume (int levels, mask; device tensors for the HIP ops -- use replicate_volume when only
+    one rank holds it) and every rank returns the same dict: "glcm" [Ng,Ng,Na], "glrlm" [Ng,Nr,Na], "gldm"
+    [Ng,2Na+1], "ngtdm" [Ng,3] (float64 tensors in the single-GPU layouts), "glszm" (P numpy [Ng,k], sizes [k]),
+    "glcm_angles" / "glrlm_angles".  Bit-identical to the single-GPU calls."""
+    rank, world = rank_world()
+    part = segment_partials(image, mask, Ng, rank, world, classes, Nr, alpha, distances, force2D,
+                            force2Ddimension, ops)
+    tables = [part["glszm"]] if "glszm" in part else []
+    if world > 1:
+        import torch.distributed as dist
+        for key in ("glcm", "glrlm", "gldm_acc", "ngtdm_acc"):     # the exchange step
+            if key in part:
+                dist.all_reduce(part[key], op=dist.ReduceOp.SUM)
+        if "glszm" in part:
+            tables = [None] * world
+            dist.all_gather_object(tables, part["glszm"])
+    out = {k: part[k] for k in ("glcm", "glrlm", "glcm_angles", "glrlm_angles") if k in part}
+    if "gldm_acc" in part:
+        out["gldm"] = ops.neigh_finalize(0, part["gldm_acc"])
+    if "ngtdm_acc" in part:
+        out["ngtdm"] = ops.neigh_finalize(1, part["ngtdm_acc"])
+    if tables:
+        P, sizes = merge_zone_tables(tables, Ng)
+        if not len(sizes):
+            raise IndexError("Calculation of GLSZM Failed.")      # empty mask, as the single-GPU call
+        out["glszm"] = (P, sizes)
+    return out

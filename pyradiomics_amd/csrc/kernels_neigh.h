@@ -24,8 +24,9 @@ struct NeighSet {
 
 template <bool NGTDM>
 __global__ void __launch_bounds__(256) neigh_kernel(NeighSet A, const uint8_t *__restrict__ L, int Nz, int Ny,
-                                                    int Nx, int Ng, int alpha, u32 *__restrict__ gldm_acc,
-                                                    u64 *__restrict__ ngtdm_acc, const int *__restrict__ flags) {
+                                                    int Nx, int zlo, int zhi, int Ng, int alpha,
+                                                    u32 *__restrict__ gldm_acc, u64 *__restrict__ ngtdm_acc,
+                                                    const int *__restrict__ flags) {
   extern __shared__ u64 lds64[];
   if (flags[0]) return;
   const int W = A.na + 1;
@@ -36,10 +37,10 @@ __global__ void __launch_bounds__(256) neigh_kernel(NeighSet A, const uint8_t *_
     else h32[i] = 0;
   }
   __syncthreads();
-  const long long n = (long long)Nz * Ny * Nx;
   const long long plane = (long long)Ny * Nx;
+  const long long n = (long long)zhi * plane;   // centres: planes zlo .. zhi-1 (neighbours: the whole volume)
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  for (long long i = (long long)zlo * plane + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int c = L[i];
     if (!c) continue;
     const int z = (int)(i / plane);
@@ -103,8 +104,9 @@ __device__ __forceinline__ unsigned nonzero_bytes3(unsigned w) {  // bit 7 of ev
 
 template <bool NGTDM>
 __global__ void __launch_bounds__(256) neigh4_kernel(RowMasks R, const uint8_t *__restrict__ L, int Nz, int Ny,
-                                                     int Nx, int Ng, int Na, u32 *__restrict__ gldm_acc,
-                                                     u64 *__restrict__ ngtdm_acc, const int *__restrict__ flags) {
+                                                     int Nx, int zlo, int zhi, int Ng, int Na,
+                                                     u32 *__restrict__ gldm_acc, u64 *__restrict__ ngtdm_acc,
+                                                     const int *__restrict__ flags) {
   extern __shared__ u64 lds64[];
   if (flags[0]) return;
   const int W = Na + 1;
@@ -116,9 +118,10 @@ __global__ void __launch_bounds__(256) neigh4_kernel(RowMasks R, const uint8_t *
   }
   __syncthreads();
   const int qpr = Nx >> 2;                      // quads per row
-  const long long nquads = (long long)Nz * Ny * qpr;
+  const long long nquads = (long long)zhi * Ny * qpr;   // centres: planes zlo .. zhi-1
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads; q += stride) {
+  for (long long q = (long long)zlo * Ny * qpr + (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads;
+       q += stride) {
     const long long row = q / qpr;
     const int x0 = (int)(q - row * qpr) << 2;
     const int z = (int)(row / Ny), y = (int)(row - (long long)z * Ny);
@@ -230,87 +233,123 @@ inline NeighPlan plan_neigh(const Geo &g, const VoxMode &vm, const int *angles_h
   return p;
 }
 
-inline int neigh_pack(Context *c, hipStream_t s, const Geo &g, const int32_t *image, const uint8_t *mask, int Ng,
-                      int *flags_d, uint8_t **levels) {
+// packs planes [plo, phi) of the 3-D-embedded volume (the rest of `levels` is not touched / not read)
+inline int neigh_pack(Context *c, hipStream_t s, const Geo &g, const NeighPlan &p, int plo, int phi,
+                      const int32_t *image, const uint8_t *mask, int Ng, int *flags_d, uint8_t **levels) {
   PRAD_TRY(c->get<uint8_t>("levels", (size_t)g.n + 64, levels));
   Timed t(*c, "pack", s);
-  const int vec_ok = ((((uintptr_t)image) | ((uintptr_t)mask) | ((uintptr_t)*levels)) & 15) == 0;
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((g.n / 16 + 255) / 256, 4096));
-  const int NX = g.size[g.nd - 1];
-  hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, s, image, mask, g.n, NX, NX, 0, Ng, *levels, flags_d,
-                     vec_ok, 0);
+  const long long plane = (long long)p.Ny * p.Nx, off = plo * plane, n = (phi - plo) * plane;
+  const int vec_ok = ((((uintptr_t)(image + off)) | ((uintptr_t)(mask + off)) | ((uintptr_t)(*levels + off))) & 15) == 0;
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n / 16 + 255) / 256, 4096));
+  hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, s, image + off, mask + off, n, p.Nx, p.Nx, 0, Ng,
+                     *levels + off, flags_d, vec_ok, 0);
   return check_launch("pack_levels_kernel");
+}
+
+// whole volume (voxel-map callers)
+inline int neigh_pack(Context *c, hipStream_t s, const Geo &g, const int32_t *image, const uint8_t *mask, int Ng,
+                      int *flags_d, uint8_t **levels) {
+  NeighPlan p;
+  p.Nz = 1; p.Ny = 1; p.Nx = g.size[g.nd - 1];
+  const long long rows = g.n / p.Nx;
+  if (rows > 0x7fffffffll) return fail(PRAD_E_ARG, "volume too large");
+  p.Ny = (int)rows;
+  return neigh_pack(c, s, g, p, 0, 1, image, mask, Ng, flags_d, levels);
+}
+
+// Integer accumulators [Ng][Na+1] (u32 for GLDM, u64 for NGTDM, layout in the header comment) of the centre
+// voxels in planes [zlo, zhi) of the 3-D-embedded volume, neighbours taken from the whole volume.  The
+// accumulators of disjoint plane ranges add up to those of the whole volume -- the z-slab split of one
+// large segment over several GPUs sums them before the finalize step.
+template <bool NGTDM>
+inline int neigh_accumulate(Context *c, hipStream_t s, const Geo &g, const VoxMode &vm, const int32_t *image,
+                            const uint8_t *mask, const int *angles_h, int Na, int Ng, int alpha, int zlo, int zhi,
+                            int *flags_d, void **acc_out, bool *done) {
+  *done = false;
+  NeighPlan p = plan_neigh(g, vm, angles_h, Na, Ng, NGTDM ? sizeof(u64) : sizeof(u32));
+  if (!p.ok) return PRAD_OK;
+  if (zlo < 0) zlo = 0;
+  if (zhi > p.Nz) zhi = p.Nz;
+  int reach = 0;
+  for (int a = 0; a < Na; a++) reach = std::max(reach, std::abs((int)p.set.o[a][0]));
+  uint8_t *levels = nullptr;
+  const int plo = std::max(0, zlo - reach), phi = std::min(p.Nz, zhi + reach);
+  if (zhi > zlo) PRAD_TRY(neigh_pack(c, s, g, p, plo, phi, image, mask, Ng, flags_d, &levels));
+  const size_t nacc = (size_t)Ng * (Na + 1);
+  u32 *acc32 = nullptr;
+  u64 *acc64 = nullptr;
+  if (NGTDM) {
+    PRAD_TRY(c->get<u64>("ngtdm_acc", nacc, &acc64));
+    PRAD_HIP(hipMemsetAsync(acc64, 0, sizeof(u64) * nacc, s));
+    *acc_out = acc64;
+  } else {
+    PRAD_TRY(c->get<u32>("gldm_acc", nacc, &acc32));
+    PRAD_HIP(hipMemsetAsync(acc32, 0, sizeof(u32) * nacc, s));
+    *acc_out = acc32;
+  }
+  if (zhi > zlo) {
+    Timed t(*c, "neigh", s);
+    const size_t lds = (NGTDM ? sizeof(u64) : sizeof(u32)) * nacc;
+    const long long ncent = (long long)(zhi - zlo) * p.Ny * p.Nx;
+    RowMasks R;
+    // the packed-byte path reads planes z-1 .. z+1 only where the row masks say so, all inside [plo, phi)
+    if ((NGTDM || alpha == 0) && (p.Nx & 3) == 0 && row_masks_from(p.set, &R)) {
+      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((ncent >> 2) + 255) / 256, 8192));
+      hipLaunchKernelGGL((neigh4_kernel<NGTDM>), dim3(gx), dim3(256), lds, s, R, levels, p.Nz, p.Ny, p.Nx, zlo, zhi,
+                         Ng, Na, acc32, acc64, flags_d);
+      PRAD_TRY(check_launch("neigh4_kernel"));
+    } else {
+      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((ncent + 255) / 256, 4096));
+      hipLaunchKernelGGL((neigh_kernel<NGTDM>), dim3(gx), dim3(256), lds, s, p.set, levels, p.Nz, p.Ny, p.Nx, zlo,
+                         zhi, Ng, alpha, acc32, acc64, flags_d);
+      PRAD_TRY(check_launch("neigh_kernel"));
+    }
+  }
+  *done = true;
+  return PRAD_OK;
+}
+
+inline int neigh_finalize_gldm(Context *c, hipStream_t s, const u32 *acc, int Ng, int Na, double *out) {
+  Timed t(*c, "finalize", s);
+  const long long total = (long long)Ng * (2 * Na + 1);
+  hipLaunchKernelGGL(finalize_gldm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, acc, Ng, Na, out);
+  return check_launch("finalize_gldm_kernel");
+}
+
+inline int neigh_finalize_ngtdm(Context *c, hipStream_t s, const u64 *acc, int Ng, int Na, double *out) {
+  Timed t(*c, "finalize", s);
+  hipLaunchKernelGGL(ngtdm_finalize_kernel, dim3((unsigned)((Ng + 63) / 64)), dim3(64), 0, s, acc, Ng, Na, out);
+  return check_launch("ngtdm_finalize_kernel");
 }
 
 inline int neigh_try_gldm(Context *c, hipStream_t s, const Geo &g, const VoxMode &vm, const int32_t *image,
                           const uint8_t *mask, const int *angles_h, int Na, int Ng, int alpha, double *out,
                           int *flags_d, bool *done) {
-  *done = false;
-  NeighPlan p = plan_neigh(g, vm, angles_h, Na, Ng, sizeof(u32));
-  if (!p.ok) return PRAD_OK;
-  uint8_t *levels = nullptr;
-  PRAD_TRY(neigh_pack(c, s, g, image, mask, Ng, flags_d, &levels));
-  u32 *acc = nullptr;
-  const size_t nacc = (size_t)Ng * (Na + 1);
-  PRAD_TRY(c->get<u32>("gldm_acc", nacc, &acc));
-  PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u32) * nacc, s));
-  {
-    Timed t(*c, "neigh", s);
-    RowMasks R;
-    if (alpha == 0 && (p.Nx & 3) == 0 && row_masks_from(p.set, &R)) {   // packed-byte path
-      const long long quads = g.n >> 2;
-      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((quads + 255) / 256, 8192));
-      hipLaunchKernelGGL((neigh4_kernel<false>), dim3(gx), dim3(256), sizeof(u32) * nacc, s, R, levels, p.Nz, p.Ny,
-                         p.Nx, Ng, Na, acc, (u64 *)nullptr, flags_d);
-      PRAD_TRY(check_launch("neigh4_kernel<gldm>"));
-    } else {
-      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((g.n + 255) / 256, 4096));
-      hipLaunchKernelGGL((neigh_kernel<false>), dim3(gx), dim3(256), sizeof(u32) * nacc, s, p.set, levels, p.Nz, p.Ny,
-                         p.Nx, Ng, alpha, acc, (u64 *)nullptr, flags_d);
-      PRAD_TRY(check_launch("neigh_kernel<gldm>"));
-    }
-  }
-  Timed t(*c, "finalize", s);
-  const long long total = (long long)Ng * (2 * Na + 1);
-  hipLaunchKernelGGL(finalize_gldm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, acc, Ng, Na, out);
-  PRAD_TRY(check_launch("finalize_gldm_kernel"));
-  *done = true;
-  return PRAD_OK;
+  void *acc = nullptr;
+  PRAD_TRY(neigh_accumulate<false>(c, s, g, vm, image, mask, angles_h, Na, Ng, alpha, 0, 1 << 30, flags_d, &acc, done));
+  if (!*done) return PRAD_OK;
+  return neigh_finalize_gldm(c, s, (const u32 *)acc, Ng, Na, out);
 }
 
 inline int neigh_try_ngtdm(Context *c, hipStream_t s, const Geo &g, const VoxMode &vm, const int32_t *image,
                            const uint8_t *mask, const int *angles_h, int Na, int Ng, double *out, int *flags_d,
                            bool *done) {
-  *done = false;
-  NeighPlan p = plan_neigh(g, vm, angles_h, Na, Ng, sizeof(u64));
-  if (!p.ok) return PRAD_OK;
-  uint8_t *levels = nullptr;
-  PRAD_TRY(neigh_pack(c, s, g, image, mask, Ng, flags_d, &levels));
-  u64 *acc = nullptr;
-  const size_t nacc = (size_t)Ng * (Na + 1);
-  PRAD_TRY(c->get<u64>("ngtdm_acc", nacc, &acc));
-  PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u64) * nacc, s));
-  {
-    Timed t(*c, "neigh", s);
-    RowMasks R;
-    if ((p.Nx & 3) == 0 && row_masks_from(p.set, &R)) {   // packed-byte path
-      const long long quads = g.n >> 2;
-      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((quads + 255) / 256, 8192));
-      hipLaunchKernelGGL((neigh4_kernel<true>), dim3(gx), dim3(256), sizeof(u64) * nacc, s, R, levels, p.Nz, p.Ny,
-                         p.Nx, Ng, Na, (u32 *)nullptr, acc, flags_d);
-      PRAD_TRY(check_launch("neigh4_kernel<ngtdm>"));
-    } else {
-      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((g.n + 255) / 256, 4096));
-      hipLaunchKernelGGL((neigh_kernel<true>), dim3(gx), dim3(256), sizeof(u64) * nacc, s, p.set, levels, p.Nz, p.Ny,
-                         p.Nx, Ng, 0, (u32 *)nullptr, acc, flags_d);
-      PRAD_TRY(check_launch("neigh_kernel<ngtdm>"));
-    }
-  }
-  Timed t(*c, "finalize", s);
-  hipLaunchKernelGGL(ngtdm_finalize_kernel, dim3((unsigned)((Ng + 63) / 64)), dim3(64), 0, s, acc, Ng, Na, out);
-  PRAD_TRY(check_launch("ngtdm_finalize_kernel"));
-  *done = true;
-  return PRAD_OK;
+  void *acc = nullptr;
+  PRAD_TRY(neigh_accumulate<true>(c, s, g, vm, image, mask, angles_h, Na, Ng, 0, 0, 1 << 30, flags_d, &acc, done));
+  if (!*done) return PRAD_OK;
+  return neigh_finalize_ngtdm(c, s, (const u64 *)acc, Ng, Na, out);
+}
+
+// widening copy of the GLDM accumulators for the exchange step (RCCL sums int64)
+__global__ void widen_u32_kernel(const u32 *__restrict__ in, long long n, long long *__restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (long long)in[i];
+}
+__global__ void narrow_i64_kernel(const long long *__restrict__ in, long long n, u32 *__restrict__ out, int *flags) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (in[i] < 0 || in[i] > 0xffffffffll) flags[1] = 1;
+  out[i] = (u32)in[i];
 }
 
 }  // namespace prad

@@ -572,6 +572,72 @@ int texture_ngtdm(const int32_t *image, const uint8_t *mask, const int *size, in
   return k.flags_h[1] ? PRAD_INDEX_ERROR : PRAD_OK;
 }
 
+// z-slab split of one large segment over several GPUs: integer accumulators of a plane range, summed by the
+// caller across ranks (RCCL all-reduce of [Ng][Na+1] int64), then finalized once
+int neigh_accumulate_i64(int family, const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                         const int *angles, int Na, int Ng, int alpha, int z_lo, int z_hi, long long *acc,
+                         hipStream_t s) {
+  if (!acc) return fail(PRAD_E_ARG, "acc is NULL");
+  if (family != 0 && family != 1) return fail(PRAD_E_ARG, "family must be 0 (GLDM) or 1 (NGTDM)");
+  if (Nd != 3) return fail(PRAD_E_UNSUPPORTED, "plane-range accumulators need a 3-D volume (Nd=%d)", Nd);
+  if (Ng < 1) return fail(PRAD_E_ARG, "Ng must be >= 1");
+  if (z_lo < 0 || z_hi > size[0] || z_lo > z_hi) return fail(PRAD_E_ARG, "plane range [%d, %d) outside 0..%d", z_lo, z_hi, size[0]);
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Call k;
+  PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, 1, nullptr, 0, -1, s));
+  PRAD_TRY(c.begin_call(s));
+  bool done = false;
+  void *raw = nullptr;
+  if (family == 0)
+    PRAD_TRY(neigh_accumulate<false>(k.c, k.s, k.g, k.vm, k.image, k.mask, k.angles_h, k.Na, Ng, alpha, z_lo, z_hi,
+                                     k.flags_d, &raw, &done));
+  else
+    PRAD_TRY(neigh_accumulate<true>(k.c, k.s, k.g, k.vm, k.image, k.mask, k.angles_h, k.Na, Ng, 0, z_lo, z_hi,
+                                    k.flags_d, &raw, &done));
+  if (!done) {
+    c.end_call(s);
+    return fail(PRAD_E_UNSUPPORTED, "plane-range accumulators need Ng <= 255, Na <= %d and [Ng][Na+1] bins within 64 KiB of LDS", PRAD_MAX_NEIGH);
+  }
+  const long long nacc = (long long)Ng * (Na + 1);
+  if (family == 0) {
+    hipLaunchKernelGGL(widen_u32_kernel, dim3((unsigned)((nacc + 255) / 256)), dim3(256), 0, s, (const u32 *)raw, nacc, acc);
+    PRAD_TRY(check_launch("widen_u32_kernel"));
+  } else {
+    PRAD_HIP(hipMemcpyAsync(acc, raw, sizeof(long long) * nacc, hipMemcpyDeviceToDevice, s));
+  }
+  PRAD_TRY(read_flags(k));
+  PRAD_TRY(c.end_call(s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  // a level outside 1..Ng under the mask: the reference fails the whole calculation (cmatrices.c:744,647)
+  return k.flags_h[0] ? PRAD_INDEX_ERROR : PRAD_OK;
+}
+
+int neigh_finalize_i64(int family, const long long *acc, int Ng, int Na, double *out, hipStream_t s) {
+  if (!acc || !out) return fail(PRAD_E_ARG, "acc/out is NULL");
+  if (family != 0 && family != 1) return fail(PRAD_E_ARG, "family must be 0 (GLDM) or 1 (NGTDM)");
+  if (Ng < 1 || Na < 1) return fail(PRAD_E_ARG, "Ng and Na must be >= 1");
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  PRAD_TRY(c.begin_call(s));
+  if (family == 0) {
+    const long long nacc = (long long)Ng * (Na + 1);
+    u32 *acc32 = nullptr;
+    int *flags = nullptr;
+    PRAD_TRY(c.get<u32>("gldm_acc", (size_t)nacc, &acc32));
+    PRAD_TRY(c.get<int>("flags", 4, &flags));
+    PRAD_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, s));
+    hipLaunchKernelGGL(narrow_i64_kernel, dim3((unsigned)((nacc + 255) / 256)), dim3(256), 0, s, acc, nacc, acc32, flags);
+    PRAD_TRY(check_launch("narrow_i64_kernel"));
+    PRAD_TRY(neigh_finalize_gldm(&c, s, acc32, Ng, Na, out));
+  } else {
+    PRAD_TRY(neigh_finalize_ngtdm(&c, s, reinterpret_cast<const u64 *>(acc), Ng, Na, out));
+  }
+  PRAD_TRY(c.end_call(s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  return PRAD_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-pointer staging
 // ------------------------------------------------------------------------------------------------
@@ -1109,6 +1175,17 @@ int prad_calculate_ngtdm(const int32_t *image, const uint8_t *mask, const int *s
                          c.own_stream);
   if (rc != PRAD_OK) return rc;
   return copy_back(c, ngtdm, d, n);
+}
+
+// ---- plane-range accumulators (one segment over several GPUs) ------------------------------
+int prad_neigh_accumulate_dev(int family, const int32_t *image, const uint8_t *mask, const int *size, int Nd,
+                              const int *angles, int Na, int Ng, int alpha, int z_lo, int z_hi, long long *acc,
+                              void *stream) {
+  return neigh_accumulate_i64(family, image, mask, size, Nd, angles, Na, Ng, alpha, z_lo, z_hi, acc,
+                              (hipStream_t)stream);
+}
+int prad_neigh_finalize_dev(int family, const long long *acc, int Ng, int Na, double *out, void *stream) {
+  return neigh_finalize_i64(family, acc, Ng, Na, out, (hipStream_t)stream);
 }
 
 // ---- GLSZM ----------------------------------------------------------------------------------

@@ -40,12 +40,19 @@ def _prep(image: torch.Tensor, mask: torch.Tensor):
 
 def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None = None, force2D: bool = False,
                force2Ddimension: int = 0, want_glcm: bool = True, want_glrlm: bool = True,
-               out_glcm: torch.Tensor | None = None, out_glrlm: torch.Tensor | None = None):
+               out_glcm: torch.Tensor | None = None, out_glrlm: torch.Tensor | None = None, angles=None):
     """GLCM [Ng,Ng,Na] and GLRLM [Ng,Nr,Na] (float64, on the device) of one discretised volume in segment
-    mode, distance 1.  Returns (glcm, glrlm, angles)."""
+    mode, distance 1.  Returns (glcm, glrlm, angles).  `angles` (int32 [na, Nd]) restricts the sweep to a subset
+    of the unidirectional distance-1 angles -- the angle shard of one rank when one segment is spread over
+    several GPUs (batch.segment_matrices_sharded); the outputs then carry those na angles only."""
     lib, image, mask, size = _prep(image, mask)
     f2d = int(force2Ddimension) if force2D else -1
-    angles = _build_angles(size, None, False, f2d)
+    if angles is None:
+        angles = _build_angles(size, None, False, f2d)
+    else:
+        angles = np.ascontiguousarray(np.asarray(angles, dtype=np.intc))
+        if angles.ndim != 2 or angles.shape[1] != image.dim() or angles.shape[0] < 1:
+            raise ValueError("angles must be int32 [na >= 1, Nd]")
     Na, Nd = angles.shape
     if Nr is None:
         Nr = int(max(image.shape))
@@ -63,12 +70,24 @@ def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None 
     return out_glcm, out_glrlm, angles
 
 
+def pair_angles(shape, distances=(1,), force2D: bool = False, force2Ddimension: int = 0):
+    """the unidirectional angle set GLCM (any distances) / GLRLM (distance 1) use for a volume of this shape"""
+    size = np.asarray(shape, dtype=np.intc)
+    return _build_angles(size, list(distances), False, int(force2Ddimension) if force2D else -1)
+
+
 def glcm(image: torch.Tensor, mask: torch.Tensor, Ng: int, distances=(1,), force2D: bool = False,
-         force2Ddimension: int = 0):
-    """GLCM [Ng, Ng, Na] float64 on the device for arbitrary distances (segment mode).  Returns (glcm, angles)."""
+         force2Ddimension: int = 0, angles=None):
+    """GLCM [Ng, Ng, Na] float64 on the device for arbitrary distances (segment mode).  Returns (glcm, angles).
+    `angles` restricts the call to a subset of the angle set (see glcm_glrlm)."""
     lib, image, mask, size = _prep(image, mask)
     f2d = int(force2Ddimension) if force2D else -1
-    angles = _build_angles(size, list(distances), False, f2d)
+    if angles is None:
+        angles = _build_angles(size, list(distances), False, f2d)
+    else:
+        angles = np.ascontiguousarray(np.asarray(angles, dtype=np.intc))
+        if angles.ndim != 2 or angles.shape[1] != image.dim() or angles.shape[0] < 1:
+            raise ValueError("angles must be int32 [na >= 1, Nd]")
     Na, Nd = angles.shape
     out = torch.empty((Ng, Ng, Na), dtype=torch.float64, device=image.device)
     rc = lib.prad_calculate_glcm_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
@@ -200,6 +219,46 @@ def ngtdm(image: torch.Tensor, mask: torch.Tensor, Ng: int, distances=(1,), forc
                                       _iptr(angles), Na, int(Ng), 1, None, 0, f2d, C.c_void_p(out.data_ptr()),
                                       _stream_ptr())
     _lib.raise_for(rc, "NGTDM")
+    return out
+
+
+NEIGH_GLDM, NEIGH_NGTDM = 0, 1
+
+
+def neigh_angles(shape, distances=(1,), force2D: bool = False, force2Ddimension: int = 0):
+    """the bidirectional angle set GLDM / NGTDM use for a volume of this shape (int32 [Na, Nd])"""
+    size = np.asarray(shape, dtype=np.intc)
+    return _build_angles(size, list(distances), True, int(force2Ddimension) if force2D else -1)
+
+
+def neigh_accumulate(family: int, image: torch.Tensor, mask: torch.Tensor, Ng: int, z_lo: int, z_hi: int,
+                     alpha: int = 0, distances=(1,), force2D: bool = False, force2Ddimension: int = 0):
+    """Integer accumulators int64 [Ng, Na+1] (on the device) of GLDM (family NEIGH_GLDM) or NGTDM (NEIGH_NGTDM) for
+    the centre voxels in planes z_lo <= z < z_hi of a 3-D volume; neighbours come from the whole volume.  The
+    accumulators of disjoint plane ranges sum to those of the whole volume (prad_neigh_accumulate_dev)."""
+    lib, image, mask, size, f2d, angles = _neigh_common(image, mask, list(distances), force2D, force2Ddimension)
+    Na, Nd = angles.shape
+    acc = torch.empty((Ng, Na + 1), dtype=torch.int64, device=image.device)
+    rc = lib.prad_neigh_accumulate_dev(int(family), C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()),
+                                       _iptr(size), Nd, _iptr(angles), Na, int(Ng), int(alpha), int(z_lo), int(z_hi),
+                                       C.c_void_p(acc.data_ptr()), _stream_ptr())
+    _lib.raise_for(rc, "GLDM" if family == NEIGH_GLDM else "NGTDM")
+    return acc
+
+
+def neigh_finalize(family: int, acc: torch.Tensor) -> torch.Tensor:
+    """GLDM [Ng, 2*Na+1] / NGTDM [Ng, 3] float64 (on the device) from summed accumulators [Ng, Na+1]"""
+    lib = _lib.load()
+    acc = acc.contiguous()
+    if acc.dtype != torch.int64 or acc.dim() != 2:
+        raise ValueError("acc must be int64 [Ng, Na+1]")
+    Ng, W = acc.shape
+    Na = W - 1
+    lib.prad_set_device(acc.device.index or 0)
+    out = torch.empty((Ng, 2 * Na + 1) if family == NEIGH_GLDM else (Ng, 3), dtype=torch.float64, device=acc.device)
+    rc = lib.prad_neigh_finalize_dev(int(family), C.c_void_p(acc.data_ptr()), int(Ng), int(Na),
+                                     C.c_void_p(out.data_ptr()), _stream_ptr())
+    _lib.raise_for(rc, "GLDM" if family == NEIGH_GLDM else "NGTDM")
     return out
 
 

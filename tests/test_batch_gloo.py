@@ -123,3 +123,78 @@ def test_voxel_maps_sharded_over_two_ranks(oracle_port):
         assert set(got[0][cname]) == set(maps)
         for k, v in maps.items():
             assert np.array_equal(got[0][cname][k], v, equal_nan=True), (cname, k)
+
+
+# ---- one segment over all ranks: angle / z-slab / level split + one exchange step -----------------------------
+def _segment_inputs():
+    rng = np.random.default_rng(11)
+    shape = (9, 12, 10)
+    field = rng.random(shape)
+    for ax in range(3):                              # a little smoothing: zones and runs longer than one voxel
+        field = field + np.roll(field, 1, axis=ax)
+    image = (1 + np.floor((field - field.min()) / (np.ptp(field) + 1e-9) * 6)).astype(np.int32)   # levels 1..6
+    mask = (rng.random(shape) < 0.85).astype(np.uint8)
+    return image, mask, 6
+
+
+def _segment_rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import binding
+    from oracle.segment_ops import OracleSegmentOps
+    from pyradiomics_amd import batch
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    image, mask, Ng = _segment_inputs()
+    if rank == 0:                                    # only rank 0 holds the volume: one broadcast replicates it
+        img_t, msk_t = batch.replicate_volume(torch.from_numpy(image), torch.from_numpy(mask), src=0)
+    else:
+        img_t, msk_t = batch.replicate_volume(None, None, src=0, device="cpu")
+    res = batch.segment_matrices_sharded(img_t, msk_t, Ng, alpha=1, ops=OracleSegmentOps(binding.port()))
+    part = batch.segment_partials(img_t, msk_t, Ng, rank, world, alpha=1, ops=OracleSegmentOps(binding.port()))
+    q.put((rank, {k: (v.numpy() if hasattr(v, "numpy") else v) for k, v in res.items()},
+           {k: v.numpy() for k, v in part.items() if k in ("glcm", "gldm_acc")}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_segment_over_two_ranks_matches_single_process(oracle_port):
+    import torch.multiprocessing as mp
+    image, mask, Ng = _segment_inputs()
+    cm = oracle_port
+    glcm, angles = cm.calculate_glcm(image, mask, [1], Ng, False, 0)
+    glrlm, _ = cm.calculate_glrlm(image, mask, Ng, max(image.shape), False, 0)
+    gldm = cm.calculate_gldm(image, mask, [1], Ng, 1, False, 0)
+    ngtdm = cm.calculate_ngtdm(image, mask, [1], Ng, False, 0)
+    glszm = cm.calculate_glszm(image, mask, Ng, int(mask.sum()), False, 0)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 977) % 2000
+    procs = [ctx.Process(target=_segment_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in procs:
+        rank, res, part = q.get(timeout=240)
+        got[rank] = (res, part)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):                              # every rank ends with the whole result
+        res = got[rank][0]
+        assert np.array_equal(res["glcm_angles"], angles)
+        assert np.array_equal(res["glcm"], glcm[0])
+        assert np.array_equal(res["glrlm"], glrlm[0])
+        assert np.array_equal(res["gldm"], gldm[0])
+        assert np.array_equal(res["ngtdm"][:, [0, 2]], ngtdm[0][:, [0, 2]])
+        np.testing.assert_allclose(res["ngtdm"][:, 1], ngtdm[0][:, 1], rtol=1e-12)   # raster-order float sum
+        P, sizes = res["glszm"]
+        dense = np.zeros_like(glszm[0])
+        dense[:, sizes - 1] = P
+        assert np.array_equal(dense, glszm[0])
+    # the shares really are disjoint: angle columns of the pair counts, planes of the dependence accumulators
+    a0, a1 = got[0][1]["glcm"], got[1][1]["glcm"]
+    assert not a0[:, :, 1::2].any() and not a1[:, :, 0::2].any() and a0.any() and a1.any()
+    assert got[0][1]["gldm_acc"].sum() + got[1][1]["gldm_acc"].sum() == int(mask.sum())
+    assert 0 < got[0][1]["gldm_acc"].sum() < int(mask.sum())

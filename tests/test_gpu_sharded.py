@@ -1,0 +1,130 @@
+"""GPU parity of the pieces behind `batch.segment_matrices_sharded` (one segment over several GPUs): the angle
+shards of GLCM / GLRLM, the plane-range accumulators of GLDM / NGTDM (prad_neigh_accumulate_dev /
+prad_neigh_finalize_dev) and the level shards of GLSZM.  One GPU plays every rank in turn; the shares are summed
+as the exchange step would and must reproduce the single-device matrices bit for bit, and the oracle's."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _volume(seed, shape, Ng, frac=0.9, smooth=True):
+    rng = np.random.default_rng(seed)
+    f = rng.random(shape)
+    if smooth:
+        for ax in range(len(shape)):
+            f = f + np.roll(f, 1, axis=ax) + np.roll(f, 2, axis=ax)
+    img = np.minimum(1 + np.floor((f - f.min()) / (np.ptp(f) + 1e-9) * Ng), Ng).astype(np.int32)
+    mask = (rng.random(shape) < frac).astype(np.uint8)
+    return img, mask
+
+
+def _sum_shares(img_t, msk_t, Ng, world, **kw):
+    from pyradiomics_amd import batch
+    total = None
+    tables = []
+    for rank in range(world):
+        part = batch.segment_partials(img_t, msk_t, Ng, rank, world, **kw)
+        tables.append(part.pop("glszm"))
+        if total is None:
+            total = part
+        else:
+            for k in ("glcm", "glrlm", "gldm_acc", "ngtdm_acc"):
+                total[k] = total[k] + part[k]
+    total["glszm"] = batch.merge_zone_tables(tables, Ng)
+    return total
+
+
+@pytest.mark.parametrize("shape,world,alpha,force2D", [
+    ((20, 18, 24), 2, 0, False),     # packed-byte neighbour kernel (Nx % 4 == 0)
+    ((20, 18, 24), 8, 0, False),
+    ((21, 17, 23), 3, 0, False),     # one-lane-per-voxel neighbour kernel
+    ((20, 18, 24), 3, 1, False),     # alpha > 0: GLDM on the general kernel, NGTDM packed
+    ((12, 20, 16), 5, 0, True),      # force2D: in-plane neighbourhoods, no halo
+    ((5, 16, 16), 8, 0, False),      # more ranks than planes: some ranks own nothing
+])
+def test_shares_sum_to_single_device_matrices(shape, world, alpha, force2D, oracle_port):
+    import torch
+    from pyradiomics_amd import engine
+    Ng = 7
+    img, mask = _volume(3, shape, Ng)
+    dev = torch.device("cuda", 0)
+    img_t, msk_t = torch.from_numpy(img).to(dev), torch.from_numpy(mask).to(dev)
+    tot = _sum_shares(img_t, msk_t, Ng, world, alpha=alpha, force2D=force2D, force2Ddimension=0)
+    g, r, angles = engine.glcm_glrlm(img_t, msk_t, Ng, None, force2D, 0)
+    assert np.array_equal(tot["glcm_angles"], angles)
+    assert torch.equal(tot["glcm"], g) and torch.equal(tot["glrlm"], r)
+    gldm = engine.neigh_finalize(engine.NEIGH_GLDM, tot["gldm_acc"])
+    ngtdm = engine.neigh_finalize(engine.NEIGH_NGTDM, tot["ngtdm_acc"])
+    assert torch.equal(gldm, engine.gldm(img_t, msk_t, Ng, alpha, (1,), force2D, 0))
+    assert torch.equal(ngtdm, engine.ngtdm(img_t, msk_t, Ng, (1,), force2D, 0))      # same integer sums: bit-equal
+    P, sizes = engine.glszm_compact(img_t, msk_t, Ng, None, force2D, 0)
+    assert np.array_equal(tot["glszm"][1], sizes) and np.array_equal(tot["glszm"][0], P.cpu().numpy())
+    # and the oracle
+    cm = oracle_port
+    assert np.array_equal(g.cpu().numpy(), cm.calculate_glcm(img, mask, [1], Ng, force2D, 0)[0][0])
+    assert np.array_equal(gldm.cpu().numpy(), cm.calculate_gldm(img, mask, [1], Ng, alpha, force2D, 0)[0])
+    ref = cm.calculate_ngtdm(img, mask, [1], Ng, force2D, 0)[0]
+    got = ngtdm.cpu().numpy()
+    assert np.array_equal(got[:, [0, 2]], ref[:, [0, 2]])
+    np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=1e-12)
+
+
+def test_accumulators_match_numpy_restatement(oracle_port):
+    """plane-range accumulators against oracle/segment_ops.py for an interior, a first and a last range"""
+    import torch
+    from oracle.segment_ops import OracleSegmentOps
+    from pyradiomics_amd import engine
+    Ng = 9
+    img, mask = _volume(5, (14, 12, 16), Ng, frac=0.8)
+    dev = torch.device("cuda", 0)
+    img_t, msk_t = torch.from_numpy(img).to(dev), torch.from_numpy(mask).to(dev)
+    ops = OracleSegmentOps(oracle_port)
+    for family, alpha in ((0, 0), (0, 2), (1, 0)):
+        for lo, hi in ((0, 14), (0, 3), (4, 9), (13, 14), (6, 6)):
+            got = engine.neigh_accumulate(family, img_t, msk_t, Ng, lo, hi, alpha)
+            want = ops.neigh_accumulate(family, torch.from_numpy(img), torch.from_numpy(mask), Ng, lo, hi, alpha,
+                                        (1,), False, 0)
+            assert got.dtype == torch.int64 and torch.equal(got.cpu(), want), (family, alpha, lo, hi)
+
+
+def test_glcm_with_other_distances_by_angle():
+    import torch
+    from pyradiomics_amd import batch, engine
+    Ng = 6
+    img, mask = _volume(8, (10, 12, 14), Ng)
+    dev = torch.device("cuda", 0)
+    img_t, msk_t = torch.from_numpy(img).to(dev), torch.from_numpy(mask).to(dev)
+    whole, angles = engine.glcm(img_t, msk_t, Ng, (1, 2))
+    tot = None
+    for rank in range(4):
+        part = batch.segment_partials(img_t, msk_t, Ng, rank, 4, classes=("glcm",), distances=(1, 2))
+        tot = part["glcm"] if tot is None else tot + part["glcm"]
+    assert np.array_equal(part["glcm_angles"], angles) and len(angles) == 62
+    assert torch.equal(tot, whole)
+
+
+def test_single_rank_call_and_errors():
+    import torch
+    from pyradiomics_amd import batch, engine
+    Ng = 5
+    img, mask = _volume(9, (8, 8, 8), Ng)
+    dev = torch.device("cuda", 0)
+    img_t, msk_t = torch.from_numpy(img).to(dev), torch.from_numpy(mask).to(dev)
+    res = batch.segment_matrices_sharded(img_t, msk_t, Ng)                   # world == 1: no process group needed
+    assert torch.equal(res["gldm"], engine.gldm(img_t, msk_t, Ng))
+    assert torch.equal(res["ngtdm"], engine.ngtdm(img_t, msk_t, Ng))
+    assert torch.equal(res["glrlm"], engine.glcm_glrlm(img_t, msk_t, Ng)[1])
+    rep_i, rep_m = batch.replicate_volume(img_t, msk_t)
+    assert rep_i.dtype == torch.int32 and rep_m.dtype == torch.uint8
+    bad = img_t.clone()
+    bad[2, 3, 4] = Ng + 1
+    msk_all = torch.ones_like(msk_t)
+    with pytest.raises(IndexError):
+        engine.neigh_accumulate(engine.NEIGH_GLDM, bad, msk_all, Ng, 0, 8)
+    with pytest.raises(ValueError):
+        engine.neigh_accumulate(engine.NEIGH_GLDM, img_t, msk_t, Ng, 3, 9)    # plane range outside the volume
+    with pytest.raises(NotImplementedError):
+        engine.neigh_accumulate(engine.NEIGH_NGTDM, img_t[0].contiguous(), msk_t[0].contiguous(), Ng, 0, 1)
+    with pytest.raises(IndexError):
+        batch.segment_matrices_sharded(img_t, torch.zeros_like(msk_t), Ng, classes=("glszm",))
