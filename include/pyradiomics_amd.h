@@ -121,7 +121,9 @@ int prad_calculate_gldm_dev(const int32_t *image, const uint8_t *mask, const int
 
 /* ---- NGTDM: calculate_ngtdm (cmatrices.c:543-658) ------------------------------------------------ */
 /* ngtdm: float64 [Nvox][Ng][3].  Column 1 (sum of |i - mean(neighbours)|) is evaluated as
- * sum_c (sum_p |c*i - s|)/c with exact integer inner sums in segment mode (<= 1e-12 relative from the
+ * sum_c (sum_p |c*i - s|)/c with exact integer inner sums in segment mode (correctly rounded to a few ulp; the
+ * reference's own raster-order sum of Nv rounded terms drifts from that by ~1e-13 .. 1e-12 relative at 10^6
+ * voxels -- tests bound the distance to the exact rational value and to the
  * reference's raster-order float64 sum) and in raster order -- bit-identical -- in voxel mode. */
 int prad_calculate_ngtdm(const int32_t *image, const uint8_t *mask, const int *size, int Nd,
                          const int *angles, int Na, int Ng,
