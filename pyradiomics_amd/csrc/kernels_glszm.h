@@ -20,6 +20,7 @@
 #include <algorithm>
 #include "prad_runtime.h"
 #include "kernels_generic.h"
+#include "kernels_neigh.h"
 
 namespace prad {
 
@@ -116,8 +117,12 @@ __global__ void __launch_bounds__(256) glszm_merge_kernel(Geo g, const int *__re
 // ---- tiled variant (Nd <= 3): zones are first labelled inside 4 x 8 x 64 tiles entirely in LDS, then only voxel
 // pairs that straddle a tile boundary are united in HBM.  Most unions (and all of their retries on large zones)
 // never leave the CU; the global forest starts from one root per (zone, tile) instead of one per voxel.
+#ifndef PRAD_TZ
 #define PRAD_TZ 8
+#endif
+#ifndef PRAD_TY
 #define PRAD_TY 8
+#endif
 #define PRAD_TX 64
 #define PRAD_TVOX (PRAD_TZ * PRAD_TY * PRAD_TX)
 struct Offsets3 {
@@ -374,6 +379,387 @@ __global__ void __launch_bounds__(256) glszm_border_full_kernel(const int *__res
   }
 }
 
+// ---- packed-byte variants (levels 1..255 as uint8, 0 = outside the ROI; the volume pack_levels writes for the
+// GLDM / NGTDM kernels) for the full 26- (MODE 1) / in-plane 8-neighbourhood (MODE 2).
+// Tile kernel: a lane owns 4 x-adjacent voxels (one LDS dword).  The tile sits in LDS with a zero halo (one plane
+// above, one row either side in y, one dword either side in x), so a neighbour outside the tile simply never
+// compares equal and no bounds are tested.  For each of the 4 (dz, dy) rows of backward neighbours the lane reads
+// 3 dwords and derives the "same level" flags of its 4 voxels with packed-byte arithmetic (xor with the replicated
+// centre level, zero-byte test) -- ~27 VALU and ~4 LDS reads per voxel instead of 13 neighbours x (bounds test,
+// address, two LDS reads, compare).  Unions, flattening and the per-component counts are those of glszm_tile_kernel.
+#define PRAD_T8_ROWDW (PRAD_TX / 4 + 2)                       // dwords per padded LDS row
+#define PRAD_T8_DW ((PRAD_TZ + 1) * (PRAD_TY + 2) * PRAD_T8_ROWDW)
+__device__ __forceinline__ unsigned t8_nonzero3(unsigned w) {  // bit 7 of every non-zero byte of the low 3 (exact)
+  return (((w & 0x7f7f7fu) + 0x7f7f7fu) | w) & 0x808080u;
+}
+// The 13 backward neighbours of a voxel as bit positions n:  n = 3r + (dx + 1) for the backward rows
+//   r = 0: (dz 0, dy -1)   1: (dz -1, dy -1)   2: (dz -1, dy 0)   3: (dz -1, dy +1),   and n = 12: (0, 0, -1).
+// t8_flags3 turns the per-byte equality bits (7 / 15 / 23) of one row into 3 contiguous bits.
+__device__ __forceinline__ unsigned t8_flags3(unsigned e) {
+  const unsigned t = (e >> 7) & 0x010101u;
+  return (t | (t >> 7) | (t >> 14)) & 7u;
+}
+__device__ __forceinline__ void t8_offset(int n, int &dz, int &dy, int &dx) {
+  const int r = (n * 11) >> 5;                       // n / 3 for n < 16
+  dz = (n >= 3 && n < 12) ? -1 : 0;
+  dy = n >= 12 ? 0 : (r == 0 ? -1 : r - 2);
+  dx = n >= 12 ? -1 : n - 3 * r - 1;
+}
+// Which of the "same level" neighbours S (13 bits) a voxel still has to be united with (redundancy rules of
+// glszm_tile_kernel): a neighbour adjacent -- within its plane -- to one already selected is tied to it by that
+// plane's own unions.  Branch-free, so the selection of a whole lane is plain ALU work and the (divergent, latency
+// bound) unions run afterwards in one compact loop over the set bits.
+template <int MODE>
+__device__ __forceinline__ unsigned t8_select(unsigned S) {
+  const bool b = S & 2u, a = S & 1u;
+  unsigned sel = b ? 2u : ((S & 4u) | (a ? 1u : (S & 0x1000u)));
+  if (MODE == 1) {
+    const bool m = S & 0x80u, e1 = S & 0x10u, e3 = S & 0x40u, e4 = S & 0x100u, e2 = S & 0x400u;
+    unsigned up = S & 0x550u;                                            // the four edge neighbours
+    up |= (!e1 && !e3) ? (S & 0x8u) : 0u;
+    up |= (!e1 && !e4) ? (S & 0x20u) : 0u;
+    up |= (!e2 && !e3) ? (S & 0x200u) : 0u;
+    up |= (!e2 && !e4) ? (S & 0x800u) : 0u;
+    sel |= m ? 0x80u : up;
+  }
+  return sel;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx,
+                                                          int *__restrict__ labels, unsigned *__restrict__ sizes,
+                                                          const int *__restrict__ flags) {
+  __shared__ unsigned lev[PRAD_T8_DW];
+  __shared__ int lab[PRAD_TVOX];
+  if (flags[0]) return;   // a masked level outside 1..Ng: the int32 kernels redo this call
+  const int tx = (Nx + PRAD_TX - 1) / PRAD_TX, ty = (Ny + PRAD_TY - 1) / PRAD_TY;
+  const int bz = blockIdx.x / (ty * tx), br = blockIdx.x % (ty * tx);
+  const int z0 = bz * PRAD_TZ, y0 = (br / tx) * PRAD_TY, x0 = (br % tx) * PRAD_TX;
+  for (int i = threadIdx.x; i < PRAD_T8_DW; i += blockDim.x) lev[i] = 0u;
+  __syncthreads();
+  const bool vec = (Nx & 3) == 0;   // every quad is a 4-byte aligned dword of the volume (and of labels / sizes rows)
+  constexpr int QPT = PRAD_TVOX / 4 / 256;   // quads per lane
+  unsigned cw[QPT];
+#pragma unroll
+  for (int q = 0; q < QPT; q++) {
+    const int quad = threadIdx.x + q * 256;
+    const int lx4 = quad & 15, ly = (quad >> 4) % PRAD_TY, lz = quad / (16 * PRAD_TY);
+    const int z = z0 + lz, y = y0 + ly, x = x0 + 4 * lx4;
+    unsigned w = 0u;
+    if (z < Nz && y < Ny && x < Nx) {
+      const long long gi = ((long long)z * Ny + y) * Nx + x;
+      if (vec) w = *reinterpret_cast<const unsigned *>(L + gi);
+      else
+        for (int b = 0; b < 4; b++)
+          if (x + b < Nx) w |= (unsigned)L[gi + b] << (8 * b);
+    }
+    cw[q] = w;
+    lev[((lz + 1) * (PRAD_TY + 2) + (ly + 1)) * PRAD_T8_ROWDW + 1 + lx4] = w;
+#pragma unroll
+    for (int b = 0; b < 4; b++) lab[quad * 4 + b] = quad * 4 + b;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < QPT; q++) {
+    const unsigned centre = cw[q];
+    if (!centre) continue;
+    const int quad = threadIdx.x + q * 256;
+    const int lx4 = quad & 15, ly = (quad >> 4) % PRAD_TY, lz = quad / (16 * PRAD_TY);
+    const unsigned *row0 = lev + ((lz + 1) * (PRAD_TY + 2) + (ly + 1)) * PRAD_T8_ROWDW + lx4;   // [0] left, [1] mid, [2] right
+    // e[r][k]: bits 7 / 15 / 23 = voxel k has the level of its neighbour at dx = -1 / 0 / +1 in backward row r
+    //   r = 0: (dz 0, dy -1)   1: (dz -1, dy -1)   2: (dz -1, dy 0)   3: (dz -1, dy +1)
+    unsigned e[4][4];
+    unsigned crep[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) crep[k] = ((centre >> (8 * k)) & 0xffu) * 0x010101u;
+#pragma unroll
+    for (int r = 0; r < (MODE == 1 ? 4 : 1); r++) {
+      const int dz = r == 0 ? 0 : -1, dy = r == 0 ? -1 : r - 2;
+      const unsigned *rp = row0 + (dz * (PRAD_TY + 2) + dy) * PRAD_T8_ROWDW;
+      const unsigned left = rp[0], mid = rp[1], right = rp[2];
+      const unsigned lo = (left >> 24) | (mid << 8), hi = (mid >> 24) | (right << 8);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned w = __builtin_amdgcn_alignbyte(hi, lo, k) & 0xffffffu;
+        e[r][k] = t8_nonzero3(w ^ crep[k]) ^ 0x808080u;
+      }
+    }
+    const unsigned lo0 = (row0[0] >> 24) | (centre << 8);      // bytes x-1 of the 4 voxels, own row
+    unsigned long long todo = 0ull;                            // bit 16k + n: unite voxel k with its neighbour n
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned c = (centre >> (8 * k)) & 0xffu;
+      unsigned S = t8_flags3(e[0][k]) | ((((lo0 >> (8 * k)) & 0xffu) == c) ? 0x1000u : 0u);
+      if (MODE == 1) S |= (t8_flags3(e[1][k]) << 3) | (t8_flags3(e[2][k]) << 6) | (t8_flags3(e[3][k]) << 9);
+      todo |= (unsigned long long)(c ? t8_select<MODE>(S) : 0u) << (16 * k);
+    }
+    while (todo) {
+      const int bit = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      int dz, dy, dx;
+      t8_offset(bit & 15, dz, dy, dx);
+      const int idx = quad * 4 + (bit >> 4);
+      lds_union(lab, idx, idx + dz * (PRAD_TX * PRAD_TY) + dy * PRAD_TX + dx);
+    }
+  }
+  __syncthreads();
+  int root[QPT][4];
+#pragma unroll
+  for (int q = 0; q < QPT; q++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int idx = (threadIdx.x + q * 256) * 4 + k;
+      root[q][k] = ((cw[q] >> (8 * k)) & 0xffu) ? lds_find(lab, idx) : -1;
+    }
+  __syncthreads();
+  unsigned *cnt = reinterpret_cast<unsigned *>(lab);          // the roots are in registers: lab becomes the counts
+  for (int k = threadIdx.x; k < PRAD_TVOX; k += blockDim.x) cnt[k] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < QPT; q++) {
+    int prev = -1;
+    unsigned run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int r = root[q][k];
+      if (r != prev) {
+        if (prev >= 0) atomicAdd(cnt + prev, run);
+        prev = r;
+        run = 0;
+      }
+      run++;
+    }
+    if (prev >= 0) atomicAdd(cnt + prev, run);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < QPT; q++) {
+    const int quad = threadIdx.x + q * 256;
+    const int lx4 = quad & 15, ly = (quad >> 4) % PRAD_TY, lz = quad / (16 * PRAD_TY);
+    const int z = z0 + lz, y = y0 + ly, x = x0 + 4 * lx4;
+    if (z >= Nz || y >= Ny || x >= Nx) continue;
+    const long long gi = ((long long)z * Ny + y) * Nx + x;
+    int lb[4];
+    unsigned sz[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int r = root[q][k];
+      if (r < 0) { lb[k] = -1; sz[k] = 0u; continue; }
+      const int rx = r % PRAD_TX, ry = (r / PRAD_TX) % PRAD_TY, rz = r / (PRAD_TX * PRAD_TY);
+      lb[k] = (int)(((long long)(z0 + rz) * Ny + (y0 + ry)) * Nx + (x0 + rx));
+      sz[k] = r == quad * 4 + k ? cnt[r] : 0u;
+    }
+    if (vec) {
+      *reinterpret_cast<int4 *>(labels + gi) = make_int4(lb[0], lb[1], lb[2], lb[3]);
+      *reinterpret_cast<uint4 *>(sizes + gi) = make_uint4(sz[0], sz[1], sz[2], sz[3]);
+    } else {
+      for (int k = 0; k < 4; k++)
+        if (x + k < Nx) { labels[gi + k] = lb[k]; sizes[gi + k] = sz[k]; }
+    }
+  }
+}
+
+// glszm_border_full_kernel on the packed levels: one byte load per neighbour instead of mask + int32 level
+template <int MODE>
+__global__ void __launch_bounds__(256) glszm_border8_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx,
+                                                            int *__restrict__ labels, const int *__restrict__ flags) {
+  if (flags[0]) return;
+  const int lane = threadIdx.x & 63;
+  const long long nrows = (long long)Nz * Ny;
+  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  const int xtiles = (Nx + PRAD_TX - 1) / PRAD_TX;
+  for (long long row = wave0; row < nrows; row += nwaves) {
+    const int z = (int)(row / Ny), y = (int)(row - (long long)z * Ny);
+    const bool row_edge = (MODE == 1 && z % PRAD_TZ == 0) || (y % PRAD_TY == 0) || (MODE == 1 && y % PRAD_TY == PRAD_TY - 1);
+    const int count = row_edge ? Nx : 2 * xtiles;
+    const long long rbase = row * Nx;
+    for (int c0 = 0; c0 < count; c0 += 64) {
+      const int c = c0 + lane;
+      int x = -1;
+      if (c < count) x = row_edge ? c : (c >> 1) * PRAD_TX + ((c & 1) ? PRAD_TX - 1 : 0);
+      int gl = 0, li = -1;
+      if (x >= 0 && x < Nx) {
+        gl = L[rbase + x];
+        if (gl) li = labels[rbase + x];
+      }
+      if (__ballot(li >= 0) == 0ull) continue;
+      auto same = [&](int dz, int dy, int dx) -> long long {
+        const int qz = z + dz, qy = y + dy, qx = x + dx;
+        if ((unsigned)qz >= (unsigned)Nz || (unsigned)qy >= (unsigned)Ny || (unsigned)qx >= (unsigned)Nx) return -1;
+        const long long j = ((long long)qz * Ny + qy) * Nx + qx;
+        return L[j] == gl ? j : -1;
+      };
+      auto pair = [&](long long j, int dz, int dy, int dx) {
+        int lj = -1;
+        if (j >= 0) {
+          const int qz = z + dz, qy = y + dy, qx = x + dx;
+          const bool same_tile = qz / PRAD_TZ == z / PRAD_TZ && qy / PRAD_TY == y / PRAD_TY && qx / PRAD_TX == x / PRAD_TX;
+          if (!same_tile) lj = labels[j];
+        }
+        const int pi = __shfl_up(li, 1), pj = __shfl_up(lj, 1);
+        if (lj >= 0 && !(lane > 0 && pi == li && pj == lj)) uf_union(labels, li, lj);
+      };
+      const bool live = li >= 0;
+      const long long jb = live ? same(0, -1, 0) : -1;
+      pair(jb, 0, -1, 0);
+      const bool nb = live && jb < 0;
+      const long long jc = nb ? same(0, -1, 1) : -1;
+      pair(jc, 0, -1, 1);
+      const long long ja = nb ? same(0, -1, -1) : -1;
+      pair(ja, 0, -1, -1);
+      const long long jd = (nb && ja < 0) ? same(0, 0, -1) : -1;
+      pair(jd, 0, 0, -1);
+      if (MODE == 1) {
+        const long long jm = live ? same(-1, 0, 0) : -1;
+        pair(jm, -1, 0, 0);
+        const bool nm = live && jm < 0;
+        const long long e1 = nm ? same(-1, -1, 0) : -1, e2 = nm ? same(-1, 1, 0) : -1;
+        const long long e3 = nm ? same(-1, 0, -1) : -1, e4 = nm ? same(-1, 0, 1) : -1;
+        pair(e1, -1, -1, 0);
+        pair(e2, -1, 1, 0);
+        pair(e3, -1, 0, -1);
+        pair(e4, -1, 0, 1);
+        pair((nm && e1 < 0 && e3 < 0) ? same(-1, -1, -1) : -1, -1, -1, -1);
+        pair((nm && e1 < 0 && e4 < 0) ? same(-1, -1, 1) : -1, -1, -1, 1);
+        pair((nm && e2 < 0 && e3 < 0) ? same(-1, 1, -1) : -1, -1, 1, -1);
+        pair((nm && e2 < 0 && e4 < 0) ? same(-1, 1, 1) : -1, -1, 1, 1);
+      }
+    }
+  }
+}
+
+// Border scan on the packed levels, 4 voxels per lane (Nx % 4 == 0).  Two loops over the rows (z, y):
+//   A  rows on a z- or y-face of their tile: a lane takes 4 x-adjacent voxels, gets the "same level" flags of all
+//      their backward neighbours from 3 loads per neighbour row (as glszm_tile8_kernel, but on global memory),
+//      applies the redundancy rules to GLOBAL sameness (see glszm_border_full_kernel) and unites only the selected
+//      pairs that straddle a tile boundary; a pair (root, root) that repeats the previous one of the lane is skipped;
+//   B  all other rows: only the voxels on the two x-faces of every tile (x mod 64 in {0, 63}) can have a backward
+//      neighbour in another tile; they are enumerated densely over the lanes (several rows per wave).
+template <int MODE>
+__global__ void __launch_bounds__(256) glszm_border8q_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx,
+                                                             int *__restrict__ labels, const int *__restrict__ flags) {
+  if (flags[0]) return;
+  const int lane = threadIdx.x & 63;
+  const long long nrows = (long long)Nz * Ny;
+  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
+  const long long plane = (long long)Ny * Nx;
+  // ---- loop A
+  for (long long row = wave0; row < nrows; row += nwaves) {
+    const int z = (int)(row / Ny), y = (int)(row - (long long)z * Ny);
+    const bool zedge = MODE == 1 && (z % PRAD_TZ == 0), y0edge = (y % PRAD_TY == 0);
+    const bool y7edge = MODE == 1 && (y % PRAD_TY == PRAD_TY - 1);
+    if (!(zedge || y0edge || y7edge)) continue;
+    const long long rbase = row * Nx;
+    for (int x = 4 * lane; x < Nx; x += 256) {
+      const unsigned centre = *reinterpret_cast<const unsigned *>(L + rbase + x);
+      if (!centre) continue;
+      unsigned crep[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) crep[k] = ((centre >> (8 * k)) & 0xffu) * 0x010101u;
+      unsigned e[4][4];
+#pragma unroll
+      for (int r = 0; r < (MODE == 1 ? 4 : 1); r++) {
+        const int dz = r == 0 ? 0 : -1, dy = r == 0 ? -1 : r - 2;
+        const int qz = z + dz, qy = y + dy;
+        unsigned lo = 0u, hi = 0u;
+        if ((unsigned)qz < (unsigned)Nz && (unsigned)qy < (unsigned)Ny) {
+          const uint8_t *rp = L + rbase + dz * plane + (long long)dy * Nx + x;
+          const unsigned mid = *reinterpret_cast<const unsigned *>(rp);
+          const unsigned left = x > 0 ? rp[-1] : 0u, right = x + 4 < Nx ? rp[4] : 0u;
+          lo = left | (mid << 8);
+          hi = (mid >> 24) | (right << 8);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned w = __builtin_amdgcn_alignbyte(hi, lo, k) & 0xffffffu;
+          e[r][k] = t8_nonzero3(w ^ crep[k]) ^ 0x808080u;
+        }
+      }
+      const unsigned lo0 = (x > 0 ? (unsigned)L[rbase + x - 1] : 0u) | (centre << 8);
+      // neighbours that lie in another tile: by row (wave-uniform) and by the voxel's position on an x-face
+      const unsigned rowcross = (zedge ? 0xff8u : 0u) | (y0edge ? 0x3fu : 0u) | (y7edge ? 0xe00u : 0u);
+      unsigned long long todo = 0ull;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned c = (centre >> (8 * k)) & 0xffu;
+        unsigned S = t8_flags3(e[0][k]) | ((((lo0 >> (8 * k)) & 0xffu) == c) ? 0x1000u : 0u);
+        if (MODE == 1) S |= (t8_flags3(e[1][k]) << 3) | (t8_flags3(e[2][k]) << 6) | (t8_flags3(e[3][k]) << 9);
+        const int xx = x + k;
+        const unsigned cross = rowcross | ((xx % PRAD_TX) == 0 ? 0x1249u : 0u) | ((xx % PRAD_TX) == PRAD_TX - 1 ? 0x924u : 0u);
+        todo |= (unsigned long long)(c ? (t8_select<MODE>(S) & cross) : 0u) << (16 * k);
+      }
+      int pli = -1, plj = -1, lk = -1, li = -1;
+      while (todo) {
+        const int bit = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int k = bit >> 4;
+        int dz, dy, dx;
+        t8_offset(bit & 15, dz, dy, dx);
+        const long long i = rbase + x + k;
+        if (k != lk) { li = labels[i]; lk = k; }
+        const int lj = labels[i + dz * plane + (long long)dy * Nx + dx];
+        if (li == pli && lj == plj) continue;      // the same two tile components as the previous pair
+        pli = li;
+        plj = lj;
+        uf_union(labels, li, lj);
+      }
+    }
+  }
+  // ---- loop B: x-faces of the tiles in the remaining rows
+  const int xtiles = (Nx + PRAD_TX - 1) / PRAD_TX;
+  const int cpr = 2 * xtiles;                        // candidates per row
+  const long long ncand = nrows * cpr;
+  const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (long long)gridDim.x * blockDim.x;
+  for (long long id = tid0; id < ncand; id += nthreads) {
+    const long long row = id / cpr;
+    const int cnd = (int)(id - row * cpr);
+    const int z = (int)(row / Ny), y = (int)(row - (long long)z * Ny);
+    if ((MODE == 1 && z % PRAD_TZ == 0) || (y % PRAD_TY == 0) || (MODE == 1 && y % PRAD_TY == PRAD_TY - 1)) continue;
+    const int x = (cnd >> 1) * PRAD_TX + ((cnd & 1) ? PRAD_TX - 1 : 0);
+    if (x >= Nx) continue;
+    const long long i = row * Nx + x;
+    const int gl = L[i];
+    if (!gl) continue;
+    const int dxc = (cnd & 1) ? 1 : -1;              // the only dx that leaves the tile from this face
+    if ((unsigned)(x + dxc) >= (unsigned)Nx) continue;
+    auto same = [&](int dz, int dy, int dx) -> bool {
+      const int qz = z + dz, qy = y + dy, qx = x + dx;
+      if ((unsigned)qz >= (unsigned)Nz || (unsigned)qy >= (unsigned)Ny || (unsigned)qx >= (unsigned)Nx) return false;
+      return L[i + dz * plane + (long long)dy * Nx + dx] == gl;
+    };
+    int li = -1;
+    auto pair = [&](int dz, int dy, int dx) {
+      if (dx != dxc) return;                          // stays inside the tile (this row is on no z- / y-face)
+      if (li < 0) li = labels[i];
+      uf_union(labels, li, labels[i + dz * plane + (long long)dy * Nx + dx]);
+    };
+    // the rules need the sameness of the neighbours that can make a cross-tile pair redundant
+    if (!same(0, -1, 0)) {
+      if (dxc > 0) { if (same(0, -1, 1)) pair(0, -1, 1); }
+      else {
+        if (same(0, -1, -1)) pair(0, -1, -1);
+        else if (same(0, 0, -1)) pair(0, 0, -1);
+      }
+    }
+    if (MODE == 1 && !same(-1, 0, 0)) {
+      const bool e1 = same(-1, -1, 0), e2 = same(-1, 1, 0);
+      if (dxc < 0) {
+        const bool e3 = same(-1, 0, -1);
+        if (e3) pair(-1, 0, -1);
+        if (!e1 && !e3 && same(-1, -1, -1)) pair(-1, -1, -1);
+        if (!e2 && !e3 && same(-1, 1, -1)) pair(-1, 1, -1);
+      } else {
+        const bool e4 = same(-1, 0, 1);
+        if (e4) pair(-1, 0, 1);
+        if (!e1 && !e4 && same(-1, -1, 1)) pair(-1, -1, 1);
+        if (!e2 && !e4 && same(-1, 1, 1)) pair(-1, 1, 1);
+      }
+    }
+  }
+}
+
 // tiled path: sizes[] holds the voxel count of every tile-local component at its tile root; fold the counts of
 // tile roots that were linked elsewhere into their global root.  One find per (zone, tile) instead of per voxel.
 // A zone that spans thousands of tiles would otherwise receive thousands of atomics on one address, so every block
@@ -381,9 +767,11 @@ __global__ void __launch_bounds__(256) glszm_border_full_kernel(const int *__res
 #define PRAD_RS_SLOTS 1024
 #define PRAD_RS_CHUNK (256 * 256)      // voxels per block
 __global__ void __launch_bounds__(256) glszm_rootsum_kernel(long long n, int *__restrict__ labels,
-                                                            unsigned *__restrict__ sizes) {
+                                                            unsigned *__restrict__ sizes,
+                                                            const int *__restrict__ flags) {
   __shared__ int hkey[PRAD_RS_SLOTS];
   __shared__ unsigned hval[PRAD_RS_SLOTS];
+  if (flags && flags[0]) return;   // the packed-byte kernels did not run: labels are not valid
   for (int k = threadIdx.x; k < PRAD_RS_SLOTS; k += blockDim.x) {
     hkey[k] = -1;
     hval[k] = 0u;
@@ -452,10 +840,12 @@ __global__ void __launch_bounds__(256) glszm_stats_kernel(long long n, const int
                                                           const unsigned *__restrict__ sizes, int *__restrict__ stats,
                                                           unsigned long long *__restrict__ stats64,
                                                           unsigned *__restrict__ small_bits, int *__restrict__ large_list,
-                                                          int large_cap, int *__restrict__ large_count) {
+                                                          int large_cap, int *__restrict__ large_count,
+                                                          const int *__restrict__ flags) {
   __shared__ unsigned bits[PRAD_SMALL_SIZES / 32];
   __shared__ unsigned smx;
   __shared__ unsigned long long scnt;
+  if (flags && flags[0]) return;
   for (int k = threadIdx.x; k < PRAD_SMALL_SIZES / 32; k += blockDim.x) bits[k] = 0u;
   if (threadIdx.x == 0) { smx = 0u; scnt = 0ull; }
   __syncthreads();
@@ -726,7 +1116,6 @@ inline unsigned glszm_grid(long long n) { return (unsigned)std::max<long long>(1
 inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *image, const uint8_t *mask,
                        const int *angles_h, int Na, int Ng, int Ns, int Nvox, const int *voxels_dev, int kernelRadius,
                        int force2Ddim, long long *nzones_out) {
-  (void)Ng;
   GlszmState &st = glszm_state();
   st.valid = false;
   int *stats = nullptr;
@@ -736,6 +1125,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
   void *hp = nullptr;
   PRAD_TRY(c.get_pinned("glszm_stats_h", sizeof(int) * 8, &hp));
   int *stats_h = (int *)hp;
+  bool stats_copied = false;
 
   if (!voxels_dev) {
     if (Nvox != 1) return fail(PRAD_E_ARG, "Nvox=%d without a voxel list", Nvox);
@@ -768,42 +1158,91 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
       A3.o[A3.na][3] = 0;
       A3.na++;
     }
+    // all 13 (all 4 in-plane) backward unit offsets present => the redundancy rules of the tile kernels apply
+    int mode = 0;
     if (tiled) {
-      const long long tiles = (long long)((dims3[0] + PRAD_TZ - 1) / PRAD_TZ) * ((dims3[1] + PRAD_TY - 1) / PRAD_TY) *
-                              ((dims3[2] + PRAD_TX - 1) / PRAD_TX);
-      // all 13 (all 4 in-plane) backward unit offsets present => the redundancy rules of the tile kernel apply
-      int mode = 0;
       if (A3.na == 13) mode = 1;
       else if (A3.na == 4) {
         mode = 2;
         for (int a = 0; a < 4; a++)
           if (A3.o[a][0] != 0) mode = 0;
       }
-      hipLaunchKernelGGL(glszm_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, s, A3, mode, image, mask, dims3[0],
-                         dims3[1], dims3[2], st.labels, st.sizes);
-      PRAD_TRY(check_launch("glszm_tile_kernel"));
-      const dim3 bgrid((unsigned)std::min<long long>(((long long)dims3[0] * dims3[1] + 3) / 4, 16384));
-      if (mode == 1)
-        hipLaunchKernelGGL(glszm_border_full_kernel<1>, bgrid, dim3(256), 0, s, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
-      else if (mode == 2)
-        hipLaunchKernelGGL(glszm_border_full_kernel<2>, bgrid, dim3(256), 0, s, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
-      else
-        hipLaunchKernelGGL(glszm_border_kernel, bgrid, dim3(256), 0, s, A3, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
-      PRAD_TRY(check_launch("glszm_border_kernel"));
-      hipLaunchKernelGGL(glszm_rootsum_kernel, dim3((unsigned)((g.n + PRAD_RS_CHUNK - 1) / PRAD_RS_CHUNK)), dim3(256), 0, s,
-                         g.n, st.labels, st.sizes);
-      PRAD_TRY(check_launch("glszm_rootsum_kernel"));
-    } else {
-      hipLaunchKernelGGL(glszm_init_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, mask, g.n, st.labels, st.sizes);
-      PRAD_TRY(check_launch("glszm_init_kernel"));
-      hipLaunchKernelGGL(glszm_merge_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g, angles_d, Na, image, mask, st.labels);
-      PRAD_TRY(check_launch("glszm_merge_kernel"));
-      hipLaunchKernelGGL(glszm_flatten_count_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g.n, st.labels, st.sizes);
-      PRAD_TRY(check_launch("glszm_flatten_count_kernel"));
     }
-    hipLaunchKernelGGL(glszm_stats_kernel, dim3(std::min(glszm_grid(g.n), 1024u)), dim3(256), 0, s, g.n, st.labels,
-                       st.sizes, stats, stats64, st.small_bits, st.large_list, st.large_cap, st.large_count);
-    PRAD_TRY(check_launch("glszm_stats_kernel"));
+    // Full neighbourhoods with levels that fit a byte run on the packed uint8 volume; a masked level outside 1..Ng
+    // (flags[0], found by the pack) sends the call through the int32 kernels instead.
+    int *flags_d = nullptr, *flags_h = nullptr;
+    bool bytes = tiled && mode != 0 && Ng >= 1 && Ng <= 255;
+    if (bytes) {
+      PRAD_TRY(c.get<int>("flags", 4, &flags_d));
+      void *fp = nullptr;
+      PRAD_TRY(c.get_pinned("glszm_flags_h", sizeof(int) * 4, &fp));
+      flags_h = (int *)fp;
+    }
+    for (int attempt = 0; attempt < 2; attempt++) {
+      if (tiled) {
+        const long long tiles = (long long)((dims3[0] + PRAD_TZ - 1) / PRAD_TZ) * ((dims3[1] + PRAD_TY - 1) / PRAD_TY) *
+                                ((dims3[2] + PRAD_TX - 1) / PRAD_TX);
+        const dim3 bgrid((unsigned)std::min<long long>(((long long)dims3[0] * dims3[1] + 3) / 4, 16384));
+        if (bytes) {
+          uint8_t *levels = nullptr;
+          PRAD_HIP(hipMemsetAsync(flags_d, 0, sizeof(int) * 4, s));
+          PRAD_TRY(neigh_pack(&c, s, g, image, mask, Ng, flags_d, &levels));
+          if (mode == 1) {
+            hipLaunchKernelGGL(glszm_tile8_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, s, levels, dims3[0], dims3[1],
+                               dims3[2], st.labels, st.sizes, flags_d);
+            if ((dims3[2] & 3) == 0)
+              hipLaunchKernelGGL(glszm_border8q_kernel<1>, bgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],
+                                 st.labels, flags_d);
+            else
+              hipLaunchKernelGGL(glszm_border8_kernel<1>, bgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],
+                                 st.labels, flags_d);
+          } else {
+            hipLaunchKernelGGL(glszm_tile8_kernel<2>, dim3((unsigned)tiles), dim3(256), 0, s, levels, dims3[0], dims3[1],
+                               dims3[2], st.labels, st.sizes, flags_d);
+            if ((dims3[2] & 3) == 0)
+              hipLaunchKernelGGL(glszm_border8q_kernel<2>, bgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],
+                                 st.labels, flags_d);
+            else
+              hipLaunchKernelGGL(glszm_border8_kernel<2>, bgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],
+                                 st.labels, flags_d);
+          }
+          PRAD_TRY(check_launch("glszm_tile8/border8_kernel"));
+        } else {
+          hipLaunchKernelGGL(glszm_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, s, A3, mode, image, mask, dims3[0],
+                             dims3[1], dims3[2], st.labels, st.sizes);
+          PRAD_TRY(check_launch("glszm_tile_kernel"));
+          if (mode == 1)
+            hipLaunchKernelGGL(glszm_border_full_kernel<1>, bgrid, dim3(256), 0, s, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
+          else if (mode == 2)
+            hipLaunchKernelGGL(glszm_border_full_kernel<2>, bgrid, dim3(256), 0, s, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
+          else
+            hipLaunchKernelGGL(glszm_border_kernel, bgrid, dim3(256), 0, s, A3, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
+          PRAD_TRY(check_launch("glszm_border_kernel"));
+        }
+        hipLaunchKernelGGL(glszm_rootsum_kernel, dim3((unsigned)((g.n + PRAD_RS_CHUNK - 1) / PRAD_RS_CHUNK)), dim3(256), 0, s,
+                           g.n, st.labels, st.sizes, (const int *)(bytes ? flags_d : nullptr));
+        PRAD_TRY(check_launch("glszm_rootsum_kernel"));
+      } else {
+        hipLaunchKernelGGL(glszm_init_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, mask, g.n, st.labels, st.sizes);
+        PRAD_TRY(check_launch("glszm_init_kernel"));
+        hipLaunchKernelGGL(glszm_merge_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g, angles_d, Na, image, mask, st.labels);
+        PRAD_TRY(check_launch("glszm_merge_kernel"));
+        hipLaunchKernelGGL(glszm_flatten_count_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g.n, st.labels, st.sizes);
+        PRAD_TRY(check_launch("glszm_flatten_count_kernel"));
+      }
+      hipLaunchKernelGGL(glszm_stats_kernel, dim3(std::min(glszm_grid(g.n), 1024u)), dim3(256), 0, s, g.n, st.labels,
+                         st.sizes, stats, stats64, st.small_bits, st.large_list, st.large_cap, st.large_count,
+                         (const int *)(bytes ? flags_d : nullptr));
+      PRAD_TRY(check_launch("glszm_stats_kernel"));
+      if (!bytes) break;
+      PRAD_HIP(hipMemcpyAsync(flags_h, flags_d, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+      PRAD_HIP(hipMemcpyAsync(stats_h, stats, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+      PRAD_HIP(hipStreamSynchronize(s));
+      stats_copied = true;
+      if (!flags_h[0]) break;
+      bytes = false;   // irregular levels: nothing was computed, run the int32 kernels
+      stats_copied = false;
+    }
     st.voxel_mode = false;
     st.image = image;
     st.boxmax = g.n;
@@ -838,8 +1277,10 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
     st.voxel_mode = true;
     st.boxmax = b;
   }
-  PRAD_HIP(hipMemcpyAsync(stats_h, stats, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
-  PRAD_HIP(hipStreamSynchronize(s));
+  if (!stats_copied) {
+    PRAD_HIP(hipMemcpyAsync(stats_h, stats, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
+    PRAD_HIP(hipStreamSynchronize(s));
+  }
   st.g = g;
   st.nvox = Nvox;
   st.device = c.device;
