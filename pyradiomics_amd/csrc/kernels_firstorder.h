@@ -1,11 +1,12 @@
 // kernels_firstorder.h -- first-order statistics of the ROI intensities (radiomics/firstorder.py:33-474), segment mode.
-//   fo_compact_kernel   ROI voxels -> dense float64 array (order irrelevant: it is sorted next)
-//   (rocPRIM radix sort of the float64 keys: the order statistics behind the percentile / median / IQR features)
-//   fo_sums_kernel      per-block partial sums of x and (x + c)^2
+//   fo_sums_kernel      per-block partial sums of x and (x + c)^2, block minimum / maximum / ROI voxel count
+//   fo_compact_kernel   ROI voxels -> dense float64 array (small ROIs / fallback only; order irrelevant: it is sorted)
+//   order statistics behind the percentile / median / IQR features: rocPRIM radix sort of the float64 keys for
+//   small ROIs, histogram selection (fo_hist_kernel, fo_gather_kernel + a sort of the few selected bins) for large
 //   fo_central_kernel   per-block partial sums of |x - mu|, (x - mu)^2..4 and count / sum of the 10-90 percentile band
 //   fo_band_kernel      per-block partial sums of |x - mu_band| over the band (robust mean absolute deviation)
-// Partials are summed on the host in block order, so results are reproducible run to run.  HBM-bound: 9 B/voxel for
-// the compaction, 8 B per ROI voxel for each of the three reductions, plus the sort.
+// Partials are summed on the host in block order, so results are reproducible run to run.  HBM-bound: every pass
+// reads the image at its own dtype + 1 B/voxel of mask.
 #pragma once
 #include "prad_runtime.h"
 
@@ -57,34 +58,174 @@ __device__ __forceinline__ double fo_block_sum(double v, double *sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
-// partial[b][0] = sum x, partial[b][1] = sum (x + c)^2
-__global__ void __launch_bounds__(256) fo_sums_kernel(const double *__restrict__ v, long long m, double shift,
-                                                      double *__restrict__ partial) {
+// The reductions read the image and the mask directly, in raster order with a fixed block layout, so their partial
+// sums (added on the host in block order) do not depend on the order the compaction happens to produce.
+// partial[b][0] = sum x, [1] = sum (x + c)^2, [2] = min x, [3] = max x, [4] = ROI voxels of the block (a block
+// without ROI voxels reports +inf / -inf / 0)
+template <typename T>
+__global__ void __launch_bounds__(256) fo_sums_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                      long long n, double shift, double *__restrict__ partial) {
   __shared__ double sh[4];
-  double s1 = 0, s2 = 0;
+  double s1 = 0, s2 = 0, mn = INFINITY, mx = -INFINITY, cnt = 0;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-    const double x = v[i], y = x + shift;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (!mask[i]) continue;
+    const double x = (double)img[i], y = x + shift;
     s1 += x;
     s2 += y * y;
+    mn = fmin(mn, x);
+    mx = fmax(mx, x);
+    cnt += 1.0;
   }
   s1 = fo_block_sum(s1, sh);
   s2 = fo_block_sum(s2, sh);
+  cnt = fo_block_sum(cnt, sh);
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fmin(mn, __shfl_xor(mn, o));
+    mx = fmax(mx, __shfl_xor(mx, o));
+  }
+  __shared__ double shm[8];
+  if ((threadIdx.x & 63) == 0) {
+    shm[threadIdx.x >> 6] = mn;
+    shm[4 + (threadIdx.x >> 6)] = mx;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    partial[blockIdx.x * 2 + 0] = s1;
-    partial[blockIdx.x * 2 + 1] = s2;
+    double *p = partial + blockIdx.x * 5;
+    p[0] = s1;
+    p[1] = s2;
+    p[2] = fmin(fmin(shm[0], shm[1]), fmin(shm[2], shm[3]));
+    p[3] = fmax(fmax(shm[4], shm[5]), fmax(shm[6], shm[7]));
+    p[4] = cnt;
+  }
+}
+
+// ---- order statistics by selection (large ROIs) ------------------------------------------------------------------
+// The percentile features need a dozen order statistics, not a sorted array.  Values are binned by the monotone map
+// bin(x) = min(BINS - 1, int((x - min) * scale)); a histogram pass locates the bins that hold the wanted ranks, a
+// gather pass copies just those bins' elements out, and only they are sorted: 2-3 passes over image + mask instead
+// of a compaction and the 8 read+write passes of a 64-bit radix sort.
+#define PRAD_FO_BINS 16384
+#define PRAD_FO_MAXSEL 12
+__device__ __forceinline__ int fo_bin(double x, double lo, double scale) {
+  const double t = (x - lo) * scale;
+  return t >= (double)(PRAD_FO_BINS - 1) ? PRAD_FO_BINS - 1 : (int)t;
+}
+template <typename T>
+__global__ void __launch_bounds__(1024) fo_hist_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                       long long n, double lo, double scale,
+                                                       unsigned *__restrict__ hist) {
+  __shared__ unsigned h[PRAD_FO_BINS];
+  for (int k = threadIdx.x; k < PRAD_FO_BINS; k += blockDim.x) h[k] = 0u;
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (mask[i]) atomicAdd(&h[fo_bin((double)img[i], lo, scale)], 1u);
+  __syncthreads();
+  for (int k = threadIdx.x; k < PRAD_FO_BINS; k += blockDim.x)
+    if (h[k]) atomicAdd(hist + k, h[k]);
+}
+struct FoSel {
+  int nsel;
+  int bin[PRAD_FO_MAXSEL];        // ascending
+  unsigned off[PRAD_FO_MAXSEL];   // start of the bin's segment in the gathered array
+};
+// smallest / largest element of every selected bin, as order-preserving u64 keys (fo_key): a bin whose two keys
+// agree holds ONE distinct value (discretised / integer images put millions of equal voxels into a bin), and every
+// rank inside it is that value -- no gather, no sort.
+__device__ __host__ __forceinline__ unsigned long long fo_key(double x) {
+  unsigned long long b;
+  memcpy(&b, &x, sizeof(b));
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __host__ __forceinline__ double fo_unkey(unsigned long long k) {
+  const unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  double x;
+  memcpy(&x, &b, sizeof(x));
+  return x;
+}
+template <typename T>
+__global__ void __launch_bounds__(1024) fo_binrange_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                          long long n, double lo, double scale, FoSel sel,
+                                                          unsigned long long *__restrict__ range /*[MAXSEL][2]*/) {
+  __shared__ unsigned long long r[PRAD_FO_MAXSEL][2];
+  if (threadIdx.x < PRAD_FO_MAXSEL) {
+    r[threadIdx.x][0] = ~0ull;
+    r[threadIdx.x][1] = 0ull;
+  }
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (!mask[i]) continue;
+    const double x = (double)img[i];
+    const int b = fo_bin(x, lo, scale);
+    if (b < sel.bin[0] || b > sel.bin[sel.nsel - 1]) continue;
+    for (int q = 0; q < sel.nsel; q++)
+      if (b == sel.bin[q]) {
+        const unsigned long long k = fo_key(x);
+        if (k < r[q][0]) atomicMin(&r[q][0], k);     // the plain read skips the atomic once the extremes are known
+        if (k > r[q][1]) atomicMax(&r[q][1], k);
+      }
+  }
+  __syncthreads();
+  if (threadIdx.x < sel.nsel) {   // same-address global atomics serialise in L2: only when they can change the value
+    unsigned long long *g = range + 2 * threadIdx.x;
+    if (r[threadIdx.x][0] < __builtin_nontemporal_load(g)) atomicMin(g, r[threadIdx.x][0]);
+    if (r[threadIdx.x][1] > __builtin_nontemporal_load(g + 1)) atomicMax(g + 1, r[threadIdx.x][1]);
+  }
+}
+
+// Every block owns a contiguous slab of the volume: it counts its elements of every selected bin in LDS, reserves
+// their output ranges with ONE global atomic per bin (per-wave atomics on a dozen cursors serialise in L2), then
+// scatters with LDS cursors.  The order inside a bin's segment is irrelevant: the segments are sorted next.
+template <typename T>
+__global__ void __launch_bounds__(1024) fo_gather_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                         long long n, double lo, double scale, FoSel sel,
+                                                         unsigned *__restrict__ cursors, double *__restrict__ out) {
+  __shared__ unsigned cnt[PRAD_FO_MAXSEL], base[PRAD_FO_MAXSEL];
+  if (threadIdx.x < PRAD_FO_MAXSEL) cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  const long long per = (n + gridDim.x - 1) / gridDim.x;
+  const long long first = (long long)blockIdx.x * per, last = min(n, first + per);
+  auto which = [&](double x) -> int {
+    const int b = fo_bin(x, lo, scale);
+    int j = -1;
+    if (b >= sel.bin[0] && b <= sel.bin[sel.nsel - 1])
+      for (int q = 0; q < sel.nsel; q++)
+        if (b == sel.bin[q]) j = q;
+    return j;
+  };
+  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
+    if (!mask[i]) continue;
+    const int j = which((double)img[i]);
+    if (j >= 0) atomicAdd(&cnt[j], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < sel.nsel) {
+    base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(cursors + threadIdx.x, cnt[threadIdx.x]) : 0u;
+    cnt[threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
+    if (!mask[i]) continue;
+    const double x = (double)img[i];
+    const int j = which(x);
+    if (j >= 0) out[sel.off[j] + base[j] + atomicAdd(&cnt[j], 1u)] = x;
   }
 }
 
 // partial[b][0..3] = sum |d|, d^2, d^3, d^4 with d = x - mu; [4] = count, [5] = sum of x with lo <= x <= hi
-__global__ void __launch_bounds__(256) fo_central_kernel(const double *__restrict__ v, long long m, double mu, double lo,
-                                                         double hi, double *__restrict__ partial) {
+template <typename T>
+__global__ void __launch_bounds__(256) fo_central_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                         long long n, double mu, double lo, double hi,
+                                                         double *__restrict__ partial) {
 #pragma clang fp contract(off)
   __shared__ double sh[4];
   double a1 = 0, a2 = 0, a3 = 0, a4 = 0, bc = 0, bs = 0;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-    const double x = v[i], d = x - mu, d2 = d * d;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (!mask[i]) continue;
+    const double x = (double)img[i], d = x - mu, d2 = d * d;
     a1 += fabs(d);
     a2 += d2;
     a3 += d2 * d;
@@ -106,13 +247,16 @@ __global__ void __launch_bounds__(256) fo_central_kernel(const double *__restric
   }
 }
 
-__global__ void __launch_bounds__(256) fo_band_kernel(const double *__restrict__ v, long long m, double mu, double lo,
-                                                      double hi, double *__restrict__ partial) {
+template <typename T>
+__global__ void __launch_bounds__(256) fo_band_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                      long long n, double mu, double lo, double hi,
+                                                      double *__restrict__ partial) {
   __shared__ double sh[4];
   double a = 0;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < m; i += stride) {
-    const double x = v[i];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    if (!mask[i]) continue;
+    const double x = (double)img[i];
     if (x >= lo && x <= hi) a += fabs(x - mu);
   }
   a = fo_block_sum(a, sh);

@@ -2,6 +2,7 @@
 // libpyradiomics_amd.so so that the rocPRIM sort templates do not slow down rebuilding the texture kernels.
 #include <hipcub/hipcub.hpp>
 #include <math.h>
+#include <stdlib.h>
 #include "kernels_firstorder.h"
 
 using namespace prad;
@@ -45,65 +46,191 @@ int sum_partials(Context &c, hipStream_t s, const double *partial_d, int blocks,
 
 }  // namespace
 
+// launches KERNEL<T> for the image dtype code of include/pyradiomics_amd.h (0 float32, 1 float64, 2 int32, 3 int16)
+#define FO_DISPATCH(KERNEL, GRID, BLOCK, ...)                                                                       \
+  switch (dtype) {                                                                                                  \
+    case 0: hipLaunchKernelGGL(KERNEL<float>, GRID, BLOCK, 0, s, (const float *)image, mask, n, __VA_ARGS__); break;  \
+    case 1: hipLaunchKernelGGL(KERNEL<double>, GRID, BLOCK, 0, s, (const double *)image, mask, n, __VA_ARGS__); break; \
+    case 2: hipLaunchKernelGGL(KERNEL<int>, GRID, BLOCK, 0, s, (const int *)image, mask, n, __VA_ARGS__); break;      \
+    default: hipLaunchKernelGGL(KERNEL<short>, GRID, BLOCK, 0, s, (const short *)image, mask, n, __VA_ARGS__); break; \
+  }
+
 extern "C" int prad_firstorder_dev(const void *image, int dtype, const uint8_t *mask, long long n,
                                    double voxelArrayShift, double *out, void *stream) {
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
   if (!image || !mask || !out || n < 1) return fail(PRAD_E_ARG, "firstorder: bad arguments");
   if (n > 2147483647LL) return fail(PRAD_E_UNSUPPORTED, "firstorder: more than 2^31-1 voxels");
+  if (dtype < 0 || dtype > 3) return fail(PRAD_E_ARG, "firstorder: dtype %d", dtype);
   hipStream_t s = (hipStream_t)stream;
-  double *vals = nullptr, *sorted = nullptr, *partial = nullptr;
-  unsigned long long *count = nullptr;
-  PRAD_TRY(c.get<double>("fo_vals", (size_t)n, &vals));
-  PRAD_TRY(c.get<double>("fo_sorted", (size_t)n, &sorted));
+  double *partial = nullptr;
   PRAD_TRY(c.get<double>("fo_partial", (size_t)PRAD_FO_BLOCKS * 8, &partial));
-  PRAD_TRY(c.get<unsigned long long>("fo_count", 1, &count));
-  PRAD_HIP(hipMemsetAsync(count, 0, sizeof(unsigned long long), s));
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+  void *php = nullptr;
+  PRAD_TRY(c.get_pinned("fo_partials_h", sizeof(double) * PRAD_FO_BLOCKS * 8, &php));
+  double *ph = (double *)php;
+  // fixed block layout over the n voxels of the array: the partial sums do not depend on anything but the input
+  const int blocks = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, PRAD_FO_BLOCKS));
   {
     Timed t(c, "firstorder", s);
-    switch (dtype) {
-      case 0: hipLaunchKernelGGL(fo_compact_kernel<float>, dim3(gx), dim3(256), 0, s, (const float *)image, mask, n, vals, count); break;
-      case 1: hipLaunchKernelGGL(fo_compact_kernel<double>, dim3(gx), dim3(256), 0, s, (const double *)image, mask, n, vals, count); break;
-      case 2: hipLaunchKernelGGL(fo_compact_kernel<int>, dim3(gx), dim3(256), 0, s, (const int *)image, mask, n, vals, count); break;
-      case 3: hipLaunchKernelGGL(fo_compact_kernel<short>, dim3(gx), dim3(256), 0, s, (const short *)image, mask, n, vals, count); break;
-      default: return fail(PRAD_E_ARG, "firstorder: dtype %d", dtype);
-    }
-    PRAD_TRY(check_launch("fo_compact_kernel"));
-  }
-  unsigned long long m64 = 0;
-  PRAD_HIP(hipMemcpyAsync(&m64, count, sizeof(m64), hipMemcpyDeviceToHost, s));
-  PRAD_HIP(hipStreamSynchronize(s));
-  const long long m = (long long)m64;
-  if (m < 1) return fail(PRAD_E_ARG, "firstorder: empty ROI");
-
-  size_t tmp_bytes = 0;
-  PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, vals, sorted, (int)m, 0, 64, s));
-  uint8_t *tmp = nullptr;
-  PRAD_TRY(c.get<uint8_t>("fo_sort_tmp", tmp_bytes + 16, &tmp));
-  const int blocks = (int)std::max<long long>(1, std::min<long long>((m + 255) / 256, PRAD_FO_BLOCKS));
-  {
-    Timed t(c, "firstorder", s);
-    PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, vals, sorted, (int)m, 0, 64, s));
-    hipLaunchKernelGGL(fo_sums_kernel, dim3(blocks), dim3(256), 0, s, sorted, m, voxelArrayShift, partial);
+    FO_DISPATCH(fo_sums_kernel, dim3(blocks), dim3(256), voxelArrayShift, partial);
     PRAD_TRY(check_launch("fo_sums_kernel"));
   }
-  double sums[2];
-  PRAD_TRY(sum_partials(c, s, partial, blocks, 2, sums));
+  PRAD_HIP(hipMemcpyAsync(ph, partial, sizeof(double) * blocks * 5, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  double sums[2] = {0, 0}, vmin = INFINITY, vmax = -INFINITY, cnt = 0;
+  for (int b = 0; b < blocks; b++) {
+    sums[0] += ph[b * 5];
+    sums[1] += ph[b * 5 + 1];
+    vmin = fmin(vmin, ph[b * 5 + 2]);
+    vmax = fmax(vmax, ph[b * 5 + 3]);
+    cnt += ph[b * 5 + 4];
+  }
+  const long long m = (long long)cnt;
+  if (m < 1) return fail(PRAD_E_ARG, "firstorder: empty ROI");
   const double mu = sums[0] / (double)m;
 
-  // order statistics: minimum, maximum and the two neighbours of each requested quantile
+  // order statistics: the two neighbours of each requested quantile (minimum / maximum come from the reduction)
   const double qs[5] = {0.1, 0.25, 0.5, 0.75, 0.9};
   Quantile qp[5];
   double os[12];
+  long long ranks[10];
   for (int k = 0; k < 5; k++) {
     qp[k] = quantile_pos(m, qs[k]);
-    PRAD_HIP(hipMemcpyAsync(os + 2 * k, sorted + qp[k].prev, sizeof(double), hipMemcpyDeviceToHost, s));
-    PRAD_HIP(hipMemcpyAsync(os + 2 * k + 1, sorted + qp[k].next, sizeof(double), hipMemcpyDeviceToHost, s));
+    ranks[2 * k] = qp[k].prev;
+    ranks[2 * k + 1] = qp[k].next;
   }
-  PRAD_HIP(hipMemcpyAsync(os + 10, sorted, sizeof(double), hipMemcpyDeviceToHost, s));
-  PRAD_HIP(hipMemcpyAsync(os + 11, sorted + (m - 1), sizeof(double), hipMemcpyDeviceToHost, s));
-  PRAD_HIP(hipStreamSynchronize(s));
+  os[10] = vmin;
+  os[11] = vmax;
+  bool selected = false;
+  static const long long select_from = getenv("PRAD_FO_SELECT_MIN") ? atoll(getenv("PRAD_FO_SELECT_MIN")) : (1LL << 20);
+  if (m >= select_from && vmax > vmin && isfinite(vmin) && isfinite(vmax)) {
+    // selection: histogram over PRAD_FO_BINS monotone bins, gather the bins that hold the ranks, sort only those
+    unsigned *hist = nullptr, *cursors = nullptr;
+    PRAD_TRY(c.get<unsigned>("fo_hist", PRAD_FO_BINS, &hist));
+    PRAD_TRY(c.get<unsigned>("fo_cursors", PRAD_FO_MAXSEL, &cursors));
+    PRAD_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned) * PRAD_FO_BINS, s));
+    PRAD_HIP(hipMemsetAsync(cursors, 0, sizeof(unsigned) * PRAD_FO_MAXSEL, s));
+    const double scale = (double)PRAD_FO_BINS / (vmax - vmin);
+    void *hp = nullptr;
+    PRAD_TRY(c.get_pinned("fo_hist_h", sizeof(unsigned) * PRAD_FO_BINS, &hp));
+    unsigned *hist_h = (unsigned *)hp;
+    {
+      Timed t(c, "firstorder", s);
+      const unsigned hgx = (unsigned)std::max<long long>(1, std::min<long long>((n + 4095) / 4096, 512));
+      FO_DISPATCH(fo_hist_kernel, dim3(hgx), dim3(1024), vmin, scale, hist);
+      PRAD_TRY(check_launch("fo_hist_kernel"));
+    }
+    PRAD_HIP(hipMemcpyAsync(hist_h, hist, sizeof(unsigned) * PRAD_FO_BINS, hipMemcpyDeviceToHost, s));
+    PRAD_HIP(hipStreamSynchronize(s));
+    // bin of every rank, position inside it
+    FoSel sel;
+    sel.nsel = 0;
+    long long within[10];
+    int which[10];
+    {
+      long long below = 0;
+      int k = 0;                       // ranks are ascending
+      for (int b = 0; b < PRAD_FO_BINS && k < 10; b++) {
+        const long long bc = hist_h[b];
+        while (k < 10 && ranks[k] < below + bc) {
+          if (sel.nsel == 0 || sel.bin[sel.nsel - 1] != b) sel.bin[sel.nsel++] = b;
+          which[k] = sel.nsel - 1;
+          within[k] = ranks[k] - below;
+          k++;
+        }
+        below += bc;
+      }
+      if (k < 10) return fail(PRAD_E_HIP, "firstorder: histogram does not cover the ROI (internal error)");
+    }
+    // bins that hold one distinct value need no gather; the others are gathered and sorted if they are small enough
+    const long long cap = 1LL << 22;
+    bool single[PRAD_FO_MAXSEL] = {false};
+    double single_val[PRAD_FO_MAXSEL] = {0};
+    long long all = 0;
+    for (int q = 0; q < sel.nsel; q++) all += hist_h[sel.bin[q]];
+    const unsigned rgx = (unsigned)std::max<long long>(1, std::min<long long>((n + 4095) / 4096, 512));
+    if (all > cap) {
+      unsigned long long *range = nullptr;
+      PRAD_TRY(c.get<unsigned long long>("fo_range", 2 * PRAD_FO_MAXSEL, &range));
+      unsigned long long init[2 * PRAD_FO_MAXSEL], got[2 * PRAD_FO_MAXSEL];
+      for (int q = 0; q < PRAD_FO_MAXSEL; q++) { init[2 * q] = ~0ull; init[2 * q + 1] = 0ull; }
+      PRAD_HIP(hipMemcpyAsync(range, init, sizeof(init), hipMemcpyHostToDevice, s));
+      {
+        Timed t(c, "firstorder", s);
+        FO_DISPATCH(fo_binrange_kernel, dim3(rgx), dim3(1024), vmin, scale, sel, range);
+        PRAD_TRY(check_launch("fo_binrange_kernel"));
+      }
+      PRAD_HIP(hipMemcpyAsync(got, range, sizeof(got), hipMemcpyDeviceToHost, s));
+      PRAD_HIP(hipStreamSynchronize(s));
+      for (int q = 0; q < sel.nsel; q++)
+        if (got[2 * q] == got[2 * q + 1]) {
+          single[q] = true;
+          single_val[q] = fo_unkey(got[2 * q]);
+        }
+    }
+    FoSel gsel;                        // the bins to gather
+    gsel.nsel = 0;
+    int gidx[PRAD_FO_MAXSEL];
+    long long total = 0;
+    for (int q = 0; q < sel.nsel; q++) {
+      gidx[q] = -1;
+      if (single[q]) continue;
+      gidx[q] = gsel.nsel;
+      gsel.bin[gsel.nsel] = sel.bin[q];
+      gsel.off[gsel.nsel] = (unsigned)total;
+      gsel.nsel++;
+      total += hist_h[sel.bin[q]];
+    }
+    if (total <= cap) {
+      if (total > 0) {
+        double *gath = nullptr;
+        PRAD_TRY(c.get<double>("fo_gather", (size_t)(2 * total), &gath));
+        double *gsorted = gath + total;
+        size_t tmp_bytes = 0;
+        PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, gath, gsorted, (int)total, 0, 64, s));
+        uint8_t *tmp = nullptr;
+        PRAD_TRY(c.get<uint8_t>("fo_sort_tmp", tmp_bytes + 16, &tmp));
+        {
+          Timed t(c, "firstorder", s);
+          FO_DISPATCH(fo_gather_kernel, dim3(rgx), dim3(1024), vmin, scale, gsel, cursors, gath);
+          PRAD_TRY(check_launch("fo_gather_kernel"));
+          PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, gath, gsorted, (int)total, 0, 64, s));
+        }
+        for (int k = 0; k < 10; k++)
+          if (!single[which[k]]) {
+            PRAD_HIP(hipMemcpyAsync(os + k, gsorted + gsel.off[gidx[which[k]]] + within[k], sizeof(double),
+                                    hipMemcpyDeviceToHost, s));
+          }
+        PRAD_HIP(hipStreamSynchronize(s));
+      }
+      for (int k = 0; k < 10; k++)
+        if (single[which[k]]) os[k] = single_val[which[k]];
+      selected = true;
+    }
+  }
+  if (!selected) {
+    // small ROIs (and large ones whose selected bins are too full): compact the ROI and sort it
+    double *vals = nullptr, *sorted = nullptr;
+    unsigned long long *count = nullptr;
+    PRAD_TRY(c.get<double>("fo_vals", (size_t)m, &vals));
+    PRAD_TRY(c.get<double>("fo_sorted", (size_t)m, &sorted));
+    PRAD_TRY(c.get<unsigned long long>("fo_count", 1, &count));
+    PRAD_HIP(hipMemsetAsync(count, 0, sizeof(unsigned long long), s));
+    size_t tmp_bytes = 0;
+    PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, vals, sorted, (int)m, 0, 64, s));
+    uint8_t *tmp = nullptr;
+    PRAD_TRY(c.get<uint8_t>("fo_sort_tmp", tmp_bytes + 16, &tmp));
+    {
+      Timed t(c, "firstorder", s);
+      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+      FO_DISPATCH(fo_compact_kernel, dim3(gx), dim3(256), vals, count);
+      PRAD_TRY(check_launch("fo_compact_kernel"));
+      PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, vals, sorted, (int)m, 0, 64, s));
+    }
+    for (int k = 0; k < 10; k++)
+      PRAD_HIP(hipMemcpyAsync(os + k, sorted + ranks[k], sizeof(double), hipMemcpyDeviceToHost, s));
+    PRAD_HIP(hipStreamSynchronize(s));
+  }
   double pq[5];
   for (int k = 0; k < 5; k++) pq[k] = lerp_np(os[2 * k], os[2 * k + 1], qp[k].gamma);
   // np.median averages the two middle elements for even counts (np.mean of the pair), middle element otherwise
@@ -111,7 +238,7 @@ extern "C" int prad_firstorder_dev(const void *image, int dtype, const uint8_t *
 
   {
     Timed t(c, "firstorder", s);
-    hipLaunchKernelGGL(fo_central_kernel, dim3(blocks), dim3(256), 0, s, sorted, m, mu, pq[0], pq[4], partial);
+    FO_DISPATCH(fo_central_kernel, dim3(blocks), dim3(256), mu, pq[0], pq[4], partial);
     PRAD_TRY(check_launch("fo_central_kernel"));
   }
   double cen[6];
@@ -121,7 +248,7 @@ extern "C" int prad_firstorder_dev(const void *image, int dtype, const uint8_t *
     const double mu_band = cen[5] / cen[4];
     {
       Timed t(c, "firstorder", s);
-      hipLaunchKernelGGL(fo_band_kernel, dim3(blocks), dim3(256), 0, s, sorted, m, mu_band, pq[0], pq[4], partial);
+      FO_DISPATCH(fo_band_kernel, dim3(blocks), dim3(256), mu_band, pq[0], pq[4], partial);
       PRAD_TRY(check_launch("fo_band_kernel"));
     }
     double band;
@@ -144,7 +271,7 @@ extern "C" int prad_firstorder_dev(const void *image, int dtype, const uint8_t *
   out[PRAD_FO_M2] = cen[1] / dm;
   out[PRAD_FO_M3] = cen[2] / dm;
   out[PRAD_FO_M4] = cen[3] / dm;
-  c.last_path = "firstorder-sort";
+  c.last_path = selected ? "firstorder-select" : "firstorder-sort";
   return PRAD_OK;
 }
 

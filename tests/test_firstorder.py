@@ -50,6 +50,67 @@ def test_segment_statistics_vs_oracle(dtype, shape, frac):
                 assert abs(got[k] - want[k]) <= 1e-11 * max(abs(want[k]), 1e-300) + 1e-9 * (k in ("m3",)) * abs(want["m2"]) ** 1.5, (k, got[k], want[k])
 
 
+def _compare_stats(got, want):
+    assert set(got) == set(want)
+    for k in want:
+        if k in EXACT:
+            assert got[k] == want[k], (k, got[k], want[k])
+        elif np.isnan(want[k]):
+            assert np.isnan(got[k]), k
+        else:
+            assert abs(got[k] - want[k]) <= 1e-11 * max(abs(want[k]), 1e-300) + 1e-9 * (k in ("m3",)) * abs(want["m2"]) ** 1.5, (k, got[k], want[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["float64", "float32", "int16", "ties51", "ties2", "outlier"])
+def test_large_roi_order_statistics_by_selection(kind):
+    """ROIs above 2^20 voxels take the histogram-selection route (no full sort): order statistics must still be the
+    exact elements numpy picks, with ties, with an outlier stretching the bin range, for every input dtype"""
+    from oracle import firstorder_oracle
+    from pyradiomics_amd import _lib, cmatrices
+    shape = (128, 128, 130)
+    rng = np.random.default_rng(21)
+    if kind in ("float64", "float32", "int16"):
+        img, mask = _volume(np.dtype(kind).type, shape, 5, 0.62)
+    elif kind == "ties51":
+        img, mask = rng.integers(0, 51, shape).astype(np.int16), rng.random(shape) < 0.7
+    elif kind == "ties2":
+        img, mask = (rng.random(shape) < 0.3).astype(np.int32) * 9 - 4, np.ones(shape, bool)
+    else:
+        img, mask = rng.standard_normal(shape) + 50.0, rng.random(shape) < 0.8
+        img[3, 4, 5] = 1e9                      # nearly everything falls into the first bin: it is gathered whole
+        mask[3, 4, 5] = True
+    for shift in (0.0, 1000.0):
+        got = cmatrices.firstorder_stats(img, mask, shift)
+        assert _lib.last_path() == "firstorder-select"
+        _compare_stats(got, firstorder_oracle.firstorder_stats(img, mask, shift))
+
+
+@pytest.mark.gpu
+def test_large_roi_heavy_ties_and_fallback_to_the_sort():
+    from oracle import firstorder_oracle
+    from pyradiomics_amd import _lib, cmatrices
+    shape = (160, 160, 172)                                   # 4.4 M voxels
+    rng = np.random.default_rng(4)
+    mask = np.ones(shape, bool)
+    # two distinct values: the selected bins exceed the gather budget but each holds ONE value -> no gather, no sort
+    img = (rng.random(shape) < 0.5).astype(np.int16) * 100
+    got = cmatrices.firstorder_stats(img, mask, 0.0)
+    assert _lib.last_path() == "firstorder-select"
+    _compare_stats(got, firstorder_oracle.firstorder_stats(img, mask, 0.0))
+    # a discretised image (32 levels), the case of the level volumes of the texture classes
+    img = rng.integers(1, 33, shape).astype(np.int32)
+    got = cmatrices.firstorder_stats(img, mask, 0.0)
+    assert _lib.last_path() == "firstorder-select"
+    _compare_stats(got, firstorder_oracle.firstorder_stats(img, mask, 0.0))
+    # an outlier stretches the bin range: nearly the whole ROI shares bin 0 with many distinct values -> full sort
+    img = rng.standard_normal(shape) + 50.0
+    img[1, 2, 3] = 1e9
+    got = cmatrices.firstorder_stats(img, mask, 0.0)
+    assert _lib.last_path() == "firstorder-sort"
+    _compare_stats(got, firstorder_oracle.firstorder_stats(img, mask, 0.0))
+
+
 @pytest.mark.gpu
 def test_segment_flat_region_and_single_voxel():
     from pyradiomics_amd import firstorder
