@@ -765,7 +765,9 @@ __global__ void __launch_bounds__(256) glszm_border8q_kernel(const uint8_t *__re
 // A zone that spans thousands of tiles would otherwise receive thousands of atomics on one address, so every block
 // owns a CONTIGUOUS slab of voxels and first combines contributions to the same root in an LDS hash table.
 #define PRAD_RS_SLOTS 1024
-#define PRAD_RS_CHUNK (256 * 256)      // voxels per block
+#ifndef PRAD_RS_CHUNK
+#define PRAD_RS_CHUNK (64 * 256)       // voxels per block (256^3: 1024 blocks; with 65536 the kernel ran 256 blocks, 3x slower)
+#endif
 __global__ void __launch_bounds__(256) glszm_rootsum_kernel(long long n, int *__restrict__ labels,
                                                             unsigned *__restrict__ sizes,
                                                             const int *__restrict__ flags) {
