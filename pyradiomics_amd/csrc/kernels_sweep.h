@@ -177,12 +177,6 @@ __device__ __forceinline__ void lds_bump(int lds_addr) {  // bare ds_add_u32 on 
   asm volatile("" ::"v"(lds_addr));
   return;
 #endif
-#ifdef PRAD_DBG_NOCONFLICT  // ablation build (wrong counts): every lane of a 32-lane group on its own bank
-  lds_addr = (lds_addr & ~0x7c) | (int)((threadIdx.x & 31u) << 2);
-#endif
-#ifdef PRAD_DBG_SAMEADDR  // ablation build (wrong counts): all lanes of a wave on one word
-  lds_addr = 4096;
-#endif
   __hip_atomic_fetch_add((lds_u32 *)(size_t)(unsigned)lds_addr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
