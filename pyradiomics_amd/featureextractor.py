@@ -158,8 +158,10 @@ class RadiomicsFeatureExtractor:
                 return read_image(os.fspath(x))
             return as_image(x)
         image, mask = load(imageFilepath), load(maskFilepath)
-        if image.shape != mask.shape:
-            raise ValueError("Image/Mask geometry mismatch: %s vs %s" % (image.shape, mask.shape))
+        if len(image.shape) != len(mask.shape):
+            raise ValueError("Image/Mask datatype or size mismatch: %s vs %s" % (image.shape, mask.shape))
+        # imageoperations.checkMask step 1 (:241-287): same grid within geometryTolerance, or correctMask resamples
+        mask = imageoperations.checkMaskGeometry(image, mask, **kwargs)
         return image, mask
 
     def execute(self, imageFilepath, maskFilepath, label=None, label_channel=None, voxelBased=False):

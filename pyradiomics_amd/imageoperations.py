@@ -310,3 +310,97 @@ def resegmentMask(image, mask, **kwargs):
     out = np.zeros(roi.shape, dtype="int")
     out[roi] = label
     return mask.like(out) if isinstance(mask, Image) else Image(out)
+
+
+# ---- image / mask geometry (imageoperations.py:177-402: checkMask step 1, _correctMask, _checkROI) -----------------
+def _index_to_physical(img):
+    """(origin [Nd], matrix [Nd, Nd]) with physical(x, y, z) = origin + matrix @ index(x, y, z)"""
+    nd = len(img.shape)
+    D = np.asarray(img.GetDirection(), dtype=np.float64).reshape(nd, nd)
+    return np.asarray(img.GetOrigin(), dtype=np.float64), D * np.asarray(img.GetSpacing(), dtype=np.float64)[None, :]
+
+
+def sameGeometry(image, mask, tolerance=None):
+    """ITK's ImageToImageFilter::VerifyInputInformation, the test sitk.LabelStatisticsImageFilter applies before it
+    looks at a voxel: equal sizes, and origin / spacing within `tolerance` x spacing[0] of the image, direction within
+    `tolerance` (element-wise; default 1e-6, the ITK default the reference leaves in place unless ``geometryTolerance``
+    is set, featureextractor.py:114-126).  Returns (ok, reason)."""
+    tol = 1e-6 if tolerance is None else float(tolerance)
+    if image.shape != mask.shape:
+        return False, "size"
+    ctol = abs(tol * image.GetSpacing()[0])
+    for name, a, b, t in (("origin", image.GetOrigin(), mask.GetOrigin(), ctol),
+                          ("spacing", image.GetSpacing(), mask.GetSpacing(), ctol),
+                          ("direction", image.GetDirection(), mask.GetDirection(), tol)):
+        if np.any(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)) > t):
+            return False, name
+    return True, ""
+
+
+def _checkROI(image, mask, **kwargs):
+    """imageoperations.py:341-402: the label must be present and the physical box of its ROI (voxel edges, hence the
+    half voxel) must lie inside the image's, with the reference's 1e-3 voxel tolerance"""
+    label = int(kwargs.get("label", 1))
+    roi = mask.array == label
+    if not roi.any():
+        raise ValueError("Label (%d) not present in mask" % label)
+    lo, hi = boundingBox(roi)                                  # numpy (z, y, x) order, inclusive
+    lo_xyz, hi_xyz = lo[::-1].astype(np.float64), hi[::-1].astype(np.float64)
+    mo, mm = _index_to_physical(mask)
+    io, im = _index_to_physical(image)
+    inv = np.linalg.inv(im)
+    bounds = np.array([inv @ (mo + mm @ (lo_xyz - 0.5) - io), inv @ (mo + mm @ (hi_xyz + 0.5) - io)])
+    tol = 1e-3
+    size_xyz = np.asarray(image.shape[::-1], dtype=np.float64)
+    if np.any(bounds.min(axis=0) < -0.5 - tol) or np.any(bounds.max(axis=0) > size_xyz - 0.5 + tol):
+        raise ValueError("Bounding box of ROI is larger than image space:\n\tROI bounds (x, y, z image coordinate space) "
+                         "%s\n\tImage Size %s" % (bounds.tolist(), tuple(image.shape[::-1])))
+
+
+def _correctMask(image, mask, **kwargs):
+    """imageoperations.py:315-338: the mask resampled onto the image grid, nearest neighbour (ITK rounds half-way
+    continuous indices up), zero outside the mask's buffer"""
+    _checkROI(image, mask, **kwargs)
+    nd = len(image.shape)
+    mo, mm = _index_to_physical(mask)
+    io, im = _index_to_physical(image)
+    A = np.linalg.inv(mm) @ im                                 # image index (x, y, z) -> mask continuous index
+    b = np.linalg.inv(mm) @ (io - mo)
+    src = mask.array
+    out = np.zeros(image.shape, dtype=src.dtype)
+    axes = [np.arange(n, dtype=np.float64) for n in image.shape[::-1]]      # x, y, z index ranges
+    if np.allclose(A, np.diag(np.diag(A)), rtol=0, atol=1e-12):
+        # axis-aligned grids (the usual case): one index vector per axis
+        idx = []
+        for d in range(nd):
+            c = np.floor(A[d, d] * axes[d] + b[d] + 0.5).astype(np.int64)
+            idx.append(c)
+        ok = [(c >= 0) & (c < src.shape[nd - 1 - d]) for d, c in enumerate(idx)]
+        sel = np.ix_(*[np.nonzero(ok[d])[0] for d in range(nd - 1, -1, -1)])            # output (z, y, x)
+        pick = np.ix_(*[idx[d][ok[d]] for d in range(nd - 1, -1, -1)])                  # source (z, y, x)
+        out[sel] = src[pick]
+    else:
+        grid = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).reshape(-1, nd)     # rows (x, y, z), x slowest
+        cont = np.floor(grid @ A.T + b + 0.5).astype(np.int64)
+        inside = np.all((cont >= 0) & (cont < np.asarray(src.shape[::-1])), axis=1)
+        vals = np.zeros(len(grid), dtype=src.dtype)
+        vals[inside] = src[tuple(cont[inside, d] for d in range(nd - 1, -1, -1))]
+        out = np.ascontiguousarray(vals.reshape(image.shape[::-1]).transpose(tuple(range(nd - 1, -1, -1))))
+    return image.like(out)
+
+
+def checkMaskGeometry(image, mask, **kwargs):
+    """Step 1 of the reference's checkMask (imageoperations.py:241-287): a mask that does not share the image's grid
+    is an error, unless ``correctMask`` asks for it to be resampled onto the image grid.  Returns the mask to use."""
+    ok, reason = sameGeometry(image, mask, kwargs.get("geometryTolerance"))
+    if ok:
+        return mask
+    if not kwargs.get("correctMask", False):
+        if reason == "size":
+            raise ValueError("Image/Mask datatype or size mismatch. Potential fix: enable correctMask, see "
+                             "Documentation:Usage:Customizing the Extraction:Settings:correctMask for more information")
+        raise ValueError("Image/Mask geometry mismatch. Potential fix: increase tolerance using geometryTolerance, "
+                         "see Documentation:Usage:Customizing the Extraction:Settings:geometryTolerance for more "
+                         "information")
+    logger.warning("Image/Mask geometry mismatch, attempting to correct Mask")
+    return _correctMask(image, mask, **kwargs)

@@ -293,3 +293,56 @@ def test_two_dimensional_image_through_the_extractor():
     for key in ("original_glcm_JointEntropy", "original_glrlm_RunEntropy", "original_glszm_ZoneEntropy",
                 "original_gldm_DependenceEntropy", "original_ngtdm_Coarseness", "original_firstorder_Mean"):
         assert float(vol3[key]) == pytest.approx(float(dev[key]), rel=1e-12), key
+
+
+def test_mask_geometry_check_and_correct_mask(oracle_port):
+    """imageoperations.checkMask step 1 / _correctMask / _checkROI: a mask on another grid is an error unless
+    correctMask resamples it (nearest neighbour) onto the image grid; geometryTolerance widens the comparison"""
+    from pyradiomics_amd import backend, imageoperations as io
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(0)
+    sp, org = (0.8, 0.9, 2.0), (5.0, -3.0, 7.0)
+    img = Image(rng.integers(0, 200, (10, 12, 14)).astype(np.int16), spacing=sp, origin=org)
+    sub = (rng.random((6, 8, 9)) < 0.6).astype(np.uint8)
+    full = np.zeros((10, 12, 14), np.uint8)
+    full[2:8, 3:11, 4:13] = sub
+    # (a) a cropped segmentation on the same lattice
+    crop = Image(sub, spacing=sp, origin=(org[0] + 4 * sp[0], org[1] + 3 * sp[1], org[2] + 2 * sp[2]))
+    with pytest.raises(ValueError, match="size mismatch"):
+        io.checkMaskGeometry(img, crop)
+    fixed = io.checkMaskGeometry(img, crop, correctMask=True)
+    assert np.array_equal(fixed.array, full) and fixed.GetOrigin() == img.GetOrigin() and fixed.shape == img.shape
+    # (b) the same crop stored with x and y swapped (a rotated direction matrix): the general resampling path
+    rot = Image(np.ascontiguousarray(sub.transpose(0, 2, 1)), spacing=(sp[1], sp[0], sp[2]), origin=crop.GetOrigin(),
+                direction=(0, 1, 0, 1, 0, 0, 0, 0, 1))
+    assert np.array_equal(io.checkMaskGeometry(img, rot, correctMask=True).array, full)
+    # (c) a finer mask grid (half the spacing in-plane): nearest neighbour picks the voxel under each image centre
+    fine = np.repeat(np.repeat(full, 2, axis=1), 2, axis=2)
+    finem = Image(fine, spacing=(sp[0] / 2, sp[1] / 2, sp[2]), origin=(org[0] - sp[0] / 4, org[1] - sp[1] / 4, org[2]))
+    assert np.array_equal(io.checkMaskGeometry(img, finem, correctMask=True).array, full)
+    # (d) tolerance: 1e-5 mm off is a mismatch at ITK's default 1e-6, fine at 1e-4
+    off = Image(full, spacing=sp, origin=(org[0] + 1e-5, org[1], org[2]))
+    with pytest.raises(ValueError, match="geometry mismatch"):
+        io.checkMaskGeometry(img, off)
+    assert io.checkMaskGeometry(img, off, geometryTolerance=1e-4) is off
+    # (e) an ROI that sticks out of the image cannot be corrected; neither can a mask without the label
+    out = Image(np.ones((6, 8, 9), np.uint8), spacing=sp, origin=(org[0] + 8 * sp[0], org[1], org[2]))
+    with pytest.raises(ValueError, match="larger than image space"):
+        io.checkMaskGeometry(img, out, correctMask=True)
+    with pytest.raises(ValueError, match="not present"):
+        io.checkMaskGeometry(img, Image(np.zeros((6, 8, 9), np.uint8), spacing=sp, origin=crop.GetOrigin()), correctMask=True)
+    # through the extractor: the corrected crop gives the features of the full-grid mask
+    backend.set(oracle_port)
+    try:
+        params = {"setting": {"binWidth": 25, "correctMask": True, "additionalInfo": False, "deviceResident": False},
+                  "featureClass": {"glcm": ["JointEntropy", "Contrast"], "glszm": ["ZonePercentage"], "firstorder": ["Mean"]}}
+        a = RadiomicsFeatureExtractor(params).execute(img, crop)
+        b = RadiomicsFeatureExtractor(params).execute(img, Image(full, spacing=sp, origin=org))
+        assert list(a) == list(b) and all(float(a[k]) == float(b[k]) for k in a) and len(a) == 4
+        params["setting"]["correctMask"] = False
+        with pytest.raises(ValueError):
+            RadiomicsFeatureExtractor(params).execute(img, crop)
+    finally:
+        from pyradiomics_amd import cmatrices
+        backend.set(cmatrices)
