@@ -158,6 +158,11 @@ class RadiomicsFeatureExtractor:
                 return read_image(os.fspath(x))
             return as_image(x)
         image, mask = load(imageFilepath), load(maskFilepath)
+        if getattr(mask, "components", None) is None and len(mask.shape) == len(image.shape) + 1:
+            # an array with a trailing component axis (a vector mask given without file geometry)
+            mask = Image(mask.array, image.GetSpacing(), image.GetOrigin(), image.GetDirection())
+        if not mask.on_device:
+            mask = imageoperations.getMask(mask, **kwargs)      # channel of a vector mask; the label must occur
         if len(image.shape) != len(mask.shape):
             raise ValueError("Image/Mask datatype or size mismatch: %s vs %s" % (image.shape, mask.shape))
         # imageoperations.checkMask step 1 (:241-287): same grid within geometryTolerance, or correctMask resamples
@@ -168,6 +173,8 @@ class RadiomicsFeatureExtractor:
         s = self.settings.copy()
         if label is not None:
             s["label"] = label
+        if label_channel is not None:
+            s["label_channel"] = label_channel
         label = s.get("label", 1)
 
         kernelRadius = 0

@@ -154,6 +154,14 @@ def read_nrrd(path: str) -> Image:
     arr = np.frombuffer(data, dtype=dtype, count=n).reshape(sizes[::-1])
     arr = arr.astype(dtype.newbyteorder("="), copy=True)
     nd = len(sizes)
+    # a segmentation object stored as a vector image: the first (fastest) axis carries the components, e.g.
+    # "kinds: list domain domain domain" / "space directions: none (..) (..) (..)" -> array (z, y, x, c), geometry of
+    # the remaining axes (imageoperations.getMask picks the channel, imageoperations.py:12-64)
+    kinds = fields.get("kinds", "").lower().split()
+    sdirs = fields.get("space directions", "").lower().split()
+    vector = nd >= 2 and ((len(kinds) == nd and kinds[0] not in ("domain", "space")) or (sdirs[:1] == ["none"]))
+    if vector:
+        nd -= 1
     spacing, direction = [1.0] * nd, list(np.eye(nd).ravel())
     if "space directions" in fields:
         vecs = [v for v in fields["space directions"].replace("none", "").split(")") if "(" in v]
@@ -164,12 +172,15 @@ def read_nrrd(path: str) -> Image:
             for r in range(min(nd, len(comp))):
                 direction[r * nd + i] = comp[r] / norm if norm else 0.0
     elif "spacings" in fields:
-        spacing = [float(s) for s in fields["spacings"].split()]
+        spacing = [float(s) for s in fields["spacings"].split() if s.lower() != "nan"][-nd:]
     origin = [0.0] * nd
     if "space origin" in fields:
         o = fields["space origin"]
         origin = [float(x) for x in o[o.index("(") + 1:o.index(")")].split(",")]
-    return Image(arr, spacing, origin, direction)
+    img = Image(arr, spacing, origin, direction)
+    if vector:
+        img.components = int(sizes[0])
+    return img
 
 
 def write_nrrd(path: str, image: Image, compress: bool = True) -> None:

@@ -404,3 +404,27 @@ def checkMaskGeometry(image, mask, **kwargs):
                          "information")
     logger.warning("Image/Mask geometry mismatch, attempting to correct Mask")
     return _correctMask(image, mask, **kwargs)
+
+
+def getMask(mask, **kwargs):
+    """imageoperations.py:12-64: picks channel ``label_channel`` (default 0) of a segmentation stored as a vector image
+    (array (z, y, x, c): an NRRD with a component axis, or an array with one more axis than its geometry) and checks
+    that the label occurs"""
+    label = kwargs.get("label", 1)
+    channel = int(kwargs.get("label_channel", 0) or 0)
+    ncomp = getattr(mask, "components", None)
+    if ncomp is None and len(mask.shape) == len(mask.GetSpacing()) + 1:
+        ncomp = mask.shape[-1]
+    if ncomp is not None:
+        if not 0 <= channel < ncomp:
+            raise ValueError("Mask %d requested, but segmentation object only contains %d objects" % (channel, ncomp))
+        logger.info("Extracting mask at index %d", channel)
+        mask = Image(np.ascontiguousarray(mask.array[..., channel]), mask.GetSpacing(), mask.GetOrigin(),
+                     mask.GetDirection())
+    arr = mask.array
+    if not np.any(arr == label):
+        labels = np.unique(arr)
+        if len(labels) == 1 and labels[0] == 0:
+            raise ValueError("No labels found in this mask (i.e. nothing is segmented)!")
+        raise ValueError("Label (%g) not present in mask. Choose from %s" % (label, labels[labels != 0]))
+    return mask

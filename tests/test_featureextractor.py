@@ -346,3 +346,45 @@ def test_mask_geometry_check_and_correct_mask(oracle_port):
     finally:
         from pyradiomics_amd import cmatrices
         backend.set(cmatrices)
+
+
+def test_vector_mask_and_label_channel(oracle_port, tmp_path):
+    """imageoperations.getMask (:12-64): a segmentation stored as a vector image (overlapping segments, one channel
+    each) -- the channel picked by label_channel is used like a scalar mask"""
+    from pyradiomics_amd import backend, imageoperations as io
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    from pyradiomics_amd.image import Image, read_image
+    rng = np.random.default_rng(3)
+    shape = (6, 9, 11)
+    img = Image(rng.integers(0, 300, shape).astype(np.int16), spacing=(0.8, 0.9, 2.0), origin=(1.0, 2.0, 3.0))
+    seg = np.stack([(rng.random(shape) < 0.5), (rng.random(shape) < 0.4)], axis=-1).astype(np.uint8)   # (z, y, x, c)
+    path = tmp_path / "seg.nrrd"
+    header = ("NRRD0004\ntype: uchar\ndimension: 4\nspace: left-posterior-superior\nsizes: 2 11 9 6\n"
+              "space directions: none (0.8,0,0) (0,0.9,0) (0,0,2)\nkinds: list domain domain domain\nencoding: raw\n"
+              "space origin: (1,2,3)\n\n")
+    path.write_bytes(header.encode("ascii") + seg.tobytes())
+    vec = read_image(str(path))
+    assert vec.components == 2 and vec.shape == shape + (2,) and vec.GetSpacing() == (0.8, 0.9, 2.0)
+    assert vec.GetOrigin() == (1.0, 2.0, 3.0)
+    for ch in (0, 1):
+        m = io.getMask(vec, label_channel=ch)
+        assert m.shape == shape and np.array_equal(m.array, seg[..., ch])
+    with pytest.raises(ValueError, match="only contains 2 objects"):
+        io.getMask(vec, label_channel=2)
+    with pytest.raises(ValueError, match="Choose from"):
+        io.getMask(vec, label=7)
+    with pytest.raises(ValueError, match="nothing is segmented"):
+        io.getMask(Image(np.zeros(shape, np.uint8)))
+    backend.set(oracle_port)
+    try:
+        params = {"setting": {"binWidth": 25, "additionalInfo": False, "deviceResident": False},
+                  "featureClass": {"glrlm": ["RunEntropy"], "firstorder": ["Median"]}}
+        ex = RadiomicsFeatureExtractor(params)
+        a = ex.execute(img, str(path), label_channel=1)
+        b = ex.execute(img, Image(seg[..., 1].copy(), spacing=(0.8, 0.9, 2.0), origin=(1.0, 2.0, 3.0)))
+        c = ex.execute(img.array, seg, label_channel=0)          # plain arrays, trailing component axis
+        d = ex.execute(img.array, seg[..., 0].copy())
+        assert all(float(a[k]) == float(b[k]) for k in b) and all(float(c[k]) == float(d[k]) for k in d) and len(a) == 2
+    finally:
+        from pyradiomics_amd import cmatrices
+        backend.set(cmatrices)
