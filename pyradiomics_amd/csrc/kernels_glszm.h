@@ -854,20 +854,31 @@ __global__ void __launch_bounds__(256) glszm_stats_kernel(long long n, const int
   const long long stride = (long long)gridDim.x * blockDim.x;
   unsigned mx = 0;
   unsigned long long cnt = 0;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (labels[i] == (int)i) {
-      const unsigned sz = sizes[i];
-      cnt++;
-      mx = max(mx, sz);
-      if (sz < PRAD_SMALL_SIZES) {
-        const unsigned bit = 1u << (sz & 31);
-        if (!(bits[sz >> 5] & bit)) atomicOr(bits + (sz >> 5), bit);
-      } else {
-        const int pos = atomicAdd(large_count, 1);
-        if (pos < large_cap) large_list[pos] = (int)sz;
-      }
+  auto root = [&](long long i) {
+    const unsigned sz = sizes[i];
+    cnt++;
+    mx = max(mx, sz);
+    if (sz < PRAD_SMALL_SIZES) {
+      const unsigned bit = 1u << (sz & 31);
+      if (!(bits[sz >> 5] & bit)) atomicOr(bits + (sz >> 5), bit);
+    } else {
+      const int pos = atomicAdd(large_count, 1);
+      if (pos < large_cap) large_list[pos] = (int)sz;
     }
+  };
+  // the scan is a stream over the labels: 16 B per lane and load
+  const long long n4 = n >> 2;
+  const int4 *lab4 = reinterpret_cast<const int4 *>(labels);
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+    const int4 l = lab4[q];
+    const long long i = q << 2;
+    if (l.x == (int)i) root(i);
+    if (l.y == (int)i + 1) root(i + 1);
+    if (l.z == (int)i + 2) root(i + 2);
+    if (l.w == (int)i + 3) root(i + 3);
   }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (labels[i] == (int)i) root(i);
   for (int o = 32; o > 0; o >>= 1) {
     mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
     cnt += __shfl_xor(cnt, o);
@@ -940,17 +951,28 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
   for (int q = threadIdx.x; q < Ng * RL; q += blockDim.x) fh[q] = 0u;
   __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (labels[i] != (int)i) continue;
+  auto root = [&](long long i) {
     const int gl = image[i];
     const int r = glszm_rank(sizes[i], small_rank, nsmall, large_sorted, nlarge);
     if (gl <= 0 || gl > Ng || r < 0 || r >= k) {
       *err = 1;
-      continue;
+      return;
     }
     if (r < RL) atomicAdd(fh + (gl - 1) * RL + r, 1u);
     else atomicAdd(out + (size_t)(gl - 1) * k + r, 1.0);
+  };
+  const long long n4 = n >> 2;
+  const int4 *lab4 = reinterpret_cast<const int4 *>(labels);
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+    const int4 l = lab4[q];
+    const long long i = q << 2;
+    if (l.x == (int)i) root(i);
+    if (l.y == (int)i + 1) root(i + 1);
+    if (l.z == (int)i + 2) root(i + 2);
+    if (l.w == (int)i + 3) root(i + 3);
   }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if (labels[i] == (int)i) root(i);
   __syncthreads();
   for (int q = threadIdx.x; q < Ng * RL; q += blockDim.x)
     if (fh[q]) atomicAdd(out + (size_t)(q / RL) * k + (q % RL), (double)fh[q]);
