@@ -83,9 +83,9 @@ class RadiomicsFeatureExtractor:
         else:
             params = paramsDict
         params = params or {}
-        unknown = set(params) - {"setting", "voxelSetting", "imageType", "featureClass"}
-        if unknown:
-            raise ValueError("unknown top-level parameter key(s): %s" % ", ".join(sorted(unknown)))
+        # the reference validates against radiomics/schemas/paramSchema.yaml here (pykwalify)
+        from . import paramcheck
+        paramcheck.validate(params, list(_IMAGE_TYPES), {n: list(c.getFeatureNames()) for n, c in getFeatureClasses().items()})
         self.settings = self._getDefaultSettings()
         self.settings.update(params.get("setting") or {})
         self.settings.update(params.get("voxelSetting") or {})

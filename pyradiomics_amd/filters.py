@@ -30,6 +30,9 @@ _DEC_LO = {
 }
 
 
+WAVELETS = tuple(sorted(_DEC_LO))
+
+
 def wavelet_filters(wavelet):
     """(dec_lo, dec_hi) float64 arrays for a wavelet name, or pass-through of a (dec_lo, dec_hi) pair"""
     if isinstance(wavelet, (tuple, list)) and len(wavelet) == 2:

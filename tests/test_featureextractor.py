@@ -388,3 +388,45 @@ def test_vector_mask_and_label_channel(oracle_port, tmp_path):
     finally:
         from pyradiomics_amd import cmatrices
         backend.set(cmatrices)
+
+
+def test_parameter_validation_follows_the_reference_schema():
+    """radiomics/schemas/paramSchema.yaml + schemaFuncs.py restated in pyradiomics_amd/paramcheck.py"""
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor as Ex
+    good = {"setting": {"binWidth": 25, "label": 1, "interpolator": "sitkBSpline", "resampledPixelSpacing": [2, 2, 0],
+                        "weightingNorm": None, "distances": [1, 2], "resegmentRange": [-3, 3], "resegmentMode": "sigma",
+                        "force2D": True, "force2Ddimension": 0, "normalize": True, "normalizeScale": 100,
+                        "geometryTolerance": 1e-4, "correctMask": True, "deviceResident": False},
+            "voxelSetting": {"kernelRadius": 2, "maskedKernel": True, "initValue": "nan", "voxelBatch": 10000},
+            "imageType": {"Original": {}, "LoG": {"sigma": [1.0, 3]}, "Wavelet": {"wavelet": "coif1", "level": 1}},
+            "featureClass": {"glcm": ["JointEntropy"], "firstorder": None, "shape": None}}
+    Ex(good)
+    bad = [
+        {"setting": {"binWidth": 0}}, {"setting": {"binWidth": "wide"}}, {"setting": {"binCount": 2.5}},
+        {"setting": {"label": 0}}, {"setting": {"normalize": 1}}, {"setting": {"minimumROIDimensions": 4}},
+        {"setting": {"distances": [0]}}, {"setting": {"distances": 1}}, {"setting": {"resegmentMode": "percent"}},
+        {"setting": {"interpolator": "sitkCubic"}}, {"setting": {"interpolator": 11}},
+        {"setting": {"weightingNorm": "chebyshev"}}, {"setting": {"force2Ddimension": 3}},
+        {"setting": {"geometryTolerance": 0}}, {"setting": {"wavelet": "db9"}},
+        {"voxelSetting": {"kernelRadius": 0}}, {"voxelSetting": {"maskedKernel": "yes"}},
+        {"imageType": {"LoG": {"sigma": [0.0]}}}, {"imageType": None}, {"featureClass": None},
+        {"featureClass": {"glcm": "JointEntropy"}}, {"featureClass": {"glcm": ["NoSuchFeature"]}},
+        {"settings": {"binWidth": 25}},
+    ]
+    for params in bad:
+        with pytest.raises(ValueError):
+            Ex(params)
+    with pytest.raises(NotImplementedError):
+        Ex({"imageType": {"LBP3D": {}}})                       # known to the reference, outside this package
+
+
+def test_reference_example_parameter_files_are_accepted():
+    """every examples/exampleSettings/*.yaml of the reference configures the extractor (shape classes are skipped)"""
+    import glob
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    files = sorted(glob.glob("/root/reference/examples/exampleSettings/*.yaml"))
+    if not files:
+        pytest.skip("reference checkout not present")
+    for f in files:
+        ex = RadiomicsFeatureExtractor(f)
+        assert ex.enabledImagetypes and "shape" not in ex.enabledFeatures
