@@ -161,8 +161,10 @@ class RadiomicsFeatureExtractor:
         if getattr(mask, "components", None) is None and len(mask.shape) == len(image.shape) + 1:
             # an array with a trailing component axis (a vector mask given without file geometry)
             mask = Image(mask.array, image.GetSpacing(), image.GetOrigin(), image.GetDirection())
-        if not mask.on_device:
-            mask = imageoperations.getMask(mask, **kwargs)      # channel of a vector mask; the label must occur
+        if getattr(mask, "components", None) is not None or len(mask.shape) == len(mask.GetSpacing()) + 1:
+            mask = imageoperations.getMask(mask, **kwargs)      # the channel of a vector mask (label_channel)
+        # (a scalar mask is not scanned here: execute() finds a missing label when it takes the bounding box, on the
+        # device, and raises the same "Label (..) not present in mask")
         if len(image.shape) != len(mask.shape):
             raise ValueError("Image/Mask datatype or size mismatch: %s vs %s" % (image.shape, mask.shape))
         # imageoperations.checkMask step 1 (:241-287): same grid within geometryTolerance, or correctMask resamples
