@@ -76,6 +76,34 @@ def test_glcm_docstring_example(oracle_port):
     assert np.array_equal(sym, want)
 
 
+# the 5x5 image of the GLRLM / GLSZM / GLDM class docstrings (glrlm.py:14-33, glszm.py:17-36, gldm.py:18-37)
+_DOC_I = np.array([[5, 2, 5, 4, 4], [3, 3, 3, 1, 3], [2, 1, 1, 1, 3], [4, 2, 2, 2, 3], [3, 5, 3, 3, 2]])
+
+
+@pytest.mark.parametrize("which", ["port", "ref"])
+def test_class_docstring_examples(which, oracle_port, request):
+    """the worked examples of the reference's class docstrings as known-answer tests for both CPU checkers"""
+    cm = oracle_port if which == "port" else request.getfixturevalue("oracle_ref")
+    ones = np.ones(_DOC_I.shape, bool)
+    # GLRLM for theta = 0 (the horizontal direction), glrlm.py:24-33
+    P, ang = cm.calculate_glrlm(_DOC_I, ones, 5, 5, False, 0)
+    a = [tuple(x) for x in ang.tolist()].index((0, 1))
+    assert np.array_equal(P[0, :, :, a], [[1, 0, 1, 0, 0], [3, 0, 1, 0, 0], [4, 1, 1, 0, 0], [1, 1, 0, 0, 0], [3, 0, 0, 0, 0]])
+    # GLSZM (8-connected zones in 2-D), glszm.py:27-36
+    P = cm.calculate_glszm(_DOC_I, ones, 5, 25, False, 0)
+    assert np.array_equal(P[0], [[0, 0, 0, 1, 0], [1, 0, 0, 0, 1], [1, 0, 1, 0, 1], [1, 1, 0, 0, 0], [3, 0, 0, 0, 0]])
+    # GLDM for alpha = 0, delta = 1: column j = voxels with j dependent neighbours (sizes 1..4), gldm.py:28-37
+    P = cm.calculate_gldm(_DOC_I, ones, [1], 5, 0, False, 0)
+    assert np.array_equal(P[0, :, :4], [[0, 1, 2, 1], [1, 2, 3, 0], [1, 4, 4, 0], [1, 2, 0, 0], [3, 0, 0, 0]])
+    assert not P[0, :, 4:].any()
+    # NGTDM of the 4x4 example, ngtdm.py:38-68 (the derivation below the table gives s_3 = 3.03; the table's 2.63 is a typo)
+    I4 = np.array([[1, 2, 5, 2], [3, 5, 1, 3], [1, 3, 5, 5], [3, 1, 1, 1]])
+    P = cm.calculate_ngtdm(I4, np.ones(I4.shape, bool), [1], 5, False, 0)[0]
+    assert np.array_equal(P[:, 0], [6, 2, 4, 0, 4]) and np.array_equal(P[:, 2], [1, 2, 3, 4, 5])
+    s3 = abs(3 - 12 / 5) + abs(3 - 18 / 5) + abs(3 - 20 / 8) + abs(3 - 5 / 3)
+    np.testing.assert_allclose(P[:, 1], [13.35, 2.0, s3, 0.0, 10.075], rtol=1e-12, atol=1e-12)
+
+
 @pytest.fixture
 def oracle_backend(oracle_port):
     from pyradiomics_amd import backend
