@@ -58,52 +58,67 @@ class RadiomicsFirstOrder(RadiomicsFeaturesBase):
 
     # -- the 19 features (firstorder.py:147-474) -----------------------------------------------------------
     def getEnergyFeatureValue(self):
+        """Σ (X(i) + c)²  with c = voxelArrayShift  (firstorder.py:135)"""
         return self.st["Energy"]
 
     def getTotalEnergyFeatureValue(self):
+        """Vvoxel · Σ (X(i) + c)²  (voxel volume in mm³ times Energy)  (firstorder.py:157)"""
         return self.st["Energy"] * np.multiply.reduce(self.pixelSpacing)
 
     def getEntropyFeatureValue(self):
+        """−Σ p(i) log2(p(i) + ε) over the discretised intensity histogram (binWidth / binCount)  (firstorder.py:181)"""
         p_i = self.coefficients["p_i"]
         return -1.0 * np.sum(p_i * np.log2(p_i + np.spacing(1)), 1)
 
     def getMinimumFeatureValue(self):
+        """min(X)  (firstorder.py:201)"""
         return self.st["Minimum"]
 
     def get10PercentileFeatureValue(self):
+        """10th percentile of X (numpy's linear interpolation between order statistics)  (firstorder.py:211)"""
         return self.st["P10"]
 
     def get90PercentileFeatureValue(self):
+        """90th percentile of X (numpy's linear interpolation between order statistics)  (firstorder.py:219)"""
         return self.st["P90"]
 
     def getMaximumFeatureValue(self):
+        """max(X)  (firstorder.py:228)"""
         return self.st["Maximum"]
 
     def getMeanFeatureValue(self):
+        """1/Np · Σ X(i)  (firstorder.py:240)"""
         return self.st["Mean"]
 
     def getMedianFeatureValue(self):
+        """median of X  (firstorder.py:252)"""
         return self.st["Median"]
 
     def getInterquartileRangeFeatureValue(self):
+        """P75 − P25  (firstorder.py:261)"""
         return self.st["P75"] - self.st["P25"]
 
     def getRangeFeatureValue(self):
+        """max(X) − min(X)  (firstorder.py:276)"""
         return self.st["Maximum"] - self.st["Minimum"]
 
     def getMeanAbsoluteDeviationFeatureValue(self):
+        """1/Np · Σ |X(i) − mean(X)|  (firstorder.py:288)"""
         return self.st["MAD"]
 
     def getRobustMeanAbsoluteDeviationFeatureValue(self):
+        """mean absolute deviation of the voxels with P10 ≤ X(i) ≤ P90 from their own mean  (firstorder.py:301)"""
         return self.st["rMAD"]
 
     def getRootMeanSquaredFeatureValue(self):
+        """sqrt(1/Np · Σ (X(i) + c)²)  (firstorder.py:334)"""
         if self.st["Np"][0] == 0:       # firstorder.py:360-362
             return 0
         return np.sqrt(self.st["Energy"] / self.st["Np"])
 
     @deprecated
     def getStandardDeviationFeatureValue(self):
+        """sqrt(Variance) (population standard deviation; not enabled by default: correlated with Variance)  (firstorder.py:359)"""
         return np.sqrt(self.st["m2"])
 
     def _m2_safe(self):
@@ -112,13 +127,17 @@ class RadiomicsFirstOrder(RadiomicsFeaturesBase):
         return m2
 
     def getSkewnessFeatureValue(self):
+        """μ3 / σ³ with central moments μk = 1/Np · Σ (X(i) − mean)^k; 0 for a flat region  (firstorder.py:379)"""
         return self.st["m3"] / self._m2_safe() ** 1.5
 
     def getKurtosisFeatureValue(self):
+        """μ4 / σ⁴ (not excess kurtosis: a normal distribution gives 3); 0 for a flat region  (firstorder.py:410)"""
         return self.st["m4"] / self._m2_safe() ** 2.0
 
     def getVarianceFeatureValue(self):
+        """1/Np · Σ (X(i) − mean)²  (firstorder.py:446)"""
         return np.sqrt(self.st["m2"]) ** 2      # np.nanstd(x) ** 2 (:462)
 
     def getUniformityFeatureValue(self):
+        """Σ p(i)² over the discretised intensity histogram  (firstorder.py:459)"""
         return np.nansum(self.coefficients["p_i"] ** 2, 1)

@@ -149,26 +149,33 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
 
     # -- features (glcm.py:260-887) --------------------------------------------------------------------
     def getAutocorrelationFeatureValue(self):
+        """Σij p(i,j) · i · j  (glcm.py:260)"""
         c = self.coefficients
         return np.nanmean(np.sum(self.P_glcm * (c["i"] * c["j"])[None, :, :, None], (1, 2)), 1)
 
     def getJointAverageFeatureValue(self):
+        """μx = Σij p(i,j) · i  (glcm.py:274)"""
         return self.coefficients["ux"].mean((1, 2, 3))
 
     def getClusterProminenceFeatureValue(self):
+        """Σij (i + j − μx − μy)⁴ p(i,j)  (glcm.py:294)"""
         return self._centred(4)
 
     def getClusterShadeFeatureValue(self):
+        """Σij (i + j − μx − μy)³ p(i,j)  (glcm.py:314)"""
         return self._centred(3)
 
     def getClusterTendencyFeatureValue(self):
+        """Σij (i + j − μx − μy)² p(i,j)  (glcm.py:334)"""
         return self._centred(2)
 
     def getContrastFeatureValue(self):
+        """Σij (i − j)² p(i,j)  (glcm.py:353)"""
         c = self.coefficients
         return np.nanmean(np.sum(self.P_glcm * (np.abs(c["i"] - c["j"]))[None, :, :, None] ** 2, (1, 2)), 1)
 
     def getCorrelationFeatureValue(self):
+        """(Σij p(i,j) · i · j − μx μy) / (σx σy); 1 where σx σy = 0 (flat region)  (glcm.py:368)"""
         c = self.coefficients
         P = self.P_glcm
         di = c["i"][None, :, :, None] - c["ux"]
@@ -180,14 +187,17 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
         return np.nanmean(corr, (1, 2, 3))
 
     def getDifferenceAverageFeatureValue(self):
+        """Σk k · p(x−y)(k)  (glcm.py:412)"""
         c = self.coefficients
         return np.nanmean(np.sum(c["kValuesDiff"][None, :, None] * c["pxSuby"], 1), 1)
 
     def getDifferenceEntropyFeatureValue(self):
+        """−Σk p(x−y)(k) log2(p(x−y)(k) + ε)  (glcm.py:428)"""
         p = self.coefficients["pxSuby"]
         return np.nanmean((-1) * np.sum(p * np.log2(p + _EPS), 1), 1)
 
     def getDifferenceVarianceFeatureValue(self):
+        """Σk (k − DifferenceAverage)² p(x−y)(k)  (glcm.py:443)"""
         c = self.coefficients
         k = c["kValuesDiff"][None, :, None]
         mean = np.sum(k * c["pxSuby"], 1, keepdims=True)
@@ -195,23 +205,29 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
 
     @deprecated
     def getDissimilarityFeatureValue(self):
+        """deprecated: equal to DifferenceAverage  (glcm.py:460)"""
         raise DeprecationWarning("GLCM - Dissimilarity is mathematically equal to GLCM - Difference Average")
 
     def getJointEnergyFeatureValue(self):
+        """Σij p(i,j)²  (glcm.py:480)"""
         return np.nanmean(np.sum(self.P_glcm ** 2, (1, 2)), 1)
 
     def getJointEntropyFeatureValue(self):
+        """HXY = −Σij p(i,j) log2(p(i,j) + ε)  (glcm.py:498)"""
         return np.nanmean(self.coefficients["HXY"], 1)
 
     @deprecated
     def getHomogeneity1FeatureValue(self):
+        """deprecated: equal to Id  (glcm.py:516)"""
         raise DeprecationWarning("GLCM - Homogeneity 1 is mathematically equal to GLCM - Inverse Difference")
 
     @deprecated
     def getHomogeneity2FeatureValue(self):
+        """deprecated: equal to Idm  (glcm.py:536)"""
         raise DeprecationWarning("GLCM - Homogeneity 2 is mathematically equal to GLCM - Inverse Difference Moment")
 
     def getImc1FeatureValue(self):
+        """(HXY − HXY1) / max(HX, HY); 0 where both marginal entropies are 0  (glcm.py:555)"""
         c = self.coefficients
         px, py = c["px"], c["py"]
         HX = (-1) * np.sum(px * np.log2(px + _EPS), (1, 2))
@@ -224,6 +240,7 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
         return np.nanmean(imc1, 1)
 
     def getImc2FeatureValue(self):
+        """sqrt(1 − exp(−2 (HXY2 − HXY))); 0 where HXY > HXY2 (numerical noise on flat regions)  (glcm.py:614)"""
         c = self.coefficients
         pxy = c["px"] * c["py"]
         HXY2 = (-1) * np.sum(pxy * np.log2(pxy + _EPS), (1, 2))
@@ -232,6 +249,7 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
         return np.nanmean(imc2, 1)
 
     def getIdmFeatureValue(self):
+        """Σk p(x−y)(k) / (1 + k²)  (glcm.py:649)"""
         return self._diff_weighted(1 + self.coefficients["kValuesDiff"] ** 2)
 
     def getMCCFeatureValue(self):
@@ -252,35 +270,44 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
         return np.nanmean(mcc, 1)
 
     def getIdmnFeatureValue(self):
+        """Σk p(x−y)(k) / (1 + k² / Ng²)  (glcm.py:709)"""
         c = self.coefficients
         return self._diff_weighted(1 + (c["kValuesDiff"] ** 2) / (c["Ng"] ** 2))
 
     def getIdFeatureValue(self):
+        """Σk p(x−y)(k) / (1 + k)  (glcm.py:729)"""
         return self._diff_weighted(1 + self.coefficients["kValuesDiff"])
 
     def getIdnFeatureValue(self):
+        """Σk p(x−y)(k) / (1 + k / Ng)  (glcm.py:744)"""
         c = self.coefficients
         return self._diff_weighted(1 + c["kValuesDiff"] / c["Ng"])
 
     def getInverseVarianceFeatureValue(self):
+        """Σ(k>0) p(x−y)(k) / k²  (glcm.py:762)"""
         c = self.coefficients
         return np.nanmean(np.sum(c["pxSuby"][:, 1:, :] / c["kValuesDiff"][None, 1:, None] ** 2, 1), 1)
 
     def getMaximumProbabilityFeatureValue(self):
+        """max p(i,j)  (glcm.py:778)"""
         return np.nanmean(np.amax(self.P_glcm, (1, 2)), 1)
 
     def getSumAverageFeatureValue(self):
+        """Σk k · p(x+y)(k), k = 2 .. 2Ng  (glcm.py:795)"""
         c = self.coefficients
         return np.nanmean(np.sum(c["kValuesSum"][None, :, None] * c["pxAddy"], 1), 1)
 
     @deprecated
     def getSumVarianceFeatureValue(self):
+        """deprecated: equal to ClusterTendency  (glcm.py:825)"""
         raise DeprecationWarning("GLCM - Sum Variance is mathematically equal to GLCM - Cluster Tendency")
 
     def getSumEntropyFeatureValue(self):
+        """−Σk p(x+y)(k) log2(p(x+y)(k) + ε)  (glcm.py:844)"""
         p = self.coefficients["pxAddy"]
         return np.nanmean((-1) * np.sum(p * np.log2(p + _EPS), 1), 1)
 
     def getSumSquaresFeatureValue(self):
+        """Σij (i − μx)² p(i,j)  (glcm.py:859)"""
         c = self.coefficients
         return np.nanmean(np.sum(self.P_glcm * (c["i"][None, :, :, None] - c["ux"]) ** 2, (1, 2)), 1)

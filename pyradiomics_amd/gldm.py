@@ -57,57 +57,73 @@ class RadiomicsGLDM(_ZoneLikeFeatures):
         return P
 
     def getSmallDependenceEmphasisFeatureValue(self):
+        """Σij P(i,j) / j² / Nz  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:138)"""
         c = self.coefficients
         return np.sum(c["pd"] / (c["jvector"][None, :] ** 2), 1) / c["Nz"]
 
     def getLargeDependenceEmphasisFeatureValue(self):
+        """Σij P(i,j) j² / Nz  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:154)"""
         return self._over_sizes(self.coefficients["jvector"] ** 2)
 
     def getGrayLevelNonUniformityFeatureValue(self):
+        """Σi (Σj P(i,j))² / Nz  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:170)"""
         c = self.coefficients
         return np.sum(c["pg"] ** 2, 1) / c["Nz"]
 
     @deprecated
     def getGrayLevelNonUniformityNormalizedFeatureValue(self):
+        """deprecated: equal to first order Uniformity  (gldm.py:186)"""
         raise DeprecationWarning("GLDM - Gray Level Non-Uniformity Normalized is mathematically equal to "
                                  "First Order - Uniformity")
 
     def getDependenceNonUniformityFeatureValue(self):
+        """Σj (Σi P(i,j))² / Nz  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:207)"""
         c = self.coefficients
         return np.sum(c["pd"] ** 2, 1) / c["Nz"]
 
     def getDependenceNonUniformityNormalizedFeatureValue(self):
+        """Σj (Σi P(i,j))² / Nz²  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:222)"""
         c = self.coefficients
         return np.sum(c["pd"] ** 2, 1) / c["Nz"] ** 2
 
     def getGrayLevelVarianceFeatureValue(self):
+        """Σij p(i,j) (i − μ)² with μ = Σij p(i,j) i  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:237)"""
         return self._level_variance()
 
     def getDependenceVarianceFeatureValue(self):
+        """Σij p(i,j) (j − μ)² with μ = Σij p(i,j) j  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:256)"""
         return self._size_variance()
 
     def getDependenceEntropyFeatureValue(self):
+        """−Σij p(i,j) log2(p(i,j) + ε)  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:275)"""
         return self._entropy()
 
     @deprecated
     def getDependencePercentageFeatureValue(self):
+        """deprecated: always 1 (every ROI voxel has a dependence zone)  (gldm.py:291)"""
         raise DeprecationWarning("GLDM - Dependence Percentage always computes 1")
 
     def getLowGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) / i² / Nz  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:310)"""
         c = self.coefficients
         return np.sum(c["pg"] / (c["ivector"][None, :] ** 2), 1) / c["Nz"]
 
     def getHighGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) i² / Nz  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:326)"""
         return self._over_levels(self.coefficients["ivector"] ** 2)
 
     def getSmallDependenceLowGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) / (i² j²) / Nz  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:342)"""
         return np.sum(self.P_gldm / ((self._iw() ** 2) * (self._jw() ** 2)), (1, 2)) / self.coefficients["Nz"]
 
     def getSmallDependenceHighGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) i² / j² / Nz  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:364)"""
         return np.sum(self.P_gldm * (self._iw() ** 2) / (self._jw() ** 2), (1, 2)) / self.coefficients["Nz"]
 
     def getLargeDependenceLowGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) j² / i² / Nz  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:387)"""
         return np.sum(self.P_gldm * (self._jw() ** 2) / (self._iw() ** 2), (1, 2)) / self.coefficients["Nz"]
 
     def getLargeDependenceHighGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) i² j² / Nz  [j = dependence size; Nz = Σ P(i,j) = Np]  (gldm.py:410)"""
         return np.sum(self.P_gldm * ((self._jw() ** 2) * (self._iw() ** 2)), (1, 2)) / self.coefficients["Nz"]

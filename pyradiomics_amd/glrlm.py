@@ -78,35 +78,43 @@ class RadiomicsGLRLM(RadiomicsFeaturesBase):
         return np.nanmean(np.sum(self.P_glrlm * weight, (1, 2)) / self.coefficients["Nr"], 1)
 
     def getShortRunEmphasisFeatureValue(self):
+        """Σij P(i,j) / j² / Nr(θ)  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:196)"""
         c = self.coefficients
         return np.nanmean(np.sum(c["pr"] / (c["jvector"][None, :, None] ** 2), 1) / c["Nr"], 1)
 
     def getLongRunEmphasisFeatureValue(self):
+        """Σij P(i,j) j² / Nr(θ)  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:213)"""
         c = self.coefficients
         return np.nanmean(np.sum(c["pr"] * (c["jvector"][None, :, None] ** 2), 1) / c["Nr"], 1)
 
     def getGrayLevelNonUniformityFeatureValue(self):
+        """Σi (Σj P(i,j))² / Nr(θ)  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:230)"""
         c = self.coefficients
         return np.nanmean(np.sum(c["pg"] ** 2, 1) / c["Nr"], 1)
 
     def getGrayLevelNonUniformityNormalizedFeatureValue(self):
+        """Σi (Σj P(i,j))² / Nr(θ)²  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:246)"""
         c = self.coefficients
         return np.nanmean(np.sum(c["pg"] ** 2, 1) / (c["Nr"] ** 2), 1)
 
     def getRunLengthNonUniformityFeatureValue(self):
+        """Σj (Σi P(i,j))² / Nr(θ)  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:262)"""
         c = self.coefficients
         return np.nanmean(np.sum(c["pr"] ** 2, 1) / c["Nr"], 1)
 
     def getRunLengthNonUniformityNormalizedFeatureValue(self):
+        """Σj (Σi P(i,j))² / Nr(θ)²  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:278)"""
         c = self.coefficients
         return np.nanmean(np.sum(c["pr"] ** 2, 1) / c["Nr"] ** 2, 1)
 
     def getRunPercentageFeatureValue(self):
+        """Nr(θ) / Np  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:294)"""
         c = self.coefficients
         Np = np.sum(c["pr"] * c["jvector"][None, :, None], 1)
         return np.nanmean(c["Nr"] / Np, 1)
 
     def getGrayLevelVarianceFeatureValue(self):
+        """Σij p(i,j) (i − μ)² with μ = Σij p(i,j) i  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:319)"""
         c = self.coefficients
         i = c["ivector"][None, :, None]
         pg = c["pg"] / c["Nr"][:, None, :]
@@ -114,6 +122,7 @@ class RadiomicsGLRLM(RadiomicsFeaturesBase):
         return np.nanmean(np.sum(pg * (i - u) ** 2, 1), 1)
 
     def getRunVarianceFeatureValue(self):
+        """Σij p(i,j) (j − μ)² with μ = Σij p(i,j) j  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:340)"""
         c = self.coefficients
         j = c["jvector"][None, :, None]
         pr = c["pr"] / c["Nr"][:, None, :]
@@ -121,25 +130,32 @@ class RadiomicsGLRLM(RadiomicsFeaturesBase):
         return np.nanmean(np.sum(pr * (j - u) ** 2, 1), 1)
 
     def getRunEntropyFeatureValue(self):
+        """−Σij p(i,j) log2(p(i,j) + ε)  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:361)"""
         p = self.P_glrlm / self.coefficients["Nr"][:, None, None, :]
         return np.nanmean(-np.sum(p * np.log2(p + _EPS), (1, 2)), 1)
 
     def getLowGrayLevelRunEmphasisFeatureValue(self):
+        """Σij P(i,j) / i² / Nr(θ)  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:383)"""
         c = self.coefficients
         return np.nanmean(np.sum(c["pg"] / (c["ivector"][None, :, None] ** 2), 1) / c["Nr"], 1)
 
     def getHighGrayLevelRunEmphasisFeatureValue(self):
+        """Σij P(i,j) i² / Nr(θ)  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:400)"""
         c = self.coefficients
         return np.nanmean(np.sum(c["pg"] * (c["ivector"][None, :, None] ** 2), 1) / c["Nr"], 1)
 
     def getShortRunLowGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) / (i² j²) / Nr(θ)  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:417)"""
         return self._joint(1.0 / ((self._i() ** 2) * (self._j() ** 2)))
 
     def getShortRunHighGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) i² / j² / Nr(θ)  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:445)"""
         return np.nanmean(np.sum(self.P_glrlm * (self._i() ** 2) / (self._j() ** 2), (1, 2)) / self.coefficients["Nr"], 1)
 
     def getLongRunLowGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) j² / i² / Nr(θ)  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:471)"""
         return np.nanmean(np.sum(self.P_glrlm * (self._j() ** 2) / (self._i() ** 2), (1, 2)) / self.coefficients["Nr"], 1)
 
     def getLongRunHighGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) i² j² / Nr(θ)  [j = run size; Nr(θ) = Σ P(i,j|θ), per angle, mean over angles]  (glrlm.py:497)"""
         return self._joint((self._j() ** 2) * (self._i() ** 2))

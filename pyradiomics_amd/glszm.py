@@ -107,55 +107,71 @@ class RadiomicsGLSZM(_ZoneLikeFeatures):
         c["jvector"] = np.delete(j, unused)
 
     def getSmallAreaEmphasisFeatureValue(self):
+        """Σij P(i,j) / j² / Nz  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:140)"""
         c = self.coefficients
         return np.sum(c["ps"] / (c["jvector"][None, :] ** 2), 1) / c["Nz"]
 
     def getLargeAreaEmphasisFeatureValue(self):
+        """Σij P(i,j) j² / Nz  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:156)"""
         return self._over_sizes(self.coefficients["jvector"] ** 2)
 
     def getGrayLevelNonUniformityFeatureValue(self):
+        """Σi (Σj P(i,j))² / Nz  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:172)"""
         c = self.coefficients
         return np.sum(c["pg"] ** 2, 1) / c["Nz"]
 
     def getGrayLevelNonUniformityNormalizedFeatureValue(self):
+        """Σi (Σj P(i,j))² / Nz²  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:187)"""
         c = self.coefficients
         return np.sum(c["pg"] ** 2, 1) / c["Nz"] ** 2
 
     def getSizeZoneNonUniformityFeatureValue(self):
+        """Σj (Σi P(i,j))² / Nz  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:202)"""
         c = self.coefficients
         return np.sum(c["ps"] ** 2, 1) / c["Nz"]
 
     def getSizeZoneNonUniformityNormalizedFeatureValue(self):
+        """Σj (Σi P(i,j))² / Nz²  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:217)"""
         c = self.coefficients
         return np.sum(c["ps"] ** 2, 1) / c["Nz"] ** 2
 
     def getZonePercentageFeatureValue(self):
+        """Nz / Np  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:232)"""
         return self.coefficients["Nz"] / self.coefficients["Np"]
 
     def getGrayLevelVarianceFeatureValue(self):
+        """Σij p(i,j) (i − μ)² with μ = Σij p(i,j) i  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:249)"""
         return self._level_variance()
 
     def getZoneVarianceFeatureValue(self):
+        """Σij p(i,j) (j − μ)² with μ = Σij p(i,j) j  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:269)"""
         return self._size_variance()
 
     def getZoneEntropyFeatureValue(self):
+        """−Σij p(i,j) log2(p(i,j) + ε)  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:289)"""
         return self._entropy()
 
     def getLowGrayLevelZoneEmphasisFeatureValue(self):
+        """Σij P(i,j) / i² / Nz  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:309)"""
         c = self.coefficients
         return np.sum(c["pg"] / (c["ivector"][None, :] ** 2), 1) / c["Nz"]
 
     def getHighGrayLevelZoneEmphasisFeatureValue(self):
+        """Σij P(i,j) i² / Nz  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:325)"""
         return self._over_levels(self.coefficients["ivector"] ** 2)
 
     def getSmallAreaLowGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) / (i² j²) / Nz  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:341)"""
         return np.sum(self.P_glszm / ((self._iw() ** 2) * (self._jw() ** 2)), (1, 2)) / self.coefficients["Nz"]
 
     def getSmallAreaHighGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) i² / j² / Nz  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:364)"""
         return np.sum(self.P_glszm * (self._iw() ** 2) / (self._jw() ** 2), (1, 2)) / self.coefficients["Nz"]
 
     def getLargeAreaLowGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) j² / i² / Nz  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:388)"""
         return np.sum(self.P_glszm * (self._jw() ** 2) / (self._iw() ** 2), (1, 2)) / self.coefficients["Nz"]
 
     def getLargeAreaHighGrayLevelEmphasisFeatureValue(self):
+        """Σij P(i,j) i² j² / Nz  [j = zone size; Nz = Σ P(i,j)]  (glszm.py:412)"""
         return np.sum(self.P_glszm * (self._iw() ** 2) * (self._jw() ** 2), (1, 2)) / self.coefficients["Nz"]

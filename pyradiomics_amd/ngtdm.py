@@ -54,6 +54,7 @@ class RadiomicsNGTDM(RadiomicsFeaturesBase):
         return f
 
     def getCoarsenessFeatureValue(self):
+        """1 / Σi p(i) s(i); 10⁶ where the sum is 0 (completely homogeneous region)  (ngtdm.py:133)"""
         c = self.coefficients
         s = np.sum(c["p_i"] * c["s_i"], 1)
         s[s != 0] = 1 / s[s != 0]
@@ -61,6 +62,7 @@ class RadiomicsNGTDM(RadiomicsFeaturesBase):
         return s
 
     def getContrastFeatureValue(self):
+        """(1 / (Ngp (Ngp − 1)) · Σij p(i) p(j) (i − j)²) · (1 / Nvp · Σi s(i)); 0 for one grey level  (ngtdm.py:153)"""
         c = self.coefficients
         p, i = c["p_i"], c["ivector"]
         div = c["Ngp"] * (c["Ngp"] - 1)
@@ -71,6 +73,7 @@ class RadiomicsNGTDM(RadiomicsFeaturesBase):
         return val
 
     def getBusynessFeatureValue(self):
+        """Σi p(i) s(i) / Σij |i p(i) − j p(j)| over levels with p ≠ 0; 0 for one grey level  (ngtdm.py:192)"""
         c = self.coefficients
         ip = c["ivector"] * c["p_i"]
         absdiff = np.sum(self._pairs(np.abs(ip[:, :, None] - ip[:, None, :])), (1, 2))
@@ -80,6 +83,7 @@ class RadiomicsNGTDM(RadiomicsFeaturesBase):
         return val
 
     def getComplexityFeatureValue(self):
+        """1 / Nvp · Σij |i − j| (p(i) s(i) + p(j) s(j)) / (p(i) + p(j)) over levels with p ≠ 0  (ngtdm.py:223)"""
         c = self.coefficients
         p, i = c["p_i"], c["ivector"]
         ps = p * c["s_i"]
@@ -89,6 +93,7 @@ class RadiomicsNGTDM(RadiomicsFeaturesBase):
         return np.sum(np.abs(i[:, :, None] - i[:, None, :]) * num / den, (1, 2)) / c["Nvp"]
 
     def getStrengthFeatureValue(self):
+        """Σij (p(i) + p(j)) (i − j)² / Σi s(i) over levels with p ≠ 0; 0 where Σ s(i) = 0  (ngtdm.py:256)"""
         c = self.coefficients
         p, i = c["p_i"], c["ivector"]
         tot = np.sum(c["s_i"], 1)

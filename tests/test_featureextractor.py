@@ -430,3 +430,18 @@ def test_reference_example_parameter_files_are_accepted():
     for f in files:
         ex = RadiomicsFeatureExtractor(f)
         assert ex.enabledImagetypes and "shape" not in ex.enabledFeatures
+
+
+def test_every_feature_is_documented_with_its_reference_location():
+    """mirror of the reference's tests/test_docstrings.py: every get<Name>FeatureValue carries a formula docstring that
+    cites the reference method it restates"""
+    import re
+    from pyradiomics_amd.featureextractor import getFeatureClasses
+    n = 0
+    for cname, cls in getFeatureClasses().items():
+        for feature in cls.getFeatureNames():
+            doc = getattr(cls, "get%sFeatureValue" % feature).__doc__
+            assert doc and doc.strip(), (cname, feature)
+            assert re.search(r"\(%s\.py:\d+(-\d+)?\)" % cname, doc), (cname, feature, doc)
+            n += 1
+    assert n == 100
