@@ -428,3 +428,29 @@ def getMask(mask, **kwargs):
             raise ValueError("No labels found in this mask (i.e. nothing is segmented)!")
         raise ValueError("Label (%g) not present in mask. Choose from %s" % (label, labels[labels != 0]))
     return mask
+
+
+def checkMask(image, mask, **kwargs):
+    """The reference's entry point (imageoperations.py:177-312) for callers that use it directly: geometry check /
+    correction, label present, ``minimumROIDimensions`` and ``minimumROISize``.  Returns (boundingBox, correctedMask)
+    with boundingBox = (L_x, U_x, L_y, U_y, L_z, U_z) as the reference, correctedMask None unless the mask was resampled.
+    (RadiomicsFeatureExtractor.execute performs the same checks on the device-resident case.)"""
+    label = int(kwargs.get("label", 1))
+    checked = checkMaskGeometry(image, mask, **kwargs)
+    corrected = None if checked is mask else checked
+    roi = checked.array == label
+    if not roi.any():
+        raise ValueError("Label (%g) not present in mask" % label)
+    lo, hi = boundingBox(roi)
+    bb = np.empty(2 * len(lo), dtype=np.int64)
+    bb[0::2], bb[1::2] = lo[::-1], hi[::-1]
+    ndims = int(np.sum(hi - lo + 1 > 1))
+    if ndims == 0:
+        raise ValueError("mask only contains 1 segmented voxel! Cannot extract features for a single voxel.")
+    minDims = kwargs.get("minimumROIDimensions", 2)
+    if ndims < minDims:
+        raise ValueError("mask has too few dimensions (number of dimensions %d, minimum required %d)" % (ndims, minDims))
+    minSize = kwargs.get("minimumROISize")
+    if minSize is not None and int(roi.sum()) <= minSize:
+        raise ValueError("Size of the ROI is too small (minimum size: %g, ROI size: %g" % (minSize, int(roi.sum())))
+    return bb, corrected

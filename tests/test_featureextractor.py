@@ -445,3 +445,31 @@ def test_every_feature_is_documented_with_its_reference_location():
             assert re.search(r"\(%s\.py:\d+(-\d+)?\)" % cname, doc), (cname, feature, doc)
             n += 1
     assert n == 100
+
+
+def test_check_mask_entry_point():
+    """imageoperations.checkMask (:177-312): bounding box in the reference's (L_x, U_x, L_y, U_y, L_z, U_z) order and
+    the ROI constraints"""
+    from pyradiomics_amd import imageoperations as io
+    from pyradiomics_amd.image import Image
+    img = Image(np.zeros((6, 8, 10), np.int16))
+    m = np.zeros((6, 8, 10), np.uint8)
+    m[1:4, 2:7, 3:9] = 1
+    bb, corrected = io.checkMask(img, Image(m))
+    assert list(bb) == [3, 8, 2, 6, 1, 3] and corrected is None
+    with pytest.raises(ValueError, match="not present"):
+        io.checkMask(img, Image(m), label=2)
+    line = np.zeros_like(m)
+    line[2, 3, 1:6] = 1
+    with pytest.raises(ValueError, match="too few dimensions"):
+        io.checkMask(img, Image(line))
+    assert list(io.checkMask(img, Image(line), minimumROIDimensions=1)[0]) == [1, 5, 3, 3, 2, 2]
+    one = np.zeros_like(m)
+    one[2, 3, 4] = 1
+    with pytest.raises(ValueError, match="1 segmented voxel"):
+        io.checkMask(img, Image(one), minimumROIDimensions=1)
+    with pytest.raises(ValueError, match="too small"):
+        io.checkMask(img, Image(m), minimumROISize=90)
+    sub = Image(m[1:4].copy(), origin=(0.0, 0.0, 1.0))
+    bb, corrected = io.checkMask(img, sub, correctMask=True)
+    assert list(bb) == [3, 8, 2, 6, 1, 3] and corrected is not None and np.array_equal(corrected.array, m)
