@@ -11,6 +11,7 @@
 #include "prad_runtime.h"
 #include "kernels_generic.h"
 #include "kernels_sweep.h"
+#include "kernels_sweepfw.h"
 #include "kernels_neigh.h"
 #include "kernels_glszm.h"
 #include "kernels_filters.h"
@@ -242,6 +243,11 @@ struct SweepPlan {
   int RSr = 0;
   bool LONGr = false;
   size_t lds_bytes_rows = 0;
+  // fixed-window lines kernel (kernels_sweepfw.h): rows of 65..512 voxels, fused table
+  bool fw = false;
+  int fwK = 8;                 // window columns per lane (4: rows up to 256, 8: up to 512)
+  int fw_blocks = 1;           // workgroups per angle
+  FwSet fwset;
 };
 
 constexpr size_t kHistBudget = 72 * 1024;      // LDS bytes a lines workgroup may spend on histograms
@@ -333,7 +339,11 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     if (v == 1 || v == 2 || v == 4) p.LPL = v;
   }
   p.vec_rows = (p.Nx % 16) == 0;
-  p.padw = std::min(64 * p.LPL, p.Nx);
+  // fixed-window kernel: needs the fused table and rows that one wave window (64 lanes x 4 or 8 columns) covers
+  p.fw = p.fused && p.Nx > 64 && p.Nx <= 512 && !getenv("PRAD_NO_FW");
+  if (const char *e = getenv("PRAD_FW_MINVOX")) p.fw = p.fw && k.g.n >= atoll(e);
+  p.fwK = p.Nx <= 256 ? 4 : 8;
+  p.padw = p.fw ? 0 : std::min(64 * p.LPL, p.Nx);
   p.pitch = (p.Nx + p.padw + 15) & ~15;   // 16-byte aligned rows: vector staging in the rows kernel for any Nx
   p.lines.count = 0;
   p.aset.count = k.Na;
@@ -365,6 +375,32 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     }
     D.LXc = (p.Nx + 64 * p.LPL - 1) / (64 * p.LPL);
     D.chunks = (long long)D.NU * D.LXc;
+  }
+  if (p.fw && p.lines.count > 0) {
+    // one workgroup (16 waves) per CU over all angles; a walk is cut into pieces so that every wave gets ~6 chunks
+    p.fw_blocks = std::max(1, cu_count() / p.lines.count);
+    if (const char *e = getenv("PRAD_FW_BLOCKS")) p.fw_blocks = std::max(1, atoi(e));
+    int per_wave = 6;
+    if (const char *e = getenv("PRAD_FW_PER_WAVE")) per_wave = std::max(1, atoi(e));
+    p.fwset.count = p.lines.count;
+    p.fwset.NX = p.Nx;
+    for (int i = 0; i < p.lines.count; i++) {
+      const SweepDesc &S = p.lines.d[i];
+      FwDesc &D = p.fwset.d[i];
+      D.slot = S.slot; D.NM = S.NM; D.NU = S.NU; D.du = S.du; D.dx = S.dx; D.sM = S.sM; D.sU = S.sU;
+      const long long want = (long long)per_wave * p.fw_blocks * 16;
+      int pieces = (int)std::max<long long>(1, (want + D.NU - 1) / D.NU);
+      int CL = ((D.NM + pieces - 1) / pieces + 7) & ~7;
+      CL = std::max(CL, 16);
+      if (const char *e = getenv("PRAD_FW_CL")) CL = std::max(8, atoi(e) & ~7);
+      D.CL = CL;
+      D.pieces = (D.NM + CL - 1) / CL;
+      const long long chunks = (long long)D.NU * D.pieces;
+      if (chunks > 2000000000LL) return p;   // (cannot happen below 2^31 voxels) -> generic path
+      D.chunks = (int)chunks;
+    }
+  } else {
+    p.fw = false;
   }
   p.ok = true;
   return p;
@@ -402,6 +438,23 @@ int launch_lines(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int
   return launch_lines_lpl<G, R, LNG, F, 1>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
 }
 
+template <bool LNG, int K>
+int launch_fw_k(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
+                int *multi) {
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_kernel<LNG, K>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+  hipLaunchKernelGGL((sweep_fw_kernel<LNG, K>), dim3(p.fw_blocks, p.fwset.count), dim3(1024), p.lds_bytes, k.s, p.fwset,
+                     levels, Ng, Nr, p.RS, glcm_acc, glrlm_acc, multi + PRAD_MAX_SWEEP, k.flags_d);
+  return check_launch("sweep_fw_kernel");
+}
+int launch_fw(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
+              int *multi) {
+  if (p.LONG) return p.fwK == 4 ? launch_fw_k<true, 4>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)
+                                : launch_fw_k<true, 8>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
+  return p.fwK == 4 ? launch_fw_k<false, 4>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)
+                    : launch_fw_k<false, 8>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
+}
+
 template <bool G, bool R, bool LNG, bool F>
 int launch_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
                 int *multi) {
@@ -421,7 +474,9 @@ template <bool G, bool R, bool F>
 int launch_sweeps(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
                   int *multi) {
   Timed t(*k.c, "sweep", k.s);
-  if (p.lines.count > 0) {
+  if (p.lines.count > 0 && p.fw && G && R && F) {
+    PRAD_TRY(launch_fw(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi));
+  } else if (p.lines.count > 0) {
     if (R && p.LONG) PRAD_TRY((launch_lines<G, R, true, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
     else PRAD_TRY((launch_lines<G, R, false, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   }
@@ -437,7 +492,8 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
   Context &c = *k.c;
   uint8_t *levels = nullptr;
   const long long nrows = (long long)p.Nz * p.Ny;
-  PRAD_TRY(c.get<uint8_t>("levels", (size_t)nrows * p.pitch + 512, &levels));
+  PRAD_TRY(c.get<uint8_t>("levels", (size_t)nrows * p.pitch + 1024, &levels));
+  levels += 512;   // the fixed-window kernel reads (and masks) up to one window before the first and behind the last row
   u32 *glcm_acc = nullptr, *glrlm_acc = nullptr;
   int *multi = nullptr;
   const size_t nglcm = glcm ? (size_t)k.Na * Ng * Ng : 0, nglrlm = glrlm ? (size_t)k.Na * Ng * Nr : 0;

@@ -1,0 +1,130 @@
+"""GPU parity of the fixed-window sweep kernel (csrc/kernels_sweepfw.h: rows of 65..512 voxels, fused GLCM+GLRLM table)
+against the CPU checkers: the reference's own cmatrices.c (oracle/_ref) when that prebuilt file travelled with the
+repo, otherwise our C restatement.  Bit-exact, every edge of the design exercised: rows that fill the window exactly
+(256 with 4 columns per lane, 512 with 8) and ragged ones, pieces + tails (PRAD_FW_CL forces many short pieces),
+rows that wrap (dy != 0 with Ny smaller / larger than Nz), runs longer than the table's length slots, flat volumes,
+partial masks, a mask with whole empty planes."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cm():
+    from pyradiomics_amd import cmatrices
+    return cmatrices
+
+
+@pytest.fixture(scope="module")
+def checker(oracle_port):
+    from oracle import binding
+    return binding.ref() if binding.have_ref() else oracle_port
+
+
+def _levels(seed, shape, Ng, kind):
+    rng = np.random.default_rng(seed)
+    if kind == "uniform":
+        return rng.integers(1, Ng + 1, size=shape).astype(np.int32)
+    if kind == "flat":
+        return np.full(shape, 1 + seed % Ng, np.int32)
+    from scipy import ndimage
+    sigma = 2.0 if kind == "smooth" else 6.0        # "blobs": runs of tens of voxels
+    f = ndimage.gaussian_filter(rng.standard_normal(shape), sigma)
+    f = (f - f.min()) / (f.max() - f.min() + 1e-12)
+    return np.minimum((f * Ng).astype(np.int32) + 1, Ng)
+
+
+def _mask(seed, shape, kind):
+    rng = np.random.default_rng(seed + 99)
+    if kind == "full":
+        return np.ones(shape, bool)
+    if kind == "random":
+        return rng.random(shape) < 0.7
+    zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, n) for n in shape], indexing="ij")
+    return (zz ** 2 + yy ** 2 + xx ** 2) < 0.8        # ball: empty corners, long outside stretches
+
+
+def _check(cm, checker, img, mask, Ng):
+    from pyradiomics_amd import _lib
+    Nr = int(max(img.shape))
+    g, r, ang = cm.calculate_glcm_glrlm(img, mask, Ng, Nr, False, 0)
+    assert _lib.last_path() == "sweep"
+    eg, eang = checker.calculate_glcm(img, mask, [1], Ng, False, 0)
+    er, _ = checker.calculate_glrlm(img, mask, Ng, Nr, False, 0)
+    assert np.array_equal(ang, eang)
+    bad = np.argwhere(g != eg)
+    assert bad.size == 0, "GLCM differs at %d entries, first (i, j, angle) = %s: %s vs %s; angle %s" % (
+        len(bad), bad[0], g[tuple(bad[0])], eg[tuple(bad[0])], ang[bad[0][-1]])
+    bad = np.argwhere(r != er)
+    assert bad.size == 0, "GLRLM differs at %d entries, first (i, len-1, angle) = %s: %s vs %s; angle %s" % (
+        len(bad), bad[0], r[tuple(bad[0])], er[tuple(bad[0])], ang[bad[0][-1]])
+
+
+SHAPES = [(20, 24, 512), (24, 20, 256), (18, 30, 511), (30, 18, 257), (9, 40, 300), (40, 9, 65), (26, 26, 128),
+          (33, 12, 200), (12, 33, 500), (70, 16, 72)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("kind", ["uniform", "smooth"])
+def test_fw_shapes(cm, checker, shape, kind):
+    img = _levels(hash(shape) % 997, shape, 32, kind)
+    _check(cm, checker, img, _mask(1, shape, "full"), 32)
+
+
+@pytest.mark.parametrize("shape", [(20, 24, 512), (30, 18, 257), (24, 20, 256)])
+@pytest.mark.parametrize("mkind", ["random", "ball"])
+@pytest.mark.parametrize("kind", ["uniform", "blobs"])
+def test_fw_masks(cm, checker, shape, mkind, kind):
+    img = _levels(5, shape, 32, kind)
+    _check(cm, checker, img, _mask(2, shape, mkind), 32)
+
+
+@pytest.mark.parametrize("shape", [(40, 44, 512), (64, 20, 256), (24, 70, 130)])
+@pytest.mark.parametrize("kind", ["blobs", "flat"])
+def test_fw_long_runs(cm, checker, shape, kind):
+    img = _levels(3, shape, 16, kind)
+    _check(cm, checker, img, _mask(3, shape, "full"), 16)
+    if kind == "flat":   # a flat slab inside noise: every line crosses it, runs end on its faces at the same step
+        img2 = _levels(4, shape, 16, "uniform")
+        img2[shape[0] // 4: shape[0] // 2, 3:-3, 10:-10] = 7
+        _check(cm, checker, img2, _mask(3, shape, "full"), 16)
+
+
+@pytest.mark.parametrize("cl", ["8", "16", "24"])
+@pytest.mark.parametrize("shape", [(37, 29, 512), (50, 21, 256), (23, 41, 100)])
+def test_fw_short_pieces(cm, checker, shape, cl, monkeypatch):
+    """every piece boundary + tail combination: pieces of 8..24 steps over walks of 21..50 steps"""
+    monkeypatch.setenv("PRAD_FW_CL", cl)
+    for kind, mkind in (("uniform", "full"), ("blobs", "ball"), ("smooth", "random")):
+        _check(cm, checker, _levels(8, shape, 24, kind), _mask(4, shape, mkind), 24)
+
+
+@pytest.mark.parametrize("Ng", [2, 7, 40])
+def test_fw_levels(cm, checker, Ng):
+    shape = (21, 22, 320)
+    _check(cm, checker, _levels(6, shape, Ng, "uniform"), _mask(5, shape, "random"), Ng)
+    _check(cm, checker, _levels(6, shape, Ng, "smooth"), _mask(5, shape, "full"), Ng)
+
+
+def test_fw_empty_planes_and_rows(cm, checker):
+    shape = (30, 30, 512)
+    img = _levels(9, shape, 32, "uniform")
+    mask = np.ones(shape, bool)
+    mask[10:14] = False
+    mask[:, 5:9] = False
+    mask[:, :, 100:140] = False
+    _check(cm, checker, img, mask, 32)
+
+
+def test_fw_matches_wrapped_lines_kernel(cm, monkeypatch):
+    """the two line kernels against each other on a volume the CPU checkers would take minutes for"""
+    shape = (160, 192, 512)
+    img = _levels(12, shape, 32, "smooth")
+    mask = _mask(7, shape, "ball")
+    g1, r1, _ = cm.calculate_glcm_glrlm(img, mask, 32, 512, False, 0)
+    monkeypatch.setenv("PRAD_NO_FW", "1")
+    g0, r0, _ = cm.calculate_glcm_glrlm(img, mask, 32, 512, False, 0)
+    assert np.array_equal(g0, g1) and np.array_equal(r0, r1)
