@@ -40,30 +40,40 @@ struct FwSet {
   FwDesc d[PRAD_MAX_SWEEP];
 };
 
-#define PRAD_FW_DEAD (-(1 << 30))   // run state of a line that must ignore its next event (stays negative for any walk)
 #define PRAD_FW_U 8
+#define PRAD_FW_WORK_STRIDE 64   // ints between the chunk counters of two angles (256 B: a line of their own)
+// A DEAD line (one that must ignore its next event) keeps its run state in a scratch zone of RS+1 row slots behind the
+// table (state >= deadbase): the plain path can then walk it like any other line for RS steps -- its ignored event is a
+// ds_add into the zone -- and only lines that stay dead longer need the checked path.
+// The whole layout of kernels_sweep.h (fused table H, long-run table G, dummies) sits Q = 4(Ng+1) bytes into the LDS,
+// because the run state kept here is s = level*P + len*Q with len counted from 1 (the exec-masked step adds Q to every
+// line after the event lanes took their fresh value, see fw_plain_word): the bin of an event is s + cur, as there.
+__host__ __device__ inline size_t fw_lds_bytes(const HistLayout &h) { return 4 * ((size_t)h.words + (size_t)(h.RS + 3) * (h.Ng + 1)); }
+
 
 struct FwTab {   // wave-uniform constants of the fused table (layout: hist_layout(true, true, true, Ng, RS))
   u32 *rl_long;
-  int Nr, P4, Q, lenmax, gB, RL4, RS, RL, dummy0b;
+  int Nr, P4, Q, lenlim, gB, RL4, RS, RL, dummy0b, deadbase;
   unsigned Qinv;
   __device__ __forceinline__ void init(const HistLayout &h, int Nr_, u32 *rl_long_) {
     rl_long = rl_long_;
     Nr = Nr_;
     Q = 4 * (h.Ng + 1);
     P4 = (h.RS + 1) * (h.Ng + 1);
-    lenmax = h.RS * Q;
+    lenlim = (h.RS + 1) * Q;   // len*Q of the first run length without a slot of its own
     RS = h.RS;
     RL = h.RL;
     RL4 = 4 * h.RL;
-    gB = 4 * h.g0 - RL4 - 4 * h.RS;
+    gB = Q + 4 * h.g0 - RL4 - 4 * h.RS;
     Qinv = (unsigned)((0x100000000ull + (unsigned)Q - 1) / (unsigned)Q);
-    dummy0b = 4 * h.dummy0;
+    dummy0b = Q + 4 * h.dummy0;
+    deadbase = Q + 4 * h.words;
   }
 };
 
 // a run of level lv (!= 0) longer than RS just ended: record its length (LDS table G, or a wave-aggregated L2 atomic)
-__device__ __forceinline__ void fw_long_event(const FwTab &T, int lv, int lb) {
+//   lb = (len - 1) * Q
+__device__ __noinline__ void fw_long_event(const FwTab &T, int lv, int lb) {
   const int idx = (int)__umulhi((unsigned)lb, T.Qinv);  // len - 1
   if (idx < T.RS + T.RL) {
     lds_bump(T.gB + __mul24(lv, T.RL4) + (idx << 2));
@@ -84,24 +94,44 @@ __device__ __forceinline__ void fw_long_event(const FwTab &T, int lv, int lb) {
 }
 
 // One voxel-step of one line, every case handled: dead lines, runs beyond the table (clamped bin + length record).
-//   pl  level*P + (len-1)*Q of the open run (unclamped), or negative = dead;  x, c = level*4 of the previous / current voxel
-template <bool LONG, bool TAIL>
-__device__ __forceinline__ void fw_checked(const FwTab &T, int dummy, int &pl, int x, int c) {
+//   s  level*P + len*Q of the open run (unclamped; 0 = a line that has not seen a voxel yet), or >= deadbase = dead
+//   x, c = level*4 of the previous / current voxel
+template <bool LONG>
+__device__ __forceinline__ void fw_checked(const FwTab &T, int dummy, int &s, int x, int c, bool tail) {
   const bool chg = c != x;
-  const bool ev = chg && pl >= 0;
-  int bin = pl;
+  const bool ev = chg && s < T.deadbase;
+  int bin = s;
   if (LONG) {
-    const int lb = pl - __mul24(x, T.P4);
-    bin = pl - lb + min(lb, T.lenmax);
-    if (ev && x != 0 && lb >= T.lenmax) fw_long_event(T, x >> PRAD_FUSED_SHIFT, lb);
+    const int lb = s - __mul24(x, T.P4);   // len*Q
+    bin = s - lb + min(lb, T.lenlim);
+    if (ev && x != 0 && lb >= T.lenlim) fw_long_event(T, x >> PRAD_FUSED_SHIFT, lb - T.Q);
   }
   lds_bump(ev ? bin + c : dummy);
-  pl = select_i32(chg, TAIL ? PRAD_FW_DEAD : __mul24(c, T.P4), pl + T.Q);
+  s = select_i32(chg, tail ? T.deadbase : __mul24(c, T.P4) + T.Q, s + T.Q);
 }
 
-// the branch-free plain step of four lines whose levels are the byte lanes of c (current) and x (previous):
-// 6 VALU (SDWA byte operands) + 1 ds_add per line.  Only valid when no line is dead and no run can reach RS.
-__device__ __forceinline__ void fw_plain_word(const FwTab &T, int dummy, int &p0, int &p1, int &p2, int &p3, u32 c, u32 x) {
+// The plain step of four lines whose levels are the byte lanes of c (current) and x (previous).  Only valid when no
+// run can outgrow its slots (margin()) -- dead lines are fine, their events land in the dead zone.
+// Exec-masked: v_cmpx leaves only the lanes whose level changed active; they compute the bin (state + level byte),
+// bump it and take the fresh state level*P; then every lane adds Q (one more voxel on the open run / the first voxel
+// of the fresh one).  4 VALU + 1 SALU + 1 ds_add per voxel-step and the LDS only sees the event lanes
+// (the branch-free select form below costs 7 VALU and sends the other lanes to dummy words).
+__device__ __forceinline__ void fw_plain_word(const FwTab &T, int dummy, u32 one, int &p0, int &p1, int &p2, int &p3, u32 c, u32 x) {
+#ifndef PRAD_FW_NOASM
+  int t;
+#define PRAD_FW_COL(J, PJ)                                                                                              \
+  "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:BYTE_" #J " src1_sel:BYTE_" #J "\n\t"                                    \
+  "v_add_u32_sdwa %[t], %[" PJ "], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t"      \
+  "ds_add_u32 %[t], %[one]\n\t"                                                                                         \
+  "v_mul_u32_u24_sdwa %[" PJ "], %[P4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t" \
+  "s_mov_b64 exec, -1\n\t"                                                                                              \
+  "v_add_u32 %[" PJ "], %[Q], %[" PJ "]\n\t"
+  asm volatile(PRAD_FW_COL(0, "p0") PRAD_FW_COL(1, "p1") PRAD_FW_COL(2, "p2") PRAD_FW_COL(3, "p3")
+               : [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [t] "=&v"(t)
+               : [c] "v"(c), [x] "v"(x), [one] "v"(one), [P4] "s"(T.P4), [Q] "s"(T.Q)
+               : "vcc", "memory");
+#undef PRAD_FW_COL
+#else
   int *p[4] = {&p0, &p1, &p2, &p3};
   int addr[4], fresh[4], grown[4];
   bool chg[4];
@@ -110,13 +140,14 @@ __device__ __forceinline__ void fw_plain_word(const FwTab &T, int dummy, int &p0
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     addr[j] = *p[j] + (int)__builtin_amdgcn_ubfe(c, 8 * j, 8);
-    fresh[j] = (int)__umul24(__builtin_amdgcn_ubfe(c, 8 * j, 8), (unsigned)T.P4);
+    fresh[j] = (int)__umul24(__builtin_amdgcn_ubfe(c, 8 * j, 8), (unsigned)T.P4) + T.Q;
     grown[j] = *p[j] + T.Q;
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) lds_bump(chg[j] ? addr[j] : dummy);
 #pragma unroll
   for (int j = 0; j < 4; j++) *p[j] = select_i32(chg[j], fresh[j], grown[j]);
+#endif
 }
 
 __device__ __forceinline__ u32 fw_shr1(u32 v) {  // lane i <- lane i-1, lane 0 <- 0
@@ -149,13 +180,19 @@ __device__ __forceinline__ void fw_make_x(const u32 (&P)[K / 4], u32 (&X)[K / 4]
 struct __attribute__((packed)) u64_unaligned { unsigned long long v; };
 template <int KW>
 __device__ __forceinline__ void fw_load(const uint8_t *p, u32 (&v)[KW]) {
-#ifdef PRAD_DBG_NOLOAD  // ablation build: synthetic levels, no memory traffic
+#ifdef PRAD_DBG_NOLOAD  // ablation build: synthetic iid levels 1..32, no memory traffic
 #pragma unroll
   for (int w = 0; w < KW; w++) {
-    const u32 x = ((u32)(size_t)p + 977u * w) * 2654435761u;
-    v[w] = (((x >> 7) & 0x1f1f1f1fu) + 0x01010101u) << PRAD_FUSED_SHIFT;
+    u32 x = ((u32)(size_t)p + 977u * w) * 0x9E3779B1u;
+    x ^= x >> 15;
+    x *= 0x85EBCA77u;
+    x ^= x >> 13;
+    v[w] = (((x >> 3) & 0x1f1f1f1fu) + 0x01010101u) << PRAD_FUSED_SHIFT;
   }
 #else
+#ifdef PRAD_DBG_L2ONLY  // ablation build: every read lands in the first MB of the volume (wrong results, L2-resident traffic)
+  p = (const uint8_t *)((size_t)p & ~(size_t)0xFFFFFFF) + ((size_t)p & 0xFFFF8);
+#endif
   if (KW == 2) {
     const unsigned long long q = reinterpret_cast<const u64_unaligned *>(p)->v;
     v[0] = (u32)q;
@@ -174,6 +211,7 @@ struct FwWave {
   static constexpr int U = PRAD_FW_U;
   const FwTab &T;
   int dummy, lane, edge_lane;
+  u32 one;         // the ds_add operand, pinned in a VGPR
   bool haspad;
   u32 cmask[KW];   // byte lanes of this lane's window columns that lie inside the row
   u32 calm[KW];    // byte lanes of window columns no line can be open on (beyond the row, not next to its exit side)
@@ -185,6 +223,8 @@ struct FwWave {
     dummy = T.dummy0b + 4 * lane;
     haspad = NX != 64 * K;
     edge_lane = haspad ? -1 : (DX > 0 ? 63 : (DX < 0 ? 0 : -1));
+    one = 1;
+    asm volatile("" : "+v"(one));
     const int col0 = first_col(NX);
 #pragma unroll
     for (int w = 0; w < KW; w++) {
@@ -224,20 +264,24 @@ struct FwWave {
   __device__ __forceinline__ void rotate_reg(int &r, int xlevel) {
     if (!haspad) {
       if (PLAIN) {
+#ifndef PRAD_FW_NOASM
+        const unsigned long long em = DX > 0 ? 0x8000000000000000ull : 1ull;   // lane 63 / lane 0
+        asm volatile("s_mov_b64 exec, %[m]\n\tds_add_u32 %[r], %[one]\n\ts_mov_b64 exec, -1" ::[m] "s"(em), [r] "v"(r), [one] "v"(one) : "memory");
+#else
         lds_bump(lane == edge_lane ? r : dummy);
+#endif
       } else if (lane == edge_lane) {
-        fw_checked<LONG, false>(T, dummy, r, xlevel, 0);
+        fw_checked<LONG>(T, dummy, r, xlevel, 0, false);
       }
     }
     r = (int)(DX > 0 ? fw_shr1((u32)r) : fw_shl1((u32)r));
   }
   // one march step on the canonical register assignment (register j = column j), all cases handled
-  template <bool TAIL>
-  __device__ __forceinline__ void single_step(const u32 (&C)[KW]) {
+  __device__ __forceinline__ void single_step(const u32 (&C)[KW], bool tail) {
     u32 X[KW];
     fw_make_x<K, DX>(P, X);
 #pragma unroll
-    for (int j = 0; j < K; j++) fw_checked<LONG, TAIL>(T, dummy, pl[j], FW_BYTE(X, j), FW_BYTE(C, j));
+    for (int j = 0; j < K; j++) fw_checked<LONG>(T, dummy, pl[j], FW_BYTE(X, j), FW_BYTE(C, j), tail);
     if (DX > 0) {
       rotate_reg<false>(pl[K - 1], FW_BYTE(C, K - 1));
       const int in = pl[K - 1];
@@ -266,7 +310,7 @@ struct FwWave {
         (void)dummy_ce;
         const int r0 = (((4 * w + 0 - k * DX) % K) + K) % K, r1 = (((4 * w + 1 - k * DX) % K) + K) % K;
         const int r2 = (((4 * w + 2 - k * DX) % K) + K) % K, r3 = (((4 * w + 3 - k * DX) % K) + K) % K;
-        fw_plain_word(T, dummy, pl[r0], pl[r1], pl[r2], pl[r3], v[k][w], X[w]);
+        fw_plain_word(T, dummy, one, pl[r0], pl[r1], pl[r2], pl[r3], v[k][w], X[w]);
       }
       if (DX > 0) rotate_reg<true>(pl[(((K - 1 - k) % K) + K) % K], 0);
       if (DX < 0) rotate_reg<true>(pl[k % K], 0);
@@ -274,17 +318,21 @@ struct FwWave {
       for (int w = 0; w < KW; w++) P[w] = v[k][w];
     }
   }
-  // true if a plain group of U steps is not safe for some line of this lane
-  __device__ __forceinline__ bool risky() {
+  // How far the lines of this lane are from needing the checked path, as the largest "bytes into the row" of any open
+  // run: a plain walk of n steps is safe while margin + n*Q <= lenlim.  YOUNG: dead lines count with their age in the
+  // dead zone (which has the same RS+1 slots); otherwise a dead line reads as "unsafe".
+  template <bool YOUNG>
+  __device__ __forceinline__ unsigned margin() {
     u32 X[KW];
     fw_make_x<K, DX>(P, X);
-    bool r = false;
+    unsigned m = 0;
 #pragma unroll
     for (int j = 0; j < K; j++) {
-      if (LONG) r = r || (unsigned)(pl[j] - __mul24(FW_BYTE(X, j), T.P4) + U * T.Q) > (unsigned)T.lenmax;
-      else r = r || pl[j] < 0;
+      unsigned a = (unsigned)(pl[j] - __mul24(FW_BYTE(X, j), T.P4));   // len*Q
+      if (YOUNG) a = min(a, (unsigned)(pl[j] - T.deadbase));
+      m = max(m, a);
     }
-    return r;
+    return m;
   }
   // lines that never see a voxel (window columns beyond the row) must not look like runs about to outgrow the table;
   // the column next to the row's exit side is spared: the line on it is still open (it closes on the next step)
@@ -299,97 +347,120 @@ struct FwWave {
     fw_make_x<K, DX>(P, X);
     bool a = false;
 #pragma unroll
-    for (int j = 0; j < K; j++) a = a || (pl[j] >= 0 && FW_BYTE(X, j) != 0);
+    for (int j = 0; j < K; j++) a = a || (pl[j] < T.deadbase && FW_BYTE(X, j) != 0);
     return __ballot(a) != 0;
   }
-  // every line of the window ends here (end of the walk / row wrap): close the open runs
-  __device__ __forceinline__ void close_all() {
-    u32 X[KW];
-    fw_make_x<K, DX>(P, X);
-#pragma unroll
-    for (int j = 0; j < K; j++) fw_checked<LONG, false>(T, dummy, pl[j], FW_BYTE(X, j), 0);
-  }
-
   __device__ __forceinline__ void run(const FwDesc &D, int NX, const uint8_t *__restrict__ L, int *work) {
     const int NM = D.NM, NU = D.NU, du = D.du;
     const long long delta = D.sM + (long long)du * D.sU;
     const uint8_t *lp = L + first_col(NX);
-    for (;;) {
-      int grabbed = 0;
-      if (lane == 0) grabbed = atomicAdd(work, 1);
-      const int chunk = __builtin_amdgcn_readfirstlane(grabbed);
+    // chunk hand-out: the first chunk of a wave is its index, the rest come from a counter that has a cache line to
+    // itself (a dequeue word saturates near 90 grabs per microsecond: 12 angles sharing one line serialised the kernel)
+    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
+    int chunk = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));  // wave-uniform
+    for (bool first = true;; first = false) {
+      if (!first) {
+        int grabbed = 0;
+        if (lane == 0) grabbed = atomicAdd(work, 1);
+        chunk = nwaves + __builtin_amdgcn_readfirstlane(grabbed);
+      }
       if (chunk >= D.chunks) break;
       const int piece = chunk / NU, u0 = chunk - piece * NU;  // piece-major: concurrent waves share planes
       const int t0 = piece * D.CL, t1 = min(NM, t0 + D.CL);
       int row = (int)((u0 + (long long)t0 * du) % NU);
       if (row < 0) row += NU;
       long long off = (long long)t0 * D.sM + (long long)row * D.sU;
+#ifdef PRAD_DBG_NODEAD     // ablation build (wrong results): every piece begins like a line start
+      const bool starts = true;
+#else
       const bool starts = t0 == 0 || (du > 0 && row == 0) || (du < 0 && row == NU - 1);
+#endif
+      int young = 0;  // plain groups that may still carry dead lines (their ignored events go to the dead zone)
+      int safe = 0;   // plain groups the last margin check vouched for
+      bool maybe_dead = !starts;
       if (starts) {
 #pragma unroll
         for (int w = 0; w < KW; w++) P[w] = 0;
         reset_lines(0);
       } else {
         load_row(lp + (off - delta), P);
-        reset_lines(PRAD_FW_DEAD);
+        reset_lines(T.deadbase);
+        young = 2;
       }
       int t = t0;
       bool wrap = false;  // the next step would leave the row range: all lines end first
-      while (t < t1) {
-        if (wrap) {
-          close_all();
+      bool tail = false;  // past the end of the piece: only runs that began inside it are still recorded
+      // One loop, two kinds of iteration: a plain group of U steps, or ONE slow step (every special case funnels into
+      // the single inlined copy of single_step: instruction-cache footprint matters more than the rare paths' speed).
+      for (;;) {
+        bool closing = false, finish = false;   // closing: every line ends here = a step onto a row of zeros
+        if (!tail && t >= t1) {
+          if (t1 == NM || wrap) closing = finish = true;   // the lines end with the piece
+          else tail = true;
+#ifdef PRAD_DBG_NOTAIL   // ablation build (wrong results): pieces stop at their end
+          if (tail) break;
+#endif
+        }
+        if (tail && !closing) {
+          if (t == NM || wrap) closing = finish = true;
+          else if (!any_alive()) break;
+        }
+        if (!tail && !closing && wrap) closing = true;     // row wrap inside the piece: new lines begin behind it
+        if (!tail && !closing) {
+          const int room = du > 0 ? NU - row : (du < 0 ? row + 1 : (1 << 30));  // steps before the row range ends
+          const bool grp = t + U <= t1 && room >= U;
+          if (grp && safe == 0) {
+            calm_padding();
+            if (!LONG && !maybe_dead) {
+              safe = 2;   // every run length has its slot and no line is dead
+            } else {
+              const unsigned m = young > 0 ? margin<true>() : margin<false>();
+              if (__ballot(m + 2 * U * T.Q > (unsigned)T.lenlim) == 0) safe = 2;
+              else if (__ballot(m + U * T.Q > (unsigned)T.lenlim) == 0) safe = 1;
+              if (safe > 0 && young == 0) maybe_dead = false;   // a dead line reads as unsafe in margin<false>
+            }
+          }
+          if (grp && safe > 0) {
+            u32 v[U][KW];
+            const uint8_t *p = lp + off;
 #pragma unroll
-          for (int w = 0; w < KW; w++) P[w] = 0;
-          reset_lines(0);
+            for (int k = 0; k < U; k++) {
+              load_row(p, v[k]);
+              p += delta;
+            }
+            calm_padding();
+            plain_group(v);
+            safe--;
+            if (young > 0) young--;
+            t += U;
+            row += U * du;
+            off += (long long)U * delta;
+            if (du != 0 && (row < 0 || row >= NU)) wrap = true;
+            continue;
+          }
+        }
+        u32 c[KW];
+        if (closing) {
+#pragma unroll
+          for (int w = 0; w < KW; w++) c[w] = 0;
+        } else {
+          load_row(lp + off, c);
+        }
+        single_step(c, tail);
+        safe = 0;
+        young = 0;
+        if (closing) {
+          if (finish) break;
+          reset_lines(0);    // (P is the row of zeros already)
           row -= du * NU;
           off -= (long long)du * NU * D.sU;
           wrap = false;
+          continue;
         }
-        const int room = du > 0 ? NU - row : (du < 0 ? row + 1 : (1 << 30));  // steps before the row range ends
-        if (t + U <= t1 && room >= U) {
-          u32 v[U][KW];
-          const uint8_t *p = lp + off;
-#pragma unroll
-          for (int k = 0; k < U; k++) {
-            load_row(p, v[k]);
-            p += delta;
-          }
-          calm_padding();
-          if (__ballot(risky()) != 0) {
-#pragma unroll
-            for (int k = 0; k < U; k++) single_step<false>(v[k]);
-          } else {
-            plain_group(v);
-          }
-          t += U;
-          row += U * du;
-          off += (long long)U * delta;
-        } else {
-          u32 c[KW];
-          load_row(lp + off, c);
-          single_step<false>(c);
-          t++;
-          row += du;
-          off += delta;
-        }
-        if (du != 0 && (row < 0 || row >= NU)) wrap = true;
-      }
-      if (t1 == NM || wrap) {  // the lines end with the piece
-        close_all();
-        continue;
-      }
-      // tail: runs that began in this piece are walked to their end; nothing that begins later is recorded
-      while (any_alive()) {
-        u32 c[KW];
-        load_row(lp + off, c);
-        single_step<true>(c);
         t++;
         row += du;
         off += delta;
-        if (t == NM || (du != 0 && (row < 0 || row >= NU))) {
-          close_all();
-          break;
-        }
+        if (du != 0 && (row < 0 || row >= NU)) wrap = true;
       }
     }
   }
@@ -406,22 +477,22 @@ __global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, const uint8_t
     if (threadIdx.x == 0) atomicExch(flags + 2, 1);
     return;
   }
-  for (int i = threadIdx.x; i < h.words; i += blockDim.x) lds[i] = 0;
+  for (int i = threadIdx.x; i < h.words + Ng + 1; i += blockDim.x) lds[i] = 0;
   __syncthreads();
   const FwDesc &D = set.d[blockIdx.y];
   FwTab T;
   T.init(h, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
   if (D.dx == 0) {
     FwWave<LONG, K, 0> w(T, set.NX);
-    w.run(D, set.NX, L, work + blockIdx.y);
+    w.run(D, set.NX, L, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
   } else if (D.dx > 0) {
     FwWave<LONG, K, 1> w(T, set.NX);
-    w.run(D, set.NX, L, work + blockIdx.y);
+    w.run(D, set.NX, L, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
   } else {
     FwWave<LONG, K, -1> w(T, set.NX);
-    w.run(D, set.NX, L, work + blockIdx.y);
+    w.run(D, set.NX, L, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
   }
-  flush_block_hist<true, true, true>(lds, h, Nr, D.slot, glcm_acc, glrlm_acc);
+  flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, D.slot, glcm_acc, glrlm_acc);
 }
 
 }  // namespace prad

@@ -247,12 +247,16 @@ struct SweepPlan {
   bool fw = false;
   int fwK = 8;                 // window columns per lane (4: rows up to 256, 8: up to 512)
   int fw_blocks = 1;           // workgroups per angle
+  int RSfw = 0;                // run-length slots of its table (one workgroup per CU: most of the 160 KB)
+  bool LONGfw = false;
+  size_t lds_fw = 0;
   FwSet fwset;
 };
 
 constexpr size_t kHistBudget = 72 * 1024;      // LDS bytes a lines workgroup may spend on histograms
 constexpr size_t kHistBudgetRows = 36 * 1024;  // same for a rows workgroup (which also holds staging tiles)
 constexpr int kRowsThreads = 512;
+constexpr size_t kHistBudgetFw = 146 * 1024;   // fixed-window kernel: one 16-wave workgroup per CU (+ its dead zone)
 
 int cu_count() {
   static thread_local int cus = 0;
@@ -377,6 +381,24 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     D.chunks = (long long)D.NU * D.LXc;
   }
   if (p.fw && p.lines.count > 0) {
+    size_t budget = kHistBudgetFw;
+    if (const char *e = getenv("PRAD_FW_BUDGET_KB")) budget = (size_t)std::max(8, atoi(e)) * 1024;   // tuning override
+    p.RSfw = fit_rs(true, true, true, Ng, Nr, budget);
+    // LDS bank of a bin = (row stride * prev + len + cur) mod 32 with row stride = (RS+1)(Ng+1) words.  On smooth images
+    // cur ~ prev +- 1, so the banks of one ds_add spread like (stride+1) * prev: give up a few length slots for a stride
+    // whose (stride+1) is odd and 5..11 banks away from 0 (512^3 smooth levels: 0.74 ms at stride = 0 mod 32, 0.57 ms at 22)
+    if (p.RSfw < Nr) {
+      for (int rs = p.RSfw; rs >= std::max(16, p.RSfw - 12); rs--) {
+        const int d = (((rs + 1) * (Ng + 1)) % 32 + 1) % 32, dist = std::min(d, 32 - d);
+        if ((d & 1) && dist >= 5 && dist <= 11) {
+          p.RSfw = rs;
+          break;
+        }
+      }
+    }
+    if (const char *e = getenv("PRAD_FW_RS")) p.RSfw = std::max(1, std::min(p.RSfw, atoi(e)));   // tuning override
+    p.LONGfw = p.RSfw < Nr;
+    p.lds_fw = fw_lds_bytes(hist_layout(true, true, true, Ng, p.RSfw));
     // one workgroup (16 waves) per CU over all angles; a walk is cut into pieces so that every wave gets ~6 chunks
     p.fw_blocks = std::max(1, cu_count() / p.lines.count);
     if (const char *e = getenv("PRAD_FW_BLOCKS")) p.fw_blocks = std::max(1, atoi(e));
@@ -442,14 +464,14 @@ template <bool LNG, int K>
 int launch_fw_k(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
                 int *multi) {
   PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_kernel<LNG, K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-  hipLaunchKernelGGL((sweep_fw_kernel<LNG, K>), dim3(p.fw_blocks, p.fwset.count), dim3(1024), p.lds_bytes, k.s, p.fwset,
-                     levels, Ng, Nr, p.RS, glcm_acc, glrlm_acc, multi + PRAD_MAX_SWEEP, k.flags_d);
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw));
+  hipLaunchKernelGGL((sweep_fw_kernel<LNG, K>), dim3(p.fw_blocks, p.fwset.count), dim3(1024), p.lds_fw, k.s, p.fwset,
+                     levels, Ng, Nr, p.RSfw, glcm_acc, glrlm_acc, multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE, k.flags_d);
   return check_launch("sweep_fw_kernel");
 }
 int launch_fw(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
               int *multi) {
-  if (p.LONG) return p.fwK == 4 ? launch_fw_k<true, 4>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)
+  if (p.LONGfw) return p.fwK == 4 ? launch_fw_k<true, 4>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)
                                 : launch_fw_k<true, 8>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
   return p.fwK == 4 ? launch_fw_k<false, 4>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)
                     : launch_fw_k<false, 8>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
@@ -499,11 +521,12 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
   const size_t nglcm = glcm ? (size_t)k.Na * Ng * Ng : 0, nglrlm = glrlm ? (size_t)k.Na * Ng * Nr : 0;
   u32 *acc = nullptr;
   // accumulators, then per-angle "multi-element" flags, then per-angle work counters of the lines kernel
-  PRAD_TRY(c.get<u32>("sweep_acc", nglcm + nglrlm + 2 * PRAD_MAX_SWEEP, &acc));
+  const size_t nctl = 2 * PRAD_MAX_SWEEP + (size_t)PRAD_FW_WORK_STRIDE * (PRAD_MAX_SWEEP + 1);
+  PRAD_TRY(c.get<u32>("sweep_acc", nglcm + nglrlm + nctl, &acc));
   glcm_acc = acc;
   glrlm_acc = acc + nglcm;
   multi = (int *)(acc + nglcm + nglrlm);
-  PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u32) * (nglcm + nglrlm + 2 * PRAD_MAX_SWEEP), k.s));
+  PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u32) * (nglcm + nglrlm + nctl), k.s));
   {
     Timed t(c, "pack", k.s);
     const int vec_ok = p.vec_rows && ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)levels)) & 15) == 0;
