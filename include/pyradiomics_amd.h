@@ -65,6 +65,24 @@ const char *prad_last_path(void);
  * the time of its dominant kernel family; used by bench.py for the roofline figure. */
 double prad_last_device_ms(void);
 double prad_last_kernel_ms(const char *kernel_family);
+/* Accumulated timing over many calls (the per-call figures above need the call to have finished, i.e. one host
+ * synchronisation per call).  prad_timing_begin: start keeping the event brackets of every following call of this
+ * thread; prad_timing_ms: sum of the brackets of a kernel family (NULL: whole calls) since then, in ms -- synchronises
+ * on the last recorded event; prad_timing_calls: calls recorded; prad_timing_end: stop and drop the records. */
+int prad_timing_begin(void);
+double prad_timing_ms(const char *kernel_family);
+int prad_timing_calls(void);
+int prad_timing_end(void);
+/* Deferred mode for the device-pointer GLCM / GLRLM entry points (segment mode): with on != 0 a call only ENQUEUES its
+ * kernels on the caller's stream and returns without synchronising the host, so consecutive volumes pipeline on the
+ * GPU.  The one thing the host learns late is whether a volume held masked levels outside [1, Ng] (which the
+ * synchronous call answers by re-running on the exact generic kernels): every deferred call latches that into a sticky
+ * device flag; prad_deferred_status synchronises the stream, returns PRAD_OK, or PRAD_E_DEFERRED if any deferred call
+ * since the last query saw such levels (its outputs are then undefined: repeat that call synchronously), and clears
+ * the flag.  Calls the sweep kernels cannot serve (voxel mode, Nd > 3, ...) run synchronously as before. */
+#define PRAD_E_DEFERRED (-6)
+int prad_set_deferred(int on);
+int prad_deferred_status(void *stream);
 
 /* ---- angles: cmatrices.h get_angle_count / build_angles (cmatrices.c:756-892) ------------------- */
 /* returns the number of angles, 0 on invalid distance (as the reference) */

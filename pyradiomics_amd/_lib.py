@@ -30,6 +30,12 @@ SYMBOLS = {
     "prad_release_workspace": (C.c_int, []),
     "prad_last_device_ms": (C.c_double, []),
     "prad_last_kernel_ms": (C.c_double, [C.c_char_p]),
+    "prad_timing_begin": (C.c_int, []),
+    "prad_timing_ms": (C.c_double, [C.c_char_p]),
+    "prad_timing_calls": (C.c_int, []),
+    "prad_timing_end": (C.c_int, []),
+    "prad_set_deferred": (C.c_int, [C.c_int]),
+    "prad_deferred_status": (C.c_int, [C.c_void_p]),
     "prad_get_angle_count": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
     "prad_build_angles": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
     "prad_calculate_glcm": (C.c_int, _COMMON + [C.c_int] + _VOX + [_vp]),

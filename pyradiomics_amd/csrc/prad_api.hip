@@ -135,8 +135,19 @@ int setup_call(Call &k, const int32_t *image, const uint8_t *mask, const int *si
   k.mask = mask;
   k.angles_h = angles;
   k.Na = Na;
-  PRAD_TRY(c.get<int>("angles", (size_t)Na * Nd, &k.angles_d));
-  PRAD_HIP(hipMemcpyAsync(k.angles_d, angles, sizeof(int) * Na * Nd, hipMemcpyHostToDevice, s));
+  {
+    int *prev = nullptr;
+    auto it = c.bufs.find(std::string("angles@") + std::to_string(c.device));
+    if (it != c.bufs.end()) prev = (int *)it->second.p;
+    PRAD_TRY(c.get<int>("angles", (size_t)Na * Nd, &k.angles_d));
+    const bool same = prev == k.angles_d && c.angles_cached.size() == (size_t)Na * Nd &&
+                      std::equal(c.angles_cached.begin(), c.angles_cached.end(), angles);
+    if (!same) {   // (a copy from pageable memory blocks the host: skip it when the table on the device is current)
+      PRAD_HIP(hipMemcpyAsync(k.angles_d, angles, sizeof(int) * Na * Nd, hipMemcpyHostToDevice, s));
+      PRAD_HIP(hipStreamSynchronize(s));
+      c.angles_cached.assign(angles, angles + (size_t)Na * Nd);
+    }
+  }
   PRAD_TRY(c.get<int>("flags", 4, &k.flags_d));
   PRAD_HIP(hipMemsetAsync(k.flags_d, 0, sizeof(int) * 4, s));
   void *fh = nullptr;
@@ -509,6 +520,10 @@ int launch_sweeps(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, in
   return PRAD_OK;
 }
 
+__global__ void latch_flags_kernel(const int *__restrict__ flags, int *__restrict__ sticky) {
+  if (flags[0] || flags[2]) sticky[0] = 1;
+}
+
 // returns PRAD_OK with *used=false if the device found irregular levels (caller then runs generic)
 int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, double *glrlm, bool *used) {
   Context &c = *k.c;
@@ -562,6 +577,14 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
       PRAD_TRY(check_launch("finalize_glrlm_kernel"));
     }
   }
+  if (c.deferred) {   // enqueue only: the verdict on the levels is latched for prad_deferred_status()
+    int *sticky = nullptr;
+    PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
+    hipLaunchKernelGGL(latch_flags_kernel, dim3(1), dim3(1), 0, k.s, k.flags_d, sticky);
+    PRAD_TRY(check_launch("latch_flags_kernel"));
+    *used = true;
+    return PRAD_OK;
+  }
   PRAD_TRY(read_flags(k));
   // flags[2]: the fused walker found its table away from LDS address 0 and did nothing (cannot happen with the current
   // toolchain: the dynamic array is the kernels' only LDS object) -- let the generic kernels redo the call
@@ -593,6 +616,7 @@ int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *siz
     c.last_path = "generic";
   }
   PRAD_TRY(c.end_call(s));
+  if (c.deferred && done) return PRAD_OK;   // nothing was read back: see prad_deferred_status()
   PRAD_HIP(hipStreamSynchronize(s));
   return k.flags_h[1] ? PRAD_INDEX_ERROR : PRAD_OK;
 }
@@ -1115,6 +1139,69 @@ int prad_release_workspace(void) {
     if (kv.second.p) (void)hipHostFree(kv.second.p);
     kv.second.p = nullptr;
     kv.second.cap = 0;
+  }
+  return PRAD_OK;
+}
+
+int prad_timing_begin(void) {
+  Context &c = ctx();
+  c.timing_accumulate = true;
+  c.all_times.clear();
+  c.all_calls.clear();
+  c.events_used = 0;
+  return PRAD_OK;
+}
+int prad_timing_end(void) {
+  Context &c = ctx();
+  c.timing_accumulate = false;
+  c.all_times.clear();
+  c.all_calls.clear();
+  return PRAD_OK;
+}
+int prad_timing_calls(void) { return (int)ctx().all_calls.size(); }
+double prad_timing_ms(const char *family) {
+  Context &c = ctx();
+  double total = 0;
+  if (!family) {
+    for (auto &ab : c.all_calls) {
+      float ms = 0;
+      if (hipEventSynchronize(ab.second) != hipSuccess || hipEventElapsedTime(&ms, ab.first, ab.second) != hipSuccess) return -1.0;
+      total += ms;
+    }
+    return total;
+  }
+  for (auto &t : c.all_times) {
+    if (t.family != family) continue;
+    float ms = 0;
+    if (hipEventSynchronize(t.b) != hipSuccess || hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) return -1.0;
+    total += ms;
+  }
+  return total;
+}
+
+int prad_set_deferred(int on) {
+  Context &c = ctx();
+  if (c.ensure_device() != PRAD_OK) return PRAD_E_HIP;
+  if (on && c.bufs.find(std::string("deferred_sticky@") + std::to_string(c.device)) == c.bufs.end()) {
+    int *sticky = nullptr;   // first use on this device: a clean sticky flag (afterwards only the status query clears it)
+    PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
+    PRAD_HIP(hipMemset(sticky, 0, sizeof(int) * 16));
+  }
+  c.deferred = on != 0;
+  return PRAD_OK;
+}
+int prad_deferred_status(void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  PRAD_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (c.bufs.find(std::string("deferred_sticky@") + std::to_string(c.device)) == c.bufs.end()) return PRAD_OK;  // no deferred call yet
+  int *sticky = nullptr;
+  PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
+  int h = 0;
+  PRAD_HIP(hipMemcpy(&h, sticky, sizeof(int), hipMemcpyDeviceToHost));
+  if (h) {
+    PRAD_HIP(hipMemset(sticky, 0, sizeof(int)));
+    return fail(PRAD_E_DEFERRED, "a deferred GLCM/GLRLM call saw masked levels outside [1, Ng]; repeat it synchronously");
   }
   return PRAD_OK;
 }

@@ -70,6 +70,15 @@ struct Context {
   hipEvent_t call_a = nullptr, call_b = nullptr;
   bool call_timed = false;
   const char *last_path = "none";
+  // deferred mode (prad_set_deferred): GLCM/GLRLM device calls only enqueue work; the "levels outside [1, Ng]" flag of
+  // every such call is latched into a sticky device word that prad_deferred_status() reads after synchronising
+  bool deferred = false;
+  // accumulated timing (prad_timing_begin): events are not recycled between calls, every bracket is kept
+  bool timing_accumulate = false;
+  std::vector<KernelTime> all_times;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> all_calls;
+  // last angle table uploaded (skips the pageable host-to-device copy when a caller repeats the same angles)
+  std::vector<int> angles_cached;
   // GLSZM phase-1 -> phase-2 state
   long long glszm_nzones = 0;
   int glszm_nvox = 0;
@@ -144,7 +153,7 @@ struct Context {
   }
   int begin_call(hipStream_t s) {
     times.clear();
-    events_used = 0;
+    if (!timing_accumulate) events_used = 0;
     call_timed = false;
     int rc;
     if ((rc = new_event(&call_a)) != PRAD_OK) return rc;
@@ -155,6 +164,10 @@ struct Context {
   int end_call(hipStream_t s) {
     PRAD_HIP(hipEventRecord(call_b, s));
     call_timed = true;
+    if (timing_accumulate) {
+      all_calls.push_back(std::make_pair(call_a, call_b));
+      all_times.insert(all_times.end(), times.begin(), times.end());
+    }
     return PRAD_OK;
   }
   int tic(const char *family, hipStream_t s) {

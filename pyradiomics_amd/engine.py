@@ -40,11 +40,15 @@ def _prep(image: torch.Tensor, mask: torch.Tensor):
 
 def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None = None, force2D: bool = False,
                force2Ddimension: int = 0, want_glcm: bool = True, want_glrlm: bool = True,
-               out_glcm: torch.Tensor | None = None, out_glrlm: torch.Tensor | None = None, angles=None):
+               out_glcm: torch.Tensor | None = None, out_glrlm: torch.Tensor | None = None, angles=None,
+               deferred: bool = False):
     """GLCM [Ng,Ng,Na] and GLRLM [Ng,Nr,Na] (float64, on the device) of one discretised volume in segment
     mode, distance 1.  Returns (glcm, glrlm, angles).  `angles` (int32 [na, Nd]) restricts the sweep to a subset
     of the unidirectional distance-1 angles -- the angle shard of one rank when one segment is spread over
-    several GPUs (batch.segment_matrices_sharded); the outputs then carry those na angles only."""
+    several GPUs (batch.segment_matrices_sharded); the outputs then carry those na angles only.
+    deferred=True only enqueues the kernels on the current stream (no host synchronisation, consecutive volumes
+    pipeline on the GPU); whether a volume held masked levels outside [1, Ng] is then reported by
+    deferred_status(), see include/pyradiomics_amd.h."""
     lib, image, mask, size = _prep(image, mask)
     f2d = int(force2Ddimension) if force2D else -1
     if angles is None:
@@ -61,13 +65,42 @@ def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None 
         out_glcm = torch.empty((Ng, Ng, Na), dtype=torch.float64, device=dev)
     if want_glrlm and out_glrlm is None:
         out_glrlm = torch.empty((Ng, Nr, Na), dtype=torch.float64, device=dev)
-    rc = lib.prad_calculate_glcm_glrlm_dev(
-        C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd, _iptr(angles), Na, int(Ng),
-        int(Nr), 1, None, 0, f2d,
-        C.c_void_p(out_glcm.data_ptr()) if want_glcm else None,
-        C.c_void_p(out_glrlm.data_ptr()) if want_glrlm else None, _stream_ptr())
+    if deferred:
+        _lib.raise_for(lib.prad_set_deferred(1), "deferred mode")
+    try:
+        rc = lib.prad_calculate_glcm_glrlm_dev(
+            C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd, _iptr(angles), Na, int(Ng),
+            int(Nr), 1, None, 0, f2d,
+            C.c_void_p(out_glcm.data_ptr()) if want_glcm else None,
+            C.c_void_p(out_glrlm.data_ptr()) if want_glrlm else None, _stream_ptr())
+    finally:
+        if deferred:
+            lib.prad_set_deferred(0)
     _lib.raise_for(rc, "GLCM+GLRLM")
     return out_glcm, out_glrlm, angles
+
+
+def deferred_status() -> None:
+    """synchronises the current stream; raises if a deferred glcm_glrlm call since the last query saw levels outside
+    [1, Ng] (its outputs are undefined: repeat that call with deferred=False)"""
+    _lib.raise_for(_lib.load().prad_deferred_status(_stream_ptr()), "deferred GLCM+GLRLM")
+
+
+def timing_begin() -> None:
+    _lib.load().prad_timing_begin()
+
+
+def timing_ms(family: str | None = None) -> float:
+    """device ms (HIP events on the launch stream) summed over every engine call since timing_begin()"""
+    return float(_lib.load().prad_timing_ms(family.encode() if family else None))
+
+
+def timing_calls() -> int:
+    return int(_lib.load().prad_timing_calls())
+
+
+def timing_end() -> None:
+    _lib.load().prad_timing_end()
 
 
 def pair_angles(shape, distances=(1,), force2D: bool = False, force2Ddimension: int = 0):

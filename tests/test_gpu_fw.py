@@ -128,3 +128,25 @@ def test_fw_matches_wrapped_lines_kernel(cm, monkeypatch):
     monkeypatch.setenv("PRAD_NO_FW", "1")
     g0, r0, _ = cm.calculate_glcm_glrlm(img, mask, 32, 512, False, 0)
     assert np.array_equal(g0, g1) and np.array_equal(r0, r1)
+
+
+def test_deferred_calls_pipeline_and_report_late(cm):
+    """deferred mode: calls only enqueue; results equal the synchronous call; irregular levels surface in the status"""
+    import torch
+    from pyradiomics_amd import engine
+    shape, Ng = (40, 48, 512), 32
+    vols = [(_levels(s, shape, Ng, "uniform"), _mask(s, shape, "random")) for s in (1, 2, 3)]
+    dev = [(torch.from_numpy(i).cuda(), torch.from_numpy(m.astype(np.uint8)).cuda()) for i, m in vols]
+    want = [engine.glcm_glrlm(i, m, Ng, 512) for i, m in dev]
+    want = [(g.clone(), r.clone()) for g, r, _ in want]
+    got = [engine.glcm_glrlm(i, m, Ng, 512, deferred=True) for i, m in dev]     # three volumes in flight
+    engine.deferred_status()
+    for (g, r, _), (eg, er) in zip(got, want):
+        assert torch.equal(g, eg) and torch.equal(r, er)
+    bad = vols[0][0].copy()
+    bad[3, 4, 5] = Ng + 1
+    mk = np.ones(shape, np.uint8)
+    engine.glcm_glrlm(torch.from_numpy(bad).cuda(), torch.from_numpy(mk).cuda(), Ng, 512, deferred=True)
+    with pytest.raises(RuntimeError):
+        engine.deferred_status()
+    engine.deferred_status()       # the flag was cleared by the query
