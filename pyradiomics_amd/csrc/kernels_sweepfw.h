@@ -495,4 +495,114 @@ __global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, const uint8_t
   flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, D.slot, glcm_acc, glrlm_acc);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The angle along the contiguous axis with the same exec-masked step: a wave owns 64 consecutive rows (row = flattened
+// (z, y)), stages 64 x 64-voxel tiles through LDS (16 B per lane coalesced in, one row per lane out) and every lane walks
+// its own row, four voxels (one staged word) per asm block.  Table layout and run state as above.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fw_row_word(const FwTab &T, u32 one, int &s, u32 c, u32 x) {
+  int t;
+#define PRAD_FW_RCOL(J)                                                                                          \
+  "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:BYTE_" #J " src1_sel:BYTE_" #J "\n\t"                             \
+  "v_add_u32_sdwa %[t], %[s], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t"   \
+  "ds_add_u32 %[t], %[one]\n\t"                                                                                  \
+  "v_mul_u32_u24_sdwa %[s], %[P4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t" \
+  "s_mov_b64 exec, -1\n\t"                                                                                       \
+  "v_add_u32 %[s], %[Q], %[s]\n\t"
+  asm volatile(PRAD_FW_RCOL(0) PRAD_FW_RCOL(1) PRAD_FW_RCOL(2) PRAD_FW_RCOL(3)
+               : [s] "+v"(s), [t] "=&v"(t)
+               : [c] "v"(c), [x] "v"(x), [one] "v"(one), [P4] "s"(T.P4), [Q] "s"(T.Q)
+               : "vcc", "memory");
+#undef PRAD_FW_RCOL
+}
+
+template <bool LONG>
+__global__ void __launch_bounds__(512) sweep_fw_rows_kernel(const uint8_t *__restrict__ L, long long nrows, int NX, int pitch,
+                                                            int slot, int Ng, int Nr, int RS, u32 *__restrict__ glcm_acc,
+                                                            u32 *__restrict__ glrlm_acc, int *__restrict__ flags) {
+  extern __shared__ u32 lds[];
+  if (flags[0]) return;
+  const HistLayout h = hist_layout(true, true, true, Ng, RS);
+  if ((unsigned)(size_t)((lds_u32 *)lds) != 0u) {
+    if (threadIdx.x == 0) atomicExch(flags + 2, 1);
+    return;
+  }
+  for (int i = threadIdx.x; i < h.words + Ng + 1; i += blockDim.x) lds[i] = 0;
+  __syncthreads();
+  FwTab T;
+  T.init(h, Nr, glrlm_acc + (size_t)slot * Ng * Nr);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int dummy = T.dummy0b + 4 * lane;
+  u32 one = 1;
+  asm volatile("" : "+v"(one));
+  // per-wave staging tile behind the table and its dead zone (16-byte aligned)
+  uint8_t *tile = reinterpret_cast<uint8_t *>(lds) + ((fw_lds_bytes(h) + 15) & ~(size_t)15) + (size_t)wave * 64 * PRAD_ROW_PITCH;
+  const long long ngroups = (nrows + 63) / 64;
+  const long long nwaves = (long long)gridDim.x * wpb;
+  const bool vec16 = (pitch & 15) == 0 && ((uintptr_t)L & 15) == 0;
+  for (long long grp = (long long)blockIdx.x * wpb + wave; grp < ngroups; grp += nwaves) {
+    const long long r0 = grp * 64;
+    int s = 0;     // run state of this lane's row
+    u32 pw = 0;    // previous staged word (its last byte is the previous voxel)
+    for (int xc = 0; xc < NX; xc += 64) {
+      if (vec16) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int rr = j * 16 + (lane >> 2);
+          const int cx = xc + (lane & 3) * 16;
+          uint4 q = make_uint4(0, 0, 0, 0);
+          if (r0 + rr < nrows && cx < NX) {
+            q = *reinterpret_cast<const uint4 *>(L + (r0 + rr) * pitch + cx);
+            const int valid = NX - cx;
+            if (valid < 16) {
+              u32 *qw = reinterpret_cast<u32 *>(&q);
+#pragma unroll
+              for (int wd = 0; wd < 4; wd++) {
+                const int keep = valid - 4 * wd;
+                qw[wd] = keep >= 4 ? qw[wd] : (keep <= 0 ? 0u : (qw[wd] & ((1u << (8 * keep)) - 1u)));
+              }
+            }
+          }
+          *reinterpret_cast<uint4 *>(tile + rr * PRAD_ROW_PITCH + (lane & 3) * 16) = q;
+        }
+      } else {
+        const bool xin = xc + lane < NX;
+#pragma unroll 8
+        for (int rr = 0; rr < 64; rr++) {
+          uint8_t b = 0;
+          if (xin && r0 + rr < nrows) b = L[(r0 + rr) * pitch + xc + lane];
+          tile[rr * PRAD_ROW_PITCH + lane] = b;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const uint4 *row = reinterpret_cast<const uint4 *>(tile + lane * PRAD_ROW_PITCH);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint4 d = row[q];
+        const u32 wds[4] = {d.x, d.y, d.z, d.w};
+        // 16 steps: safe on the plain path while len*Q + 16 Q stays within the table's length slots
+        const unsigned m = (unsigned)(s - __mul24((int)(pw >> 24), T.P4));
+        if (LONG && __ballot(m + 16 * T.Q > (unsigned)T.lenlim) != 0) {
+#pragma unroll 1
+          for (int k = 0; k < 4; k++) {
+            const u32 c = wds[k], x = __builtin_amdgcn_alignbyte(c, pw, 3);
+#pragma unroll
+            for (int b = 0; b < 4; b++) fw_checked<LONG>(T, dummy, s, (int)((x >> (8 * b)) & 0xffu), (int)((c >> (8 * b)) & 0xffu), false);
+            pw = c;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            fw_row_word(T, one, s, wds[k], __builtin_amdgcn_alignbyte(wds[k], pw, 3));
+            pw = wds[k];
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    fw_checked<LONG>(T, dummy, s, (int)(pw >> 24), 0, false);   // the row ends: close its open run
+  }
+  flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, slot, glcm_acc, glrlm_acc);
+}
+
 }  // namespace prad

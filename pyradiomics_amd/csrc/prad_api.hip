@@ -261,6 +261,9 @@ struct SweepPlan {
   int RSfw = 0;                // run-length slots of its table (one workgroup per CU: most of the 160 KB)
   bool LONGfw = false;
   size_t lds_fw = 0;
+  int RSfw_rows = 0;           // same for the fixed-window rows kernel (8 waves + their staging tiles)
+  bool LONGfw_rows = false;
+  size_t lds_fw_rows = 0;
   FwSet fwset;
 };
 
@@ -410,6 +413,17 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     if (const char *e = getenv("PRAD_FW_RS")) p.RSfw = std::max(1, std::min(p.RSfw, atoi(e)));   // tuning override
     p.LONGfw = p.RSfw < Nr;
     p.lds_fw = fw_lds_bytes(hist_layout(true, true, true, Ng, p.RSfw));
+    {
+      const size_t tiles = (size_t)(kRowsThreads / 64) * 64 * PRAD_ROW_PITCH;
+      int rs = fit_rs(true, true, true, Ng, Nr, 100 * 1024);
+      for (int r = rs; rs < Nr && r >= std::max(16, rs - 12); r--) {   // same bank-stride rule as above
+        const int d = (((r + 1) * (Ng + 1)) % 32 + 1) % 32, dist = std::min(d, 32 - d);
+        if ((d & 1) && dist >= 5 && dist <= 11) { rs = r; break; }
+      }
+      p.RSfw_rows = rs;
+      p.LONGfw_rows = rs < Nr;
+      p.lds_fw_rows = ((fw_lds_bytes(hist_layout(true, true, true, Ng, rs)) + 15) & ~(size_t)15) + tiles;
+    }
     // one workgroup (16 waves) per CU over all angles; a walk is cut into pieces so that every wave gets ~6 chunks
     p.fw_blocks = std::max(1, cu_count() / p.lines.count);
     if (const char *e = getenv("PRAD_FW_BLOCKS")) p.fw_blocks = std::max(1, atoi(e));
@@ -503,6 +517,18 @@ int launch_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int 
   return check_launch("sweep_rows_kernel");
 }
 
+template <bool LNG>
+int launch_fw_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc) {
+  const long long nrows = (long long)p.Nz * p.Ny, groups = (nrows + 63) / 64;
+  const int wpb = kRowsThreads / 64;
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + wpb - 1) / wpb, (long long)cu_count()));
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_rows_kernel<LNG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw_rows));
+  hipLaunchKernelGGL((sweep_fw_rows_kernel<LNG>), dim3(gx), dim3(kRowsThreads), p.lds_fw_rows, k.s, levels, nrows, p.Nx,
+                     p.pitch, p.row_slot, Ng, Nr, p.RSfw_rows, glcm_acc, glrlm_acc, k.flags_d);
+  return check_launch("sweep_fw_rows_kernel");
+}
+
 template <bool G, bool R, bool F>
 int launch_sweeps(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
                   int *multi) {
@@ -513,7 +539,10 @@ int launch_sweeps(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, in
     if (R && p.LONG) PRAD_TRY((launch_lines<G, R, true, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
     else PRAD_TRY((launch_lines<G, R, false, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   }
-  if (p.row_slot >= 0) {
+  if (p.row_slot >= 0 && p.fw && G && R && F && !getenv("PRAD_NO_FW_ROWS")) {
+    if (p.LONGfw_rows) PRAD_TRY(launch_fw_rows<true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc));
+    else PRAD_TRY(launch_fw_rows<false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc));
+  } else if (p.row_slot >= 0) {
     if (R && p.LONGr) PRAD_TRY((launch_rows<G, R, true, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
     else PRAD_TRY((launch_rows<G, R, false, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   }
