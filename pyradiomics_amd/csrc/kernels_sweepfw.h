@@ -205,14 +205,14 @@ __device__ __forceinline__ void fw_load(const uint8_t *p, u32 (&v)[KW]) {
 
 #define FW_BYTE(W, j) ((int)__builtin_amdgcn_ubfe((W)[(j) >> 2], 8 * ((j) & 3), 8))
 
-template <bool LONG, int K, int DX>
+template <bool LONG, int K, int DX, bool HASPAD>
 struct FwWave {
   static constexpr int KW = K / 4;
   static constexpr int U = PRAD_FW_U;
   const FwTab &T;
   int dummy, lane, edge_lane;
   u32 one;         // the ds_add operand, pinned in a VGPR
-  bool haspad;
+  static constexpr bool haspad = HASPAD;   // the row is shorter than the window (NX != 64*K)
   u32 cmask[KW];   // byte lanes of this lane's window columns that lie inside the row
   u32 calm[KW];    // byte lanes of window columns no line can be open on (beyond the row, not next to its exit side)
   int pl[K];       // run state of the line that arrives at column j at the next step
@@ -221,7 +221,6 @@ struct FwWave {
   __device__ __forceinline__ FwWave(const FwTab &T_, int NX) : T(T_) {
     lane = threadIdx.x & 63;
     dummy = T.dummy0b + 4 * lane;
-    haspad = NX != 64 * K;
     edge_lane = haspad ? -1 : (DX > 0 ? 63 : (DX < 0 ? 0 : -1));
     one = 1;
     asm volatile("" : "+v"(one));
@@ -428,7 +427,7 @@ struct FwWave {
               load_row(p, v[k]);
               p += delta;
             }
-            calm_padding();
+            if (safe == 1) calm_padding();   // (second group of a pair: the first one let the padding lines grow)
             plain_group(v);
             safe--;
             if (young > 0) young--;
@@ -466,7 +465,7 @@ struct FwWave {
   }
 };
 
-template <bool LONG, int K>
+template <bool LONG, int K, bool HASPAD>
 __global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, const uint8_t *__restrict__ L, int Ng, int Nr, int RS,
                                                         u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
                                                         int *__restrict__ work, int *__restrict__ flags) {
@@ -483,13 +482,13 @@ __global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, const uint8_t
   FwTab T;
   T.init(h, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
   if (D.dx == 0) {
-    FwWave<LONG, K, 0> w(T, set.NX);
+    FwWave<LONG, K, 0, HASPAD> w(T, set.NX);
     w.run(D, set.NX, L, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
   } else if (D.dx > 0) {
-    FwWave<LONG, K, 1> w(T, set.NX);
+    FwWave<LONG, K, 1, HASPAD> w(T, set.NX);
     w.run(D, set.NX, L, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
   } else {
-    FwWave<LONG, K, -1> w(T, set.NX);
+    FwWave<LONG, K, -1, HASPAD> w(T, set.NX);
     w.run(D, set.NX, L, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
   }
   flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, D.slot, glcm_acc, glrlm_acc);
@@ -603,6 +602,107 @@ __global__ void __launch_bounds__(512) sweep_fw_rows_kernel(const uint8_t *__res
     fw_checked<LONG>(T, dummy, s, (int)(pw >> 24), 0, false);   // the row ends: close its open run
   }
   flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, slot, glcm_acc, glrlm_acc);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pack + the x angle in one pass over the boundary arrays.  The pack is HBM-bound (5 B in, 1 B out per voxel) and
+// leaves VALU and LDS idle; the walk along x is LDS/VALU work on exactly the bytes the pack has just produced.  A wave
+// owns 64 consecutive rows, moves 64 x 64-voxel tiles: int32 levels (16 B per lane) + mask bytes (4 B per lane) ->
+// level*4 bytes -> global packed volume AND a per-wave LDS tile, then every lane walks its own row from the tile.
+// Needs Nx % 4 == 0 (vector loads of whole 4-voxel pieces); other shapes take pack_levels + the rows kernel.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool LONG, bool WALK>
+__global__ void __launch_bounds__(1024) pack_rows_fw_kernel(const int *__restrict__ image, const uint8_t *__restrict__ mask,
+                                                            long long nrows, int NX, int pitch, uint8_t *__restrict__ L,
+                                                            int slot, int Ng, int Nr, int RS, u32 *__restrict__ glcm_acc,
+                                                            u32 *__restrict__ glrlm_acc, int *__restrict__ flags) {
+  extern __shared__ u32 lds[];
+  const HistLayout h = hist_layout(true, true, true, Ng, RS);
+  if (WALK && (unsigned)(size_t)((lds_u32 *)lds) != 0u) {
+    if (threadIdx.x == 0) atomicExch(flags + 2, 1);
+    return;
+  }
+  if (WALK) {
+    for (int i = threadIdx.x; i < h.words + Ng + 1; i += blockDim.x) lds[i] = 0;
+    __syncthreads();
+  }
+  FwTab T;
+  T.init(h, Nr, glrlm_acc + (size_t)slot * Ng * Nr);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int dummy = T.dummy0b + 4 * lane;
+  u32 one = 1;
+  asm volatile("" : "+v"(one));
+  uint8_t *tile = reinterpret_cast<uint8_t *>(lds) + (WALK ? ((fw_lds_bytes(h) + 15) & ~(size_t)15) : 0) + (size_t)wave * 64 * PRAD_ROW_PITCH;
+  const long long ngroups = (nrows + 63) / 64;
+  const long long nwaves = (long long)gridDim.x * wpb;
+  const int sub = lane >> 4, piece = lane & 15;   // an instruction covers 4 rows x 16 four-voxel pieces
+  int bad = 0;
+  for (long long grp = (long long)blockIdx.x * wpb + wave; grp < ngroups; grp += nwaves) {
+    const long long r0 = grp * 64;
+    int s = 0;
+    u32 pw = 0;
+    for (int xc = 0; xc < NX; xc += 64) {
+      const int cx = xc + 4 * piece;
+      const bool xin = cx < NX;
+#pragma unroll 1
+      for (int half = 0; half < 2; half++) {   // 2 x 8 instructions: 40 VGPRs of loads in flight instead of 80
+        int4 q[8];
+        u32 mk[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const long long row = r0 + 4 * (8 * half + i) + sub;
+          q[i] = make_int4(0, 0, 0, 0);
+          mk[i] = 0;
+          if (xin && row < nrows) {
+            const long long e = row * NX + cx;
+            q[i] = *reinterpret_cast<const int4 *>(image + e);
+            mk[i] = *reinterpret_cast<const u32 *>(mask + e);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int lv[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
+          u32 o = 0;
+#pragma unroll
+          for (int b = 0; b < 4; b++) {
+            const bool in = (mk[i] >> (8 * b)) & 0xffu;
+            bad |= in && (lv[b] < 1 || lv[b] > Ng);
+            o |= (in ? (((u32)lv[b] << PRAD_FUSED_SHIFT) & 0xffu) : 0u) << (8 * b);
+          }
+          const int tr = 4 * (8 * half + i) + sub;
+          const long long row = r0 + tr;
+          if (xin && row < nrows) *reinterpret_cast<u32 *>(L + row * pitch + cx) = o;
+          if (WALK) *reinterpret_cast<u32 *>(tile + tr * PRAD_ROW_PITCH + 4 * piece) = o;
+        }
+      }
+      if (WALK) {
+        __builtin_amdgcn_wave_barrier();
+        const uint4 *rowp = reinterpret_cast<const uint4 *>(tile + lane * PRAD_ROW_PITCH);
+#pragma unroll 1
+        for (int qq = 0; qq < 4; qq++) {
+          const uint4 d = rowp[qq];
+          const u32 wds[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const u32 c = wds[k], x = __builtin_amdgcn_alignbyte(c, pw, 3);
+            const unsigned m = (unsigned)(s - __mul24((int)(pw >> 24), T.P4));
+            if (LONG && __ballot(m + 4 * T.Q > (unsigned)T.lenlim) != 0) {
+#pragma unroll
+              for (int b = 0; b < 4; b++) fw_checked<LONG>(T, dummy, s, (int)((x >> (8 * b)) & 0xffu), (int)((c >> (8 * b)) & 0xffu), false);
+            } else {
+              fw_row_word(T, one, s, c, x);
+            }
+            pw = c;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (WALK) fw_checked<LONG>(T, dummy, s, (int)(pw >> 24), 0, false);
+  }
+  if (bad) flags[0] = 1;
+  // (a volume with irregular levels is redone on the generic kernels: what was accumulated here is never read)
+  if (WALK) flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, slot, glcm_acc, glrlm_acc);
 }
 
 }  // namespace prad

@@ -261,6 +261,10 @@ struct SweepPlan {
   int RSfw = 0;                // run-length slots of its table (one workgroup per CU: most of the 160 KB)
   bool LONGfw = false;
   size_t lds_fw = 0;
+  bool fw_packrows = false;    // pack + x angle fused (kernels_sweepfw.h pack_rows_fw_kernel): Nx % 4 == 0
+  int RSfw_pr = 0;
+  bool LONGfw_pr = false;
+  size_t lds_fw_pr = 0;
   int RSfw_rows = 0;           // same for the fixed-window rows kernel (8 waves + their staging tiles)
   bool LONGfw_rows = false;
   size_t lds_fw_rows = 0;
@@ -424,6 +428,18 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
       p.LONGfw_rows = rs < Nr;
       p.lds_fw_rows = ((fw_lds_bytes(hist_layout(true, true, true, Ng, rs)) + 15) & ~(size_t)15) + tiles;
     }
+    // (worth it once every wave slot of the GPU has a 64-row group of its own: 512^3 0.20 -> 0.19 ms, 256^3 loses)
+    if (p.row_slot >= 0 && p.Nx % 4 == 0 && p.pitch % 4 == 0 && (long long)p.Nz * p.Ny >= 64LL * 16 * cu_count() * 3 / 4 &&
+        !getenv("PRAD_NO_PACKROWS")) {
+      const size_t tiles = (size_t)16 * 64 * PRAD_ROW_PITCH;
+      const int rs = fit_rs(true, true, true, Ng, Nr, 66 * 1024);
+      if (rs >= std::min(Nr, 8)) {
+        p.fw_packrows = true;
+        p.RSfw_pr = rs;
+        p.LONGfw_pr = rs < Nr;
+        p.lds_fw_pr = ((fw_lds_bytes(hist_layout(true, true, true, Ng, rs)) + 15) & ~(size_t)15) + tiles;
+      }
+    }
     // one workgroup (16 waves) per CU over all angles; a walk is cut into pieces so that every wave gets ~6 chunks
     p.fw_blocks = std::max(1, cu_count() / p.lines.count);
     if (const char *e = getenv("PRAD_FW_BLOCKS")) p.fw_blocks = std::max(1, atoi(e));
@@ -485,14 +501,20 @@ int launch_lines(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int
   return launch_lines_lpl<G, R, LNG, F, 1>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
 }
 
+template <bool LNG, int K, bool HASPAD>
+int launch_fw_kp(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
+                 int *multi) {
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_kernel<LNG, K, HASPAD>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw));
+  hipLaunchKernelGGL((sweep_fw_kernel<LNG, K, HASPAD>), dim3(p.fw_blocks, p.fwset.count), dim3(1024), p.lds_fw, k.s, p.fwset,
+                     levels, Ng, Nr, p.RSfw, glcm_acc, glrlm_acc, multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE, k.flags_d);
+  return check_launch("sweep_fw_kernel");
+}
 template <bool LNG, int K>
 int launch_fw_k(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
                 int *multi) {
-  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_kernel<LNG, K>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw));
-  hipLaunchKernelGGL((sweep_fw_kernel<LNG, K>), dim3(p.fw_blocks, p.fwset.count), dim3(1024), p.lds_fw, k.s, p.fwset,
-                     levels, Ng, Nr, p.RSfw, glcm_acc, glrlm_acc, multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE, k.flags_d);
-  return check_launch("sweep_fw_kernel");
+  if (p.Nx != 64 * K) return launch_fw_kp<LNG, K, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
+  return launch_fw_kp<LNG, K, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
 }
 int launch_fw(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
               int *multi) {
@@ -518,6 +540,17 @@ int launch_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int 
 }
 
 template <bool LNG>
+int launch_pack_rows(Call &k, const SweepPlan &p, uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc) {
+  const long long nrows = (long long)p.Nz * p.Ny, groups = (nrows + 63) / 64;
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + 15) / 16, (long long)cu_count()));
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pack_rows_fw_kernel<LNG, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw_pr));
+  hipLaunchKernelGGL((pack_rows_fw_kernel<LNG, true>), dim3(gx), dim3(1024), p.lds_fw_pr, k.s, k.image, k.mask, nrows, p.Nx,
+                     p.pitch, levels, p.row_slot, Ng, Nr, p.RSfw_pr, glcm_acc, glrlm_acc, k.flags_d);
+  return check_launch("pack_rows_fw_kernel");
+}
+
+template <bool LNG>
 int launch_fw_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc) {
   const long long nrows = (long long)p.Nz * p.Ny, groups = (nrows + 63) / 64;
   const int wpb = kRowsThreads / 64;
@@ -531,7 +564,7 @@ int launch_fw_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, i
 
 template <bool G, bool R, bool F>
 int launch_sweeps(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
-                  int *multi) {
+                  int *multi, bool rows_done = false) {
   Timed t(*k.c, "sweep", k.s);
   if (p.lines.count > 0 && p.fw && G && R && F) {
     PRAD_TRY(launch_fw(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi));
@@ -539,6 +572,7 @@ int launch_sweeps(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, in
     if (R && p.LONG) PRAD_TRY((launch_lines<G, R, true, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
     else PRAD_TRY((launch_lines<G, R, false, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   }
+  if (rows_done) return PRAD_OK;   // the x angle was walked by pack_rows_fw_kernel
   if (p.row_slot >= 0 && p.fw && G && R && F && !getenv("PRAD_NO_FW_ROWS")) {
     if (p.LONGfw_rows) PRAD_TRY(launch_fw_rows<true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc));
     else PRAD_TRY(launch_fw_rows<false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc));
@@ -571,7 +605,13 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
   glrlm_acc = acc + nglcm;
   multi = (int *)(acc + nglcm + nglrlm);
   PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u32) * (nglcm + nglrlm + nctl), k.s));
-  {
+  const bool packrows = p.fw && p.fw_packrows && glcm && glrlm && p.fused &&
+                        ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)levels)) & 15) == 0;
+  if (packrows) {
+    Timed t(c, "pack", k.s);   // (the x angle's walk is hidden inside: the family name says what bounds the kernel)
+    if (p.LONGfw_pr) PRAD_TRY(launch_pack_rows<true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc));
+    else PRAD_TRY(launch_pack_rows<false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc));
+  } else {
     Timed t(c, "pack", k.s);
     const int vec_ok = p.vec_rows && ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)levels)) & 15) == 0;
     const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n / 16 + 255) / 256, 4096));
@@ -581,7 +621,7 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
                        Ng, levels, k.flags_d, vec_ok, shift);
     PRAD_TRY(check_launch("pack_levels_kernel"));
   }
-  if (glcm && glrlm && p.fused) PRAD_TRY((launch_sweeps<true, true, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+  if (glcm && glrlm && p.fused) PRAD_TRY((launch_sweeps<true, true, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi, packrows)));
   else if (glcm && glrlm) PRAD_TRY((launch_sweeps<true, true, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   else if (glcm) PRAD_TRY((launch_sweeps<true, false, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   else PRAD_TRY((launch_sweeps<false, true, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
