@@ -153,6 +153,69 @@ def cpu_baseline_all_cores(levels: int, size: int, nz: int = 24):
             "sample": "%d processes x %dx%dx%d slab each, %.1f s wall" % (nproc, nz, size, size, dt)}
 
 
+def mode_batch(device, rank: int, cases: int, fence):
+    """north_star 'batched mode' (BASELINE config 5 in miniature): whole cases -- a 256^3 volume, ball ROI, Original +
+    8 wavelet sub-bands, all six feature classes -- through RadiomicsFeatureExtractor.execute, `cases` per rank,
+    no collective.  Returns (cases, seconds, features per case)."""
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    from pyradiomics_amd.image import Image
+    N = 256
+    params = {"setting": {"binCount": 32, "additionalInfo": False}, "imageType": {"Original": {}, "Wavelet": {}}}
+    zz, yy, xx = np.ogrid[:N, :N, :N]
+    roi = np.zeros((N, N, N), dtype=np.int16)
+    roi[((zz - N / 2) ** 2 + (yy - N / 2) ** 2 + (xx - N / 2) ** 2) < (0.45 * N) ** 2] = 1
+    ex = RadiomicsFeatureExtractor(params)
+    vols = [(make_volume(N, 32, "smooth", 1000 * rank + c, device)[0] * 25).cpu().numpy().astype(np.int16)
+            for c in range(cases + 1)]
+    out = ex.execute(Image(vols[0]), Image(roi))          # warm-up: code objects, workspace
+    fence()
+    t0 = time.perf_counter()
+    for c in range(1, cases + 1):
+        out = ex.execute(Image(vols[c]), Image(roi))
+    fence()
+    return cases, time.perf_counter() - t0, len(out)
+
+
+def mode_voxel(device, rank: int, world: int, size: int, fence):
+    """north_star 'voxel-based mode' (BASELINE config 4): GLCM JointEntropy map of a size^3 volume with the
+    exampleVoxel.yaml window (force2D, kernelRadius 2), every voxel a kernel centre; the centre list is cut into
+    z-slabs, one per rank (batch.voxel_maps_sharded's split), the volume is resident on every rank, no collective.
+    Returns (kernels of this rank, seconds)."""
+    from pyradiomics_amd import engine
+    img, msk = make_volume(size, 32, "smooth", 0, device)
+    z0, z1 = (size * rank) // world, (size * (rank + 1)) // world
+    zz, yy, xx = torch.meshgrid(torch.arange(z0, z1, device=device, dtype=torch.int32),
+                                torch.arange(size, device=device, dtype=torch.int32),
+                                torch.arange(size, device=device, dtype=torch.int32), indexing="ij")
+    vox = torch.stack([zz.reshape(-1), yy.reshape(-1), xx.reshape(-1)])
+    del zz, yy, xx
+    kw = dict(kernelRadius=2, force2D=True, force2Ddimension=0)
+    engine.voxel_glcm_features(img, msk, 32, vox[:, :4096].contiguous(), ["JointEntropy"], **kw)
+    fence()
+    t0 = time.perf_counter()
+    res = engine.voxel_glcm_features(img, msk, 32, vox, ["JointEntropy"], **kw)
+    fence()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(res["JointEntropy"]).all())
+    return int(vox.shape[1]), dt
+
+
+def host_boundary(image, mask, Ng: int, Nr: int):
+    """the drop-in call itself: pageable host numpy arrays in, float64 matrices out (PCIe inclusive; never `value`)"""
+    from pyradiomics_amd import cmatrices
+    img_h, msk_h = image.cpu().numpy(), mask.cpu().numpy()
+    cmatrices.calculate_glcm_glrlm(img_h[:8], msk_h[:8], Ng, Nr, False, 0)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        cmatrices.calculate_glcm_glrlm(img_h, msk_h, Ng, Nr, False, 0)
+        best = min(best, time.perf_counter() - t0)
+    return {"ms_per_call": round(best * 1e3, 3), "Mvoxels_s": round(img_h.size / best / 1e6, 1),
+            "input_GBps": round(5.0 * img_h.size / best / 1e9, 2),
+            "note": "cmatrices.calculate_glcm_glrlm on pageable numpy int32 + uint8 arrays, best of 3; inputs go "
+                    "through the pinned staging ring (4 host threads), PCIe Gen5 x16"}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,6 +225,8 @@ def main() -> None:
     ap.add_argument("--levels", type=int, default=32)
     ap.add_argument("--dist", choices=["uniform", "smooth"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true", help="skip the batch / voxel-based side figures")
+    ap.add_argument("--no-host-boundary", action="store_true", help="skip the host-pointer (drop-in) call timing")
     ap.add_argument("--cpu-voxels", type=int, default=320 * 512 * 512,
                     help="voxels in the CPU baseline sample (default: a 320-slice slab, ~10 s on one core)")
     args = ap.parse_args()
@@ -226,10 +291,35 @@ def main() -> None:
     for _ in range(sync_steps):
         step()
     sync_ms = (time.perf_counter() - t1) / sync_steps * 1e3
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    def max_over_ranks(x: float) -> float:
+        if not dist_on:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    elapsed = max_over_ranks(elapsed)
+    modes = None
+    if not args.no_modes:
+        # the two sharded modes north_star names, each rank on its own share, barrier + max-over-ranks like the headline
+        torch.cuda.empty_cache()
+        nc, dt_b, nfeat = mode_batch(device, rank, 3, fence)
+        dt_b = max_over_ranks(dt_b)
+        nk, dt_v = mode_voxel(device, rank, world, args.size, fence)
+        dt_v = max_over_ranks(dt_v)
+        nk_all = nk
+        if dist_on:
+            t = torch.tensor([nk], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            nk_all = int(t.item())
+        modes = {"batch": {"value": round(world * nc / dt_b, 2), "unit": "cases/s", "cases_per_rank": nc,
+                           "features_per_case": nfeat,
+                           "case": "256^3 int16 volume from host memory, ball ROI (38 % of the box), Original + 8 wavelet "
+                                   "sub-bands, six feature classes; one case at a time per GPU"},
+                 "voxel": {"value": round(nk_all / dt_v / 1e6, 2), "unit": "Mkernels/s", "kernels": nk_all,
+                           "case": "%d^3 volume, GLCM JointEntropy map, exampleVoxel.yaml window (force2D, kernelRadius 2), "
+                                   "every voxel a centre, centres split into z-slabs over the ranks" % args.size}}
+        torch.cuda.empty_cache()
 
     # size-independent property checks on the full-size result (every ordered neighbour pair / every voxel counted)
     gl = glcm.sum(dim=(0, 1)).cpu().numpy()
@@ -258,6 +348,7 @@ def main() -> None:
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "sync_call_ms_per_step": round(sync_ms, 4),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8 levels / u32 counts / f64 out", "data": "synthetic",
+            "modes": modes,
             "config": {"workload": "GLCM+GLRLM matrix build, %d^3 int32+uint8 volume resident in HBM, %d grey levels, "
                                    "full mask, 13 angles, %s levels; one volume per GPU (batch sharding, no collective)"
                                    % (args.size, args.levels, args.dist),
@@ -277,6 +368,8 @@ def main() -> None:
                         "pipeline_* uses pack+sweeps+finalize",
             },
         }
+        if world == 1 and not args.no_host_boundary:
+            out["host_boundary"] = host_boundary(image, mask, Ng, Nr)
         if world == 1 and not args.no_cpu_baseline:
             cb, (img, msk, g_cpu, r_cpu, Nr_s) = cpu_baseline(image, mask, Ng, args.cpu_voxels)
             # same slab through the GPU path: the CPU run doubles as a bit-exact parity check

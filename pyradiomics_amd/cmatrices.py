@@ -69,7 +69,11 @@ def _vptr(a):
 def _parse_arrays(image, mask):
     """_cmatrices.c:1023-1085 (try_parse_arrays): int32 / bool, C-contiguous, equal rank and shape."""
     img = np.ascontiguousarray(np.asarray(image).astype(np.intc, copy=False))
-    msk = np.ascontiguousarray(np.asarray(mask).astype(np.bool_, copy=False))
+    msk = np.asarray(mask)
+    if msk.dtype in (np.uint8, np.int8):
+        msk = np.ascontiguousarray(msk).view(np.uint8)     # one byte per voxel already, the kernels test != 0: no copy
+    else:
+        msk = np.ascontiguousarray(msk.astype(np.bool_, copy=False))
     if img.ndim != msk.ndim:
         raise ValueError("Expected image and mask to have equal number of dimensions.")
     if img.shape != msk.shape:
