@@ -29,10 +29,18 @@ import numpy as np
 import torch
 
 # Fabric (HBM + Infinity Cache) bytes per engine call at the default workload, from the committed PMC profile
-# profiles/r01j_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 correction applied to
-# the 16 B/lane streams): pack 679 MB + 201 MB, sweep_lines 1002 MB + 3 MB, sweep_rows 191 MB + 3 MB.
-# rocprof cannot run inside bench.py; the figure is only reported when the workload matches the profiled one.
-PROFILED_TRAFFIC = {"workload": (512, 32, "uniform"), "bytes": 2.08e9, "source": "profiles/r01j_pmc.md"}
+# profiles/r02a_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE calibrated on the
+# kernels' own access widths: x2 for pack_rows' 16 B/lane loads, /0.572 for sweep_fw's 8 B/lane loads -- one angle
+# alone reads the 134 MB level volume exactly once and reports 76.8 MB): pack_rows 0.80 GB + 0.152 GB written,
+# sweep_fw 1.24 GB (12 angles, 9.3 volume reads) + 0.016 GB.  rocprof cannot run inside bench.py; the figure is only
+# reported when the workload matches the profiled one.
+PROFILED_TRAFFIC = {"workload": (512, 32, "uniform"), "bytes": 2.21e9, "source": "profiles/r02a_pmc.md"}
+# Secondary rooflines of the dominant kernel (it is not HBM-bound): wave-instructions per launch from the same PMC pass,
+# ceilings from scripts/microbench.hip on this GPU (profiles/r02a_microbench.log): a conflict-free ds_add_u32 retires every
+# 4.1 cycles per CU, an independent integer VALU instruction every 2.65 cycles per SIMD (256 CUs x 4 SIMDs, 2.4 GHz).
+PROFILED_INSTS = {"workload": (512, 32, "uniform"), "lds": 2.802e7, "valu": 1.379e8, "source": "profiles/r02a_pmc.md"}
+LDS_ATOMIC_PEAK = 256 * 2.4e9 / 4.1       # ds_add wave-instructions / s
+VALU_PEAK = 1024 * 2.4e9 / 2.65           # VALU wave-instructions / s
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 ALG_BYTES_PER_VOXEL = 5.0       # int32 level + uint8 mask, read once
 
@@ -343,7 +351,7 @@ def main() -> None:
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
         copy_gbps = measured_copy_bandwidth(device)
         out = {
-            "metric": "Mvoxels/s for GLCM+GLRLM build, 512^3 vol @32 bins",
+            "metric": "Mvoxels/s for GLCM+GLRLM build, %d^3 vol @%d bins" % (args.size, args.levels),
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 4), "sync_call_ms_per_step": round(sync_ms, 4),
             "higher_is_better": True, "scaling": "weak",
@@ -354,7 +362,8 @@ def main() -> None:
                                    % (args.size, args.levels, args.dist),
                        "size": args.size, "levels": args.levels, "dist": args.dist},
             "roofline": {
-                "bound": "hbm", "kernel": "sweep_lines_kernel+sweep_rows_kernel (13 angle sweeps)",
+                "bound": "hbm", "kernel": "sweep_fw_kernel (12 of the 13 angles; the x angle is walked inside "
+                                          "pack_rows_fw_kernel, see pipeline_*)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": PROFILED_TRAFFIC["bytes"] if (args.size, args.levels, args.dist) == PROFILED_TRAFFIC["workload"] else None,
@@ -368,6 +377,19 @@ def main() -> None:
                         "pipeline_* uses pack+sweeps+finalize",
             },
         }
+        if (args.size, args.levels, args.dist) == PROFILED_INSTS["workload"]:
+            t = sweep_ms * 1e-3
+            out["roofline"]["secondary"] = {
+                "bound": "lds_atomic", "achieved": round(PROFILED_INSTS["lds"] / t / 1e9, 2), "peak": round(LDS_ATOMIC_PEAK / 1e9, 2),
+                "unit": "G ds_add wave-instructions/s", "frac": round(PROFILED_INSTS["lds"] / t / LDS_ATOMIC_PEAK, 4),
+                "note": "one LDS atomic per run end (1.11 per voxel-step on iid levels); on random bins the LDS array needs "
+                        "6.5 cycles per instruction (70 % bank-conflict cycles), and each ds_add holds its SIMD ~8.8 cycles",
+                "source": PROFILED_INSTS["source"]}
+            out["roofline"]["secondary_valu"] = {
+                "bound": "valu", "achieved": round(PROFILED_INSTS["valu"] / t / 1e9, 2), "peak": round(VALU_PEAK / 1e9, 2),
+                "unit": "G VALU wave-instructions/s", "frac": round(PROFILED_INSTS["valu"] / t / VALU_PEAK, 4),
+                "note": "5.5 VALU per voxel-step (4 in the exec-masked step, SDWA forms at ~4 cycles each)",
+                "source": PROFILED_INSTS["source"]}
         if world == 1 and not args.no_host_boundary:
             out["host_boundary"] = host_boundary(image, mask, Ng, Nr)
         if world == 1 and not args.no_cpu_baseline:

@@ -119,10 +119,15 @@ __device__ __forceinline__ void fw_checked(const FwTab &T, int dummy, int &s, in
 __device__ __forceinline__ void fw_plain_word(const FwTab &T, int dummy, u32 one, int &p0, int &p1, int &p2, int &p3, u32 c, u32 x) {
 #ifndef PRAD_FW_NOASM
   int t;
+#ifdef PRAD_DBG_NOBUMP   // ablation build: everything but the LDS atomic
+#define PRAD_FW_DSADD ""
+#else
+#define PRAD_FW_DSADD "ds_add_u32 %[t], %[one]\n\t"
+#endif
 #define PRAD_FW_COL(J, PJ)                                                                                              \
   "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:BYTE_" #J " src1_sel:BYTE_" #J "\n\t"                                    \
   "v_add_u32_sdwa %[t], %[" PJ "], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t"      \
-  "ds_add_u32 %[t], %[one]\n\t"                                                                                         \
+  PRAD_FW_DSADD                                                                                                          \
   "v_mul_u32_u24_sdwa %[" PJ "], %[P4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t" \
   "s_mov_b64 exec, -1\n\t"                                                                                              \
   "v_add_u32 %[" PJ "], %[Q], %[" PJ "]\n\t"
