@@ -31,3 +31,12 @@ def oracle_ref():
         if not binding.have_ref():
             pytest.skip("oracle/_ref/libcmatrices_ref.so not available")
     return binding.ref()
+
+
+@pytest.fixture(scope="session")
+def checker(oracle_port):
+    """The CPU checker the GPU parity tests compare against: the reference's OWN cmatrices.c (oracle/_ref, built in the
+    dev container and shipped to the GPU box with the repo snapshot) when present, else our C restatement (which
+    tests/test_oracle.py pins bit-for-bit to the reference)."""
+    from oracle import binding
+    return binding.ref() if binding.have_ref() else oracle_port

@@ -1,0 +1,65 @@
+"""GPU parity at BASELINE.json's own sizes, against the reference's own cmatrices.c when
+oracle/_ref/libcmatrices_ref.so travelled with the repo (else our C restatement):
+  C2  synthetic 256^3 volume, full mask, 32 grey levels, ALL FIVE matrices, iid and smooth levels;
+  C4  voxel-based GLCM JointEntropy with the exampleVoxel.yaml window (force2D, kernelRadius 2) on a 512^3 volume:
+      >= 10^4 sampled kernel centres, fused device feature vs the reference's per-kernel matrix + the numpy formula
+      of glcm.py:560-576."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _volume(n, kind, seed):
+    import torch
+    from bench import make_volume
+    img, msk = make_volume(n, 32, kind, seed, torch.device("cuda", 0))
+    return img, msk
+
+
+@pytest.mark.parametrize("kind", ["uniform", "smooth"])
+def test_c2_all_five_matrices_256(kind, checker):
+    from pyradiomics_amd import cmatrices as cm, _lib
+    n, Ng = 256, 32
+    img_d, msk_d = _volume(n, kind, 3)
+    img, msk = img_d.cpu().numpy(), msk_d.cpu().numpy().astype(bool)
+    g, r, ang = cm.calculate_glcm_glrlm(img, msk, Ng, n, False, 0)
+    assert _lib.last_path() == "sweep"
+    eg, eang = checker.calculate_glcm(img, msk, [1], Ng, False, 0)
+    assert np.array_equal(ang, eang) and np.array_equal(g, eg), "GLCM"
+    er, _ = checker.calculate_glrlm(img, msk, Ng, n, False, 0)
+    assert np.array_equal(r, er), "GLRLM"
+    assert np.array_equal(cm.calculate_gldm(img, msk, [1], Ng, 0, False, 0), checker.calculate_gldm(img, msk, [1], Ng, 0, False, 0)), "GLDM"
+    a, b = cm.calculate_ngtdm(img, msk, [1], Ng, False, 0), checker.calculate_ngtdm(img, msk, [1], Ng, False, 0)
+    assert np.array_equal(a[..., 0], b[..., 0]) and np.array_equal(a[..., 2], b[..., 2]), "NGTDM counts"
+    np.testing.assert_allclose(a[..., 1], b[..., 1], rtol=1e-10, atol=0)   # float column: summation order (1e-6 is the bar)
+    Ns = int(msk.sum())
+    assert np.array_equal(cm.calculate_glszm(img, msk, Ng, Ns, False, 0), checker.calculate_glszm(img, msk, Ng, Ns, False, 0)), "GLSZM"
+
+
+def test_c4_voxel_joint_entropy_512_sampled(checker):
+    import torch
+    from pyradiomics_amd import engine
+    n, Ng, nk = 512, 32, 12000
+    img_d, msk_d = _volume(n, "smooth", 5)
+    rng = np.random.default_rng(11)
+    vox = np.stack([rng.integers(0, n, nk), rng.integers(0, n, nk), rng.integers(0, n, nk)]).astype(np.int32)
+    vox[:, :64] = np.array([[0, 0, 0], [n - 1, n - 1, n - 1], [0, n - 1, 0], [n // 2, 0, n - 1]], np.int32).T.repeat(16, 1)  # corners
+    kw = dict(kernelRadius=2, force2D=True, force2Ddimension=0)
+    got = engine.voxel_glcm_features(img_d, msk_d, Ng, torch.from_numpy(vox).cuda(), ["JointEntropy"], **kw)["JointEntropy"]
+    assert engine.last_path() == "voxel-fused"
+    got = got.cpu().numpy()
+    # the reference's route: per-kernel matrices from the C checker, then glcm.py:145-188 (symmetrise, drop empty
+    # angles, normalise) and :560-576 (JointEntropy = -sum p log2(p + eps), mean over angles)
+    img, msk = img_d.cpu().numpy(), msk_d.cpu().numpy().astype(bool)
+    want = np.empty(nk)
+    for s in range(0, nk, 2000):
+        P, _ = checker.calculate_glcm(img, msk, [1], Ng, True, 0, kernelRadius=2, voxels=vox[:, s:s + 2000])
+        P = P + P.transpose(0, 2, 1, 3)
+        tot = P.sum((1, 2))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            p = P / tot[:, None, None, :]
+            ent = -(p * np.log2(p + np.spacing(1))).sum((1, 2))
+        ent[tot == 0] = np.nan
+        want[s:s + 2000] = np.nanmean(ent, axis=1)
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)

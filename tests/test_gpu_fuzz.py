@@ -38,7 +38,7 @@ def _case(rng):
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_random_configurations_match_oracle(seed, oracle_port):
+def test_random_configurations_match_oracle(seed, checker):
     from pyradiomics_amd import cmatrices as cm
     rng = np.random.default_rng(1000 + seed)
     for it in range(16):
@@ -46,28 +46,28 @@ def test_random_configurations_match_oracle(seed, oracle_port):
         tag = "seed %d it %d shape %s Ng %d force2D %s/%d dist %s alpha %d" % (seed, it, shape, Ng, force2D, f2d, dist, alpha)
         Nr = max(shape)
         try:
-            want = oracle_port.calculate_glcm(img, mask, dist, Ng, force2D, f2d)
+            want = checker.calculate_glcm(img, mask, dist, Ng, force2D, f2d)
         except (RuntimeError, IndexError) as e:          # e.g. no angle for this distance in this shape
             with pytest.raises(type(e)):
                 cm.calculate_glcm(img, mask, dist, Ng, force2D, f2d)
             continue
         got = cm.calculate_glcm(img, mask, dist, Ng, force2D, f2d)
         assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), "GLCM " + tag
-        want = oracle_port.calculate_glrlm(img, mask, Ng, Nr, force2D, f2d)
+        want = checker.calculate_glrlm(img, mask, Ng, Nr, force2D, f2d)
         got = cm.calculate_glrlm(img, mask, Ng, Nr, force2D, f2d)
         assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), "GLRLM " + tag
         g, r, _ = cm.calculate_glcm_glrlm(img, mask, Ng, Nr, force2D, f2d)
         assert np.array_equal(r, want[0]), "fused GLRLM " + tag
-        assert np.array_equal(g, oracle_port.calculate_glcm(img, mask, [1], Ng, force2D, f2d)[0]), "fused GLCM " + tag
-        want = oracle_port.calculate_gldm(img, mask, dist, Ng, alpha, force2D, f2d)
+        assert np.array_equal(g, checker.calculate_glcm(img, mask, [1], Ng, force2D, f2d)[0]), "fused GLCM " + tag
+        want = checker.calculate_gldm(img, mask, dist, Ng, alpha, force2D, f2d)
         assert np.array_equal(cm.calculate_gldm(img, mask, dist, Ng, alpha, force2D, f2d), want), "GLDM " + tag
-        want = oracle_port.calculate_ngtdm(img, mask, dist, Ng, force2D, f2d)
+        want = checker.calculate_ngtdm(img, mask, dist, Ng, force2D, f2d)
         got = cm.calculate_ngtdm(img, mask, dist, Ng, force2D, f2d)
         assert np.array_equal(got[..., [0, 2]], want[..., [0, 2]]), "NGTDM counts " + tag
         np.testing.assert_allclose(got[..., 1], want[..., 1], rtol=1e-12, atol=0, err_msg="NGTDM " + tag)
         Ns = int(mask.sum())
         if Ns:
-            want = oracle_port.calculate_glszm(img, mask, Ng, Ns, force2D, f2d)
+            want = checker.calculate_glszm(img, mask, Ng, Ns, force2D, f2d)
             got = cm.calculate_glszm(img, mask, Ng, Ns, force2D, f2d)
             assert got.shape == want.shape and np.array_equal(got, want), "GLSZM " + tag
             Pc, sizes = cm.calculate_glszm_compact(img, mask, Ng, Ns, force2D, f2d)
@@ -75,7 +75,7 @@ def test_random_configurations_match_oracle(seed, oracle_port):
 
 
 @pytest.mark.parametrize("seed", range(3))
-def test_random_voxel_batches_match_oracle(seed, oracle_port):
+def test_random_voxel_batches_match_oracle(seed, checker):
     from pyradiomics_amd import cmatrices as cm
     rng = np.random.default_rng(2000 + seed)
     for it in range(6):
@@ -90,23 +90,23 @@ def test_random_voxel_batches_match_oracle(seed, oracle_port):
         vox = pts[rng.choice(len(pts), size=min(40, len(pts)), replace=False)].T.astype(np.int32)
         kw = dict(kernelRadius=radius, voxels=vox)
         tag = "seed %d it %d shape %s Ng %d r %d force2D %s/%d" % (seed, it, shape, Ng, radius, force2D, f2d)
-        want = oracle_port.calculate_glcm(img, mask, [1], Ng, force2D, f2d, **kw)
+        want = checker.calculate_glcm(img, mask, [1], Ng, force2D, f2d, **kw)
         got = cm.calculate_glcm(img, mask, [1], Ng, force2D, f2d, **kw)
         assert np.array_equal(got[0], want[0]), "voxel GLCM " + tag
-        want = oracle_port.calculate_glrlm(img, mask, Ng, max(shape), force2D, f2d, **kw)
+        want = checker.calculate_glrlm(img, mask, Ng, max(shape), force2D, f2d, **kw)
         got = cm.calculate_glrlm(img, mask, Ng, max(shape), force2D, f2d, **kw)
         assert np.array_equal(got[0], want[0]), "voxel GLRLM " + tag
         assert np.array_equal(cm.calculate_gldm(img, mask, [1], Ng, 0, force2D, f2d, **kw),
-                              oracle_port.calculate_gldm(img, mask, [1], Ng, 0, force2D, f2d, **kw)), "voxel GLDM " + tag
+                              checker.calculate_gldm(img, mask, [1], Ng, 0, force2D, f2d, **kw)), "voxel GLDM " + tag
         assert np.array_equal(cm.calculate_ngtdm(img, mask, [1], Ng, force2D, f2d, **kw),
-                              oracle_port.calculate_ngtdm(img, mask, [1], Ng, force2D, f2d, **kw)), "voxel NGTDM " + tag
+                              checker.calculate_ngtdm(img, mask, [1], Ng, force2D, f2d, **kw)), "voxel NGTDM " + tag
         Ns = int(mask.sum())
         assert np.array_equal(cm.calculate_glszm(img, mask, Ng, Ns, force2D, f2d, **kw),
-                              oracle_port.calculate_glszm(img, mask, Ng, Ns, force2D, f2d, **kw)), "voxel GLSZM " + tag
+                              checker.calculate_glszm(img, mask, Ng, Ns, force2D, f2d, **kw)), "voxel GLSZM " + tag
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_random_medium_volumes_match_oracle(seed, oracle_port):
+def test_random_medium_volumes_match_oracle(seed, checker):
     """volumes big enough for the multi-line-per-lane sweeps (LPL 2 / 4), the 64x64 row tiles and many GLSZM tiles"""
     from pyradiomics_amd import cmatrices as cm
     rng = np.random.default_rng(3000 + seed)
@@ -123,24 +123,24 @@ def test_random_medium_volumes_match_oracle(seed, oracle_port):
     tag = "seed %d shape %s Ng %d" % (seed, shape, Ng)
     Nr = max(shape)
     g, r, ang = cm.calculate_glcm_glrlm(img, mask, Ng, Nr, False, 0)
-    want_g, want_ang = oracle_port.calculate_glcm(img, mask, [1], Ng, False, 0)
+    want_g, want_ang = checker.calculate_glcm(img, mask, [1], Ng, False, 0)
     assert np.array_equal(ang, want_ang) and np.array_equal(g, want_g), "GLCM " + tag
-    assert np.array_equal(r, oracle_port.calculate_glrlm(img, mask, Ng, Nr, False, 0)[0]), "GLRLM " + tag
+    assert np.array_equal(r, checker.calculate_glrlm(img, mask, Ng, Nr, False, 0)[0]), "GLRLM " + tag
     assert np.array_equal(cm.calculate_gldm(img, mask, [1], Ng, 0, False, 0),
-                          oracle_port.calculate_gldm(img, mask, [1], Ng, 0, False, 0)), "GLDM " + tag
-    got, want = cm.calculate_ngtdm(img, mask, [1], Ng, False, 0), oracle_port.calculate_ngtdm(img, mask, [1], Ng, False, 0)
+                          checker.calculate_gldm(img, mask, [1], Ng, 0, False, 0)), "GLDM " + tag
+    got, want = cm.calculate_ngtdm(img, mask, [1], Ng, False, 0), checker.calculate_ngtdm(img, mask, [1], Ng, False, 0)
     assert np.array_equal(got[..., [0, 2]], want[..., [0, 2]]), "NGTDM counts " + tag
     # s_i is a rational number, sum_c S_c / c with integer S_c.  The HIP path evaluates exactly that (a few ulp);
     # the reference adds ~10^6 rounded terms in raster order and sits 1e-13 .. 1e-12 relative away from it.
     import torch
     from fractions import Fraction
     from oracle.segment_ops import OracleSegmentOps
-    acc = OracleSegmentOps(oracle_port).neigh_accumulate(1, torch.from_numpy(img), torch.from_numpy(mask.astype(np.uint8)),
+    acc = OracleSegmentOps(checker).neigh_accumulate(1, torch.from_numpy(img), torch.from_numpy(mask.astype(np.uint8)),
                                                          Ng, 0, shape[0], 0, (1,), False, 0).numpy()
     exact = np.array([float(sum(Fraction(int(acc[g, c]), c) for c in range(1, acc.shape[1]))) for g in range(Ng)])
     np.testing.assert_allclose(got[0, :, 1], exact, rtol=1e-14, atol=0, err_msg="NGTDM vs exact " + tag)
     np.testing.assert_allclose(want[0, :, 1], exact, rtol=1e-10, atol=0, err_msg="reference NGTDM vs exact " + tag)
     Ns = int(mask.sum())
-    want = oracle_port.calculate_glszm(img, mask, Ng, Ns, False, 0)
+    want = checker.calculate_glszm(img, mask, Ng, Ns, False, 0)
     got = cm.calculate_glszm(img, mask, Ng, Ns, False, 0)
     assert got.shape == want.shape and np.array_equal(got, want), "GLSZM " + tag

@@ -18,12 +18,6 @@ def cm():
     return cmatrices
 
 
-@pytest.fixture(scope="module")
-def checker(oracle_port):
-    from oracle import binding
-    return binding.ref() if binding.have_ref() else oracle_port
-
-
 def _levels(seed, shape, Ng, kind):
     rng = np.random.default_rng(seed)
     if kind == "uniform":

@@ -75,53 +75,53 @@ SHAPES = [(5, 6, 7), (1, 9, 9), (9, 1, 5), (4, 4, 1), (12, 10, 8), (3, 70, 65), 
 @pytest.mark.parametrize("shape", SHAPES)
 @pytest.mark.parametrize("Ng", [3, 32])
 @pytest.mark.parametrize("frac", [1.0, 0.6])
-def test_segment_3d(cm, oracle_port, shape, Ng, frac):
+def test_segment_3d(cm, checker, shape, Ng, frac):
     img, mask = _vol(hash((shape, Ng)) % 1000, shape, Ng, frac)
-    _check_all(cm, oracle_port, img, mask, Ng, expect_path="sweep")
+    _check_all(cm, checker, img, mask, Ng, expect_path="sweep")
 
 
 @pytest.mark.parametrize("shape", [(12, 10, 8), (3, 70, 65)])
 @pytest.mark.parametrize("f2d", [0, 1, 2])
-def test_segment_force2d(cm, oracle_port, shape, f2d):
+def test_segment_force2d(cm, checker, shape, f2d):
     img, mask = _vol(7, shape, 8, 0.7)
-    _check_all(cm, oracle_port, img, mask, 8, True, f2d, expect_path="sweep")
+    _check_all(cm, checker, img, mask, 8, True, f2d, expect_path="sweep")
 
 
 @pytest.mark.parametrize("shape", [(40, 50), (1, 64), (7,), (2, 3, 4, 3)])
-def test_other_ranks(cm, oracle_port, shape):
+def test_other_ranks(cm, checker, shape):
     img, mask = _vol(3, shape, 5, 0.8)
-    _check_all(cm, oracle_port, img, mask, 5)
+    _check_all(cm, checker, img, mask, 5)
 
 
-def test_smooth_volume_long_runs(cm, oracle_port):
+def test_smooth_volume_long_runs(cm, checker):
     img, mask = _vol(11, (40, 48, 150), 16, 1.0, smooth=True)
-    _check_all(cm, oracle_port, img, mask, 16, expect_path="sweep")
+    _check_all(cm, checker, img, mask, 16, expect_path="sweep")
     img[:] = 4   # one level everywhere: runs as long as the volume, GLSZM is a single zone
-    _check_all(cm, oracle_port, img, mask, 16, expect_path="sweep")
+    _check_all(cm, checker, img, mask, 16, expect_path="sweep")
 
 
-def test_distances_two(cm, oracle_port):
+def test_distances_two(cm, checker):
     img, mask = _vol(5, (9, 10, 11), 6, 0.8)
-    _check_all(cm, oracle_port, img, mask, 6, dist=(1, 2), alpha=1)
-    _check_all(cm, oracle_port, img, mask, 6, dist=(2,), alpha=2)
+    _check_all(cm, checker, img, mask, 6, dist=(1, 2), alpha=1)
+    _check_all(cm, checker, img, mask, 6, dist=(2,), alpha=2)
 
 
-def test_large_ng_generic(cm, oracle_port):
+def test_large_ng_generic(cm, checker):
     img, mask = _vol(6, (8, 9, 10), 300, 0.9)
-    _check_all(cm, oracle_port, img, mask, 300)
+    _check_all(cm, checker, img, mask, 300)
 
 
 @pytest.mark.parametrize("force2D", [False, True])
-def test_voxel_mode(cm, oracle_port, force2D):
+def test_voxel_mode(cm, checker, force2D):
     img, mask = _vol(9, (10, 14, 12), 7, 0.7)
     rng = np.random.default_rng(0)
     co = np.array(np.where(mask))
     sel = rng.choice(co.shape[1], 200, replace=False)
-    _check_all(cm, oracle_port, img, mask, 7, force2D, 0, vox=co[:, sel], radius=2, expect_path=None)
-    _check_all(cm, oracle_port, img, mask, 7, force2D, 0, vox=co[:, sel[:5]], radius=1)
+    _check_all(cm, checker, img, mask, 7, force2D, 0, vox=co[:, sel], radius=2, expect_path=None)
+    _check_all(cm, checker, img, mask, 7, force2D, 0, vox=co[:, sel[:5]], radius=1)
 
 
-def test_irregular_levels_match_reference_semantics(cm, oracle_port):
+def test_irregular_levels_match_reference_semantics(cm, checker):
     """Levels <= 0 or > Ng under the mask: IndexError where the reference raises, aliased bins where it doesn't."""
     img, mask = _vol(2, (6, 7, 8), 5, 1.0)
     bad = img.copy()
@@ -129,14 +129,14 @@ def test_irregular_levels_match_reference_semantics(cm, oracle_port):
     for fn, args in (("calculate_glcm", ([1], 5, False, 0)), ("calculate_glrlm", (5, 8, False, 0)),
                      ("calculate_gldm", ([1], 5, 0, False, 0)), ("calculate_ngtdm", ([1], 5, False, 0))):
         with pytest.raises(IndexError):
-            getattr(oracle_port, fn)(bad, mask, *args)
+            getattr(checker, fn)(bad, mask, *args)
         with pytest.raises(IndexError):
             getattr(cm, fn)(bad, mask, *args)
     big = img.copy()
     big[1, 1, 1] = 6      # one level above Ng: the reference aliases / raises depending on the flat index
     for fn, args in (("calculate_glcm", ([1], 5, False, 0)), ("calculate_glrlm", (5, 8, False, 0))):
         try:
-            want = getattr(oracle_port, fn)(big, mask, *args)[0]
+            want = getattr(checker, fn)(big, mask, *args)[0]
         except IndexError:
             with pytest.raises(IndexError):
                 getattr(cm, fn)(big, mask, *args)
@@ -144,13 +144,13 @@ def test_irregular_levels_match_reference_semantics(cm, oracle_port):
             assert np.array_equal(getattr(cm, fn)(big, mask, *args)[0], want)
 
 
-def test_empty_mask_and_single_voxel(cm, oracle_port):
+def test_empty_mask_and_single_voxel(cm, checker):
     img, _ = _vol(1, (5, 5, 5), 4, 1.0)
     none = np.zeros(img.shape, bool)
     one = none.copy()
     one[2, 2, 2] = True
     for m in (none, one):
-        _check_all(cm, oracle_port, img, m, 4)
+        _check_all(cm, checker, img, m, 4)
 
 
 def test_argument_errors(cm):
@@ -167,7 +167,7 @@ def test_argument_errors(cm):
         cm.calculate_glcm(img, mask, [1], 4, False, 0, 1, np.zeros((2, 2), int))
 
 
-def test_glszm_zone_list_order(cm, oracle_port):
+def test_glszm_zone_list_order(cm, checker):
     """tempData parity: zones listed in raster order of their first voxel (cmatrices.c:255-258)."""
     import ctypes as C
     from pyradiomics_amd import _lib
@@ -179,12 +179,12 @@ def test_glszm_zone_list_order(cm, oracle_port):
     n = lib.prad_glszm_zones(0, buf.ctypes.data_as(C.POINTER(C.c_int)), cap)
     assert n > 0 and buf[2 * n] == -1
     # reference order from the oracle's calculate_glszm
-    L = oracle_port.L
+    L = checker.L
     m2 = mask.copy()
     size = np.array(img.shape, dtype=np.intc)
     strides = np.array([s // 4 for s in img.strides], dtype=np.intc)
     bb = np.concatenate([np.zeros(3, np.intc), size - 1]).astype(np.intc)
-    ang = oracle_port.generate_angles(size, [1], 1, 0, 0)
+    ang = checker.generate_angles(size, [1], 1, 0, 0)
     temp = np.empty(2 * cap + 1, dtype=np.intc)
     ip = C.POINTER(C.c_int)
     L.calculate_glszm(img.ctypes.data_as(ip), m2.ctypes.data_as(C.c_char_p), size.ctypes.data_as(ip),
@@ -193,31 +193,31 @@ def test_glszm_zone_list_order(cm, oracle_port):
     assert np.array_equal(buf[:2 * n + 1], temp[:2 * n + 1])
 
 
-def test_medium_volume_vs_oracle(cm, oracle_port):
+def test_medium_volume_vs_oracle(cm, checker):
     """128^3 at 32 levels: large enough to exercise the persistent-grid paths, seconds for the oracle."""
     img, mask = _vol(0, (128, 128, 128), 32, 1.0)
     g, r, _ = cm.calculate_glcm_glrlm(img, mask, 32, 128, False, 0)
-    assert np.array_equal(g, oracle_port.calculate_glcm(img, mask, [1], 32, False, 0)[0])
-    assert np.array_equal(r, oracle_port.calculate_glrlm(img, mask, 32, 128, False, 0)[0])
+    assert np.array_equal(g, checker.calculate_glcm(img, mask, [1], 32, False, 0)[0])
+    assert np.array_equal(r, checker.calculate_glrlm(img, mask, 32, 128, False, 0)[0])
 
 
 @pytest.mark.parametrize("shape", [(9, 12, 16), (1, 20, 64), (6, 1, 8), (20, 24, 132), (4, 4, 4)])
 @pytest.mark.parametrize("frac", [1.0, 0.55])
-def test_gldm_ngtdm_packed_byte_path(cm, oracle_port, shape, frac):
+def test_gldm_ngtdm_packed_byte_path(cm, checker, shape, frac):
     """Nx % 4 == 0 takes the 4-voxels-per-lane packed-byte kernels (neigh4_kernel); all force2D variants, levels up
     to 255, alpha = 0 (packed) and alpha = 2 (per-neighbour kernel)"""
     for Ng in (5, 255):
         img, mask = _vol(sum(shape) + Ng, shape, Ng, frac)
         for force2D, f2d in ((False, 0), (True, 0), (True, 1), (True, 2)):
             try:
-                want = oracle_port.calculate_gldm(img, mask, [1], Ng, 0, force2D, f2d)
+                want = checker.calculate_gldm(img, mask, [1], Ng, 0, force2D, f2d)
             except RuntimeError:
                 continue        # no angle left for this shape / force2D combination
             assert np.array_equal(cm.calculate_gldm(img, mask, [1], Ng, 0, force2D, f2d), want)
             assert np.array_equal(cm.calculate_gldm(img, mask, [1], Ng, 2, force2D, f2d),
-                                  oracle_port.calculate_gldm(img, mask, [1], Ng, 2, force2D, f2d))
+                                  checker.calculate_gldm(img, mask, [1], Ng, 2, force2D, f2d))
             a = cm.calculate_ngtdm(img, mask, [1], Ng, force2D, f2d)
-            b = oracle_port.calculate_ngtdm(img, mask, [1], Ng, force2D, f2d)
+            b = checker.calculate_ngtdm(img, mask, [1], Ng, force2D, f2d)
             assert np.array_equal(a[..., 0], b[..., 0]) and np.array_equal(a[..., 2], b[..., 2])
             np.testing.assert_allclose(a[..., 1], b[..., 1], rtol=1e-12, atol=0)
 
@@ -271,7 +271,7 @@ def test_level_counts_and_tensor_inputs_of_the_operator_module():
 
 
 @pytest.mark.parametrize("shape", [(6, 40, 300), (40, 6, 200), (150, 130, 8)])
-def test_long_runs_all_three_mechanisms(cm, oracle_port, shape):
+def test_long_runs_all_three_mechanisms(cm, checker, shape):
     """runs longer than the LDS table's run-length slots: lengths just above RS go to the LDS long-run table,
     full-row / full-column runs of flat regions to the wave-aggregated L2 atomics -- along every axis"""
     rng = np.random.default_rng(21)
@@ -285,8 +285,8 @@ def test_long_runs_all_three_mechanisms(cm, oracle_port, shape):
     Nr = max(shape)
     g, r, ang = cm.calculate_glcm_glrlm(img, mask, Ng, Nr, False, 0)
     assert _lib.last_path() == "sweep"
-    assert np.array_equal(r, oracle_port.calculate_glrlm(img, mask, Ng, Nr, False, 0)[0])
-    assert np.array_equal(g, oracle_port.calculate_glcm(img, mask, [1], Ng, False, 0)[0])
+    assert np.array_equal(r, checker.calculate_glrlm(img, mask, Ng, Nr, False, 0)[0])
+    assert np.array_equal(g, checker.calculate_glcm(img, mask, [1], Ng, False, 0)[0])
     assert r[0, :, 80:, :].sum() > 0 and r[0, :, 20:78, :].sum() > 0      # both long-run paths were exercised
 
 
@@ -341,10 +341,10 @@ def test_full_size_512_properties():
     assert st["Median"] == (lvl((nroi - 1) // 2) + lvl(nroi // 2)) / 2 and st["P10"] >= 1 and st["P90"] <= Ng
 
 
-def test_workspace_query_and_release(cm, oracle_port):
+def test_workspace_query_and_release(cm, checker):
     from pyradiomics_amd import engine
     img, mask = _vol(3, (20, 24, 28), 8, 0.8)
-    want = oracle_port.calculate_glszm(img, mask, 8, int(mask.sum()), False, 0)
+    want = checker.calculate_glszm(img, mask, 8, int(mask.sum()), False, 0)
     assert np.array_equal(cm.calculate_glszm(img, mask, 8, int(mask.sum()), False, 0), want)
     assert engine.workspace_bytes() > 0
     engine.release_workspace()
@@ -352,4 +352,4 @@ def test_workspace_query_and_release(cm, oracle_port):
     with pytest.raises(ValueError):            # phase 2 without phase 1: the zone list went with the workspace
         _ = cm._lib.raise_for(cm._lib.load().prad_fill_glszm(np.zeros(8).ctypes.data, 1, 8, 1), "fill")
     assert np.array_equal(cm.calculate_glszm(img, mask, 8, int(mask.sum()), False, 0), want)
-    _check_all(cm, oracle_port, img, mask, 8)
+    _check_all(cm, checker, img, mask, 8)
