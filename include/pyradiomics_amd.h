@@ -211,7 +211,7 @@ int prad_fill_glszm_compact_dev(double *glszm, int Ng, int nsizes, void *stream)
  * the angles that are non-empty for the voxel.  feature_ids: 0 Autocorrelation, 1 JointAverage, 2 ClusterProminence,
  * 3 ClusterShade, 4 ClusterTendency, 5 Contrast, 6 Correlation, 7 DifferenceAverage, 8 DifferenceEntropy,
  * 9 DifferenceVariance, 10 JointEnergy, 11 JointEntropy, 12 Imc1, 13 Imc2, 14 Idm, 15 Idmn, 16 Id, 17 Idn,
- * 18 InverseVariance, 19 MaximumProbability, 20 SumAverage, 21 SumEntropy, 22 SumSquares (MCC is not offered).
+ * 18 InverseVariance, 19 MaximumProbability, 20 SumAverage, 21 SumEntropy, 22 SumSquares (MCC: prad_voxel_glcm_mcc).
  *   out         float64 [nfeat][Nvox]
  *   empty_mask  uint32 [Nvox] (optional): bit a set <=> angle a has no voxel pair in kernel v
  *   any_nonempty uint32 [1] (optional): OR of the non-empty angle bits over all kernels (JointAverage, which the
@@ -227,6 +227,23 @@ int prad_voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, cons
                                  const int *angles, int Na, int Ng, int Nvox, const int *voxels, int kernelRadius,
                                  int force2Ddim, int symmetric, const int *feature_ids, int nfeat, double *out,
                                  uint32_t *empty_mask, uint32_t *any_nonempty, void *stream);
+
+/* MCC (glcm.py:665-707), the one GLCM feature that is an eigenvalue problem: sqrt of the second largest eigenvalue of
+ * Q(i,j) = sum_k p(i,k) p(j,k) / (px(i) py(k) + eps), per angle, mean over the non-empty angles (np.nanmean).  One wave
+ * per matrix runs a cyclic Jacobi iteration on the symmetric matrix A A^T that is similar to Q, restricted to the grey
+ * levels that occur (at most 64 of them; more -> PRAD_E_UNSUPPORTED and the caller's host route).
+ *   prad_voxel_glcm_mcc[_dev]  out float64 [Nvox]: per kernel (NaN when no angle has a voxel pair); arguments as for
+ *                              prad_voxel_glcm_features
+ *   prad_glcm_mcc_dev          glcm: DEVICE float64 raw counts [Ng][Ng][Na] (reference layout); out: HOST float64 [Na],
+ *                              NaN for an angle without pairs
+ * The reference's "a matrix of a single grey level -> 1" rule (glcm.py:702-703) depends on the grey levels of the whole
+ * ROI and stays with the caller. */
+int prad_voxel_glcm_mcc(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                        int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim, int symmetric, double *out);
+int prad_voxel_glcm_mcc_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                            int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim, int symmetric,
+                            double *out, void *stream);
+int prad_glcm_mcc_dev(const double *glcm, int Ng, int Na, int symmetric, double *out, void *stream);
 
 /* Fused voxel-based feature maps of the other four texture classes (same idea, same window rule as above).
  * family: 1 = GLDM (alpha = gldm_a; angles bidirectional), 2 = NGTDM (bidirectional), 3 = GLRLM (unidirectional, mean

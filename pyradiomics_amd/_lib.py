@@ -59,6 +59,9 @@ SYMBOLS = {
     "prad_fill_glszm_compact_dev": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "prad_voxel_glcm_features": (C.c_int, _COMMON + [C.c_int] + _VOX + [C.c_int, _ip, C.c_int, _vp, _vp, _vp]),
     "prad_voxel_glcm_features_dev": (C.c_int, _COMMON + [C.c_int] + _VOX + [C.c_int, _ip, C.c_int, _vp, _vp, _vp, _vp]),
+    "prad_voxel_glcm_mcc": (C.c_int, _COMMON + [C.c_int] + _VOX + [C.c_int, _vp]),
+    "prad_voxel_glcm_mcc_dev": (C.c_int, _COMMON + [C.c_int] + _VOX + [C.c_int, _vp, _vp]),
+    "prad_glcm_mcc_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _vp]),
     "prad_roi_minmax_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.POINTER(C.c_double), _vp]),
     "prad_digitize_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.POINTER(C.c_double), C.c_int, _vp, _ip, _vp]),
     "prad_voxel_texture_features_dev": (C.c_int, [C.c_int, _vp, _vp, _ip, C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -214,7 +214,7 @@ class RadiomicsFeaturesBase:
         except NotImplementedError:
             return None
         out = []
-        rest = [n for n in names if n in host_only]
+        rest = [n for n in names if n not in vals]      # host_only names and whatever the device declined
         if rest:
             getattr(self, "_initHostOnly", self._initCalculation)(None)
         for n in names:

@@ -323,6 +323,8 @@ def segment_features(cls, image, mask, Ng, features, distances=(1,), force2D=Fal
         table = VOXEL_GLCM_FEATURES
     else:
         table = _ZONE_LIKE[cls][1]
+    want_mcc = cls == "glcm" and "MCC" in features
+    features = [f for f in features if not (cls == "glcm" and f == "MCC")]
     missing = [f for f in features if f not in table]
     if missing:
         raise NotImplementedError("not available in the fused segment kernels: %s" % ", ".join(missing))
@@ -331,7 +333,18 @@ def segment_features(cls, image, mask, Ng, features, distances=(1,), force2D=Fal
             g = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glcm")["glcm_dev"]
         else:
             g, _ = engine.glcm(image, mask, int(Ng), dist, force2D, force2Ddimension)
-        vals = _angle_mean(*engine.glcm_features(g, symmetrical))
+        vals = _angle_mean(*engine.glcm_features(g, symmetrical)) if features else []
+        if want_mcc:
+            res = {f: float(vals[table.index(f)]) for f in features}
+            try:     # (absent from the result when more than 64 grey levels occur: the caller's host route takes it)
+                with np.errstate(invalid="ignore"):
+                    import warnings
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore", RuntimeWarning)
+                        res["MCC"] = float(np.nanmean(engine.glcm_mcc(g, symmetrical)))
+            except NotImplementedError:
+                pass
+            return res
     elif cls == "glrlm":
         r = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glrlm")["glrlm_dev"]
         vals = _angle_mean(*engine.zone_matrix_features(r, np.arange(1, r.shape[1] + 1)))
@@ -412,6 +425,8 @@ def voxel_glcm_features(image, mask, distances, Ng, force2D, force2Ddimension, k
     """-> {feature name: float64 [Nvox]} for the kernels centred on `voxels` (int [Nd, Nvox]).
     Raises NotImplementedError when the fused kernel does not cover the request (Ng > 64, MCC, ...): the caller
     then uses calculate_glcm and the numpy feature formulas."""
+    want_mcc = "MCC" in features
+    all_features, features = features, [f for f in features if f != "MCC"]
     unknown = [f for f in features if f not in VOXEL_GLCM_FEATURES]
     if unknown:
         raise NotImplementedError("not available in the fused voxel kernel: %s" % ", ".join(unknown))
@@ -420,6 +435,14 @@ def voxel_glcm_features(image, mask, distances, Ng, force2D, force2Ddimension, k
     if vox is None:
         raise RuntimeError("voxel_glcm_features needs a voxel list")
     Na, Nd = angles.shape
+    mcc = None
+    if want_mcc:      # its own kernel (one Jacobi eigenvalue iteration per kernel and angle, csrc/kernels_mcc.h)
+        mcc = np.empty(Nvox, dtype=np.float64)
+        rc = _lib.load().prad_voxel_glcm_mcc(_vptr(img), _vptr(msk), _iptr(size), Nd, _iptr(angles), Na, int(Ng), Nvox,
+                                             _vptr(vox), int(kernelRadius), f2d, 1 if symmetrical else 0, _vptr(mcc))
+        _lib.raise_for(rc, "voxel GLCM MCC")
+        if not features:
+            return {"MCC": mcc}
     ids = np.array([VOXEL_GLCM_FEATURES.index(f) for f in features], dtype=np.intc)
     out = np.empty((len(ids), Nvox), dtype=np.float64)
     empty = np.empty(Nvox, dtype=np.uint32)
@@ -433,4 +456,6 @@ def voxel_glcm_features(image, mask, distances, Ng, force2D, force2Ddimension, k
         # glcm.py:292 takes a plain mean over the angles kept for the batch: NaN wherever a kernel lacks an angle
         # that some other kernel of the batch has
         res["JointAverage"] = np.where((empty & anyne[0]) != 0, np.nan, res["JointAverage"])
+    if mcc is not None:
+        res["MCC"] = mcc
     return res

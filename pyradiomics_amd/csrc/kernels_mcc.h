@@ -1,0 +1,248 @@
+// kernels_mcc.h -- Maximal Correlation Coefficient on the device (glcm.py:665-707): the one GLCM feature that is an
+// eigenvalue problem.  MCC = sqrt(second largest eigenvalue of Q), Q(i,j) = sum_k p(i,k) p(j,k) / (px(i) py(k) + eps).
+// Q is similar to M = A A^T with A(i,k) = p(i,k) / sqrt(px(i) py(k) + eps), a symmetric positive semi-definite matrix, so a
+// cyclic Jacobi iteration gives its whole spectrum to machine precision.  ONE WAVE per matrix:
+//   1. marginals px, py; the n grey levels that occur at all (rows / columns of zeros only add zero eigenvalues)
+//   2. M restricted to those levels, n x n float64 in LDS (n <= 64; more -> the caller's host route)
+//   3. parallel cyclic Jacobi: a round-robin tournament pairs the n indices into n/2 disjoint (p, q) per step, the n/2
+//      rotations of a step are applied together (all row pairs, then all column pairs); converged when the off-diagonal
+//      mass is below 1e-30 of the diagonal's
+//   4. second largest diagonal entry.
+// Segment mode: one wave per angle on the raw count matrix [Ng][Ng][Na].  Voxel mode: one wave per kernel centre
+// builds the window's counts per angle in LDS (as kernels_voxel.h pass A) and runs the same routine.
+#pragma once
+#include "prad_runtime.h"
+#include "kernels_voxel.h"
+
+namespace prad {
+
+#define PRAD_MCC_NMAX 64
+
+struct MccScratch {
+  double *M;    // [nmax * nmax]
+  double *px;   // [Ng]
+  double *py;   // [Ng]
+  double *cs;   // [nmax] (c, s) of the step's rotations
+  int *idx;     // [nmax] grey levels that occur
+  int *pq;      // [nmax] (p, q) of the step's rotations
+};
+// (the iteration pads an odd number of levels with one zero row / column: arrays are sized for nmax rounded up to even)
+__host__ __device__ inline size_t mcc_scratch_bytes(int Ng, int nmax) {
+  nmax += nmax & 1;
+  return sizeof(double) * ((size_t)nmax * nmax + 2 * (size_t)Ng + nmax) + sizeof(int) * 2 * (size_t)nmax;
+}
+__device__ __forceinline__ MccScratch mcc_scratch(void *base, int Ng, int nmax) {
+  MccScratch S;
+  nmax += nmax & 1;
+  S.M = (double *)base;
+  S.px = S.M + (size_t)nmax * nmax;
+  S.py = S.px + Ng;
+  S.cs = S.py + Ng;
+  S.idx = (int *)(S.cs + nmax);
+  S.pq = S.idx + nmax;
+  return S;
+}
+__device__ __forceinline__ void mcc_wave_sync() {   // LDS written by one lane is read by another lane of the same wave
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// C(i, j): count (already symmetrised if wanted) of the ordered level pair, tot: their sum (> 0).
+// Returns sqrt(lambda_2) (0 when fewer than two levels occur); *too_many is set when more than nmax levels occur.
+template <class Acc>
+__device__ double wave_mcc(Acc C, int Ng, double tot, MccScratch S, int nmax, int *too_many) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  const double eps = 2.220446049250313e-16;
+  for (int i = lane; i < Ng; i += 64) {
+    double r = 0, c = 0;
+    for (int j = 0; j < Ng; j++) {
+      r += C(i, j) / tot;
+      c += C(j, i) / tot;
+    }
+    S.px[i] = r;
+    S.py[i] = c;
+  }
+  mcc_wave_sync();
+  int n = 0;
+  for (int base = 0; base < Ng; base += 64) {
+    const int i = base + lane;
+    const bool pres = i < Ng && (S.px[i] > 0 || S.py[i] > 0);
+    const unsigned long long m = __ballot(pres);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (pres && n + before < nmax) S.idx[n + before] = i;
+    n += __popcll(m);
+  }
+  if (n > nmax) {
+    if (lane == 0) *too_many = 1;
+    return __builtin_nan("");
+  }
+  if (n < 2) return 0.0;
+  mcc_wave_sync();
+  const int np = n + (n & 1);
+  for (int e = lane; e < np * np; e += 64) {
+    const int a = e / np, b = e - a * np;
+    double v = 0;
+    if (a < n && b < n) {
+      const int ia = S.idx[a], ib = S.idx[b];
+      const double pxa = S.px[ia], pxb = S.px[ib];
+      for (int k = 0; k < n; k++) {
+        const int ik = S.idx[k];
+        const double ca = C(ia, ik), cb = C(ib, ik);
+        if (ca != 0 && cb != 0) {
+          const double pyk = S.py[ik];
+          v += ((ca / tot) / sqrt(pxa * pyk + eps)) * ((cb / tot) / sqrt(pxb * pyk + eps));
+        }
+      }
+    }
+    S.M[e] = v;
+  }
+  mcc_wave_sync();
+  const int m1 = np - 1, half = np / 2;
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = 0, dia = 0;
+    for (int e = lane; e < np * np; e += 64) {
+      const int a = e / np, b = e - a * np;
+      const double v = S.M[e];
+      if (a == b) dia += v * v; else off += v * v;
+    }
+    off = wave_sum_f64(off);
+    dia = wave_sum_f64(dia);
+    if (off <= 1e-30 * dia) break;
+    for (int step = 0; step < m1; step++) {
+      if (lane < half) {
+        int p, q;
+        if (lane == 0) { p = step; q = m1; }
+        else { p = (step + lane) % m1; q = (step - lane + m1) % m1; }
+        const double app = S.M[p * np + p], aqq = S.M[q * np + q], apq = S.M[p * np + q];
+        double c = 1.0, s = 0.0;
+        if (apq != 0.0) {
+          const double theta = (aqq - app) / (2.0 * apq);
+          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(t * t + 1.0);
+          s = t * c;
+        }
+        S.pq[2 * lane] = p; S.pq[2 * lane + 1] = q;
+        S.cs[2 * lane] = c; S.cs[2 * lane + 1] = s;
+      }
+      mcc_wave_sync();
+      for (int w = lane; w < half * np; w += 64) {      // J^T M: rows p, q of every pair
+        const int t = w / np, r = w - t * np;
+        const int p = S.pq[2 * t], q = S.pq[2 * t + 1];
+        const double c = S.cs[2 * t], s = S.cs[2 * t + 1];
+        const double mp = S.M[p * np + r], mq = S.M[q * np + r];
+        S.M[p * np + r] = c * mp - s * mq;
+        S.M[q * np + r] = s * mp + c * mq;
+      }
+      mcc_wave_sync();
+      for (int w = lane; w < half * np; w += 64) {      // (J^T M) J: columns p, q of every pair
+        const int t = w / np, r = w - t * np;
+        const int p = S.pq[2 * t], q = S.pq[2 * t + 1];
+        const double c = S.cs[2 * t], s = S.cs[2 * t + 1];
+        const double mp = S.M[r * np + p], mq = S.M[r * np + q];
+        S.M[r * np + p] = c * mp - s * mq;
+        S.M[r * np + q] = s * mp + c * mq;
+      }
+      mcc_wave_sync();
+    }
+  }
+  // second largest eigenvalue: the largest one with its first position masked out
+  double d = lane < n ? S.M[lane * np + lane] : -1.0;
+  const double top = wave_max_f64(d);
+  const unsigned long long at = __ballot(d == top);
+  const int first = (int)(__ffsll((long long)at) - 1);
+  if (lane == first) d = -1.0;
+  const double second = wave_max_f64(d);
+  return sqrt(fmax(second, 0.0));
+}
+
+// segment mode: counts [Ng][Ng][Na] float64 (raw, reference layout) -> out[a] = MCC of angle a (NaN: no pair)
+__global__ void __launch_bounds__(64) glcm_matrix_mcc_kernel(const double *__restrict__ counts, int Ng, int Na, int symmetric,
+                                                             int nmax, double *__restrict__ out, int *__restrict__ too_many) {
+  extern __shared__ double mcc_lds[];
+  const int a = blockIdx.x, lane = threadIdx.x;
+  auto C = [&](int i, int j) -> double {
+    const double v = counts[((size_t)i * Ng + j) * Na + a];
+    return symmetric ? v + counts[((size_t)j * Ng + i) * Na + a] : v;
+  };
+  double tot = 0;
+  for (int e = lane; e < Ng * Ng; e += 64) tot += C(e / Ng, e % Ng);
+  tot = wave_sum_f64(tot);
+  double v = __builtin_nan("");
+  if (tot > 0) v = wave_mcc(C, Ng, tot, mcc_scratch(mcc_lds, Ng, nmax), nmax, too_many);
+  if (lane == 0) out[a] = v;
+}
+
+#define PRAD_MCC_WAVES 2
+// voxel mode: out[v] = mean over the non-empty angles of the per-angle MCC of kernel v (NaN: no angle has a pair)
+__global__ void __launch_bounds__(64 * PRAD_MCC_WAVES) voxel_glcm_mcc_kernel(
+    const uint8_t *__restrict__ L, int Nz, int Ny, int Nx, VoxAngles A, int Ng, int nvox, const int *__restrict__ voxels,
+    int vox_nd, int radius, int f2d3, int symmetric, int nmax, double *__restrict__ out, int *__restrict__ too_many,
+    const int *__restrict__ flags) {
+  extern __shared__ double mcc_lds[];
+  if (flags[0]) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t per_wave = (mcc_scratch_bytes(Ng, nmax) + sizeof(u32) * (size_t)Ng * Ng + 15) & ~(size_t)15;
+  char *base = (char *)mcc_lds + per_wave * wave;
+  MccScratch S = mcc_scratch(base, Ng, nmax);
+  u32 *tab = (u32 *)(base + mcc_scratch_bytes(Ng, nmax));
+  for (int i = lane; i < Ng * Ng; i += 64) tab[i] = 0;
+  mcc_wave_sync();
+  const bool sym = symmetric != 0;
+  for (int v = blockIdx.x * PRAD_MCC_WAVES + wave; v < nvox; v += gridDim.x * PRAD_MCC_WAVES) {
+    int c[3] = {0, 0, 0};
+    for (int d = 0; d < vox_nd; d++) c[3 - vox_nd + d] = voxels[(long long)d * nvox + v];
+    const int dims[3] = {Nz, Ny, Nx};
+    int lo[3], ext[3];
+    for (int d = 0; d < 3; d++) {
+      if (d == f2d3 || d < 3 - vox_nd) { lo[d] = c[d]; ext[d] = 1; }
+      else {
+        lo[d] = max(c[d] - radius, 0);
+        ext[d] = min(c[d] + radius, dims[d] - 1) - lo[d] + 1;
+      }
+    }
+    const int W = ext[0] * ext[1] * ext[2];
+    double acc = 0;
+    int n_angles = 0;
+    for (int a = 0; a < A.na; a++) {
+      const int dz = A.o[a][0], dy = A.o[a][1], dx = A.o[a][2];
+      int np = 0;
+      for (int k = lane; k < W; k += 64) {
+        const int kx = k % ext[2], kr = k / ext[2];
+        const int ky = kr % ext[1], kz = kr / ext[1];
+        const int qz = kz + dz, qy = ky + dy, qx = kx + dx;
+        if ((unsigned)qz >= (unsigned)ext[0] || (unsigned)qy >= (unsigned)ext[1] || (unsigned)qx >= (unsigned)ext[2]) continue;
+        const int li = L[((long long)(lo[0] + kz) * Ny + (lo[1] + ky)) * Nx + lo[2] + kx];
+        if (!li) continue;
+        const int lj = L[((long long)(lo[0] + qz) * Ny + (lo[1] + qy)) * Nx + lo[2] + qx];
+        if (!lj) continue;
+        np++;
+        atomicAdd(&tab[(li - 1) * Ng + (lj - 1)], 1u);
+        if (sym) atomicAdd(&tab[(lj - 1) * Ng + (li - 1)], 1u);
+      }
+      np = wave_sum_i32(np);
+      if (np == 0) continue;
+      mcc_wave_sync();
+      auto C = [&](int i, int j) -> double { return (double)tab[i * Ng + j]; };
+      acc += wave_mcc(C, Ng, (double)((sym ? 2 : 1) * np), S, nmax, too_many);
+      n_angles++;
+      mcc_wave_sync();
+      for (int k = lane; k < W; k += 64) {        // clear what this angle wrote
+        const int kx = k % ext[2], kr = k / ext[2];
+        const int ky = kr % ext[1], kz = kr / ext[1];
+        const int qz = kz + dz, qy = ky + dy, qx = kx + dx;
+        if ((unsigned)qz >= (unsigned)ext[0] || (unsigned)qy >= (unsigned)ext[1] || (unsigned)qx >= (unsigned)ext[2]) continue;
+        const int li = L[((long long)(lo[0] + kz) * Ny + (lo[1] + ky)) * Nx + lo[2] + kx];
+        if (!li) continue;
+        const int lj = L[((long long)(lo[0] + qz) * Ny + (lo[1] + qy)) * Nx + lo[2] + qx];
+        if (!lj) continue;
+        tab[(li - 1) * Ng + (lj - 1)] = 0;
+        tab[(lj - 1) * Ng + (li - 1)] = 0;
+      }
+      mcc_wave_sync();
+    }
+    if (lane == 0) out[v] = n_angles ? acc / (double)n_angles : __builtin_nan("");
+  }
+}
+
+}  // namespace prad

@@ -16,6 +16,7 @@
 #include "kernels_glszm.h"
 #include "kernels_filters.h"
 #include "kernels_voxel.h"
+#include "kernels_mcc.h"
 #include "kernels_voxtex.h"
 #include "kernels_binning.h"
 
@@ -1013,6 +1014,59 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
   return PRAD_OK;
 }
 
+int voxel_glcm_mcc_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                       int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim, int symmetric, double *out,
+                       hipStream_t s) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Geo g;
+  PRAD_TRY(make_geo(size, Nd, &g));
+  if (!image || !mask || !angles || !voxels || !out) return fail(PRAD_E_ARG, "voxel_glcm_mcc: NULL pointer");
+  if (Nvox < 1 || kernelRadius <= 0) return fail(PRAD_E_ARG, "voxel_glcm_mcc: Nvox/kernelRadius must be >= 1");
+  if (Nd > 3 || Ng < 1 || Ng > 64 || Na < 1 || Na > PRAD_VOX_MAX_ANGLES)
+    return fail(PRAD_E_UNSUPPORTED, "voxel_glcm_mcc: needs Nd <= 3, Ng <= 64, Na <= %d", PRAD_VOX_MAX_ANGLES);
+  VoxAngles A;
+  A.na = Na;
+  for (int a = 0; a < Na; a++) {
+    for (int d = 0; d < 4; d++) A.o[a][d] = 0;
+    for (int d = 0; d < Nd; d++) {
+      const int o = angles[a * Nd + d];
+      if (o < -127 || o > 127) return fail(PRAD_E_UNSUPPORTED, "voxel_glcm_mcc: angle offset %d", o);
+      A.o[a][3 - Nd + d] = (signed char)o;
+    }
+  }
+  int dims[3] = {1, 1, 1};
+  for (int d = 0; d < Nd; d++) dims[3 - Nd + d] = g.size[d];
+  const int f2d3 = force2Ddim >= 0 ? 3 - Nd + force2Ddim : -1;
+  PRAD_TRY(c.begin_call(s));
+  int *flags = nullptr;
+  PRAD_TRY(c.get<int>("flags", 4, &flags));
+  PRAD_HIP(hipMemsetAsync(flags, 0, sizeof(int) * 4, s));
+  uint8_t *levels = nullptr;
+  PRAD_TRY(neigh_pack(&c, s, g, image, mask, Ng, flags, &levels));
+  {
+    Timed t(c, "voxel", s);
+    const int nmax = std::min(Ng, PRAD_MCC_NMAX);
+    const size_t per_wave = (mcc_scratch_bytes(Ng, nmax) + sizeof(u32) * (size_t)Ng * Ng + 15) & ~(size_t)15;
+    const size_t lds = per_wave * PRAD_MCC_WAVES;
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((long long)Nvox + PRAD_MCC_WAVES - 1) / PRAD_MCC_WAVES,
+                                                                           (long long)cu_count() * 8));
+    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_mcc_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(voxel_glcm_mcc_kernel, dim3(gx), dim3(64 * PRAD_MCC_WAVES), lds, s, levels, dims[0], dims[1], dims[2],
+                       A, Ng, Nvox, voxels, Nd, kernelRadius, f2d3, symmetric, nmax, out, flags + 3, flags);
+    PRAD_TRY(check_launch("voxel_glcm_mcc_kernel"));
+  }
+  void *fh = nullptr;
+  PRAD_TRY(c.get_pinned("flags_h", sizeof(int) * 4, &fh));
+  PRAD_HIP(hipMemcpyAsync(fh, flags, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  PRAD_TRY(c.end_call(s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  if (((int *)fh)[0]) return fail(PRAD_E_UNSUPPORTED, "voxel_glcm_mcc: masked levels outside [1, Ng]; use the matrix path");
+  c.last_path = "voxel-fused";
+  return PRAD_OK;
+}
+
 int voxel_texture_features_dev(int family, const int32_t *image, const uint8_t *mask, const int *size, int Nd,
                                const int *angles, int Na, int Ng, int alpha, int Nvox, const int *voxels, int kernelRadius,
                                int force2Ddim, const int *feature_ids, int nfeat, double *out, hipStream_t s) {
@@ -1593,6 +1647,54 @@ int prad_voxel_glcm_features(const int32_t *image, const uint8_t *mask, const in
   if (empty_mask) PRAD_HIP(hipMemcpy(empty_mask, d_masks + 1, sizeof(unsigned) * Nvox, hipMemcpyDeviceToHost));
   if (any_nonempty) PRAD_HIP(hipMemcpy(any_nonempty, d_masks, sizeof(unsigned), hipMemcpyDeviceToHost));
   return PRAD_OK;
+}
+
+int prad_glcm_mcc_dev(const double *glcm, int Ng, int Na, int symmetric, double *out, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!glcm || !out || Ng < 1 || Na < 1) return fail(PRAD_E_ARG, "glcm_mcc: bad arguments");
+  const int nmax = std::min(Ng, PRAD_MCC_NMAX);
+  const size_t lds = mcc_scratch_bytes(Ng, nmax);
+  if (lds > 150 * 1024) return fail(PRAD_E_UNSUPPORTED, "glcm_mcc: Ng=%d exceeds the LDS scratch", Ng);
+  hipStream_t s = (hipStream_t)stream;
+  double *d_out = nullptr;
+  int *d_flag = nullptr;
+  PRAD_TRY(c.get<double>("mcc_out", (size_t)Na, &d_out));
+  PRAD_TRY(c.get<int>("mcc_flag", 4, &d_flag));
+  PRAD_HIP(hipMemsetAsync(d_flag, 0, sizeof(int) * 4, s));
+  {
+    Timed t(c, "features", s);
+    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&glcm_matrix_mcc_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(glcm_matrix_mcc_kernel, dim3(Na), dim3(64), lds, s, glcm, Ng, Na, symmetric, nmax, d_out, d_flag);
+    PRAD_TRY(check_launch("glcm_matrix_mcc_kernel"));
+  }
+  int flag = 0;
+  PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * Na, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  if (flag) return fail(PRAD_E_UNSUPPORTED, "glcm_mcc: more than %d grey levels occur; use the host route", PRAD_MCC_NMAX);
+  return PRAD_OK;
+}
+
+int prad_voxel_glcm_mcc_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                            int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim, int symmetric,
+                            double *out, void *stream) {
+  return voxel_glcm_mcc_dev(image, mask, size, Nd, angles, Na, Ng, Nvox, voxels, kernelRadius, force2Ddim, symmetric, out,
+                            (hipStream_t)stream);
+}
+int prad_voxel_glcm_mcc(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                        int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim, int symmetric, double *out) {
+  Context &c = ctx();
+  Staged st;
+  PRAD_TRY(stage_inputs(c, image, mask, size, Nd, Nvox, voxels, &st));
+  if (!voxels || !out) return fail(PRAD_E_ARG, "voxel_glcm_mcc: bad arguments");
+  double *d_out = nullptr;
+  PRAD_TRY(c.get<double>("o_mcc", (size_t)Nvox, &d_out));
+  int rc = voxel_glcm_mcc_dev(st.image, st.mask, size, Nd, angles, Na, Ng, Nvox, st.voxels, kernelRadius, force2Ddim,
+                              symmetric, d_out, c.own_stream);
+  if (rc != PRAD_OK) return rc;
+  return copy_back(c, out, d_out, (size_t)Nvox);
 }
 
 int prad_voxel_texture_features_dev(int family, const int32_t *image, const uint8_t *mask, const int *size, int Nd,

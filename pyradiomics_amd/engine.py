@@ -145,6 +145,40 @@ def glcm_features(glcm: torch.Tensor, symmetric: bool = True):
     return out, empty != 0
 
 
+def glcm_mcc(glcm: torch.Tensor, symmetric: bool = True):
+    """per-angle MCC (glcm.py:665-707) from the raw device matrix [Ng, Ng, Na]: float64 numpy [Na], NaN for an angle
+    without pairs.  Raises NotImplementedError when more than 64 grey levels occur (host route)."""
+    lib = _lib.load()
+    glcm = glcm.contiguous()
+    Ng, _, Na = glcm.shape
+    lib.prad_set_device(glcm.device.index or 0)
+    out = np.empty(Na, dtype=np.float64)
+    rc = lib.prad_glcm_mcc_dev(C.c_void_p(glcm.data_ptr()), int(Ng), int(Na), 1 if symmetric else 0,
+                               out.ctypes.data_as(C.POINTER(C.c_double)), _stream_ptr())
+    _lib.raise_for(rc, "GLCM MCC")
+    return out
+
+
+def voxel_glcm_mcc(image: torch.Tensor, mask: torch.Tensor, Ng: int, voxels: torch.Tensor, kernelRadius: int = 1,
+                   force2D: bool = False, force2Ddimension: int = 0, symmetrical: bool = True, distances=(1,)):
+    """voxel-based MCC map, everything device-resident: float64 tensor [Nvox]"""
+    lib, image, mask, size = _prep(image, mask)
+    f2d = int(force2Ddimension) if force2D else -1
+    angles = _build_angles(size, list(distances), False, f2d)
+    Na, Nd = angles.shape
+    vox = voxels.to(torch.int32).contiguous()
+    if vox.dim() != 2 or vox.shape[0] != Nd:
+        raise RuntimeError("Expecting voxel indices array to be 2-dimensional")
+    Nvox = int(vox.shape[1])
+    out = torch.empty(Nvox, dtype=torch.float64, device=image.device)
+    rc = lib.prad_voxel_glcm_mcc_dev(
+        C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd, _iptr(angles), Na, int(Ng), Nvox,
+        C.c_void_p(vox.data_ptr()), int(kernelRadius), f2d, 1 if symmetrical else 0, C.c_void_p(out.data_ptr()),
+        _stream_ptr())
+    _lib.raise_for(rc, "voxel GLCM MCC")
+    return out
+
+
 def zone_matrix_features(P: torch.Tensor, jvals):
     """the 16 features GLRLM / GLSZM / GLDM share, per angle, from a device count matrix [Ni, Nj] or [Ni, Nj, Na] with
     level values 1..Ni and size values `jvals` [Nj]: (float64 numpy [Na, 16], bool numpy [Na] = matrix empty)"""

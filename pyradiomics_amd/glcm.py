@@ -63,15 +63,18 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
         come straight from the device (no (Nvox, Ng, Ng, Na) intermediate); otherwise the reference's route
         (matrix + numpy formulas, base.py:253-273) is taken.  `fusedVoxel: False` in the settings forces the latter."""
         if self.weightingNorm is None:
-            seg = self._fusedSegmentFeatures("glcm", host_only=("MCC",), symmetrical=self.symmetricalGLCM)
+            seg = self._fusedSegmentFeatures("glcm", symmetrical=self.symmetricalGLCM)
             if seg is not None:
-                yield from seg
+                for ok, n, v in seg:     # glcm.py:702-703: a ROI of one grey level has 1 x 1 matrices -> MCC = 1
+                    yield ok, n, (np.array(1.0) if n == "MCC" and ok and len(self.coefficients["grayLevels"]) < 2 else v)
                 return
         fused = getattr(self.cMatrices, "voxel_glcm_features", None)
         names = [n for n, on in self.enabledFeatures.items() if on]
         if (self.voxelBased and voxelCoordinates is not None and fused is not None and names
                 and self.settings.get("fusedVoxel", True) and self.weightingNorm is None):
-            covered = getattr(self.cMatrices, "VOXEL_GLCM_FEATURES", names)
+            covered = list(getattr(self.cMatrices, "VOXEL_GLCM_FEATURES", names))
+            if hasattr(self.cMatrices, "voxel_glcm_features") and len(self.coefficients["grayLevels"]) >= 2:
+                covered.append("MCC")                              # (a one-level ROI takes the reference's "-> 1" rule)
             dev_names = [n for n in names if n in covered]
             rest = [n for n in names if n not in covered]          # MCC (and deprecated names, which only raise)
             try:
@@ -81,6 +84,16 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
                              voxelCoordinates, dev_names, self.symmetricalGLCM) if dev_names else {}
             except NotImplementedError:
                 vals = None
+                if "MCC" in dev_names:                             # e.g. more than 64 levels: everything but MCC may still fuse
+                    dev_names = [n for n in dev_names if n != "MCC"]
+                    rest = [n for n in names if n not in dev_names]
+                    try:
+                        vals = fused(self.imageArray, self.maskArray, np.array(self.settings.get("distances", [1])),
+                                     self.coefficients["Ng"], self.settings.get("force2D", False),
+                                     self.settings.get("force2Ddimension", 0), self.settings.get("kernelRadius", 1),
+                                     voxelCoordinates, dev_names, self.symmetricalGLCM) if dev_names else {}
+                    except NotImplementedError:
+                        vals = None
             if vals is not None:
                 if rest:                                           # only these take the per-kernel matrix route
                     self._initHostOnly(voxelCoordinates)

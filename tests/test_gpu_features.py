@@ -238,24 +238,49 @@ def test_segment_features_kernels_on_degenerate_matrices():
     assert not e[0] and z[0, 0] == pytest.approx(1 / 9) and z[0, 6] == pytest.approx(1 / 3) and z[0, 9] == pytest.approx(0, abs=1e-12)
 
 
-def test_voxel_glcm_with_mcc_keeps_the_fused_kernel_for_the_other_features():
-    """MCC is the one GLCM feature without a fused evaluation: requesting it must not push the other 23 onto the
-    per-kernel matrix route"""
-    from pyradiomics_amd import cmatrices, glcm
-    image, mask, _ = load_case("breast1")
-    kw = dict(binWidth=25, kernelRadius=1, maskedKernel=True, initValue=np.nan, voxelBased=True, label=1)
-    out = {}
-    for fused in (True, False):
-        fc = glcm.RadiomicsGLCM(image, mask, fusedVoxel=fused, **kw)
-        for n in ("MCC", "JointEntropy", "Contrast"):
-            fc.enableFeatureByName(n)
-        calls = []
-        orig = cmatrices.voxel_glcm_features
-        cmatrices.voxel_glcm_features = lambda *a, **k: (calls.append(a[8]), orig(*a, **k))[1]
-        try:
-            out[fused] = {k: v.array for k, v in fc.execute().items()}
-        finally:
-            cmatrices.voxel_glcm_features = orig
-        assert (calls == [["JointEntropy", "Contrast"]]) == fused
-    for n in out[True]:
-        np.testing.assert_allclose(out[True][n], out[False][n], rtol=1e-9, atol=1e-12, equal_nan=True, err_msg=n)
+def test_voxel_mcc_on_the_device():
+    """MCC (an eigenvalue problem per kernel and angle, csrc/kernels_mcc.h) is evaluated on the device too: no per-kernel
+    matrix reaches the host, and the map equals the reference's route (matrix + the numpy formula of glcm.py:665-707)"""
+    from pyradiomics_amd import _lib, cmatrices, glcm
+    for case, radius, f2d in (("breast1", 1, False), ("brain2", 2, True)):
+        image, mask, _ = load_case(case)
+        kw = dict(binWidth=25, kernelRadius=radius, maskedKernel=True, initValue=np.nan, voxelBased=True, label=1,
+                  force2D=f2d, force2Ddimension=0)
+        out = {}
+        for fused in (True, False):
+            fc = glcm.RadiomicsGLCM(image, mask, fusedVoxel=fused, **kw)
+            for n in ("MCC", "JointEntropy", "Contrast"):
+                fc.enableFeatureByName(n)
+            calls, mats = [], []
+            orig, orig_m = cmatrices.voxel_glcm_features, cmatrices.calculate_glcm
+            cmatrices.voxel_glcm_features = lambda *a, **k: (calls.append(a[8]), orig(*a, **k))[1]
+            cmatrices.calculate_glcm = lambda *a, **k: (mats.append(1), orig_m(*a, **k))[1]
+            try:
+                out[fused] = {k: v.array for k, v in fc.execute().items()}
+                if fused:
+                    assert _lib.last_path() == "voxel-fused"
+            finally:
+                cmatrices.voxel_glcm_features, cmatrices.calculate_glcm = orig, orig_m
+            assert (calls == [["MCC", "JointEntropy", "Contrast"]]) == fused
+            assert (len(mats) == 0) == fused          # the fused route never builds (Nvox, Ng, Ng, Na)
+        for n in out[True]:
+            np.testing.assert_allclose(out[True][n], out[False][n], rtol=1e-9, atol=1e-10, equal_nan=True, err_msg=n)
+
+
+def test_segment_mcc_on_the_device_and_special_cases():
+    import torch
+    from pyradiomics_amd import engine
+    rng = np.random.default_rng(4)
+    for Ng, sym in ((2, True), (5, False), (32, True), (64, True)):
+        P = rng.integers(0, 50, size=(Ng, Ng, 3)).astype(np.float64)
+        P[:, :, 1] = 0                              # an angle without pairs -> NaN
+        P[:, :, 2] = 0
+        P[Ng // 2, Ng // 2, 2] = 7                  # one grey level only -> second eigenvalue 0
+        got = engine.glcm_mcc(torch.from_numpy(P).cuda(), sym)
+        M = P[:, :, 0] + (P[:, :, 0].T if sym else 0)
+        p = M / M.sum()
+        A = p / np.sqrt(np.outer(p.sum(1), p.sum(0)) + np.spacing(1))
+        want = np.linalg.svd(A, compute_uv=False)[1]
+        assert got[0] == pytest.approx(want, rel=1e-10) and np.isnan(got[1]) and got[2] == 0.0
+    with pytest.raises(NotImplementedError):          # more than 64 grey levels occur: host route
+        engine.glcm_mcc(torch.from_numpy(rng.integers(1, 9, size=(80, 80, 1)).astype(np.float64)).cuda(), True)
