@@ -52,10 +52,27 @@ struct RGaussCoef {
   double N0, N1, N2, N3, D1, D2, D3, D4, M1, M2, M3, M4, BN1, BN2, BN3, BN4, BM1, BM2, BM3, BM4;
 };
 
-// data viewed as [outer][ln][inner]; lane = (outer index, inner index); scratch holds the causal pass in float64
+// final store of a pass: plain float image, or (last pass of a Laplacian term) acc = first ? v / sp2 : acc + v / sp2 with the
+// roundings of the separate accumulation step (the term is rounded to float32 first, ITK's image type)
+__device__ __forceinline__ void rg_store(float *__restrict__ o, float *__restrict__ acc, long long idx, double v, double sp2,
+                                         int first) {
+  const float f = (float)v;
+  if (acc) {
+    const double a = first ? 0.0 : (double)acc[idx];
+    acc[idx] = (float)(a + (double)f / sp2);
+  } else {
+    o[idx] = f;
+  }
+}
+
+// data viewed as [outer][ln][inner]; lane = (outer index, inner index); scratch holds the causal pass in float64.
+// A lane walks its line serially, so memory parallelism has to come from the lane itself: samples are fetched in
+// batches of PRAD_RG_B independent loads ahead of the recursion that consumes them.
+#define PRAD_RG_B 8
 __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restrict__ in, long long outer, int ln,
                                                           long long inner, RGaussCoef c,
-                                                          double *__restrict__ scratch, float *__restrict__ out) {
+                                                          double *__restrict__ scratch, float *__restrict__ out,
+                                                          float *__restrict__ acc, double sp2, int first) {
 #pragma clang fp contract(off)  // ITK's line arithmetic is plain multiply / add; keep the same roundings
   const long long lines = outer * inner;
   const long long line = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,7 +80,6 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
   const long long base = (line / inner) * ln * inner + (line % inner);
   const float *d = in + base;
   double *s = scratch + base;
-  float *o = out + base;
   const long long st = inner;
   // causal pass (itkRecursiveSeparableImageFilter.hxx FilterDataArray)
   const double v1 = d[0];
@@ -80,7 +96,22 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
   {
     double dm1 = x3, dm2 = x2, dm3 = x1;       // data[i-1], [i-2], [i-3]
     double p1 = s3, p2 = s2, p3 = s1, p4 = s0; // scratch[i-1..i-4]
-    for (int i = 4; i < ln; i++) {
+    int i = 4;
+    for (; i + PRAD_RG_B <= ln; i += PRAD_RG_B) {
+      float buf[PRAD_RG_B];
+#pragma unroll
+      for (int k = 0; k < PRAD_RG_B; k++) buf[k] = d[(long long)(i + k) * st];
+#pragma unroll
+      for (int k = 0; k < PRAD_RG_B; k++) {
+        const double di = buf[k];
+        double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
+        v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
+        s[(long long)(i + k) * st] = v;
+        dm3 = dm2; dm2 = dm1; dm1 = di;
+        p4 = p3; p3 = p2; p2 = p1; p1 = v;
+      }
+    }
+    for (; i < ln; i++) {
       const double di = d[(long long)i * st];
       double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
       v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
@@ -100,18 +131,36 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
   a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
   a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
   a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
-  o[(long long)(ln - 1) * st] = (float)(s[(long long)(ln - 1) * st] + a1);
-  o[(long long)(ln - 2) * st] = (float)(s[(long long)(ln - 2) * st] + a2);
-  o[(long long)(ln - 3) * st] = (float)(s[(long long)(ln - 3) * st] + a3);
-  o[(long long)(ln - 4) * st] = (float)(s[(long long)(ln - 4) * st] + a4);
+  rg_store(out, acc, base + (long long)(ln - 1) * st, s[(long long)(ln - 1) * st] + a1, sp2, first);
+  rg_store(out, acc, base + (long long)(ln - 2) * st, s[(long long)(ln - 2) * st] + a2, sp2, first);
+  rg_store(out, acc, base + (long long)(ln - 3) * st, s[(long long)(ln - 3) * st] + a3, sp2, first);
+  rg_store(out, acc, base + (long long)(ln - 4) * st, s[(long long)(ln - 4) * st] + a4, sp2, first);
   {
     // scratch[i-1] = data[i]*M1 + data[i+1]*M2 + data[i+2]*M3 + data[i+3]*M4 - (scratch[i]*D1 + ... + scratch[i+3]*D4)
     double dp0 = d[(long long)(ln - 4) * st], dp1 = y2, dp2 = y1, dp3 = v2;  // data[i], [i+1], [i+2], [i+3] at i = ln-4
     double q0 = a4, q1 = a3, q2 = a2, q3 = a1;                              // scratch[i], [i+1], [i+2], [i+3]
-    for (int i = ln - 4; i > 0; i--) {
+    int i = ln - 4;
+    for (; i - PRAD_RG_B >= 0; i -= PRAD_RG_B) {      // produces samples i-1 .. i-B
+      float buf[PRAD_RG_B];
+      double sb[PRAD_RG_B];
+#pragma unroll
+      for (int k = 0; k < PRAD_RG_B; k++) {
+        buf[k] = d[(long long)(i - 1 - k) * st];
+        sb[k] = s[(long long)(i - 1 - k) * st];
+      }
+#pragma unroll
+      for (int k = 0; k < PRAD_RG_B; k++) {
+        double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
+        v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
+        rg_store(out, acc, base + (long long)(i - 1 - k) * st, sb[k] + v, sp2, first);
+        dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = buf[k];
+        q3 = q2; q2 = q1; q1 = q0; q0 = v;
+      }
+    }
+    for (; i > 0; i--) {
       double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
       v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
-      o[(long long)(i - 1) * st] = (float)(s[(long long)(i - 1) * st] + v);
+      rg_store(out, acc, base + (long long)(i - 1) * st, s[(long long)(i - 1) * st] + v, sp2, first);
       dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = d[(long long)(i - 1) * st];
       q3 = q2; q2 = q1; q1 = q0; q0 = v;
     }
@@ -123,24 +172,28 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
 // a 256-byte row segment, the lane then walks its own line inside the tile (pitch 65: conflict-free).  Causal tiles
 // run from the start of the line, anti-causal tiles from its end, so each direction's 4 boundary samples sit in
 // its first tile.
-#define PRAD_RG_T 64
+#define PRAD_RG_T 64     // lines per workgroup (one lane each)
+#define PRAD_RG_W 32     // samples per tile: 25 KB of LDS per wave instead of 50, twice the waves per CU
 __global__ void __launch_bounds__(64) rgauss_xline_kernel(const float *__restrict__ in, long long lines, int ln,
                                                           RGaussCoef c, double *__restrict__ scratch,
-                                                          float *__restrict__ out) {
+                                                          float *__restrict__ out, float *__restrict__ acc, double sp2,
+                                                          int first) {
 #pragma clang fp contract(off)
-  __shared__ float tin[PRAD_RG_T][PRAD_RG_T + 1];
-  __shared__ double tsc[PRAD_RG_T][PRAD_RG_T + 1];
+  __shared__ float tin[PRAD_RG_T][PRAD_RG_W + 1];
+  __shared__ double tsc[PRAD_RG_T][PRAD_RG_W + 1];
   const int lane = threadIdx.x;
   const long long l0 = (long long)blockIdx.x * PRAD_RG_T;
   const int nl = (int)min((long long)PRAD_RG_T, lines - l0);
   const bool mine = lane < nl;
   // ---- causal ----
   double dm1 = 0, dm2 = 0, dm3 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, v1 = 0;
-  for (int c0 = 0; c0 < ln; c0 += PRAD_RG_T) {
-    const int w = min(PRAD_RG_T, ln - c0);
+  for (int c0 = 0; c0 < ln; c0 += PRAD_RG_W) {
+    const int w = min(PRAD_RG_W, ln - c0);
     __syncthreads();
-    for (int t = 0; t < nl; t++)
-      if (lane < w) tin[t][lane] = in[(l0 + t) * ln + c0 + lane];
+    for (int t = 0; t < nl; t += 2) {      // two rows of 32 samples per wave instruction
+      const int tt = t + (lane >> 5), cc = lane & 31;
+      if (tt < nl && cc < w) tin[tt][cc] = in[(l0 + tt) * ln + c0 + cc];
+    }
     __syncthreads();
     if (mine) {
       int j = 0;
@@ -170,19 +223,23 @@ __global__ void __launch_bounds__(64) rgauss_xline_kernel(const float *__restric
       }
     }
     __syncthreads();
-    for (int t = 0; t < nl; t++)
-      if (lane < w) scratch[(l0 + t) * ln + c0 + lane] = tsc[t][lane];
+    for (int t = 0; t < nl; t += 2) {
+      const int tt = t + (lane >> 5), cc = lane & 31;
+      if (tt < nl && cc < w) scratch[(l0 + tt) * ln + c0 + cc] = tsc[tt][cc];
+    }
   }
   // ---- anti-causal: tiles [e - w, e) walking down from e = ln ----
   double dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-  for (int e = ln; e > 0; e -= PRAD_RG_T) {
-    const int b = max(e - PRAD_RG_T, 0), w = e - b;
+  for (int e = ln; e > 0; e -= PRAD_RG_W) {
+    const int b = max(e - PRAD_RG_W, 0), w = e - b;
     __syncthreads();
-    for (int t = 0; t < nl; t++)
-      if (lane < w) {
-        tin[t][lane] = in[(l0 + t) * ln + b + lane];
-        tsc[t][lane] = scratch[(l0 + t) * ln + b + lane];
+    for (int t = 0; t < nl; t += 2) {
+      const int tt = t + (lane >> 5), cc = lane & 31;
+      if (tt < nl && cc < w) {
+        tin[tt][cc] = in[(l0 + tt) * ln + b + cc];
+        tsc[tt][cc] = scratch[(l0 + tt) * ln + b + cc];
       }
+    }
     __syncthreads();
     if (mine) {
       int j = w - 1;                         // tile-local index of the sample being produced
@@ -210,17 +267,10 @@ __global__ void __launch_bounds__(64) rgauss_xline_kernel(const float *__restric
       }
     }
     __syncthreads();
-    for (int t = 0; t < nl; t++)
-      if (lane < w) out[(l0 + t) * ln + b + lane] = (float)tsc[t][lane];
-  }
-}
-
-__global__ void log_accumulate_kernel(float *__restrict__ acc, const float *__restrict__ cur, long long n,
-                                      double spacing2, int first) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const double a = first ? 0.0 : (double)acc[i];
-    acc[i] = (float)(a + (double)cur[i] / spacing2);
+    for (int t = 0; t < nl; t += 2) {
+      const int tt = t + (lane >> 5), cc = lane & 31;
+      if (tt < nl && cc < w) rg_store(out, acc, (l0 + tt) * ln + b + cc, tsc[tt][cc], sp2, first);
+    }
   }
 }
 
