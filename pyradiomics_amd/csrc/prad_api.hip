@@ -458,7 +458,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
       const long long want = (long long)per_wave * p.fw_blocks * 16;
       int pieces = (int)std::max<long long>(1, (want + D.NU - 1) / D.NU);
       int CL = ((D.NM + pieces - 1) / pieces + 7) & ~7;
-      CL = std::max(CL, 16);
+      CL = std::max(CL, D.NM >= 128 ? 64 : 16);   // (shorter pieces only multiply the piece start / tail overhead)
       if (const char *e = getenv("PRAD_FW_CL")) CL = std::max(8, atoi(e) & ~7);
       D.CL = CL;
       D.pieces = (D.NM + CL - 1) / CL;

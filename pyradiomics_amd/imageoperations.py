@@ -219,6 +219,13 @@ def resampleImage(image, mask, **kwargs):
         step = (new / old)[::-1]
         ri = engine.resample(img.device_tensor(), start[::-1], step, newsize[::-1], codes[str(interpolator)])
         rm = engine.resample(msk.device_tensor(), start[::-1], step, newsize[::-1], 0)
+        # The upload widens narrow integer pixel types (uint8 -> int16, uint16 -> int32 ...), and the kernel clamps to the
+        # range of what it was given; ITK's CastPixelWithBoundsChecking (and the host route below) clamp to the ORIGINAL
+        # pixel type: B-spline overshoot of an unsigned image must not survive as negative / above-maximum values.
+        src_dtype = img._array.dtype if getattr(img, "_array", None) is not None else None
+        if src_dtype is not None and np.issubdtype(src_dtype, np.integer) and str(interpolator) in ("sitkBSpline", "3"):
+            info = np.iinfo(src_dtype)
+            ri = ri.clamp(min=int(info.min), max=int(info.max))
         return (Image(None, tuple(new), origin, msk.direction, tensor=ri),
                 Image(None, tuple(new), origin, msk.direction, tensor=rm))
     src = img.array

@@ -201,3 +201,22 @@ def test_filters_match_wheel_golden():
             out = list(filters.getLoGImage(Image(x, spacing), None, sigma=[sigma]))
             if out:
                 assert np.abs(out[0][0].array - want).max() <= 1e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("dtype", ["uint8", "uint16", "int16"])
+def test_bspline_resample_device_route_clamps_to_the_original_pixel_type(dtype):
+    """narrow unsigned images are widened for the upload; B-spline overshoot must still be clamped to the ORIGINAL
+    range (ITK's CastPixelWithBoundsChecking), as the host route does"""
+    from pyradiomics_amd import imageoperations
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(5)
+    hi = np.iinfo(dtype).max
+    a = np.where(rng.random((12, 14, 16)) < 0.5, np.iinfo(dtype).min, hi).astype(dtype)     # maximal ringing
+    m = np.zeros(a.shape, np.uint8)
+    m[2:10, 3:11, 3:13] = 1
+    kw = dict(resampledPixelSpacing=[0.7, 0.7, 0.7], interpolator="sitkBSpline", padDistance=2)
+    host_i, host_m = imageoperations.resampleImage(Image(a.copy()), Image(m.copy()), deviceResident=False, **kw)
+    dev_i, dev_m = imageoperations.resampleImage(Image(a.copy()), Image(m.copy()), deviceResident=True, **kw)
+    got = dev_i.array.astype(np.int64)
+    assert got.min() >= np.iinfo(dtype).min and got.max() <= hi
+    assert np.array_equal(got, host_i.array.astype(np.int64)) and np.array_equal(dev_m.array, host_m.array)
