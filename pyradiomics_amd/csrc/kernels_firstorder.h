@@ -58,6 +58,37 @@ __device__ __forceinline__ double fo_block_sum(double v, double *sh) {
   return sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// ROI scan shared by every pass: threads t, t + nthreads, ... take 16-byte pieces (8 int16 / 4 float32 / 2 float64 voxels
+// with their 8 / 4 / 2 mask bytes) of [first, last) in a fixed assignment, so a pass issues one wide load per 2..8
+// voxels instead of two narrow ones per voxel (the scalar form ran at a fifth of HBM speed: load-issue bound).
+// f(x) is called for every ROI voxel of the thread, in index order.  Unaligned views take the scalar form.
+template <typename T, typename F>
+__device__ __forceinline__ void fo_scan(const T *__restrict__ img, const uint8_t *__restrict__ mask, long long first,
+                                        long long last, long long t, long long nthreads, F f) {
+  constexpr int E = 16 / (int)sizeof(T);
+  if ((((uintptr_t)(img + first)) & 15) == 0 && (((uintptr_t)(mask + first)) & (E - 1)) == 0) {
+    const long long nvec = (last - first) / E;
+    for (long long v = t; v < nvec; v += nthreads) {
+      const long long i = first + v * E;
+      const uint4 q = *reinterpret_cast<const uint4 *>(img + i);
+      T vals[E];
+      memcpy(vals, &q, 16);
+      uint8_t mk[E];
+      if (E == 8) { const uint2 m = *reinterpret_cast<const uint2 *>(mask + i); memcpy(mk, &m, 8); }
+      else if (E == 4) { const unsigned m = *reinterpret_cast<const unsigned *>(mask + i); memcpy(mk, &m, 4); }
+      else { const unsigned short m = *reinterpret_cast<const unsigned short *>(mask + i); memcpy(mk, &m, 2); }
+#pragma unroll
+      for (int e = 0; e < E; e++)
+        if (mk[e]) f((double)vals[e]);
+    }
+    for (long long i = first + nvec * E + t; i < last; i += nthreads)
+      if (mask[i]) f((double)img[i]);
+  } else {
+    for (long long i = first + t; i < last; i += nthreads)
+      if (mask[i]) f((double)img[i]);
+  }
+}
+
 // The reductions read the image and the mask directly, in raster order with a fixed block layout, so their partial
 // sums (added on the host in block order) do not depend on the order the compaction happens to produce.
 // partial[b][0] = sum x, [1] = sum (x + c)^2, [2] = min x, [3] = max x, [4] = ROI voxels of the block (a block
@@ -67,16 +98,14 @@ __global__ void __launch_bounds__(256) fo_sums_kernel(const T *__restrict__ img,
                                                       long long n, double shift, double *__restrict__ partial) {
   __shared__ double sh[4];
   double s1 = 0, s2 = 0, mn = INFINITY, mx = -INFINITY, cnt = 0;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (!mask[i]) continue;
-    const double x = (double)img[i], y = x + shift;
+  fo_scan(img, mask, 0, n, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x, [&](double x) {
+    const double y = x + shift;
     s1 += x;
     s2 += y * y;
     mn = fmin(mn, x);
     mx = fmax(mx, x);
     cnt += 1.0;
-  }
+  });
   s1 = fo_block_sum(s1, sh);
   s2 = fo_block_sum(s2, sh);
   cnt = fo_block_sum(cnt, sh);
@@ -118,9 +147,8 @@ __global__ void __launch_bounds__(1024) fo_hist_kernel(const T *__restrict__ img
   __shared__ unsigned h[PRAD_FO_BINS];
   for (int k = threadIdx.x; k < PRAD_FO_BINS; k += blockDim.x) h[k] = 0u;
   __syncthreads();
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    if (mask[i]) atomicAdd(&h[fo_bin((double)img[i], lo, scale)], 1u);
+  fo_scan(img, mask, 0, n, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x,
+          [&](double x) { atomicAdd(&h[fo_bin(x, lo, scale)], 1u); });
   __syncthreads();
   for (int k = threadIdx.x; k < PRAD_FO_BINS; k += blockDim.x)
     if (h[k]) atomicAdd(hist + k, h[k]);
@@ -154,19 +182,16 @@ __global__ void __launch_bounds__(1024) fo_binrange_kernel(const T *__restrict__
     r[threadIdx.x][1] = 0ull;
   }
   __syncthreads();
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (!mask[i]) continue;
-    const double x = (double)img[i];
+  fo_scan(img, mask, 0, n, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x, [&](double x) {
     const int b = fo_bin(x, lo, scale);
-    if (b < sel.bin[0] || b > sel.bin[sel.nsel - 1]) continue;
+    if (b < sel.bin[0] || b > sel.bin[sel.nsel - 1]) return;
     for (int q = 0; q < sel.nsel; q++)
       if (b == sel.bin[q]) {
         const unsigned long long k = fo_key(x);
         if (k < r[q][0]) atomicMin(&r[q][0], k);     // the plain read skips the atomic once the extremes are known
         if (k > r[q][1]) atomicMax(&r[q][1], k);
       }
-  }
+  });
   __syncthreads();
   if (threadIdx.x < sel.nsel) {   // same-address global atomics serialise in L2: only when they can change the value
     unsigned long long *g = range + 2 * threadIdx.x;
@@ -185,8 +210,8 @@ __global__ void __launch_bounds__(1024) fo_gather_kernel(const T *__restrict__ i
   __shared__ unsigned cnt[PRAD_FO_MAXSEL], base[PRAD_FO_MAXSEL];
   if (threadIdx.x < PRAD_FO_MAXSEL) cnt[threadIdx.x] = 0u;
   __syncthreads();
-  const long long per = (n + gridDim.x - 1) / gridDim.x;
-  const long long first = (long long)blockIdx.x * per, last = min(n, first + per);
+  const long long per = (((n + gridDim.x - 1) / gridDim.x) + 15) & ~15LL;   // slabs start on 16-voxel boundaries (wide loads)
+  const long long first = min(n, (long long)blockIdx.x * per), last = min(n, first + per);
   auto which = [&](double x) -> int {
     const int b = fo_bin(x, lo, scale);
     int j = -1;
@@ -195,23 +220,20 @@ __global__ void __launch_bounds__(1024) fo_gather_kernel(const T *__restrict__ i
         if (b == sel.bin[q]) j = q;
     return j;
   };
-  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
-    if (!mask[i]) continue;
-    const int j = which((double)img[i]);
+  fo_scan(img, mask, first, last, (long long)threadIdx.x, (long long)blockDim.x, [&](double x) {
+    const int j = which(x);
     if (j >= 0) atomicAdd(&cnt[j], 1u);
-  }
+  });
   __syncthreads();
   if (threadIdx.x < sel.nsel) {
     base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(cursors + threadIdx.x, cnt[threadIdx.x]) : 0u;
     cnt[threadIdx.x] = 0u;
   }
   __syncthreads();
-  for (long long i = first + threadIdx.x; i < last; i += blockDim.x) {
-    if (!mask[i]) continue;
-    const double x = (double)img[i];
+  fo_scan(img, mask, first, last, (long long)threadIdx.x, (long long)blockDim.x, [&](double x) {
     const int j = which(x);
     if (j >= 0) out[sel.off[j] + base[j] + atomicAdd(&cnt[j], 1u)] = x;
-  }
+  });
 }
 
 // partial[b][0..3] = sum |d|, d^2, d^3, d^4 with d = x - mu; [4] = count, [5] = sum of x with lo <= x <= hi
@@ -222,10 +244,8 @@ __global__ void __launch_bounds__(256) fo_central_kernel(const T *__restrict__ i
 #pragma clang fp contract(off)
   __shared__ double sh[4];
   double a1 = 0, a2 = 0, a3 = 0, a4 = 0, bc = 0, bs = 0;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (!mask[i]) continue;
-    const double x = (double)img[i], d = x - mu, d2 = d * d;
+  fo_scan(img, mask, 0, n, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x, [&](double x) {
+    const double d = x - mu, d2 = d * d;
     a1 += fabs(d);
     a2 += d2;
     a3 += d2 * d;
@@ -234,7 +254,7 @@ __global__ void __launch_bounds__(256) fo_central_kernel(const T *__restrict__ i
       bc += 1.0;
       bs += x;
     }
-  }
+  });
   a1 = fo_block_sum(a1, sh);
   a2 = fo_block_sum(a2, sh);
   a3 = fo_block_sum(a3, sh);
@@ -253,12 +273,9 @@ __global__ void __launch_bounds__(256) fo_band_kernel(const T *__restrict__ img,
                                                       double *__restrict__ partial) {
   __shared__ double sh[4];
   double a = 0;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (!mask[i]) continue;
-    const double x = (double)img[i];
+  fo_scan(img, mask, 0, n, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x, [&](double x) {
     if (x >= lo && x <= hi) a += fabs(x - mu);
-  }
+  });
   a = fo_block_sum(a, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = a;
 }
