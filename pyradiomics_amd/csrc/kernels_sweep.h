@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256) pack_levels_kernel(const int *__restrict_
                                                           const uint8_t *__restrict__ mask, long long n, int NX,
                                                           int pitch, int padw, int Ng,
                                                           uint8_t *__restrict__ levels, int *__restrict__ flags,
-                                                          int vec_ok, int shift) {
+                                                          int vec_ok, int shift, uint8_t *__restrict__ rowzero = nullptr) {
   const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long nthreads = (long long)gridDim.x * blockDim.x;
   const bool linear = (padw == 0 && pitch == NX);
@@ -73,6 +73,17 @@ __global__ void __launch_bounds__(256) pack_levels_kernel(const int *__restrict_
         ow[w] = o;
       }
       const uint4 o4 = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+      if (rowzero) {   // rows that hold a voxel outside the ROI (kernels_sweepfw.h); zeroed by the caller beforehand
+        u32 zb = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) zb |= (ow[w] - 0x01010101u) & ~ow[w] & 0x80808080u;
+        if (zb) {
+          flags[3] = 1;
+          const long long e0 = t << 4;
+          rowzero[e0 / NX] = 1;
+          rowzero[(e0 + 15) / NX] = 1;      // (a 16-voxel piece spans at most two rows when NX >= 16; marking both is safe)
+        }
+      }
       if (linear) {
         reinterpret_cast<uint4 *>(levels)[t] = o4;
       } else {
@@ -90,6 +101,10 @@ __global__ void __launch_bounds__(256) pack_levels_kernel(const int *__restrict_
     const int l = image[i];
     bad |= in && (l < 1 || l > Ng);
     const uint8_t v = in ? (uint8_t)(l << shift) : (uint8_t)0;
+    if (rowzero && !v) {
+      rowzero[i / NX] = 1;
+      flags[3] = 1;
+    }
     if (linear) {
       levels[i] = v;
     } else {

@@ -37,6 +37,8 @@ struct FwDesc {
 struct FwSet {
   int count;
   int NX;
+  int pitch;         // bytes per row of the packed volume (row r of rowzero[] starts at r * pitch)
+  int nrows;         // rows of the packed volume
   FwDesc d[PRAD_MAX_SWEEP];
 };
 
@@ -116,6 +118,8 @@ __device__ __forceinline__ void fw_checked(const FwTab &T, int dummy, int &s, in
 // bump it and take the fresh state level*P; then every lane adds Q (one more voxel on the open run / the first voxel
 // of the fresh one).  4 VALU + 1 SALU + 1 ds_add per voxel-step and the LDS only sees the event lanes
 // (the branch-free select form below costs 7 VALU and sends the other lanes to dummy words).
+// Lines inside a stretch of voxels outside the ROI (level 0) run the same step: their "run" ends in the scratch words in
+// front of the table; FwWave::calm_zero() keeps their length from growing (it would walk the address into the table).
 __device__ __forceinline__ void fw_plain_word(const FwTab &T, int dummy, u32 one, int &p0, int &p1, int &p2, int &p3, u32 c, u32 x) {
 #ifndef PRAD_FW_NOASM
   int t;
@@ -316,8 +320,8 @@ struct FwWave {
         const int r2 = (((4 * w + 2 - k * DX) % K) + K) % K, r3 = (((4 * w + 3 - k * DX) % K) + K) % K;
         fw_plain_word(T, dummy, one, pl[r0], pl[r1], pl[r2], pl[r3], v[k][w], X[w]);
       }
-      if (DX > 0) rotate_reg<true>(pl[(((K - 1 - k) % K) + K) % K], 0);
-      if (DX < 0) rotate_reg<true>(pl[k % K], 0);
+      if (DX > 0) rotate_reg<true>(pl[(((K - 1 - k) % K) + K) % K], FW_BYTE(v[k], K - 1));
+      if (DX < 0) rotate_reg<true>(pl[k % K], FW_BYTE(v[k], 0));
 #pragma unroll
       for (int w = 0; w < KW; w++) P[w] = v[k][w];
     }
@@ -332,7 +336,8 @@ struct FwWave {
     unsigned m = 0;
 #pragma unroll
     for (int j = 0; j < K; j++) {
-      unsigned a = (unsigned)(pl[j] - __mul24(FW_BYTE(X, j), T.P4));   // len*Q
+      const int xj = FW_BYTE(X, j);
+      unsigned a = (unsigned)(pl[j] - __mul24(xj, T.P4));   // len*Q
       if (YOUNG) a = min(a, (unsigned)(pl[j] - T.deadbase));
       m = max(m, a);
     }
@@ -346,6 +351,19 @@ struct FwWave {
     for (int j = 0; j < K; j++)
       if ((calm[j >> 2] >> (8 * (j & 3))) & 0xffu) pl[j] = 0;
   }
+  // The same for lines inside a stretch of voxels outside the ROI (previous level 0), called before every group that
+  // touches a row holding such voxels: the stretch is no run, its "length" restarts (a dead line too: whatever run it
+  // was waiting on has ended, and nobody records the end of a stretch), so it never grows more than U steps and its
+  // end lands in the scratch words below the table.  2 VALU per column per group, on masked rows only; making the
+  // step itself skip such lines costs a VALU per voxel-step AND a second copy of the group (measured +5 % on full
+  // masks from the register copies between the two).
+  __device__ __forceinline__ void calm_zero() {
+    u32 X[KW];
+    fw_make_x<K, DX>(P, X);
+#pragma unroll
+    for (int j = 0; j < K; j++)
+      if (FW_BYTE(X, j) == 0) pl[j] = 0;
+  }
   __device__ __forceinline__ bool any_alive() {
     u32 X[KW];
     fw_make_x<K, DX>(P, X);
@@ -354,9 +372,21 @@ struct FwWave {
     for (int j = 0; j < K; j++) a = a || (pl[j] < T.deadbase && FW_BYTE(X, j) != 0);
     return __ballot(a) != 0;
   }
-  __device__ __forceinline__ void run(const FwDesc &D, int NX, const uint8_t *__restrict__ L, int *work) {
+  __device__ __forceinline__ void run(const FwDesc &D, int NX, int pitch, long long nrows, const uint8_t *__restrict__ L,
+                                      const uint8_t *__restrict__ rowzero, bool anyzero, int *work) {
     const int NM = D.NM, NU = D.NU, du = D.du;
     const long long delta = D.sM + (long long)du * D.sU;
+    // row numbers of the packed volume (rowzero[r] != 0: row r holds a voxel outside the ROI), wave-uniform like `off`
+    const long long sMr = D.sM / pitch, sUr = D.sU / pitch, dri = sMr + (long long)du * sUr;
+    // Row flags, 64 marching steps at a time: bit j of `zm` = flag of row ri0 + (j - 1) * dri (bit 0 is the row the
+    // lines come from), one vector load + ballot per 56 steps; between reloads a group costs three SALU instructions
+    // (per-group loads cost 4 % of a SIMD-issue-bound kernel; scalar loads share lgkmcnt with the ds_adds in flight and
+    // their wait drains the LDS queue, +8 %).  A row wrap invalidates the window.
+    const int rlast = (int)nrows - 1;                                   // (volumes stay below 2^31 voxels)
+    const int zlane = (lane - 1) * (int)dri;
+    auto zwindow = [&](long long r) -> unsigned long long {
+      return __ballot(rowzero[min(max((int)r + zlane, 0), rlast)] != 0);
+    };
     const uint8_t *lp = L + first_col(NX);
     // chunk hand-out: the first chunk of a wave is its index, the rest come from a counter that has a cache line to
     // itself (a dequeue word saturates near 90 grabs per microsecond: 12 angles sharing one line, or one angle cut
@@ -380,6 +410,9 @@ struct FwWave {
       int row = (int)((u0 + (long long)t0 * du) % NU);
       if (row < 0) row += NU;
       long long off = (long long)t0 * D.sM + (long long)row * D.sU;
+      long long ri = (long long)t0 * sMr + (long long)row * sUr;   // row number of `off`
+      unsigned long long zm = 0;   // zwindow() of the stretch being marched; zpos = bit of the current row
+      int zpos = 65;
 #ifdef PRAD_DBG_NODEAD     // ablation build (wrong results): every piece begins like a line start
       const bool starts = true;
 #else
@@ -419,6 +452,23 @@ struct FwWave {
         if (!tail && !closing) {
           const int room = du > 0 ? NU - row : (du < 0 ? row + 1 : (1 << 30));  // steps before the row range ends
           const bool grp = t + U <= t1 && room >= U;
+          bool za = false;   // some row of this group (or the one before it) has voxels outside the ROI
+          if (grp) {
+#ifdef PRAD_DBG_NOZ      // ablation build (wrong results on partial masks): no row flags, never zero-aware
+            za = false;
+#else
+            if (!rowzero) {
+              za = true;
+            } else if (anyzero) {
+              if (zpos + U > 64) {
+                zm = zwindow(ri);
+                zpos = 1;
+              }
+              za = ((zm >> (zpos - 1)) & ((1ull << (U + 1)) - 1)) != 0;
+            }
+#endif
+          }
+          if (LONG && za) calm_zero();   // (without LONG every length a line can reach has its slot)
           if (grp && safe == 0) {
             calm_padding();
             if (!LONG && !maybe_dead) {
@@ -445,6 +495,8 @@ struct FwWave {
             t += U;
             row += U * du;
             off += (long long)U * delta;
+            ri += (long long)U * dri;
+            zpos += U;
             if (du != 0 && (row < 0 || row >= NU)) wrap = true;
             continue;
           }
@@ -464,12 +516,16 @@ struct FwWave {
           reset_lines(0);    // (P is the row of zeros already)
           row -= du * NU;
           off -= (long long)du * NU * D.sU;
+          ri -= (long long)du * NU * sUr;
+          zpos = 65;
           wrap = false;
           continue;
         }
         t++;
+        zpos++;
         row += du;
         off += delta;
+        ri += dri;
         if (du != 0 && (row < 0 || row >= NU)) wrap = true;
       }
     }
@@ -477,11 +533,13 @@ struct FwWave {
 };
 
 template <bool LONG, int K, bool HASPAD>
-__global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, const uint8_t *__restrict__ L, int Ng, int Nr, int RS,
+__global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, const uint8_t *__restrict__ L,
+                                                        const uint8_t *__restrict__ rowzero, int Ng, int Nr, int RS,
                                                         u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
                                                         int *__restrict__ work, int *__restrict__ flags) {
   extern __shared__ u32 lds[];
   if (flags[0]) return;  // irregular levels: the generic path will redo this call
+  const bool anyzero = flags[3] != 0;   // the pack kernel saw a voxel outside the ROI (else the row flags are not read)
   const HistLayout h = hist_layout(true, true, true, Ng, RS);
   if ((unsigned)(size_t)((lds_u32 *)lds) != 0u) {  // table offsets are used as LDS addresses
     if (threadIdx.x == 0) atomicExch(flags + 2, 1);
@@ -494,13 +552,13 @@ __global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, const uint8_t
   T.init(h, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
   if (D.dx == 0) {
     FwWave<LONG, K, 0, HASPAD> w(T, set.NX);
-    w.run(D, set.NX, L, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
+    w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
   } else if (D.dx > 0) {
     FwWave<LONG, K, 1, HASPAD> w(T, set.NX);
-    w.run(D, set.NX, L, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
+    w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
   } else {
     FwWave<LONG, K, -1, HASPAD> w(T, set.NX);
-    w.run(D, set.NX, L, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
+    w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
   }
   flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, D.slot, glcm_acc, glrlm_acc);
 }
@@ -515,13 +573,16 @@ __device__ __forceinline__ void fw_row_word(const FwTab &T, u32 one, int &s, u32
 #define PRAD_FW_RCOL(J)                                                                                          \
   "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:BYTE_" #J " src1_sel:BYTE_" #J "\n\t"                             \
   "v_add_u32_sdwa %[t], %[s], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t"   \
-  "ds_add_u32 %[t], %[one]\n\t"                                                                                  \
   "v_mul_u32_u24_sdwa %[s], %[P4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t" \
+  "v_cmpx_ne_u32_sdwa vcc, %[x], %[z] src0_sel:BYTE_" #J " src1_sel:DWORD\n\t"                                  \
+  "ds_add_u32 %[t], %[one]\n\t"                                                                                  \
   "s_mov_b64 exec, -1\n\t"                                                                                       \
   "v_add_u32 %[s], %[Q], %[s]\n\t"
+  u32 z = 0;      // zero aware (see fw_plain_word<true>): a stretch of unmasked voxels never touches the table
+  asm volatile("" : "+v"(z));
   asm volatile(PRAD_FW_RCOL(0) PRAD_FW_RCOL(1) PRAD_FW_RCOL(2) PRAD_FW_RCOL(3)
                : [s] "+v"(s), [t] "=&v"(t)
-               : [c] "v"(c), [x] "v"(x), [one] "v"(one), [P4] "s"(T.P4), [Q] "s"(T.Q)
+               : [c] "v"(c), [x] "v"(x), [one] "v"(one), [P4] "s"(T.P4), [Q] "s"(T.Q), [z] "v"(z)
                : "vcc", "memory");
 #undef PRAD_FW_RCOL
 }
@@ -591,7 +652,7 @@ __global__ void __launch_bounds__(512) sweep_fw_rows_kernel(const uint8_t *__res
         const uint4 d = row[q];
         const u32 wds[4] = {d.x, d.y, d.z, d.w};
         // 16 steps: safe on the plain path while len*Q + 16 Q stays within the table's length slots
-        const unsigned m = (unsigned)(s - __mul24((int)(pw >> 24), T.P4));
+        const unsigned m = (pw >> 24) ? (unsigned)(s - __mul24((int)(pw >> 24), T.P4)) : 0u;
         if (LONG && __ballot(m + 16 * T.Q > (unsigned)T.lenlim) != 0) {
 #pragma unroll 1
           for (int k = 0; k < 4; k++) {
@@ -626,7 +687,8 @@ template <bool LONG, bool WALK>
 __global__ void __launch_bounds__(1024) pack_rows_fw_kernel(const int *__restrict__ image, const uint8_t *__restrict__ mask,
                                                             long long nrows, int NX, int pitch, uint8_t *__restrict__ L,
                                                             int slot, int Ng, int Nr, int RS, u32 *__restrict__ glcm_acc,
-                                                            u32 *__restrict__ glrlm_acc, int *__restrict__ flags) {
+                                                            u32 *__restrict__ glrlm_acc, int *__restrict__ flags,
+                                                            uint8_t *__restrict__ rowzero) {
   extern __shared__ u32 lds[];
   const HistLayout h = hist_layout(true, true, true, Ng, RS);
   if (WALK && (unsigned)(size_t)((lds_u32 *)lds) != 0u) {
@@ -652,6 +714,7 @@ __global__ void __launch_bounds__(1024) pack_rows_fw_kernel(const int *__restric
     const long long r0 = grp * 64;
     int s = 0;
     u32 pw = 0;
+    u32 zacc = 0;     // bit 7 of some byte set <=> this lane's row holds a voxel outside the ROI
     for (int xc = 0; xc < NX; xc += 64) {
       const int cx = xc + 4 * piece;
       const bool xin = cx < NX;
@@ -696,7 +759,8 @@ __global__ void __launch_bounds__(1024) pack_rows_fw_kernel(const int *__restric
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const u32 c = wds[k], x = __builtin_amdgcn_alignbyte(c, pw, 3);
-            const unsigned m = (unsigned)(s - __mul24((int)(pw >> 24), T.P4));
+            if (xc + 16 * qq + 4 * k < NX) zacc |= (c - 0x01010101u) & ~c & 0x80808080u;   // a zero byte (Nx % 4 == 0)
+            const unsigned m = (pw >> 24) ? (unsigned)(s - __mul24((int)(pw >> 24), T.P4)) : 0u;
             if (LONG && __ballot(m + 4 * T.Q > (unsigned)T.lenlim) != 0) {
 #pragma unroll
               for (int b = 0; b < 4; b++) fw_checked<LONG>(T, dummy, s, (int)((x >> (8 * b)) & 0xffu), (int)((c >> (8 * b)) & 0xffu), false);
@@ -709,7 +773,13 @@ __global__ void __launch_bounds__(1024) pack_rows_fw_kernel(const int *__restric
         __builtin_amdgcn_wave_barrier();
       }
     }
-    if (WALK) fw_checked<LONG>(T, dummy, s, (int)(pw >> 24), 0, false);
+    if (WALK) {
+      fw_checked<LONG>(T, dummy, s, (int)(pw >> 24), 0, false);
+      if (rowzero && r0 + lane < nrows) {
+        rowzero[r0 + lane] = zacc ? 1 : 0;
+        if (zacc) flags[3] = 1;     // (benign race: every writer stores the same value)
+      }
+    }
   }
   if (bad) flags[0] = 1;
   // (a volume with irregular levels is redone on the generic kernels: what was accumulated here is never read)

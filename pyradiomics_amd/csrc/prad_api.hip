@@ -108,7 +108,7 @@ struct Call {
   const int *angles_h;    // host [Na][Nd]
   int *angles_d;          // device copy
   int Na;
-  int *flags_d;           // device int[4]: [0] pack saw irregular level, [1] generic index error, [2] sweep LDS base != 0
+  int *flags_d;           // device int[4]: [0] pack saw irregular level, [1] generic index error, [2] sweep LDS base != 0, [3] the pack kernel saw a voxel outside the ROI
   int *flags_h;           // pinned
 };
 
@@ -455,6 +455,8 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
       const SweepDesc &S = p.lines.d[i];
       FwDesc &D = p.fwset.d[i];
       D.slot = S.slot; D.NM = S.NM; D.NU = S.NU; D.du = S.du; D.dx = S.dx; D.sM = S.sM; D.sU = S.sU;
+      p.fwset.pitch = p.pitch;
+      p.fwset.nrows = p.Nz * p.Ny;
       const long long want = (long long)per_wave * p.fw_blocks * 16;
       int pieces = (int)std::max<long long>(1, (want + D.NU - 1) / D.NU);
       int CL = ((D.NM + pieces - 1) / pieces + 7) & ~7;
@@ -508,10 +510,12 @@ int launch_lines(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int
 template <bool LNG, int K, bool HASPAD>
 int launch_fw_kp(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
                  int *multi) {
+  uint8_t *rowzero = nullptr;   // written by the pack kernel of this call (sweep_glcm_glrlm)
+  PRAD_TRY(k.c->get<uint8_t>("rowzero", (size_t)p.Nz * p.Ny + 64, &rowzero));
   PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_kernel<LNG, K, HASPAD>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw));
   hipLaunchKernelGGL((sweep_fw_kernel<LNG, K, HASPAD>), dim3(p.fw_blocks, p.fwset.count), dim3(1024), p.lds_fw, k.s, p.fwset,
-                     levels, Ng, Nr, p.RSfw, glcm_acc, glrlm_acc, multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE, k.flags_d);
+                     levels, (const uint8_t *)rowzero, Ng, Nr, p.RSfw, glcm_acc, glrlm_acc, multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE, k.flags_d);
   return check_launch("sweep_fw_kernel");
 }
 template <bool LNG, int K>
@@ -545,12 +549,14 @@ int launch_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int 
 
 template <bool LNG>
 int launch_pack_rows(Call &k, const SweepPlan &p, uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc) {
+  uint8_t *rowzero = nullptr;
+  PRAD_TRY(k.c->get<uint8_t>("rowzero", (size_t)p.Nz * p.Ny + 64, &rowzero));
   const long long nrows = (long long)p.Nz * p.Ny, groups = (nrows + 63) / 64;
   const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + 15) / 16, (long long)cu_count()));
   PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pack_rows_fw_kernel<LNG, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw_pr));
   hipLaunchKernelGGL((pack_rows_fw_kernel<LNG, true>), dim3(gx), dim3(1024), p.lds_fw_pr, k.s, k.image, k.mask, nrows, p.Nx,
-                     p.pitch, levels, p.row_slot, Ng, Nr, p.RSfw_pr, glcm_acc, glrlm_acc, k.flags_d);
+                     p.pitch, levels, p.row_slot, Ng, Nr, p.RSfw_pr, glcm_acc, glrlm_acc, k.flags_d, rowzero);
   return check_launch("pack_rows_fw_kernel");
 }
 
@@ -621,8 +627,13 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
     const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n / 16 + 255) / 256, 4096));
     // the fused walker reads level*4 bytes (see Walker<true, true, LONG, true>); it only exists for Ng <= 44
     const int shift = (glcm && glrlm && p.fused) ? PRAD_FUSED_SHIFT : 0;
+    uint8_t *rowzero = nullptr;
+    if (p.fw) {
+      PRAD_TRY(c.get<uint8_t>("rowzero", (size_t)nrows + 64, &rowzero));
+      PRAD_HIP(hipMemsetAsync(rowzero, 0, (size_t)nrows, k.s));
+    }
     hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, k.s, k.image, k.mask, k.g.n, p.Nx, p.pitch, p.padw,
-                       Ng, levels, k.flags_d, vec_ok, shift);
+                       Ng, levels, k.flags_d, vec_ok, shift, rowzero);
     PRAD_TRY(check_launch("pack_levels_kernel"));
   }
   if (glcm && glrlm && p.fused) PRAD_TRY((launch_sweeps<true, true, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi, packrows)));
