@@ -79,9 +79,15 @@ int prad_timing_end(void);
  * synchronous call answers by re-running on the exact generic kernels): every deferred call latches that into a sticky
  * device flag; prad_deferred_status synchronises the stream, returns PRAD_OK, or PRAD_E_DEFERRED if any deferred call
  * since the last query saw such levels (its outputs are then undefined: repeat that call synchronously), and clears
- * the flag.  Calls the sweep kernels cannot serve (voxel mode, Nd > 3, ...) run synchronously as before. */
+ * the flag.  Calls the sweep kernels cannot serve (voxel mode, Nd > 3, ...) run synchronously as before.
+ * Lanes: deferred whole-volume calls are dealt round-robin onto `n` internal streams (default 2, environment
+ * PRAD_LANES; 1 = everything stays on the caller's stream), each with its own workspace and each waiting for the work
+ * queued on the caller's stream at the time of the call, so the kernels of consecutive volumes share the GPU.  The
+ * caller's stream does NOT wait for a lane: inputs and outputs of a deferred call belong to the library until
+ * prad_deferred_status returns (it synchronises the stream and every lane). */
 #define PRAD_E_DEFERRED (-6)
 int prad_set_deferred(int on);
+int prad_set_lanes(int n);                 /* 0 = default; returns PRAD_E_ARG outside [0, 4] */
 int prad_deferred_status(void *stream);
 
 /* ---- angles: cmatrices.h get_angle_count / build_angles (cmatrices.c:756-892) ------------------- */

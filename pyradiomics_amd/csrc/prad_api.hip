@@ -141,15 +141,16 @@ int setup_call(Call &k, const int32_t *image, const uint8_t *mask, const int *si
   k.Na = Na;
   {
     int *prev = nullptr;
-    auto it = c.bufs.find(std::string("angles@") + std::to_string(c.device));
+    auto it = c.bufs.find(c.key("angles"));
     if (it != c.bufs.end()) prev = (int *)it->second.p;
     PRAD_TRY(c.get<int>("angles", (size_t)Na * Nd, &k.angles_d));
-    const bool same = prev == k.angles_d && c.angles_cached.size() == (size_t)Na * Nd &&
-                      std::equal(c.angles_cached.begin(), c.angles_cached.end(), angles);
+    std::vector<int> &cached = c.angle_cache();
+    const bool same = prev == k.angles_d && cached.size() == (size_t)Na * Nd &&
+                      std::equal(cached.begin(), cached.end(), angles);
     if (!same) {   // (a copy from pageable memory blocks the host: skip it when the table on the device is current)
       PRAD_HIP(hipMemcpyAsync(k.angles_d, angles, sizeof(int) * Na * Nd, hipMemcpyHostToDevice, s));
       PRAD_HIP(hipStreamSynchronize(s));
-      c.angles_cached.assign(angles, angles + (size_t)Na * Nd);
+      cached.assign(angles, angles + (size_t)Na * Nd);
     }
   }
   PRAD_TRY(c.get<int>("flags", 4, &k.flags_d));
@@ -684,6 +685,11 @@ int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *siz
   if (Ng < 1 || (glrlm && Nr < 1)) return fail(PRAD_E_ARG, "Ng/Nr must be >= 1");
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
+  struct LaneGuard {
+    Context &c;
+    ~LaneGuard() { c.lane = -1; }
+  } lane_guard{c};
+  if (c.deferred && !voxels) PRAD_TRY(c.lane_begin(s, &s));   // whole-volume deferred calls alternate between lanes
   Call k;
   PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, Nvox, voxels, kernelRadius, force2Ddim, s));
   PRAD_TRY(c.begin_call(s));
@@ -1387,7 +1393,7 @@ int prad_release_workspace(void) {
   }
   c.bufs.clear();
   c.pinned.clear();
-  c.angles_cached.clear();                // (the cached angle table and the deferred flag lived in the workspace)
+  for (auto &v : c.angles_cached) v.clear();   // (the cached angle tables and the deferred flag lived in the workspace)
   StageRing &r = stage_ring();
   for (int i = 0; i < kStageRing; i++) {
     r.buf[i] = nullptr;
@@ -1435,7 +1441,7 @@ double prad_timing_ms(const char *family) {
 int prad_set_deferred(int on) {
   Context &c = ctx();
   if (c.ensure_device() != PRAD_OK) return PRAD_E_HIP;
-  if (on && c.bufs.find(std::string("deferred_sticky@") + std::to_string(c.device)) == c.bufs.end()) {
+  if (on && !c.has("deferred_sticky")) {
     int *sticky = nullptr;   // first use on this device: a clean sticky flag (afterwards only the status query clears it)
     PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
     PRAD_HIP(hipMemset(sticky, 0, sizeof(int) * 16));
@@ -1443,11 +1449,20 @@ int prad_set_deferred(int on) {
   c.deferred = on != 0;
   return PRAD_OK;
 }
+int prad_set_lanes(int n) {
+  Context &c = ctx();
+  if (n < 0 || n > PRAD_MAX_LANES) return fail(PRAD_E_ARG, "lanes=%d outside [0, %d]", n, PRAD_MAX_LANES);
+  PRAD_TRY(c.lanes_sync());
+  c.lanes = n;          // 0: back to the default (PRAD_LANES or 2) at the next deferred call
+  c.lane_seq = 0;
+  return PRAD_OK;
+}
 int prad_deferred_status(void *stream) {
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
   PRAD_HIP(hipStreamSynchronize((hipStream_t)stream));
-  if (c.bufs.find(std::string("deferred_sticky@") + std::to_string(c.device)) == c.bufs.end()) return PRAD_OK;  // no deferred call yet
+  PRAD_TRY(c.lanes_sync());
+  if (!c.has("deferred_sticky")) return PRAD_OK;  // no deferred call yet
   int *sticky = nullptr;
   PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
   int h = 0;

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <map>
@@ -57,6 +58,8 @@ struct KernelTime {
   hipEvent_t a, b;
 };
 
+#define PRAD_MAX_LANES 4
+
 struct Context {
   int device = 0;
   bool device_set = false;
@@ -77,8 +80,18 @@ struct Context {
   bool timing_accumulate = false;
   std::vector<KernelTime> all_times;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> all_calls;
-  // last angle table uploaded (skips the pageable host-to-device copy when a caller repeats the same angles)
-  std::vector<int> angles_cached;
+  // last angle table uploaded (skips the pageable host-to-device copy when a caller repeats the same angles), per lane
+  std::vector<int> angles_cached[PRAD_MAX_LANES + 1];
+  // Lanes: deferred whole-volume GLCM/GLRLM calls alternate between `lanes` internal streams, each with a workspace of
+  // its own, so that the kernels of consecutive volumes share the GPU: the HBM-bound pack of one volume runs while the
+  // issue-bound sweep of the previous one holds other CUs, launch gaps and kernel tails are filled (512^3: 0.63 ->
+  // 0.56 ms per volume, 256^3: 0.167 -> 0.107).  Forcing the sweeps of the two lanes to run one after the other (only
+  // the pack underneath) measured slower (0.60 ms).  lane = -1: the caller's stream and the plain workspace.
+  int lanes = 0;       // 0 = not configured yet (PRAD_LANES, default 2; 1 = off)
+  int lane = -1;
+  unsigned long long lane_seq = 0;
+  hipStream_t lane_stream[PRAD_MAX_LANES] = {};
+  hipEvent_t lane_in[PRAD_MAX_LANES] = {};
   // GLSZM phase-1 -> phase-2 state
   long long glszm_nzones = 0;
   int glszm_nvox = 0;
@@ -99,9 +112,41 @@ struct Context {
     return PRAD_OK;
   }
 
+  // workspace key: buffers are per device and per lane, except the ones every lane shares ("deferred_*")
+  std::string key(const char *name) const {
+    std::string k(name);
+    if (lane >= 0 && k.compare(0, 9, "deferred_") != 0) k += "#" + std::to_string(lane);
+    return k + "@" + std::to_string(device);
+  }
+  bool has(const char *name) const { return bufs.find(key(name)) != bufs.end(); }
+  std::vector<int> &angle_cache() { return angles_cached[lane + 1]; }
+  int lane_begin(hipStream_t user, hipStream_t *s) {   // the next lane: its stream waits for everything queued on `user`
+    if (lanes == 0) {
+      const char *e = getenv("PRAD_LANES");
+      lanes = e ? atoi(e) : 2;
+      lanes = lanes < 1 ? 1 : (lanes > PRAD_MAX_LANES ? PRAD_MAX_LANES : lanes);
+    }
+    if (lanes == 1) return PRAD_OK;
+    const int l = (int)(lane_seq++ % (unsigned)lanes);
+    if (!lane_stream[l]) {
+      PRAD_HIP(hipStreamCreateWithFlags(&lane_stream[l], hipStreamNonBlocking));
+      PRAD_HIP(hipEventCreateWithFlags(&lane_in[l], hipEventDisableTiming));
+    }
+    PRAD_HIP(hipEventRecord(lane_in[l], user));
+    PRAD_HIP(hipStreamWaitEvent(lane_stream[l], lane_in[l], 0));
+    lane = l;
+    *s = lane_stream[l];
+    return PRAD_OK;
+  }
+  int lanes_sync() {
+    for (int l = 0; l < PRAD_MAX_LANES; l++)
+      if (lane_stream[l]) PRAD_HIP(hipStreamSynchronize(lane_stream[l]));
+    return PRAD_OK;
+  }
+
   // returns device pointer of at least `bytes` (contents undefined)
   int get(const char *name, size_t bytes, void **out) {
-    DevBuf &b = bufs[std::string(name) + "@" + std::to_string(device)];
+    DevBuf &b = bufs[key(name)];
     if (b.cap < bytes) {
       if (b.p) (void)hipFree(b.p);
       b.p = nullptr;

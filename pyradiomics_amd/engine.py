@@ -38,6 +38,9 @@ def _prep(image: torch.Tensor, mask: torch.Tensor):
     return lib, image, mask, size
 
 
+_deferred_keep: list = []
+
+
 def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None = None, force2D: bool = False,
                force2Ddimension: int = 0, want_glcm: bool = True, want_glrlm: bool = True,
                out_glcm: torch.Tensor | None = None, out_glrlm: torch.Tensor | None = None, angles=None,
@@ -67,6 +70,8 @@ def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None 
         out_glrlm = torch.empty((Ng, Nr, Na), dtype=torch.float64, device=dev)
     if deferred:
         _lib.raise_for(lib.prad_set_deferred(1), "deferred mode")
+        _deferred_keep.append((image, mask, out_glcm, out_glrlm))   # the lanes read/write these until deferred_status()
+        del _deferred_keep[:-64]
     try:
         rc = lib.prad_calculate_glcm_glrlm_dev(
             C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd, _iptr(angles), Na, int(Ng),
@@ -83,7 +88,15 @@ def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None 
 def deferred_status() -> None:
     """synchronises the current stream; raises if a deferred glcm_glrlm call since the last query saw levels outside
     [1, Ng] (its outputs are undefined: repeat that call with deferred=False)"""
-    _lib.raise_for(_lib.load().prad_deferred_status(_stream_ptr()), "deferred GLCM+GLRLM")
+    try:
+        _lib.raise_for(_lib.load().prad_deferred_status(_stream_ptr()), "deferred GLCM+GLRLM")
+    finally:
+        _deferred_keep.clear()
+
+
+def set_lanes(n: int) -> None:
+    """internal streams the deferred whole-volume calls alternate between (0 = default 2, 1 = caller's stream only)"""
+    _lib.raise_for(_lib.load().prad_set_lanes(int(n)), "lanes")
 
 
 def timing_begin() -> None:

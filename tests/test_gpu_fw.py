@@ -144,3 +144,34 @@ def test_deferred_calls_pipeline_and_report_late(cm):
     with pytest.raises(RuntimeError):
         engine.deferred_status()
     engine.deferred_status()       # the flag was cleared by the query
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 3])
+def test_deferred_lanes_agree(cm, lanes):
+    """deferred whole-volume calls alternate between the library's lanes (internal streams + workspaces): five volumes
+    of different shapes in flight, every result equal to the synchronous call; inputs produced on the caller's stream
+    right before the call (the lane has to wait for them)"""
+    import torch
+    from pyradiomics_amd import engine
+    Ng = 24
+    shapes = [(30, 40, 512), (44, 28, 256), (30, 40, 512), (25, 33, 300), (44, 28, 256)]
+    vols = [(_levels(10 + i, s, Ng, "smooth" if i % 2 else "uniform"), _mask(20 + i, s, "ball" if i % 2 else "full"))
+            for i, s in enumerate(shapes)]
+    want = []
+    for i, m in vols:
+        g, r, _ = engine.glcm_glrlm(torch.from_numpy(i).cuda(), torch.from_numpy(m.astype(np.uint8)).cuda(), Ng, 512)
+        want.append((g.clone(), r.clone()))
+    engine.set_lanes(lanes)
+    try:
+        got = []
+        for i, m in vols:
+            di = torch.from_numpy(i).cuda(non_blocking=True) + 0      # (a kernel on the caller's stream feeds the call)
+            dm = torch.from_numpy(m.astype(np.uint8)).cuda(non_blocking=True)
+            got.append(engine.glcm_glrlm(di, dm, Ng, 512, deferred=True))
+        engine.deferred_status()
+        for (g, r, _), (eg, er) in zip(got, want):
+            assert torch.equal(g, eg) and torch.equal(r, er)
+    finally:
+        engine.set_lanes(0)
+    with pytest.raises(ValueError):
+        engine.set_lanes(9)
