@@ -153,6 +153,28 @@ __global__ void __launch_bounds__(1024) fo_hist_kernel(const T *__restrict__ img
   for (int k = threadIdx.x; k < PRAD_FO_BINS; k += blockDim.x)
     if (h[k]) atomicAdd(hist + k, h[k]);
 }
+// Integer images (int16 / int32: CT, MR, level images) whose value range fits the LDS: the EXACT histogram of the ROI,
+// count of every value base .. base + R - 1.  Every first-order statistic is a function of it (sums over values
+// weighted by counts, order statistics from the cumulative counts), so this pass replaces hist + gather + sort +
+// central + band (four more reads of the volume).
+#define PRAD_FO_EXACT_MAX 32768
+template <typename T>
+__global__ void __launch_bounds__(1024) fo_exact_hist_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                             long long n, double base, int R,
+                                                             unsigned *__restrict__ hist) {
+  extern __shared__ unsigned fo_h[];
+  for (int k = threadIdx.x; k < R; k += blockDim.x) fo_h[k] = 0u;
+  __syncthreads();
+  fo_scan(img, mask, 0, n, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x,
+          [&](double x) {
+            const int k = (int)(x - base);        // exact: integers below 2^31
+            if ((unsigned)k < (unsigned)R) atomicAdd(&fo_h[k], 1u);
+          });
+  __syncthreads();
+  for (int k = threadIdx.x; k < R; k += blockDim.x)
+    if (fo_h[k]) atomicAdd(hist + k, fo_h[k]);
+}
+
 struct FoSel {
   int nsel;
   int bin[PRAD_FO_MAXSEL];        // ascending

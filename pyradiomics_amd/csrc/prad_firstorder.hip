@@ -101,6 +101,90 @@ extern "C" int prad_firstorder_dev(const void *image, int dtype, const uint8_t *
   }
   os[10] = vmin;
   os[11] = vmax;
+  // ---- integer images with a value range that fits the LDS: everything from the exact histogram -------------------
+  const bool exact_off = getenv("PRAD_FO_NO_EXACT") != nullptr;   // (tests: the selection route on integer images)
+  if (!exact_off && (dtype == 2 || dtype == 3) && vmax - vmin < (double)PRAD_FO_EXACT_MAX && m >= (1LL << 16)) {
+    const int R = (int)(vmax - vmin) + 1;
+    unsigned *hist = nullptr;
+    PRAD_TRY(c.get<unsigned>("fo_exact_hist", PRAD_FO_EXACT_MAX, &hist));
+    void *hp = nullptr;
+    PRAD_TRY(c.get_pinned("fo_exact_hist_h", sizeof(unsigned) * PRAD_FO_EXACT_MAX, &hp));
+    const unsigned *H = (const unsigned *)hp;
+    PRAD_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned) * R, s));
+    {
+      Timed t(c, "firstorder", s);
+      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 8191) / 8192, 512));
+      const size_t lds = sizeof(unsigned) * (size_t)R;
+      switch (dtype) {
+        case 2:
+          PRAD_HIP(hipFuncSetAttribute((const void *)fo_exact_hist_kernel<int>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(fo_exact_hist_kernel<int>, dim3(gx), dim3(1024), lds, s, (const int *)image, mask, n, vmin, R, hist);
+          break;
+        default:
+          PRAD_HIP(hipFuncSetAttribute((const void *)fo_exact_hist_kernel<short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL(fo_exact_hist_kernel<short>, dim3(gx), dim3(1024), lds, s, (const short *)image, mask, n, vmin, R, hist);
+          break;
+      }
+      PRAD_TRY(check_launch("fo_exact_hist_kernel"));
+    }
+    PRAD_HIP(hipMemcpyAsync(hp, hist, sizeof(unsigned) * R, hipMemcpyDeviceToHost, s));
+    PRAD_HIP(hipStreamSynchronize(s));
+    // order statistics from the cumulative counts (ranks ascend)
+    {
+      long long below = 0;
+      int k = 0;
+      for (int b = 0; b < R && k < 10; b++) {
+        below += H[b];
+        while (k < 10 && ranks[k] < below) os[k++] = vmin + (double)b;
+      }
+      if (k < 10) return fail(PRAD_E_HIP, "firstorder: exact histogram does not cover the ROI (internal error)");
+    }
+    double pq[5];
+    for (int k = 0; k < 5; k++) pq[k] = lerp_np(os[2 * k], os[2 * k + 1], qp[k].gamma);
+    const double median = (m % 2) ? os[4] : (os[4] + os[5]) / 2.0;
+    // sums over the distinct values, ascending, in extended precision (the reference sums the raw voxels pairwise)
+    long double a1 = 0, a2 = 0, a3 = 0, a4 = 0, bc = 0, bs = 0;
+    for (int b = 0; b < R; b++) {
+      if (!H[b]) continue;
+      const long double w = (long double)H[b], x = (long double)(vmin + (double)b), d = x - (long double)mu, d2 = d * d;
+      a1 += w * fabsl(d);
+      a2 += w * d2;
+      a3 += w * d2 * d;
+      a4 += w * d2 * d2;
+      if ((double)x >= pq[0] && (double)x <= pq[4]) {
+        bc += w;
+        bs += w * x;
+      }
+    }
+    double rmad = NAN;
+    if (bc > 0) {
+      const long double mub = bs / bc;
+      long double band = 0;
+      for (int b = 0; b < R; b++) {
+        const double x = vmin + (double)b;
+        if (H[b] && x >= pq[0] && x <= pq[4]) band += (long double)H[b] * fabsl((long double)x - mub);
+      }
+      rmad = (double)(band / bc);
+    }
+    const double dm = (double)m;
+    out[PRAD_FO_NP] = dm;
+    out[PRAD_FO_ENERGY] = sums[1];
+    out[PRAD_FO_MINIMUM] = os[10];
+    out[PRAD_FO_P10] = pq[0];
+    out[PRAD_FO_P25] = pq[1];
+    out[PRAD_FO_MEDIAN] = median;
+    out[PRAD_FO_P75] = pq[3];
+    out[PRAD_FO_P90] = pq[4];
+    out[PRAD_FO_MAXIMUM] = os[11];
+    out[PRAD_FO_MEAN] = mu;
+    out[PRAD_FO_MAD] = (double)(a1 / dm);
+    out[PRAD_FO_RMAD] = rmad;
+    out[PRAD_FO_M2] = (double)(a2 / dm);
+    out[PRAD_FO_M3] = (double)(a3 / dm);
+    out[PRAD_FO_M4] = (double)(a4 / dm);
+    c.last_path = "firstorder-exact";
+    return PRAD_OK;
+  }
   bool selected = false;
   static const long long select_from = getenv("PRAD_FO_SELECT_MIN") ? atoll(getenv("PRAD_FO_SELECT_MIN")) : (1LL << 20);
   if (m >= select_from && vmax > vmin && isfinite(vmin) && isfinite(vmax)) {

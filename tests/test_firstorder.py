@@ -63,9 +63,11 @@ def _compare_stats(got, want):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["float64", "float32", "int16", "ties51", "ties2", "outlier"])
-def test_large_roi_order_statistics_by_selection(kind):
+def test_large_roi_order_statistics_by_selection(kind, monkeypatch):
     """ROIs above 2^20 voxels take the histogram-selection route (no full sort): order statistics must still be the
-    exact elements numpy picks, with ties, with an outlier stretching the bin range, for every input dtype"""
+    exact elements numpy picks, with ties, with an outlier stretching the bin range, for every input dtype.  Integer
+    images with a value range below 32768 take the exact-histogram route instead (one pass after the min / max
+    reduction); both routes are checked on them."""
     from oracle import firstorder_oracle
     from pyradiomics_amd import _lib, cmatrices
     shape = (128, 128, 130)
@@ -80,14 +82,20 @@ def test_large_roi_order_statistics_by_selection(kind):
         img, mask = rng.standard_normal(shape) + 50.0, rng.random(shape) < 0.8
         img[3, 4, 5] = 1e9                      # nearly everything falls into the first bin: it is gathered whole
         mask[3, 4, 5] = True
+    integer = kind in ("int16", "ties51", "ties2")
     for shift in (0.0, 1000.0):
         got = cmatrices.firstorder_stats(img, mask, shift)
-        assert _lib.last_path() == "firstorder-select"
+        assert _lib.last_path() == ("firstorder-exact" if integer else "firstorder-select")
         _compare_stats(got, firstorder_oracle.firstorder_stats(img, mask, shift))
+    if integer:
+        monkeypatch.setenv("PRAD_FO_NO_EXACT", "1")
+        got = cmatrices.firstorder_stats(img, mask, 0.0)
+        assert _lib.last_path() == "firstorder-select"
+        _compare_stats(got, firstorder_oracle.firstorder_stats(img, mask, 0.0))
 
 
 @pytest.mark.gpu
-def test_large_roi_heavy_ties_and_fallback_to_the_sort():
+def test_large_roi_heavy_ties_and_fallback_to_the_sort(monkeypatch):
     from oracle import firstorder_oracle
     from pyradiomics_amd import _lib, cmatrices
     shape = (160, 160, 172)                                   # 4.4 M voxels
@@ -95,14 +103,31 @@ def test_large_roi_heavy_ties_and_fallback_to_the_sort():
     mask = np.ones(shape, bool)
     # two distinct values: the selected bins exceed the gather budget but each holds ONE value -> no gather, no sort
     img = (rng.random(shape) < 0.5).astype(np.int16) * 100
-    got = cmatrices.firstorder_stats(img, mask, 0.0)
+    for env, path in ((None, "firstorder-exact"), ("1", "firstorder-select")):
+        if env:
+            monkeypatch.setenv("PRAD_FO_NO_EXACT", env)
+        got = cmatrices.firstorder_stats(img, mask, 0.0)
+        assert _lib.last_path() == path
+        _compare_stats(got, firstorder_oracle.firstorder_stats(img, mask, 0.0))
+        # a discretised image (32 levels), the case of the level volumes of the texture classes
+        lev = rng.integers(1, 33, shape).astype(np.int32)
+        got = cmatrices.firstorder_stats(lev, mask, 0.0)
+        assert _lib.last_path() == path
+        _compare_stats(got, firstorder_oracle.firstorder_stats(lev, mask, 0.0))
+    monkeypatch.delenv("PRAD_FO_NO_EXACT")
+    # integers spread over more than 32768 values: back to the selection route
+    wide = rng.integers(-40000, 40000, shape).astype(np.int32)
+    got = cmatrices.firstorder_stats(wide, mask, 0.0)
     assert _lib.last_path() == "firstorder-select"
-    _compare_stats(got, firstorder_oracle.firstorder_stats(img, mask, 0.0))
-    # a discretised image (32 levels), the case of the level volumes of the texture classes
-    img = rng.integers(1, 33, shape).astype(np.int32)
-    got = cmatrices.firstorder_stats(img, mask, 0.0)
-    assert _lib.last_path() == "firstorder-select"
-    _compare_stats(got, firstorder_oracle.firstorder_stats(img, mask, 0.0))
+    _compare_stats(got, firstorder_oracle.firstorder_stats(wide, mask, 0.0))
+    # the widest range the exact route takes (32768 distinct values), partial mask
+    edge = rng.integers(-20000, 12768, shape).astype(np.int16)
+    edge[0, 0, 0], edge[0, 0, 1] = -20000, 12767
+    pm = rng.random(shape) < 0.6
+    pm[0, 0, :2] = True
+    got = cmatrices.firstorder_stats(edge, pm, 7.0)
+    assert _lib.last_path() == "firstorder-exact"
+    _compare_stats(got, firstorder_oracle.firstorder_stats(edge, pm, 7.0))
     # an outlier stretches the bin range: nearly the whole ROI shares bin 0 with many distinct values -> full sort
     img = rng.standard_normal(shape) + 50.0
     img[1, 2, 3] = 1e9
