@@ -11,6 +11,7 @@
 //   log_accumulate_kernel  Laplacian accumulation  acc += d2 / spacing^2
 // Arithmetic of both filters lives in third-party wheels absent from the reference tree: parity unpinned.
 #pragma once
+#include <type_traits>
 #include "prad_runtime.h"
 
 namespace prad {
@@ -69,6 +70,10 @@ __device__ __forceinline__ void rg_store(float *__restrict__ o, float *__restric
 // A lane walks its line serially, so memory parallelism has to come from the lane itself: samples are fetched in
 // batches of PRAD_RG_B independent loads ahead of the recursion that consumes them.
 #define PRAD_RG_B 8
+// ACCLOAD: the pass accumulates into an image that already holds earlier terms (acc != nullptr, first == 0); a template
+// parameter because a load behind a run-time condition gets its own `s_waitcnt vmcnt(0)` (every step of the
+// derivative passes then waited for its accumulator load alone: 205 us instead of 94)
+template <bool ACCLOAD>
 __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restrict__ in, long long outer, int ln,
                                                           long long inner, RGaussCoef c,
                                                           double *__restrict__ scratch, float *__restrict__ out,
@@ -141,18 +146,26 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
     double q0 = a4, q1 = a3, q2 = a2, q3 = a1;                              // scratch[i], [i+1], [i+2], [i+3]
     int i = ln - 4;
     for (; i - PRAD_RG_B >= 0; i -= PRAD_RG_B) {      // produces samples i-1 .. i-B
-      float buf[PRAD_RG_B];
+      float buf[PRAD_RG_B], ab[PRAD_RG_B];
       double sb[PRAD_RG_B];
 #pragma unroll
       for (int k = 0; k < PRAD_RG_B; k++) {
         buf[k] = d[(long long)(i - 1 - k) * st];
         sb[k] = s[(long long)(i - 1 - k) * st];
+        // (the accumulator too: a load right before its store, one per step, left the derivative passes at 205 us
+        // against 94 us for the smoothing ones -- the compiler keeps it behind the previous step's store)
+        ab[k] = ACCLOAD ? acc[base + (long long)(i - 1 - k) * st] : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < PRAD_RG_B; k++) {
         double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
         v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
-        rg_store(out, acc, base + (long long)(i - 1 - k) * st, sb[k] + v, sp2, first);
+        {
+          const long long idx = base + (long long)(i - 1 - k) * st;
+          const float f = (float)(sb[k] + v);
+          if (acc) acc[idx] = (float)((double)ab[k] + (double)f / sp2);     // = rg_store
+          else out[idx] = f;
+        }
         dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = buf[k];
         q3 = q2; q2 = q1; q1 = q0; q0 = v;
       }
@@ -272,6 +285,192 @@ __global__ void __launch_bounds__(64) rgauss_xline_kernel(const float *__restric
       if (tt < nl && cc < w) rg_store(out, acc, (l0 + tt) * ln + b + cc, tsc[tt][cc], sp2, first);
     }
   }
+}
+
+// The same pass with the line cut in two and both directions of the recursion in flight: a 256^3 volume has 65 536
+// lines = 1 024 waves of 64 lines, one per SIMD of the GPU, each alternating load / recurse / store with nothing to
+// hide the latencies behind (290 us per pass, against 125 us for the strided axes).  Here a workgroup is two waves on
+// the same 64 lines.  Phase 1: the forward wave runs the causal recursion over [0, m), the backward wave the
+// anti-causal one over [m, ln); each leaves its float64 partial in `scratch`.  Phase 2: each continues into the other
+// half, adds its value to the partial stored there (causal + anti-causal, the same sum in either order) and stores the
+// result.  Twice the waves, half the dependent chain, the same traffic; the next tile is fetched into registers while
+// the current one is recursed.  Waves only share LDS with themselves (no workgroup barrier but the one between the
+// phases).
+// AM: 0 = plain float output, 1 = first Laplacian term (acc = v / sp2), 2 = later term (acc += v / sp2).  The phase
+// (partial into scratch / final) and AM are compile-time in every loop: with run-time flags the tile loop was a maze
+// of branches, each load group followed by its own wait.
+template <int W, int AM>
+__global__ void __launch_bounds__(128) rgauss_xline2_kernel(const float *__restrict__ in, long long lines, int ln,
+                                                            RGaussCoef c, double *scratch, float *__restrict__ out,
+                                                            float *__restrict__ acc, double sp2) {
+#pragma clang fp contract(off)
+  constexpr int RPI = 64 / W;            // rows of W samples per wave instruction
+  __shared__ float tin_[2][PRAD_RG_T][W + 1];
+  __shared__ double tsc_[2][PRAD_RG_T][W + 1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float(*tin)[W + 1] = tin_[wave];
+  double(*tsc)[W + 1] = tsc_[wave];
+  const long long l0 = (long long)blockIdx.x * PRAD_RG_T;
+  const int nl = (int)min((long long)PRAD_RG_T, lines - l0);
+  const bool mine = lane < nl;
+  const int m = (((ln + W - 1) / W) / 2) * W;      // the split (4 <= m <= ln - 4: the caller guarantees ln >= 2 W)
+  const int rr = lane / W, cc = lane % W;
+  // global index of this lane's k-th element of the tile at column c0 (clamped: loads are never conditional)
+  auto gidx = [&](int k, int c0, int w) __attribute__((always_inline)) -> long long {
+    return (l0 + min(k * RPI + rr, nl - 1)) * ln + c0 + min(cc, w - 1);
+  };
+  // (macros, not lambdas taking the arrays by reference: those left all four arrays in scratch memory)
+#define PRAD_XL_FETCH(PF, PS, C0, WW)                                                                     \
+  {                                                                                                       \
+    const int c0_ = (C0), w_ = (WW);                                                                      \
+    _Pragma("unroll") for (int k = 0; k < W; k++) PF[k] = in[gidx(k, c0_, w_)];                          \
+    if (FIN) {                                                                                            \
+      _Pragma("unroll") for (int k = 0; k < W; k++)                                                       \
+          PS[k] = __hip_atomic_load(scratch + gidx(k, c0_, w_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    }                                                                                                     \
+  }
+#define PRAD_XL_COMMIT(PF, PS)                                                                            \
+  {                                                                                                       \
+    _Pragma("unroll") for (int k = 0; k < W; k++) {                                                       \
+      tin[k * RPI + rr][cc] = PF[k];                                                                      \
+      if (FIN) tsc[k * RPI + rr][cc] = PS[k];                                                             \
+    }                                                                                                     \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                \
+    __builtin_amdgcn_wave_barrier();                                                                      \
+  }
+  auto put = [&](auto fin_tag, int c0, int w) __attribute__((always_inline)) {     // tile results (tsc) -> scratch / the output image, coalesced
+    constexpr bool FIN = decltype(fin_tag)::value;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float ab[W];
+    if (FIN && AM == 2) {              // all accumulator loads first
+#pragma unroll
+      for (int k = 0; k < W; k++) ab[k] = acc[gidx(k, c0, w)];
+    }
+#pragma unroll
+    for (int k = 0; k < W; k++) {
+      const int tt = k * RPI + rr;
+      if (tt < nl && cc < w) {
+        const long long idx = (l0 + tt) * ln + c0 + cc;
+        if (FIN) {
+          const float f = (float)tsc[tt][cc];
+          if (AM == 0) out[idx] = f;
+          else acc[idx] = (float)((AM == 2 ? (double)ab[k] : 0.0) + (double)f / sp2);   // = rg_store
+        } else {
+          scratch[idx] = tsc[tt][cc];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  double t1 = 0, t2 = 0, t3 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0;   // recursion state: 3 (4) data samples, 4 outputs
+  auto forward = [&](auto fin_tag, int r0, int r1) __attribute__((always_inline)) {
+    constexpr bool FIN = decltype(fin_tag)::value;
+    float pfA[W], pfB[W];      // two tiles in flight ahead of the recursion (a 256^3 volume only has 2 048 such waves:
+    double psA[W], psB[W];     // one tile each left ~4 MB in flight on the whole GPU, 178 us per pass)
+    PRAD_XL_FETCH(pfA, psA, r0, min(W, r1 - r0));
+    if (r0 + W < r1) PRAD_XL_FETCH(pfB, psB, r0 + W, min(W, r1 - r0 - W));
+    int par = 0;
+    for (int c0 = r0; c0 < r1; c0 += W, par ^= 1) {
+      const int w = min(W, r1 - c0);
+      if (par == 0) {
+        PRAD_XL_COMMIT(pfA, psA);
+        if (c0 + 2 * W < r1) PRAD_XL_FETCH(pfA, psA, c0 + 2 * W, min(W, r1 - c0 - 2 * W));
+      } else {
+        PRAD_XL_COMMIT(pfB, psB);
+        if (c0 + 2 * W < r1) PRAD_XL_FETCH(pfB, psB, c0 + 2 * W, min(W, r1 - c0 - 2 * W));
+      }
+#ifndef PRAD_DBG_XL_NOCOMPUTE
+      if (mine) {
+        int j = 0;
+        if (c0 == 0) {
+          const double v1 = tin[lane][0];
+          const double x1 = tin[lane][1], x2 = tin[lane][2], x3 = tin[lane][3];
+          double s0 = v1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+          double s1 = x1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+          double s2 = x2 * c.N0 + x1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+          double s3 = x3 * c.N0 + x2 * c.N1 + x1 * c.N2 + v1 * c.N3;
+          s0 -= v1 * c.BN1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
+          s1 -= s0 * c.D1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
+          s2 -= s1 * c.D1 + s0 * c.D2 + v1 * c.BN3 + v1 * c.BN4;
+          s3 -= s2 * c.D1 + s1 * c.D2 + s0 * c.D3 + v1 * c.BN4;
+          tsc[lane][0] = s0; tsc[lane][1] = s1; tsc[lane][2] = s2; tsc[lane][3] = s3;   // (c0 == 0 is never final)
+          t1 = x3; t2 = x2; t3 = x1;
+          u1 = s3; u2 = s2; u3 = s1; u4 = s0;
+          j = 4;
+        }
+        for (; j < w; j++) {
+          const double di = tin[lane][j];
+          double v = di * c.N0 + t1 * c.N1 + t2 * c.N2 + t3 * c.N3;
+          v -= u1 * c.D1 + u2 * c.D2 + u3 * c.D3 + u4 * c.D4;
+          tsc[lane][j] = FIN ? v + tsc[lane][j] : v;
+          t3 = t2; t2 = t1; t1 = di;
+          u4 = u3; u3 = u2; u2 = u1; u1 = v;
+        }
+      }
+#endif
+      put(fin_tag, c0, w);
+    }
+  };
+  double t0 = 0;   // (backward: t0..t3 = data[i], [i+1], [i+2], [i+3]; u1..u4 = outputs [i], [i+1], [i+2], [i+3])
+  auto backward = [&](auto fin_tag, int r0, int r1) __attribute__((always_inline)) {
+    constexpr bool FIN = decltype(fin_tag)::value;
+    float pfA[W], pfB[W];      // two tiles in flight ahead of the recursion (a 256^3 volume only has 2 048 such waves:
+    double psA[W], psB[W];     // one tile each left ~4 MB in flight on the whole GPU, 178 us per pass)
+    auto tile_b = [&](int e) { return max(e - W, r0); };       // tile [tile_b(e), e)
+    PRAD_XL_FETCH(pfA, psA, tile_b(r1), r1 - tile_b(r1));
+    if (tile_b(r1) > r0) PRAD_XL_FETCH(pfB, psB, tile_b(r1 - W), r1 - W - tile_b(r1 - W));
+    int par = 0;
+    for (int e = r1; e > r0; e -= W, par ^= 1) {
+      const int b = tile_b(e), w = e - b;
+      const int e2 = e - 2 * W;                                 // end of the tile after next
+      if (par == 0) {
+        PRAD_XL_COMMIT(pfA, psA);
+        if (e2 > r0) PRAD_XL_FETCH(pfA, psA, tile_b(e2), e2 - tile_b(e2));
+      } else {
+        PRAD_XL_COMMIT(pfB, psB);
+        if (e2 > r0) PRAD_XL_FETCH(pfB, psB, tile_b(e2), e2 - tile_b(e2));
+      }
+#ifndef PRAD_DBG_XL_NOCOMPUTE
+      if (mine) {
+        int j = w - 1;
+        if (e == ln) {
+          const double v2 = tin[lane][w - 1], y1 = tin[lane][w - 2], y2 = tin[lane][w - 3];
+          double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+          double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+          double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+          double a4 = y2 * c.M1 + y1 * c.M2 + v2 * c.M3 + v2 * c.M4;
+          a1 -= v2 * c.BM1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+          a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+          a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
+          a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
+          tsc[lane][w - 1] = a1; tsc[lane][w - 2] = a2; tsc[lane][w - 3] = a3; tsc[lane][w - 4] = a4;   // (never final)
+          t0 = tin[lane][w - 4]; t1 = y2; t2 = y1; t3 = v2;
+          u1 = a4; u2 = a3; u3 = a2; u4 = a1;
+          j = w - 5;
+        }
+        for (; j >= 0; j--) {
+          double v = t0 * c.M1 + t1 * c.M2 + t2 * c.M3 + t3 * c.M4;
+          v -= u1 * c.D1 + u2 * c.D2 + u3 * c.D3 + u4 * c.D4;
+          t3 = t2; t2 = t1; t1 = t0; t0 = tin[lane][j];
+          tsc[lane][j] = FIN ? tsc[lane][j] + v : v;
+          u4 = u3; u3 = u2; u2 = u1; u1 = v;
+        }
+      }
+#endif
+      put(fin_tag, b, w);
+    }
+  };
+  using No = std::integral_constant<bool, false>;
+  using Yes = std::integral_constant<bool, true>;
+  if (wave == 0) forward(No{}, 0, m);
+  else backward(No{}, m, ln);
+  __threadfence();
+  __syncthreads();
+  if (wave == 0) forward(Yes{}, m, ln);
+  else backward(Yes{}, 0, m);
+#undef PRAD_XL_FETCH
+#undef PRAD_XL_COMMIT
 }
 
 }  // namespace prad

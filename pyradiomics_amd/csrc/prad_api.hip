@@ -1301,13 +1301,27 @@ int log_dev(const float *in, const int *size, int Nd, const double *spacing, dou
         float *dst = forced_dst ? forced_dst : pp[flip];
         float *acc = accumulate ? out : nullptr;
         const double sp2 = spacing[ax] * spacing[ax];
-        if (inner == 1 && g.size[ax] >= 8) {      // contiguous axis: LDS-tiled walk (see kernels_filters.h; a lane-per-line walk of this axis measured 343 us instead of 294 at 256^3)
+        const bool accload = acc != nullptr && !first;
+        if (inner == 1 && g.size[ax] >= 64 && !getenv("PRAD_LOG_NO_SPLIT")) {   // contiguous axis, two waves per 64 lines (kernels_filters.h)
+          const unsigned gx = (unsigned)((lines + PRAD_RG_T - 1) / PRAD_RG_T);
+#define PRAD_XL2(W, AM) hipLaunchKernelGGL((rgauss_xline2_kernel<W, AM>), dim3(gx), dim3(128), 0, s, cur, lines, g.size[ax], k, scratch, dst, acc, sp2)
+#define PRAD_XL2W(W) do { if (!acc) PRAD_XL2(W, 0); else if (first) PRAD_XL2(W, 1); else PRAD_XL2(W, 2); } while (0)
+          if (lines <= (1 << 17) && !getenv("PRAD_LOG_W32")) PRAD_XL2W(16);
+          else PRAD_XL2W(32);
+#undef PRAD_XL2W
+#undef PRAD_XL2
+          PRAD_TRY(check_launch("rgauss_xline2_kernel"));
+        } else if (inner == 1 && g.size[ax] >= 8) {      // contiguous axis: LDS-tiled walk (see kernels_filters.h; a lane-per-line walk of this axis measured 343 us instead of 294 at 256^3)
           hipLaunchKernelGGL(rgauss_xline_kernel, dim3((unsigned)((lines + PRAD_RG_T - 1) / PRAD_RG_T)), dim3(64), 0, s, cur,
                              lines, g.size[ax], k, scratch, dst, acc, sp2, first ? 1 : 0);
           PRAD_TRY(check_launch("rgauss_xline_kernel"));
         } else {
-          hipLaunchKernelGGL(rgauss_line_kernel, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, cur, outer,
-                             g.size[ax], inner, k, scratch, dst, acc, sp2, first ? 1 : 0);
+          if (accload)
+            hipLaunchKernelGGL(rgauss_line_kernel<true>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, cur, outer,
+                               g.size[ax], inner, k, scratch, dst, acc, sp2, 0);
+          else
+            hipLaunchKernelGGL(rgauss_line_kernel<false>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, cur, outer,
+                               g.size[ax], inner, k, scratch, dst, acc, sp2, first ? 1 : 0);
           PRAD_TRY(check_launch("rgauss_line_kernel"));
         }
         cur = dst;
