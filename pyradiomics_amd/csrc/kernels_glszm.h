@@ -43,6 +43,8 @@ struct GlszmState {
   const int32_t *image = nullptr;  // segment mode: levels are read from the image at fill time
   int *labels = nullptr;           // segment: [n] root label or -1
   unsigned *sizes = nullptr;       // segment: [n] zone size at root index
+  int *rootlist = nullptr;         // segment, byte path: tile roots (glszm_tile8_kernel); rootctl[0] entries, valid
+  int *rootctl = nullptr;          //   while rootctl[1] == 0 (nullptr: the consumers scan the label volume)
   int *zones = nullptr;            // voxel: [boxmax][2][nvox] (level,size) interleaved by kernel
   int *zone_count = nullptr;       // voxel: [nvox]
 };
@@ -151,6 +153,7 @@ __global__ void __launch_bounds__(256) glszm_merge_kernel(Geo g, const int *__re
 #endif
 #define PRAD_TX 64
 #define PRAD_TVOX (PRAD_TZ * PRAD_TY * PRAD_TX)
+#define PRAD_GZ_TILE_ROOTS 1024    // roots per tile the tile-root list takes (glszm_tile8_kernel)
 struct Offsets3 {
   int na;
   signed char o[32][4];   // backward neighbours only (linear offset < 0), embedded in 3-D
@@ -454,7 +457,8 @@ __device__ __forceinline__ unsigned t8_select(unsigned S) {
 template <int MODE>
 __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx,
                                                           int *__restrict__ labels, unsigned *__restrict__ sizes,
-                                                          int *__restrict__ flags) {
+                                                          int *__restrict__ flags, int *__restrict__ rootlist,
+                                                          int *__restrict__ rootctl) {
   __shared__ unsigned lev[PRAD_T8_DW];
   __shared__ int lab[PRAD_TVOX];
   if (flags[0]) return;   // a masked level outside 1..Ng: the int32 kernels redo this call
@@ -583,6 +587,34 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
     } else {
       for (int k = 0; k < 4; k++)
         if (x + k < Nx) { labels[gi + k] = lb[k]; sizes[gi + k] = sz[k]; }
+    }
+  }
+  // The tile roots of the volume as a list (rootlist, rootctl[0] entries): what comes after the unions -- folding the
+  // tile counts into the zone roots, zone statistics, the fill -- only concerns them, ~1 M entries on a structured
+  // 512^3 volume against 134 M voxels to scan.  A tile with more than PRAD_GZ_TILE_ROOTS roots (noise) gives up and
+  // raises rootctl[1]: the consumers then scan the label volume as before.
+  __shared__ int lcount, lbase;
+  if (threadIdx.x == 0) lcount = 0;
+  __syncthreads();
+  int mypos = nroots ? atomicAdd(&lcount, nroots) : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lbase = -1;
+    if (lcount > PRAD_GZ_TILE_ROOTS) atomicOr(rootctl + 1, 1);
+    else if (lcount > 0) lbase = atomicAdd(rootctl, lcount);
+  }
+  __syncthreads();
+  if (lbase >= 0 && nroots) {
+#pragma unroll
+    for (int q = 0; q < QPT; q++) {
+      const int quad = threadIdx.x + q * 256;
+      const int lx4 = quad & 15, ly = (quad >> 4) % PRAD_TY, lz = quad / (16 * PRAD_TY);
+      const int z = z0 + lz, y = y0 + ly, x = x0 + 4 * lx4;
+      if (z >= Nz || y >= Ny || x >= Nx) continue;
+      const long long gi = ((long long)z * Ny + y) * Nx + x;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (root[q][k] == quad * 4 + k) rootlist[lbase + mypos++] = (int)(gi + k);
     }
   }
   if ((blockIdx.x & 63) == 0) {   // a sample of the tiles is enough (one atomic per wave of EVERY tile cost 0.6 - 1 ms)
@@ -977,17 +1009,26 @@ __global__ void __launch_bounds__(256) glszm_border8s_kernel(const uint8_t *__re
 #endif
 __global__ void __launch_bounds__(256) glszm_rootsum_kernel(long long n, int *__restrict__ labels,
                                                             unsigned *__restrict__ sizes,
-                                                            const int *__restrict__ flags) {
+                                                            const int *__restrict__ flags,
+                                                            const int *__restrict__ rootlist,
+                                                            const int *__restrict__ rootctl) {
   __shared__ int hkey[PRAD_RS_SLOTS];
   __shared__ unsigned hval[PRAD_RS_SLOTS];
   if (flags && flags[0]) return;   // the packed-byte kernels did not run: labels are not valid
+  const bool listmode = rootctl && rootctl[1] == 0;
+  const long long total = listmode ? (long long)rootctl[0] : n;
+  // (list mode: the entries are spread over the whole grid, 1024 or more per block -- slabs of PRAD_RS_CHUNK would
+  // leave a 256^3 volume with 37 busy workgroups)
+  const long long per = listmode ? max(1024LL, (total + gridDim.x - 1) / gridDim.x) : (long long)PRAD_RS_CHUNK;
+  const long long lo = (long long)blockIdx.x * per, hi = min(total, lo + per);
+  if (lo >= hi) return;
   for (int k = threadIdx.x; k < PRAD_RS_SLOTS; k += blockDim.x) {
     hkey[k] = -1;
     hval[k] = 0u;
   }
   __syncthreads();
-  const long long lo = (long long)blockIdx.x * PRAD_RS_CHUNK, hi = min(n, lo + PRAD_RS_CHUNK);
-  for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+  for (long long j = lo + threadIdx.x; j < hi; j += blockDim.x) {
+    const long long i = listmode ? (long long)rootlist[j] : j;
     const unsigned sz = sizes[i];
     if (sz == 0u) continue;
     const int l = labels[i];
@@ -1010,8 +1051,6 @@ __global__ void __launch_bounds__(256) glszm_rootsum_kernel(long long n, int *__
     if (hkey[k] >= 0 && hval[k]) atomicAdd(sizes + hkey[k], hval[k]);
 }
 
-// label[i] = root(i) and size[root] += 1.  x-adjacent voxels usually share a root, so each wave first collapses
-// runs of equal roots among its lanes and issues one atomic per run instead of one per voxel.
 __global__ void __launch_bounds__(256) glszm_flatten_count_kernel(long long n, int *__restrict__ labels,
                                                                    unsigned *__restrict__ sizes) {
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -1050,7 +1089,9 @@ __global__ void __launch_bounds__(256) glszm_stats_kernel(long long n, const int
                                                           unsigned long long *__restrict__ stats64,
                                                           unsigned *__restrict__ small_bits, int *__restrict__ large_list,
                                                           int large_cap, int *__restrict__ large_count,
-                                                          const int *__restrict__ flags) {
+                                                          const int *__restrict__ flags,
+                                                          const int *__restrict__ rootlist = nullptr,
+                                                          const int *__restrict__ rootctl = nullptr) {
   __shared__ unsigned bits[PRAD_SMALL_SIZES / 32];
   __shared__ unsigned smx;
   __shared__ unsigned long long scnt;
@@ -1073,19 +1114,27 @@ __global__ void __launch_bounds__(256) glszm_stats_kernel(long long n, const int
       if (pos < large_cap) large_list[pos] = (int)sz;
     }
   };
-  // the scan is a stream over the labels: 16 B per lane and load
-  const long long n4 = n >> 2;
-  const int4 *lab4 = reinterpret_cast<const int4 *>(labels);
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
-    const int4 l = lab4[q];
-    const long long i = q << 2;
-    if (l.x == (int)i) root(i);
-    if (l.y == (int)i + 1) root(i + 1);
-    if (l.z == (int)i + 2) root(i + 2);
-    if (l.w == (int)i + 3) root(i + 3);
+  if (rootctl && rootctl[1] == 0) {      // the tile-root list: a zone root is a tile root that kept its label
+    const long long m = rootctl[0];
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+      const int i = rootlist[j];
+      if (labels[i] == i) root(i);
+    }
+  } else {
+    // the scan is a stream over the labels: 16 B per lane and load
+    const long long n4 = n >> 2;
+    const int4 *lab4 = reinterpret_cast<const int4 *>(labels);
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+      const int4 l = lab4[q];
+      const long long i = q << 2;
+      if (l.x == (int)i) root(i);
+      if (l.y == (int)i + 1) root(i + 1);
+      if (l.z == (int)i + 2) root(i + 2);
+      if (l.w == (int)i + 3) root(i + 3);
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      if (labels[i] == (int)i) root(i);
   }
-  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    if (labels[i] == (int)i) root(i);
   for (int o = 32; o > 0; o >>= 1) {
     mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
     cnt += __shfl_xor(cnt, o);
@@ -1153,7 +1202,9 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
                                                                  const int *__restrict__ image, int Ng, int k, int RL,
                                                                  const int *__restrict__ small_rank, int nsmall,
                                                                  const int *__restrict__ large_sorted, int nlarge,
-                                                                 double *__restrict__ out, int *__restrict__ err) {
+                                                                 double *__restrict__ out, int *__restrict__ err,
+                                                                 const int *__restrict__ rootlist = nullptr,
+                                                                 const int *__restrict__ rootctl = nullptr) {
   extern __shared__ unsigned fh[];
   for (int q = threadIdx.x; q < Ng * RL; q += blockDim.x) fh[q] = 0u;
   __syncthreads();
@@ -1168,18 +1219,26 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
     if (r < RL) atomicAdd(fh + (gl - 1) * RL + r, 1u);
     else atomicAdd(out + (size_t)(gl - 1) * k + r, 1.0);
   };
-  const long long n4 = n >> 2;
-  const int4 *lab4 = reinterpret_cast<const int4 *>(labels);
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
-    const int4 l = lab4[q];
-    const long long i = q << 2;
-    if (l.x == (int)i) root(i);
-    if (l.y == (int)i + 1) root(i + 1);
-    if (l.z == (int)i + 2) root(i + 2);
-    if (l.w == (int)i + 3) root(i + 3);
+  if (rootctl && rootctl[1] == 0) {      // the tile-root list (glszm_tile8_kernel)
+    const long long m = rootctl[0];
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+      const int i = rootlist[j];
+      if (labels[i] == i) root(i);
+    }
+  } else {
+    const long long n4 = n >> 2;
+    const int4 *lab4 = reinterpret_cast<const int4 *>(labels);
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+      const int4 l = lab4[q];
+      const long long i = q << 2;
+      if (l.x == (int)i) root(i);
+      if (l.y == (int)i + 1) root(i + 1);
+      if (l.z == (int)i + 2) root(i + 2);
+      if (l.w == (int)i + 3) root(i + 3);
+    }
+    for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+      if (labels[i] == (int)i) root(i);
   }
-  for (long long i = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    if (labels[i] == (int)i) root(i);
   __syncthreads();
   for (int q = threadIdx.x; q < Ng * RL; q += blockDim.x)
     if (fh[q]) atomicAdd(out + (size_t)(q / RL) * k + (q % RL), (double)fh[q]);
@@ -1418,10 +1477,13 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
         if (bytes) {
           uint8_t *levels = nullptr;
           PRAD_HIP(hipMemsetAsync(flags_d, 0, sizeof(int) * 4, s));
+          PRAD_TRY(c.get<int>("glszm_rootlist", (size_t)tiles * PRAD_GZ_TILE_ROOTS, &st.rootlist));
+          PRAD_TRY(c.get<int>("glszm_rootctl", 4, &st.rootctl));
+          PRAD_HIP(hipMemsetAsync(st.rootctl, 0, sizeof(int) * 4, s));
           PRAD_TRY(neigh_pack(&c, s, g, image, mask, Ng, flags_d, &levels));
           if (mode == 1) {
             hipLaunchKernelGGL(glszm_tile8_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, s, levels, dims3[0], dims3[1],
-                               dims3[2], st.labels, st.sizes, flags_d);
+                               dims3[2], st.labels, st.sizes, flags_d, st.rootlist, st.rootctl);
             if ((dims3[2] & 3) == 0) {
               // Both are launched, the device picks: flags[3] = number of tile-local components in every 64th tile (glszm_tile8_kernel).
               // Many voxels per component (structured images) -> the strip kernel with its de-duplicated wide
@@ -1438,7 +1500,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
                                  st.labels, flags_d);
           } else {
             hipLaunchKernelGGL(glszm_tile8_kernel<2>, dim3((unsigned)tiles), dim3(256), 0, s, levels, dims3[0], dims3[1],
-                               dims3[2], st.labels, st.sizes, flags_d);
+                               dims3[2], st.labels, st.sizes, flags_d, st.rootlist, st.rootctl);
             if ((dims3[2] & 3) == 0) {
               // Both are launched, the device picks: flags[3] = number of tile-local components in every 64th tile (glszm_tile8_kernel).
               // Many voxels per component (structured images) -> the strip kernel with its de-duplicated wide
@@ -1456,6 +1518,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
           }
           PRAD_TRY(check_launch("glszm_tile8/border8_kernel"));
         } else {
+          st.rootlist = st.rootctl = nullptr;
           hipLaunchKernelGGL(glszm_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, s, A3, mode, image, mask, dims3[0],
                              dims3[1], dims3[2], st.labels, st.sizes);
           PRAD_TRY(check_launch("glszm_tile_kernel"));
@@ -1468,9 +1531,11 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
           PRAD_TRY(check_launch("glszm_border_kernel"));
         }
         hipLaunchKernelGGL(glszm_rootsum_kernel, dim3((unsigned)((g.n + PRAD_RS_CHUNK - 1) / PRAD_RS_CHUNK)), dim3(256), 0, s,
-                           g.n, st.labels, st.sizes, (const int *)(bytes ? flags_d : nullptr));
+                           g.n, st.labels, st.sizes, (const int *)(bytes ? flags_d : nullptr), (const int *)st.rootlist,
+                           (const int *)st.rootctl);
         PRAD_TRY(check_launch("glszm_rootsum_kernel"));
       } else {
+        st.rootlist = st.rootctl = nullptr;
         hipLaunchKernelGGL(glszm_init_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, mask, g.n, st.labels, st.sizes);
         PRAD_TRY(check_launch("glszm_init_kernel"));
         hipLaunchKernelGGL(glszm_merge_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g, angles_d, Na, image, mask, st.labels);
@@ -1480,7 +1545,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
       }
       hipLaunchKernelGGL(glszm_stats_kernel, dim3(std::min(glszm_grid(g.n), 1024u)), dim3(256), 0, s, g.n, st.labels,
                          st.sizes, stats, stats64, st.small_bits, st.large_list, st.large_cap, st.large_count,
-                         (const int *)(bytes ? flags_d : nullptr));
+                         (const int *)(bytes ? flags_d : nullptr), (const int *)st.rootlist, (const int *)st.rootctl);
       PRAD_TRY(check_launch("glszm_stats_kernel"));
       if (!bytes) break;
       PRAD_HIP(hipMemcpyAsync(flags_h, flags_d, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
@@ -1632,7 +1697,7 @@ inline int glszm_fill_compact(Context &c, hipStream_t s, double *out_dev, int Ng
     const int RL = Ng <= 8192 ? std::max(1, std::min(k, 8192 / Ng)) : 0;
     hipLaunchKernelGGL(glszm_fill_compact_kernel, dim3(std::min(glszm_grid(st.g.n), 2048u)), dim3(256),
                        sizeof(unsigned) * Ng * RL, s, st.g.n, st.labels, st.sizes, st.image, Ng, k, RL, st.small_rank,
-                       st.nsmall, large_d, st.nlarge, out_dev, err);
+                       st.nsmall, large_d, st.nlarge, out_dev, err, (const int *)st.rootlist, (const int *)st.rootctl);
     PRAD_TRY(check_launch("glszm_fill_compact_kernel"));
   }
   void *hp = nullptr;
