@@ -20,6 +20,7 @@ namespace prad {
 
 struct MccScratch {
   double *M;    // [nmax * nmax]
+  double *A;    // [nmax * (nmax + 1)]  A(i, k) = p(i, k) / sqrt(px(i) py(k) + eps) on the occurring levels (odd row pitch)
   double *px;   // [Ng]
   double *py;   // [Ng]
   double *cs;   // [nmax] (c, s) of the step's rotations
@@ -29,13 +30,14 @@ struct MccScratch {
 // (the iteration pads an odd number of levels with one zero row / column: arrays are sized for nmax rounded up to even)
 __host__ __device__ inline size_t mcc_scratch_bytes(int Ng, int nmax) {
   nmax += nmax & 1;
-  return sizeof(double) * ((size_t)nmax * nmax + 2 * (size_t)Ng + nmax) + sizeof(int) * 2 * (size_t)nmax;
+  return sizeof(double) * ((size_t)nmax * nmax + (size_t)nmax * (nmax + 1) + 2 * (size_t)Ng + nmax) + sizeof(int) * 2 * (size_t)nmax;
 }
 __device__ __forceinline__ MccScratch mcc_scratch(void *base, int Ng, int nmax) {
   MccScratch S;
   nmax += nmax & 1;
   S.M = (double *)base;
-  S.px = S.M + (size_t)nmax * nmax;
+  S.A = S.M + (size_t)nmax * nmax;
+  S.px = S.A + (size_t)nmax * (nmax + 1);
   S.py = S.px + Ng;
   S.cs = S.py + Ng;
   S.idx = (int *)(S.cs + nmax);
@@ -80,19 +82,23 @@ __device__ double wave_mcc(Acc C, int Ng, double tot, MccScratch S, int nmax, in
   if (n < 2) return 0.0;
   mcc_wave_sync();
   const int np = n + (n & 1);
+  // A once (n^2 divisions and square roots instead of n^3: the products below are the same values in the same order)
+  const int ap = np + 1;
+  for (int e = lane; e < n * n; e += 64) {
+    const int a = e / n, k = e - a * n;
+    const int ia = S.idx[a], ik = S.idx[k];
+    const double ca = C(ia, ik);
+    S.A[a * ap + k] = ca != 0 ? (ca / tot) / sqrt(S.px[ia] * S.py[ik] + eps) : 0.0;
+  }
+  mcc_wave_sync();
   for (int e = lane; e < np * np; e += 64) {
     const int a = e / np, b = e - a * np;
     double v = 0;
     if (a < n && b < n) {
-      const int ia = S.idx[a], ib = S.idx[b];
-      const double pxa = S.px[ia], pxb = S.px[ib];
+      const double *ra = S.A + a * ap, *rb = S.A + b * ap;
       for (int k = 0; k < n; k++) {
-        const int ik = S.idx[k];
-        const double ca = C(ia, ik), cb = C(ib, ik);
-        if (ca != 0 && cb != 0) {
-          const double pyk = S.py[ik];
-          v += ((ca / tot) / sqrt(pxa * pyk + eps)) * ((cb / tot) / sqrt(pxb * pyk + eps));
-        }
+        const double x = ra[k], y = rb[k];
+        if (x != 0 && y != 0) v += x * y;
       }
     }
     S.M[e] = v;
@@ -156,21 +162,168 @@ __device__ double wave_mcc(Acc C, int Ng, double tot, MccScratch S, int nmax, in
   return sqrt(fmax(second, 0.0));
 }
 
+// The same routine for a whole workgroup (segment mode: one matrix per angle, 13 matrices in all -- a single wave per
+// matrix spent ~1 ms in the latency chain of ~250 Jacobi steps, each two passes of 8 dependent LDS round trips per lane;
+// with PRAD_MCC_BT threads a pass is 2 round trips).  Same arithmetic, same order of the rotations: same bits.
+#define PRAD_MCC_BT 256
+__device__ __forceinline__ double block_sum_f64(double v, double *red) {    // every thread gets the sum
+  v = wave_sum_f64(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0;
+  for (int w = 0; w < PRAD_MCC_BT / 64; w++) t += red[w];
+  return t;
+}
+template <class Acc>
+__device__ double block_mcc(Acc C, int Ng, double tot, MccScratch S, int nmax, int *too_many, double *red, int *shn) {
+#pragma clang fp contract(off)
+  const int tid = threadIdx.x, NT = PRAD_MCC_BT;
+  const double eps = 2.220446049250313e-16;
+  for (int i = tid; i < Ng; i += NT) {
+    double r = 0, c = 0;
+    for (int j = 0; j < Ng; j++) {
+      r += C(i, j) / tot;
+      c += C(j, i) / tot;
+    }
+    S.px[i] = r;
+    S.py[i] = c;
+  }
+  __syncthreads();
+  if (tid < 64) {          // the occurring levels, in order (one wave: ballot ranks)
+    int n = 0;
+    for (int base = 0; base < Ng; base += 64) {
+      const int i = base + tid;
+      const bool pres = i < Ng && (S.px[i] > 0 || S.py[i] > 0);
+      const unsigned long long m = __ballot(pres);
+      const int before = __popcll(m & ((1ull << tid) - 1ull));
+      if (pres && n + before < nmax) S.idx[n + before] = i;
+      n += __popcll(m);
+    }
+    if (tid == 0) *shn = n;
+  }
+  __syncthreads();
+  const int n = *shn;
+  if (n > nmax) {
+    if (tid == 0) *too_many = 1;
+    return __builtin_nan("");
+  }
+  if (n < 2) return 0.0;
+  const int np = n + (n & 1), ap = np + 1;
+  for (int e = tid; e < n * n; e += NT) {
+    const int a = e / n, k = e - a * n;
+    const int ia = S.idx[a], ik = S.idx[k];
+    const double ca = C(ia, ik);
+    S.A[a * ap + k] = ca != 0 ? (ca / tot) / sqrt(S.px[ia] * S.py[ik] + eps) : 0.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < np * np; e += NT) {
+    const int a = e / np, b = e - a * np;
+    double v = 0;
+    if (a < n && b < n) {
+      const double *ra = S.A + a * ap, *rb = S.A + b * ap;
+      for (int k = 0; k < n; k++) {
+        const double x = ra[k], y = rb[k];
+        if (x != 0 && y != 0) v += x * y;
+      }
+    }
+    S.M[e] = v;
+  }
+  __syncthreads();
+  const int m1 = np - 1, half = np / 2;
+  for (int sweep = 0; sweep < 30; sweep++) {
+    double off = 0, dia = 0;
+    for (int e = tid; e < np * np; e += NT) {
+      const int a = e / np, b = e - a * np;
+      const double v = S.M[e];
+      if (a == b) dia += v * v; else off += v * v;
+    }
+    off = block_sum_f64(off, red);
+    dia = block_sum_f64(dia, red);
+    if (off <= 1e-30 * dia) break;
+    for (int step = 0; step < m1; step++) {
+      if (tid < half) {
+        int p, q;
+        if (tid == 0) { p = step; q = m1; }
+        else { p = (step + tid) % m1; q = (step - tid + m1) % m1; }
+        const double app = S.M[p * np + p], aqq = S.M[q * np + q], apq = S.M[p * np + q];
+        double c = 1.0, s = 0.0;
+        if (apq != 0.0) {
+          const double theta = (aqq - app) / (2.0 * apq);
+          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          c = 1.0 / sqrt(t * t + 1.0);
+          s = t * c;
+        }
+        S.pq[2 * tid] = p; S.pq[2 * tid + 1] = q;
+        S.cs[2 * tid] = c; S.cs[2 * tid + 1] = s;
+      }
+      __syncthreads();
+      for (int w = tid; w < half * np; w += NT) {      // J^T M: rows p, q of every pair
+        const int t = w / np, r = w - t * np;
+        const int p = S.pq[2 * t], q = S.pq[2 * t + 1];
+        const double c = S.cs[2 * t], s = S.cs[2 * t + 1];
+        const double mp = S.M[p * np + r], mq = S.M[q * np + r];
+        S.M[p * np + r] = c * mp - s * mq;
+        S.M[q * np + r] = s * mp + c * mq;
+      }
+      __syncthreads();
+      for (int w = tid; w < half * np; w += NT) {      // (J^T M) J: columns p, q of every pair
+        const int t = w / np, r = w - t * np;
+        const int p = S.pq[2 * t], q = S.pq[2 * t + 1];
+        const double c = S.cs[2 * t], s = S.cs[2 * t + 1];
+        const double mp = S.M[r * np + p], mq = S.M[r * np + q];
+        S.M[r * np + p] = c * mp - s * mq;
+        S.M[r * np + q] = s * mp + c * mq;
+      }
+      __syncthreads();
+    }
+  }
+  // second largest eigenvalue (first wave; the value is read by thread 0)
+  double second = 0;
+  if (tid < 64) {
+    double d = tid < n ? S.M[tid * np + tid] : -1.0;
+    const double top = wave_max_f64(d);
+    const unsigned long long at = __ballot(d == top);
+    const int first = (int)(__ffsll((long long)at) - 1);
+    if (tid == first) d = -1.0;
+    second = wave_max_f64(d);
+  }
+  return sqrt(fmax(second, 0.0));
+}
+
 // segment mode: counts [Ng][Ng][Na] float64 (raw, reference layout) -> out[a] = MCC of angle a (NaN: no pair)
-__global__ void __launch_bounds__(64) glcm_matrix_mcc_kernel(const double *__restrict__ counts, int Ng, int Na, int symmetric,
-                                                             int nmax, double *__restrict__ out, int *__restrict__ too_many) {
+__global__ void __launch_bounds__(PRAD_MCC_BT) glcm_matrix_mcc_kernel(const double *__restrict__ counts, int Ng, int Na,
+                                                                      int symmetric, int nmax, int staged,
+                                                                      double *__restrict__ out, int *__restrict__ too_many) {
   extern __shared__ double mcc_lds[];
-  const int a = blockIdx.x, lane = threadIdx.x;
-  auto C = [&](int i, int j) -> double {
+  __shared__ double red[PRAD_MCC_BT / 64];
+  __shared__ int shn;
+  const int a = blockIdx.x, tid = threadIdx.x;
+  auto G = [&](int i, int j) -> double {
     const double v = counts[((size_t)i * Ng + j) * Na + a];
     return symmetric ? v + counts[((size_t)j * Ng + i) * Na + a] : v;
   };
-  double tot = 0;
-  for (int e = lane; e < Ng * Ng; e += 64) tot += C(e / Ng, e % Ng);
-  tot = wave_sum_f64(tot);
   double v = __builtin_nan("");
-  if (tot > 0) v = wave_mcc(C, Ng, tot, mcc_scratch(mcc_lds, Ng, nmax), nmax, too_many);
-  if (lane == 0) out[a] = v;
+  if (staged) {
+    // the angle's (symmetrised) counts go to LDS once: the routine reads every entry ~Ng times, and in the [Ng][Ng][Na]
+    // layout each read is a cache line of its own
+    double *Cs = (double *)((char *)mcc_lds + ((mcc_scratch_bytes(Ng, nmax) + 15) & ~(size_t)15));
+    double tot = 0;
+    for (int e = tid; e < Ng * Ng; e += PRAD_MCC_BT) {
+      const double c = G(e / Ng, e % Ng);
+      Cs[e] = c;
+      tot += c;
+    }
+    tot = block_sum_f64(tot, red);
+    auto C = [&](int i, int j) -> double { return Cs[i * Ng + j]; };
+    if (tot > 0) v = block_mcc(C, Ng, tot, mcc_scratch(mcc_lds, Ng, nmax), nmax, too_many, red, &shn);
+  } else {
+    double tot = 0;
+    for (int e = tid; e < Ng * Ng; e += PRAD_MCC_BT) tot += G(e / Ng, e % Ng);
+    tot = block_sum_f64(tot, red);
+    if (tot > 0) v = block_mcc(G, Ng, tot, mcc_scratch(mcc_lds, Ng, nmax), nmax, too_many, red, &shn);
+  }
+  if (tid == 0) out[a] = v;
 }
 
 #define PRAD_MCC_WAVES 2

@@ -1712,8 +1712,11 @@ int prad_glcm_mcc_dev(const double *glcm, int Ng, int Na, int symmetric, double 
   PRAD_TRY(c.ensure_device());
   if (!glcm || !out || Ng < 1 || Na < 1) return fail(PRAD_E_ARG, "glcm_mcc: bad arguments");
   const int nmax = std::min(Ng, PRAD_MCC_NMAX);
-  const size_t lds = mcc_scratch_bytes(Ng, nmax);
+  size_t lds = mcc_scratch_bytes(Ng, nmax);
   if (lds > 150 * 1024) return fail(PRAD_E_UNSUPPORTED, "glcm_mcc: Ng=%d exceeds the LDS scratch", Ng);
+  const size_t staged_lds = ((lds + 15) & ~(size_t)15) + sizeof(double) * (size_t)Ng * Ng;   // + the angle's counts
+  const int staged = staged_lds <= 150 * 1024;
+  if (staged) lds = staged_lds;
   hipStream_t s = (hipStream_t)stream;
   double *d_out = nullptr;
   int *d_flag = nullptr;
@@ -1724,7 +1727,7 @@ int prad_glcm_mcc_dev(const double *glcm, int Ng, int Na, int symmetric, double 
     Timed t(c, "features", s);
     PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&glcm_matrix_mcc_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(glcm_matrix_mcc_kernel, dim3(Na), dim3(64), lds, s, glcm, Ng, Na, symmetric, nmax, d_out, d_flag);
+    hipLaunchKernelGGL(glcm_matrix_mcc_kernel, dim3(Na), dim3(PRAD_MCC_BT), lds, s, glcm, Ng, Na, symmetric, nmax, staged, d_out, d_flag);
     PRAD_TRY(check_launch("glcm_matrix_mcc_kernel"));
   }
   int flag = 0;

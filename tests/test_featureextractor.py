@@ -180,7 +180,12 @@ def test_device_resident_route_equals_host_array_route():
     mid = RadiomicsFeatureExtractor(params).execute(IMG, LBL)
     for k in keys:
         a, b = float(mid[k]), float(host[k])
-        assert a == b or (np.isnan(a) and np.isnan(b)), (k, a, b)
+        if "_firstorder_" in k:
+            # the device crop pads its rows to a multiple of 4 voxels (outside the ROI): the first-order block
+            # reductions partition a differently shaped array, i.e. the same terms are summed in another order
+            assert a == b or (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1e-13 * abs(b), (k, a, b)
+        else:
+            assert a == b or (np.isnan(a) and np.isnan(b)), (k, a, b)
 
 
 @pytest.mark.gpu
