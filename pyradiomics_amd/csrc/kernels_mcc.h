@@ -230,63 +230,92 @@ __device__ double block_mcc(Acc C, int Ng, double tot, MccScratch S, int nmax, i
     S.M[e] = v;
   }
   __syncthreads();
-  const int m1 = np - 1, half = np / 2;
-  for (int sweep = 0; sweep < 30; sweep++) {
-    double off = 0, dia = 0;
-    for (int e = tid; e < np * np; e += NT) {
-      const int a = e / np, b = e - a * np;
-      const double v = S.M[e];
-      if (a == b) dia += v * v; else off += v * v;
-    }
-    off = block_sum_f64(off, red);
-    dia = block_sum_f64(dia, red);
-    if (off <= 1e-30 * dia) break;
-    for (int step = 0; step < m1; step++) {
-      if (tid < half) {
-        int p, q;
-        if (tid == 0) { p = step; q = m1; }
-        else { p = (step + tid) % m1; q = (step - tid + m1) % m1; }
-        const double app = S.M[p * np + p], aqq = S.M[q * np + q], apq = S.M[p * np + q];
-        double c = 1.0, s = 0.0;
-        if (apq != 0.0) {
-          const double theta = (aqq - app) / (2.0 * apq);
-          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-          c = 1.0 / sqrt(t * t + 1.0);
-          s = t * c;
+  // Only the second largest eigenvalue is wanted: Householder reduction of M to tridiagonal form (n - 2 reflections, each
+  // a matrix-vector product and a rank-2 update over the workgroup), then its position by Sturm counts -- 64 shifts per
+  // round, one per lane, every round narrows the bracket 65-fold (absolute accuracy ~ n eps ||M||, as LAPACK's on the
+  // reference side).  ~40 us per matrix at n = 32; the cyclic Jacobi iteration this replaces (kept in wave_mcc for the
+  // voxel maps, whose matrices are tiny) needed ~280 rotation steps of 4 barriers each: 0.6 ms.
+  double *dg = S.px, *sd = S.py;              // diagonal / sub-diagonal of T (the marginals are not needed any more)
+  double *u = S.A, *pv = S.A + nmax + 1, *hk = red;   // reflector, M u / h (A is free: nmax (nmax + 1) >= 2 (nmax + 1)), {h, K, u_l}
+  for (int i = n - 1; i >= 1; i--) {
+    const int l = i - 1;                      // the reflector annihilates M[i][0 .. l-1]
+    if (tid < 64) {
+      double v = 0;
+      if (l >= 1) {
+        for (int k = tid; k <= l; k += 64) v += S.M[i * np + k] * S.M[i * np + k];
+        v = wave_sum_f64(v);
+      }
+      if (tid == 0) {
+        const double f = S.M[i * np + l];
+        if (l == 0 || v == 0.0 || v == f * f) {      // nothing to annihilate
+          sd[i] = f;
+          hk[0] = 0.0;
+        } else {
+          const double g = f >= 0 ? -sqrt(v) : sqrt(v);
+          sd[i] = g;
+          hk[0] = v - f * g;
+          hk[2] = f - g;
         }
-        S.pq[2 * tid] = p; S.pq[2 * tid + 1] = q;
-        S.cs[2 * tid] = c; S.cs[2 * tid + 1] = s;
       }
-      __syncthreads();
-      for (int w = tid; w < half * np; w += NT) {      // J^T M: rows p, q of every pair
-        const int t = w / np, r = w - t * np;
-        const int p = S.pq[2 * t], q = S.pq[2 * t + 1];
-        const double c = S.cs[2 * t], s = S.cs[2 * t + 1];
-        const double mp = S.M[p * np + r], mq = S.M[q * np + r];
-        S.M[p * np + r] = c * mp - s * mq;
-        S.M[q * np + r] = s * mp + c * mq;
-      }
-      __syncthreads();
-      for (int w = tid; w < half * np; w += NT) {      // (J^T M) J: columns p, q of every pair
-        const int t = w / np, r = w - t * np;
-        const int p = S.pq[2 * t], q = S.pq[2 * t + 1];
-        const double c = S.cs[2 * t], s = S.cs[2 * t + 1];
-        const double mp = S.M[r * np + p], mq = S.M[r * np + q];
-        S.M[r * np + p] = c * mp - s * mq;
-        S.M[r * np + q] = s * mp + c * mq;
-      }
-      __syncthreads();
     }
+    __syncthreads();
+    const double h = hk[0];
+    if (h == 0.0) continue;                   // (uniform: hk[0] is not rewritten before the next barrier)
+    for (int k = tid; k <= l; k += NT) u[k] = k == l ? hk[2] : S.M[i * np + k];
+    __syncthreads();
+    for (int j = tid; j <= l; j += NT) {
+      double acc = 0;
+      for (int k = 0; k <= l; k++) acc += S.M[j * np + k] * u[k];
+      pv[j] = acc / h;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      double v = 0;
+      for (int k = tid; k <= l; k += 64) v += u[k] * pv[k];
+      v = wave_sum_f64(v);
+      if (tid == 0) hk[1] = v / (h + h);
+    }
+    __syncthreads();
+    const double K = hk[1];
+    for (int e = tid; e < (l + 1) * (l + 1); e += NT) {
+      const int j = e / (l + 1), k = e - j * (l + 1);
+      const double qj = pv[j] - K * u[j], qk = pv[k] - K * u[k];
+      S.M[j * np + k] -= u[j] * qk + qj * u[k];
+    }
+    __syncthreads();
   }
-  // second largest eigenvalue (first wave; the value is read by thread 0)
+  for (int i = tid; i < n; i += NT) dg[i] = S.M[i * np + i];
+  if (tid == 0) sd[0] = 0.0;
+  __syncthreads();
   double second = 0;
   if (tid < 64) {
-    double d = tid < n ? S.M[tid * np + tid] : -1.0;
-    const double top = wave_max_f64(d);
-    const unsigned long long at = __ballot(d == top);
-    const int first = (int)(__ffsll((long long)at) - 1);
-    if (tid == first) d = -1.0;
-    second = wave_max_f64(d);
+    // Gershgorin bracket, then multisection on N(x) = #{eigenvalues < x}: lambda_(n-1) = sup{x : N(x) <= n - 2}
+    double lo = 1e300, hi = -1e300;
+    for (int i = tid; i < n; i += 64) {
+      const double r = fabs(sd[i]) + (i + 1 < n ? fabs(sd[i + 1]) : 0.0);
+      lo = fmin(lo, dg[i] - r);
+      hi = fmax(hi, dg[i] + r);
+    }
+    lo = -wave_max_f64(-lo);
+    hi = wave_max_f64(hi);
+    const double tiny = 1e-300;
+    for (int round = 0; round < 14 && hi > lo; round++) {
+      const double x = lo + (hi - lo) * (double)(tid + 1) / 65.0;
+      double q = dg[0] - x;
+      int cnt = q < 0;
+      for (int i = 1; i < n; i++) {
+        if (q == 0.0) q = tiny;
+        q = dg[i] - x - sd[i] * sd[i] / q;
+        cnt += q < 0;
+      }
+      const unsigned long long below = __ballot(cnt <= n - 2);      // a prefix of the lanes (N is monotone)
+      const int nb = __popcll(below);
+      const double nlo = nb > 0 ? __shfl(x, nb - 1) : lo, nhi = nb < 64 ? __shfl(x, nb) : hi;
+      if (nlo == lo && nhi == hi) break;
+      lo = nlo;
+      hi = nhi;
+    }
+    second = 0.5 * (lo + hi);
   }
   return sqrt(fmax(second, 0.0));
 }

@@ -282,5 +282,24 @@ def test_segment_mcc_on_the_device_and_special_cases():
         A = p / np.sqrt(np.outer(p.sum(1), p.sum(0)) + np.spacing(1))
         want = np.linalg.svd(A, compute_uv=False)[1]
         assert got[0] == pytest.approx(want, rel=1e-10) and np.isnan(got[1]) and got[2] == 0.0
+    # the tridiagonal route (Householder + Sturm counts) on the shapes that strain it: odd sizes, levels that never
+    # occur, a banded matrix (weak coupling: small second eigenvalue), a block matrix with lambda_2 = lambda_3 = ... = 1
+    for Ng in (3, 7, 17, 33, 64):
+        P = rng.integers(0, 30, size=(Ng, Ng, 4)).astype(np.float64)
+        P[Ng // 3] = 0
+        P[:, Ng // 3] = 0
+        band = np.abs(np.subtract.outer(np.arange(Ng), np.arange(Ng))) <= 1
+        P[:, :, 1] = band * rng.integers(1, 30, size=(Ng, Ng)) + 1e-3
+        P[:, :, 2] = np.eye(Ng) * 5
+        P[:, :, 3] = np.kron(np.eye((Ng + 1) // 2), np.ones((2, 2)))[:Ng, :Ng] * 3
+        got = engine.glcm_mcc(torch.from_numpy(P).cuda(), True)
+        for a in range(4):
+            M = P[:, :, a] + P[:, :, a].T
+            p = M / M.sum()
+            A = p / np.sqrt(np.outer(p.sum(1), p.sum(0)) + np.spacing(1))
+            keep = p.sum(1) > 0
+            sv = np.linalg.svd(A[np.ix_(keep, keep)], compute_uv=False)
+            want = sv[1] if len(sv) > 1 else 0.0
+            assert got[a] == pytest.approx(want, rel=1e-9, abs=1e-12), (Ng, a, got[a], want)
     with pytest.raises(NotImplementedError):          # more than 64 grey levels occur: host route
         engine.glcm_mcc(torch.from_numpy(rng.integers(1, 9, size=(80, 80, 1)).astype(np.float64)).cuda(), True)
