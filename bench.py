@@ -29,16 +29,16 @@ import numpy as np
 import torch
 
 # Fabric (HBM + Infinity Cache) bytes per engine call at the default workload, from the committed PMC profile
-# profiles/r02a_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE calibrated on the
-# kernels' own access widths: x2 for pack_rows' 16 B/lane loads, /0.572 for sweep_fw's 8 B/lane loads -- one angle
-# alone reads the 134 MB level volume exactly once and reports 76.8 MB): pack_rows 0.80 GB + 0.152 GB written,
-# sweep_fw 1.24 GB (12 angles, 9.3 volume reads) + 0.016 GB.  rocprof cannot run inside bench.py; the figure is only
+# profiles/r02b_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE calibrated on the
+# kernels' own access widths: x2 for pack_rows' 16 B/lane loads, /0.524 for sweep_fw's 8 B/lane loads -- one angle
+# alone reads the 134 MB level volume exactly once and reports 70.4 MB): pack_rows 0.80 GB + 0.152 GB written,
+# sweep_fw 1.36 GB (12 angles, 10.2 volume reads).  rocprof cannot run inside bench.py; the figure is only
 # reported when the workload matches the profiled one.
-PROFILED_TRAFFIC = {"workload": (512, 32, "uniform"), "bytes": 2.21e9, "source": "profiles/r02a_pmc.md"}
+PROFILED_TRAFFIC = {"workload": (512, 32, "uniform"), "bytes": 2.31e9, "kernel_bytes": 1.36e9, "source": "profiles/r02b_pmc.md"}
 # Secondary rooflines of the dominant kernel (it is not HBM-bound): wave-instructions per launch from the same PMC pass,
 # ceilings from scripts/microbench.hip on this GPU (profiles/r02a_microbench.log): a conflict-free ds_add_u32 retires every
 # 4.1 cycles per CU, an independent integer VALU instruction every 2.65 cycles per SIMD (256 CUs x 4 SIMDs, 2.4 GHz).
-PROFILED_INSTS = {"workload": (512, 32, "uniform"), "lds": 2.802e7, "valu": 1.379e8, "source": "profiles/r02a_pmc.md"}
+PROFILED_INSTS = {"workload": (512, 32, "uniform"), "lds": 2.802e7, "valu": 1.399e8, "source": "profiles/r02b_pmc.md"}
 LDS_ATOMIC_PEAK = 256 * 2.4e9 / 4.1       # ds_add wave-instructions / s
 VALU_PEAK = 1024 * 2.4e9 / 2.65           # VALU wave-instructions / s
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -391,7 +391,8 @@ def main() -> None:
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": PROFILED_TRAFFIC["bytes"] if (args.size, args.levels, args.dist) == PROFILED_TRAFFIC["workload"] else None,
-                "traffic_source": PROFILED_TRAFFIC["source"],
+                "traffic_source": PROFILED_TRAFFIC["source"] + " (fabric bytes of pack + sweeps per volume; traffic_kernel: the sweep kernel's share)",
+                "traffic_kernel": PROFILED_TRAFFIC["kernel_bytes"] if (args.size, args.levels, args.dist) == PROFILED_TRAFFIC["workload"] else None,
                 "algorithmic_bytes": alg_bytes, "kernel_ms": round(sweep_ms, 4),
                 "pipeline_ms": round(pipe_ms, 4), "pack_ms": round(kernel_ms["pack"] / args.steps, 4),
                 "finalize_ms": round(kernel_ms["finalize"] / args.steps, 4),
