@@ -37,11 +37,55 @@ def split_slabs(n: int, parts: int, halo: int = 0):
     return out
 
 
-def run_batch(cases: Sequence, worker: Callable, gather: bool = True):
+def _run_threaded(indices, cases, worker, threads: int):
+    """`threads` cases of this rank in flight on the one GPU: the library keeps its context (workspaces, streams, error
+    state) per host thread and its C calls release the GIL, so one case's Python / launch overhead (a third of a 256^3
+    case) runs under another case's kernels.  Every thread works on a HIP stream of its own."""
+    import queue
+    import threading
+    todo = queue.Queue()
+    for i in indices:
+        todo.put(i)
+    out, errors = {}, []
+
+    def loop():
+        try:
+            import torch
+            ctx = torch.cuda.stream(torch.cuda.Stream()) if torch.cuda.is_available() else None
+        except ImportError:
+            ctx = None
+        if ctx is not None:
+            ctx.__enter__()
+        try:
+            while not errors:
+                try:
+                    i = todo.get_nowait()
+                except queue.Empty:
+                    return
+                out[i] = worker(cases[i])
+        except BaseException as e:          # surfaces in the caller's thread
+            errors.append(e)
+        finally:
+            if ctx is not None:
+                ctx.__exit__(None, None, None)
+
+    pool = [threading.Thread(target=loop) for _ in range(max(1, min(threads, len(indices))))]
+    for t in pool:
+        t.start()
+    for t in pool:
+        t.join()
+    if errors:
+        raise errors[0]
+    return out
+
+
+def run_batch(cases: Sequence, worker: Callable, gather: bool = True, threads: int = 1):
     """Applies `worker(case)` to this rank's shard.  With gather=True rank 0 returns the results of ALL cases in
-    input order (other ranks return None); with gather=False every rank returns {case_index: result} of its own."""
+    input order (other ranks return None); with gather=False every rank returns {case_index: result} of its own.
+    threads > 1: that many cases of the shard at a time (host threads sharing the rank's GPU, see _run_threaded)."""
     rank, world = rank_world()
-    mine = {i: worker(cases[i]) for i in shard_indices(len(cases), rank, world)}
+    idx = shard_indices(len(cases), rank, world)
+    mine = _run_threaded(idx, cases, worker, threads) if threads > 1 else {i: worker(cases[i]) for i in idx}
     if not gather or world == 1:
         return [mine[i] for i in range(len(cases))] if (gather and world == 1) else mine
     import torch.distributed as dist

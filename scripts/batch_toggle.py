@@ -8,5 +8,5 @@ dev = torch.device("cuda", 0)
 def fence():
     torch.cuda.synchronize()
 for _ in range(2):
-    nc, dt, nf = mode_batch(dev, 0, 4, fence)
+    nc, dt, nf = mode_batch(dev, 0, 9, fence)
     print("%.2f cases/s (%.1f ms per case, %d features)" % (nc / dt, dt / nc * 1e3, nf), flush=True)
