@@ -1318,6 +1318,12 @@ __global__ void __launch_bounds__(64) glszm_voxel_kernel(Geo g, VoxMode vm, cons
                                                          int *__restrict__ zones, int *__restrict__ zone_count,
                                                          int *__restrict__ stats,
                                                          unsigned long long *__restrict__ stats64, int Ns_eff) {
+  // (one wave per workgroup: the wave's maximum / zone count are combined in LDS and lane 0 -- active whenever any lane of
+  // the wave is -- issues the two global atomics; one pair per CENTRE on these two words serialises in L2)
+  __shared__ int smx;
+  __shared__ unsigned long long snz;
+  if (threadIdx.x == 0) { smx = 0; snz = 0ull; }
+  __syncthreads();
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= vm.nvox) return;
   const long long NV = vm.nvox;
@@ -1370,8 +1376,13 @@ __global__ void __launch_bounds__(64) glszm_voxel_kernel(Geo g, VoxMode vm, cons
   if (nproc > Ns_eff || nz >= 2 * Ns_eff) stats[1] = 1;  // cmatrices.c:174,226 (processedStack) and :274
   zone_count[v] = nz;
   if (nz) {
-    atomicMax(stats, mx);
-    atomicAdd(stats64, (unsigned long long)nz);
+    atomicMax(&smx, mx);
+    atomicAdd(&snz, (unsigned long long)nz);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && snz) {
+    atomicMax(stats, smx);
+    atomicAdd(stats64, snz);
   }
 }
 

@@ -54,6 +54,12 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 
 // out: [nfeat][nvox] float64; empty_mask[v]: bit a set <=> angle a had no pair in kernel v;
 // any_nonempty[0]: OR over all kernels of the non-empty angle bits
+// SM: the features this instantiation can produce (a compile-time mask: everything else -- accumulators, histograms, fp64
+// terms -- is compiled out).  The all-features kernel needs 209 VGPRs, i.e. 2 waves per SIMD for a kernel that waits on LDS
+// and cache round trips; the light one (joint entropy / energy / maximum / average: the usual voxel-map requests) fits
+// several times the waves.
+#define PRAD_VF_LIGHT ((1u << VF_JointEntropy) | (1u << VF_JointEnergy) | (1u << VF_MaximumProbability) | (1u << VF_JointAverage))
+template <unsigned SM>
 __global__ void __launch_bounds__(64 * PRAD_VOX_WAVES) voxel_glcm_kernel(
     const uint8_t *__restrict__ L, int Nz, int Ny, int Nx, VoxAngles A, int Ng, int nvox,
     const int *__restrict__ voxels, int vox_nd, int radius, int f2d3, int symmetric, unsigned feat_mask,
@@ -74,12 +80,25 @@ __global__ void __launch_bounds__(64 * PRAD_VOX_WAVES) voxel_glcm_kernel(
   const bool sym = symmetric != 0;
   const int w = sym ? 2 : 1;
   const double Ngd = (double)Ng;
-  const bool need_cov = feat_mask & (1u << VF_Correlation);
-  const bool need_dv = feat_mask & (1u << VF_DifferenceVariance);
-  const bool need_imc = feat_mask & ((1u << VF_Imc1) | (1u << VF_Imc2));
-  const bool need_imc2 = feat_mask & (1u << VF_Imc2);
-  const bool need_max = feat_mask & (1u << VF_MaximumProbability);
+  feat_mask &= SM;
+#define PRAD_WANT(f) (((SM >> (f)) & 1u) && ((feat_mask >> (f)) & 1u))
+  const bool need_cov = PRAD_WANT(VF_Correlation);
+  const bool need_dv = PRAD_WANT(VF_DifferenceVariance);
+  const bool need_imc = PRAD_WANT(VF_Imc1) || PRAD_WANT(VF_Imc2);
+  const bool need_imc2 = PRAD_WANT(VF_Imc2);
+  const bool need_max = PRAD_WANT(VF_MaximumProbability);
+  // what a request really needs (wave-uniform branches): a JointEntropy-only map -- the voxel-based benchmark -- skips the
+  // marginal / difference / sum histograms and every other feature's fp64 terms (4 divisions and a dozen products per pair)
+  const bool need_rows = need_imc;
+  const bool need_dif = PRAD_WANT(VF_DifferenceEntropy), need_sum = PRAD_WANT(VF_SumEntropy);
+  const bool need_moments = PRAD_WANT(VF_Autocorrelation) || PRAD_WANT(VF_ClusterTendency) || PRAD_WANT(VF_ClusterShade) ||
+                            PRAD_WANT(VF_ClusterProminence) || PRAD_WANT(VF_SumSquares) || need_cov;
+  const bool need_dterms = PRAD_WANT(VF_Contrast) || PRAD_WANT(VF_Idm) || PRAD_WANT(VF_Idmn) || PRAD_WANT(VF_Id) ||
+                           PRAD_WANT(VF_Idn) || PRAD_WANT(VF_InverseVariance) || PRAD_WANT(VF_DifferenceAverage) ||
+                           PRAD_WANT(VF_SumAverage) || need_dv;
+  const bool need_plogp = PRAD_WANT(VF_JointEntropy) || need_imc;
 
+  unsigned reported = 0;     // angle bits this wave has already OR-ed into *any_nonempty (lane 0)
   for (int v = blockIdx.x * PRAD_VOX_WAVES + wave; v < nvox; v += gridDim.x * PRAD_VOX_WAVES) {
     // centre and window box in the 3-D embedding
     int c[3] = {0, 0, 0};
@@ -102,31 +121,68 @@ __global__ void __launch_bounds__(64 * PRAD_VOX_WAVES) voxel_glcm_kernel(
     int n_angles = 0, n_imc2 = 0;
     unsigned emask = 0;
 
+    // Window voxels of this lane, decomposed and loaded ONCE per centre (windows of up to 128 voxels: every 2-D window,
+    // 3^3 and 5^3); the three passes of every angle then only fetch the neighbour level.  The integer divisions of the
+    // decomposition and the reloads were most of the kernel's instructions (a 5x5 window fills 25 of 64 lanes).
+    constexpr int MAXIT = 2;
+    const bool cached = W <= 64 * MAXIT;
+    int ckx[MAXIT], cky[MAXIT], ckz[MAXIT], cli[MAXIT];
+    if (cached) {
+#pragma unroll
+      for (int it = 0; it < MAXIT; it++) {
+        const int k = lane + 64 * it;
+        ckx[it] = k % ext[2];
+        const int kr = k / ext[2];
+        cky[it] = kr % ext[1];
+        ckz[it] = kr / ext[1];
+        cli[it] = k < W ? (int)L[((long long)(lo[0] + ckz[it]) * Ny + (lo[1] + cky[it])) * Nx + lo[2] + ckx[it]] : 0;
+      }
+    }
     for (int a = 0; a < A.na; a++) {
       const int dz = A.o[a][0], dy = A.o[a][1], dx = A.o[a][2];
+      int clj[MAXIT];      // neighbour level of the cached voxels for this angle (0: no pair)
+      if (cached) {
+#pragma unroll
+        for (int it = 0; it < MAXIT; it++) {
+          const int qz = ckz[it] + dz, qy = cky[it] + dy, qx = ckx[it] + dx;
+          const bool ok = cli[it] != 0 && (unsigned)qz < (unsigned)ext[0] && (unsigned)qy < (unsigned)ext[1] &&
+                          (unsigned)qx < (unsigned)ext[2];
+          clj[it] = ok ? (int)L[((long long)(lo[0] + qz) * Ny + (lo[1] + qy)) * Nx + lo[2] + qx] : 0;
+        }
+      }
+      auto for_pairs = [&](auto body) __attribute__((always_inline)) {
+        if (cached) {
+#pragma unroll
+          for (int it = 0; it < MAXIT; it++)
+            if (clj[it]) body(cli[it], clj[it]);
+        } else {
+          for (int k = lane; k < W; k += 64) {
+            const int kx = k % ext[2], kr = k / ext[2];
+            const int ky = kr % ext[1], kz = kr / ext[1];
+            const int qz = kz + dz, qy = ky + dy, qx = kx + dx;
+            if ((unsigned)qz >= (unsigned)ext[0] || (unsigned)qy >= (unsigned)ext[1] || (unsigned)qx >= (unsigned)ext[2]) continue;
+            const int li = L[((long long)(lo[0] + kz) * Ny + (lo[1] + ky)) * Nx + lo[2] + kx];
+            if (!li) continue;
+            const int lj = L[((long long)(lo[0] + qz) * Ny + (lo[1] + qy)) * Nx + lo[2] + qx];
+            if (!lj) continue;
+            body(li, lj);
+          }
+        }
+      };
       // ---- pass A: integer counts ----
       int np = 0, si = 0, sj = 0;
-      for (int k = lane; k < W; k += 64) {
-        const int kx = k % ext[2], kr = k / ext[2];
-        const int ky = kr % ext[1], kz = kr / ext[1];
-        const int qz = kz + dz, qy = ky + dy, qx = kx + dx;
-        if ((unsigned)qz >= (unsigned)ext[0] || (unsigned)qy >= (unsigned)ext[1] || (unsigned)qx >= (unsigned)ext[2]) continue;
-        const int li = L[((long long)(lo[0] + kz) * Ny + (lo[1] + ky)) * Nx + lo[2] + kx];
-        if (!li) continue;
-        const int lj = L[((long long)(lo[0] + qz) * Ny + (lo[1] + qy)) * Nx + lo[2] + qx];
-        if (!lj) continue;
+      for_pairs([&](int li, int lj) __attribute__((always_inline)) {
         np++; si += li; sj += lj;
         atomicAdd(&tab[(li - 1) * Ng + (lj - 1)], 1u);
-        atomicAdd(&rowx[li - 1], 1u);
-        if (sym) {
-          atomicAdd(&tab[(lj - 1) * Ng + (li - 1)], 1u);
-          atomicAdd(&rowx[lj - 1], 1u);
-        } else {
-          atomicAdd(&rowy[lj - 1], 1u);
+        if (sym) atomicAdd(&tab[(lj - 1) * Ng + (li - 1)], 1u);
+        if (need_rows) {
+          atomicAdd(&rowx[li - 1], 1u);
+          if (sym) atomicAdd(&rowx[lj - 1], 1u);
+          else atomicAdd(&rowy[lj - 1], 1u);
         }
-        atomicAdd(&dif[abs(li - lj)], (u32)w);
-        atomicAdd(&sum[li + lj - 2], (u32)w);
-      }
+        if (need_dif) atomicAdd(&dif[abs(li - lj)], (u32)w);
+        if (need_sum) atomicAdd(&sum[li + lj - 2], (u32)w);
+            });
       np = wave_sum_i32(np);
       if (np == 0) { emask |= 1u << a; continue; }   // nothing was written
       si = wave_sum_i32(si);
@@ -138,36 +194,34 @@ __global__ void __launch_bounds__(64 * PRAD_VOX_WAVES) voxel_glcm_kernel(
       n_angles++;
       u_ja += ux;
       // ---- histogram-based features (linear in the angle sum) ----
-      for (int k = lane; k < 2 * Ng + 1; k += 64) {
-        if (k < Ng) {
-          const double pd = (double)dif[k] / T;
-          acc[VF_DifferenceEntropy] -= pd * log2(pd + eps);
+      if (need_dif || need_sum) {
+        for (int k = lane; k < 2 * Ng + 1; k += 64) {
+          if (k < Ng && need_dif) {
+            const double pd = (double)dif[k] / T;
+            acc[VF_DifferenceEntropy] -= pd * log2(pd + eps);
+          }
+          if (need_sum) {
+            const double ps = (double)sum[k] / T;
+            acc[VF_SumEntropy] -= ps * log2(ps + eps);
+          }
         }
-        const double ps = (double)sum[k] / T;
-        acc[VF_SumEntropy] -= ps * log2(ps + eps);
       }
       // ---- pass B ----
       double cov = 0, vx = 0, vy = 0, da = 0, d2 = 0, hxy = 0, hxy1 = 0, hx = 0, hy = 0, pmax = 0;
-      for (int k = lane; k < W; k += 64) {
-        const int kx = k % ext[2], kr = k / ext[2];
-        const int ky = kr % ext[1], kz = kr / ext[1];
-        const int qz = kz + dz, qy = ky + dy, qx = kx + dx;
-        if ((unsigned)qz >= (unsigned)ext[0] || (unsigned)qy >= (unsigned)ext[1] || (unsigned)qx >= (unsigned)ext[2]) continue;
-        const int li = L[((long long)(lo[0] + kz) * Ny + (lo[1] + ky)) * Nx + lo[2] + kx];
-        if (!li) continue;
-        const int lj = L[((long long)(lo[0] + qz) * Ny + (lo[1] + qy)) * Nx + lo[2] + qx];
-        if (!lj) continue;
+      for_pairs([&](int li, int lj) __attribute__((always_inline)) {
         const double cnt = (double)tab[(li - 1) * Ng + (lj - 1)];
         const double p = cnt * iT;
         const double occ = (double)w / cnt;            // this occurrence's share of its entry (both mirrored entries)
-        acc[VF_JointEnergy] += occ * p * p;
-        const double plogp = p * log2(p + eps);
-        acc[VF_JointEntropy] -= occ * plogp;
-        hxy -= occ * plogp;
-        pmax = fmax(pmax, p);
+        if (PRAD_WANT(VF_JointEnergy)) acc[VF_JointEnergy] += occ * p * p;
+        if (need_plogp) {
+          const double plogp = p * log2(p + eps);
+          acc[VF_JointEntropy] -= occ * plogp;
+          hxy -= occ * plogp;
+        }
+        if (need_max) pmax = fmax(pmax, p);
         const double di = (double)li, dj = (double)lj, d = fabs(di - dj);
         // terms of sums over entries weighted by p: each ordered entry contributes 1/T per occurrence
-        const int reps = sym ? 2 : 1;
+        const int reps = (sym ? 2 : 1) * (need_moments ? 1 : 0);
         for (int r = 0; r < reps; r++) {
           const double ii = r ? dj : di, jj = r ? di : dj;
           const double s = ii + jj - ux - uy;
@@ -181,16 +235,18 @@ __global__ void __launch_bounds__(64 * PRAD_VOX_WAVES) voxel_glcm_kernel(
           vy += iT * (jj - uy) * (jj - uy);
         }
         const double wt = (double)w * iT;
-        acc[VF_Contrast] += wt * d * d;
-        acc[VF_Idm] += wt / (1.0 + d * d);
-        acc[VF_Idmn] += wt / (1.0 + (d * d) / (Ngd * Ngd));
-        acc[VF_Id] += wt / (1.0 + d);
-        acc[VF_Idn] += wt / (1.0 + d / Ngd);
-        if (d != 0.0) acc[VF_InverseVariance] += wt / (d * d);
-        acc[VF_DifferenceAverage] += wt * d;
-        acc[VF_SumAverage] += wt * (di + dj);
-        da += wt * d;
-        d2 += wt * d * d;
+        if (need_dterms) {
+          acc[VF_Contrast] += wt * d * d;
+          acc[VF_Idm] += wt / (1.0 + d * d);
+          acc[VF_Idmn] += wt / (1.0 + (d * d) / (Ngd * Ngd));
+          acc[VF_Id] += wt / (1.0 + d);
+          acc[VF_Idn] += wt / (1.0 + d / Ngd);
+          if (d != 0.0) acc[VF_InverseVariance] += wt / (d * d);
+          acc[VF_DifferenceAverage] += wt * d;
+          acc[VF_SumAverage] += wt * (di + dj);
+          da += wt * d;
+          d2 += wt * d * d;
+        }
         if (need_imc) {
           const double pxi = (double)rowx[li - 1] * iT, pyj = (double)ry[lj - 1] * iT;
           hxy1 -= wt * log2(pxi * pyj + eps);
@@ -202,7 +258,7 @@ __global__ void __launch_bounds__(64 * PRAD_VOX_WAVES) voxel_glcm_kernel(
             hy -= pyj * log2(pyj + eps) / (double)rowy[lj - 1];
           }
         }
-      }
+            });
       // ---- per-angle non-linear features (wave-uniform after reduction) ----
       if (need_cov) {
         cov = wave_sum_f64(cov); vx = wave_sum_f64(vx); vy = wave_sum_f64(vy);
@@ -232,28 +288,21 @@ __global__ void __launch_bounds__(64 * PRAD_VOX_WAVES) voxel_glcm_kernel(
         }
       }
       // ---- pass C: clear what this angle wrote ----
-      for (int k = lane; k < W; k += 64) {
-        const int kx = k % ext[2], kr = k / ext[2];
-        const int ky = kr % ext[1], kz = kr / ext[1];
-        const int qz = kz + dz, qy = ky + dy, qx = kx + dx;
-        if ((unsigned)qz >= (unsigned)ext[0] || (unsigned)qy >= (unsigned)ext[1] || (unsigned)qx >= (unsigned)ext[2]) continue;
-        const int li = L[((long long)(lo[0] + kz) * Ny + (lo[1] + ky)) * Nx + lo[2] + kx];
-        if (!li) continue;
-        const int lj = L[((long long)(lo[0] + qz) * Ny + (lo[1] + qy)) * Nx + lo[2] + qx];
-        if (!lj) continue;
+      for_pairs([&](int li, int lj) __attribute__((always_inline)) {
         tab[(li - 1) * Ng + (lj - 1)] = 0;
         tab[(lj - 1) * Ng + (li - 1)] = 0;
-        rowx[li - 1] = 0; rowx[lj - 1] = 0; rowy[lj - 1] = 0;
-        dif[abs(li - lj)] = 0;
-        sum[li + lj - 2] = 0;
-      }
+        if (need_rows) { rowx[li - 1] = 0; rowx[lj - 1] = 0; rowy[lj - 1] = 0; }
+        if (need_dif) dif[abs(li - lj)] = 0;
+        if (need_sum) sum[li + lj - 2] = 0;
+            });
     }
 
     // ---- reduce, average over non-empty angles, store ----
     const double nan = __longlong_as_double(0x7ff8000000000000LL);
     const double invA = n_angles ? 1.0 / (double)n_angles : nan;
+#pragma unroll
     for (int f = 0; f < VF_COUNT; f++) {
-      if (!(feat_mask & (1u << f))) continue;
+      if (!PRAD_WANT(f)) continue;
       double val;
       if (f == VF_Correlation) val = u_corr * invA;
       else if (f == VF_DifferenceVariance) val = u_dv * invA;
@@ -267,9 +316,15 @@ __global__ void __launch_bounds__(64 * PRAD_VOX_WAVES) voxel_glcm_kernel(
     if (lane == 0) {
       empty_mask[v] = emask;
       const unsigned nonempty = ~emask & (A.na >= 32 ? 0xffffffffu : ((1u << A.na) - 1u));
-      if (nonempty) atomicOr(any_nonempty, nonempty);
+      // (once per NEW bit and wave: one atomic per centre on this single word serialised the whole map in L2 -- 16.7 M
+      // same-address atomics took as long as the kernel's 190 ms)
+      if (nonempty & ~reported) {
+        atomicOr(any_nonempty, nonempty & ~reported);
+        reported |= nonempty;
+      }
     }
   }
+#undef PRAD_WANT
 }
 
 }  // namespace prad

@@ -1015,10 +1015,17 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
     const size_t lds = sizeof(u32) * PRAD_VOX_WAVES * ((size_t)Ng * Ng + 5 * (size_t)Ng + 1);
     const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((long long)Nvox + PRAD_VOX_WAVES - 1) / PRAD_VOX_WAVES,
                                                                            (long long)cu_count() * 8));
-    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(voxel_glcm_kernel, dim3(gx), dim3(64 * PRAD_VOX_WAVES), lds, s, levels, dims[0], dims[1], dims[2],
-                       A, Ng, Nvox, voxels, Nd, kernelRadius, f2d3, symmetric, fmask, slot_d, out, em, an, flags);
+    if ((fmask & ~PRAD_VF_LIGHT) == 0) {
+      PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_kernel<PRAD_VF_LIGHT>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(voxel_glcm_kernel<PRAD_VF_LIGHT>, dim3(gx), dim3(64 * PRAD_VOX_WAVES), lds, s, levels, dims[0], dims[1],
+                         dims[2], A, Ng, Nvox, voxels, Nd, kernelRadius, f2d3, symmetric, fmask, slot_d, out, em, an, flags);
+    } else {
+      PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_kernel<0xffffffffu>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(voxel_glcm_kernel<0xffffffffu>, dim3(gx), dim3(64 * PRAD_VOX_WAVES), lds, s, levels, dims[0], dims[1],
+                         dims[2], A, Ng, Nvox, voxels, Nd, kernelRadius, f2d3, symmetric, fmask, slot_d, out, em, an, flags);
+    }
     PRAD_TRY(check_launch("voxel_glcm_kernel"));
   }
   void *fh = nullptr;
