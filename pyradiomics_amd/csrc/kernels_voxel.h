@@ -327,4 +327,132 @@ __global__ void __launch_bounds__(64 * PRAD_VOX_WAVES) voxel_glcm_kernel(
 #undef PRAD_WANT
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The usual voxel-map requests (JointEntropy / JointEnergy / MaximumProbability / JointAverage: PRAD_VF_LIGHT) on windows
+// of at most 64 voxels (every 2-D window up to 7x7, 3^3): the general kernel above spent ~1 060 VALU instructions per
+// centre on them, most of it fp64 log2 / division sequences and DPP reduction chains.  Here
+//   * every sum over matrix ENTRIES is written per pair OCCURRENCE without a division: an entry of count c out of T pairs
+//     is met c / w times, so  -sum_entries p log2(p + eps) = -(w / T) sum_occurrences log2(c / T + eps)  and
+//     sum_entries p^2 = (w / T^2) sum_occurrences c;
+//   * log2(c / T + eps) = LG[c] - LG[T] + eps T / (c ln 2) with LG[n] = log2(n) tabulated for n <= 256 (c and T are
+//     small integers; the first-order term in eps is exact to ~1e-30);
+//   * the pair count of an angle is a ballot popcount; one DPP reduction per requested feature at the very end;
+//   * the window decomposition (integer divisions) is redone only when the window's extents change (the map's border).
+// One lane per window voxel; bit-compatible with nothing (float sums in another order): within 1e-12 of the general kernel.
+__global__ void __launch_bounds__(64 * PRAD_VOX_WAVES) voxel_glcm_light_kernel(
+    const uint8_t *__restrict__ L, int Nz, int Ny, int Nx, VoxAngles A, int Ng, int nvox,
+    const int *__restrict__ voxels, int vox_nd, int radius, int f2d3, int symmetric, unsigned feat_mask,
+    const int *__restrict__ feat_slot, double *__restrict__ out, unsigned *__restrict__ empty_mask,
+    unsigned *__restrict__ any_nonempty, const int *__restrict__ flags) {
+  extern __shared__ u32 lds[];
+  if (flags[0]) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double *LG = reinterpret_cast<double *>(lds);          // [257] log2(n), [0] unused
+  double *RC = LG + 257;                                 // [257] 1 / n
+  u32 *tab = reinterpret_cast<u32 *>(RC + 257) + (size_t)wave * Ng * Ng;
+  for (int i = threadIdx.x; i < 257; i += blockDim.x) {
+    LG[i] = i ? log2((double)i) : 0.0;
+    RC[i] = i ? 1.0 / (double)i : 0.0;
+  }
+  for (int i = lane; i < Ng * Ng; i += 64) tab[i] = 0;
+  __syncthreads();
+  const bool sym = symmetric != 0;
+  const int w = sym ? 2 : 1;
+  const double eps_ln2 = 2.220446049250313e-16 / 0.6931471805599453;
+  const bool want_ent = (feat_mask >> VF_JointEntropy) & 1u, want_en = (feat_mask >> VF_JointEnergy) & 1u;
+  const bool want_max = (feat_mask >> VF_MaximumProbability) & 1u, want_ja = (feat_mask >> VF_JointAverage) & 1u;
+  unsigned reported = 0;
+  int pe0 = -1, pe1 = -1, pe2 = -1;      // extents the cached decomposition belongs to
+  int kx = 0, ky = 0, kz = 0;
+  for (int v = blockIdx.x * PRAD_VOX_WAVES + wave; v < nvox; v += gridDim.x * PRAD_VOX_WAVES) {
+    int c[3] = {0, 0, 0};
+    for (int d = 0; d < vox_nd; d++) c[3 - vox_nd + d] = voxels[(long long)d * nvox + v];
+    const int dims[3] = {Nz, Ny, Nx};
+    int lo[3], ext[3];
+    for (int d = 0; d < 3; d++) {
+      if (d == f2d3 || d < 3 - vox_nd) { lo[d] = c[d]; ext[d] = 1; }
+      else {
+        lo[d] = max(c[d] - radius, 0);
+        ext[d] = min(c[d] + radius, dims[d] - 1) - lo[d] + 1;
+      }
+    }
+    const int W = ext[0] * ext[1] * ext[2];
+    if (ext[0] != pe0 || ext[1] != pe1 || ext[2] != pe2) {   // (wave-uniform)
+      kx = lane % ext[2];
+      const int kr = lane / ext[2];
+      ky = kr % ext[1];
+      kz = kr / ext[1];
+      pe0 = ext[0]; pe1 = ext[1]; pe2 = ext[2];
+    }
+    const uint8_t *base = L + ((long long)lo[0] * Ny + lo[1]) * Nx + lo[2];
+    const int li = lane < W ? (int)base[((long long)kz * Ny + ky) * Nx + kx] : 0;
+    double a_ent = 0, a_en = 0, u_max = 0, u_ja = 0;
+    int n_angles = 0;
+    unsigned emask = 0;
+    for (int a = 0; a < A.na; a++) {
+      const int qz = kz + A.o[a][0], qy = ky + A.o[a][1], qx = kx + A.o[a][2];
+      const bool inb = li != 0 && (unsigned)qz < (unsigned)ext[0] && (unsigned)qy < (unsigned)ext[1] && (unsigned)qx < (unsigned)ext[2];
+      const int lj = inb ? (int)base[((long long)qz * Ny + qy) * Nx + qx] : 0;
+      const bool pair = lj != 0;
+      const int np = __popcll(__ballot(pair));
+      if (np == 0) { emask |= 1u << a; continue; }
+      const int e1 = (li - 1) * Ng + (lj - 1), e2 = (lj - 1) * Ng + (li - 1);
+      if (pair) {
+        atomicAdd(&tab[e1], 1u);
+        if (sym) atomicAdd(&tab[e2], 1u);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int T = w * np;
+      const double iT = RC[T];           // (T <= 2 * 64)
+      n_angles++;
+      const int cnt = pair ? (int)tab[e1] : 0;
+      if (pair) {
+        if (want_ent) a_ent -= ((double)w * iT) * (LG[cnt] - LG[T] + eps_ln2 * (double)T * RC[cnt]);
+        if (want_en) a_en += ((double)w * iT * iT) * (double)cnt;
+      }
+      if (want_max) {
+        int m = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+        u_max += (double)m * iT;
+      }
+      if (want_ja) {
+        int sij = pair ? (sym ? li + lj : li) : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sij += __shfl_xor(sij, o);
+        u_ja += (double)sij * iT;          // sym: (si + sj) / (2 np); else si / np
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (pair) {
+        tab[e1] = 0;
+        tab[e2] = 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    const double nan = __longlong_as_double(0x7ff8000000000000LL);
+    const double invA = n_angles ? 1.0 / (double)n_angles : nan;
+    if (want_ent) {
+      const double r = wave_sum_f64(a_ent) * invA;
+      if (lane == 0) out[(size_t)feat_slot[VF_JointEntropy] * nvox + v] = r;
+    }
+    if (want_en) {
+      const double r = wave_sum_f64(a_en) * invA;
+      if (lane == 0) out[(size_t)feat_slot[VF_JointEnergy] * nvox + v] = r;
+    }
+    if (lane == 0) {
+      if (want_max) out[(size_t)feat_slot[VF_MaximumProbability] * nvox + v] = u_max * invA;
+      if (want_ja) out[(size_t)feat_slot[VF_JointAverage] * nvox + v] = u_ja * invA;
+      empty_mask[v] = emask;
+      const unsigned nonempty = ~emask & (A.na >= 32 ? 0xffffffffu : ((1u << A.na) - 1u));
+      if (nonempty & ~reported) {
+        atomicOr(any_nonempty, nonempty & ~reported);
+        reported |= nonempty;
+      }
+    }
+  }
+}
+
 }  // namespace prad

@@ -1015,7 +1015,16 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
     const size_t lds = sizeof(u32) * PRAD_VOX_WAVES * ((size_t)Ng * Ng + 5 * (size_t)Ng + 1);
     const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((long long)Nvox + PRAD_VOX_WAVES - 1) / PRAD_VOX_WAVES,
                                                                            (long long)cu_count() * 8));
-    if ((fmask & ~PRAD_VF_LIGHT) == 0) {
+    long long wmax = 1;                       // largest window of the call
+    for (int d = 0; d < 3; d++)
+      if (d != f2d3 && d >= 3 - Nd) wmax *= std::min(2 * kernelRadius + 1, dims[d]);
+    if ((fmask & ~PRAD_VF_LIGHT) == 0 && wmax <= 64 && !getenv("PRAD_VOX_NO_LIGHT")) {
+      const size_t lds2 = sizeof(double) * 2 * 257 + sizeof(u32) * PRAD_VOX_WAVES * (size_t)Ng * Ng;
+      PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_light_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+      hipLaunchKernelGGL(voxel_glcm_light_kernel, dim3(gx), dim3(64 * PRAD_VOX_WAVES), lds2, s, levels, dims[0], dims[1],
+                         dims[2], A, Ng, Nvox, voxels, Nd, kernelRadius, f2d3, symmetric, fmask, slot_d, out, em, an, flags);
+    } else if ((fmask & ~PRAD_VF_LIGHT) == 0) {
       PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_kernel<PRAD_VF_LIGHT>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(voxel_glcm_kernel<PRAD_VF_LIGHT>, dim3(gx), dim3(64 * PRAD_VOX_WAVES), lds, s, levels, dims[0], dims[1],

@@ -303,3 +303,29 @@ def test_segment_mcc_on_the_device_and_special_cases():
             assert got[a] == pytest.approx(want, rel=1e-9, abs=1e-12), (Ng, a, got[a], want)
     with pytest.raises(NotImplementedError):          # more than 64 grey levels occur: host route
         engine.glcm_mcc(torch.from_numpy(rng.integers(1, 9, size=(80, 80, 1)).astype(np.float64)).cuda(), True)
+
+
+@pytest.mark.parametrize("force2D,radius,symmetrical", [(True, 2, True), (True, 3, True), (False, 1, True), (True, 2, False),
+                                                       (False, 1, False)])
+def test_light_voxel_glcm_kernel_equals_the_general_one(force2D, radius, symmetrical, monkeypatch):
+    """the entropy / energy / maximum / average maps take a kernel of their own on windows of at most 64 voxels
+    (division-free occurrence sums, tabulated log2): same maps as the general kernel within 1e-12, on a masked volume
+    with holes (empty angles, partial windows at the border)"""
+    import torch
+    from pyradiomics_amd import engine
+    rng = np.random.default_rng(11)
+    shape = (18, 40, 44)
+    img = rng.integers(1, 17, shape).astype(np.int32)
+    msk = (rng.random(shape) < 0.8).astype(np.uint8)
+    msk[5:9, 10:20, 12:30] = 0                       # a hole larger than the window: centres with no pair at all
+    di, dm = torch.from_numpy(img).cuda(), torch.from_numpy(msk).cuda()
+    vox = torch.nonzero(dm).T.to(torch.int32).contiguous()
+    feats = ["JointEntropy", "JointEnergy", "MaximumProbability", "JointAverage"]
+    kw = dict(kernelRadius=radius, force2D=force2D, force2Ddimension=0, symmetrical=symmetrical)
+    light = {k: v.cpu().numpy() for k, v in engine.voxel_glcm_features(di, dm, 16, vox, feats, **kw).items()}
+    one = engine.voxel_glcm_features(di, dm, 16, vox, ["JointEntropy"], **kw)["JointEntropy"].cpu().numpy()
+    monkeypatch.setenv("PRAD_VOX_NO_LIGHT", "1")
+    gen = {k: v.cpu().numpy() for k, v in engine.voxel_glcm_features(di, dm, 16, vox, feats, **kw).items()}
+    for k in feats:
+        np.testing.assert_allclose(light[k], gen[k], rtol=1e-12, atol=1e-13, equal_nan=True, err_msg=k)
+    np.testing.assert_array_equal(one, light["JointEntropy"])
