@@ -175,3 +175,27 @@ def test_deferred_lanes_agree(cm, lanes):
         engine.set_lanes(0)
     with pytest.raises(ValueError):
         engine.set_lanes(9)
+
+
+def test_lanes_survive_a_workspace_release_and_mixed_sizes(cm):
+    """deferred volumes of alternating shapes (every call re-plans and regrows its lane's workspace), a workspace
+    release between two deferred batches, a synchronous call in between: all results equal the synchronous ones"""
+    import torch
+    from pyradiomics_amd import engine
+    Ng = 16
+    shapes = [(20, 24, 512), (33, 21, 128), (20, 24, 512), (12, 50, 300), (40, 40, 64), (33, 21, 128)]
+    vols = [(torch.from_numpy(_levels(30 + i, s, Ng, "blobs")).cuda(), torch.from_numpy(_mask(40 + i, s, "random").astype(np.uint8)).cuda())
+            for i, s in enumerate(shapes)]
+    want = []
+    for i, m in vols:
+        g, r, _ = engine.glcm_glrlm(i, m, Ng, 512)
+        want.append((g.clone(), r.clone()))
+    for round_ in range(2):
+        got = [engine.glcm_glrlm(i, m, Ng, 512, deferred=True) for i, m in vols[:3]]
+        g_sync, r_sync, _ = engine.glcm_glrlm(vols[4][0], vols[4][1], Ng, 512)        # a synchronous call in between
+        got += [engine.glcm_glrlm(i, m, Ng, 512, deferred=True) for i, m in vols[3:]]
+        engine.deferred_status()
+        assert torch.equal(g_sync, want[4][0]) and torch.equal(r_sync, want[4][1])
+        for (g, r, _), (eg, er) in zip(got, want):
+            assert torch.equal(g, eg) and torch.equal(r, er)
+        engine.release_workspace()
