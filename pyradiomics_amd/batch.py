@@ -213,16 +213,18 @@ def replicate_volume(image, mask, src: int = 0, device=None):
         levels = torch.where(mask.bool(), image, torch.zeros_like(image))
         lo, hi = int(levels.min()), int(levels.max())
         narrow = lo >= 0 and hi <= 255
-        head = [(tuple(image.shape), narrow)]
+        # a voxel inside the mask with level 0 is an input error the matrix calls must still see (IndexError): it
+        # cannot be told apart from "outside" in the packed form, so it is refused -- on EVERY rank, through the
+        # header, before anybody waits in the data broadcast
+        bad = bool(((levels == 0) & mask.bool()).any())
+        head = [(tuple(image.shape), narrow, bad)]
     dist.broadcast_object_list(head, src=src)
-    shape, narrow = head[0]
+    shape, narrow, bad = head[0]
+    if bad:
+        raise IndexError("level 0 under the mask")
     dtype = torch.uint8 if narrow else torch.int32
     if rank == src:
         packed = levels.to(dtype).contiguous()
-        # a voxel inside the mask with level 0 is an input error the matrix calls must still see (IndexError):
-        # it cannot be told apart from "outside" in the packed form, so it is refused here
-        if bool(((levels == 0) & mask.bool()).any()):
-            raise IndexError("level 0 under the mask")
     else:
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu"

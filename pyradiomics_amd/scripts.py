@@ -161,8 +161,10 @@ def extract_segment(case_idx, case, extractor, out_dir=None):
     try:
         t = time.perf_counter()
         label = case.get("Label") or None
+        channel = case.get("Label_channel") or None       # scripts/segment.py:60-66: both columns override the parameter file
         fv.update((k, _scalar(v)) for k, v in extractor.execute(case["Image"], case["Mask"],
-                                                                int(label) if label is not None else None).items())
+                                                                int(label) if label is not None else None,
+                                                                int(channel) if channel is not None else None).items())
         logger.info("Case %s processed in %.3f s", case_idx, time.perf_counter() - t)
     except (KeyboardInterrupt, SystemExit):
         raise
@@ -187,8 +189,9 @@ def extract_voxel(case_idx, case, extractor, out_dir=None, unix_path=False):
         os.makedirs(out_dir, exist_ok=True)
         t = time.perf_counter()
         label = case.get("Label") or None
+        channel = case.get("Label_channel") or None
         result = extractor.execute(case["Image"], case["Mask"], int(label) if label is not None else None,
-                                   voxelBased=True)
+                                   int(channel) if channel is not None else None, voxelBased=True)
         for k, v in result.items():
             if isinstance(v, Image):
                 target = os.path.join(out_dir, "Case-%d_%s.nrrd" % (case_idx, k))
