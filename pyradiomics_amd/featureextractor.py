@@ -214,7 +214,8 @@ class RadiomicsFeatureExtractor:
             describe("original", image, mask)
         if s.get("normalize", False):                  # featureextractor.py:432-433: before anything else sees the image
             image = imageoperations.normalizeImage(image, **s)
-        if s.get("resampledPixelSpacing") is not None:  # :436-440
+        # :436-440 (the reference's loadImage only resamples when BOTH the spacing and an interpolator are given)
+        if s.get("resampledPixelSpacing") is not None and s.get("interpolator") is not None:
             if not np.any(mask.array == label):
                 raise ValueError("Label (%g) not present in mask" % label)
             image, mask = imageoperations.resampleImage(image, mask, **s)

@@ -224,6 +224,10 @@ def process_cases(cases, param, overrides, mode="segment", jobs=1, gpus=None, ou
     work = [(i, c, mode, out_dir, unix_path) for i, c in cases]
     if jobs == 1:
         from .featureextractor import RadiomicsFeatureExtractor
+        if gpus:                                   # --gpus with a single job: that GPU, not whichever is current
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.set_device(int(gpus[0]))
         _WORKER["extractor"] = RadiomicsFeatureExtractor(param, **overrides) if param else RadiomicsFeatureExtractor(**overrides)
         return [_run_case(w)[1] for w in work]
     import multiprocessing as mp
