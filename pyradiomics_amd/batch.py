@@ -47,13 +47,17 @@ def _run_threaded(indices, cases, worker, threads: int):
     for i in indices:
         todo.put(i)
     out, errors = {}, []
+    try:
+        import torch
+        parent_dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    except ImportError:
+        torch, parent_dev = None, None
 
     def loop():
-        try:
-            import torch
-            ctx = torch.cuda.stream(torch.cuda.Stream()) if torch.cuda.is_available() else None
-        except ImportError:
-            ctx = None
+        ctx = None
+        if parent_dev is not None:
+            torch.cuda.set_device(parent_dev)      # torch's current device is per thread: stay on this rank's GPU
+            ctx = torch.cuda.stream(torch.cuda.Stream())
         if ctx is not None:
             ctx.__enter__()
         try:
