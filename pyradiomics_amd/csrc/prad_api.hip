@@ -1391,7 +1391,12 @@ int prad_set_device(int device) {
   if (device < 0 || device >= n) return fail(PRAD_E_ARG, "device %d not in [0,%d)", device, n);
   Context &c = ctx();
   if (c.device != device) {
-    c.own_stream = nullptr;  // streams belong to a device; a new one is created lazily
+    c.own_stream = nullptr;  // streams belong to a device; new ones are created lazily
+    for (int l = 0; l < PRAD_MAX_LANES; l++) {
+      if (c.lane_stream[l]) (void)hipStreamSynchronize(c.lane_stream[l]);
+      c.lane_stream[l] = nullptr;
+      c.lane_in[l] = nullptr;
+    }
     c.event_pool.clear();
     c.events_used = 0;
   }
