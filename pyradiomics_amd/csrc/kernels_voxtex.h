@@ -8,7 +8,7 @@
 //     GLRLM  items = runs along one angle              (i = level, j = run length), per angle, then the mean over
 //                                                      the non-empty angles (np.nanmean, e.g. glrlm.py:225)
 //     GLSZM  items = zones (connected components)      (i = level, j = zone size)
-// Every feature of these three classes is a function of the same sums over items (zl_reduce): sums over matrix
+// Every feature of these three classes is a function of the same sums over items (zl_accumulate): sums over matrix
 // ENTRIES such as sum_i pg(i)^2 or -sum p log2 p are produced per item through the item's multiplicity (number of
 // items sharing its level / its j / both), so the mostly empty matrix is never formed.
 //     NGTDM  per-level n_i and s_i (s_i summed in raster order like cmatrices.c:637-652, hence bit-identical),
@@ -62,34 +62,44 @@ __device__ __forceinline__ int vt_shift(const VtWindow &w, int k, const signed c
   return (qz * w.ext[1] + qy) * w.ext[2] + qx;
 }
 
-// ---- sums over an item list (i, j) -----------------------------------------------------------------------
-struct ZlSums {
-  double n;                       // items
-  double inv_j2, j2, j1;          // sum 1/j^2, j^2, j
-  double i2, inv_i2;              // sum i^2, 1/i^2
-  double c1, c2, c3, c4;          // sum 1/(i^2 j^2), i^2/j^2, j^2/i^2, i^2 j^2
-  double mg, mj, ent;             // sum_i pg^2, sum_j pj^2, -sum p log2(p + eps)   (through multiplicities)
-  double var_i, var_j;            // sum (i - mean i)^2 / n, sum (j - mean j)^2 / n
+// ---- features of an item list (i, j) -----------------------------------------------------------------------
+// feature numbering shared by GLRLM / GLSZM / GLDM (names in pyradiomics_amd/cmatrices.py)
+enum { ZF_SmallEmphasis = 0, ZF_LargeEmphasis, ZF_GrayLevelNonUniformity, ZF_GrayLevelNonUniformityNormalized,
+       ZF_SizeNonUniformity, ZF_SizeNonUniformityNormalized, ZF_Percentage, ZF_GrayLevelVariance, ZF_SizeVariance,
+       ZF_Entropy, ZF_LowGrayLevelEmphasis, ZF_HighGrayLevelEmphasis, ZF_SmallLowGrayLevelEmphasis,
+       ZF_SmallHighGrayLevelEmphasis, ZF_LargeLowGrayLevelEmphasis, ZF_LargeHighGrayLevelEmphasis, ZF_COUNT };
+
+// tables in global memory (12 KB, cache-resident; in LDS they cost the kernel two of its five workgroups per CU):
+// n = 0 .. PRAD_VT_MAXW  ->  log2(n), 1 / n, 1 / n^2
+#define PRAD_VT_TAB (PRAD_VT_MAXW + 1)
+struct ZlTables {
+  const double *lg, *rc, *rc2;
 };
 
-__device__ __forceinline__ ZlSums zl_reduce(const int *it_i, const int *it_j, int n, int lane) {
-  ZlSums s;
-  double a_inv_j2 = 0, a_j2 = 0, a_j1 = 0, a_i1 = 0, a_i2 = 0, a_inv_i2 = 0, a_c1 = 0, a_c2 = 0, a_c3 = 0, a_c4 = 0,
-         a_mg = 0, a_mj = 0, a_ent = 0;
-  const double nd = (double)n;
+// Adds the 16 features of one item list (one angle of GLRLM; the whole window for GLDM / GLSZM) to acc[] -- as PER-LANE
+// partial sums: every feature but Percentage is (a sum over items) / n or / n^2, so the lane's terms are scaled by the
+// list's 1 / n right away and ONE wave reduction per feature at the end of the centre serves all lists (13 angles used to
+// mean 13 x 14 fp64 DPP chains and 13 x 16 divisions by every lane).  Only the two means need a reduction per list, and
+// they are integer sums.  1 / i^2, 1 / j^2 come from a table; log2(m / n + eps) = lg[m] - lg[n] + eps n / (m ln 2) (m, n
+// small integers; first order in eps is exact to 1e-30).  Percentage (n / sum j) is added on lane 0.
+__device__ __forceinline__ void zl_accumulate(const int *it_i, const int *it_j, int n, int lane, const ZlTables &T,
+                                              double (&acc)[ZF_COUNT]) {
+  const double nd = (double)n, inv_n = T.rc[n], inv_n2 = inv_n * inv_n;
+  const double eps_n_ln2 = (2.220446049250313e-16 / 0.6931471805599453) * nd;
+  int si = 0, sj = 0;
+  for (int k = lane; k < n; k += 64) {
+    si += it_i[k];
+    sj += it_j[k];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    si += __shfl_xor(si, o);
+    sj += __shfl_xor(sj, o);
+  }
+  const double ui = (double)si / nd, uj = (double)sj / nd;
   for (int k = lane; k < n; k += 64) {
     const int ii = it_i[k], jj = it_j[k];
-    const double i = (double)ii, j = (double)jj, i2 = i * i, j2 = j * j;
-    a_inv_j2 += 1.0 / j2;
-    a_j2 += j2;
-    a_j1 += j;
-    a_i1 += i;
-    a_i2 += i2;
-    a_inv_i2 += 1.0 / i2;
-    a_c1 += 1.0 / (i2 * j2);
-    a_c2 += i2 / j2;
-    a_c3 += j2 / i2;
-    a_c4 += i2 * j2;
+    const double i = (double)ii, j = (double)jj, i2 = i * i, j2 = j * j, ri = T.rc2[ii], rj = T.rc2[jj];
     int same_i = 0, same_j = 0, same_ij = 0;
     for (int q = 0; q < n; q++) {
       const bool ei = it_i[q] == ii, ej = it_j[q] == jj;
@@ -97,63 +107,24 @@ __device__ __forceinline__ ZlSums zl_reduce(const int *it_i, const int *it_j, in
       same_j += ej;
       same_ij += ei && ej;
     }
-    a_mg += (double)same_i;
-    a_mj += (double)same_j;
-    a_ent += log2((double)same_ij / nd + 2.220446049250313e-16);
+    const double di = i - ui, dj = j - uj;
+    acc[ZF_SmallEmphasis] += rj * inv_n;
+    acc[ZF_LargeEmphasis] += j2 * inv_n;
+    acc[ZF_GrayLevelNonUniformity] += (double)same_i * inv_n;
+    acc[ZF_GrayLevelNonUniformityNormalized] += (double)same_i * inv_n2;
+    acc[ZF_SizeNonUniformity] += (double)same_j * inv_n;
+    acc[ZF_SizeNonUniformityNormalized] += (double)same_j * inv_n2;
+    acc[ZF_GrayLevelVariance] += di * di * inv_n;
+    acc[ZF_SizeVariance] += dj * dj * inv_n;
+    acc[ZF_Entropy] -= (T.lg[same_ij] - T.lg[n] + eps_n_ln2 * T.rc[same_ij]) * inv_n;
+    acc[ZF_LowGrayLevelEmphasis] += ri * inv_n;
+    acc[ZF_HighGrayLevelEmphasis] += i2 * inv_n;
+    acc[ZF_SmallLowGrayLevelEmphasis] += ri * rj * inv_n;
+    acc[ZF_SmallHighGrayLevelEmphasis] += i2 * rj * inv_n;
+    acc[ZF_LargeLowGrayLevelEmphasis] += j2 * ri * inv_n;
+    acc[ZF_LargeHighGrayLevelEmphasis] += i2 * j2 * inv_n;
   }
-  s.n = nd;
-  s.inv_j2 = wave_sum_f64(a_inv_j2);
-  s.j2 = wave_sum_f64(a_j2);
-  s.j1 = wave_sum_f64(a_j1);
-  const double i1 = wave_sum_f64(a_i1);
-  s.i2 = wave_sum_f64(a_i2);
-  s.inv_i2 = wave_sum_f64(a_inv_i2);
-  s.c1 = wave_sum_f64(a_c1);
-  s.c2 = wave_sum_f64(a_c2);
-  s.c3 = wave_sum_f64(a_c3);
-  s.c4 = wave_sum_f64(a_c4);
-  s.mg = wave_sum_f64(a_mg);
-  s.mj = wave_sum_f64(a_mj);
-  s.ent = -wave_sum_f64(a_ent) / nd;
-  const double ui = i1 / nd, uj = s.j1 / nd;
-  double vi = 0, vj = 0;
-  for (int k = lane; k < n; k += 64) {
-    const double di = (double)it_i[k] - ui, dj = (double)it_j[k] - uj;
-    vi += di * di;
-    vj += dj * dj;
-  }
-  s.var_i = wave_sum_f64(vi) / nd;
-  s.var_j = wave_sum_f64(vj) / nd;
-  return s;
-}
-
-// feature numbering shared by GLRLM / GLSZM / GLDM (names in pyradiomics_amd/cmatrices.py)
-enum { ZF_SmallEmphasis = 0, ZF_LargeEmphasis, ZF_GrayLevelNonUniformity, ZF_GrayLevelNonUniformityNormalized,
-       ZF_SizeNonUniformity, ZF_SizeNonUniformityNormalized, ZF_Percentage, ZF_GrayLevelVariance, ZF_SizeVariance,
-       ZF_Entropy, ZF_LowGrayLevelEmphasis, ZF_HighGrayLevelEmphasis, ZF_SmallLowGrayLevelEmphasis,
-       ZF_SmallHighGrayLevelEmphasis, ZF_LargeLowGrayLevelEmphasis, ZF_LargeHighGrayLevelEmphasis, ZF_COUNT };
-
-__device__ __forceinline__ double zl_feature(const ZlSums &s, int f) {
-  const double n = s.n;
-  switch (f) {
-    case ZF_SmallEmphasis: return s.inv_j2 / n;
-    case ZF_LargeEmphasis: return s.j2 / n;
-    case ZF_GrayLevelNonUniformity: return s.mg / n;
-    case ZF_GrayLevelNonUniformityNormalized: return s.mg / (n * n);
-    case ZF_SizeNonUniformity: return s.mj / n;
-    case ZF_SizeNonUniformityNormalized: return s.mj / (n * n);
-    case ZF_Percentage: return n / s.j1;
-    case ZF_GrayLevelVariance: return s.var_i;
-    case ZF_SizeVariance: return s.var_j;
-    case ZF_Entropy: return s.ent;
-    case ZF_LowGrayLevelEmphasis: return s.inv_i2 / n;
-    case ZF_HighGrayLevelEmphasis: return s.i2 / n;
-    case ZF_SmallLowGrayLevelEmphasis: return s.c1 / n;
-    case ZF_SmallHighGrayLevelEmphasis: return s.c2 / n;
-    case ZF_LargeLowGrayLevelEmphasis: return s.c3 / n;
-    case ZF_LargeHighGrayLevelEmphasis: return s.c4 / n;
-  }
-  return __builtin_nan("");
+  if (lane == 0) acc[ZF_Percentage] += nd / (double)sj;
 }
 
 // append `flag` lanes' (i, j) to the item list; returns the new length (wave-uniform)
@@ -174,10 +145,11 @@ __device__ __forceinline__ int vt_append(int *it_i, int *it_j, int n, bool flag,
 __global__ void __launch_bounds__(64 * PRAD_VT_WAVES) voxel_zonelike_kernel(
     int family, const uint8_t *__restrict__ L, int Nz, int Ny, int Nx, VoxAngles A, int alpha, int nvox,
     const int *__restrict__ voxels, int vox_nd, int radius, int f2d3, const int *__restrict__ feature_ids, int nfeat,
-    double *__restrict__ out, const int *__restrict__ flags) {
+    double *__restrict__ out, const int *__restrict__ flags, const double *__restrict__ tabs) {
   __shared__ int lds[PRAD_VT_WAVES * PRAD_VT_LDS_PER_WAVE];
   if (flags[0]) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const ZlTables T{tabs, tabs + PRAD_VT_TAB, tabs + 2 * PRAD_VT_TAB};
   int *wl = lds + wave * PRAD_VT_LDS_PER_WAVE, *it_i = wl + PRAD_VT_MAXW, *it_j = it_i + PRAD_VT_MAXW,
       *aux = it_j + PRAD_VT_MAXW;
   for (int v = blockIdx.x * PRAD_VT_WAVES + wave; v < nvox; v += gridDim.x * PRAD_VT_WAVES) {
@@ -206,8 +178,7 @@ __global__ void __launch_bounds__(64 * PRAD_VT_WAVES) voxel_zonelike_kernel(
       }
       __builtin_amdgcn_wave_barrier();
       if (n) {
-        const ZlSums s = zl_reduce(it_i, it_j, n, lane);
-        for (int f = 0; f < ZF_COUNT; f++) acc[f] = zl_feature(s, f);
+        zl_accumulate(it_i, it_j, n, lane, T, acc);
         groups = 1;
       }
     } else if (family == PRAD_VT_GLRLM) {
@@ -240,8 +211,7 @@ __global__ void __launch_bounds__(64 * PRAD_VT_WAVES) voxel_zonelike_kernel(
         // cmatrices.c:524-534: no line of this angle holds more than one ROI voxel -> its run-length-1 column (all it
         // can contain) is zeroed: the angle is empty
         if (__ballot(multi) == 0ull || n == 0) continue;
-        const ZlSums s = zl_reduce(it_i, it_j, n, lane);
-        for (int f = 0; f < ZF_COUNT; f++) acc[f] += zl_feature(s, f);
+        zl_accumulate(it_i, it_j, n, lane, T, acc);
         groups++;
         __builtin_amdgcn_wave_barrier();
       }
@@ -284,17 +254,25 @@ __global__ void __launch_bounds__(64 * PRAD_VT_WAVES) voxel_zonelike_kernel(
         __builtin_amdgcn_wave_barrier();
       }
       if (n) {
-        const ZlSums s = zl_reduce(it_i, it_j, n, lane);
-        for (int f = 0; f < ZF_COUNT; f++) acc[f] = zl_feature(s, f);
+        zl_accumulate(it_i, it_j, n, lane, T, acc);
         groups = 1;
       }
     }
+    // one reduction per requested feature (acc[] holds per-lane partial sums); static indices keep acc[] in registers
+    unsigned want = 0;
+    for (int f = 0; f < nfeat; f++) want |= 1u << feature_ids[f];
+    double red[ZF_COUNT];
+#pragma unroll
+    for (int id = 0; id < ZF_COUNT; id++) red[id] = ((want >> id) & 1u) ? wave_sum_f64(acc[id]) : 0.0;
     if (lane == 0) {
       for (int f = 0; f < nfeat; f++) {
         const int id = feature_ids[f];
+        double val = 0.0;
+#pragma unroll
+        for (int q = 0; q < ZF_COUNT; q++) val = q == id ? red[q] : val;
         double r;
         if (groups == 0) r = family == PRAD_VT_GLRLM ? __builtin_nan("") : 0.0;
-        else r = acc[id] / (double)groups;
+        else r = val / (double)groups;
         out[(long long)f * nvox + v] = r;
       }
     }

@@ -1149,8 +1149,20 @@ int voxel_texture_features_dev(int family, const int32_t *image, const uint8_t *
                          Ng, Nvox, voxels, Nd, kernelRadius, f2d3, ids_d, nfeat, out, flags);
       PRAD_TRY(check_launch("voxel_ngtdm_kernel"));
     } else {
+      double *tabs = nullptr;          // log2(n), 1 / n, 1 / n^2 for n <= PRAD_VT_MAXW (kernels_voxtex.h zl_accumulate)
+      const bool fresh = !c.has("vt_tables");
+      PRAD_TRY(c.get<double>("vt_tables", 3 * PRAD_VT_TAB, &tabs));
+      if (fresh) {
+        std::vector<double> h(3 * PRAD_VT_TAB, 0.0);
+        for (int i = 1; i < PRAD_VT_TAB; i++) {
+          h[i] = log2((double)i);
+          h[PRAD_VT_TAB + i] = 1.0 / (double)i;
+          h[2 * PRAD_VT_TAB + i] = 1.0 / ((double)i * (double)i);
+        }
+        PRAD_HIP(hipMemcpy(tabs, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice));
+      }
       hipLaunchKernelGGL(voxel_zonelike_kernel, dim3(gx), dim3(64 * PRAD_VT_WAVES), 0, s, family, levels, dims[0], dims[1],
-                         dims[2], A, alpha, Nvox, voxels, Nd, kernelRadius, f2d3, ids_d, nfeat, out, flags);
+                         dims[2], A, alpha, Nvox, voxels, Nd, kernelRadius, f2d3, ids_d, nfeat, out, flags, (const double *)tabs);
       PRAD_TRY(check_launch("voxel_zonelike_kernel"));
     }
   }
