@@ -61,6 +61,25 @@ __device__ __forceinline__ int vt_shift(const VtWindow &w, int k, const signed c
   if ((unsigned)qz >= (unsigned)w.ext[0] || (unsigned)qy >= (unsigned)w.ext[1] || (unsigned)qx >= (unsigned)w.ext[2]) return -1;
   return (qz * w.ext[1] + qy) * w.ext[2] + qx;
 }
+// The same without the two integer divisions per call (a GLDM voxel asks for 26 neighbours, a GLRLM run walks its line
+// step by step): the voxel's coordinates once, then adds and bounds tests.
+struct VtPos {
+  int x, y, z;
+};
+__device__ __forceinline__ VtPos vt_pos(const VtWindow &w, int k) {
+  VtPos p;
+  p.x = k % w.ext[2];
+  const int kr = k / w.ext[2];
+  p.y = kr % w.ext[1];
+  p.z = kr / w.ext[1];
+  return p;
+}
+// index of p displaced by m * o, or -1 outside the window
+__device__ __forceinline__ int vt_at(const VtWindow &w, const VtPos &p, const signed char *o, int m = 1) {
+  const int qz = p.z + m * o[0], qy = p.y + m * o[1], qx = p.x + m * o[2];
+  if ((unsigned)qz >= (unsigned)w.ext[0] || (unsigned)qy >= (unsigned)w.ext[1] || (unsigned)qx >= (unsigned)w.ext[2]) return -1;
+  return (qz * w.ext[1] + qy) * w.ext[2] + qx;
+}
 
 // ---- features of an item list (i, j) -----------------------------------------------------------------------
 // feature numbering shared by GLRLM / GLSZM / GLDM (names in pyradiomics_amd/cmatrices.py)
@@ -166,8 +185,9 @@ __global__ void __launch_bounds__(64 * PRAD_VT_WAVES) voxel_zonelike_kernel(
         const int lv = k < w.W ? wl[k] : 0;
         int dep = 0;
         if (lv) {
+          const VtPos pk = vt_pos(w, k);
           for (int a = 0; a < A.na; a++) {
-            const int q = vt_shift(w, k, A.o[a]);
+            const int q = vt_at(w, pk, A.o[a]);
             if (q >= 0) {
               const int lq = wl[q];
               dep += (lq && abs(lq - lv) <= alpha) ? 1 : 0;
@@ -192,16 +212,20 @@ __global__ void __launch_bounds__(64 * PRAD_VT_WAVES) voxel_zonelike_kernel(
           bool start = false;
           int len = 0;
           if (lv) {
-            const int p = vt_shift(w, k, back);
+            const VtPos pk = vt_pos(w, k);
+            const int p = vt_at(w, pk, back);
             start = !(p >= 0 && wl[p] == lv);
-            int q = vt_shift(w, k, A.o[a]);
-            for (int t = q; t >= 0 && !multi; t = vt_shift(w, t, A.o[a]))   // a second ROI voxel further along this line
+            for (int m = 1; !multi; m++) {           // a second ROI voxel further along this line
+              const int t = vt_at(w, pk, A.o[a], m);
+              if (t < 0) break;
               multi = wl[t] != 0;
+            }
             if (start) {
               len = 1;
-              while (q >= 0 && wl[q] == lv) {
+              for (int m = 1;; m++) {
+                const int q = vt_at(w, pk, A.o[a], m);
+                if (q < 0 || wl[q] != lv) break;
                 len++;
-                q = vt_shift(w, q, A.o[a]);
               }
             }
           }
@@ -225,8 +249,9 @@ __global__ void __launch_bounds__(64 * PRAD_VT_WAVES) voxel_zonelike_kernel(
           const int lv = wl[k];
           if (!lv) continue;
           int best = aux[k];
+          const VtPos pk = vt_pos(w, k);
           for (int a = 0; a < A.na; a++) {
-            const int q = vt_shift(w, k, A.o[a]);
+            const int q = vt_at(w, pk, A.o[a]);
             if (q >= 0 && wl[q] == lv) best = min(best, aux[q]);
           }
           best = min(best, aux[best]);                 // one pointer jump
@@ -308,8 +333,9 @@ __global__ void __launch_bounds__(64 * PRAD_VT_WAVES) voxel_ngtdm_kernel(
       double diff = 0.0;
       if (lv) {
         int cnt = 0, sum = 0;
+        const VtPos pk = vt_pos(w, k);
         for (int a = 0; a < A.na; a++) {
-          const int q = vt_shift(w, k, A.o[a]);
+          const int q = vt_at(w, pk, A.o[a]);
           if (q >= 0 && wl[q]) {
             cnt++;
             sum += wl[q];
