@@ -299,19 +299,22 @@ __global__ void __launch_bounds__(64) rgauss_xline_kernel(const float *__restric
 // AM: 0 = plain float output, 1 = first Laplacian term (acc = v / sp2), 2 = later term (acc += v / sp2).  The phase
 // (partial into scratch / final) and AM are compile-time in every loop: with run-time flags the tile loop was a maze
 // of branches, each load group followed by its own wait.
-template <int W, int AM>
+// TL: lines per wave (64: every lane recurses; 32: half the lanes do, but a row piece is 32 samples = a full 128-byte
+// line per access at the LDS cost of 16-sample tiles, and a 256^3 volume gets 4 096 waves instead of 2 048)
+template <int W, int TL, int AM>
 __global__ void __launch_bounds__(128) rgauss_xline2_kernel(const float *__restrict__ in, long long lines, int ln,
                                                             RGaussCoef c, double *scratch, float *__restrict__ out,
                                                             float *__restrict__ acc, double sp2) {
 #pragma clang fp contract(off)
   constexpr int RPI = 64 / W;            // rows of W samples per wave instruction
-  __shared__ float tin_[2][PRAD_RG_T][W + 1];
-  __shared__ double tsc_[2][PRAD_RG_T][W + 1];
+  constexpr int NI = TL * W / 64;        // load / store instructions per tile
+  __shared__ float tin_[2][TL][W + 1];
+  __shared__ double tsc_[2][TL][W + 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float(*tin)[W + 1] = tin_[wave];
   double(*tsc)[W + 1] = tsc_[wave];
-  const long long l0 = (long long)blockIdx.x * PRAD_RG_T;
-  const int nl = (int)min((long long)PRAD_RG_T, lines - l0);
+  const long long l0 = (long long)blockIdx.x * TL;
+  const int nl = (int)min((long long)TL, lines - l0);
   const bool mine = lane < nl;
   const int m = (((ln + W - 1) / W) / 2) * W;      // the split (4 <= m <= ln - 4: the caller guarantees ln >= 2 W)
   const int rr = lane / W, cc = lane % W;
@@ -323,15 +326,15 @@ __global__ void __launch_bounds__(128) rgauss_xline2_kernel(const float *__restr
 #define PRAD_XL_FETCH(PF, PS, C0, WW)                                                                     \
   {                                                                                                       \
     const int c0_ = (C0), w_ = (WW);                                                                      \
-    _Pragma("unroll") for (int k = 0; k < W; k++) PF[k] = in[gidx(k, c0_, w_)];                          \
+    _Pragma("unroll") for (int k = 0; k < NI; k++) PF[k] = in[gidx(k, c0_, w_)];                          \
     if (FIN) {                                                                                            \
-      _Pragma("unroll") for (int k = 0; k < W; k++)                                                       \
+      _Pragma("unroll") for (int k = 0; k < NI; k++)                                                      \
           PS[k] = __hip_atomic_load(scratch + gidx(k, c0_, w_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
     }                                                                                                     \
   }
 #define PRAD_XL_COMMIT(PF, PS)                                                                            \
   {                                                                                                       \
-    _Pragma("unroll") for (int k = 0; k < W; k++) {                                                       \
+    _Pragma("unroll") for (int k = 0; k < NI; k++) {                                                      \
       tin[k * RPI + rr][cc] = PF[k];                                                                      \
       if (FIN) tsc[k * RPI + rr][cc] = PS[k];                                                             \
     }                                                                                                     \
@@ -342,13 +345,13 @@ __global__ void __launch_bounds__(128) rgauss_xline2_kernel(const float *__restr
     constexpr bool FIN = decltype(fin_tag)::value;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    float ab[W];
+    float ab[NI];
     if (FIN && AM == 2) {              // all accumulator loads first
 #pragma unroll
-      for (int k = 0; k < W; k++) ab[k] = acc[gidx(k, c0, w)];
+      for (int k = 0; k < NI; k++) ab[k] = acc[gidx(k, c0, w)];
     }
 #pragma unroll
-    for (int k = 0; k < W; k++) {
+    for (int k = 0; k < NI; k++) {
       const int tt = k * RPI + rr;
       if (tt < nl && cc < w) {
         const long long idx = (l0 + tt) * ln + c0 + cc;
@@ -366,8 +369,8 @@ __global__ void __launch_bounds__(128) rgauss_xline2_kernel(const float *__restr
   double t1 = 0, t2 = 0, t3 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0;   // recursion state: 3 (4) data samples, 4 outputs
   auto forward = [&](auto fin_tag, int r0, int r1) __attribute__((always_inline)) {
     constexpr bool FIN = decltype(fin_tag)::value;
-    float pfA[W], pfB[W];      // two tiles in flight ahead of the recursion (a 256^3 volume only has 2 048 such waves:
-    double psA[W], psB[W];     // one tile each left ~4 MB in flight on the whole GPU, 178 us per pass)
+    float pfA[NI], pfB[NI];      // two tiles in flight ahead of the recursion (a 256^3 volume only has 2 048 such waves:
+    double psA[NI], psB[NI];     // one tile each left ~4 MB in flight on the whole GPU, 178 us per pass)
     PRAD_XL_FETCH(pfA, psA, r0, min(W, r1 - r0));
     if (r0 + W < r1) PRAD_XL_FETCH(pfB, psB, r0 + W, min(W, r1 - r0 - W));
     int par = 0;
@@ -415,8 +418,8 @@ __global__ void __launch_bounds__(128) rgauss_xline2_kernel(const float *__restr
   double t0 = 0;   // (backward: t0..t3 = data[i], [i+1], [i+2], [i+3]; u1..u4 = outputs [i], [i+1], [i+2], [i+3])
   auto backward = [&](auto fin_tag, int r0, int r1) __attribute__((always_inline)) {
     constexpr bool FIN = decltype(fin_tag)::value;
-    float pfA[W], pfB[W];      // two tiles in flight ahead of the recursion (a 256^3 volume only has 2 048 such waves:
-    double psA[W], psB[W];     // one tile each left ~4 MB in flight on the whole GPU, 178 us per pass)
+    float pfA[NI], pfB[NI];      // two tiles in flight ahead of the recursion (a 256^3 volume only has 2 048 such waves:
+    double psA[NI], psB[NI];     // one tile each left ~4 MB in flight on the whole GPU, 178 us per pass)
     auto tile_b = [&](int e) { return max(e - W, r0); };       // tile [tile_b(e), e)
     PRAD_XL_FETCH(pfA, psA, tile_b(r1), r1 - tile_b(r1));
     if (tile_b(r1) > r0) PRAD_XL_FETCH(pfB, psB, tile_b(r1 - W), r1 - W - tile_b(r1 - W));

@@ -1331,11 +1331,14 @@ int log_dev(const float *in, const int *size, int Nd, const double *spacing, dou
         const double sp2 = spacing[ax] * spacing[ax];
         const bool accload = acc != nullptr && !first;
         if (inner == 1 && g.size[ax] >= 64 && !getenv("PRAD_LOG_NO_SPLIT")) {   // contiguous axis, two waves per 64 lines (kernels_filters.h)
-          const unsigned gx = (unsigned)((lines + PRAD_RG_T - 1) / PRAD_RG_T);
-#define PRAD_XL2(W, AM) hipLaunchKernelGGL((rgauss_xline2_kernel<W, AM>), dim3(gx), dim3(128), 0, s, cur, lines, g.size[ax], k, scratch, dst, acc, sp2)
-#define PRAD_XL2W(W) do { if (!acc) PRAD_XL2(W, 0); else if (first) PRAD_XL2(W, 1); else PRAD_XL2(W, 2); } while (0)
-          if (lines <= (1 << 17) && !getenv("PRAD_LOG_W32")) PRAD_XL2W(16);
-          else PRAD_XL2W(32);
+#define PRAD_XL2(W, TL, AM) hipLaunchKernelGGL((rgauss_xline2_kernel<W, TL, AM>), dim3((unsigned)((lines + TL - 1) / TL)), dim3(128), 0, s, cur, lines, g.size[ax], k, scratch, dst, acc, sp2)
+#define PRAD_XL2W(W, TL) do { if (!acc) PRAD_XL2(W, TL, 0); else if (first) PRAD_XL2(W, TL, 1); else PRAD_XL2(W, TL, 2); } while (0)
+          // tile = 16 samples x 64 lines per wave; measured at 256^3: 176 us, against 191 us for 32 x 64 (50 KB of LDS per
+          // workgroup) and 265 us for 32 x 32 (128-byte row pieces, twice the waves, half the lanes recursing)
+          static const int xl_mode = getenv("PRAD_LOG_XL") ? atoi(getenv("PRAD_LOG_XL")) : 0;   // tuning override
+          if (xl_mode == 2) PRAD_XL2W(32, 64);
+          else if (xl_mode == 3) PRAD_XL2W(32, 32);
+          else PRAD_XL2W(16, 64);
 #undef PRAD_XL2W
 #undef PRAD_XL2
           PRAD_TRY(check_launch("rgauss_xline2_kernel"));
