@@ -88,6 +88,9 @@ int prad_timing_end(void);
 #define PRAD_E_DEFERRED (-6)
 int prad_set_deferred(int on);
 int prad_set_lanes(int n);                 /* 0 = default; returns PRAD_E_ARG outside [0, 4] */
+/* makes `stream` wait ON THE DEVICE for every deferred call issued so far (no host synchronisation): afterwards work
+ * queued on `stream` may read the outputs of those calls; the levels verdict still needs prad_deferred_status */
+int prad_deferred_join(void *stream);
 int prad_deferred_status(void *stream);
 
 /* ---- angles: cmatrices.h get_angle_count / build_angles (cmatrices.c:756-892) ------------------- */

@@ -1507,6 +1507,11 @@ int prad_set_lanes(int n) {
   c.lane_seq = 0;
   return PRAD_OK;
 }
+int prad_deferred_join(void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  return c.lanes_join((hipStream_t)stream);
+}
 int prad_deferred_status(void *stream) {
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());

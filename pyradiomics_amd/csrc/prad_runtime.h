@@ -138,6 +138,15 @@ struct Context {
     *s = lane_stream[l];
     return PRAD_OK;
   }
+  // `s` waits (on the device, no host synchronisation) for everything queued on the lanes so far
+  int lanes_join(hipStream_t s) {
+    for (int l = 0; l < PRAD_MAX_LANES; l++)
+      if (lane_stream[l]) {
+        PRAD_HIP(hipEventRecord(lane_in[l], lane_stream[l]));      // (the event of the lane is free between calls)
+        PRAD_HIP(hipStreamWaitEvent(s, lane_in[l], 0));
+      }
+    return PRAD_OK;
+  }
   int lanes_sync() {
     for (int l = 0; l < PRAD_MAX_LANES; l++)
       if (lane_stream[l]) PRAD_HIP(hipStreamSynchronize(lane_stream[l]));

@@ -49,9 +49,10 @@ def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None 
     mode, distance 1.  Returns (glcm, glrlm, angles).  `angles` (int32 [na, Nd]) restricts the sweep to a subset
     of the unidirectional distance-1 angles -- the angle shard of one rank when one segment is spread over
     several GPUs (batch.segment_matrices_sharded); the outputs then carry those na angles only.
-    deferred=True only enqueues the kernels on the current stream (no host synchronisation, consecutive volumes
-    pipeline on the GPU); whether a volume held masked levels outside [1, Ng] is then reported by
-    deferred_status(), see include/pyradiomics_amd.h."""
+    deferred=True only enqueues the kernels (no host synchronisation; consecutive volumes alternate between the
+    library's two internal streams and share the GPU): the outputs are valid after deferred_status() -- which also
+    reports whether a volume held masked levels outside [1, Ng] -- or, for work queued on the current stream, after
+    deferred_join(); see include/pyradiomics_amd.h."""
     lib, image, mask, size = _prep(image, mask)
     f2d = int(force2Ddimension) if force2D else -1
     if angles is None:
@@ -92,6 +93,12 @@ def deferred_status() -> None:
         _lib.raise_for(_lib.load().prad_deferred_status(_stream_ptr()), "deferred GLCM+GLRLM")
     finally:
         _deferred_keep.clear()
+
+
+def deferred_join() -> None:
+    """the current stream waits (on the device) for every deferred glcm_glrlm call issued so far: torch work queued
+    afterwards may consume their outputs without a host synchronisation (deferred_status still reports the levels)"""
+    _lib.raise_for(_lib.load().prad_deferred_join(_stream_ptr()), "deferred join")
 
 
 def set_lanes(n: int) -> None:

@@ -199,3 +199,19 @@ def test_lanes_survive_a_workspace_release_and_mixed_sizes(cm):
         for (g, r, _), (eg, er) in zip(got, want):
             assert torch.equal(g, eg) and torch.equal(r, er)
         engine.release_workspace()
+
+
+def test_deferred_join_orders_the_callers_stream(cm):
+    """deferred_join(): the caller's stream waits for the lanes on the device; torch work queued afterwards sees the
+    outputs without any host synchronisation in between"""
+    import torch
+    from pyradiomics_amd import engine
+    Ng, shape = 16, (40, 48, 512)
+    vols = [(torch.from_numpy(_levels(50 + i, shape, Ng, "uniform")).cuda(), torch.from_numpy(_mask(60 + i, shape, "full").astype(np.uint8)).cuda())
+            for i in range(4)]
+    want = [engine.glcm_glrlm(i, m, Ng, 512)[0].sum().item() for i, m in vols]
+    got = [engine.glcm_glrlm(i, m, Ng, 512, deferred=True) for i, m in vols]
+    engine.deferred_join()
+    sums = torch.stack([g.sum() for g, _, _ in got])          # on the caller's stream, right behind the join
+    engine.deferred_status()
+    assert sums.tolist() == want
