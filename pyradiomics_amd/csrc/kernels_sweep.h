@@ -847,8 +847,46 @@ __global__ void finalize_glcm_kernel(const u32 *__restrict__ acc, const u32 *__r
   out[idx] = (double)acc[(size_t)a * Ng * Ng + ij];
 }
 
+// The two GLCM post-passes as one launch (five tiny kernels per volume were 17 % of a 256^3 call): the first nb1
+// workgroups convert the off-diagonal counts, the others resolve the diagonal from the runs, one wave per (level, angle).
+__global__ void __launch_bounds__(256) finalize_glcm_diag_kernel(const u32 *__restrict__ glcm_acc,
+                                                                 const u32 *__restrict__ glrlm_acc, int Ng, int Nr, int Na,
+                                                                 int nb1, double *__restrict__ glcm_out,
+                                                                 int *__restrict__ multi) {
+  if ((int)blockIdx.x < nb1) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)Ng * Ng * Na;
+    if (idx >= total) return;
+    const int a = (int)(idx % Na);
+    const long long ij = idx / Na;
+    const int i = (int)(ij / Ng), j = (int)(ij - (long long)i * Ng);
+    if (i == j) return;  // the diagonal comes from the runs (below)
+    glcm_out[idx] = (double)glcm_acc[(size_t)a * Ng * Ng + ij];
+    return;
+  }
+  const int pair = ((int)blockIdx.x - nb1) * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pair >= Ng * Na) return;
+  const int i = pair % Ng, a = pair / Ng;
+  const u32 *row = glrlm_acc + ((size_t)a * Ng + i) * Nr;
+  unsigned long long pairs = 0;
+  int found = 0;
+  for (int r = lane; r < Nr; r += 64) {
+    const u32 v = row[r];
+    pairs += (unsigned long long)r * v;
+    found |= (r > 0 && v != 0);
+  }
+  const u32 *grow = glcm_acc + ((size_t)a * Ng + i) * Ng;
+  for (int j = lane; j < Ng; j += 64) found |= (grow[j] != 0);
+  for (int o = 32; o > 0; o >>= 1) pairs += __shfl_xor(pairs, o);
+  if (lane == 0) glcm_out[((size_t)i * Ng + i) * Na + a] = (double)pairs;
+  if (__ballot(found) != 0 && lane == 0) multi[a] = 1;
+}
+
+// flags / sticky (deferred calls, both may be null): the levels verdict of the call is latched by this launch too
 __global__ void finalize_glrlm_kernel(const u32 *__restrict__ acc, const int *__restrict__ multi, int Ng, int Nr,
-                                      int Na, double *__restrict__ out) {
+                                      int Na, double *__restrict__ out, const int *__restrict__ flags = nullptr,
+                                      int *__restrict__ sticky = nullptr) {
+  if (sticky && blockIdx.x == 0 && threadIdx.x == 0 && (flags[0] || flags[2])) sticky[0] = 1;
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)Ng * Nr * Na;
   if (idx >= total) return;

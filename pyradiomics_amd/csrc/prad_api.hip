@@ -641,32 +641,43 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
   else if (glcm && glrlm) PRAD_TRY((launch_sweeps<true, true, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   else if (glcm) PRAD_TRY((launch_sweeps<true, false, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
   else PRAD_TRY((launch_sweeps<false, true, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+  int *sticky = nullptr;       // deferred calls latch their levels verdict; finalize_glrlm_kernel does it when it runs
+  if (c.deferred) PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
+  bool latched = false;
   {
     Timed t(c, "finalize", k.s);
-    if (glcm) {
+    if (glcm && glrlm && p.fused) {
+      const int nb1 = (int)blocks_for((long long)Ng * Ng * k.Na), nb2 = (Ng * k.Na + 3) / 4;
+      hipLaunchKernelGGL(finalize_glcm_diag_kernel, dim3(nb1 + nb2), dim3(256), 0, k.s, glcm_acc, glrlm_acc, Ng, Nr, k.Na, nb1,
+                         glcm, multi);
+      PRAD_TRY(check_launch("finalize_glcm_diag_kernel"));
+    } else if (glcm) {
       hipLaunchKernelGGL(finalize_glcm_kernel, dim3(blocks_for((long long)Ng * Ng * k.Na)), dim3(256), 0, k.s,
                          glcm_acc, glrlm_acc, Ng, Nr, k.Na, p.fused ? 1 : 0, glcm);
       PRAD_TRY(check_launch("finalize_glcm_kernel"));
     }
     if (glrlm && p.fused) {
-      hipLaunchKernelGGL(glcm_diag_resolve_kernel, dim3(Ng, k.Na), dim3(64), 0, k.s, glcm_acc, glrlm_acc, Ng, Nr, k.Na,
-                         glcm, multi);
-      PRAD_TRY(check_launch("glcm_diag_resolve_kernel"));
+      if (!glcm) {
+        hipLaunchKernelGGL(glcm_diag_resolve_kernel, dim3(Ng, k.Na), dim3(64), 0, k.s, glcm_acc, glrlm_acc, Ng, Nr, k.Na,
+                           glcm, multi);
+        PRAD_TRY(check_launch("glcm_diag_resolve_kernel"));
+      }
       hipLaunchKernelGGL(multi_check_kernel, dim3(128, k.Na), dim3(256), 0, k.s, p.aset, levels, p.Nz, p.Ny, p.Nx,
                          p.pitch, multi);
       PRAD_TRY(check_launch("multi_check_kernel"));
     }
     if (glrlm) {
       hipLaunchKernelGGL(finalize_glrlm_kernel, dim3(blocks_for((long long)Ng * Nr * k.Na)), dim3(256), 0, k.s,
-                         glrlm_acc, multi, Ng, Nr, k.Na, glrlm);
+                         glrlm_acc, multi, Ng, Nr, k.Na, glrlm, (const int *)k.flags_d, sticky);
       PRAD_TRY(check_launch("finalize_glrlm_kernel"));
+      latched = sticky != nullptr;
     }
   }
   if (c.deferred) {   // enqueue only: the verdict on the levels is latched for prad_deferred_status()
-    int *sticky = nullptr;
-    PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
-    hipLaunchKernelGGL(latch_flags_kernel, dim3(1), dim3(1), 0, k.s, k.flags_d, sticky);
-    PRAD_TRY(check_launch("latch_flags_kernel"));
+    if (!latched) {
+      hipLaunchKernelGGL(latch_flags_kernel, dim3(1), dim3(1), 0, k.s, k.flags_d, sticky);
+      PRAD_TRY(check_launch("latch_flags_kernel"));
+    }
     *used = true;
     return PRAD_OK;
   }
