@@ -295,6 +295,12 @@ int prad_digitize_dev(const void *image, int dtype, const uint8_t *mask, long lo
                       int32_t *levels, int *max_level, void *stream);
 int prad_level_counts_dev(const int32_t *levels, const uint8_t *mask, long long n, int Ng, long long *counts,
                           void *stream);
+/* prad_digitize_counts_dev: prad_digitize_dev and the level census in ONE pass over the image (base.py:119-125 needs
+ *                      both for every derived image): counts (HOST int64, nedges + 1 entries, may be NULL) receives the
+ *                      number of ROI voxels per level 0..nedges.  Any number of edges (beyond 7 680 the edge list is
+ *                      searched in global memory instead of LDS). */
+int prad_digitize_counts_dev(const void *image, int dtype, const uint8_t *mask, long long n, const double *edges,
+                             int nedges, int32_t *levels, int *max_level, long long *counts, void *stream);
 
 /* ---- first-order statistics of the ROI intensities (radiomics/firstorder.py:33-474; device pointers) -----------
  * Segment mode.  The reference computes these with numpy on image[mask] (firstorder.py:96-101); here the ROI is

@@ -10,15 +10,19 @@ import subprocess
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpyradiomics_amd.so")
 SOURCES = ["prad_api.hip", "prad_firstorder.hip", "prad_features.hip", "prad_resample.hip"]
-HEADERS = ["prad_runtime.h", "kernels_generic.h", "kernels_sweep.h", "kernels_neigh.h", "kernels_glszm.h", "kernels_filters.h", "kernels_voxel.h", "kernels_voxtex.h", "kernels_binning.h", "kernels_firstorder.h", "kernels_features.h", "kernels_resample.h",
-           os.path.join("..", "..", "include", "pyradiomics_amd.h")]
+
+
+def _headers() -> list:
+    """every header a translation unit can include: all of csrc/*.h plus the public C ABI"""
+    hs = sorted(f for f in os.listdir(CSRC) if f.endswith(".h"))
+    return hs + [os.path.join("..", "..", "include", "pyradiomics_amd.h")]
 
 
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + _headers())
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -79,14 +79,14 @@ class RadiomicsFeaturesBase:
         return matrix
 
     def _applyBinningDevice(self, tensor):
-        """binImage + grey-level bookkeeping in HBM (prad_roi_minmax_dev / prad_digitize_dev / prad_level_counts_dev).
+        """binImage + grey-level bookkeeping in HBM (prad_roi_minmax_dev, then levels and the level census in one pass:
+        prad_digitize_counts_dev).
         All feature classes of one derived image share the result: the reference re-bins per class (base.py:119-125)."""
         from . import engine
         key = ("levels", self.settings.get("binWidth", 25), self.settings.get("binCount"), id(self.maskArray))
         memo = self.inputImage._derived
         if key not in memo:
-            levels, top, edges = engine.bin_image(tensor, self.maskArray, **self.settings)
-            counts = engine.level_counts(levels, self.maskArray, top)
+            levels, top, edges, counts = engine.bin_image(tensor, self.maskArray, with_counts=True, **self.settings)
             levels._prad_memo = {"mask": self.maskArray}      # lets cMatrices serve GLCM and GLRLM from one sweep
             memo[key] = (levels, np.flatnonzero(counts[1:]) + 1, int(counts[1:].sum()), self.maskArray,
                          counts[1:][counts[1:] > 0])

@@ -37,50 +37,128 @@ def split_slabs(n: int, parts: int, halo: int = 0):
     return out
 
 
-def _run_threaded(indices, cases, worker, threads: int):
-    """`threads` cases of this rank in flight on the one GPU: the library keeps its context (workspaces, streams, error
-    state) per host thread and its C calls release the GIL, so one case's Python / launch overhead (a third of a 256^3
-    case) runs under another case's kernels.  Every thread works on a HIP stream of its own."""
-    import queue
-    import threading
-    todo = queue.Queue()
-    for i in indices:
-        todo.put(i)
-    out, errors = {}, []
-    try:
-        import torch
-        parent_dev = torch.cuda.current_device() if torch.cuda.is_available() else None
-    except ImportError:
-        torch, parent_dev = None, None
+class _WorkerPool:
+    """Persistent host threads for one GPU.  The native library keeps its context (workspaces, pinned buffers, lane
+    streams, events) per host thread, so the threads must outlive a run_batch call: fresh threads per call would leave
+    their contexts' device memory behind when they exit (hundreds of MB per 256^3 case) and would re-allocate every
+    workspace inside the next call.  A thread that does end (shutdown_pools, interpreter exit) frees its workspace."""
 
-    def loop():
+    def __init__(self, threads: int, device):
+        import queue
+        import threading
+        self.jobs = queue.Queue()
+        self.device = device
+        self.threads = [threading.Thread(target=self._loop, daemon=True) for _ in range(threads)]
+        for t in self.threads:
+            t.start()
+
+    def _loop(self):
         ctx = None
-        if parent_dev is not None:
-            torch.cuda.set_device(parent_dev)      # torch's current device is per thread: stay on this rank's GPU
+        try:
+            import torch
+        except ImportError:
+            torch = None
+        if torch is not None and self.device is not None:
+            torch.cuda.set_device(self.device)      # torch's current device is per thread: stay on this rank's GPU
             ctx = torch.cuda.stream(torch.cuda.Stream())
-        if ctx is not None:
             ctx.__enter__()
         try:
-            while not errors:
-                try:
-                    i = todo.get_nowait()
-                except queue.Empty:
+            while True:
+                job = self.jobs.get()
+                if job is None:
                     return
-                out[i] = worker(cases[i])
-        except BaseException as e:          # surfaces in the caller's thread
-            errors.append(e)
+                job()
         finally:
             if ctx is not None:
                 ctx.__exit__(None, None, None)
+                try:                                  # this thread's native context dies with it: give its HBM back
+                    from . import engine
+                    engine.release_workspace()
+                except Exception:
+                    pass
 
-    pool = [threading.Thread(target=loop) for _ in range(max(1, min(threads, len(indices))))]
-    for t in pool:
-        t.start()
-    for t in pool:
-        t.join()
-    if errors:
-        raise errors[0]
-    return out
+    def run(self, indices, cases, worker):
+        import threading
+        out, errors = {}, []
+        left = [len(indices)]
+        lock, done = threading.Lock(), threading.Event()
+        if not indices:
+            return out
+
+        def make(i):
+            def job():
+                try:
+                    if not errors:
+                        out[i] = worker(cases[i])
+                except BaseException as e:          # surfaces in the caller's thread
+                    errors.append(e)
+                finally:
+                    with lock:
+                        left[0] -= 1
+                        if left[0] == 0:
+                            done.set()
+            return job
+
+        for i in indices:
+            self.jobs.put(make(i))
+        done.wait()
+        if errors:
+            raise errors[0]
+        return out
+
+    def each(self, fn):
+        """runs fn() once on EVERY thread of the pool (warm-up: each thread allocates its own native workspace)"""
+        import threading
+        barrier = threading.Barrier(len(self.threads))
+
+        def job(_):
+            barrier.wait()          # a thread that took one of these jobs cannot take a second one
+            return fn()
+
+        return self.run(list(range(len(self.threads))), [None] * len(self.threads), job)
+
+    def shutdown(self):
+        for _ in self.threads:
+            self.jobs.put(None)
+        for t in self.threads:
+            t.join()
+
+
+_POOLS: dict = {}
+
+
+def shutdown_pools() -> None:
+    """ends the worker threads of every pool (each frees the native workspace it held)"""
+    for key in list(_POOLS):
+        _POOLS.pop(key).shutdown()
+
+
+def _pool(threads: int):
+    try:
+        import torch
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    except ImportError:
+        dev = None
+    key = (dev, max(1, threads))
+    if key not in _POOLS:
+        if not _POOLS:
+            import atexit
+            atexit.register(shutdown_pools)
+        _POOLS[key] = _WorkerPool(key[1], dev)
+    return _POOLS[key]
+
+
+def warm_threads(fn, threads: int):
+    """fn() once on each of the `threads` worker threads run_batch(threads=) will use on this GPU"""
+    return _pool(threads).each(fn)
+
+
+def _run_threaded(indices, cases, worker, threads: int):
+    """`threads` cases of this rank in flight on the one GPU: the library keeps its context (workspaces, streams, error
+    state) per host thread and its C calls release the GIL, so one case's Python / launch overhead (a third of a 256^3
+    case) runs under another case's kernels.  Every thread works on a HIP stream of its own; the threads persist
+    between calls (_WorkerPool)."""
+    return _pool(threads).run(list(indices), cases, worker)
 
 
 def run_batch(cases: Sequence, worker: Callable, gather: bool = True, threads: int = 1):

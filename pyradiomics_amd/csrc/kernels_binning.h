@@ -111,18 +111,30 @@ __global__ void __launch_bounds__(256) roi_minmax_kernel(const T *__restrict__ x
   }
 }
 
-template <typename T>
+// LDS_EDGES: the edge list is staged in LDS (<= 7680 edges), otherwise it is searched in global memory (binWidth 1 on a
+// 0..30000 image: 30 000 edges, cache-resident).  COUNTS: 0 = none, 1 = per-wave private LDS tables of nedges + 1 words
+// (one pass gives levels AND the ROI voxels per level: grayLevels / Ns / the first-order histogram), 2 = global atomics.
+template <typename T, bool LDS_EDGES, int COUNTS>
 __global__ void __launch_bounds__(256) digitize_kernel(const T *__restrict__ x, const uint8_t *__restrict__ mask,
                                                        long long n, const double *__restrict__ edges, int nedges,
-                                                       int *__restrict__ levels, int *__restrict__ maxlevel) {
-  extern __shared__ double se[];
+                                                       int *__restrict__ levels, int *__restrict__ maxlevel,
+                                                       unsigned long long *__restrict__ counts) {
+  extern __shared__ double se_raw[];
   constexpr int E = 16 / (int)sizeof(T);
-  for (int i = threadIdx.x; i < nedges; i += blockDim.x) se[i] = edges[i];
-  __syncthreads();
+  const double *se = LDS_EDGES ? se_raw : edges;
+  const int nb = nedges + 1;
+  unsigned int *cnt = reinterpret_cast<unsigned int *>(se_raw + (LDS_EDGES ? nedges : 0));   // [4][nb] when COUNTS == 1
+  if (LDS_EDGES)
+    for (int i = threadIdx.x; i < nedges; i += blockDim.x) se_raw[i] = edges[i];
+  if (COUNTS == 1)
+    for (int i = threadIdx.x; i < 4 * nb; i += blockDim.x) cnt[i] = 0u;
+  if (LDS_EDGES || COUNTS == 1) __syncthreads();
+  unsigned int *mine = cnt + (threadIdx.x >> 6) * nb;
   // number of edges <= v (np.digitize): the edges are (nearly) equidistant, so start from the arithmetic guess and let
-  // the comparisons against the real edge values decide -- the same answer as a bisection, in ~2 LDS reads instead of 6
+  // the comparisons against the real edge values decide -- the same answer as a bisection, in ~2 reads instead of 6
   const double e0 = se[0];
-  const double inv = nedges > 1 && se[nedges - 1] > e0 ? (double)(nedges - 1) / (se[nedges - 1] - e0) : 0.0;
+  const double elast = se[nedges - 1];
+  const double inv = nedges > 1 && elast > e0 ? (double)(nedges - 1) / (elast - e0) : 0.0;
   int top = 0;
   auto level_of = [&](double v) -> int {
     int k = 0;
@@ -133,6 +145,8 @@ __global__ void __launch_bounds__(256) digitize_kernel(const T *__restrict__ x, 
       while (k > 0 && se[k - 1] > v) k--;
     }
     top = max(top, k);
+    if (COUNTS == 1) atomicAdd(mine + k, 1u);
+    if (COUNTS == 2) atomicAdd(counts + k, 1ull);
     return k;
   };
   const bool aligned = (((uintptr_t)x) & 15) == 0 && (((uintptr_t)mask) & (E - 1)) == 0 && (((uintptr_t)levels) & 15) == 0;
@@ -157,6 +171,12 @@ __global__ void __launch_bounds__(256) digitize_kernel(const T *__restrict__ x, 
   if (threadIdx.x == 0) {
     top = max(max(stop[0], stop[1]), max(stop[2], stop[3]));
     if (top) atomicMax(maxlevel, top);
+  }
+  if (COUNTS == 1) {   // (a block sees fewer than 2^32 voxels: 32-bit partial sums)
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+      const unsigned int v = cnt[i] + cnt[nb + i] + cnt[2 * nb + i] + cnt[3 * nb + i];
+      if (v) atomicAdd(counts + i, (unsigned long long)v);
+    }
   }
 }
 

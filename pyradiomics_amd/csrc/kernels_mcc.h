@@ -371,7 +371,8 @@ __global__ void __launch_bounds__(64 * PRAD_MCC_WAVES) voxel_glcm_mcc_kernel(
   for (int i = lane; i < Ng * Ng; i += 64) tab[i] = 0;
   mcc_wave_sync();
   const bool sym = symmetric != 0;
-  for (int v = blockIdx.x * PRAD_MCC_WAVES + wave; v < nvox; v += gridDim.x * PRAD_MCC_WAVES) {
+  const int nwaves = (int)(blockDim.x >> 6);   // 2, or 1 when two per-wave scratch areas exceed the LDS (Ng 63, 64)
+  for (int v = blockIdx.x * nwaves + wave; v < nvox; v += gridDim.x * nwaves) {
     int c[3] = {0, 0, 0};
     for (int d = 0; d < vox_nd; d++) c[3 - vox_nd + d] = voxels[(long long)d * nvox + v];
     const int dims[3] = {Nz, Ny, Nx};

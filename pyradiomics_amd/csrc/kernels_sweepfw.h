@@ -539,6 +539,9 @@ __global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, const uint8_t
                                                         int *__restrict__ work, int *__restrict__ flags) {
   extern __shared__ u32 lds[];
   if (flags[0]) return;  // irregular levels: the generic path will redo this call
+#ifdef PRAD_FW_SETPRIO   // experiment: issue priority over the co-resident pack waves of the neighbouring volume
+  __builtin_amdgcn_s_setprio(PRAD_FW_SETPRIO);
+#endif
   const bool anyzero = flags[3] != 0;   // the pack kernel saw a voxel outside the ROI (else the row flags are not read)
   const HistLayout h = hist_layout(true, true, true, Ng, RS);
   if ((unsigned)(size_t)((lds_u32 *)lds) != 0u) {  // table offsets are used as LDS addresses
@@ -740,8 +743,11 @@ __global__ void __launch_bounds__(1024) pack_rows_fw_kernel(const int *__restric
 #pragma unroll
           for (int b = 0; b < 4; b++) {
             const bool in = (mk[i] >> (8 * b)) & 0xffu;
-            bad |= in && (lv[b] < 1 || lv[b] > Ng);
-            o |= (in ? (((u32)lv[b] << PRAD_FUSED_SHIFT) & 0xffu) : 0u) << (8 * b);
+            const bool regular = in && lv[b] >= 1 && lv[b] <= Ng;
+            bad |= in && !regular;
+            // (a level outside 1..Ng packs as 0: the walk below must never index the tables with it -- the volume is
+            // redone on the generic kernels anyway)
+            o |= (regular ? ((u32)lv[b] << PRAD_FUSED_SHIFT) : 0u) << (8 * b);
           }
           const int tr = 4 * (8 * half + i) + sub;
           const long long row = r0 + tr;

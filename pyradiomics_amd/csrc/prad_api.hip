@@ -1092,12 +1092,20 @@ int voxel_glcm_mcc_dev(const int32_t *image, const uint8_t *mask, const int *siz
     Timed t(c, "voxel", s);
     const int nmax = std::min(Ng, PRAD_MCC_NMAX);
     const size_t per_wave = (mcc_scratch_bytes(Ng, nmax) + sizeof(u32) * (size_t)Ng * Ng + 15) & ~(size_t)15;
-    const size_t lds = per_wave * PRAD_MCC_WAVES;
-    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((long long)Nvox + PRAD_MCC_WAVES - 1) / PRAD_MCC_WAVES,
-                                                                           (long long)cu_count() * 8));
+    // two waves per workgroup unless their scratch areas exceed the 160 KiB a workgroup may declare (Ng = 63, 64:
+    // 2 x 84 KB) -- then one wave per workgroup, and more workgroups
+    constexpr size_t kLdsMax = 160 * 1024;
+    if (per_wave > kLdsMax) {
+      (void)c.end_call(s);
+      return fail(PRAD_E_UNSUPPORTED, "voxel_glcm_mcc: %zu B of LDS per kernel window exceed the device limit; use the matrix path", per_wave);
+    }
+    const int waves = per_wave * PRAD_MCC_WAVES <= kLdsMax ? PRAD_MCC_WAVES : 1;
+    const size_t lds = per_wave * waves;
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((long long)Nvox + waves - 1) / waves,
+                                                                           (long long)cu_count() * 8 * (PRAD_MCC_WAVES / waves)));
     PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_mcc_kernel),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(voxel_glcm_mcc_kernel, dim3(gx), dim3(64 * PRAD_MCC_WAVES), lds, s, levels, dims[0], dims[1], dims[2],
+    hipLaunchKernelGGL(voxel_glcm_mcc_kernel, dim3(gx), dim3(64 * waves), lds, s, levels, dims[0], dims[1], dims[2],
                        A, Ng, Nvox, voxels, Nd, kernelRadius, f2d3, symmetric, nmax, out, flags + 3, flags);
     PRAD_TRY(check_launch("voxel_glcm_mcc_kernel"));
   }
@@ -1400,6 +1408,32 @@ int log_dev(const float *in, const int *size, int Nd, const double *spacing, dou
 // =================================================================================================
 // extern "C"
 // =================================================================================================
+namespace {
+template <typename T>
+int launch_digitize(const T *image, const uint8_t *mask, long long n, const double *e_d, int nedges, int32_t *levels,
+                    int *top, unsigned long long *counts_d, hipStream_t s) {
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+  const size_t edge_b = sizeof(double) * (size_t)nedges, cnt_b = 4 * sizeof(unsigned) * ((size_t)nedges + 1);
+  const bool lds_edges = edge_b <= 60 * 1024;
+  // counts in LDS while edges + four private tables fit 64 KB (nedges <= 2 700), otherwise straight global atomics
+  // (that many levels spread the atomics over as many addresses)
+  const int counts = !counts_d ? 0 : ((lds_edges && edge_b + cnt_b <= 64 * 1024) ? 1 : 2);
+#define PRAD_DIG(LE, CN)                                                                                              \
+  hipLaunchKernelGGL((digitize_kernel<T, LE, CN>), dim3(gx), dim3(256), (LE ? edge_b : 0) + (CN == 1 ? cnt_b : 0), s, image, \
+                     mask, n, e_d, nedges, levels, top, counts_d)
+  if (lds_edges) {
+    if (counts == 0) PRAD_DIG(true, 0);
+    else if (counts == 1) PRAD_DIG(true, 1);
+    else PRAD_DIG(true, 2);
+  } else {
+    if (counts == 0) PRAD_DIG(false, 0);
+    else PRAD_DIG(false, 2);
+  }
+#undef PRAD_DIG
+  return check_launch("digitize_kernel");
+}
+}  // namespace
+
 extern "C" {
 
 const char *prad_version(void) { return kVersion; }
@@ -1454,7 +1488,7 @@ int prad_release_workspace(void) {
   }
   c.bufs.clear();
   c.pinned.clear();
-  for (auto &v : c.angles_cached) v.clear();   // (the cached angle tables and the deferred flag lived in the workspace)
+  c.angles_cached.clear();   // (the cached angle tables and the deferred flag lived in the workspace)
   StageRing &r = stage_ring();
   for (int i = 0; i < kStageRing; i++) {
     r.buf[i] = nullptr;
@@ -1846,34 +1880,41 @@ int prad_roi_minmax_dev(const void *image, int dtype, const uint8_t *mask, long 
   return PRAD_OK;
 }
 
-int prad_digitize_dev(const void *image, int dtype, const uint8_t *mask, long long n, const double *edges, int nedges,
-                      int32_t *levels, int *max_level, void *stream) {
+int prad_digitize_counts_dev(const void *image, int dtype, const uint8_t *mask, long long n, const double *edges,
+                             int nedges, int32_t *levels, int *max_level, long long *counts, void *stream) {
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
   if (!image || !mask || !edges || !levels || n < 1 || nedges < 1) return fail(PRAD_E_ARG, "digitize: bad arguments");
-  if ((size_t)nedges * sizeof(double) > 60 * 1024) return fail(PRAD_E_UNSUPPORTED, "digitize: %d edges exceed the LDS table", nedges);
   hipStream_t s = (hipStream_t)stream;
   double *e_d = nullptr;
   int *top = nullptr;
+  unsigned long long *cnt_d = nullptr;
   PRAD_TRY(c.get<double>("bin_edges", (size_t)nedges, &e_d));
   PRAD_TRY(c.get<int>("bin_top", 1, &top));
   PRAD_HIP(hipMemcpyAsync(e_d, edges, sizeof(double) * nedges, hipMemcpyHostToDevice, s));
   PRAD_HIP(hipMemsetAsync(top, 0, sizeof(int), s));
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
-  const size_t lds = sizeof(double) * nedges;
+  if (counts) {
+    PRAD_TRY(c.get<unsigned long long>("bin_counts", (size_t)nedges + 1, &cnt_d));
+    PRAD_HIP(hipMemsetAsync(cnt_d, 0, sizeof(unsigned long long) * ((size_t)nedges + 1), s));
+  }
   switch (dtype) {
-    case 0: hipLaunchKernelGGL(digitize_kernel<float>, dim3(gx), dim3(256), lds, s, (const float *)image, mask, n, e_d, nedges, levels, top); break;
-    case 1: hipLaunchKernelGGL(digitize_kernel<double>, dim3(gx), dim3(256), lds, s, (const double *)image, mask, n, e_d, nedges, levels, top); break;
-    case 2: hipLaunchKernelGGL(digitize_kernel<int>, dim3(gx), dim3(256), lds, s, (const int *)image, mask, n, e_d, nedges, levels, top); break;
-    case 3: hipLaunchKernelGGL(digitize_kernel<short>, dim3(gx), dim3(256), lds, s, (const short *)image, mask, n, e_d, nedges, levels, top); break;
+    case 0: PRAD_TRY(launch_digitize((const float *)image, mask, n, e_d, nedges, levels, top, cnt_d, s)); break;
+    case 1: PRAD_TRY(launch_digitize((const double *)image, mask, n, e_d, nedges, levels, top, cnt_d, s)); break;
+    case 2: PRAD_TRY(launch_digitize((const int *)image, mask, n, e_d, nedges, levels, top, cnt_d, s)); break;
+    case 3: PRAD_TRY(launch_digitize((const short *)image, mask, n, e_d, nedges, levels, top, cnt_d, s)); break;
     default: return fail(PRAD_E_ARG, "digitize: dtype %d", dtype);
   }
-  PRAD_TRY(check_launch("digitize_kernel"));
   int t = 0;
   PRAD_HIP(hipMemcpyAsync(&t, top, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (counts) PRAD_HIP(hipMemcpyAsync(counts, cnt_d, sizeof(long long) * ((size_t)nedges + 1), hipMemcpyDeviceToHost, s));
   PRAD_HIP(hipStreamSynchronize(s));
   if (max_level) *max_level = t;
   return PRAD_OK;
+}
+
+int prad_digitize_dev(const void *image, int dtype, const uint8_t *mask, long long n, const double *edges, int nedges,
+                      int32_t *levels, int *max_level, void *stream) {
+  return prad_digitize_counts_dev(image, dtype, mask, n, edges, nedges, levels, max_level, nullptr, stream);
 }
 
 int prad_level_counts_dev(const int32_t *levels, const uint8_t *mask, long long n, int Ng, long long *counts,

@@ -80,8 +80,10 @@ struct Context {
   bool timing_accumulate = false;
   std::vector<KernelTime> all_times;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> all_calls;
-  // last angle table uploaded (skips the pageable host-to-device copy when a caller repeats the same angles), per lane
-  std::vector<int> angles_cached[PRAD_MAX_LANES + 1];
+  // last angle table uploaded (skips the pageable host-to-device copy when a caller repeats the same angles), per
+  // workspace buffer: keyed like the device buffer it describes (lane AND device -- a thread that alternates between two
+  // GPUs must not take GPU 1's table for GPU 0's)
+  std::map<std::string, std::vector<int>> angles_cached;
   // Lanes: deferred whole-volume GLCM/GLRLM calls alternate between `lanes` internal streams, each with a workspace of
   // its own, so that the kernels of consecutive volumes share the GPU: the HBM-bound pack of one volume runs while the
   // issue-bound sweep of the previous one holds other CUs, launch gaps and kernel tails are filled (512^3: 0.63 ->
@@ -119,7 +121,7 @@ struct Context {
     return k + "@" + std::to_string(device);
   }
   bool has(const char *name) const { return bufs.find(key(name)) != bufs.end(); }
-  std::vector<int> &angle_cache() { return angles_cached[lane + 1]; }
+  std::vector<int> &angle_cache() { return angles_cached[key("angles")]; }
   int lane_begin(hipStream_t user, hipStream_t *s) {   // the next lane: its stream waits for everything queued on `user`
     if (lanes == 0) {
       const char *e = getenv("PRAD_LANES");

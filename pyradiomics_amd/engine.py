@@ -72,7 +72,6 @@ def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None 
     if deferred:
         _lib.raise_for(lib.prad_set_deferred(1), "deferred mode")
         _deferred_keep.append((image, mask, out_glcm, out_glrlm))   # the lanes read/write these until deferred_status()
-        del _deferred_keep[:-64]
     try:
         rc = lib.prad_calculate_glcm_glrlm_dev(
             C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd, _iptr(angles), Na, int(Ng),
@@ -469,8 +468,10 @@ def _mask_u8(mask: torch.Tensor) -> torch.Tensor:
     return mask.contiguous() if mask.dtype == torch.uint8 else (mask != 0).view(torch.uint8)
 
 
-def bin_image(image: torch.Tensor, mask: torch.Tensor, **kwargs):
-    """imageoperations.binImage + base._applyBinning on the device: returns (levels int32 tensor, Ng, edges).
+def bin_image(image: torch.Tensor, mask: torch.Tensor, with_counts: bool = False, **kwargs):
+    """imageoperations.binImage + base._applyBinning on the device: returns (levels int32 tensor, Ng, edges), plus the
+    ROI voxel count per level (int64 numpy [Ng + 1], [0] = ROI voxels below the first edge: none) with `with_counts` --
+    produced by the same pass over the image (prad_digitize_counts_dev).
     The edges come from pyradiomics_amd.imageoperations.getBinEdges fed with the ROI's (min, max), which is all
     that function depends on, so levels are identical to the host route."""
     from . import imageoperations
@@ -489,10 +490,14 @@ def bin_image(image: torch.Tensor, mask: torch.Tensor, **kwargs):
     edges = np.asarray(imageoperations.getBinEdges(np.array([mm[0], mm[1]], dtype=np_dtype), **kwargs), dtype=np.float64)
     levels = torch.empty(image.shape, dtype=torch.int32, device=image.device)
     top = C.c_int(0)
-    rc = lib.prad_digitize_dev(C.c_void_p(image.data_ptr()), _DTYPE_CODES[image.dtype], C.c_void_p(mask.data_ptr()), n,
-                               edges.ctypes.data_as(C.POINTER(C.c_double)), len(edges), C.c_void_p(levels.data_ptr()),
-                               C.byref(top), _stream_ptr())
+    counts = np.zeros(len(edges) + 1, dtype=np.int64) if with_counts else None
+    rc = lib.prad_digitize_counts_dev(C.c_void_p(image.data_ptr()), _DTYPE_CODES[image.dtype], C.c_void_p(mask.data_ptr()), n,
+                                      edges.ctypes.data_as(C.POINTER(C.c_double)), len(edges), C.c_void_p(levels.data_ptr()),
+                                      C.byref(top), counts.ctypes.data_as(C.POINTER(C.c_longlong)) if with_counts else None,
+                                      _stream_ptr())
     _lib.raise_for(rc, "digitize")
+    if with_counts:
+        return levels, int(top.value), edges, counts[:int(top.value) + 1]
     return levels, int(top.value), edges
 
 

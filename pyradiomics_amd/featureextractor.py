@@ -225,7 +225,7 @@ class RadiomicsFeatureExtractor:
             # featureextractor.py:471-482: work on the ROI's bounding box grown by padDistance from here on (a speed-up
             # the user opts into; filters then see the crop's borders instead of the image's)
             image, mask = imageoperations.cropToTumorMask(image, mask, label, padDistance=s.get("padDistance", 5),
-                                                          deviceResident=on_dev)
+                                                          deviceResident=on_dev, alignRows=False)
         if s.get("resegmentRange") is not None:
             if not np.any(mask.array == label):
                 raise ValueError("Label (%g) not present in mask" % label)

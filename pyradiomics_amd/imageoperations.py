@@ -76,11 +76,12 @@ def roiTensor(mask, label=1):
     return mask._derived[key]
 
 
-def cropToTumorMask(image, mask, label=1, padDistance=0, deviceResident=False):
+def cropToTumorMask(image, mask, label=1, padDistance=0, deviceResident=False, alignRows=True):
     """Crops image and mask to the ROI bounding box padded by `padDistance` voxels, clipped to the image
     (imageoperations.py:407-445).  Accepts / returns pyradiomics_amd.image.Image.  With `deviceResident` the crop
     is a device-to-device copy of the sub-box and the cropped mask Image is memoised on `mask`, so every derived
-    image of one case shares one cropped ROI."""
+    image of one case shares one cropped ROI.  `alignRows=False` keeps the device crop at the reference's exact extent
+    (the preCrop stage: filters applied afterwards see the crop's borders, so its extent must match the reference's)."""
     img, msk = as_image(image), as_image(mask)
     bkey = ("bbox", label)
     if bkey not in msk._derived:
@@ -88,7 +89,7 @@ def cropToTumorMask(image, mask, label=1, padDistance=0, deviceResident=False):
     lo, hi = msk._derived[bkey]
     lo = np.maximum(lo - padDistance, 0)
     hi = np.minimum(hi + padDistance, np.array(msk.shape) - 1)
-    if deviceResident:
+    if deviceResident and alignRows:
         # Rows of a multiple of 4 voxels keep every kernel on its packed 4-voxels-per-lane path (a 231-wide crop of a
         # 256^3 case sent GLSZM, GLDM and NGTDM down their one-voxel-per-lane kernels: 2-3x slower).  The extra columns
         # lie outside the ROI's bounding box, so they are outside the ROI: no matrix, no statistic sees them.
@@ -106,7 +107,7 @@ def cropToTumorMask(image, mask, label=1, padDistance=0, deviceResident=False):
     if not deviceResident:
         return (Image(img.array[sl], img.spacing, origin, img.direction),
                 Image(msk.array[sl], msk.spacing, origin, msk.direction))
-    ckey = ("crop", label, padDistance)
+    ckey = ("crop", label, padDistance, bool(alignRows))
     if ckey not in msk._derived:
         msk._derived[ckey] = Image(None, msk.spacing, origin, msk.direction,
                                    tensor=msk.device_tensor()[sl].contiguous())

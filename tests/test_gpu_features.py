@@ -267,6 +267,29 @@ def test_voxel_mcc_on_the_device():
             np.testing.assert_allclose(out[True][n], out[False][n], rtol=1e-9, atol=1e-10, equal_nan=True, err_msg=n)
 
 
+@pytest.mark.parametrize("Ng", [62, 63, 64])
+def test_voxel_mcc_at_the_top_of_its_level_range(Ng):
+    """Ng = 63 / 64: two per-wave scratch areas of the voxel MCC kernel exceed the 160 KiB of LDS a workgroup may
+    declare (2 x 84 KB), the launch then runs one wave per workgroup instead of failing with PRAD_E_HIP; values against
+    the matrix route + the numpy formula of glcm.py:665-707"""
+    from pyradiomics_amd import _lib, glcm
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(Ng)
+    arr = rng.integers(0, Ng, size=(6, 9, 10)).astype(np.int16)
+    arr.flat[0], arr.flat[1] = 0, Ng - 1
+    msk = np.ones(arr.shape, dtype=np.int32)
+    kw = dict(binWidth=1, kernelRadius=1, maskedKernel=True, initValue=np.nan, voxelBased=True, label=1)
+    out = {}
+    for fused in (True, False):
+        fc = glcm.RadiomicsGLCM(Image(arr), Image(msk), fusedVoxel=fused, **kw)
+        fc.enableFeatureByName("MCC")
+        out[fused] = fc.execute()["MCC"].array
+        assert fc.coefficients["Ng"] == Ng
+        if fused:
+            assert _lib.last_path() == "voxel-fused"
+    np.testing.assert_allclose(out[True], out[False], rtol=1e-9, atol=1e-10, equal_nan=True)
+
+
 def test_segment_mcc_on_the_device_and_special_cases():
     import torch
     from pyradiomics_amd import engine

@@ -43,7 +43,7 @@ def _sum_shares(img_t, msk_t, Ng, world, **kw):
     ((12, 20, 16), 5, 0, True),      # force2D: in-plane neighbourhoods, no halo
     ((5, 16, 16), 8, 0, False),      # more ranks than planes: some ranks own nothing
 ])
-def test_shares_sum_to_single_device_matrices(shape, world, alpha, force2D, oracle_port):
+def test_shares_sum_to_single_device_matrices(shape, world, alpha, force2D, checker):
     import torch
     from pyradiomics_amd import engine
     Ng = 7
@@ -61,7 +61,7 @@ def test_shares_sum_to_single_device_matrices(shape, world, alpha, force2D, orac
     P, sizes = engine.glszm_compact(img_t, msk_t, Ng, None, force2D, 0)
     assert np.array_equal(tot["glszm"][1], sizes) and np.array_equal(tot["glszm"][0], P.cpu().numpy())
     # and the oracle
-    cm = oracle_port
+    cm = checker
     assert np.array_equal(g.cpu().numpy(), cm.calculate_glcm(img, mask, [1], Ng, force2D, 0)[0][0])
     assert np.array_equal(gldm.cpu().numpy(), cm.calculate_gldm(img, mask, [1], Ng, alpha, force2D, 0)[0])
     ref = cm.calculate_ngtdm(img, mask, [1], Ng, force2D, 0)[0]
