@@ -3,15 +3,18 @@
 32 grey levels (full mask, distance 1, 13 angles), 1..8 GPUs.
 
 One "step" = one pass of the hot path over one volume that is already resident in HBM as the boundary dtypes
-(int32 levels + uint8 mask, 5 B/voxel): pack -> 13 angle sweeps -> float64 GLCM [32,32,13] + GLRLM [32,512,13]
+(int32 levels + uint8 mask, 5 B/voxel): pack -> 13 angle walks -> float64 GLCM [32,32,13] + GLRLM [32,512,13]
 in HBM.  With N > 1 GPUs every rank builds the matrices of its own volume (batch mode shards cases, no collective:
 SURVEY.md section 8e), so scaling is "weak" and value = N * voxels * steps / max-over-ranks time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--size 512] [--dist uniform|smooth]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (plus `roofline` and, at N=1, `cpu_baseline`).
+`--gpus N` with N > 1 re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1` (one rank per GPU over RCCL) unless it already runs under such a launch.
+
+Rank 0 prints ONE JSON line: the headline (`value`, `roofline`), every other BASELINE config under `modes` (smooth
+headline variant, config 2 five matrices 256^3, config 3 filter stack 256^3, config 4 voxel maps 2-D and 3-D windows,
+config 5 batch of whole cases) and, at N = 1, `cpu_baseline` + `host_boundary`.
 """
 from __future__ import annotations
 
@@ -28,21 +31,16 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-# Fabric (HBM + Infinity Cache) bytes per engine call at the default workload, from the committed PMC profile
-# profiles/r02b_pmc.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE calibrated on the
-# kernels' own access widths: x2 for pack_rows' 16 B/lane loads, /0.524 for sweep_fw's 8 B/lane loads -- one angle
-# alone reads the 134 MB level volume exactly once and reports 70.4 MB): pack_rows 0.80 GB + 0.152 GB written,
-# sweep_fw 1.36 GB (12 angles, 10.2 volume reads).  rocprof cannot run inside bench.py; the figure is only
-# reported when the workload matches the profiled one.
-PROFILED_TRAFFIC = {"workload": (512, 32, "uniform"), "bytes": 2.31e9, "kernel_bytes": 1.36e9, "source": "profiles/r02b_pmc.md"}
-# Secondary rooflines of the dominant kernel (it is not HBM-bound): wave-instructions per launch from the same PMC pass,
-# ceilings from scripts/microbench.hip on this GPU (profiles/r02a_microbench.log): a conflict-free ds_add_u32 retires every
-# 4.1 cycles per CU, an independent integer VALU instruction every 2.65 cycles per SIMD (256 CUs x 4 SIMDs, 2.4 GHz).
-PROFILED_INSTS = {"workload": (512, 32, "uniform"), "lds": 2.802e7, "valu": 1.399e8, "source": "profiles/r02b_pmc.md"}
-LDS_ATOMIC_PEAK = 256 * 2.4e9 / 4.1       # ds_add wave-instructions / s
-VALU_PEAK = 1024 * 2.4e9 / 2.65           # VALU wave-instructions / s
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 ALG_BYTES_PER_VOXEL = 5.0       # int32 level + uint8 mask, read once
+# Secondary rooflines of the dominant kernel (it is not HBM-bound): ceilings from scripts/microbench.hip on this GPU
+# (profiles/r02a_microbench.log): a conflict-free ds_add_u32 retires every 4.1 cycles per CU, an independent integer VALU
+# instruction every 2.65 cycles per SIMD (256 CUs x 4 SIMDs, 2.4 GHz).
+LDS_ATOMIC_PEAK = 256 * 2.4e9 / 4.1       # ds_add wave-instructions / s
+VALU_PEAK = 1024 * 2.4e9 / 2.65           # VALU wave-instructions / s
+# Counter figures that rocprofv3 collects (it cannot run inside bench.py): written by scripts/prof_r03.sh into this file
+# from --pmc passes over THIS bench command with the committed build; used only when the workload matches.
+PROFILED_FILE = os.path.join(ROOT, "profiles", "r03_counters.json")
 
 
 def make_volume(size: int, levels: int, dist: str, seed: int, device) -> tuple[torch.Tensor, torch.Tensor]:
@@ -135,11 +133,9 @@ def cpu_baseline_all_cores(levels: int, size: int, nz: int = 24):
     """The only way the reference uses more than one core: one process per case (scripts/__init__.py:387-416).
     nproc single-threaded workers, each on its own nz x size x size slab, started together; aggregate Mvoxels/s."""
     import subprocess
-    import sys
     nproc = usable_cores()
-    root = os.path.dirname(os.path.abspath(__file__))
     procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_worker", str(nz), str(size), str(size), str(levels), str(i)],
-                              cwd=root, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for i in range(nproc)]
+                              cwd=ROOT, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for i in range(nproc)]
     try:
         for p in procs:
             if p.stdout.readline().strip() != "ready":
@@ -161,6 +157,126 @@ def cpu_baseline_all_cores(levels: int, size: int, nz: int = 24):
             "sample": "%d processes x %dx%dx%d slab each, %.1f s wall" % (nproc, nz, size, size, dt)}
 
 
+def frac_of_hbm(nbytes: float, ms: float) -> dict:
+    """roofline entry of one stage: algorithmic bytes over its device time against the HBM peak"""
+    gbps = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"ms": round(ms, 4), "algorithmic_bytes": int(nbytes), "achieved_GBps": round(gbps, 1),
+            "frac": round(gbps / HBM_PEAK_GBPS, 5)}
+
+
+def headline_loop(engine, image, mask, Ng, Nr, steps, warmup, fence, outs):
+    """K deferred steps enqueued back to back (pipeline mode: the pack of volume N rides in the walk launch of volume
+    N-1; deferred_join flushes the last volume INSIDE the timed region), bracketed by fence().  Returns (seconds,
+    per-family device ms per step, last outputs)."""
+    state = {"n": 0, "g": None, "r": None}
+
+    def step(deferred=True):
+        o = outs[state["n"] % len(outs)]
+        state["n"] += 1
+        g, r, _ = engine.glcm_glrlm(image, mask, Ng, Nr, out_glcm=o[0], out_glrlm=o[1], deferred=deferred)
+        o[0], o[1] = g, r
+        state["g"], state["r"] = g, r
+
+    for _ in range(warmup):
+        step()
+    engine.deferred_status()
+    fence()
+    engine.timing_begin()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    engine.deferred_join()            # the last volume's walks + finalize are enqueued here, before the closing fence
+    fence()
+    elapsed = time.perf_counter() - t0
+    engine.deferred_status()          # raises if any step saw levels outside [1, Ng] (none can: synthetic levels)
+    assert engine.timing_calls() == steps
+    fam = {f: engine.timing_ms(f) / steps for f in ("pack", "sweep", "rows", "finalize")}
+    fam["device"] = engine.timing_ms(None) / steps
+    engine.timing_end()
+    return elapsed, fam, (state["g"], state["r"])
+
+
+def mode_config2(device, engine, size=256, levels=32):
+    """BASELINE config 2: all five texture matrices of one size^3 volume (uniform and smooth levels), device-resident,
+    synchronous calls; device ms per matrix from the library's HIP events, 5 B/voxel algorithmic per matrix call."""
+    out = {"case": "%d^3 int32+uint8 volume, %d grey levels, full mask; per matrix: device ms of the synchronous call "
+                   "(HIP events), 5 B/voxel algorithmic" % (size, levels)}
+    for dist in ("uniform", "smooth"):
+        img, msk = make_volume(size, levels, dist, 0, device)
+        n = img.numel()
+        jobs = {"glcm_glrlm": lambda: engine.glcm_glrlm(img, msk, levels, size),
+                "gldm": lambda: engine.gldm(img, msk, levels),
+                "ngtdm": lambda: engine.ngtdm(img, msk, levels),
+                "glszm": lambda: engine.glszm_compact(img, msk, levels, n)}
+        res, total = {}, 0.0
+        for name, fn in jobs.items():
+            fn()
+            best_dev, best_wall = 1e9, 1e9
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                best_wall = min(best_wall, (time.perf_counter() - t0) * 1e3)
+                best_dev = min(best_dev, engine.last_device_ms())
+            res[name] = dict(frac_of_hbm(ALG_BYTES_PER_VOXEL * n, best_dev), wall_ms=round(best_wall, 4), path=engine.last_path())
+            total += best_wall
+        res["total_wall_ms"] = round(total, 4)
+        res["Mvoxels_s_all_five"] = round(n / (total * 1e-3) / 1e6, 1)
+        out[dist] = res
+    return out
+
+
+def mode_config3(device, engine, size=256):
+    """BASELINE config 3: wavelet (coif1, 8 sub-bands) + LoG (sigma 1..5 mm) of a size^3 int16 volume, every derived
+    image re-discretised to 32 levels (binCount) and pushed through GLCM+GLRLM; nothing leaves HBM.  Per-stage wall ms
+    (synchronised per stage) with the stage's algorithmic bytes.  Filter parity is UNPINNED (no PyWavelets / SimpleITK in
+    this run): see DESIGN.md."""
+    lv, msk = make_volume(size, 32, "smooth", 0, device)
+    img = (lv.to(torch.float32) * 25.0 + 3.0).to(torch.int16)
+    n = img.numel()
+
+    def run():
+        t = {}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        derived = engine.wavelet_images(img)
+        torch.cuda.synchronize()
+        t["wavelet_x8"] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        for s in (1.0, 2.0, 3.0, 4.0, 5.0):
+            derived["log-sigma-%g" % s] = engine.log_image(img, (1.0, 1.0, 1.0), s)
+        torch.cuda.synchronize()
+        t["log_x5"] = (time.perf_counter() - t0) * 1e3
+        tb = tm = 0.0
+        for name, d in derived.items():
+            t0 = time.perf_counter()
+            levels, Ng, _, _ = engine.bin_image(d, msk, with_counts=True, binCount=32)
+            torch.cuda.synchronize()
+            tb += (time.perf_counter() - t0) * 1e3
+            t0 = time.perf_counter()
+            engine.glcm_glrlm(levels, msk, Ng, size)
+            torch.cuda.synchronize()
+            tm += (time.perf_counter() - t0) * 1e3
+            assert engine.last_path() == "sweep"
+        t["binning_x13"] = tb
+        t["glcm_glrlm_x13"] = tm
+        return t
+
+    run()
+    t = run()
+    # algorithmic bytes: wavelet 8 B in + 8 x 8 B out per voxel (float64); LoG 4 B in + 4 B out per sigma (float32); binning
+    # per image: min/max pass (dtype + 1) + digitize pass (dtype + 1 in, 4 out); matrices 5 B per voxel and image
+    bin_bytes = 8 * (2 * 9 + 4) + 5 * (2 * 5 + 4)
+    stages = {"wavelet_x8": frac_of_hbm(72.0 * n, t["wavelet_x8"]), "log_x5": frac_of_hbm(5 * 8.0 * n, t["log_x5"]),
+              "binning_x13": frac_of_hbm(float(bin_bytes) * n, t["binning_x13"]),
+              "glcm_glrlm_x13": frac_of_hbm(13 * 5.0 * n, t["glcm_glrlm_x13"])}
+    total = sum(t.values())
+    return {"case": "%d^3 int16 volume -> 8 wavelet sub-bands + 5 LoG images -> binCount 32 -> GLCM+GLRLM, wall ms per "
+                    "stage (one synchronisation per stage / image); filter arithmetic unpinned" % size,
+            "stages": stages, "total_ms": round(total, 3), "Mvoxels_s_derived": round(13 * n / (total * 1e-3) / 1e6, 1)}
+
+
 def mode_batch(device, rank: int, cases: int, fence):
     """north_star 'batched mode' (BASELINE config 5 in miniature): whole cases -- a 256^3 volume, ball ROI, Original +
     8 wavelet sub-bands, all six feature classes -- through RadiomicsFeatureExtractor.execute, `cases` per rank,
@@ -178,25 +294,28 @@ def mode_batch(device, rank: int, cases: int, fence):
     ex = RadiomicsFeatureExtractor(params)
     vols = [(make_volume(N, 32, "smooth", 1000 * rank + c, device)[0] * 25).cpu().numpy().astype(np.int16)
             for c in range(cases + 1)]
-    out = ex.execute(Image(vols[0]), Image(roi))          # warm-up: code objects, workspace
+    ex.execute(Image(vols[0]), Image(roi))          # warm-up: code objects, workspace
 
     def one(c):
         return ex.execute(Image(vols[c]), Image(roi))
 
-    if threads > 1:                                       # (every thread warms its own workspace)
-        batch._run_threaded(list(range(threads)), [0] * threads, one, threads)
+    if threads > 1:                                       # every worker thread warms its own workspace
+        batch.warm_threads(lambda: one(0), threads)
     fence()
     t0 = time.perf_counter()
-    res = batch._run_threaded(list(range(cases)), list(range(1, cases + 1)), one, threads)
+    if threads > 1:
+        res = batch._run_threaded(list(range(cases)), list(range(1, cases + 1)), one, threads)
+    else:
+        res = {i: one(i + 1) for i in range(cases)}
     fence()
     return cases, time.perf_counter() - t0, len(res[0])
 
 
-def mode_voxel(device, rank: int, world: int, size: int, fence):
-    """north_star 'voxel-based mode' (BASELINE config 4): GLCM JointEntropy map of a size^3 volume with the
-    exampleVoxel.yaml window (force2D, kernelRadius 2), every voxel a kernel centre; the centre list is cut into
-    z-slabs, one per rank (batch.voxel_maps_sharded's split), the volume is resident on every rank, no collective.
-    Returns (kernels of this rank, seconds)."""
+def mode_voxel(device, rank: int, world: int, size: int, fence, three_d: bool = False):
+    """north_star 'voxel-based mode' (BASELINE config 4): GLCM JointEntropy map of a size^3 volume, every voxel a kernel
+    centre -- the exampleVoxel.yaml window (force2D, kernelRadius 2: 5 x 5) or, with three_d, the 3-D 5^3 window; the
+    centre list is cut into z-slabs, one per rank (batch.voxel_maps_sharded's split), the volume is resident on every
+    rank, no collective.  Returns (kernels of this rank, seconds, kernel device ms)."""
     from pyradiomics_amd import engine
     img, msk = make_volume(size, 32, "smooth", 0, device)
     z0, z1 = (size * rank) // world, (size * (rank + 1)) // world
@@ -205,15 +324,16 @@ def mode_voxel(device, rank: int, world: int, size: int, fence):
                                 torch.arange(size, device=device, dtype=torch.int32), indexing="ij")
     vox = torch.stack([zz.reshape(-1), yy.reshape(-1), xx.reshape(-1)])
     del zz, yy, xx
-    kw = dict(kernelRadius=2, force2D=True, force2Ddimension=0)
+    kw = dict(kernelRadius=2, force2D=not three_d, force2Ddimension=0)
     engine.voxel_glcm_features(img, msk, 32, vox[:, :4096].contiguous(), ["JointEntropy"], **kw)
     fence()
     t0 = time.perf_counter()
     res = engine.voxel_glcm_features(img, msk, 32, vox, ["JointEntropy"], **kw)
     fence()
     dt = time.perf_counter() - t0
+    kms = engine.last_kernel_ms("voxel")
     assert bool(torch.isfinite(res["JointEntropy"]).all())
-    return int(vox.shape[1]), dt
+    return int(vox.shape[1]), dt, kms
 
 
 def host_boundary(image, mask, Ng: int, Nr: int):
@@ -232,6 +352,19 @@ def host_boundary(image, mask, Ng: int, Nr: int):
                     "through the pinned staging ring (4 host threads), PCIe Gen5 x16"}
 
 
+def respawn_under_torchrun(n: int) -> None:
+    """`python bench.py --gpus N` (N > 1) outside a torch.distributed launch: become that launch"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,8 +374,12 @@ def main() -> None:
     ap.add_argument("--levels", type=int, default=32)
     ap.add_argument("--dist", choices=["uniform", "smooth"], default="uniform")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-modes", action="store_true", help="skip the batch / voxel-based side figures")
+    ap.add_argument("--no-modes", action="store_true", help="skip the side figures (smooth variant, configs 2-5)")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the host-pointer (drop-in) call timing")
+    ap.add_argument("--deferred-mode", choices=["pipeline", "lanes"], default=None,
+                    help="how deferred calls overlap (default: the library's, i.e. pipeline unless PRAD_DEFERRED_MODE=lanes)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share "
+                                                      "one GPU on a test box)")
     ap.add_argument("--cpu-voxels", type=int, default=320 * 512 * 512,
                     help="voxels in the CPU baseline sample (default: a 320-slice slab, ~10 s on one core)")
     args = ap.parse_args()
@@ -250,42 +387,36 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        respawn_under_torchrun(args.gpus)                 # does not return
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)              # (several ranks may share a GPU when a box has fewer: test setups)
+    device = torch.device("cuda", local_rank % ndev)
     dist_on = world > 1 or "RANK" in os.environ      # any torch.distributed launch (also a 1-rank one) takes the N>1 path
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     from pyradiomics_amd import engine
+    if args.deferred_mode:
+        engine.set_deferred_mode(1 if args.deferred_mode == "pipeline" else 0)
+    mode_name = args.deferred_mode or ("lanes" if os.environ.get("PRAD_DEFERRED_MODE") == "lanes" else "pipeline")
 
     image, mask = make_volume(args.size, args.levels, args.dist, seed=rank, device=device)
     Ng, Nr = args.levels, args.size
     nvox = image.numel()
-    glcm = glrlm = None
-    outs = [[None, None] for _ in range(4)]     # deferred steps alternate between the library's lanes: one output set each
-    nstep = 0
+    outs = [[None, None] for _ in range(4)]     # consecutive deferred volumes are in flight together: one output set each
 
-    def step(deferred=False):
-        nonlocal glcm, glrlm, nstep
-        o = outs[nstep % len(outs)]
-        nstep += 1
-        glcm, glrlm, _ = engine.glcm_glrlm(image, mask, Ng, Nr, out_glcm=o[0], out_glrlm=o[1], deferred=deferred)
-        o[0], o[1] = glcm, glrlm
-
-    step()                                     # (synchronous: the dispatch verdict is read back)
+    g0, r0, _ = engine.glcm_glrlm(image, mask, Ng, Nr)     # (synchronous: the dispatch verdict is read back)
     assert engine.last_path() == "sweep", "bench must run the sweep kernels, got %s" % engine.last_path()
-    for _ in range(args.warmup):               # warm-up steps run like the timed ones (deferred: both lanes allocate
-        step(deferred=True)                    # their workspaces here, not inside the timed region)
-    engine.deferred_status()
 
     def fence():
         torch.cuda.synchronize()
@@ -293,73 +424,85 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Timed region: K steps ENQUEUED back to back (deferred mode: no host synchronisation inside a step; the library deals
-    # consecutive volumes onto its two lanes = internal streams, so the pack kernel of one volume shares the GPU with the
-    # sweep kernel of the previous one), bracketed by barrier + synchronize.
-    lanes = int(os.environ.get("PRAD_LANES", "2"))
-    fence()
-    engine.timing_begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(deferred=True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    engine.deferred_status()          # raises if any step saw levels outside [1, Ng] (none can: synthetic levels)
-    assert engine.timing_calls() == args.steps
-    overlapped_ms = {fam: engine.timing_ms(fam) for fam in ("pack", "sweep", "finalize")}
-    engine.timing_end()
-    # Kernel durations for the roofline: the same K deferred steps on ONE lane (the caller's stream), where a kernel has
-    # the GPU to itself -- with two lanes the launches of consecutive volumes overlap in time and a launch's duration
-    # (reported as overlapped_kernel_ms) no longer says how fast the kernel is.  HIP events on the launch stream.
-    engine.set_lanes(1)
-    fence()
-    engine.timing_begin()
-    t0s = time.perf_counter()
-    for _ in range(args.steps):
-        step(deferred=True)
-    fence()
-    serial_elapsed = time.perf_counter() - t0s
-    engine.deferred_status()
-    kernel_ms = {fam: engine.timing_ms(fam) for fam in ("pack", "sweep", "finalize")}
-    device_ms = engine.timing_ms(None)
-    engine.timing_end()
-    engine.set_lanes(0)
+    cdev = device if args.backend == "nccl" else torch.device("cpu")     # where the control-plane scalars live
+
+    def max_over_ranks(x: float) -> float:
+        if not dist_on:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    elapsed, fam, (glcm, glrlm) = headline_loop(engine, image, mask, Ng, Nr, args.steps, args.warmup, fence, outs)
+    assert torch.equal(glcm, g0) and torch.equal(glrlm, r0), "deferred and synchronous matrices differ"
     # the synchronous drop-in call (host waits for every volume and reads the status back), informational
     sync_steps = max(3, min(10, args.steps))
     fence()
     t1 = time.perf_counter()
     for _ in range(sync_steps):
-        step()
+        engine.glcm_glrlm(image, mask, Ng, Nr, out_glcm=outs[0][0], out_glrlm=outs[0][1])
     sync_ms = (time.perf_counter() - t1) / sync_steps * 1e3
-    def max_over_ranks(x: float) -> float:
-        if not dist_on:
-            return x
-        t = torch.tensor([x], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
-
+    sync_fam = {f: engine.last_kernel_ms(f) for f in ("pack", "sweep", "rows", "finalize")}
     elapsed = max_over_ranks(elapsed)
+
     modes = None
     if not args.no_modes:
-        # the two sharded modes north_star names, each rank on its own share, barrier + max-over-ranks like the headline
+        modes = {}
+
+        def guarded(name, fn):
+            try:
+                torch.cuda.empty_cache()
+                modes[name] = fn()
+            except Exception as e:                 # a side figure never breaks the bench line
+                modes[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+        if world == 1:
+            def smooth():
+                im2, mk2 = make_volume(args.size, args.levels, "smooth", seed=rank, device=device)
+                el, f2, _ = headline_loop(engine, im2, mk2, Ng, Nr, args.steps, args.warmup, fence, [[None, None] for _ in range(4)])
+                ms2 = el / args.steps * 1e3
+                return {"value": round(nvox * args.steps / el / 1e6, 1), "unit": "Mvoxels/s", "ms_per_step": round(ms2, 4),
+                        "kernel": frac_of_hbm(ALG_BYTES_PER_VOXEL * nvox, f2["sweep"]), "rows_ms": round(f2["rows"], 4),
+                        "job_frac": round(ALG_BYTES_PER_VOXEL * nvox / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                        "case": "the headline on low-pass filtered noise (SURVEY 8d C2(ii)): same size / levels / steps"}
+            guarded("smooth", smooth)
+            guarded("config2", lambda: mode_config2(device, engine))
+            guarded("config3", lambda: mode_config3(device, engine))
+
+        def batch_mode():
+            nc, dt_b, nfeat = mode_batch(device, rank, 12, fence)
+            dt_b = max_over_ranks(dt_b)
+            return {"value": round(world * nc / dt_b, 2), "unit": "cases/s", "cases_per_rank": nc, "features_per_case": nfeat,
+                    "ms_per_case_per_gpu": round(dt_b / nc * 1e3, 2),
+                    "case": "256^3 int16 volume from host memory, ball ROI (38 %% of the box), Original + 8 wavelet "
+                            "sub-bands, six feature classes; %s cases in flight per GPU (host threads, "
+                            "batch.run_batch(threads=))" % os.environ.get("PRAD_BATCH_THREADS", "3")}
+
+        def voxel_mode(three_d):
+            nk, dt_v, kms = mode_voxel(device, rank, world, args.size, fence, three_d)
+            dt_v = max_over_ranks(dt_v)
+            nk_all = nk
+            if dist_on:
+                t = torch.tensor([nk], dtype=torch.float64, device=cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                nk_all = int(t.item())
+            # 5 B/voxel in + 8 B per centre and feature map out
+            return {"value": round(nk_all / dt_v / 1e6, 2), "unit": "Mkernels/s", "kernels": nk_all,
+                    "kernel": frac_of_hbm(13.0 * nk, kms),
+                    "case": "%d^3 volume, GLCM JointEntropy map, %s window, every voxel a centre, centres split into "
+                            "z-slabs over the ranks" % (args.size, "3-D 5x5x5 (kernelRadius 2)" if three_d else
+                                                        "exampleVoxel.yaml 5x5 (force2D, kernelRadius 2)")}
+        # the sharded modes run on every rank (barrier + max-over-ranks like the headline)
+        try:
+            modes["batch"] = batch_mode()
+        except Exception as e:
+            if dist_on:
+                raise
+            modes["batch"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         torch.cuda.empty_cache()
-        nc, dt_b, nfeat = mode_batch(device, rank, 12, fence)
-        dt_b = max_over_ranks(dt_b)
-        nk, dt_v = mode_voxel(device, rank, world, args.size, fence)
-        dt_v = max_over_ranks(dt_v)
-        nk_all = nk
-        if dist_on:
-            t = torch.tensor([nk], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            nk_all = int(t.item())
-        modes = {"batch": {"value": round(world * nc / dt_b, 2), "unit": "cases/s", "cases_per_rank": nc,
-                           "features_per_case": nfeat,
-                           "case": "256^3 int16 volume from host memory, ball ROI (38 %% of the box), Original + 8 wavelet "
-                                   "sub-bands, six feature classes; %s cases in flight per GPU (host threads, "
-                                   "batch.run_batch(threads=))" % os.environ.get("PRAD_BATCH_THREADS", "3")},
-                 "voxel": {"value": round(nk_all / dt_v / 1e6, 2), "unit": "Mkernels/s", "kernels": nk_all,
-                           "case": "%d^3 volume, GLCM JointEntropy map, exampleVoxel.yaml window (force2D, kernelRadius 2), "
-                                   "every voxel a centre, centres split into z-slabs over the ranks" % args.size}}
+        modes["voxel"] = voxel_mode(False)
+        torch.cuda.empty_cache()
+        modes["voxel3d"] = voxel_mode(True)
         torch.cuda.empty_cache()
 
     # size-independent property checks on the full-size result (every ordered neighbour pair / every voxel counted)
@@ -378,11 +521,19 @@ def main() -> None:
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * nvox * args.steps / elapsed / 1e6
-        sweep_ms = kernel_ms["sweep"] / args.steps
-        pipe_ms = device_ms / args.steps
+        sweep_ms = fam["sweep"]
         alg_bytes = ALG_BYTES_PER_VOXEL * nvox
         achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
         copy_gbps = measured_copy_bandwidth(device)
+        prof = None
+        try:
+            with open(PROFILED_FILE) as f:
+                prof = json.load(f)
+            if tuple(prof.get("workload", ())) != (args.size, args.levels, args.dist) or prof.get("deferred_mode") != mode_name:
+                prof = None
+        except (OSError, ValueError):
+            prof = None
+        inline = mode_name == "pipeline" and fam["pack"] < 0.02
         out = {
             "metric": "Mvoxels/s for GLCM+GLRLM build, %d^3 vol @%d bins" % (args.size, args.levels),
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": world, "steps": args.steps,
@@ -393,46 +544,47 @@ def main() -> None:
             "config": {"workload": "GLCM+GLRLM matrix build, %d^3 int32+uint8 volume resident in HBM, %d grey levels, "
                                    "full mask, 13 angles, %s levels; one volume per GPU (batch sharding, no collective)"
                                    % (args.size, args.levels, args.dist),
-                       "size": args.size, "levels": args.levels, "dist": args.dist},
+                       "size": args.size, "levels": args.levels, "dist": args.dist, "deferred_mode": mode_name},
             "roofline": {
-                "bound": "hbm", "kernel": "sweep_fw_kernel (12 of the 13 angles; the x angle is walked inside "
-                                          "pack_rows_fw_kernel, see pipeline_*)",
+                "bound": "hbm",
+                "kernel": "sweep_fw_kernel: the 12 line angles of one volume" +
+                          (" + the pack (5 B/voxel read, 1 B/voxel written) of the next volume as a side job of the same "
+                           "launch" if inline else "") + "; the x angle is sweep_fw_rows_kernel (rows_ms)",
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": PROFILED_TRAFFIC["bytes"] if (args.size, args.levels, args.dist) == PROFILED_TRAFFIC["workload"] else None,
-                "traffic_source": PROFILED_TRAFFIC["source"] + " (fabric bytes of pack + sweeps per volume; traffic_kernel: the sweep kernel's share)",
-                "traffic_kernel": PROFILED_TRAFFIC["kernel_bytes"] if (args.size, args.levels, args.dist) == PROFILED_TRAFFIC["workload"] else None,
-                "algorithmic_bytes": alg_bytes, "kernel_ms": round(sweep_ms, 4),
-                "pipeline_ms": round(pipe_ms, 4), "pack_ms": round(kernel_ms["pack"] / args.steps, 4),
-                "finalize_ms": round(kernel_ms["finalize"] / args.steps, 4),
-                "pipeline_achieved": round(alg_bytes / (pipe_ms * 1e-3) / 1e9, 2),
+                "traffic": prof["bytes"] if prof else None,
+                "traffic_kernel": prof["kernel_bytes"] if prof else None,
+                "traffic_source": prof["source"] if prof else "rocprofv3 --pmc cannot run inside bench.py; see profiles/",
+                "algorithmic_bytes": alg_bytes, "kernel_ms": round(sweep_ms, 4), "rows_ms": round(fam["rows"], 4),
+                "pack_ms": round(fam["pack"], 4), "finalize_ms": round(fam["finalize"], 4),
+                "pipeline_ms": round(fam["device"], 4),
+                "pipeline_achieved": round(alg_bytes / (fam["device"] * 1e-3) / 1e9, 2),
                 "measured_copy_GBps": round(copy_gbps, 1), "frac_of_measured_copy": round(achieved / copy_gbps, 5),
-                "lanes": lanes, "serial_ms_per_step": round(serial_elapsed / args.steps * 1e3, 4),
-                "overlapped_kernel_ms": round(overlapped_ms["sweep"] / args.steps, 4),
-                "overlapped_pack_ms": round(overlapped_ms["pack"] / args.steps, 4),
-                "job_achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 2), "job_frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
-                "note": "achieved = 5 B/voxel x voxels / sweep kernel duration, HIP events on the launch stream over a second "
-                        "K-step deferred loop on ONE lane (kernel_ms, pack_ms, finalize_ms, pipeline_*: launches do not "
-                        "overlap there); the timed region that gives `value` runs the volumes on `lanes` lanes, where "
-                        "launches of consecutive volumes share the GPU (overlapped_*: duration of a launch there); "
-                        "job_* = 5 B/voxel over ms_per_step",
+                "job_achieved": round(alg_bytes / (ms * 1e-3) / 1e9, 2),
+                "job_frac": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                "sync_call_kernel_ms": {k: round(v, 4) for k, v in sync_fam.items()},
+                "note": "achieved = 5 B/voxel x voxels / duration of the dominant launch, HIP events on the launch stream "
+                        "inside the timed region (all launches of a step sit on one stream in pipeline mode, so a launch's "
+                        "duration is the kernel's); pipeline_* = the whole call (walks + x angle + finalize + memsets) "
+                        "between its events; job_* = 5 B/voxel over ms_per_step (wall, max over ranks)",
             },
         }
-        if (args.size, args.levels, args.dist) == PROFILED_INSTS["workload"]:
+        if prof and "lds" in prof:
             t = sweep_ms * 1e-3
             out["roofline"]["secondary"] = {
-                "bound": "lds_atomic", "achieved": round(PROFILED_INSTS["lds"] / t / 1e9, 2), "peak": round(LDS_ATOMIC_PEAK / 1e9, 2),
-                "unit": "G ds_add wave-instructions/s", "frac": round(PROFILED_INSTS["lds"] / t / LDS_ATOMIC_PEAK, 4),
-                "note": "one LDS atomic per run end (1.11 per voxel-step on iid levels); on random bins the LDS array needs "
-                        "6.5 cycles per instruction (70 % bank-conflict cycles), and each ds_add holds its SIMD ~8.8 cycles",
-                "source": PROFILED_INSTS["source"]}
+                "bound": "lds_atomic", "achieved": round(prof["lds"] / t / 1e9, 2), "peak": round(LDS_ATOMIC_PEAK / 1e9, 2),
+                "unit": "G ds_add wave-instructions/s", "frac": round(prof["lds"] / t / LDS_ATOMIC_PEAK, 4),
+                "note": "one LDS atomic per run end; each ds_add holds the LDS operand bus 4.1 cycles per CU",
+                "source": prof["source"]}
             out["roofline"]["secondary_valu"] = {
-                "bound": "valu", "achieved": round(PROFILED_INSTS["valu"] / t / 1e9, 2), "peak": round(VALU_PEAK / 1e9, 2),
-                "unit": "G VALU wave-instructions/s", "frac": round(PROFILED_INSTS["valu"] / t / VALU_PEAK, 4),
-                "note": "5.5 VALU per voxel-step (4 in the exec-masked step, SDWA forms at ~4 cycles each)",
-                "source": PROFILED_INSTS["source"]}
+                "bound": "valu", "achieved": round(prof["valu"] / t / 1e9, 2), "peak": round(VALU_PEAK / 1e9, 2),
+                "unit": "G VALU wave-instructions/s", "frac": round(prof["valu"] / t / VALU_PEAK, 4),
+                "source": prof["source"]}
         if world == 1 and not args.no_host_boundary:
-            out["host_boundary"] = host_boundary(image, mask, Ng, Nr)
+            try:
+                out["host_boundary"] = host_boundary(image, mask, Ng, Nr)
+            except Exception as e:
+                out["host_boundary"] = {"error": str(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             cb, (img, msk, g_cpu, r_cpu, Nr_s) = cpu_baseline(image, mask, Ng, args.cpu_voxels)
             # same slab through the GPU path: the CPU run doubles as a bit-exact parity check

@@ -84,10 +84,17 @@ int prad_timing_end(void);
  * PRAD_LANES; 1 = everything stays on the caller's stream), each with its own workspace and each waiting for the work
  * queued on the caller's stream at the time of the call, so the kernels of consecutive volumes share the GPU.  The
  * caller's stream does NOT wait for a lane: inputs and outputs of a deferred call belong to the library until
- * prad_deferred_status returns (it synchronises the stream and every lane). */
+ * prad_deferred_status returns (it synchronises the stream and every lane).
+ * Pipeline (the default deferred mode; prad_set_deferred_mode(0) or PRAD_DEFERRED_MODE=lanes selects the lanes):
+ * deferred whole-volume calls stay on the caller's stream and form a two-stage pipeline -- call N launches the walks of
+ * volume N-1 with the PACK of volume N riding in the same launch as a side job of the walking waves (the pack is
+ * HBM-bound, the walk issue-bound: the pack's memory time disappears), then finalizes volume N-1.  Volume N is walked by
+ * the next deferred call, or by prad_deferred_join / prad_deferred_status, which flush the pipeline.  As with the lanes,
+ * inputs and outputs of a deferred call belong to the library until one of those two returns. */
 #define PRAD_E_DEFERRED (-6)
 int prad_set_deferred(int on);
 int prad_set_lanes(int n);                 /* 0 = default; returns PRAD_E_ARG outside [0, 4] */
+int prad_set_deferred_mode(int mode);      /* 1 pipeline, 0 lanes, -1 environment default (PRAD_DEFERRED_MODE); flushes */
 /* makes `stream` wait ON THE DEVICE for every deferred call issued so far (no host synchronisation): afterwards work
  * queued on `stream` may read the outputs of those calls; the levels verdict still needs prad_deferred_status */
 int prad_deferred_join(void *stream);

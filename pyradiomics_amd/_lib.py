@@ -36,6 +36,7 @@ SYMBOLS = {
     "prad_timing_end": (C.c_int, []),
     "prad_set_deferred": (C.c_int, [C.c_int]),
     "prad_set_lanes": (C.c_int, [C.c_int]),
+    "prad_set_deferred_mode": (C.c_int, [C.c_int]),
     "prad_deferred_join": (C.c_int, [C.c_void_p]),
     "prad_deferred_status": (C.c_int, [C.c_void_p]),
     "prad_get_angle_count": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),

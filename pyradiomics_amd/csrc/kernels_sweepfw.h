@@ -35,27 +35,53 @@ struct FwDesc {
   int chunks;        // NU * pieces
 };
 struct FwSet {
-  int count;
+  int count;         // line angles (roles 0 .. count-1)
   int NX;
   int pitch;         // bytes per row of the packed volume (row r of rowzero[] starts at r * pitch)
   int nrows;         // rows of the packed volume
+  int rows_role;     // 1: one more role (index `count`) walks the angle along x (output column rows_slot) in the same launch
+  int rows_slot;
+  int RSr;           // run-length slots of the rows role's table (it shares the workgroup's LDS with 16 staging tiles)
+  int first_block[PRAD_MAX_SWEEP + 2];   // role r owns workgroups [first_block[r], first_block[r + 1]) of the 1-D grid
   FwDesc d[PRAD_MAX_SWEEP];
+};
+
+// The NEXT volume's pack (int32 level + uint8 mask -> level*4 bytes, row flags, "irregular level" flag) as a side job of
+// this launch: every wave of the line roles owns the 1024-voxel units pw, pw + W, pw + 2W, ... (pw = its index among the W
+// packing waves), issues a unit's loads in front of a plain group of its walk and converts / stores behind it.  The pack is
+// HBM-bound and the walk is issue-bound, so the pack's memory time disappears behind the walk's VALU / LDS work; only its
+// ~6 VALU per voxel remain (a pure pack kernel of its own takes 0.15 ms per 512^3 volume and cannot share a CU's issue
+// slots with the sweep without slowing it down by as much: profiles/r03_probes.md).
+// Needs the linear layout (pitch == NX, hence NX % 16 == 0) and 16-byte aligned arrays; n16 == 0: nothing to pack.
+struct PackJob {
+  const int *image;
+  const uint8_t *mask;
+  uint8_t *levels;
+  uint8_t *rowzero;   // zeroed by the caller
+  int *flags;         // the packed volume's own flag words ([0] irregular level under the mask, [3] some voxel outside the ROI)
+  long long n16;      // 16-voxel pieces
+  int NX, Ng;
+  int every;          // a unit every `every` plain groups
 };
 
 #define PRAD_FW_U 8
 #define PRAD_FW_WORK_STRIDE 64   // ints between the chunk counters of two angles (256 B: a line of their own)
-// A DEAD line (one that must ignore its next event) keeps its run state in a scratch zone of RS+1 row slots behind the
-// table (state >= deadbase): the plain path can then walk it like any other line for RS steps -- its ignored event is a
-// ds_add into the zone -- and only lines that stay dead longer need the checked path.
 // The whole layout of kernels_sweep.h (fused table H, long-run table G, dummies) sits Q = 4(Ng+1) bytes into the LDS,
 // because the run state kept here is s = level*P + len*Q with len counted from 1 (the exec-masked step adds Q to every
 // line after the event lanes took their fresh value, see fw_plain_word): the bin of an event is s + cur, as there.
-__host__ __device__ inline size_t fw_lds_bytes(const HistLayout &h) { return 4 * ((size_t)h.words + (size_t)(h.RS + 3) * (h.Ng + 1)); }
+// Level 0 (a stretch of voxels outside the ROI, or a line that has not seen a voxel yet) owns the block [0, P + Q) in
+// front of the real rows: whatever is added there is never read.  A DEAD line (one that must ignore its next event:
+// a piece that does not begin at a line start knows the previous row but not how long the open runs are) is a line
+// whose state says level 0 although its previous level is not 0: s = age*Q < P + Q = alive0.  The plain path walks it
+// like any other line for up to RS steps -- its ignored event is a ds_add into the level-0 block -- and the checked path
+// keeps it from growing out of that block.  (Until round 3 dead states sat BEHIND the table, s >= deadbase, which an open
+// run of a high level and several hundred voxels also reached: its end was then taken for a dead line's and dropped.)
+__host__ __device__ inline size_t fw_lds_bytes(const HistLayout &h) { return 4 * ((size_t)h.words + (size_t)(h.Ng + 1)); }
 
 
 struct FwTab {   // wave-uniform constants of the fused table (layout: hist_layout(true, true, true, Ng, RS))
   u32 *rl_long;
-  int Nr, P4, Q, lenlim, gB, RL4, RS, RL, dummy0b, deadbase;
+  int Nr, P4, Q, lenlim, gB, RL4, RS, RL, dummy0b, alive0, deadmax;
   unsigned Qinv;
   __device__ __forceinline__ void init(const HistLayout &h, int Nr_, u32 *rl_long_) {
     rl_long = rl_long_;
@@ -69,7 +95,8 @@ struct FwTab {   // wave-uniform constants of the fused table (layout: hist_layo
     gB = Q + 4 * h.g0 - RL4 - 4 * h.RS;
     Qinv = (unsigned)((0x100000000ull + (unsigned)Q - 1) / (unsigned)Q);
     dummy0b = Q + 4 * h.dummy0;
-    deadbase = Q + 4 * h.words;
+    alive0 = (h.RS + 2) * Q;     // smallest state of a line inside a run of a real level (level 1, len 1)
+    deadmax = (h.RS + 1) * Q;    // a dead line's state stops growing here (checked path)
   }
 };
 
@@ -96,12 +123,13 @@ __device__ __noinline__ void fw_long_event(const FwTab &T, int lv, int lb) {
 }
 
 // One voxel-step of one line, every case handled: dead lines, runs beyond the table (clamped bin + length record).
-//   s  level*P + len*Q of the open run (unclamped; 0 = a line that has not seen a voxel yet), or >= deadbase = dead
+//   s  level*P + len*Q of the open run (unclamped; 0 = a line that has not seen a voxel yet), or < alive0 = dead / level 0
 //   x, c = level*4 of the previous / current voxel
 template <bool LONG>
 __device__ __forceinline__ void fw_checked(const FwTab &T, int dummy, int &s, int x, int c, bool tail) {
   const bool chg = c != x;
-  const bool ev = chg && s < T.deadbase;
+  const bool alive = s >= T.alive0;
+  const bool ev = chg && alive;
   int bin = s;
   if (LONG) {
     const int lb = s - __mul24(x, T.P4);   // len*Q
@@ -109,7 +137,7 @@ __device__ __forceinline__ void fw_checked(const FwTab &T, int dummy, int &s, in
     if (ev && x != 0 && lb >= T.lenlim) fw_long_event(T, x >> PRAD_FUSED_SHIFT, lb - T.Q);
   }
   lds_bump(ev ? bin + c : dummy);
-  s = select_i32(chg, tail ? T.deadbase : __mul24(c, T.P4) + T.Q, s + T.Q);
+  s = select_i32(chg, tail ? 0 : __mul24(c, T.P4) + T.Q, alive ? s + T.Q : min(s + T.Q, T.deadmax));
 }
 
 // The plain step of four lines whose levels are the byte lanes of c (current) and x (previous).  Only valid when no
@@ -211,6 +239,90 @@ __device__ __forceinline__ void fw_load(const uint8_t *p, u32 (&v)[KW]) {
   }
 #endif
 }
+
+// One wave's share of a PackJob (see there).  begin() issues the loads of the next unit when one is due, finish() converts
+// and stores it; both are wave-uniform no-ops otherwise.
+struct PackWave {
+  const PackJob &J;
+  long long ubase;      // first 16-voxel piece of the wave's next unit (wave-uniform), >= J.n16: done
+  long long ustride;    // pieces between two units of this wave
+  int lane, tick;
+  bool loaded;          // wave-uniform
+  int bad;
+  int4 q0, q1, q2, q3;
+  uint4 m;
+  __device__ __forceinline__ PackWave(const PackJob &J_, long long pw, long long W) : J(J_) {
+    lane = threadIdx.x & 63;
+    ubase = pw >= 0 ? pw * 64 : J_.n16;
+    ustride = W * 64;
+    tick = 0;
+    loaded = false;
+    bad = 0;
+  }
+  __device__ __forceinline__ bool pending() const { return ubase < J.n16; }
+  __device__ __forceinline__ void load() {
+    const long long t = ubase + lane;
+    q0 = q1 = q2 = q3 = make_int4(0, 0, 0, 0);
+    m = make_uint4(0, 0, 0, 0);
+    if (t < J.n16) {
+      const int4 *im4 = reinterpret_cast<const int4 *>(J.image) + 4 * t;
+      m = reinterpret_cast<const uint4 *>(J.mask)[t];
+      q0 = im4[0];
+      q1 = im4[1];
+      q2 = im4[2];
+      q3 = im4[3];
+    }
+    loaded = true;
+  }
+  // a unit is due every J.every calls
+  __device__ __forceinline__ void begin() {
+    if (!pending()) return;
+    if (++tick < J.every) return;
+    tick = 0;
+    load();
+  }
+  __device__ __forceinline__ void finish() {
+    if (!loaded) return;
+    loaded = false;
+    const long long t = ubase + lane;
+    ubase += ustride;
+    if (t >= J.n16) return;
+    const int lv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    const u32 mw[4] = {m.x, m.y, m.z, m.w};
+    u32 ow[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      u32 o = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const bool in = (mw[w] >> (8 * b)) & 0xffu;
+        const int l = lv[w * 4 + b];
+        const bool regular = in && l >= 1 && l <= J.Ng;
+        bad |= in && !regular;
+        o |= (regular ? ((u32)l << PRAD_FUSED_SHIFT) : 0u) << (8 * b);   // (an irregular level packs as 0: never a table index)
+      }
+      ow[w] = o;
+    }
+    u32 zb = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) zb |= (ow[w] - 0x01010101u) & ~ow[w] & 0x80808080u;
+    if (zb) {   // the piece holds a voxel outside the ROI: flag its row(s) (a 16-voxel piece spans at most two rows)
+      J.flags[3] = 1;
+      const unsigned e0 = (unsigned)(t << 4);       // (volumes stay below 2^31 voxels)
+      J.rowzero[e0 / (unsigned)J.NX] = 1;
+      J.rowzero[(e0 + 15u) / (unsigned)J.NX] = 1;
+    }
+    reinterpret_cast<uint4 *>(J.levels)[t] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+  }
+  // whatever the walk left over (a launch whose walk is much shorter than the pack, or no walk at all)
+  __device__ __forceinline__ void drain() {
+    while (pending()) {
+      load();
+      finish();
+    }
+    if (bad) J.flags[0] = 1;
+  }
+};
 
 #define FW_BYTE(W, j) ((int)__builtin_amdgcn_ubfe((W)[(j) >> 2], 8 * ((j) & 3), 8))
 
@@ -338,7 +450,7 @@ struct FwWave {
     for (int j = 0; j < K; j++) {
       const int xj = FW_BYTE(X, j);
       unsigned a = (unsigned)(pl[j] - __mul24(xj, T.P4));   // len*Q
-      if (YOUNG) a = min(a, (unsigned)(pl[j] - T.deadbase));
+      if (YOUNG) a = min(a, (unsigned)pl[j]);     // (a dead line: pl = age*Q, and a is huge)
       m = max(m, a);
     }
     return m;
@@ -369,11 +481,12 @@ struct FwWave {
     fw_make_x<K, DX>(P, X);
     bool a = false;
 #pragma unroll
-    for (int j = 0; j < K; j++) a = a || (pl[j] < T.deadbase && FW_BYTE(X, j) != 0);
+    for (int j = 0; j < K; j++) a = a || (pl[j] >= T.alive0 && FW_BYTE(X, j) != 0);
     return __ballot(a) != 0;
   }
   __device__ __forceinline__ void run(const FwDesc &D, int NX, int pitch, long long nrows, const uint8_t *__restrict__ L,
-                                      const uint8_t *__restrict__ rowzero, bool anyzero, int *work) {
+                                      const uint8_t *__restrict__ rowzero, bool anyzero, int *work, int bx, int nblocks,
+                                      PackWave &pk) {
     const int NM = D.NM, NU = D.NU, du = D.du;
     const long long delta = D.sM + (long long)du * D.sU;
     // row numbers of the packed volume (rowzero[r] != 0: row r holds a voxel outside the ROI), wave-uniform like `off`
@@ -392,8 +505,8 @@ struct FwWave {
     // itself (a dequeue word saturates near 90 grabs per microsecond: 12 angles sharing one line, or one angle cut
     // into 16 384 tiny chunks, serialised the kernel on it; dealing out MORE rounds statically measured 10 % slower at
     // 512^3 -- walks of wrapping rows and of the window edges do not cost the same)
-    const int nwaves = (int)(gridDim.x * (blockDim.x >> 6));
-    const int wid = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));  // wave-uniform
+    const int nwaves = (int)(nblocks * (blockDim.x >> 6));      // waves of this role (bx = workgroup index within it)
+    const int wid = __builtin_amdgcn_readfirstlane((int)(bx * (blockDim.x >> 6) + (threadIdx.x >> 6)));  // wave-uniform
     const int static_rounds = 1;
     for (int it = 0;; it++) {
       int chunk;
@@ -427,7 +540,7 @@ struct FwWave {
         reset_lines(0);
       } else {
         load_row(lp + (off - delta), P);
-        reset_lines(T.deadbase);
+        reset_lines(0);            // dead: level 0 as far as the state goes, although P holds real levels
         young = 2;
       }
       int t = t0;
@@ -488,8 +601,10 @@ struct FwWave {
               load_row(p, v[k]);
               p += delta;
             }
+            pk.begin();                      // (the next volume's pack rides along: loads out, ...
             if (safe == 1) calm_padding();   // (second group of a pair: the first one let the padding lines grow)
             plain_group(v);
+            pk.finish();                     //  ... bytes stored behind the group's VALU / LDS work)
             safe--;
             if (young > 0) young--;
             t += U;
@@ -532,40 +647,6 @@ struct FwWave {
   }
 };
 
-template <bool LONG, int K, bool HASPAD>
-__global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, const uint8_t *__restrict__ L,
-                                                        const uint8_t *__restrict__ rowzero, int Ng, int Nr, int RS,
-                                                        u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
-                                                        int *__restrict__ work, int *__restrict__ flags) {
-  extern __shared__ u32 lds[];
-  if (flags[0]) return;  // irregular levels: the generic path will redo this call
-#ifdef PRAD_FW_SETPRIO   // experiment: issue priority over the co-resident pack waves of the neighbouring volume
-  __builtin_amdgcn_s_setprio(PRAD_FW_SETPRIO);
-#endif
-  const bool anyzero = flags[3] != 0;   // the pack kernel saw a voxel outside the ROI (else the row flags are not read)
-  const HistLayout h = hist_layout(true, true, true, Ng, RS);
-  if ((unsigned)(size_t)((lds_u32 *)lds) != 0u) {  // table offsets are used as LDS addresses
-    if (threadIdx.x == 0) atomicExch(flags + 2, 1);
-    return;
-  }
-  for (int i = threadIdx.x; i < h.words + Ng + 1; i += blockDim.x) lds[i] = 0;
-  __syncthreads();
-  const FwDesc &D = set.d[blockIdx.y];
-  FwTab T;
-  T.init(h, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
-  if (D.dx == 0) {
-    FwWave<LONG, K, 0, HASPAD> w(T, set.NX);
-    w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
-  } else if (D.dx > 0) {
-    FwWave<LONG, K, 1, HASPAD> w(T, set.NX);
-    w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
-  } else {
-    FwWave<LONG, K, -1, HASPAD> w(T, set.NX);
-    w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, work + PRAD_FW_WORK_STRIDE * blockIdx.y);
-  }
-  flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, D.slot, glcm_acc, glrlm_acc);
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // The angle along the contiguous axis with the same exec-masked step: a wave owns 64 consecutive rows (row = flattened
 // (z, y)), stages 64 x 64-voxel tiles through LDS (16 B per lane coalesced in, one row per lane out) and every lane walks
@@ -581,7 +662,7 @@ __device__ __forceinline__ void fw_row_word(const FwTab &T, u32 one, int &s, u32
   "ds_add_u32 %[t], %[one]\n\t"                                                                                  \
   "s_mov_b64 exec, -1\n\t"                                                                                       \
   "v_add_u32 %[s], %[Q], %[s]\n\t"
-  u32 z = 0;      // zero aware (see fw_plain_word<true>): a stretch of unmasked voxels never touches the table
+  u32 z = 0;      // zero aware: a stretch of unmasked voxels never touches the table
   asm volatile("" : "+v"(z));
   asm volatile(PRAD_FW_RCOL(0) PRAD_FW_RCOL(1) PRAD_FW_RCOL(2) PRAD_FW_RCOL(3)
                : [s] "+v"(s), [t] "=&v"(t)
@@ -590,21 +671,15 @@ __device__ __forceinline__ void fw_row_word(const FwTab &T, u32 one, int &s, u32
 #undef PRAD_FW_RCOL
 }
 
+// LDS bytes of the rows role: its table (RSr length slots) + one staging tile per wave
+__host__ __device__ inline size_t fw_rows_lds_bytes(const HistLayout &h, int waves) {
+  return ((fw_lds_bytes(h) + 15) & ~(size_t)15) + (size_t)waves * 64 * PRAD_ROW_PITCH;
+}
+
+// rows role of sweep_fw_kernel: workgroup bx of nblocks; the LDS table (layout h, zeroed by the caller) sits at address 0
 template <bool LONG>
-__global__ void __launch_bounds__(512) sweep_fw_rows_kernel(const uint8_t *__restrict__ L, long long nrows, int NX, int pitch,
-                                                            int slot, int Ng, int Nr, int RS, u32 *__restrict__ glcm_acc,
-                                                            u32 *__restrict__ glrlm_acc, int *__restrict__ flags) {
-  extern __shared__ u32 lds[];
-  if (flags[0]) return;
-  const HistLayout h = hist_layout(true, true, true, Ng, RS);
-  if ((unsigned)(size_t)((lds_u32 *)lds) != 0u) {
-    if (threadIdx.x == 0) atomicExch(flags + 2, 1);
-    return;
-  }
-  for (int i = threadIdx.x; i < h.words + Ng + 1; i += blockDim.x) lds[i] = 0;
-  __syncthreads();
-  FwTab T;
-  T.init(h, Nr, glrlm_acc + (size_t)slot * Ng * Nr);
+__device__ __forceinline__ void fw_rows_role(const HistLayout &h, const FwTab &T, u32 *lds, const uint8_t *__restrict__ L,
+                                             long long nrows, int NX, int pitch, int bx, int nblocks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
   const int dummy = T.dummy0b + 4 * lane;
   u32 one = 1;
@@ -612,9 +687,9 @@ __global__ void __launch_bounds__(512) sweep_fw_rows_kernel(const uint8_t *__res
   // per-wave staging tile behind the table and its dead zone (16-byte aligned)
   uint8_t *tile = reinterpret_cast<uint8_t *>(lds) + ((fw_lds_bytes(h) + 15) & ~(size_t)15) + (size_t)wave * 64 * PRAD_ROW_PITCH;
   const long long ngroups = (nrows + 63) / 64;
-  const long long nwaves = (long long)gridDim.x * wpb;
+  const long long nwaves = (long long)nblocks * wpb;
   const bool vec16 = (pitch & 15) == 0 && ((uintptr_t)L & 15) == 0;
-  for (long long grp = (long long)blockIdx.x * wpb + wave; grp < ngroups; grp += nwaves) {
+  for (long long grp = (long long)bx * wpb + wave; grp < ngroups; grp += nwaves) {
     const long long r0 = grp * 64;
     int s = 0;     // run state of this lane's row
     u32 pw = 0;    // previous staged word (its last byte is the previous voxel)
@@ -676,120 +751,87 @@ __global__ void __launch_bounds__(512) sweep_fw_rows_kernel(const uint8_t *__res
     }
     fw_checked<LONG>(T, dummy, s, (int)(pw >> 24), 0, false);   // the row ends: close its open run
   }
-  flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, slot, glcm_acc, glrlm_acc);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// pack + the x angle in one pass over the boundary arrays.  The pack is HBM-bound (5 B in, 1 B out per voxel) and
-// leaves VALU and LDS idle; the walk along x is LDS/VALU work on exactly the bytes the pack has just produced.  A wave
-// owns 64 consecutive rows, moves 64 x 64-voxel tiles: int32 levels (16 B per lane) + mask bytes (4 B per lane) ->
-// level*4 bytes -> global packed volume AND a per-wave LDS tile, then every lane walks its own row from the tile.
-// Needs Nx % 4 == 0 (vector loads of whole 4-voxel pieces); other shapes take pack_levels + the rows kernel.
-// ---------------------------------------------------------------------------------------------------------------
-template <bool LONG, bool WALK>
-__global__ void __launch_bounds__(1024) pack_rows_fw_kernel(const int *__restrict__ image, const uint8_t *__restrict__ mask,
-                                                            long long nrows, int NX, int pitch, uint8_t *__restrict__ L,
+// the angle along x as a launch of its own (8-wave workgroups: table + 8 staging tiles leave room for a second kind of
+// workgroup on the CU).  As a ROLE of sweep_fw_kernel (16-wave workgroups next to the line roles') the same walk measured
+// slower per CU -- 22.9 CU-ms instead of 14 at 512^3, the whole launch 0.477 ms against 0.38 + 0.055 for the two
+// launches (profiles/r03_probes.md) -- so the role is off unless PRAD_FW_ROWS_ROLE is set.
+template <bool LONG>
+__global__ void __launch_bounds__(512) sweep_fw_rows_kernel(const uint8_t *__restrict__ L, long long nrows, int NX, int pitch,
                                                             int slot, int Ng, int Nr, int RS, u32 *__restrict__ glcm_acc,
-                                                            u32 *__restrict__ glrlm_acc, int *__restrict__ flags,
-                                                            uint8_t *__restrict__ rowzero) {
+                                                            u32 *__restrict__ glrlm_acc, int *__restrict__ flags) {
   extern __shared__ u32 lds[];
+  if (flags[0]) return;
   const HistLayout h = hist_layout(true, true, true, Ng, RS);
-  if (WALK && (unsigned)(size_t)((lds_u32 *)lds) != 0u) {
+  if ((unsigned)(size_t)((lds_u32 *)lds) != 0u) {
     if (threadIdx.x == 0) atomicExch(flags + 2, 1);
     return;
   }
-  if (WALK) {
-    for (int i = threadIdx.x; i < h.words + Ng + 1; i += blockDim.x) lds[i] = 0;
-    __syncthreads();
-  }
+  for (int i = threadIdx.x; i < h.words + Ng + 1; i += blockDim.x) lds[i] = 0;
+  __syncthreads();
   FwTab T;
   T.init(h, Nr, glrlm_acc + (size_t)slot * Ng * Nr);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-  const int dummy = T.dummy0b + 4 * lane;
-  u32 one = 1;
-  asm volatile("" : "+v"(one));
-  uint8_t *tile = reinterpret_cast<uint8_t *>(lds) + (WALK ? ((fw_lds_bytes(h) + 15) & ~(size_t)15) : 0) + (size_t)wave * 64 * PRAD_ROW_PITCH;
-  const long long ngroups = (nrows + 63) / 64;
-  const long long nwaves = (long long)gridDim.x * wpb;
-  const int sub = lane >> 4, piece = lane & 15;   // an instruction covers 4 rows x 16 four-voxel pieces
-  int bad = 0;
-  for (long long grp = (long long)blockIdx.x * wpb + wave; grp < ngroups; grp += nwaves) {
-    const long long r0 = grp * 64;
-    int s = 0;
-    u32 pw = 0;
-    u32 zacc = 0;     // bit 7 of some byte set <=> this lane's row holds a voxel outside the ROI
-    for (int xc = 0; xc < NX; xc += 64) {
-      const int cx = xc + 4 * piece;
-      const bool xin = cx < NX;
-#pragma unroll 1
-      for (int half = 0; half < 2; half++) {   // 2 x 8 instructions: 40 VGPRs of loads in flight instead of 80
-        int4 q[8];
-        u32 mk[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const long long row = r0 + 4 * (8 * half + i) + sub;
-          q[i] = make_int4(0, 0, 0, 0);
-          mk[i] = 0;
-          if (xin && row < nrows) {
-            const long long e = row * NX + cx;
-            q[i] = *reinterpret_cast<const int4 *>(image + e);
-            mk[i] = *reinterpret_cast<const u32 *>(mask + e);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-          const int lv[4] = {q[i].x, q[i].y, q[i].z, q[i].w};
-          u32 o = 0;
-#pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const bool in = (mk[i] >> (8 * b)) & 0xffu;
-            const bool regular = in && lv[b] >= 1 && lv[b] <= Ng;
-            bad |= in && !regular;
-            // (a level outside 1..Ng packs as 0: the walk below must never index the tables with it -- the volume is
-            // redone on the generic kernels anyway)
-            o |= (regular ? ((u32)lv[b] << PRAD_FUSED_SHIFT) : 0u) << (8 * b);
-          }
-          const int tr = 4 * (8 * half + i) + sub;
-          const long long row = r0 + tr;
-          if (xin && row < nrows) *reinterpret_cast<u32 *>(L + row * pitch + cx) = o;
-          if (WALK) *reinterpret_cast<u32 *>(tile + tr * PRAD_ROW_PITCH + 4 * piece) = o;
+  fw_rows_role<LONG>(h, T, lds, L, nrows, NX, pitch, (int)blockIdx.x, (int)gridDim.x);
+  flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, slot, glcm_acc, glrlm_acc);
+}
+
+// One launch per volume: a 1-D grid of one 16-wave workgroup per CU, cut into ROLES -- the line angles (fixed-window
+// walks) and, when the caller's angle list holds it, the angle along x (fw_rows_role) -- plus the pack of the NEXT volume
+// as a side job of the line roles' waves (PackJob).  A volume whose pack found irregular levels (flags[0]) is skipped --
+// the generic kernels redo that call -- but the side job still runs.
+template <bool LONG, int K, bool HASPAD>
+__global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, PackJob pj, const uint8_t *__restrict__ L,
+                                                        const uint8_t *__restrict__ rowzero, int Ng, int Nr, int RS,
+                                                        u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
+                                                        int *__restrict__ work, int *__restrict__ flags) {
+  extern __shared__ u32 lds[];
+  const int nroles = set.count + (set.rows_role ? 1 : 0);
+  int role = 0;
+  while (role + 1 < nroles && (int)blockIdx.x >= set.first_block[role + 1]) role++;
+  const int bx = (int)blockIdx.x - set.first_block[role], nblocks = set.first_block[role + 1] - set.first_block[role];
+  const bool is_rows = set.rows_role && role == set.count;
+  // packing waves: those of the line roles (workgroups [0, first_block[count]) of the grid)
+  const int wpb = (int)(blockDim.x >> 6);
+  const long long pwaves = (long long)set.first_block[set.count] * wpb;
+  const long long pw = is_rows ? -1 : __builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
+  PackWave pk(pj, pw, pwaves);
+  const bool skip = set.count + set.rows_role == 0 || flags[0] != 0;  // nothing to walk / irregular levels
+#ifdef PRAD_FW_SETPRIO   // experiment: issue priority over co-resident waves of another launch
+  __builtin_amdgcn_s_setprio(PRAD_FW_SETPRIO);
+#endif
+  if (!skip) {
+    const bool anyzero = flags[3] != 0;   // the pack saw a voxel outside the ROI (else the row flags are not read)
+    const int rs = is_rows ? set.RSr : RS;
+    const HistLayout h = hist_layout(true, true, true, Ng, rs);
+    if ((unsigned)(size_t)((lds_u32 *)lds) != 0u) {  // table offsets are used as LDS addresses
+      if (threadIdx.x == 0) atomicExch(flags + 2, 1);
+    } else {
+      for (int i = threadIdx.x; i < h.words + Ng + 1; i += blockDim.x) lds[i] = 0;
+      __syncthreads();
+      const int slot = is_rows ? set.rows_slot : set.d[role].slot;
+      FwTab T;
+      T.init(h, Nr, glrlm_acc + (size_t)slot * Ng * Nr);
+      if (is_rows) {
+        fw_rows_role<LONG>(h, T, lds, L, set.nrows, set.NX, set.pitch, bx, nblocks);
+      } else {
+        const FwDesc &D = set.d[role];
+        int *wk = work + PRAD_FW_WORK_STRIDE * role;
+        if (D.dx == 0) {
+          FwWave<LONG, K, 0, HASPAD> w(T, set.NX);
+          w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk);
+        } else if (D.dx > 0) {
+          FwWave<LONG, K, 1, HASPAD> w(T, set.NX);
+          w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk);
+        } else {
+          FwWave<LONG, K, -1, HASPAD> w(T, set.NX);
+          w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk);
         }
       }
-      if (WALK) {
-        __builtin_amdgcn_wave_barrier();
-        const uint4 *rowp = reinterpret_cast<const uint4 *>(tile + lane * PRAD_ROW_PITCH);
-#pragma unroll 1
-        for (int qq = 0; qq < 4; qq++) {
-          const uint4 d = rowp[qq];
-          const u32 wds[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const u32 c = wds[k], x = __builtin_amdgcn_alignbyte(c, pw, 3);
-            if (xc + 16 * qq + 4 * k < NX) zacc |= (c - 0x01010101u) & ~c & 0x80808080u;   // a zero byte (Nx % 4 == 0)
-            const unsigned m = (pw >> 24) ? (unsigned)(s - __mul24((int)(pw >> 24), T.P4)) : 0u;
-            if (LONG && __ballot(m + 4 * T.Q > (unsigned)T.lenlim) != 0) {
-#pragma unroll
-              for (int b = 0; b < 4; b++) fw_checked<LONG>(T, dummy, s, (int)((x >> (8 * b)) & 0xffu), (int)((c >> (8 * b)) & 0xffu), false);
-            } else {
-              fw_row_word(T, one, s, c, x);
-            }
-            pw = c;
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-    }
-    if (WALK) {
-      fw_checked<LONG>(T, dummy, s, (int)(pw >> 24), 0, false);
-      if (rowzero && r0 + lane < nrows) {
-        rowzero[r0 + lane] = zacc ? 1 : 0;
-        if (zacc) flags[3] = 1;     // (benign race: every writer stores the same value)
-      }
+      flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, slot, glcm_acc, glrlm_acc);
     }
   }
-  if (bad) flags[0] = 1;
-  // (a volume with irregular levels is redone on the generic kernels: what was accumulated here is never read)
-  if (WALK) flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, slot, glcm_acc, glrlm_acc);
+  pk.drain();
 }
 
 }  // namespace prad

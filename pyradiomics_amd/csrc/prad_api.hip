@@ -266,13 +266,10 @@ struct SweepPlan {
   int RSfw = 0;                // run-length slots of its table (one workgroup per CU: most of the 160 KB)
   bool LONGfw = false;
   size_t lds_fw = 0;
-  bool fw_packrows = false;    // pack + x angle fused (kernels_sweepfw.h pack_rows_fw_kernel): Nx % 4 == 0
-  int RSfw_pr = 0;
-  bool LONGfw_pr = false;
-  size_t lds_fw_pr = 0;
-  int RSfw_rows = 0;           // same for the fixed-window rows kernel (8 waves + their staging tiles)
-  bool LONGfw_rows = false;
-  size_t lds_fw_rows = 0;
+  int RSfw_rows = 0;           // length slots of the rows role's table (it shares the LDS with 16 staging tiles)
+  size_t lds_fw_launch = 0;    // dynamic LDS of the launch: the larger of the two role kinds
+  size_t lds_fw_rows = 0;      // the x angle as a launch of its own (sweep_fw_rows_kernel)
+  bool LONGfw_any = false;     // some role's table does not hold every run length
   FwSet fwset;
 };
 
@@ -422,7 +419,31 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     if (const char *e = getenv("PRAD_FW_RS")) p.RSfw = std::max(1, std::min(p.RSfw, atoi(e)));   // tuning override
     p.LONGfw = p.RSfw < Nr;
     p.lds_fw = fw_lds_bytes(hist_layout(true, true, true, Ng, p.RSfw));
-    {
+    // Roles of the one launch (kernels_sweepfw.h sweep_fw_kernel): the line angles and, if the angle list holds it, the angle
+    // along x.  One 16-wave workgroup per CU over all roles; the rows role is cheaper than a line walk (alone on the GPU:
+    // 0.058 vs 0.085 ms at 512^3), so it gets fewer workgroups.
+    const bool rows_role = p.row_slot >= 0 && getenv("PRAD_FW_ROWS_ROLE");   // (measured slower than a launch of its own)
+    p.fwset.rows_role = rows_role ? 1 : 0;
+    p.fwset.rows_slot = p.row_slot;
+    p.fwset.RSr = 1;
+    p.lds_fw_launch = p.lds_fw;
+    p.LONGfw_any = p.LONGfw;
+    if (rows_role) {
+      int rs = fit_rs(true, true, true, Ng, Nr, 76 * 1024);
+      while (rs > 1 && fw_rows_lds_bytes(hist_layout(true, true, true, Ng, rs), 16) > 160 * 1024 - 512) rs--;
+      for (int r = rs; rs < Nr && r >= std::max(16, rs - 12); r--) {   // same bank-stride rule as above
+        const int d = (((r + 1) * (Ng + 1)) % 32 + 1) % 32, dist = std::min(d, 32 - d);
+        if ((d & 1) && dist >= 5 && dist <= 11) { rs = r; break; }
+      }
+      if (rs < std::min(Nr, 4) || fw_rows_lds_bytes(hist_layout(true, true, true, Ng, rs), 16) > 160 * 1024 - 512) {
+        return SweepPlan();   // (cannot happen for Ng <= 44: the table of 4 length slots takes 36 KB) -> generic path
+      }
+      p.RSfw_rows = rs;
+      p.fwset.RSr = rs;
+      p.lds_fw_launch = std::max(p.lds_fw, fw_rows_lds_bytes(hist_layout(true, true, true, Ng, rs), 16));
+      p.LONGfw_any = p.LONGfw || rs < Nr;
+    }
+    if (p.row_slot >= 0 && !rows_role) {   // the x angle as a launch of its own: 8 waves + their staging tiles
       const size_t tiles = (size_t)(kRowsThreads / 64) * 64 * PRAD_ROW_PITCH;
       int rs = fit_rs(true, true, true, Ng, Nr, 100 * 1024);
       for (int r = rs; rs < Nr && r >= std::max(16, rs - 12); r--) {   // same bank-stride rule as above
@@ -430,24 +451,30 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
         if ((d & 1) && dist >= 5 && dist <= 11) { rs = r; break; }
       }
       p.RSfw_rows = rs;
-      p.LONGfw_rows = rs < Nr;
       p.lds_fw_rows = ((fw_lds_bytes(hist_layout(true, true, true, Ng, rs)) + 15) & ~(size_t)15) + tiles;
     }
-    // (worth it once every wave slot of the GPU has a 64-row group of its own: 512^3 0.20 -> 0.19 ms, 256^3 loses)
-    if (p.row_slot >= 0 && p.Nx % 4 == 0 && p.pitch % 4 == 0 && (long long)p.Nz * p.Ny >= 64LL * 16 * cu_count() * 3 / 4 &&
-        !getenv("PRAD_NO_PACKROWS")) {
-      const size_t tiles = (size_t)16 * 64 * PRAD_ROW_PITCH;
-      const int rs = fit_rs(true, true, true, Ng, Nr, 66 * 1024);
-      if (rs >= std::min(Nr, 8)) {
-        p.fw_packrows = true;
-        p.RSfw_pr = rs;
-        p.LONGfw_pr = rs < Nr;
-        p.lds_fw_pr = ((fw_lds_bytes(hist_layout(true, true, true, Ng, rs)) + 15) & ~(size_t)15) + tiles;
+    {
+      const int nroles = p.lines.count + (rows_role ? 1 : 0);
+      int total = cu_count();
+      if (const char *e = getenv("PRAD_FW_BLOCKS")) total = std::max(nroles, atoi(e));   // tuning override: workgroups of the launch
+      double wrows = 2.8;
+      if (const char *e = getenv("PRAD_FW_ROWS_WEIGHT")) wrows = std::max(0.05, atof(e));
+      const double wsum = p.lines.count + (rows_role ? wrows : 0.0);
+      int blocks[PRAD_MAX_SWEEP + 1], used = 0;
+      for (int r = 0; r < nroles; r++) {
+        const double w = (rows_role && r == p.lines.count) ? wrows : 1.0;
+        blocks[r] = std::max(1, (int)(total * w / wsum));
+        used += blocks[r];
       }
+      for (int r = 0; used < total && total >= nroles; r = (r + 1) % p.lines.count) {   // the remainder goes to line roles
+        blocks[r]++;
+        used++;
+      }
+      p.fwset.first_block[0] = 0;
+      for (int r = 0; r < nroles; r++) p.fwset.first_block[r + 1] = p.fwset.first_block[r] + blocks[r];
+      for (int r = nroles + 1; r < PRAD_MAX_SWEEP + 2; r++) p.fwset.first_block[r] = p.fwset.first_block[nroles];
+      p.fw_blocks = p.fwset.first_block[nroles];
     }
-    // one workgroup (16 waves) per CU over all angles; a walk is cut into pieces so that every wave gets ~6 chunks
-    p.fw_blocks = std::max(1, cu_count() / p.lines.count);
-    if (const char *e = getenv("PRAD_FW_BLOCKS")) p.fw_blocks = std::max(1, atoi(e));
     int per_wave = 6;
     if (const char *e = getenv("PRAD_FW_PER_WAVE")) per_wave = std::max(1, atoi(e));
     p.fwset.count = p.lines.count;
@@ -458,7 +485,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
       D.slot = S.slot; D.NM = S.NM; D.NU = S.NU; D.du = S.du; D.dx = S.dx; D.sM = S.sM; D.sU = S.sU;
       p.fwset.pitch = p.pitch;
       p.fwset.nrows = p.Nz * p.Ny;
-      const long long want = (long long)per_wave * p.fw_blocks * 16;
+      const long long want = (long long)per_wave * (p.fwset.first_block[i + 1] - p.fwset.first_block[i]) * 16;
       int pieces = (int)std::max<long long>(1, (want + D.NU - 1) / D.NU);
       int CL = ((D.NM + pieces - 1) / pieces + 7) & ~7;
       CL = std::max(CL, D.NM >= 128 ? 64 : 16);   // (shorter pieces only multiply the piece start / tail overhead)
@@ -509,28 +536,40 @@ int launch_lines(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int
 }
 
 template <bool LNG, int K, bool HASPAD>
-int launch_fw_kp(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
-                 int *multi) {
-  uint8_t *rowzero = nullptr;   // written by the pack kernel of this call (sweep_glcm_glrlm)
-  PRAD_TRY(k.c->get<uint8_t>("rowzero", (size_t)p.Nz * p.Ny + 64, &rowzero));
+int launch_fw_kp(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels, const uint8_t *rowzero, int Ng, int Nr,
+                 u32 *glcm_acc, u32 *glrlm_acc, int *multi, int *flags_d) {
   PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_kernel<LNG, K, HASPAD>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw));
-  hipLaunchKernelGGL((sweep_fw_kernel<LNG, K, HASPAD>), dim3(p.fw_blocks, p.fwset.count), dim3(1024), p.lds_fw, k.s, p.fwset,
-                     levels, (const uint8_t *)rowzero, Ng, Nr, p.RSfw, glcm_acc, glrlm_acc, multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE, k.flags_d);
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw_launch));
+  hipLaunchKernelGGL((sweep_fw_kernel<LNG, K, HASPAD>), dim3(p.fw_blocks), dim3(1024), p.lds_fw_launch, k.s, p.fwset, pj,
+                     levels, rowzero, Ng, Nr, p.RSfw, glcm_acc, glrlm_acc, multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE, flags_d);
   return check_launch("sweep_fw_kernel");
 }
 template <bool LNG, int K>
-int launch_fw_k(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
-                int *multi) {
-  if (p.Nx != 64 * K) return launch_fw_kp<LNG, K, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
-  return launch_fw_kp<LNG, K, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
+int launch_fw_k(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels, const uint8_t *rowzero, int Ng, int Nr,
+                u32 *glcm_acc, u32 *glrlm_acc, int *multi, int *flags_d) {
+  if (p.Nx != 64 * K) return launch_fw_kp<LNG, K, true>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
+  return launch_fw_kp<LNG, K, false>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
 }
-int launch_fw(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
-              int *multi) {
-  if (p.LONGfw) return p.fwK == 4 ? launch_fw_k<true, 4>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)
-                                : launch_fw_k<true, 8>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
-  return p.fwK == 4 ? launch_fw_k<false, 4>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)
-                    : launch_fw_k<false, 8>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
+// the fixed-window launch of one volume: every line angle, the angle along x (rows role) and, optionally, the pack of the
+// NEXT volume as a side job
+int launch_fw(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels, const uint8_t *rowzero, int Ng, int Nr,
+              u32 *glcm_acc, u32 *glrlm_acc, int *multi, int *flags_d) {
+  if (p.LONGfw_any) return p.fwK == 4 ? launch_fw_k<true, 4>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
+                                    : launch_fw_k<true, 8>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
+  return p.fwK == 4 ? launch_fw_k<false, 4>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
+                    : launch_fw_k<false, 8>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
+}
+
+template <bool LNG>
+int launch_fw_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *flags_d) {
+  const long long nrows = (long long)p.Nz * p.Ny, groups = (nrows + 63) / 64;
+  const int wpb = kRowsThreads / 64;
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + wpb - 1) / wpb, (long long)cu_count()));
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_rows_kernel<LNG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw_rows));
+  hipLaunchKernelGGL((sweep_fw_rows_kernel<LNG>), dim3(gx), dim3(kRowsThreads), p.lds_fw_rows, k.s, levels, nrows, p.Nx,
+                     p.pitch, p.row_slot, Ng, Nr, p.RSfw_rows, glcm_acc, glrlm_acc, flags_d);
+  return check_launch("sweep_fw_rows_kernel");
 }
 
 template <bool G, bool R, bool LNG, bool F>
@@ -548,136 +587,196 @@ int launch_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int 
   return check_launch("sweep_rows_kernel");
 }
 
-template <bool LNG>
-int launch_pack_rows(Call &k, const SweepPlan &p, uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc) {
-  uint8_t *rowzero = nullptr;
-  PRAD_TRY(k.c->get<uint8_t>("rowzero", (size_t)p.Nz * p.Ny + 64, &rowzero));
-  const long long nrows = (long long)p.Nz * p.Ny, groups = (nrows + 63) / 64;
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + 15) / 16, (long long)cu_count()));
-  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pack_rows_fw_kernel<LNG, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw_pr));
-  hipLaunchKernelGGL((pack_rows_fw_kernel<LNG, true>), dim3(gx), dim3(1024), p.lds_fw_pr, k.s, k.image, k.mask, nrows, p.Nx,
-                     p.pitch, levels, p.row_slot, Ng, Nr, p.RSfw_pr, glcm_acc, glrlm_acc, k.flags_d, rowzero);
-  return check_launch("pack_rows_fw_kernel");
+// One packed volume between its pack and its finalize: device pointers of ONE workspace set (Context::lane) and the plan.
+struct VolState {
+  bool valid = false;
+  SweepPlan p;
+  int Ng = 0, Nr = 0, Na = 0;
+  double *glcm = nullptr, *glrlm = nullptr;   // outputs (device), either may be NULL
+  uint8_t *levels = nullptr, *rowzero = nullptr;
+  u32 *acc = nullptr, *glcm_acc = nullptr, *glrlm_acc = nullptr;
+  int *multi = nullptr;
+  int *flags_d = nullptr;
+  bool packed_inline = false;   // the pack rides in the previous volume's sweep launch (PackJob)
+};
+
+// workspace of a volume + the memsets that must precede its pack and its sweeps
+int vol_prepare(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, double *glrlm, VolState &v) {
+  Context &c = *k.c;
+  v.valid = true;
+  v.p = p;
+  v.Ng = Ng;
+  v.Nr = Nr;
+  v.Na = k.Na;
+  v.glcm = glcm;
+  v.glrlm = glrlm;
+  v.flags_d = k.flags_d;
+  const long long nrows = (long long)p.Nz * p.Ny;
+  PRAD_TRY(c.get<uint8_t>("levels", (size_t)nrows * p.pitch + 1024, &v.levels));
+  v.levels += 512;   // the fixed-window kernel reads (and masks) up to one window before the first and behind the last row
+  const size_t nglcm = glcm ? (size_t)k.Na * Ng * Ng : 0, nglrlm = glrlm ? (size_t)k.Na * Ng * Nr : 0;
+  // accumulators, then per-angle "multi-element" flags, then per-role work counters of the lines kernels
+  const size_t nctl = 2 * PRAD_MAX_SWEEP + (size_t)PRAD_FW_WORK_STRIDE * (PRAD_MAX_SWEEP + 1);
+  PRAD_TRY(c.get<u32>("sweep_acc", nglcm + nglrlm + nctl, &v.acc));
+  v.glcm_acc = v.acc;
+  v.glrlm_acc = v.acc + nglcm;
+  v.multi = (int *)(v.acc + nglcm + nglrlm);
+  PRAD_HIP(hipMemsetAsync(v.acc, 0, sizeof(u32) * (nglcm + nglrlm + nctl), k.s));
+  v.rowzero = nullptr;
+  if (p.fw) {
+    PRAD_TRY(c.get<uint8_t>("rowzero", (size_t)nrows + 64, &v.rowzero));
+    PRAD_HIP(hipMemsetAsync(v.rowzero, 0, (size_t)nrows, k.s));
+  }
+  return PRAD_OK;
 }
 
-template <bool LNG>
-int launch_fw_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc) {
-  const long long nrows = (long long)p.Nz * p.Ny, groups = (nrows + 63) / 64;
-  const int wpb = kRowsThreads / 64;
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + wpb - 1) / wpb, (long long)cu_count()));
-  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_rows_kernel<LNG>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw_rows));
-  hipLaunchKernelGGL((sweep_fw_rows_kernel<LNG>), dim3(gx), dim3(kRowsThreads), p.lds_fw_rows, k.s, levels, nrows, p.Nx,
-                     p.pitch, p.row_slot, Ng, Nr, p.RSfw_rows, glcm_acc, glrlm_acc, k.flags_d);
-  return check_launch("sweep_fw_rows_kernel");
+// can this volume's pack ride in another volume's sweep launch?  (linear layout, vector loads)
+bool pack_inline_ok(const Call &k, const VolState &v) {
+  return v.p.fw && v.glcm && v.glrlm && v.p.fused && v.p.pitch == v.p.Nx && v.p.padw == 0 && (k.g.n % 16) == 0 &&
+         ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)v.levels)) & 15) == 0;
+}
+
+PackJob make_pack_job(const Call &k, const VolState &v, const VolState *host) {
+  PackJob j;
+  memset(&j, 0, sizeof(j));
+  j.image = k.image;
+  j.mask = k.mask;
+  j.levels = v.levels;
+  j.rowzero = v.rowzero;
+  j.flags = v.flags_d;
+  j.n16 = k.g.n / 16;
+  j.NX = v.p.Nx;
+  j.Ng = v.Ng;
+  // cadence: spread the units over the host launch's plain groups (both counted per wave)
+  double groups = 0;
+  if (host)
+    for (int i = 0; i < host->p.fwset.count; i++) groups += (double)host->p.fwset.d[i].NM * host->p.fwset.d[i].NU / PRAD_FW_U;
+  const double units = (double)j.n16 / 64.0;
+  j.every = (int)std::max(1.0, std::min(64.0, std::floor(0.92 * groups / std::max(1.0, units))));
+  if (const char *e = getenv("PRAD_PACK_EVERY")) j.every = std::max(1, atoi(e));
+  return j;
+}
+
+int vol_pack_standalone(Call &k, VolState &v) {
+  Context &c = *k.c;
+  const SweepPlan &p = v.p;
+  Timed t(c, "pack", k.s);
+  const int vec_ok = p.vec_rows && ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)v.levels)) & 15) == 0;
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n / 16 + 255) / 256, 4096));
+  // the fused walker reads level*4 bytes (see Walker<true, true, LONG, true>); it only exists for Ng <= 44
+  const int shift = (v.glcm && v.glrlm && p.fused) ? PRAD_FUSED_SHIFT : 0;
+  hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, k.s, k.image, k.mask, k.g.n, p.Nx, p.pitch, p.padw,
+                     v.Ng, v.levels, v.flags_d, vec_ok, shift, v.rowzero);
+  return check_launch("pack_levels_kernel");
 }
 
 template <bool G, bool R, bool F>
-int launch_sweeps(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
-                  int *multi, bool rows_done = false) {
-  Timed t(*k.c, "sweep", k.s);
+int launch_sweeps(Call &k, const VolState &v, const PackJob &pj) {
+  const SweepPlan &p = v.p;
   if (p.lines.count > 0 && p.fw && G && R && F) {
-    PRAD_TRY(launch_fw(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi));
-  } else if (p.lines.count > 0) {
-    if (R && p.LONG) PRAD_TRY((launch_lines<G, R, true, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
-    else PRAD_TRY((launch_lines<G, R, false, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+    {
+      Timed t(*k.c, "sweep", k.s);
+      PRAD_TRY(launch_fw(k, p, pj, v.levels, v.rowzero, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi, v.flags_d));
+    }
+    if (p.row_slot >= 0 && !p.fwset.rows_role) {
+      Timed t(*k.c, "rows", k.s);
+      if (p.RSfw_rows < v.Nr) PRAD_TRY(launch_fw_rows<true>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.flags_d));
+      else PRAD_TRY(launch_fw_rows<false>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.flags_d));
+    }
+    return PRAD_OK;
   }
-  if (rows_done) return PRAD_OK;   // the x angle was walked by pack_rows_fw_kernel
-  if (p.row_slot >= 0 && p.fw && G && R && F && !getenv("PRAD_NO_FW_ROWS")) {
-    if (p.LONGfw_rows) PRAD_TRY(launch_fw_rows<true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc));
-    else PRAD_TRY(launch_fw_rows<false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc));
-  } else if (p.row_slot >= 0) {
-    if (R && p.LONGr) PRAD_TRY((launch_rows<G, R, true, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
-    else PRAD_TRY((launch_rows<G, R, false, F>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
+  Timed t(*k.c, "sweep", k.s);
+  if (p.lines.count > 0) {
+    if (R && p.LONG) PRAD_TRY((launch_lines<G, R, true, F>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi)));
+    else PRAD_TRY((launch_lines<G, R, false, F>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi)));
+  }
+  if (p.row_slot >= 0) {
+    if (R && p.LONGr) PRAD_TRY((launch_rows<G, R, true, F>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi)));
+    else PRAD_TRY((launch_rows<G, R, false, F>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi)));
   }
   return PRAD_OK;
+}
+
+// the sweeps of volume v; `pj` (n16 > 0) = the pack of another volume as a side job of the fixed-window launch
+int vol_sweep(Call &k, const VolState &v, const PackJob &pj) {
+  if (pj.n16 > 0 && !(v.p.fw && v.p.lines.count > 0 && v.glcm && v.glrlm && v.p.fused))
+    return fail(PRAD_E_ARG, "internal: a pack job needs a fixed-window host launch");
+  if (v.glcm && v.glrlm && v.p.fused) return launch_sweeps<true, true, true>(k, v, pj);
+  if (v.glcm && v.glrlm) return launch_sweeps<true, true, false>(k, v, pj);
+  if (v.glcm) return launch_sweeps<true, false, false>(k, v, pj);
+  return launch_sweeps<false, true, false>(k, v, pj);
 }
 
 __global__ void latch_flags_kernel(const int *__restrict__ flags, int *__restrict__ sticky) {
   if (flags[0] || flags[2]) sticky[0] = 1;
 }
 
-// returns PRAD_OK with *used=false if the device found irregular levels (caller then runs generic)
-int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, double *glrlm, bool *used) {
+// u32 accumulators -> float64 matrices in the reference layouts; `sticky` (deferred calls): latch the levels verdict
+int vol_finalize(Call &k, const VolState &v, int *sticky) {
   Context &c = *k.c;
-  uint8_t *levels = nullptr;
-  const long long nrows = (long long)p.Nz * p.Ny;
-  PRAD_TRY(c.get<uint8_t>("levels", (size_t)nrows * p.pitch + 1024, &levels));
-  levels += 512;   // the fixed-window kernel reads (and masks) up to one window before the first and behind the last row
-  u32 *glcm_acc = nullptr, *glrlm_acc = nullptr;
-  int *multi = nullptr;
-  const size_t nglcm = glcm ? (size_t)k.Na * Ng * Ng : 0, nglrlm = glrlm ? (size_t)k.Na * Ng * Nr : 0;
-  u32 *acc = nullptr;
-  // accumulators, then per-angle "multi-element" flags, then per-angle work counters of the lines kernel
-  const size_t nctl = 2 * PRAD_MAX_SWEEP + (size_t)PRAD_FW_WORK_STRIDE * (PRAD_MAX_SWEEP + 1);
-  PRAD_TRY(c.get<u32>("sweep_acc", nglcm + nglrlm + nctl, &acc));
-  glcm_acc = acc;
-  glrlm_acc = acc + nglcm;
-  multi = (int *)(acc + nglcm + nglrlm);
-  PRAD_HIP(hipMemsetAsync(acc, 0, sizeof(u32) * (nglcm + nglrlm + nctl), k.s));
-  const bool packrows = p.fw && p.fw_packrows && glcm && glrlm && p.fused &&
-                        ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)levels)) & 15) == 0;
-  if (packrows) {
-    Timed t(c, "pack", k.s);   // (the x angle's walk is hidden inside: the family name says what bounds the kernel)
-    if (p.LONGfw_pr) PRAD_TRY(launch_pack_rows<true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc));
-    else PRAD_TRY(launch_pack_rows<false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc));
-  } else {
-    Timed t(c, "pack", k.s);
-    const int vec_ok = p.vec_rows && ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)levels)) & 15) == 0;
-    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n / 16 + 255) / 256, 4096));
-    // the fused walker reads level*4 bytes (see Walker<true, true, LONG, true>); it only exists for Ng <= 44
-    const int shift = (glcm && glrlm && p.fused) ? PRAD_FUSED_SHIFT : 0;
-    uint8_t *rowzero = nullptr;
-    if (p.fw) {
-      PRAD_TRY(c.get<uint8_t>("rowzero", (size_t)nrows + 64, &rowzero));
-      PRAD_HIP(hipMemsetAsync(rowzero, 0, (size_t)nrows, k.s));
-    }
-    hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, k.s, k.image, k.mask, k.g.n, p.Nx, p.pitch, p.padw,
-                       Ng, levels, k.flags_d, vec_ok, shift, rowzero);
-    PRAD_TRY(check_launch("pack_levels_kernel"));
-  }
-  if (glcm && glrlm && p.fused) PRAD_TRY((launch_sweeps<true, true, true>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi, packrows)));
-  else if (glcm && glrlm) PRAD_TRY((launch_sweeps<true, true, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
-  else if (glcm) PRAD_TRY((launch_sweeps<true, false, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
-  else PRAD_TRY((launch_sweeps<false, true, false>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi)));
-  int *sticky = nullptr;       // deferred calls latch their levels verdict; finalize_glrlm_kernel does it when it runs
-  if (c.deferred) PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
+  const SweepPlan &p = v.p;
+  const int Ng = v.Ng, Nr = v.Nr, Na = v.Na;
+  double *glcm = v.glcm, *glrlm = v.glrlm;
   bool latched = false;
   {
     Timed t(c, "finalize", k.s);
     if (glcm && glrlm && p.fused) {
-      const int nb1 = (int)blocks_for((long long)Ng * Ng * k.Na), nb2 = (Ng * k.Na + 3) / 4;
-      hipLaunchKernelGGL(finalize_glcm_diag_kernel, dim3(nb1 + nb2), dim3(256), 0, k.s, glcm_acc, glrlm_acc, Ng, Nr, k.Na, nb1,
-                         glcm, multi);
+      const int nb1 = (int)blocks_for((long long)Ng * Ng * Na), nb2 = (Ng * Na + 3) / 4;
+      hipLaunchKernelGGL(finalize_glcm_diag_kernel, dim3(nb1 + nb2), dim3(256), 0, k.s, v.glcm_acc, v.glrlm_acc, Ng, Nr, Na, nb1,
+                         glcm, v.multi);
       PRAD_TRY(check_launch("finalize_glcm_diag_kernel"));
     } else if (glcm) {
-      hipLaunchKernelGGL(finalize_glcm_kernel, dim3(blocks_for((long long)Ng * Ng * k.Na)), dim3(256), 0, k.s,
-                         glcm_acc, glrlm_acc, Ng, Nr, k.Na, p.fused ? 1 : 0, glcm);
+      hipLaunchKernelGGL(finalize_glcm_kernel, dim3(blocks_for((long long)Ng * Ng * Na)), dim3(256), 0, k.s,
+                         v.glcm_acc, v.glrlm_acc, Ng, Nr, Na, p.fused ? 1 : 0, glcm);
       PRAD_TRY(check_launch("finalize_glcm_kernel"));
     }
     if (glrlm && p.fused) {
       if (!glcm) {
-        hipLaunchKernelGGL(glcm_diag_resolve_kernel, dim3(Ng, k.Na), dim3(64), 0, k.s, glcm_acc, glrlm_acc, Ng, Nr, k.Na,
-                           glcm, multi);
+        hipLaunchKernelGGL(glcm_diag_resolve_kernel, dim3(Ng, Na), dim3(64), 0, k.s, v.glcm_acc, v.glrlm_acc, Ng, Nr, Na,
+                           glcm, v.multi);
         PRAD_TRY(check_launch("glcm_diag_resolve_kernel"));
       }
-      hipLaunchKernelGGL(multi_check_kernel, dim3(128, k.Na), dim3(256), 0, k.s, p.aset, levels, p.Nz, p.Ny, p.Nx,
-                         p.pitch, multi);
+      hipLaunchKernelGGL(multi_check_kernel, dim3(128, Na), dim3(256), 0, k.s, p.aset, v.levels, p.Nz, p.Ny, p.Nx,
+                         p.pitch, v.multi);
       PRAD_TRY(check_launch("multi_check_kernel"));
     }
     if (glrlm) {
-      hipLaunchKernelGGL(finalize_glrlm_kernel, dim3(blocks_for((long long)Ng * Nr * k.Na)), dim3(256), 0, k.s,
-                         glrlm_acc, multi, Ng, Nr, k.Na, glrlm, (const int *)k.flags_d, sticky);
+      hipLaunchKernelGGL(finalize_glrlm_kernel, dim3(blocks_for((long long)Ng * Nr * Na)), dim3(256), 0, k.s,
+                         v.glrlm_acc, v.multi, Ng, Nr, Na, glrlm, (const int *)v.flags_d, sticky);
       PRAD_TRY(check_launch("finalize_glrlm_kernel"));
       latched = sticky != nullptr;
     }
   }
+  if (sticky && !latched) {
+    hipLaunchKernelGGL(latch_flags_kernel, dim3(1), dim3(1), 0, k.s, v.flags_d, sticky);
+    PRAD_TRY(check_launch("latch_flags_kernel"));
+  }
+  return PRAD_OK;
+}
+
+// returns PRAD_OK with *used=false if the device found irregular levels (caller then runs generic)
+int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, double *glrlm, bool *used) {
+  Context &c = *k.c;
+  VolState v;
+  PRAD_TRY(vol_prepare(k, p, Ng, Nr, glcm, glrlm, v));
+  PRAD_TRY(vol_pack_standalone(k, v));
+  PackJob pj;
+  memset(&pj, 0, sizeof(pj));
+  if (getenv("PRAD_FUSEPACK_PROTO") && pack_inline_ok(k, v)) {
+    // measurement prototype: the launch packs THIS volume a second time into scratch buffers (results unaffected)
+    VolState scratch = v;
+    PRAD_TRY(c.get<uint8_t>("proto_levels", (size_t)k.g.n + 1024, &scratch.levels));
+    PRAD_TRY(c.get<uint8_t>("proto_rowzero", (size_t)p.Nz * p.Ny + 64, &scratch.rowzero));
+    PRAD_TRY(c.get<int>("proto_flags", 4, &scratch.flags_d));
+    PRAD_HIP(hipMemsetAsync(scratch.rowzero, 0, (size_t)p.Nz * p.Ny, k.s));
+    PRAD_HIP(hipMemsetAsync(scratch.flags_d, 0, sizeof(int) * 4, k.s));
+    pj = make_pack_job(k, scratch, &v);
+  }
+  PRAD_TRY(vol_sweep(k, v, pj));
+  int *sticky = nullptr;       // deferred calls latch their levels verdict
+  if (c.deferred) PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
+  PRAD_TRY(vol_finalize(k, v, sticky));
   if (c.deferred) {   // enqueue only: the verdict on the levels is latched for prad_deferred_status()
-    if (!latched) {
-      hipLaunchKernelGGL(latch_flags_kernel, dim3(1), dim3(1), 0, k.s, k.flags_d, sticky);
-      PRAD_TRY(check_launch("latch_flags_kernel"));
-    }
     *used = true;
     return PRAD_OK;
   }
@@ -685,6 +784,90 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
   // flags[2]: the fused walker found its table away from LDS address 0 and did nothing (cannot happen with the current
   // toolchain: the dynamic array is the kernels' only LDS object) -- let the generic kernels redo the call
   *used = (k.flags_h[0] == 0 && k.flags_h[2] == 0);
+  return PRAD_OK;
+}
+
+// ---- deferred calls as a two-stage pipeline (the default deferred mode; PRAD_DEFERRED_MODE=lanes selects the lanes) -------
+// A deferred whole-volume call N launches { walks of volume N-1 + pack of volume N } as ONE fixed-window launch (the pack
+// is a side job of the walking waves: kernels_sweepfw.h PackJob), then the x angle and the finalize of volume N-1.  Volume
+// N itself stays PENDING (packed, not yet walked) until the next deferred call or until prad_deferred_status /
+// prad_deferred_join flush it.  Two workspace sets alternate (Context::lane selects the set; the stream is the caller's).
+struct PipeState {
+  VolState pending;
+  hipStream_t s = nullptr;      // stream the pending volume's pack was enqueued on
+  unsigned long long seq = 0;
+  hipEvent_t ev = nullptr;
+  int mode = -1;                // 1 pipeline, 0 lanes
+};
+PipeState &pipe_state() {
+  static thread_local PipeState p;
+  return p;
+}
+bool pipeline_mode() {
+  PipeState &ps = pipe_state();
+  if (ps.mode < 0) {
+    const char *e = getenv("PRAD_DEFERRED_MODE");
+    ps.mode = (e && strcmp(e, "lanes") == 0) ? 0 : 1;
+  }
+  return ps.mode == 1;
+}
+int pipeline_sticky(Context &c, int **sticky) { return c.get<int>("deferred_sticky", 16, sticky); }
+
+// walks + finalize of the pending volume on stream s (pj: the next volume's pack as a side job, or n16 == 0)
+int pipeline_retire(Context &c, hipStream_t s, const PackJob &pj) {
+  PipeState &ps = pipe_state();
+  if (ps.s != s) {   // the pack ran on another stream: order the two on the device
+    if (!ps.ev) PRAD_HIP(hipEventCreateWithFlags(&ps.ev, hipEventDisableTiming));
+    PRAD_HIP(hipEventRecord(ps.ev, ps.s));
+    PRAD_HIP(hipStreamWaitEvent(s, ps.ev, 0));
+  }
+  Call k;
+  k.c = &c;
+  k.s = s;
+  k.Na = ps.pending.Na;
+  k.flags_d = ps.pending.flags_d;
+  int *sticky = nullptr;
+  PRAD_TRY(pipeline_sticky(c, &sticky));
+  PRAD_TRY(vol_sweep(k, ps.pending, pj));
+  PRAD_TRY(vol_finalize(k, ps.pending, sticky));
+  ps.pending.valid = false;
+  return PRAD_OK;
+}
+
+// nothing pending afterwards (kernels enqueued on the pending volume's own stream; no host synchronisation)
+int pipeline_flush(Context &c) {
+  PipeState &ps = pipe_state();
+  if (!ps.pending.valid) return PRAD_OK;
+  PackJob none;
+  memset(&none, 0, sizeof(none));
+  const size_t before = c.times.size();
+  PRAD_TRY(pipeline_retire(c, ps.s, none));
+  if (c.timing_accumulate) c.all_times.insert(c.all_times.end(), c.times.begin() + (long)before, c.times.end());
+  return PRAD_OK;
+}
+
+// one deferred call in pipeline mode; *handled = false: the volume is not a fixed-window one, the caller takes the
+// ordinary deferred route (the pipeline has been drained)
+int pipeline_step(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, double *glrlm, bool *handled) {
+  Context &c = *k.c;
+  PipeState &ps = pipe_state();
+  *handled = false;
+  if (!(p.ok && p.fw && p.lines.count > 0 && glcm && glrlm && p.fused)) return pipeline_flush(c);
+  VolState v;
+  PRAD_TRY(vol_prepare(k, p, Ng, Nr, glcm, glrlm, v));
+  PackJob pj;
+  memset(&pj, 0, sizeof(pj));
+  bool inl = false;
+  if (ps.pending.valid) {
+    inl = pack_inline_ok(k, v) && !getenv("PRAD_NO_INLINE_PACK");
+    if (inl) pj = make_pack_job(k, v, &ps.pending);
+    PRAD_TRY(pipeline_retire(c, k.s, pj));
+  }
+  if (!inl) PRAD_TRY(vol_pack_standalone(k, v));
+  v.packed_inline = inl;
+  ps.pending = v;
+  ps.s = k.s;
+  *handled = true;
   return PRAD_OK;
 }
 
@@ -700,13 +883,19 @@ int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *siz
     Context &c;
     ~LaneGuard() { c.lane = -1; }
   } lane_guard{c};
-  if (c.deferred && !voxels) PRAD_TRY(c.lane_begin(s, &s));   // whole-volume deferred calls alternate between lanes
+  const bool pipe = c.deferred && !voxels && pipeline_mode();
+  if (c.deferred && !voxels && !pipe) PRAD_TRY(c.lane_begin(s, &s));   // lanes mode: whole-volume deferred calls alternate between lanes
+  if (pipe) c.lane = (int)(pipe_state().seq++ & 1);                    // pipeline mode: the workspace sets alternate, the stream is the caller's
   Call k;
   PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, Nvox, voxels, kernelRadius, force2Ddim, s));
   PRAD_TRY(c.begin_call(s));
   SweepPlan p = plan_sweep(k, Ng, Nr, glcm != nullptr, glrlm != nullptr);
   bool done = false;
-  if (p.ok) {
+  if (pipe) {
+    PRAD_TRY(pipeline_step(k, p, Ng, Nr, glcm, glrlm, &done));
+    if (done) c.last_path = "sweep";
+  }
+  if (!done && p.ok) {
     PRAD_TRY(sweep_glcm_glrlm(k, p, Ng, Nr, glcm, glrlm, &done));
     if (done) c.last_path = "sweep";
   }
@@ -1451,6 +1640,13 @@ int prad_set_device(int device) {
   if (device < 0 || device >= n) return fail(PRAD_E_ARG, "device %d not in [0,%d)", device, n);
   Context &c = ctx();
   if (c.device != device) {
+    if (pipe_state().pending.valid && c.device_set && hipSetDevice(c.device) == hipSuccess) {
+      (void)pipeline_flush(c);   // a volume still pending on the old device: retire it there
+      if (pipe_state().s) (void)hipStreamSynchronize(pipe_state().s);
+    }
+    pipe_state().pending.valid = false;
+    pipe_state().s = nullptr;
+    pipe_state().ev = nullptr;
     c.own_stream = nullptr;  // streams belong to a device; new ones are created lazily
     for (int l = 0; l < PRAD_MAX_LANES; l++) {
       if (c.lane_stream[l]) (void)hipStreamSynchronize(c.lane_stream[l]);
@@ -1474,6 +1670,11 @@ long long prad_workspace_bytes(void) {
 }
 int prad_release_workspace(void) {
   Context &c = ctx();
+  if (pipe_state().pending.valid) {        // the pending volume's buffers are about to go away: retire it first
+    (void)pipeline_flush(c);
+    if (pipe_state().s) (void)hipStreamSynchronize(pipe_state().s);
+    pipe_state().pending.valid = false;
+  }
   glszm_state().valid = false;            // its zone list lives in the workspace
   for (auto &kv : c.bufs) {
     if (kv.second.p) (void)hipFree(kv.second.p);
@@ -1552,14 +1753,34 @@ int prad_set_lanes(int n) {
   c.lane_seq = 0;
   return PRAD_OK;
 }
+int prad_set_deferred_mode(int mode) {
+  if (mode < -1 || mode > 1) return fail(PRAD_E_ARG, "deferred mode %d (0 lanes, 1 pipeline, -1 environment default)", mode);
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  PipeState &ps = pipe_state();
+  PRAD_TRY(pipeline_flush(c));
+  if (ps.s) PRAD_HIP(hipStreamSynchronize(ps.s));
+  PRAD_TRY(c.lanes_sync());
+  ps.mode = mode;
+  return PRAD_OK;
+}
 int prad_deferred_join(void *stream) {
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
+  PipeState &ps = pipe_state();
+  PRAD_TRY(pipeline_flush(c));
+  if (ps.s && ps.s != (hipStream_t)stream) {   // the flushed work sits on the stream of its pack
+    if (!ps.ev) PRAD_HIP(hipEventCreateWithFlags(&ps.ev, hipEventDisableTiming));
+    PRAD_HIP(hipEventRecord(ps.ev, ps.s));
+    PRAD_HIP(hipStreamWaitEvent((hipStream_t)stream, ps.ev, 0));
+  }
   return c.lanes_join((hipStream_t)stream);
 }
 int prad_deferred_status(void *stream) {
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
+  PRAD_TRY(pipeline_flush(c));
+  if (pipe_state().s) PRAD_HIP(hipStreamSynchronize(pipe_state().s));
   PRAD_HIP(hipStreamSynchronize((hipStream_t)stream));
   PRAD_TRY(c.lanes_sync());
   if (!c.has("deferred_sticky")) return PRAD_OK;  // no deferred call yet

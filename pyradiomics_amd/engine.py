@@ -105,6 +105,12 @@ def set_lanes(n: int) -> None:
     _lib.raise_for(_lib.load().prad_set_lanes(int(n)), "lanes")
 
 
+def set_deferred_mode(mode: int) -> None:
+    """how deferred whole-volume calls overlap: 1 = two-stage pipeline on the caller's stream (volume N's pack rides in the
+    walk launch of volume N-1; default), 0 = lanes (internal streams), -1 = environment default; flushes pending work"""
+    _lib.raise_for(_lib.load().prad_set_deferred_mode(int(mode)), "deferred mode")
+
+
 def timing_begin() -> None:
     _lib.load().prad_timing_begin()
 

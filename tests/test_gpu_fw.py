@@ -124,7 +124,29 @@ def test_fw_matches_wrapped_lines_kernel(cm, monkeypatch):
     assert np.array_equal(g0, g1) and np.array_equal(r0, r1)
 
 
-def test_deferred_calls_pipeline_and_report_late(cm):
+@pytest.mark.parametrize("shape", [(24, 30, 512), (300, 12, 128), (12, 300, 72), (128, 128, 128)])
+@pytest.mark.parametrize("level", [11, 32])
+def test_fw_very_long_runs_of_high_levels(cm, checker, shape, level):
+    """a flat volume of a HIGH level: every run spans its whole line (up to 512 voxels).  Until round 3 a dead line was one
+    whose state lay behind the table, and level*P + len*Q of such a run crossed that mark -- its end was dropped (the x
+    angle of a (24, 30, 512) volume of level 11 lost GLRLM[10][511] and the GLCM diagonal that derives from it)"""
+    img = np.full(shape, level, np.int32)
+    img[1, 2, 3] = 5                               # (and one voxel that cuts a few of the runs)
+    _check(cm, checker, img, _mask(1, shape, "full"), 32)
+    _check(cm, checker, img, _mask(3, shape, "ball"), 32)
+
+
+@pytest.fixture(params=["pipeline", "lanes"])
+def deferred_mode(request):
+    """both ways deferred calls overlap: the two-stage pipeline (volume N's pack rides in the walk launch of volume N-1)
+    and the lanes (internal streams)"""
+    from pyradiomics_amd import engine
+    engine.set_deferred_mode(1 if request.param == "pipeline" else 0)
+    yield request.param
+    engine.set_deferred_mode(-1)
+
+
+def test_deferred_calls_pipeline_and_report_late(cm, deferred_mode):
     """deferred mode: calls only enqueue; results equal the synchronous call; irregular levels surface in the status"""
     import torch
     from pyradiomics_amd import engine
@@ -147,7 +169,7 @@ def test_deferred_calls_pipeline_and_report_late(cm):
 
 
 @pytest.mark.parametrize("lanes", [1, 2, 3])
-def test_deferred_lanes_agree(cm, lanes):
+def test_deferred_lanes_agree(cm, lanes, deferred_mode):
     """deferred whole-volume calls alternate between the library's lanes (internal streams + workspaces): five volumes
     of different shapes in flight, every result equal to the synchronous call; inputs produced on the caller's stream
     right before the call (the lane has to wait for them)"""
@@ -177,7 +199,7 @@ def test_deferred_lanes_agree(cm, lanes):
         engine.set_lanes(9)
 
 
-def test_lanes_survive_a_workspace_release_and_mixed_sizes(cm):
+def test_lanes_survive_a_workspace_release_and_mixed_sizes(cm, deferred_mode):
     """deferred volumes of alternating shapes (every call re-plans and regrows its lane's workspace), a workspace
     release between two deferred batches, a synchronous call in between: all results equal the synchronous ones"""
     import torch
@@ -201,7 +223,7 @@ def test_lanes_survive_a_workspace_release_and_mixed_sizes(cm):
         engine.release_workspace()
 
 
-def test_deferred_join_orders_the_callers_stream(cm):
+def test_deferred_join_orders_the_callers_stream(cm, deferred_mode):
     """deferred_join(): the caller's stream waits for the lanes on the device; torch work queued afterwards sees the
     outputs without any host synchronisation in between"""
     import torch
@@ -215,3 +237,48 @@ def test_deferred_join_orders_the_callers_stream(cm):
     sums = torch.stack([g.sum() for g, _, _ in got])          # on the caller's stream, right behind the join
     engine.deferred_status()
     assert sums.tolist() == want
+
+
+def test_pipeline_packs_inside_the_previous_walk_and_flushes(cm, checker):
+    """pipeline mode in detail: the pack of volume N is a side job of volume N-1's walk launch (no pack launch of its own
+    from the second call on: the "pack" timing family stays empty), a volume whose rows are no multiple of 16 voxels or
+    that is no fixed-window volume takes its own pack / the ordinary route, partial masks raise row flags through the side
+    job, and the last volume is walked by the flush; every result bit-equal to the CPU checker"""
+    import torch
+    from pyradiomics_amd import engine
+    Ng = 32
+    shapes = [(24, 30, 512), (24, 30, 512), (20, 26, 256), (18, 22, 300), (24, 30, 512), (30, 30, 64), (24, 30, 512)]
+    kinds = ["uniform", "smooth", "uniform", "blobs", "flat", "uniform", "smooth"]
+    masks = ["full", "ball", "random", "full", "full", "random", "ball"]
+    vols = [(_levels(70 + i, s, Ng, k), _mask(80 + i, s, m)) for i, (s, k, m) in enumerate(zip(shapes, kinds, masks))]
+    dev = [(torch.from_numpy(i).cuda(), torch.from_numpy(m.astype(np.uint8)).cuda()) for i, m in vols]
+    engine.set_deferred_mode(1)
+    try:
+        engine.timing_begin()
+        got = [engine.glcm_glrlm(i, m, Ng, 512, deferred=True) for i, m in dev]
+        engine.deferred_status()
+        pack_ms = engine.timing_ms("pack")
+        engine.timing_end()
+        for n, ((img, mask), (g, r, _)) in enumerate(zip(vols, got)):
+            eg, _ = checker.calculate_glcm(img, mask, [1], Ng, False, 0)
+            er, _ = checker.calculate_glrlm(img, mask, Ng, 512, False, 0)
+            assert np.array_equal(g.cpu().numpy(), eg[0]), "GLCM of volume %d %s" % (n, shapes[n])
+            assert np.array_equal(r.cpu().numpy(), er[0]), "GLRLM of volume %d %s" % (n, shapes[n])
+        # same-shape volumes back to back: only the first one packs in a launch of its own
+        engine.timing_begin()
+        got = [engine.glcm_glrlm(dev[0][0], dev[0][1], Ng, 512, deferred=True) for _ in range(4)]
+        engine.deferred_status()
+        t_pack, t_sweep = engine.timing_ms("pack"), engine.timing_ms("sweep")
+        engine.timing_end()
+        assert t_sweep > 0 and pack_ms > 0
+        one = engine.glcm_glrlm(dev[0][0], dev[0][1], Ng, 512)
+        engine.timing_begin()
+        engine.glcm_glrlm(dev[0][0], dev[0][1], Ng, 512, deferred=True)
+        engine.deferred_status()
+        t_one_pack = engine.timing_ms("pack")
+        engine.timing_end()
+        assert t_pack < 1.5 * t_one_pack + 0.01, (t_pack, t_one_pack)     # 4 volumes, ONE standalone pack
+        for g, r, _ in got:
+            assert torch.equal(g, one[0]) and torch.equal(r, one[1])
+    finally:
+        engine.set_deferred_mode(-1)
