@@ -39,19 +39,17 @@ struct FwSet {
   int NX;
   int pitch;         // bytes per row of the packed volume (row r of rowzero[] starts at r * pitch)
   int nrows;         // rows of the packed volume
-  int rows_role;     // 1: one more role (index `count`) walks the angle along x (output column rows_slot) in the same launch
-  int rows_slot;
-  int RSr;           // run-length slots of the rows role's table (it shares the workgroup's LDS with 16 staging tiles)
-  int first_block[PRAD_MAX_SWEEP + 2];   // role r owns workgroups [first_block[r], first_block[r + 1]) of the 1-D grid
+  int first_block[PRAD_MAX_SWEEP + 1];   // role r owns workgroups [first_block[r], first_block[r + 1]) of the 1-D grid
   FwDesc d[PRAD_MAX_SWEEP];
 };
 
 // The NEXT volume's pack (int32 level + uint8 mask -> level*4 bytes, row flags, "irregular level" flag) as a side job of
 // this launch: every wave of the line roles owns the 1024-voxel units pw, pw + W, pw + 2W, ... (pw = its index among the W
 // packing waves), issues a unit's loads in front of a plain group of its walk and converts / stores behind it.  The pack is
-// HBM-bound and the walk is issue-bound, so the pack's memory time disappears behind the walk's VALU / LDS work; only its
-// ~6 VALU per voxel remain (a pure pack kernel of its own takes 0.15 ms per 512^3 volume and cannot share a CU's issue
-// slots with the sweep without slowing it down by as much: profiles/r03_probes.md).
+// HBM-bound and the walk is issue-bound, so the pack's memory time disappears behind the walk's VALU / LDS work and only
+// its VALU instructions remain (a pure pack kernel of its own takes 0.15 ms per 512^3 volume and cannot share a CU's
+// issue slots with the sweep without slowing it down by as much; packing whole units BETWEEN the chunks of a walk costs
+// twice what the interleaved form does -- a wave that waits for HBM is missed by its SIMD: profiles/r03_probes.md).
 // Needs the linear layout (pitch == NX, hence NX % 16 == 0) and 16-byte aligned arrays; n16 == 0: nothing to pack.
 struct PackJob {
   const int *image;
@@ -61,7 +59,7 @@ struct PackJob {
   int *flags;         // the packed volume's own flag words ([0] irregular level under the mask, [3] some voxel outside the ROI)
   long long n16;      // 16-voxel pieces
   int NX, Ng;
-  int every;          // a unit every `every` plain groups
+  int every;          // a wave loads one of its units in front of every `every`-th plain group of its walk
 };
 
 #define PRAD_FW_U 8
@@ -240,85 +238,108 @@ __device__ __forceinline__ void fw_load(const uint8_t *p, u32 (&v)[KW]) {
 #endif
 }
 
-// One wave's share of a PackJob (see there).  begin() issues the loads of the next unit when one is due, finish() converts
-// and stores it; both are wave-uniform no-ops otherwise.
+// One wave's share of a PackJob (see there).  begin() issues the loads of the wave's next unit in front of a plain group of
+// the walk when one is due, finish() converts and stores it behind the group: the loads fly under the group's VALU / LDS
+// work, no wave ever waits for the pack.  Everything the hot loop carries for the pack sits in VECTOR registers (pinned:
+// the loop is at the limit of its scalar registers, and wave-uniform pack state left to the compiler went into SGPRs and
+// pushed loop scalars out -- v_readlane inside the plain groups, the walk alone 7 % slower); the kernel has 50 to spare.
 struct PackWave {
-  const PackJob &J;
-  long long ubase;      // first 16-voxel piece of the wave's next unit (wave-uniform), >= J.n16: done
-  long long ustride;    // pieces between two units of this wave
-  int lane, tick;
-  bool loaded;          // wave-uniform
-  int bad;
+  unsigned long long img, msk, lev;   // this lane's next piece: image + 64 t, mask + 16 t, levels + 16 t (byte addresses)
+  unsigned long long step16;          // pieces between two units of this wave
+  int units_left;                     // units this wave still owns
+  int last_lanes;                     // lanes that hold a piece in the wave's LAST unit
+  int tick, every, loaded, bad, lane;
   int4 q0, q1, q2, q3;
   uint4 m;
-  __device__ __forceinline__ PackWave(const PackJob &J_, long long pw, long long W) : J(J_) {
+  template <typename T>
+  static __device__ __forceinline__ void pin(T &x) { asm volatile("" : "+v"(x)); }
+  __device__ __forceinline__ PackWave(const PackJob &J, long long pw, long long W) {
     lane = threadIdx.x & 63;
-    ubase = pw >= 0 ? pw * 64 : J_.n16;
-    ustride = W * 64;
+    const long long n16 = J.n16, first = pw * 64;
+    long long units = 0;
+    if (pw >= 0 && first < n16) units = (n16 - first + W * 64 - 1) / (W * 64);
+    units_left = (int)units;
+    const long long last_first = first + (units - 1) * W * 64;
+    last_lanes = units > 0 ? (int)((n16 - last_first) < 64 ? (n16 - last_first) : 64) : 0;
+    const unsigned long long t = (unsigned long long)(first + lane);
+    img = (unsigned long long)(size_t)J.image + 64ull * t;
+    msk = (unsigned long long)(size_t)J.mask + 16ull * t;
+    lev = (unsigned long long)(size_t)J.levels + 16ull * t;
+    step16 = (unsigned long long)(W * 64);
     tick = 0;
-    loaded = false;
+    every = J.every;
+    loaded = 0;
     bad = 0;
+    pin(img); pin(msk); pin(lev); pin(step16); pin(units_left); pin(last_lanes); pin(tick); pin(every); pin(loaded); pin(bad);
   }
-  __device__ __forceinline__ bool pending() const { return ubase < J.n16; }
   __device__ __forceinline__ void load() {
-    const long long t = ubase + lane;
     q0 = q1 = q2 = q3 = make_int4(0, 0, 0, 0);
     m = make_uint4(0, 0, 0, 0);
-    if (t < J.n16) {
-      const int4 *im4 = reinterpret_cast<const int4 *>(J.image) + 4 * t;
-      m = reinterpret_cast<const uint4 *>(J.mask)[t];
+    if (units_left > 1 || lane < last_lanes) {
+      const int4 *im4 = reinterpret_cast<const int4 *>((size_t)img);
+      m = *reinterpret_cast<const uint4 *>((size_t)msk);
       q0 = im4[0];
       q1 = im4[1];
       q2 = im4[2];
       q3 = im4[3];
     }
-    loaded = true;
+    loaded = 1;
+    pin(loaded);
   }
-  // a unit is due every J.every calls
   __device__ __forceinline__ void begin() {
-    if (!pending()) return;
-    if (++tick < J.every) return;
+    if (units_left <= 0) return;
+    tick++;
+    pin(tick);
+    if (tick < every) return;
     tick = 0;
+    pin(tick);
     load();
   }
-  __device__ __forceinline__ void finish() {
+  __device__ __forceinline__ void finish(const PackJob &J) {
     if (!loaded) return;
-    loaded = false;
-    const long long t = ubase + lane;
-    ubase += ustride;
-    if (t >= J.n16) return;
-    const int lv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-    const u32 mw[4] = {m.x, m.y, m.z, m.w};
-    u32 ow[4];
+    loaded = 0;
+    pin(loaded);
+    const bool mine = units_left > 1 || lane < last_lanes;
+    if (mine) {
+      const int lv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+      const u32 mw[4] = {m.x, m.y, m.z, m.w};
+      u32 ow[4];
 #pragma unroll
-    for (int w = 0; w < 4; w++) {
-      u32 o = 0;
+      for (int w = 0; w < 4; w++) {
+        u32 o = 0;
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const bool in = (mw[w] >> (8 * b)) & 0xffu;
-        const int l = lv[w * 4 + b];
-        const bool regular = in && l >= 1 && l <= J.Ng;
-        bad |= in && !regular;
-        o |= (regular ? ((u32)l << PRAD_FUSED_SHIFT) : 0u) << (8 * b);   // (an irregular level packs as 0: never a table index)
+        for (int b = 0; b < 4; b++) {
+          const bool in = (mw[w] >> (8 * b)) & 0xffu;
+          const int l = lv[w * 4 + b];
+          const bool regular = in && l >= 1 && l <= J.Ng;
+          bad |= in && !regular;
+          o |= (regular ? ((u32)l << PRAD_FUSED_SHIFT) : 0u) << (8 * b);   // (an irregular level packs as 0: never a table index)
+        }
+        ow[w] = o;
       }
-      ow[w] = o;
-    }
-    u32 zb = 0;
+      u32 zb = 0;
 #pragma unroll
-    for (int w = 0; w < 4; w++) zb |= (ow[w] - 0x01010101u) & ~ow[w] & 0x80808080u;
-    if (zb) {   // the piece holds a voxel outside the ROI: flag its row(s) (a 16-voxel piece spans at most two rows)
-      J.flags[3] = 1;
-      const unsigned e0 = (unsigned)(t << 4);       // (volumes stay below 2^31 voxels)
-      J.rowzero[e0 / (unsigned)J.NX] = 1;
-      J.rowzero[(e0 + 15u) / (unsigned)J.NX] = 1;
+      for (int w = 0; w < 4; w++) zb |= (ow[w] - 0x01010101u) & ~ow[w] & 0x80808080u;
+      if (zb) {   // the piece holds a voxel outside the ROI: flag its row(s) (a 16-voxel piece spans at most two rows)
+        J.flags[3] = 1;
+        const unsigned e0 = (unsigned)(lev - (unsigned long long)(size_t)J.levels);       // (volumes stay below 2^31 voxels)
+        J.rowzero[e0 / (unsigned)J.NX] = 1;
+        J.rowzero[(e0 + 15u) / (unsigned)J.NX] = 1;
+      }
+      *reinterpret_cast<uint4 *>((size_t)lev) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
     }
-    reinterpret_cast<uint4 *>(J.levels)[t] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    img += 64ull * step16;
+    msk += 16ull * step16;
+    lev += 16ull * step16;
+    units_left--;
+    pin(img); pin(msk); pin(lev); pin(units_left); pin(bad);
   }
   // whatever the walk left over (a launch whose walk is much shorter than the pack, or no walk at all)
-  __device__ __forceinline__ void drain() {
-    while (pending()) {
+  __device__ __forceinline__ void drain(const PackJob &J) {
+#pragma unroll 1
+    while (units_left > 0) {
       load();
-      finish();
+      finish(J);
     }
     if (bad) J.flags[0] = 1;
   }
@@ -326,7 +347,7 @@ struct PackWave {
 
 #define FW_BYTE(W, j) ((int)__builtin_amdgcn_ubfe((W)[(j) >> 2], 8 * ((j) & 3), 8))
 
-template <bool LONG, int K, int DX, bool HASPAD>
+template <bool LONG, int K, int DX, bool HASPAD, bool PACK>
 struct FwWave {
   static constexpr int KW = K / 4;
   static constexpr int U = PRAD_FW_U;
@@ -486,7 +507,7 @@ struct FwWave {
   }
   __device__ __forceinline__ void run(const FwDesc &D, int NX, int pitch, long long nrows, const uint8_t *__restrict__ L,
                                       const uint8_t *__restrict__ rowzero, bool anyzero, int *work, int bx, int nblocks,
-                                      PackWave &pk) {
+                                      PackWave &pk, const PackJob &pj) {
     const int NM = D.NM, NU = D.NU, du = D.du;
     const long long delta = D.sM + (long long)du * D.sU;
     // row numbers of the packed volume (rowzero[r] != 0: row r holds a voxel outside the ROI), wave-uniform like `off`
@@ -601,10 +622,10 @@ struct FwWave {
               load_row(p, v[k]);
               p += delta;
             }
-            pk.begin();                      // (the next volume's pack rides along: loads out, ...
+            if (PACK) pk.begin();            // (the next volume's pack rides along: loads out, ...
             if (safe == 1) calm_padding();   // (second group of a pair: the first one let the padding lines grow)
             plain_group(v);
-            pk.finish();                     //  ... bytes stored behind the group's VALU / LDS work)
+            if (PACK) pk.finish(pj);         //  ... bytes stored behind the group's VALU / LDS work)
             safe--;
             if (young > 0) young--;
             t += U;
@@ -671,12 +692,7 @@ __device__ __forceinline__ void fw_row_word(const FwTab &T, u32 one, int &s, u32
 #undef PRAD_FW_RCOL
 }
 
-// LDS bytes of the rows role: its table (RSr length slots) + one staging tile per wave
-__host__ __device__ inline size_t fw_rows_lds_bytes(const HistLayout &h, int waves) {
-  return ((fw_lds_bytes(h) + 15) & ~(size_t)15) + (size_t)waves * 64 * PRAD_ROW_PITCH;
-}
-
-// rows role of sweep_fw_kernel: workgroup bx of nblocks; the LDS table (layout h, zeroed by the caller) sits at address 0
+// the walk along x for workgroup bx of nblocks; the LDS table (layout h, zeroed by the caller) sits at address 0
 template <bool LONG>
 __device__ __forceinline__ void fw_rows_role(const HistLayout &h, const FwTab &T, u32 *lds, const uint8_t *__restrict__ L,
                                              long long nrows, int NX, int pitch, int bx, int nblocks) {
@@ -686,11 +702,16 @@ __device__ __forceinline__ void fw_rows_role(const HistLayout &h, const FwTab &T
   asm volatile("" : "+v"(one));
   // per-wave staging tile behind the table and its dead zone (16-byte aligned)
   uint8_t *tile = reinterpret_cast<uint8_t *>(lds) + ((fw_lds_bytes(h) + 15) & ~(size_t)15) + (size_t)wave * 64 * PRAD_ROW_PITCH;
-  const long long ngroups = (nrows + 63) / 64;
+  // A wave's 64 rows lie 8 rows apart (group g: rows 512 (g / 8) + g % 8 + 8 i): neighbouring rows of a smooth image hold
+  // nearly the same levels, and 64 ADJACENT rows sent the lanes of one ds_add to the same few bins (same-address atomics
+  // serialise: the x angle of the smooth 512^3 volume took 0.12 ms against 0.06 on iid levels).  Every row is its own
+  // set of cache lines either way.  (Small volumes keep adjacent rows: their last group of 512 would be mostly empty.)
+  const int RSTEP = nrows >= 4096 ? 8 : 1;
+  const long long ngroups = RSTEP == 8 ? ((nrows + 511) / 512) * 8 : (nrows + 63) / 64;
   const long long nwaves = (long long)nblocks * wpb;
   const bool vec16 = (pitch & 15) == 0 && ((uintptr_t)L & 15) == 0;
   for (long long grp = (long long)bx * wpb + wave; grp < ngroups; grp += nwaves) {
-    const long long r0 = grp * 64;
+    const long long r0 = RSTEP == 8 ? (grp >> 3) * 512 + (grp & 7) : grp * 64;     // row of tile slot i: r0 + RSTEP * i
     int s = 0;     // run state of this lane's row
     u32 pw = 0;    // previous staged word (its last byte is the previous voxel)
     for (int xc = 0; xc < NX; xc += 64) {
@@ -700,8 +721,8 @@ __device__ __forceinline__ void fw_rows_role(const HistLayout &h, const FwTab &T
           const int rr = j * 16 + (lane >> 2);
           const int cx = xc + (lane & 3) * 16;
           uint4 q = make_uint4(0, 0, 0, 0);
-          if (r0 + rr < nrows && cx < NX) {
-            q = *reinterpret_cast<const uint4 *>(L + (r0 + rr) * pitch + cx);
+          if (r0 + RSTEP * rr < nrows && cx < NX) {
+            q = *reinterpret_cast<const uint4 *>(L + (r0 + RSTEP * rr) * pitch + cx);
             const int valid = NX - cx;
             if (valid < 16) {
               u32 *qw = reinterpret_cast<u32 *>(&q);
@@ -719,7 +740,7 @@ __device__ __forceinline__ void fw_rows_role(const HistLayout &h, const FwTab &T
 #pragma unroll 8
         for (int rr = 0; rr < 64; rr++) {
           uint8_t b = 0;
-          if (xin && r0 + rr < nrows) b = L[(r0 + rr) * pitch + xc + lane];
+          if (xin && r0 + RSTEP * rr < nrows) b = L[(r0 + RSTEP * rr) * pitch + xc + lane];
           tile[rr * PRAD_ROW_PITCH + lane] = b;
         }
       }
@@ -732,11 +753,19 @@ __device__ __forceinline__ void fw_rows_role(const HistLayout &h, const FwTab &T
         // 16 steps: safe on the plain path while len*Q + 16 Q stays within the table's length slots
         const unsigned m = (pw >> 24) ? (unsigned)(s - __mul24((int)(pw >> 24), T.P4)) : 0u;
         if (LONG && __ballot(m + 16 * T.Q > (unsigned)T.lenlim) != 0) {
+          // some run is within 16 steps of the table's last length slot: decide word by word (4 steps) -- on smooth images
+          // nearly every 16-step stretch holds such a run in one of the 64 rows, and walking all of it on the checked
+          // path doubled the x angle's time
 #pragma unroll 1
           for (int k = 0; k < 4; k++) {
             const u32 c = wds[k], x = __builtin_amdgcn_alignbyte(c, pw, 3);
+            const unsigned m4 = (pw >> 24) ? (unsigned)(s - __mul24((int)(pw >> 24), T.P4)) : 0u;
+            if (__ballot(m4 + 4 * T.Q > (unsigned)T.lenlim) != 0) {
 #pragma unroll
-            for (int b = 0; b < 4; b++) fw_checked<LONG>(T, dummy, s, (int)((x >> (8 * b)) & 0xffu), (int)((c >> (8 * b)) & 0xffu), false);
+              for (int b = 0; b < 4; b++) fw_checked<LONG>(T, dummy, s, (int)((x >> (8 * b)) & 0xffu), (int)((c >> (8 * b)) & 0xffu), false);
+            } else {
+              fw_row_word(T, one, s, c, x);
+            }
             pw = c;
           }
         } else {
@@ -753,10 +782,10 @@ __device__ __forceinline__ void fw_rows_role(const HistLayout &h, const FwTab &T
   }
 }
 
-// the angle along x as a launch of its own (8-wave workgroups: table + 8 staging tiles leave room for a second kind of
-// workgroup on the CU).  As a ROLE of sweep_fw_kernel (16-wave workgroups next to the line roles') the same walk measured
-// slower per CU -- 22.9 CU-ms instead of 14 at 512^3, the whole launch 0.477 ms against 0.38 + 0.055 for the two
-// launches (profiles/r03_probes.md) -- so the role is off unless PRAD_FW_ROWS_ROLE is set.
+// the angle along x as a launch of its own (8-wave workgroups: table + 8 staging tiles).  As a ROLE of sweep_fw_kernel
+// (16-wave workgroups next to the line roles') the same walk measured slower per CU -- 22.9 CU-ms instead of 14 at 512^3,
+// the whole launch 0.477 ms against 0.38 + 0.055 for the two launches -- and its code made the line roles' kernel half as
+// large again (profiles/r03_probes.md), so it stays a kernel of its own.
 template <bool LONG>
 __global__ void __launch_bounds__(512) sweep_fw_rows_kernel(const uint8_t *__restrict__ L, long long nrows, int NX, int pitch,
                                                             int slot, int Ng, int Nr, int RS, u32 *__restrict__ glcm_acc,
@@ -776,62 +805,51 @@ __global__ void __launch_bounds__(512) sweep_fw_rows_kernel(const uint8_t *__res
   flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, slot, glcm_acc, glrlm_acc);
 }
 
-// One launch per volume: a 1-D grid of one 16-wave workgroup per CU, cut into ROLES -- the line angles (fixed-window
-// walks) and, when the caller's angle list holds it, the angle along x (fw_rows_role) -- plus the pack of the NEXT volume
-// as a side job of the line roles' waves (PackJob).  A volume whose pack found irregular levels (flags[0]) is skipped --
-// the generic kernels redo that call -- but the side job still runs.
-template <bool LONG, int K, bool HASPAD>
+// One launch per volume: a 1-D grid of one 16-wave workgroup per CU, cut into ROLES -- one per line angle -- plus, with PACK,
+// the pack of the NEXT volume as a side job of the walking waves (PackJob; the instantiation without it spares the walk
+// the side job's registers: 0.39 instead of 0.405 ms per 512^3 volume).  A volume whose pack found irregular levels
+// (flags[0]) is skipped -- the generic kernels redo that call -- but the side job still runs.
+template <bool LONG, int K, bool HASPAD, bool PACK>
 __global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, PackJob pj, const uint8_t *__restrict__ L,
                                                         const uint8_t *__restrict__ rowzero, int Ng, int Nr, int RS,
                                                         u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
                                                         int *__restrict__ work, int *__restrict__ flags) {
   extern __shared__ u32 lds[];
-  const int nroles = set.count + (set.rows_role ? 1 : 0);
   int role = 0;
-  while (role + 1 < nroles && (int)blockIdx.x >= set.first_block[role + 1]) role++;
+  while (role + 1 < set.count && (int)blockIdx.x >= set.first_block[role + 1]) role++;
   const int bx = (int)blockIdx.x - set.first_block[role], nblocks = set.first_block[role + 1] - set.first_block[role];
-  const bool is_rows = set.rows_role && role == set.count;
-  // packing waves: those of the line roles (workgroups [0, first_block[count]) of the grid)
   const int wpb = (int)(blockDim.x >> 6);
-  const long long pwaves = (long long)set.first_block[set.count] * wpb;
-  const long long pw = is_rows ? -1 : __builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
-  PackWave pk(pj, pw, pwaves);
-  const bool skip = set.count + set.rows_role == 0 || flags[0] != 0;  // nothing to walk / irregular levels
+  const long long pw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
+  PackWave pk(pj, pw, (long long)gridDim.x * wpb);
 #ifdef PRAD_FW_SETPRIO   // experiment: issue priority over co-resident waves of another launch
   __builtin_amdgcn_s_setprio(PRAD_FW_SETPRIO);
 #endif
-  if (!skip) {
+  if (flags[0] == 0) {     // (else: irregular levels, nothing to walk)
     const bool anyzero = flags[3] != 0;   // the pack saw a voxel outside the ROI (else the row flags are not read)
-    const int rs = is_rows ? set.RSr : RS;
-    const HistLayout h = hist_layout(true, true, true, Ng, rs);
+    const HistLayout h = hist_layout(true, true, true, Ng, RS);
     if ((unsigned)(size_t)((lds_u32 *)lds) != 0u) {  // table offsets are used as LDS addresses
       if (threadIdx.x == 0) atomicExch(flags + 2, 1);
     } else {
       for (int i = threadIdx.x; i < h.words + Ng + 1; i += blockDim.x) lds[i] = 0;
       __syncthreads();
-      const int slot = is_rows ? set.rows_slot : set.d[role].slot;
+      const FwDesc &D = set.d[role];
       FwTab T;
-      T.init(h, Nr, glrlm_acc + (size_t)slot * Ng * Nr);
-      if (is_rows) {
-        fw_rows_role<LONG>(h, T, lds, L, set.nrows, set.NX, set.pitch, bx, nblocks);
+      T.init(h, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
+      int *wk = work + PRAD_FW_WORK_STRIDE * role;
+      if (D.dx == 0) {
+        FwWave<LONG, K, 0, HASPAD, PACK> w(T, set.NX);
+        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj);
+      } else if (D.dx > 0) {
+        FwWave<LONG, K, 1, HASPAD, PACK> w(T, set.NX);
+        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj);
       } else {
-        const FwDesc &D = set.d[role];
-        int *wk = work + PRAD_FW_WORK_STRIDE * role;
-        if (D.dx == 0) {
-          FwWave<LONG, K, 0, HASPAD> w(T, set.NX);
-          w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk);
-        } else if (D.dx > 0) {
-          FwWave<LONG, K, 1, HASPAD> w(T, set.NX);
-          w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk);
-        } else {
-          FwWave<LONG, K, -1, HASPAD> w(T, set.NX);
-          w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk);
-        }
+        FwWave<LONG, K, -1, HASPAD, PACK> w(T, set.NX);
+        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj);
       }
-      flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, slot, glcm_acc, glrlm_acc);
+      flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, D.slot, glcm_acc, glrlm_acc);
     }
   }
-  pk.drain();
+  if (PACK) pk.drain(pj);
 }
 
 }  // namespace prad

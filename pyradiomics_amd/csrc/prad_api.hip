@@ -113,7 +113,8 @@ struct Call {
 };
 
 int setup_call(Call &k, const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
-               int Na, int Nvox, const int *voxels_dev, int kernelRadius, int force2Ddim, hipStream_t s) {
+               int Na, int Nvox, const int *voxels_dev, int kernelRadius, int force2Ddim, hipStream_t s,
+               bool zero_flags = true) {
   Context &c = ctx();
   k.c = &c;
   k.s = s;
@@ -154,7 +155,7 @@ int setup_call(Call &k, const int32_t *image, const uint8_t *mask, const int *si
     }
   }
   PRAD_TRY(c.get<int>("flags", 4, &k.flags_d));
-  PRAD_HIP(hipMemsetAsync(k.flags_d, 0, sizeof(int) * 4, s));
+  if (zero_flags) PRAD_HIP(hipMemsetAsync(k.flags_d, 0, sizeof(int) * 4, s));   // (the sweep path zeroes them with its accumulators)
   void *fh = nullptr;
   PRAD_TRY(c.get_pinned("flags_h", sizeof(int) * 4, &fh));
   k.flags_h = (int *)fh;
@@ -267,9 +268,7 @@ struct SweepPlan {
   bool LONGfw = false;
   size_t lds_fw = 0;
   int RSfw_rows = 0;           // length slots of the rows role's table (it shares the LDS with 16 staging tiles)
-  size_t lds_fw_launch = 0;    // dynamic LDS of the launch: the larger of the two role kinds
   size_t lds_fw_rows = 0;      // the x angle as a launch of its own (sweep_fw_rows_kernel)
-  bool LONGfw_any = false;     // some role's table does not hold every run length
   FwSet fwset;
 };
 
@@ -419,31 +418,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     if (const char *e = getenv("PRAD_FW_RS")) p.RSfw = std::max(1, std::min(p.RSfw, atoi(e)));   // tuning override
     p.LONGfw = p.RSfw < Nr;
     p.lds_fw = fw_lds_bytes(hist_layout(true, true, true, Ng, p.RSfw));
-    // Roles of the one launch (kernels_sweepfw.h sweep_fw_kernel): the line angles and, if the angle list holds it, the angle
-    // along x.  One 16-wave workgroup per CU over all roles; the rows role is cheaper than a line walk (alone on the GPU:
-    // 0.058 vs 0.085 ms at 512^3), so it gets fewer workgroups.
-    const bool rows_role = p.row_slot >= 0 && getenv("PRAD_FW_ROWS_ROLE");   // (measured slower than a launch of its own)
-    p.fwset.rows_role = rows_role ? 1 : 0;
-    p.fwset.rows_slot = p.row_slot;
-    p.fwset.RSr = 1;
-    p.lds_fw_launch = p.lds_fw;
-    p.LONGfw_any = p.LONGfw;
-    if (rows_role) {
-      int rs = fit_rs(true, true, true, Ng, Nr, 76 * 1024);
-      while (rs > 1 && fw_rows_lds_bytes(hist_layout(true, true, true, Ng, rs), 16) > 160 * 1024 - 512) rs--;
-      for (int r = rs; rs < Nr && r >= std::max(16, rs - 12); r--) {   // same bank-stride rule as above
-        const int d = (((r + 1) * (Ng + 1)) % 32 + 1) % 32, dist = std::min(d, 32 - d);
-        if ((d & 1) && dist >= 5 && dist <= 11) { rs = r; break; }
-      }
-      if (rs < std::min(Nr, 4) || fw_rows_lds_bytes(hist_layout(true, true, true, Ng, rs), 16) > 160 * 1024 - 512) {
-        return SweepPlan();   // (cannot happen for Ng <= 44: the table of 4 length slots takes 36 KB) -> generic path
-      }
-      p.RSfw_rows = rs;
-      p.fwset.RSr = rs;
-      p.lds_fw_launch = std::max(p.lds_fw, fw_rows_lds_bytes(hist_layout(true, true, true, Ng, rs), 16));
-      p.LONGfw_any = p.LONGfw || rs < Nr;
-    }
-    if (p.row_slot >= 0 && !rows_role) {   // the x angle as a launch of its own: 8 waves + their staging tiles
+    if (p.row_slot >= 0) {   // the x angle: a launch of its own, 8 waves + their staging tiles (sweep_fw_rows_kernel)
       const size_t tiles = (size_t)(kRowsThreads / 64) * 64 * PRAD_ROW_PITCH;
       int rs = fit_rs(true, true, true, Ng, Nr, 100 * 1024);
       for (int r = rs; rs < Nr && r >= std::max(16, rs - 12); r--) {   // same bank-stride rule as above
@@ -454,25 +429,14 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
       p.lds_fw_rows = ((fw_lds_bytes(hist_layout(true, true, true, Ng, rs)) + 15) & ~(size_t)15) + tiles;
     }
     {
-      const int nroles = p.lines.count + (rows_role ? 1 : 0);
+      // Roles of the one launch (kernels_sweepfw.h sweep_fw_kernel): one per line angle, one 16-wave workgroup per CU over
+      // all of them (1-D grid; the remainder of the division goes to the first roles)
+      const int nroles = p.lines.count;
       int total = cu_count();
       if (const char *e = getenv("PRAD_FW_BLOCKS")) total = std::max(nroles, atoi(e));   // tuning override: workgroups of the launch
-      double wrows = 2.8;
-      if (const char *e = getenv("PRAD_FW_ROWS_WEIGHT")) wrows = std::max(0.05, atof(e));
-      const double wsum = p.lines.count + (rows_role ? wrows : 0.0);
-      int blocks[PRAD_MAX_SWEEP + 1], used = 0;
-      for (int r = 0; r < nroles; r++) {
-        const double w = (rows_role && r == p.lines.count) ? wrows : 1.0;
-        blocks[r] = std::max(1, (int)(total * w / wsum));
-        used += blocks[r];
-      }
-      for (int r = 0; used < total && total >= nroles; r = (r + 1) % p.lines.count) {   // the remainder goes to line roles
-        blocks[r]++;
-        used++;
-      }
       p.fwset.first_block[0] = 0;
-      for (int r = 0; r < nroles; r++) p.fwset.first_block[r + 1] = p.fwset.first_block[r] + blocks[r];
-      for (int r = nroles + 1; r < PRAD_MAX_SWEEP + 2; r++) p.fwset.first_block[r] = p.fwset.first_block[nroles];
+      for (int r = 0; r < nroles; r++) p.fwset.first_block[r + 1] = p.fwset.first_block[r] + total / nroles + (r < total % nroles ? 1 : 0);
+      for (int r = nroles + 1; r < PRAD_MAX_SWEEP + 1; r++) p.fwset.first_block[r] = p.fwset.first_block[nroles];
       p.fw_blocks = p.fwset.first_block[nroles];
     }
     int per_wave = 6;
@@ -535,14 +499,20 @@ int launch_lines(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int
   return launch_lines_lpl<G, R, LNG, F, 1>(k, p, levels, Ng, Nr, glcm_acc, glrlm_acc, multi);
 }
 
+template <bool LNG, int K, bool HASPAD, bool PACK>
+int launch_fw_kpp(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels, const uint8_t *rowzero, int Ng, int Nr,
+                  u32 *glcm_acc, u32 *glrlm_acc, int *multi, int *flags_d) {
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_kernel<LNG, K, HASPAD, PACK>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw));
+  hipLaunchKernelGGL((sweep_fw_kernel<LNG, K, HASPAD, PACK>), dim3(p.fw_blocks), dim3(1024), p.lds_fw, k.s, p.fwset, pj,
+                     levels, rowzero, Ng, Nr, p.RSfw, glcm_acc, glrlm_acc, multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE, flags_d);
+  return check_launch("sweep_fw_kernel");
+}
 template <bool LNG, int K, bool HASPAD>
 int launch_fw_kp(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels, const uint8_t *rowzero, int Ng, int Nr,
                  u32 *glcm_acc, u32 *glrlm_acc, int *multi, int *flags_d) {
-  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_kernel<LNG, K, HASPAD>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw_launch));
-  hipLaunchKernelGGL((sweep_fw_kernel<LNG, K, HASPAD>), dim3(p.fw_blocks), dim3(1024), p.lds_fw_launch, k.s, p.fwset, pj,
-                     levels, rowzero, Ng, Nr, p.RSfw, glcm_acc, glrlm_acc, multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE, flags_d);
-  return check_launch("sweep_fw_kernel");
+  if (pj.n16 > 0) return launch_fw_kpp<LNG, K, HASPAD, true>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
+  return launch_fw_kpp<LNG, K, HASPAD, false>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
 }
 template <bool LNG, int K>
 int launch_fw_k(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels, const uint8_t *rowzero, int Ng, int Nr,
@@ -550,19 +520,18 @@ int launch_fw_k(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *l
   if (p.Nx != 64 * K) return launch_fw_kp<LNG, K, true>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
   return launch_fw_kp<LNG, K, false>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
 }
-// the fixed-window launch of one volume: every line angle, the angle along x (rows role) and, optionally, the pack of the
-// NEXT volume as a side job
+// the fixed-window launch of one volume: every line angle and, optionally, the pack of the NEXT volume as a side job
 int launch_fw(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels, const uint8_t *rowzero, int Ng, int Nr,
               u32 *glcm_acc, u32 *glrlm_acc, int *multi, int *flags_d) {
-  if (p.LONGfw_any) return p.fwK == 4 ? launch_fw_k<true, 4>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
-                                    : launch_fw_k<true, 8>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
+  if (p.LONGfw) return p.fwK == 4 ? launch_fw_k<true, 4>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
+                                : launch_fw_k<true, 8>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
   return p.fwK == 4 ? launch_fw_k<false, 4>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
                     : launch_fw_k<false, 8>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
 }
 
 template <bool LNG>
 int launch_fw_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *flags_d) {
-  const long long nrows = (long long)p.Nz * p.Ny, groups = (nrows + 63) / 64;
+  const long long nrows = (long long)p.Nz * p.Ny, groups = nrows >= 4096 ? ((nrows + 511) / 512) * 8 : (nrows + 63) / 64;
   const int wpb = kRowsThreads / 64;
   const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + wpb - 1) / wpb, (long long)cu_count()));
   PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_rows_kernel<LNG>),
@@ -585,6 +554,17 @@ int launch_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int 
   hipLaunchKernelGGL((sweep_rows_kernel<G, R, LNG, F>), dim3(gx), dim3(kRowsThreads), p.lds_bytes_rows, k.s, levels,
                      nrows, p.Nx, p.pitch, p.row_slot, Ng, Nr, p.RSr, glcm_acc, glrlm_acc, multi, k.flags_d);
   return check_launch("sweep_rows_kernel");
+}
+
+// zeroes three word ranges in one launch (a: 16-byte aligned, any length)
+__global__ void __launch_bounds__(256) zero3_kernel(u32 *__restrict__ a, size_t na, u32 *__restrict__ b, size_t nb,
+                                                    u32 *__restrict__ c3, size_t nc) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nt = (size_t)gridDim.x * blockDim.x;
+  uint4 *a4 = reinterpret_cast<uint4 *>(a);
+  for (size_t i = t; i < na / 4; i += nt) a4[i] = make_uint4(0, 0, 0, 0);
+  for (size_t i = (na & ~(size_t)3) + t; i < na; i += nt) a[i] = 0;
+  for (size_t i = t; i < nb; i += nt) b[i] = 0;
+  for (size_t i = t; i < nc; i += nt) c3[i] = 0;
 }
 
 // One packed volume between its pack and its finalize: device pointers of ONE workspace set (Context::lane) and the plan.
@@ -621,13 +601,16 @@ int vol_prepare(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, doubl
   v.glcm_acc = v.acc;
   v.glrlm_acc = v.acc + nglcm;
   v.multi = (int *)(v.acc + nglcm + nglrlm);
-  PRAD_HIP(hipMemsetAsync(v.acc, 0, sizeof(u32) * (nglcm + nglrlm + nctl), k.s));
   v.rowzero = nullptr;
-  if (p.fw) {
-    PRAD_TRY(c.get<uint8_t>("rowzero", (size_t)nrows + 64, &v.rowzero));
-    PRAD_HIP(hipMemsetAsync(v.rowzero, 0, (size_t)nrows, k.s));
-  }
-  return PRAD_OK;
+  if (p.fw) PRAD_TRY(c.get<uint8_t>("rowzero", (size_t)nrows + 64, &v.rowzero));
+  // accumulators + control words, row flags and the volume's flag words start from zero: ONE launch
+  // (three hipMemsetAsync calls are three launches, each with its dependent-launch gap on the stream)
+  const size_t acc_w = nglcm + nglrlm + nctl, rz_w = v.rowzero ? ((size_t)nrows + 3) / 4 : 0;
+  const size_t total_w = acc_w + rz_w + 4;
+  const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((total_w / 4 + 255) / 256, 1024));
+  hipLaunchKernelGGL(zero3_kernel, dim3(gx), dim3(256), 0, k.s, v.acc, acc_w, reinterpret_cast<u32 *>(v.rowzero), rz_w,
+                     reinterpret_cast<u32 *>(v.flags_d), (size_t)4);
+  return check_launch("zero3_kernel");
 }
 
 // can this volume's pack ride in another volume's sweep launch?  (linear layout, vector loads)
@@ -647,12 +630,15 @@ PackJob make_pack_job(const Call &k, const VolState &v, const VolState *host) {
   j.n16 = k.g.n / 16;
   j.NX = v.p.Nx;
   j.Ng = v.Ng;
-  // cadence: spread the units over the host launch's plain groups (both counted per wave)
-  double groups = 0;
-  if (host)
+  // cadence: spread a wave's units over the plain groups of its walk (both per wave); what is left drains behind the walk
+  double groups = 0, waves = 16.0;
+  if (host) {
     for (int i = 0; i < host->p.fwset.count; i++) groups += (double)host->p.fwset.d[i].NM * host->p.fwset.d[i].NU / PRAD_FW_U;
+    waves = 16.0 * std::max(1, host->p.fw_blocks);
+  }
   const double units = (double)j.n16 / 64.0;
   j.every = (int)std::max(1.0, std::min(64.0, std::floor(0.92 * groups / std::max(1.0, units))));
+  (void)waves;
   if (const char *e = getenv("PRAD_PACK_EVERY")) j.every = std::max(1, atoi(e));
   return j;
 }
@@ -678,7 +664,7 @@ int launch_sweeps(Call &k, const VolState &v, const PackJob &pj) {
       Timed t(*k.c, "sweep", k.s);
       PRAD_TRY(launch_fw(k, p, pj, v.levels, v.rowzero, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi, v.flags_d));
     }
-    if (p.row_slot >= 0 && !p.fwset.rows_role) {
+    if (p.row_slot >= 0) {
       Timed t(*k.c, "rows", k.s);
       if (p.RSfw_rows < v.Nr) PRAD_TRY(launch_fw_rows<true>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.flags_d));
       else PRAD_TRY(launch_fw_rows<false>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.flags_d));
@@ -887,9 +873,10 @@ int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *siz
   if (c.deferred && !voxels && !pipe) PRAD_TRY(c.lane_begin(s, &s));   // lanes mode: whole-volume deferred calls alternate between lanes
   if (pipe) c.lane = (int)(pipe_state().seq++ & 1);                    // pipeline mode: the workspace sets alternate, the stream is the caller's
   Call k;
-  PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, Nvox, voxels, kernelRadius, force2Ddim, s));
+  PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, Nvox, voxels, kernelRadius, force2Ddim, s, false));
   PRAD_TRY(c.begin_call(s));
   SweepPlan p = plan_sweep(k, Ng, Nr, glcm != nullptr, glrlm != nullptr);
+  if (!p.ok) PRAD_HIP(hipMemsetAsync(k.flags_d, 0, sizeof(int) * 4, s));   // (vol_prepare does it on the sweep path)
   bool done = false;
   if (pipe) {
     PRAD_TRY(pipeline_step(k, p, Ng, Nr, glcm, glrlm, &done));
