@@ -61,6 +61,9 @@ int prad_release_workspace(void);
 /* name of the code path taken by this thread's last calculate_* call ("sweep", "generic", ...);
  * lets tests assert that the fast kernels (not a fallback) produced a result. */
 const char *prad_last_path(void);
+/* which sweep kernels the plan of this thread's last GLCM / GLRLM call chose: "fw" (fixed window, fused table: <= 44 grey
+ * levels, rows of 65..512 voxels), "fw2" (fixed window, two tables, 16-bit levels: 45+ levels), "lines" (wrapped lines). */
+const char *prad_last_variant(void);
 /* Total device time (ms, HIP events on the work stream) of this thread's last calculate_* call, and
  * the time of its dominant kernel family; used by bench.py for the roofline figure. */
 double prad_last_device_ms(void);

@@ -23,6 +23,7 @@ SYMBOLS = {
     "prad_version": (C.c_char_p, []),
     "prad_last_error": (C.c_char_p, []),
     "prad_last_path": (C.c_char_p, []),
+    "prad_last_variant": (C.c_char_p, []),
     "prad_device_count": (C.c_int, []),
     "prad_set_device": (C.c_int, [C.c_int]),
     "prad_get_device": (C.c_int, []),
@@ -120,8 +121,16 @@ def last_error() -> str:
     return load().prad_last_error().decode("utf-8", "replace")
 
 
+def last_variant() -> str:
+    return load().prad_last_variant().decode()
+
+
 def last_path() -> str:
     return load().prad_last_path().decode()
+
+
+def last_variant() -> str:
+    return load().prad_last_variant().decode()
 
 
 def raise_for(rc: int, what: str) -> None:

@@ -1,0 +1,482 @@
+// kernels_sweepfw2.h -- the fixed-window line sweeps for 45 .. ~175 grey levels (binWidth 25 on CT gives 60 - 160), gfx950.
+//
+// The fused table H[prev][len][cur] of kernels_sweepfw.h grows with (Ng+1)^2 x length slots: beyond 44 levels the 160 KB
+// of LDS no longer hold the 16+ slots the plain path needs, and level*4 no longer fits the byte lanes the step reads.
+// Same geometry here (a wave owns a window of 64*K columns that covers whole rows, lines with dx != 0 drift through
+// renamed registers, pieces / dead lines / tails exactly as there), different accumulation:
+//   * levels are 16-bit elements (level*4; 0 outside the ROI), two columns per dword, SDWA word selects;
+//   * TWO tables, interleaved row by row at LDS address 0:  row(level) = [ A: cur 0..Ng | B: len 1..RS2 ],
+//     S = 4 (Ng + 1 + RS2) bytes.  A run end (prev, len, cur) adds to A[prev][cur] (the GLCM pair; the diagonal comes from
+//     the runs as before) and to B[prev][len] (the GLRLM bin): 5 VALU + 2 ds_add + 1 SALU per voxel-step against
+//     4 + 1 + 1 of the fused step -- about 1.3x its time -- but the table is (Ng+1)(Ng+1+RS2) words: 64 levels with 128
+//     run lengths take 50 KB, 128 levels with 128 lengths 132 KB, and with that many length slots the checked path
+//     (runs beyond the slots) is rare on any image;
+//   * a line's state is two registers: p = level * S (its A row) and q = p + 4 Ng + 4 len (its B cursor); level 0 (a
+//     stretch outside the ROI, a line that has not seen a voxel, a DEAD line of a piece that did not begin at a line
+//     start) is row 0, which is never read.
+// The angle along x is walked by the separate-table rows kernel of kernels_sweep.h on an 8-bit copy of the levels.
+#pragma once
+#include "kernels_sweepfw.h"
+
+namespace prad {
+
+struct Fw2Tab {
+  u32 *rl_long;
+  int Nr, Ng, RS2;
+  int S, S4, K1, lenlim, dead_qmax;
+  __device__ __forceinline__ void init(int Ng_, int RS2_, int Nr_, u32 *rl_long_) {
+    rl_long = rl_long_;
+    Nr = Nr_;
+    Ng = Ng_;
+    RS2 = RS2_;
+    S4 = Ng_ + 1 + RS2_;
+    S = 4 * S4;
+    K1 = 4 * Ng_;              // q = p + K1 + 4 len: len = 1 sits right behind the A row
+    lenlim = 4 * RS2_;         // 4 len of the last length slot
+    dead_qmax = K1 + lenlim;   // a level-0 line's cursor stops growing here (checked path)
+  }
+};
+__host__ __device__ inline size_t fw2_table_words(int Ng, int RS2) { return (size_t)(Ng + 1) * (size_t)(Ng + 1 + RS2); }
+
+// a run of level lv (!= 0) longer than RS2 just ended: one L2 atomic per distinct (level, length) of the wave
+__device__ __noinline__ void fw2_long_event(const Fw2Tab &T, int lv, int idx) {
+  const unsigned key = ((unsigned)lv << 20) | (unsigned)idx;
+  bool pending = true;
+  while (pending) {
+    const unsigned first = (unsigned)__builtin_amdgcn_readfirstlane((int)key);
+    const bool same = key == first;
+    const unsigned long long m = __ballot(same);
+    if (same) {
+      if ((int)(__ffsll((long long)m) - 1) == (int)(threadIdx.x & 63))
+        atomicAdd(&T.rl_long[(size_t)(lv - 1) * T.Nr + idx], (u32)__popcll(m));
+      pending = false;
+    }
+  }
+}
+
+// One voxel-step of one line, every case handled.  x, c = level*4 of the previous / current voxel.
+template <bool LONG>
+__device__ __forceinline__ void fw2_checked(const Fw2Tab &T, int dummy, int &p, int &q, int x, int c, bool tail) {
+  const bool chg = c != x;
+  const bool alive = p >= T.S;
+  const bool ev = chg && alive;
+  const int lb = q - p - T.K1;                 // 4 len
+  const bool inlds = !LONG || lb <= T.lenlim;
+  lds_bump(ev ? p + c : dummy);                // the pair (cur = 0: the run ended at a line end / outside the ROI: ignored)
+  lds_bump((ev && inlds) ? q : dummy);         // the run
+  if (LONG && ev && !inlds) fw2_long_event(T, x >> PRAD_FUSED_SHIFT, (lb >> 2) - 1);
+  const int fp = tail ? 0 : __mul24(c, T.S4);
+  const int grown = alive ? q + 4 : min(q + 4, T.dead_qmax);
+  q = select_i32(chg, fp + T.K1 + 4, grown);
+  p = select_i32(chg, fp, p);
+}
+
+// The plain step of the two lines whose levels are the 16-bit halves of c (current) and x (previous); exec-masked like
+// fw_plain_word.  Only valid while no run can outgrow its length slots (margin()).
+__device__ __forceinline__ void fw2_plain_word(const Fw2Tab &T, u32 one, int &p0, int &q0, int &p1, int &q1, u32 c, u32 x) {
+  int t;
+#define PRAD_FW2_COL(J, PJ, QJ)                                                                                          \
+  "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:WORD_" #J " src1_sel:WORD_" #J "\n\t"                                     \
+  "v_add_u32_sdwa %[t], %[" PJ "], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #J "\n\t"       \
+  "ds_add_u32 %[t], %[one]\n\t"                                                                                          \
+  "ds_add_u32 %[" QJ "], %[one]\n\t"                                                                                     \
+  "v_mul_u32_u24_sdwa %[" PJ "], %[S4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #J "\n\t" \
+  "v_add_u32 %[" QJ "], %[K1], %[" PJ "]\n\t"                                                                            \
+  "s_mov_b64 exec, -1\n\t"                                                                                               \
+  "v_add_u32 %[" QJ "], 4, %[" QJ "]\n\t"
+  asm volatile(PRAD_FW2_COL(0, "p0", "q0") PRAD_FW2_COL(1, "p1", "q1")
+               : [p0] "+v"(p0), [q0] "+v"(q0), [p1] "+v"(p1), [q1] "+v"(q1), [t] "=&v"(t)
+               : [c] "v"(c), [x] "v"(x), [one] "v"(one), [S4] "s"(T.S4), [K1] "s"(T.K1)
+               : "vcc", "memory");
+#undef PRAD_FW2_COL
+}
+
+struct __attribute__((packed)) u128_unaligned { u32 a, b, c, d; };
+template <int KW>
+__device__ __forceinline__ void fw2_load(const uint8_t *p, u32 (&v)[KW]) {
+  if (KW == 4) {
+    const u128_unaligned q = *reinterpret_cast<const u128_unaligned *>(p);
+    v[0] = q.a;
+    v[1] = q.b;
+    v[KW - 2] = q.c;
+    v[KW - 1] = q.d;
+  } else {
+    const unsigned long long q = reinterpret_cast<const u64_unaligned *>(p)->v;
+    v[0] = (u32)q;
+    v[KW - 1] = (u32)(q >> 32);
+  }
+}
+
+// previous levels of the lines that ARRIVE at this lane's columns: the previous row shifted by dx columns (16-bit elements)
+template <int K, int DX>
+__device__ __forceinline__ void fw2_make_x(const u32 (&P)[K / 2], u32 (&X)[K / 2]) {
+  constexpr int KW = K / 2;
+  if (DX == 0) {
+#pragma unroll
+    for (int w = 0; w < KW; w++) X[w] = P[w];
+  } else if (DX > 0) {  // column j gets the element of column j-1
+    const u32 in = fw_shr1(P[KW - 1]);
+#pragma unroll
+    for (int w = KW - 1; w >= 1; w--) X[w] = __builtin_amdgcn_alignbyte(P[w], P[w - 1], 2);
+    X[0] = __builtin_amdgcn_alignbyte(P[0], in, 2);
+  } else {              // column j gets the element of column j+1
+    const u32 in = fw_shl1(P[0]);
+#pragma unroll
+    for (int w = 0; w < KW - 1; w++) X[w] = __builtin_amdgcn_alignbyte(P[w + 1], P[w], 2);
+    X[KW - 1] = __builtin_amdgcn_alignbyte(in, P[KW - 1], 2);
+  }
+}
+
+#define FW2_EL(W, j) ((int)__builtin_amdgcn_ubfe((W)[(j) >> 1], 16 * ((j) & 1), 16))
+
+template <bool LONG, int K, int DX, bool HASPAD>
+struct Fw2Wave {
+  static constexpr int KW = K / 2;
+  static constexpr int U = PRAD_FW_U;
+  const Fw2Tab &T;
+  int dummy, lane, edge_lane;
+  u32 one;
+  static constexpr bool haspad = HASPAD;
+  u32 cmask[KW];   // halves of this lane's window columns that lie inside the row
+  u32 calm[KW];    // halves of window columns no line can be open on
+  int lp[K], lq[K];   // A row / B cursor of the line that arrives at column j at the next step
+  u32 P[KW];       // levels of the previous row (this lane's columns)
+
+  __device__ __forceinline__ Fw2Wave(const Fw2Tab &T_, int NX) : T(T_) {
+    lane = threadIdx.x & 63;
+    dummy = 4 * lane;            // row 0 is scratch and at least 64 words long (Ng >= 40, RS2 >= 24 or Nr)
+    edge_lane = haspad ? -1 : (DX > 0 ? 63 : (DX < 0 ? 0 : -1));
+    one = 1;
+    asm volatile("" : "+v"(one));
+    const int col0 = first_col(NX);
+#pragma unroll
+    for (int w = 0; w < KW; w++) {
+      u32 m = 0, q = 0;
+#pragma unroll
+      for (int b = 0; b < 2; b++) {
+        const int col = col0 + 2 * w + b;
+        const bool outside = col < 0 || col >= NX, feeder_outside = col - DX < 0 || col - DX >= NX;
+        if (!outside) m |= 0xffffu << (16 * b);
+        if (outside && feeder_outside) q |= 0xffffu << (16 * b);
+      }
+      cmask[w] = m;
+      calm[w] = q;
+    }
+  }
+  __device__ __forceinline__ int first_col(int NX) const { return (threadIdx.x & 63) * K - (DX < 0 ? 64 * K - NX : 0); }
+
+  __device__ __forceinline__ void reset_lines() {
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+      lp[j] = 0;
+      lq[j] = T.K1;
+    }
+  }
+  __device__ __forceinline__ void load_row(const uint8_t *p, u32 (&v)[KW]) const {
+    fw2_load<KW>(p, v);
+    if (haspad) {
+#pragma unroll
+      for (int w = 0; w < KW; w++) v[w] &= cmask[w];
+    }
+  }
+  // cross-lane move of the one line that changes lane, after the line that leaves the row was closed (its run is recorded:
+  // B[prev][len]; there is no pair across the row's edge)
+  template <bool PLAIN>
+  __device__ __forceinline__ void rotate_reg(int &rp, int &rq, int xlevel) {
+    if (!haspad) {
+      if (PLAIN) {
+        const unsigned long long em = DX > 0 ? 0x8000000000000000ull : 1ull;   // lane 63 / lane 0
+        asm volatile("s_mov_b64 exec, %[m]\n\tds_add_u32 %[r], %[one]\n\ts_mov_b64 exec, -1" ::[m] "s"(em), [r] "v"(rq), [one] "v"(one) : "memory");
+      } else if (lane == edge_lane) {
+        fw2_checked<LONG>(T, dummy, rp, rq, xlevel, 0, false);
+      }
+    }
+    rp = (int)(DX > 0 ? fw_shr1((u32)rp) : fw_shl1((u32)rp));
+    rq = (int)(DX > 0 ? fw_shr1((u32)rq) : fw_shl1((u32)rq));
+    if (lane == (DX > 0 ? 0 : 63)) rq = T.K1;     // the line that enters from outside the window: level 0, length 0
+  }
+  __device__ __forceinline__ void single_step(const u32 (&C)[KW], bool tail) {
+    u32 X[KW];
+    fw2_make_x<K, DX>(P, X);
+#pragma unroll
+    for (int j = 0; j < K; j++) fw2_checked<LONG>(T, dummy, lp[j], lq[j], FW2_EL(X, j), FW2_EL(C, j), tail);
+    if (DX > 0) {
+      rotate_reg<false>(lp[K - 1], lq[K - 1], FW2_EL(C, K - 1));
+      const int ip = lp[K - 1], iq = lq[K - 1];
+#pragma unroll
+      for (int j = K - 1; j >= 1; j--) {
+        lp[j] = lp[j - 1];
+        lq[j] = lq[j - 1];
+      }
+      lp[0] = ip;
+      lq[0] = iq;
+    } else if (DX < 0) {
+      rotate_reg<false>(lp[0], lq[0], FW2_EL(C, 0));
+      const int ip = lp[0], iq = lq[0];
+#pragma unroll
+      for (int j = 0; j < K - 1; j++) {
+        lp[j] = lp[j + 1];
+        lq[j] = lq[j + 1];
+      }
+      lp[K - 1] = ip;
+      lq[K - 1] = iq;
+    }
+#pragma unroll
+    for (int w = 0; w < KW; w++) P[w] = C[w];
+  }
+  // U plain steps with renamed registers
+  __device__ __forceinline__ void plain_group(const u32 (&v)[U][KW]) {
+#pragma unroll
+    for (int k = 0; k < U; k++) {
+      u32 X[KW];
+      fw2_make_x<K, DX>(P, X);
+#pragma unroll
+      for (int w = 0; w < KW; w++) {
+        const int r0 = (((2 * w + 0 - k * DX) % K) + K) % K, r1 = (((2 * w + 1 - k * DX) % K) + K) % K;
+        fw2_plain_word(T, one, lp[r0], lq[r0], lp[r1], lq[r1], v[k][w], X[w]);
+      }
+      if (DX > 0) {
+        const int r = (((K - 1 - k) % K) + K) % K;
+        rotate_reg<true>(lp[r], lq[r], FW2_EL(v[k], K - 1));
+      }
+      if (DX < 0) {
+        const int r = k % K;
+        rotate_reg<true>(lp[r], lq[r], FW2_EL(v[k], 0));
+      }
+#pragma unroll
+      for (int w = 0; w < KW; w++) P[w] = v[k][w];
+    }
+  }
+  // 4 len of the longest open run (level-0 lines count with their age): a plain walk of n steps is safe while
+  // margin + 4 n <= lenlim
+  __device__ __forceinline__ unsigned margin() {
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < K; j++) m = max(m, (unsigned)(lq[j] - lp[j] - T.K1));
+    return m;
+  }
+  __device__ __forceinline__ void calm_padding() {
+    if (!haspad) return;
+#pragma unroll
+    for (int j = 0; j < K; j++)
+      if ((calm[j >> 1] >> (16 * (j & 1))) & 0xffffu) {
+        lp[j] = 0;
+        lq[j] = T.K1;
+      }
+  }
+  // lines inside a stretch of voxels outside the ROI (and dead lines): the stretch is no run, its "length" restarts
+  __device__ __forceinline__ void calm_level0() {
+#pragma unroll
+    for (int j = 0; j < K; j++)
+      if (lp[j] < T.S) lq[j] = T.K1;
+  }
+  __device__ __forceinline__ bool any_alive() {
+    u32 X[KW];
+    fw2_make_x<K, DX>(P, X);
+    bool a = false;
+#pragma unroll
+    for (int j = 0; j < K; j++) a = a || (lp[j] >= T.S && FW2_EL(X, j) != 0);
+    return __ballot(a) != 0;
+  }
+  __device__ __forceinline__ void run(const FwDesc &D, int NX, int pitch, long long nrows, const uint8_t *__restrict__ L,
+                                      int *work, int bx, int nblocks) {
+    const int NM = D.NM, NU = D.NU, du = D.du;
+    const long long delta = D.sM + (long long)du * D.sU;
+    const uint8_t *lpb = L + 2 * (long long)first_col(NX);
+    const int nwaves = (int)(nblocks * (blockDim.x >> 6));
+    const int wid = __builtin_amdgcn_readfirstlane((int)(bx * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    for (int it = 0;; it++) {
+      int chunk;
+      if (it == 0) {
+        chunk = wid;
+      } else {
+        int grabbed = 0;
+        if (lane == 0) grabbed = atomicAdd(work, 1);
+        chunk = nwaves + __builtin_amdgcn_readfirstlane(grabbed);
+      }
+      if (chunk >= D.chunks) break;
+      const int piece = chunk / NU, u0 = chunk - piece * NU;
+      const int t0 = piece * D.CL, t1 = min(NM, t0 + D.CL);
+      int row = (int)((u0 + (long long)t0 * du) % NU);
+      if (row < 0) row += NU;
+      long long off = (long long)t0 * D.sM + (long long)row * D.sU;
+      const bool starts = t0 == 0 || (du > 0 && row == 0) || (du < 0 && row == NU - 1);
+      int safe = 0;
+      reset_lines();               // (a piece that does not begin at a line start: every line DEAD = level 0)
+      if (starts) {
+#pragma unroll
+        for (int w = 0; w < KW; w++) P[w] = 0;
+      } else {
+        load_row(lpb + (off - delta), P);
+      }
+      int t = t0;
+      bool wrap = false, tail = false;
+      for (;;) {
+        bool closing = false, finish = false;
+        if (!tail && t >= t1) {
+          if (t1 == NM || wrap) closing = finish = true;
+          else tail = true;
+        }
+        if (tail && !closing) {
+          if (t == NM || wrap) closing = finish = true;
+          else if (!any_alive()) break;
+        }
+        if (!tail && !closing && wrap) closing = true;
+        if (!tail && !closing) {
+          const int room = du > 0 ? NU - row : (du < 0 ? row + 1 : (1 << 30));
+          const bool grp = t + U <= t1 && room >= U;
+          if (grp && safe == 0) {
+            calm_padding();
+            if (!LONG) {
+              safe = 2;            // every run length (and every age) has its slot
+            } else {
+              calm_level0();       // (ages restart: only real runs decide)
+              const unsigned m = margin();
+              if (__ballot(m + 4 * 2 * U > (unsigned)T.lenlim) == 0) safe = 2;
+              else if (__ballot(m + 4 * U > (unsigned)T.lenlim) == 0) safe = 1;
+            }
+          }
+          if (grp && safe > 0) {
+            u32 v[U][KW];
+            const uint8_t *p = lpb + off;
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+              load_row(p, v[k]);
+              p += delta;
+            }
+            if (safe == 1) calm_padding();
+            plain_group(v);
+            safe--;
+            t += U;
+            row += U * du;
+            off += (long long)U * delta;
+            if (du != 0 && (row < 0 || row >= NU)) wrap = true;
+            continue;
+          }
+        }
+        u32 c[KW];
+        if (closing) {
+#pragma unroll
+          for (int w = 0; w < KW; w++) c[w] = 0;
+        } else {
+          load_row(lpb + off, c);
+        }
+        single_step(c, tail);
+        safe = 0;
+        if (closing) {
+          if (finish) break;
+          reset_lines();
+          row -= du * NU;
+          off -= (long long)du * NU * D.sU;
+          wrap = false;
+          continue;
+        }
+        t++;
+        row += du;
+        off += delta;
+        if (du != 0 && (row < 0 || row >= NU)) wrap = true;
+      }
+    }
+  }
+};
+
+// table -> global accumulators (angle-major u32, the layout of kernels_sweep.h)
+__device__ __forceinline__ void fw2_flush(const u32 *lds, const Fw2Tab &T, int slot, u32 *__restrict__ glcm_acc,
+                                          u32 *__restrict__ glrlm_acc) {
+  __syncthreads();
+  const int Ng = T.Ng;
+  u32 *gd = glcm_acc + (size_t)slot * Ng * Ng;
+  for (int i = threadIdx.x; i < Ng * Ng; i += blockDim.x) {
+    const int p = i / Ng, c = i - p * Ng;
+    if (p == c) continue;  // the diagonal comes from the GLRLM in finalize
+    const u32 v = lds[(size_t)(p + 1) * T.S4 + c + 1];
+    if (v) atomicAdd(gd + i, v);
+  }
+  u32 *rd = glrlm_acc + (size_t)slot * Ng * T.Nr;
+  const int nl = min(T.RS2, T.Nr);
+  for (int i = threadIdx.x; i < Ng * nl; i += blockDim.x) {
+    const int p = i / nl, l = i - p * nl;
+    const u32 v = lds[(size_t)(p + 1) * T.S4 + Ng + 1 + l];
+    if (v) atomicAdd(rd + (size_t)p * T.Nr + l, v);
+  }
+}
+
+template <bool LONG, int K, bool HASPAD>
+__global__ void __launch_bounds__(1024) sweep_fw2_kernel(FwSet set, const uint8_t *__restrict__ L, int Ng, int Nr, int RS2,
+                                                         u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
+                                                         int *__restrict__ work, int *__restrict__ flags) {
+  extern __shared__ u32 lds[];
+  if (flags[0]) return;  // irregular levels: the generic path will redo this call
+  if ((unsigned)(size_t)((lds_u32 *)lds) != 0u) {  // table offsets are used as LDS addresses
+    if (threadIdx.x == 0) atomicExch(flags + 2, 1);
+    return;
+  }
+  int role = 0;
+  while (role + 1 < set.count && (int)blockIdx.x >= set.first_block[role + 1]) role++;
+  const int bx = (int)blockIdx.x - set.first_block[role], nblocks = set.first_block[role + 1] - set.first_block[role];
+  const int words = (int)fw2_table_words(Ng, RS2);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) lds[i] = 0;
+  __syncthreads();
+  const FwDesc &D = set.d[role];
+  Fw2Tab T;
+  T.init(Ng, RS2, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
+  int *wk = work + PRAD_FW_WORK_STRIDE * role;
+  if (D.dx == 0) {
+    Fw2Wave<LONG, K, 0, HASPAD> w(T, set.NX);
+    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks);
+  } else if (D.dx > 0) {
+    Fw2Wave<LONG, K, 1, HASPAD> w(T, set.NX);
+    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks);
+  } else {
+    Fw2Wave<LONG, K, -1, HASPAD> w(T, set.NX);
+    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks);
+  }
+  fw2_flush(lds, T, D.slot, glcm_acc, glrlm_acc);
+}
+
+// pack for this path: 16-bit level*4 elements (rows of pitch16 BYTES) and, for the rows kernel, plain 8-bit levels
+__global__ void __launch_bounds__(256) pack_levels16_kernel(const int *__restrict__ image, const uint8_t *__restrict__ mask,
+                                                            long long n, int NX, int pitch16, int pitch8, int Ng,
+                                                            uint8_t *__restrict__ L16, uint8_t *__restrict__ L8,
+                                                            int *__restrict__ flags) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nthreads = (long long)gridDim.x * blockDim.x;
+  int bad = 0;
+  // 4 voxels per lane and step when rows are whole 4-voxel pieces; else one by one
+  if ((NX & 3) == 0) {
+    const long long n4 = n >> 2;
+    const int upr = NX >> 2;
+    for (long long t = tid; t < n4; t += nthreads) {
+      const int4 q = reinterpret_cast<const int4 *>(image)[t];
+      const u32 m = reinterpret_cast<const u32 *>(mask)[t];
+      const int lv[4] = {q.x, q.y, q.z, q.w};
+      u32 e[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const bool in = (m >> (8 * b)) & 0xffu;
+        const bool regular = in && lv[b] >= 1 && lv[b] <= Ng;
+        bad |= in && !regular;
+        e[b] = regular ? (u32)lv[b] : 0u;
+      }
+      const long long row = t / upr;
+      const int x = (int)(t - row * upr) << 2;
+      *reinterpret_cast<uint2 *>(L16 + row * pitch16 + 2 * x) =
+          make_uint2((e[0] << PRAD_FUSED_SHIFT) | (e[1] << (16 + PRAD_FUSED_SHIFT)), (e[2] << PRAD_FUSED_SHIFT) | (e[3] << (16 + PRAD_FUSED_SHIFT)));
+      *reinterpret_cast<u32 *>(L8 + row * pitch8 + x) = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
+    }
+  } else {
+    for (long long i = tid; i < n; i += nthreads) {
+      const bool in = mask[i] != 0;
+      const int l = image[i];
+      const bool regular = in && l >= 1 && l <= Ng;
+      bad |= in && !regular;
+      const long long row = i / NX;
+      const int x = (int)(i - row * NX);
+      *reinterpret_cast<unsigned short *>(L16 + row * pitch16 + 2 * x) = (unsigned short)(regular ? (l << PRAD_FUSED_SHIFT) : 0);
+      L8[row * pitch8 + x] = (uint8_t)(regular ? l : 0);
+    }
+  }
+  if (bad) flags[0] = 1;
+}
+
+}  // namespace prad

@@ -12,6 +12,7 @@
 #include "kernels_generic.h"
 #include "kernels_sweep.h"
 #include "kernels_sweepfw.h"
+#include "kernels_sweepfw2.h"
 #include "kernels_neigh.h"
 #include "kernels_glszm.h"
 #include "kernels_filters.h"
@@ -269,6 +270,12 @@ struct SweepPlan {
   size_t lds_fw = 0;
   int RSfw_rows = 0;           // length slots of the rows role's table (it shares the LDS with 16 staging tiles)
   size_t lds_fw_rows = 0;      // the x angle as a launch of its own (sweep_fw_rows_kernel)
+  // two-table fixed-window kernel (kernels_sweepfw2.h): 45+ grey levels
+  bool fw2 = false;
+  int RS2 = 0;                 // run-length slots per level row
+  bool LONGfw2 = false;
+  size_t lds_fw2 = 0;
+  int pitch16 = 0;             // bytes per row of the 16-bit level volume
   FwSet fwset;
 };
 
@@ -321,7 +328,26 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
       p.RSr = rsr;
     }
   }
-  if (!p.fused) {
+  // Two-table fixed-window kernel for the line angles when the fused table does not fit (45+ levels): rows that one wave
+  // window covers, a level row [Ng + 1 pairs | RS2 lengths] table within the LDS, and the rows kernel (separate tables, here
+  // with up to 100 KB for them) for the angle along x
+  if (want_glcm && want_glrlm && !p.fused && Ng >= 40 && p.Nx > 64 && p.Nx <= 512 && !getenv("PRAD_NO_FW2")) {
+    const long long maxwords = (158 * 1024) / 4;
+    long long rs2 = maxwords / (Ng + 1) - (Ng + 1);
+    if (const char *e = getenv("PRAD_FW2_RS")) rs2 = std::min<long long>(rs2, atoll(e));   // tuning override
+    rs2 = std::min<long long>(rs2, Nr);
+    if (rs2 < Nr && ((Ng + 1 + rs2) & 1) == 0) rs2--;      // odd row stride: consecutive levels on different banks
+    const int rsr = fit_rs(true, true, false, Ng, Nr, 116 * 1024);   // (+ 40 KB of staging tiles: within the 160 KB)
+    if ((rs2 >= 24 || rs2 >= Nr) && rs2 >= 1 && rsr >= std::min(Nr, 4)) {
+      p.fw2 = true;
+      p.RS2 = (int)rs2;
+      p.LONGfw2 = rs2 < Nr;
+      p.lds_fw2 = 4 * fw2_table_words(Ng, p.RS2);
+      p.RS = 0;
+      p.RSr = rsr;
+    }
+  }
+  if (!p.fused && !p.fw2) {
     p.RS = want_glrlm ? fit_rs(want_glcm, true, false, Ng, Nr, kHistBudget) : 0;
     p.RSr = want_glrlm ? fit_rs(want_glcm, true, false, Ng, Nr, kHistBudgetRows) : 0;
     if (p.RS < 0 || p.RSr < 0) return p;
@@ -366,7 +392,9 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
   p.fw = p.fused && p.Nx > 64 && p.Nx <= 512 && !getenv("PRAD_NO_FW");
   if (const char *e = getenv("PRAD_FW_MINVOX")) p.fw = p.fw && k.g.n >= atoll(e);
   p.fwK = p.Nx <= 256 ? 4 : 8;
-  p.padw = p.fw ? 0 : std::min(64 * p.LPL, p.Nx);
+  if (p.fw2) p.fwK = p.Nx <= 256 ? 4 : 8;
+  p.padw = (p.fw || p.fw2) ? 0 : std::min(64 * p.LPL, p.Nx);
+  p.pitch16 = 2 * ((p.Nx + 7) & ~7);
   p.pitch = (p.Nx + p.padw + 15) & ~15;   // 16-byte aligned rows: vector staging in the rows kernel for any Nx
   p.lines.count = 0;
   p.aset.count = k.Na;
@@ -399,7 +427,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     D.LXc = (p.Nx + 64 * p.LPL - 1) / (64 * p.LPL);
     D.chunks = (long long)D.NU * D.LXc;
   }
-  if (p.fw && p.lines.count > 0) {
+  if ((p.fw || p.fw2) && p.lines.count > 0) {
     size_t budget = kHistBudgetFw;
     if (const char *e = getenv("PRAD_FW_BUDGET_KB")) budget = (size_t)std::max(8, atoi(e)) * 1024;   // tuning override
     p.RSfw = fit_rs(true, true, true, Ng, Nr, budget);
@@ -418,7 +446,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     if (const char *e = getenv("PRAD_FW_RS")) p.RSfw = std::max(1, std::min(p.RSfw, atoi(e)));   // tuning override
     p.LONGfw = p.RSfw < Nr;
     p.lds_fw = fw_lds_bytes(hist_layout(true, true, true, Ng, p.RSfw));
-    if (p.row_slot >= 0) {   // the x angle: a launch of its own, 8 waves + their staging tiles (sweep_fw_rows_kernel)
+    if (p.row_slot >= 0 && p.fw) {   // the x angle: a launch of its own, 8 waves + their staging tiles (sweep_fw_rows_kernel)
       const size_t tiles = (size_t)(kRowsThreads / 64) * 64 * PRAD_ROW_PITCH;
       int rs = fit_rs(true, true, true, Ng, Nr, 100 * 1024);
       for (int r = rs; rs < Nr && r >= std::max(16, rs - 12); r--) {   // same bank-stride rule as above
@@ -448,6 +476,12 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
       FwDesc &D = p.fwset.d[i];
       D.slot = S.slot; D.NM = S.NM; D.NU = S.NU; D.du = S.du; D.dx = S.dx; D.sM = S.sM; D.sU = S.sU;
       p.fwset.pitch = p.pitch;
+      if (p.fw2) {   // byte strides of the 16-bit level volume
+        const bool march_z = S.sM >= S.sU;
+        D.sM = march_z ? (long long)p.Ny * p.pitch16 : p.pitch16;
+        D.sU = march_z ? p.pitch16 : (long long)p.Ny * p.pitch16;
+        p.fwset.pitch = p.pitch16;
+      }
       p.fwset.nrows = p.Nz * p.Ny;
       const long long want = (long long)per_wave * (p.fwset.first_block[i + 1] - p.fwset.first_block[i]) * 16;
       int pieces = (int)std::max<long long>(1, (want + D.NU - 1) / D.NU);
@@ -462,6 +496,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     }
   } else {
     p.fw = false;
+    if (p.fw2) return SweepPlan();   // (only the x angle was asked for: not worth a plan of its own) -> generic path
   }
   p.ok = true;
   return p;
@@ -529,6 +564,31 @@ int launch_fw(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *lev
                     : launch_fw_k<false, 8>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
 }
 
+template <bool LNG, int K>
+int launch_fw2_k(Call &k, const SweepPlan &p, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *multi,
+                 int *flags_d) {
+  int *work = multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE;
+  if (p.Nx != 64 * K) {
+    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw2_kernel<LNG, K, true>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw2));
+    hipLaunchKernelGGL((sweep_fw2_kernel<LNG, K, true>), dim3(p.fw_blocks), dim3(1024), p.lds_fw2, k.s, p.fwset, levels16, Ng, Nr,
+                       p.RS2, glcm_acc, glrlm_acc, work, flags_d);
+  } else {
+    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw2_kernel<LNG, K, false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw2));
+    hipLaunchKernelGGL((sweep_fw2_kernel<LNG, K, false>), dim3(p.fw_blocks), dim3(1024), p.lds_fw2, k.s, p.fwset, levels16, Ng, Nr,
+                       p.RS2, glcm_acc, glrlm_acc, work, flags_d);
+  }
+  return check_launch("sweep_fw2_kernel");
+}
+int launch_fw2(Call &k, const SweepPlan &p, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *multi,
+               int *flags_d) {
+  if (p.LONGfw2) return p.fwK == 4 ? launch_fw2_k<true, 4>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
+                                 : launch_fw2_k<true, 8>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
+  return p.fwK == 4 ? launch_fw2_k<false, 4>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
+                    : launch_fw2_k<false, 8>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
+}
+
 template <bool LNG>
 int launch_fw_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *flags_d) {
   const long long nrows = (long long)p.Nz * p.Ny, groups = nrows >= 4096 ? ((nrows + 511) / 512) * 8 : (nrows + 63) / 64;
@@ -574,6 +634,7 @@ struct VolState {
   int Ng = 0, Nr = 0, Na = 0;
   double *glcm = nullptr, *glrlm = nullptr;   // outputs (device), either may be NULL
   uint8_t *levels = nullptr, *rowzero = nullptr;
+  uint8_t *levels16 = nullptr;   // 16-bit level*4 elements (two-table fixed-window kernel)
   u32 *acc = nullptr, *glcm_acc = nullptr, *glrlm_acc = nullptr;
   int *multi = nullptr;
   int *flags_d = nullptr;
@@ -594,6 +655,11 @@ int vol_prepare(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, doubl
   const long long nrows = (long long)p.Nz * p.Ny;
   PRAD_TRY(c.get<uint8_t>("levels", (size_t)nrows * p.pitch + 1024, &v.levels));
   v.levels += 512;   // the fixed-window kernel reads (and masks) up to one window before the first and behind the last row
+  v.levels16 = nullptr;
+  if (p.fw2) {
+    PRAD_TRY(c.get<uint8_t>("levels16", (size_t)nrows * p.pitch16 + 4096, &v.levels16));
+    v.levels16 += 2048;
+  }
   const size_t nglcm = glcm ? (size_t)k.Na * Ng * Ng : 0, nglrlm = glrlm ? (size_t)k.Na * Ng * Nr : 0;
   // accumulators, then per-angle "multi-element" flags, then per-role work counters of the lines kernels
   const size_t nctl = 2 * PRAD_MAX_SWEEP + (size_t)PRAD_FW_WORK_STRIDE * (PRAD_MAX_SWEEP + 1);
@@ -647,6 +713,12 @@ int vol_pack_standalone(Call &k, VolState &v) {
   Context &c = *k.c;
   const SweepPlan &p = v.p;
   Timed t(c, "pack", k.s);
+  if (p.fw2) {   // 16-bit elements for the line walks + plain 8-bit levels for the rows kernel, one pass
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n / 4 + 255) / 256, 8192));
+    hipLaunchKernelGGL(pack_levels16_kernel, dim3(gx), dim3(256), 0, k.s, k.image, k.mask, k.g.n, p.Nx, p.pitch16, p.pitch, v.Ng,
+                       v.levels16, v.levels, v.flags_d);
+    return check_launch("pack_levels16_kernel");
+  }
   const int vec_ok = p.vec_rows && ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)v.levels)) & 15) == 0;
   const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n / 16 + 255) / 256, 4096));
   // the fused walker reads level*4 bytes (see Walker<true, true, LONG, true>); it only exists for Ng <= 44
@@ -668,6 +740,18 @@ int launch_sweeps(Call &k, const VolState &v, const PackJob &pj) {
       Timed t(*k.c, "rows", k.s);
       if (p.RSfw_rows < v.Nr) PRAD_TRY(launch_fw_rows<true>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.flags_d));
       else PRAD_TRY(launch_fw_rows<false>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.flags_d));
+    }
+    return PRAD_OK;
+  }
+  if (p.fw2 && G && R && !F && p.lines.count > 0) {
+    {
+      Timed t(*k.c, "sweep", k.s);
+      PRAD_TRY(launch_fw2(k, p, v.levels16, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi, v.flags_d));
+    }
+    if (p.row_slot >= 0) {
+      Timed t(*k.c, "rows", k.s);
+      if (p.LONGr) PRAD_TRY((launch_rows<G, R, true, F>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi)));
+      else PRAD_TRY((launch_rows<G, R, false, F>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi)));
     }
     return PRAD_OK;
   }
@@ -706,7 +790,8 @@ int vol_finalize(Call &k, const VolState &v, int *sticky) {
   bool latched = false;
   {
     Timed t(c, "finalize", k.s);
-    if (glcm && glrlm && p.fused) {
+    const bool runs_diag = p.fused || p.fw2;     // the walks left the GLCM diagonal to the runs
+    if (glcm && glrlm && runs_diag) {
       const int nb1 = (int)blocks_for((long long)Ng * Ng * Na), nb2 = (Ng * Na + 3) / 4;
       hipLaunchKernelGGL(finalize_glcm_diag_kernel, dim3(nb1 + nb2), dim3(256), 0, k.s, v.glcm_acc, v.glrlm_acc, Ng, Nr, Na, nb1,
                          glcm, v.multi);
@@ -716,7 +801,7 @@ int vol_finalize(Call &k, const VolState &v, int *sticky) {
                          v.glcm_acc, v.glrlm_acc, Ng, Nr, Na, p.fused ? 1 : 0, glcm);
       PRAD_TRY(check_launch("finalize_glcm_kernel"));
     }
-    if (glrlm && p.fused) {
+    if (glrlm && runs_diag) {
       if (!glcm) {
         hipLaunchKernelGGL(glcm_diag_resolve_kernel, dim3(Ng, Na), dim3(64), 0, k.s, v.glcm_acc, v.glrlm_acc, Ng, Nr, Na,
                            glcm, v.multi);
@@ -878,6 +963,7 @@ int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *siz
   SweepPlan p = plan_sweep(k, Ng, Nr, glcm != nullptr, glrlm != nullptr);
   if (!p.ok) PRAD_HIP(hipMemsetAsync(k.flags_d, 0, sizeof(int) * 4, s));   // (vol_prepare does it on the sweep path)
   bool done = false;
+  c.last_variant = !p.ok ? "none" : (p.fw2 ? "fw2" : (p.fw && glcm && glrlm ? "fw" : "lines"));
   if (pipe) {
     PRAD_TRY(pipeline_step(k, p, Ng, Nr, glcm, glrlm, &done));
     if (done) c.last_path = "sweep";
@@ -1615,6 +1701,7 @@ extern "C" {
 const char *prad_version(void) { return kVersion; }
 const char *prad_last_error(void) { return err_state().msg; }
 const char *prad_last_path(void) { return ctx().last_path; }
+const char *prad_last_variant(void) { return ctx().last_variant; }
 
 int prad_device_count(void) {
   int n = 0;

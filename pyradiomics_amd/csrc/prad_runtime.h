@@ -73,6 +73,7 @@ struct Context {
   hipEvent_t call_a = nullptr, call_b = nullptr;
   bool call_timed = false;
   const char *last_path = "none";
+  const char *last_variant = "none";   // which sweep kernels served the last GLCM / GLRLM call ("fw", "fw2", "lines")
   // deferred mode (prad_set_deferred): GLCM/GLRLM device calls only enqueue work; the "levels outside [1, Ng]" flag of
   // every such call is latched into a sticky device word that prad_deferred_status() reads after synchronising
   bool deferred = false;

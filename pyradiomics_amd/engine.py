@@ -281,6 +281,11 @@ def last_path() -> str:
     return _lib.last_path()
 
 
+def last_variant() -> str:
+    """which sweep kernels served the last GLCM / GLRLM call: "fw", "fw2" or "lines" """
+    return _lib.last_variant()
+
+
 def _neigh_common(image, mask, distances, force2D, force2Ddimension):
     lib, image, mask, size = _prep(image, mask)
     f2d = int(force2Ddimension) if force2D else -1

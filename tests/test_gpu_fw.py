@@ -282,3 +282,62 @@ def test_pipeline_packs_inside_the_previous_walk_and_flushes(cm, checker):
             assert torch.equal(g, one[0]) and torch.equal(r, one[1])
     finally:
         engine.set_deferred_mode(-1)
+
+
+# ---- the two-table fixed-window kernel (csrc/kernels_sweepfw2.h): 45+ grey levels ------------------------------------------
+def _check2(cm, checker, img, mask, Ng):
+    from pyradiomics_amd import _lib
+    _check(cm, checker, img, mask, Ng)
+    assert _lib.last_variant() == "fw2", _lib.last_variant()
+
+
+@pytest.mark.parametrize("Ng", [44, 64, 100, 128, 160])
+@pytest.mark.parametrize("shape", [(20, 24, 512), (24, 20, 256), (18, 30, 300), (30, 18, 130), (9, 40, 66)])
+def test_fw2_levels_and_shapes(cm, checker, Ng, shape):
+    """Ng 45 .. 160 on the fixed-window kernel with two tables and 16-bit level elements: rows that fill the window (256
+    with 4 columns per lane, 512 with 8) and ragged ones, iid and smooth levels, bit-exact against the reference C"""
+    for kind in ("uniform", "smooth"):
+        _check2(cm, checker, _levels(hash(shape) % 991 + Ng, shape, Ng, kind), _mask(1, shape, "full"), Ng)
+
+
+@pytest.mark.parametrize("Ng", [64, 128])
+@pytest.mark.parametrize("mkind", ["random", "ball"])
+def test_fw2_masks(cm, checker, Ng, mkind):
+    for shape, kind in (((20, 24, 512), "uniform"), ((30, 18, 257), "blobs"), ((24, 20, 256), "smooth")):
+        _check2(cm, checker, _levels(5 + Ng, shape, Ng, kind), _mask(2, shape, mkind), Ng)
+
+
+@pytest.mark.parametrize("Ng", [64, 150])
+def test_fw2_long_runs_pieces_and_flat_volumes(cm, checker, Ng, monkeypatch):
+    """runs longer than the table's length slots (Ng = 150 leaves ~100 of them; PRAD_FW2_RS forces 24), flat volumes of a
+    high level, many short pieces (dead lines + tails)"""
+    for shape in ((40, 44, 512), (64, 20, 256), (24, 70, 130)):
+        for kind in ("blobs", "flat"):
+            img = _levels(9 + Ng, shape, Ng, kind)
+            if kind == "flat":
+                img[:] = Ng
+                img[1, 2, 3] = 5
+            _check2(cm, checker, img, _mask(3, shape, "full"), Ng)
+    monkeypatch.setenv("PRAD_FW2_RS", "24")
+    monkeypatch.setenv("PRAD_FW_CL", "16")
+    for shape in ((40, 44, 512), (70, 16, 200)):
+        for kind in ("blobs", "smooth", "flat"):
+            _check2(cm, checker, _levels(11 + Ng, shape, Ng, kind), _mask(4, shape, "ball" if kind != "flat" else "full"), Ng)
+
+
+def test_fw2_equals_the_lines_kernels_and_serves_deferred_calls(cm, monkeypatch):
+    import torch
+    from pyradiomics_amd import engine
+    Ng, shape = 64, (48, 40, 512)
+    img = torch.from_numpy(_levels(77, shape, Ng, "smooth")).cuda()
+    mask = torch.from_numpy(_mask(7, shape, "ball").astype(np.uint8)).cuda()
+    g1, r1, _ = engine.glcm_glrlm(img, mask, Ng, 512)
+    assert engine.last_variant() == "fw2"
+    got = [engine.glcm_glrlm(img, mask, Ng, 512, deferred=True) for _ in range(3)]
+    engine.deferred_status()
+    for g, r, _ in got:
+        assert torch.equal(g, g1) and torch.equal(r, r1)
+    monkeypatch.setenv("PRAD_NO_FW2", "1")
+    g0, r0, _ = engine.glcm_glrlm(img, mask, Ng, 512)
+    assert engine.last_variant() == "lines"
+    assert torch.equal(g0, g1) and torch.equal(r0, r1)
