@@ -1,12 +1,13 @@
-// kernels_sweepfw2.h -- the fixed-window line sweeps for 45 .. ~175 grey levels (binWidth 25 on CT gives 60 - 160), gfx950.
+// kernels_sweepfw2.h -- the fixed-window line sweeps for 44 .. ~160 grey levels (binWidth 25 on CT gives 60 - 160), gfx950.
 //
 // The fused table H[prev][len][cur] of kernels_sweepfw.h grows with (Ng+1)^2 x length slots: beyond 44 levels the 160 KB
 // of LDS no longer hold the 16+ slots the plain path needs, and level*4 no longer fits the byte lanes the step reads.
 // Same geometry here (a wave owns a window of 64*K columns that covers whole rows, lines with dx != 0 drift through
 // renamed registers, pieces / dead lines / tails exactly as there), different accumulation:
 //   * levels are 16-bit elements (level*4; 0 outside the ROI), two columns per dword, SDWA word selects;
-//   * TWO tables, interleaved row by row at LDS address 0:  row(level) = [ A: cur 0..Ng | B: len 1..RS2 ],
-//     S = 4 (Ng + 1 + RS2) bytes.  A run end (prev, len, cur) adds to A[prev][cur] (the GLCM pair; the diagonal comes from
+//   * TWO tables, interleaved row by row at LDS address 0:  row(level) = [ A: cur 0..Ng | B: C copies of len 1..RS2 ],
+//     S = 4 (Ng + 1 + C RS2) bytes; lane l uses copy l mod C of B (on iid levels nearly every run has length 1: the 64
+//     lanes of a ds_add would otherwise share Ng addresses, and same-address atomics serialise at 2 cycles a lane).  A run end (prev, len, cur) adds to A[prev][cur] (the GLCM pair; the diagonal comes from
 //     the runs as before) and to B[prev][len] (the GLRLM bin): 5 VALU + 2 ds_add + 1 SALU per voxel-step against
 //     4 + 1 + 1 of the fused step -- about 1.3x its time -- but the table is (Ng+1)(Ng+1+RS2) words: 64 levels with 128
 //     run lengths take 50 KB, 128 levels with 128 lengths 132 KB, and with that many length slots the checked path
@@ -22,21 +23,21 @@ namespace prad {
 
 struct Fw2Tab {
   u32 *rl_long;
-  int Nr, Ng, RS2;
-  int S, S4, K1, lenlim, dead_qmax;
-  __device__ __forceinline__ void init(int Ng_, int RS2_, int Nr_, u32 *rl_long_) {
+  int Nr, Ng, RS2, C;
+  int S, S4, K1, lenlim;
+  __device__ __forceinline__ void init(int Ng_, int RS2_, int C_, int Nr_, u32 *rl_long_) {
     rl_long = rl_long_;
     Nr = Nr_;
     Ng = Ng_;
     RS2 = RS2_;
-    S4 = Ng_ + 1 + RS2_;
+    C = C_;
+    S4 = Ng_ + 1 + C_ * RS2_;
     S = 4 * S4;
-    K1 = 4 * Ng_;              // q = p + K1 + 4 len: len = 1 sits right behind the A row
+    K1 = 4 * Ng_;              // q = p + K1 + 4 RS2 copy + 4 len: len = 1 of copy 0 sits right behind the A row
     lenlim = 4 * RS2_;         // 4 len of the last length slot
-    dead_qmax = K1 + lenlim;   // a level-0 line's cursor stops growing here (checked path)
   }
 };
-__host__ __device__ inline size_t fw2_table_words(int Ng, int RS2) { return (size_t)(Ng + 1) * (size_t)(Ng + 1 + RS2); }
+__host__ __device__ inline size_t fw2_table_words(int Ng, int RS2, int C) { return (size_t)(Ng + 1) * (size_t)(Ng + 1 + C * RS2); }
 
 // a run of level lv (!= 0) longer than RS2 just ended: one L2 atomic per distinct (level, length) of the wave
 __device__ __noinline__ void fw2_long_event(const Fw2Tab &T, int lv, int idx) {
@@ -56,24 +57,24 @@ __device__ __noinline__ void fw2_long_event(const Fw2Tab &T, int lv, int idx) {
 
 // One voxel-step of one line, every case handled.  x, c = level*4 of the previous / current voxel.
 template <bool LONG>
-__device__ __forceinline__ void fw2_checked(const Fw2Tab &T, int dummy, int &p, int &q, int x, int c, bool tail) {
+__device__ __forceinline__ void fw2_checked(const Fw2Tab &T, int k1, int dummy, int &p, int &q, int x, int c, bool tail) {
   const bool chg = c != x;
   const bool alive = p >= T.S;
   const bool ev = chg && alive;
-  const int lb = q - p - T.K1;                 // 4 len
+  const int lb = q - p - k1;                   // 4 len (k1: this lane's K1 + offset of its B copy)
   const bool inlds = !LONG || lb <= T.lenlim;
   lds_bump(ev ? p + c : dummy);                // the pair (cur = 0: the run ended at a line end / outside the ROI: ignored)
   lds_bump((ev && inlds) ? q : dummy);         // the run
   if (LONG && ev && !inlds) fw2_long_event(T, x >> PRAD_FUSED_SHIFT, (lb >> 2) - 1);
   const int fp = tail ? 0 : __mul24(c, T.S4);
-  const int grown = alive ? q + 4 : min(q + 4, T.dead_qmax);
-  q = select_i32(chg, fp + T.K1 + 4, grown);
+  const int grown = alive ? q + 4 : min(q + 4, k1 + T.lenlim);   // (a level-0 line's cursor stops at the last slot)
+  q = select_i32(chg, fp + k1 + 4, grown);
   p = select_i32(chg, fp, p);
 }
 
 // The plain step of the two lines whose levels are the 16-bit halves of c (current) and x (previous); exec-masked like
 // fw_plain_word.  Only valid while no run can outgrow its length slots (margin()).
-__device__ __forceinline__ void fw2_plain_word(const Fw2Tab &T, u32 one, int &p0, int &q0, int &p1, int &q1, u32 c, u32 x) {
+__device__ __forceinline__ void fw2_plain_word(const Fw2Tab &T, int k1, u32 one, int &p0, int &q0, int &p1, int &q1, u32 c, u32 x) {
   int t;
 #define PRAD_FW2_COL(J, PJ, QJ)                                                                                          \
   "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:WORD_" #J " src1_sel:WORD_" #J "\n\t"                                     \
@@ -86,7 +87,7 @@ __device__ __forceinline__ void fw2_plain_word(const Fw2Tab &T, u32 one, int &p0
   "v_add_u32 %[" QJ "], 4, %[" QJ "]\n\t"
   asm volatile(PRAD_FW2_COL(0, "p0", "q0") PRAD_FW2_COL(1, "p1", "q1")
                : [p0] "+v"(p0), [q0] "+v"(q0), [p1] "+v"(p1), [q1] "+v"(q1), [t] "=&v"(t)
-               : [c] "v"(c), [x] "v"(x), [one] "v"(one), [S4] "s"(T.S4), [K1] "s"(T.K1)
+               : [c] "v"(c), [x] "v"(x), [one] "v"(one), [S4] "s"(T.S4), [K1] "v"(k1)
                : "vcc", "memory");
 #undef PRAD_FW2_COL
 }
@@ -135,6 +136,8 @@ struct Fw2Wave {
   static constexpr int U = PRAD_FW_U;
   const Fw2Tab &T;
   int dummy, lane, edge_lane;
+  int k1v;         // K1 + byte offset of this lane's B copy
+  int kdelta;      // k1v minus the k1v of the lane a drifting line comes from (lane 0 / 63: the line comes from outside, k1v)
   u32 one;
   static constexpr bool haspad = HASPAD;
   u32 cmask[KW];   // halves of this lane's window columns that lie inside the row
@@ -148,6 +151,12 @@ struct Fw2Wave {
     edge_lane = haspad ? -1 : (DX > 0 ? 63 : (DX < 0 ? 0 : -1));
     one = 1;
     asm volatile("" : "+v"(one));
+    k1v = T.K1 + (lane % T.C) * T.lenlim;
+    {
+      const int src = lane - (DX > 0 ? 1 : -1);
+      kdelta = (DX == 0 || src < 0 || src > 63) ? k1v : ((lane % T.C) - (src % T.C)) * T.lenlim;
+    }
+    asm volatile("" : "+v"(k1v), "+v"(kdelta));
     const int col0 = first_col(NX);
 #pragma unroll
     for (int w = 0; w < KW; w++) {
@@ -169,7 +178,7 @@ struct Fw2Wave {
 #pragma unroll
     for (int j = 0; j < K; j++) {
       lp[j] = 0;
-      lq[j] = T.K1;
+      lq[j] = k1v;
     }
   }
   __device__ __forceinline__ void load_row(const uint8_t *p, u32 (&v)[KW]) const {
@@ -188,18 +197,18 @@ struct Fw2Wave {
         const unsigned long long em = DX > 0 ? 0x8000000000000000ull : 1ull;   // lane 63 / lane 0
         asm volatile("s_mov_b64 exec, %[m]\n\tds_add_u32 %[r], %[one]\n\ts_mov_b64 exec, -1" ::[m] "s"(em), [r] "v"(rq), [one] "v"(one) : "memory");
       } else if (lane == edge_lane) {
-        fw2_checked<LONG>(T, dummy, rp, rq, xlevel, 0, false);
+        fw2_checked<LONG>(T, k1v, dummy, rp, rq, xlevel, 0, false);
       }
     }
     rp = (int)(DX > 0 ? fw_shr1((u32)rp) : fw_shl1((u32)rp));
-    rq = (int)(DX > 0 ? fw_shr1((u32)rq) : fw_shl1((u32)rq));
-    if (lane == (DX > 0 ? 0 : 63)) rq = T.K1;     // the line that enters from outside the window: level 0, length 0
+    rq = (int)(DX > 0 ? fw_shr1((u32)rq) : fw_shl1((u32)rq)) + kdelta;   // (the cursor moves to this lane's copy of the slots;
+                                                                           //  the line that enters from outside: level 0, length 0)
   }
   __device__ __forceinline__ void single_step(const u32 (&C)[KW], bool tail) {
     u32 X[KW];
     fw2_make_x<K, DX>(P, X);
 #pragma unroll
-    for (int j = 0; j < K; j++) fw2_checked<LONG>(T, dummy, lp[j], lq[j], FW2_EL(X, j), FW2_EL(C, j), tail);
+    for (int j = 0; j < K; j++) fw2_checked<LONG>(T, k1v, dummy, lp[j], lq[j], FW2_EL(X, j), FW2_EL(C, j), tail);
     if (DX > 0) {
       rotate_reg<false>(lp[K - 1], lq[K - 1], FW2_EL(C, K - 1));
       const int ip = lp[K - 1], iq = lq[K - 1];
@@ -233,7 +242,7 @@ struct Fw2Wave {
 #pragma unroll
       for (int w = 0; w < KW; w++) {
         const int r0 = (((2 * w + 0 - k * DX) % K) + K) % K, r1 = (((2 * w + 1 - k * DX) % K) + K) % K;
-        fw2_plain_word(T, one, lp[r0], lq[r0], lp[r1], lq[r1], v[k][w], X[w]);
+        fw2_plain_word(T, k1v, one, lp[r0], lq[r0], lp[r1], lq[r1], v[k][w], X[w]);
       }
       if (DX > 0) {
         const int r = (((K - 1 - k) % K) + K) % K;
@@ -252,7 +261,7 @@ struct Fw2Wave {
   __device__ __forceinline__ unsigned margin() {
     unsigned m = 0;
 #pragma unroll
-    for (int j = 0; j < K; j++) m = max(m, (unsigned)(lq[j] - lp[j] - T.K1));
+    for (int j = 0; j < K; j++) m = max(m, (unsigned)(lq[j] - lp[j] - k1v));
     return m;
   }
   __device__ __forceinline__ void calm_padding() {
@@ -261,14 +270,14 @@ struct Fw2Wave {
     for (int j = 0; j < K; j++)
       if ((calm[j >> 1] >> (16 * (j & 1))) & 0xffffu) {
         lp[j] = 0;
-        lq[j] = T.K1;
+        lq[j] = k1v;
       }
   }
   // lines inside a stretch of voxels outside the ROI (and dead lines): the stretch is no run, its "length" restarts
   __device__ __forceinline__ void calm_level0() {
 #pragma unroll
     for (int j = 0; j < K; j++)
-      if (lp[j] < T.S) lq[j] = T.K1;
+      if (lp[j] < T.S) lq[j] = k1v;
   }
   __device__ __forceinline__ bool any_alive() {
     u32 X[KW];
@@ -396,13 +405,14 @@ __device__ __forceinline__ void fw2_flush(const u32 *lds, const Fw2Tab &T, int s
   const int nl = min(T.RS2, T.Nr);
   for (int i = threadIdx.x; i < Ng * nl; i += blockDim.x) {
     const int p = i / nl, l = i - p * nl;
-    const u32 v = lds[(size_t)(p + 1) * T.S4 + Ng + 1 + l];
+    u32 v = 0;
+    for (int cp = 0; cp < T.C; cp++) v += lds[(size_t)(p + 1) * T.S4 + Ng + 1 + cp * T.RS2 + l];
     if (v) atomicAdd(rd + (size_t)p * T.Nr + l, v);
   }
 }
 
 template <bool LONG, int K, bool HASPAD>
-__global__ void __launch_bounds__(1024) sweep_fw2_kernel(FwSet set, const uint8_t *__restrict__ L, int Ng, int Nr, int RS2,
+__global__ void __launch_bounds__(1024) sweep_fw2_kernel(FwSet set, const uint8_t *__restrict__ L, int Ng, int Nr, int RS2, int C,
                                                          u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
                                                          int *__restrict__ work, int *__restrict__ flags) {
   extern __shared__ u32 lds[];
@@ -414,12 +424,12 @@ __global__ void __launch_bounds__(1024) sweep_fw2_kernel(FwSet set, const uint8_
   int role = 0;
   while (role + 1 < set.count && (int)blockIdx.x >= set.first_block[role + 1]) role++;
   const int bx = (int)blockIdx.x - set.first_block[role], nblocks = set.first_block[role + 1] - set.first_block[role];
-  const int words = (int)fw2_table_words(Ng, RS2);
+  const int words = (int)fw2_table_words(Ng, RS2, C);
   for (int i = threadIdx.x; i < words; i += blockDim.x) lds[i] = 0;
   __syncthreads();
   const FwDesc &D = set.d[role];
   Fw2Tab T;
-  T.init(Ng, RS2, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
+  T.init(Ng, RS2, C, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
   int *wk = work + PRAD_FW_WORK_STRIDE * role;
   if (D.dx == 0) {
     Fw2Wave<LONG, K, 0, HASPAD> w(T, set.NX);

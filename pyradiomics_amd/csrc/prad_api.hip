@@ -273,6 +273,7 @@ struct SweepPlan {
   // two-table fixed-window kernel (kernels_sweepfw2.h): 45+ grey levels
   bool fw2 = false;
   int RS2 = 0;                 // run-length slots per level row
+  int fw2_copies = 1;          // copies of the run-length slots in a row (lane l uses copy l mod copies)
   bool LONGfw2 = false;
   size_t lds_fw2 = 0;
   int pitch16 = 0;             // bytes per row of the 16-bit level volume
@@ -332,17 +333,31 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
   // window covers, a level row [Ng + 1 pairs | RS2 lengths] table within the LDS, and the rows kernel (separate tables, here
   // with up to 100 KB for them) for the angle along x
   if (want_glcm && want_glrlm && !p.fused && Ng >= 40 && p.Nx > 64 && p.Nx <= 512 && !getenv("PRAD_NO_FW2")) {
+    // run-length slots per level row and copies of them (lane l adds to copy l mod C): as many copies as leave >= 32 slots
+    // (or every length), slots capped at 64 -- longer runs take the checked path, and empty slots cost zeroing and flushing
     const long long maxwords = (158 * 1024) / 4;
-    long long rs2 = maxwords / (Ng + 1) - (Ng + 1);
+    const long long room = maxwords / (Ng + 1) - (Ng + 1);
+    int copies = 1;
+    long long rs2 = std::min<long long>(room, Nr);
+    for (int cc = 8; cc >= 2; cc >>= 1)
+      if (room / cc >= std::min<long long>(32, Nr)) {
+        copies = cc;
+        rs2 = std::min<long long>(std::min<long long>(room / cc, 64), Nr);
+        break;
+      }
+    if (const char *e = getenv("PRAD_FW2_COPIES")) {   // tuning override
+      copies = std::max(1, std::min(8, atoi(e)));
+      rs2 = std::min<long long>(std::min<long long>(room / copies, copies > 1 ? 64 : Nr), Nr);
+    }
     if (const char *e = getenv("PRAD_FW2_RS")) rs2 = std::min<long long>(rs2, atoll(e));   // tuning override
-    rs2 = std::min<long long>(rs2, Nr);
-    if (rs2 < Nr && ((Ng + 1 + rs2) & 1) == 0) rs2--;      // odd row stride: consecutive levels on different banks
+    if (rs2 < Nr && ((Ng + 1 + copies * rs2) & 1) == 0) rs2--;      // odd row stride: consecutive levels on different banks
     const int rsr = fit_rs(true, true, false, Ng, Nr, 116 * 1024);   // (+ 40 KB of staging tiles: within the 160 KB)
     if ((rs2 >= 24 || rs2 >= Nr) && rs2 >= 1 && rsr >= std::min(Nr, 4)) {
       p.fw2 = true;
       p.RS2 = (int)rs2;
       p.LONGfw2 = rs2 < Nr;
-      p.lds_fw2 = 4 * fw2_table_words(Ng, p.RS2);
+      p.fw2_copies = copies;
+      p.lds_fw2 = 4 * fw2_table_words(Ng, p.RS2, copies);
       p.RS = 0;
       p.RSr = rsr;
     }
@@ -572,12 +587,12 @@ int launch_fw2_k(Call &k, const SweepPlan &p, const uint8_t *levels16, int Ng, i
     PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw2_kernel<LNG, K, true>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw2));
     hipLaunchKernelGGL((sweep_fw2_kernel<LNG, K, true>), dim3(p.fw_blocks), dim3(1024), p.lds_fw2, k.s, p.fwset, levels16, Ng, Nr,
-                       p.RS2, glcm_acc, glrlm_acc, work, flags_d);
+                       p.RS2, p.fw2_copies, glcm_acc, glrlm_acc, work, flags_d);
   } else {
     PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw2_kernel<LNG, K, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw2));
     hipLaunchKernelGGL((sweep_fw2_kernel<LNG, K, false>), dim3(p.fw_blocks), dim3(1024), p.lds_fw2, k.s, p.fwset, levels16, Ng, Nr,
-                       p.RS2, glcm_acc, glrlm_acc, work, flags_d);
+                       p.RS2, p.fw2_copies, glcm_acc, glrlm_acc, work, flags_d);
   }
   return check_launch("sweep_fw2_kernel");
 }
