@@ -113,7 +113,9 @@ __global__ void __launch_bounds__(256) roi_minmax_kernel(const T *__restrict__ x
 
 // LDS_EDGES: the edge list is staged in LDS (<= 7680 edges), otherwise it is searched in global memory (binWidth 1 on a
 // 0..30000 image: 30 000 edges, cache-resident).  COUNTS: 0 = none, 1 = per-wave private LDS tables of nedges + 1 words
-// (one pass gives levels AND the ROI voxels per level: grayLevels / Ns / the first-order histogram), 2 = global atomics.
+// (one pass gives levels AND the ROI voxels per level: grayLevels / Ns / the first-order histogram), 2 = global atomics,
+// 3 = a private table per THREAD, [level][thread] (<= 48 edges: the usual 16 - 32 grey levels; neighbouring voxels of a smooth
+// image share their level, so the lanes of a wave would hit one word of a per-wave table 64 times over).
 template <typename T, bool LDS_EDGES, int COUNTS>
 __global__ void __launch_bounds__(256) digitize_kernel(const T *__restrict__ x, const uint8_t *__restrict__ mask,
                                                        long long n, const double *__restrict__ edges, int nedges,
@@ -123,13 +125,15 @@ __global__ void __launch_bounds__(256) digitize_kernel(const T *__restrict__ x, 
   constexpr int E = 16 / (int)sizeof(T);
   const double *se = LDS_EDGES ? se_raw : edges;
   const int nb = nedges + 1;
-  unsigned int *cnt = reinterpret_cast<unsigned int *>(se_raw + (LDS_EDGES ? nedges : 0));   // [4][nb] when COUNTS == 1
+  unsigned int *cnt = reinterpret_cast<unsigned int *>(se_raw + (LDS_EDGES ? nedges : 0));   // [4][nb] (COUNTS == 1) / [nb][256] (3)
   if (LDS_EDGES)
     for (int i = threadIdx.x; i < nedges; i += blockDim.x) se_raw[i] = edges[i];
   if (COUNTS == 1)
     for (int i = threadIdx.x; i < 4 * nb; i += blockDim.x) cnt[i] = 0u;
-  if (LDS_EDGES || COUNTS == 1) __syncthreads();
-  unsigned int *mine = cnt + (threadIdx.x >> 6) * nb;
+  if (COUNTS == 3)
+    for (int i = threadIdx.x; i < 256 * nb; i += blockDim.x) cnt[i] = 0u;
+  if (LDS_EDGES || COUNTS == 1 || COUNTS == 3) __syncthreads();
+  unsigned int *mine = COUNTS == 3 ? cnt + threadIdx.x : cnt + (threadIdx.x >> 6) * nb;
   // number of edges <= v (np.digitize): the edges are (nearly) equidistant, so start from the arithmetic guess and let
   // the comparisons against the real edge values decide -- the same answer as a bisection, in ~2 reads instead of 6
   const double e0 = se[0];
@@ -147,6 +151,7 @@ __global__ void __launch_bounds__(256) digitize_kernel(const T *__restrict__ x, 
     top = max(top, k);
     if (COUNTS == 1) atomicAdd(mine + k, 1u);
     if (COUNTS == 2) atomicAdd(counts + k, 1ull);
+    if (COUNTS == 3) mine[k * 256] += 1u;          // (this thread's own word: bank = thread mod 32, no conflict)
     return k;
   };
   const bool aligned = (((uintptr_t)x) & 15) == 0 && (((uintptr_t)mask) & (E - 1)) == 0 && (((uintptr_t)levels) & 15) == 0;
@@ -171,6 +176,14 @@ __global__ void __launch_bounds__(256) digitize_kernel(const T *__restrict__ x, 
   if (threadIdx.x == 0) {
     top = max(max(stop[0], stop[1]), max(stop[2], stop[3]));
     if (top) atomicMax(maxlevel, top);
+  }
+  if (COUNTS == 3) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+      unsigned int v = 0;
+      for (int j = 0; j < 256; j++) v += cnt[i * 256 + ((j + i) & 255)];     // (rotated: the threads read different banks)
+      if (v) atomicAdd(counts + i, (unsigned long long)v);
+    }
   }
   if (COUNTS == 1) {   // (a block sees fewer than 2^32 voxels: 32-bit partial sums)
     for (int i = threadIdx.x; i < nb; i += blockDim.x) {

@@ -1694,13 +1694,15 @@ int launch_digitize(const T *image, const uint8_t *mask, long long n, const doub
   const bool lds_edges = edge_b <= 60 * 1024;
   // counts in LDS while edges + four private tables fit 64 KB (nedges <= 2 700), otherwise straight global atomics
   // (that many levels spread the atomics over as many addresses)
-  const int counts = !counts_d ? 0 : ((lds_edges && edge_b + cnt_b <= 64 * 1024) ? 1 : 2);
+  const size_t cnt3_b = 256 * sizeof(unsigned) * ((size_t)nedges + 1);     // a table per thread
+  const int counts = !counts_d ? 0 : (nedges <= 48 ? 3 : ((lds_edges && edge_b + cnt_b <= 64 * 1024) ? 1 : 2));
 #define PRAD_DIG(LE, CN)                                                                                              \
-  hipLaunchKernelGGL((digitize_kernel<T, LE, CN>), dim3(gx), dim3(256), (LE ? edge_b : 0) + (CN == 1 ? cnt_b : 0), s, image, \
-                     mask, n, e_d, nedges, levels, top, counts_d)
+  hipLaunchKernelGGL((digitize_kernel<T, LE, CN>), dim3(gx), dim3(256),                                               \
+                     (LE ? edge_b : 0) + (CN == 1 ? cnt_b : (CN == 3 ? cnt3_b : 0)), s, image, mask, n, e_d, nedges, levels, top, counts_d)
   if (lds_edges) {
     if (counts == 0) PRAD_DIG(true, 0);
     else if (counts == 1) PRAD_DIG(true, 1);
+    else if (counts == 3) PRAD_DIG(true, 3);
     else PRAD_DIG(true, 2);
   } else {
     if (counts == 0) PRAD_DIG(false, 0);
@@ -2170,8 +2172,13 @@ int prad_roi_minmax_dev(const void *image, int dtype, const uint8_t *mask, long 
   hipStream_t s = (hipStream_t)stream;
   unsigned long long *keys = nullptr;
   PRAD_TRY(c.get<unsigned long long>("minmax_keys", 2, &keys));
-  const unsigned long long init[2] = {~0ull, 0ull};
-  PRAD_HIP(hipMemcpyAsync(keys, init, sizeof(init), hipMemcpyHostToDevice, s));
+  // (pinned staging: a copy from / to pageable memory goes through the runtime's bounce buffer and blocks the host)
+  void *pin = nullptr;
+  PRAD_TRY(c.get_pinned("bin_pin", 4096, &pin));
+  unsigned long long *init = (unsigned long long *)pin, *outk = init + 2;
+  init[0] = ~0ull;
+  init[1] = 0ull;
+  PRAD_HIP(hipMemcpyAsync(keys, init, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
   const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 2048));
   switch (dtype) {
     case 0: hipLaunchKernelGGL(roi_minmax_kernel<float>, dim3(gx), dim3(256), 0, s, (const float *)image, mask, n, keys); break;
@@ -2181,12 +2188,11 @@ int prad_roi_minmax_dev(const void *image, int dtype, const uint8_t *mask, long 
     default: return fail(PRAD_E_ARG, "roi_minmax: dtype %d", dtype);
   }
   PRAD_TRY(check_launch("roi_minmax_kernel"));
-  unsigned long long out[2];
-  PRAD_HIP(hipMemcpyAsync(out, keys, sizeof(out), hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipMemcpyAsync(outk, keys, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
   PRAD_HIP(hipStreamSynchronize(s));
-  if (out[1] == 0ull) return fail(PRAD_E_ARG, "roi_minmax: empty ROI");
-  minmax[0] = f64_unkey(out[0]);
-  minmax[1] = f64_unkey(out[1]);
+  if (outk[1] == 0ull) return fail(PRAD_E_ARG, "roi_minmax: empty ROI");
+  minmax[0] = f64_unkey(outk[0]);
+  minmax[1] = f64_unkey(outk[1]);
   return PRAD_OK;
 }
 
@@ -2201,11 +2207,23 @@ int prad_digitize_counts_dev(const void *image, int dtype, const uint8_t *mask, 
   unsigned long long *cnt_d = nullptr;
   PRAD_TRY(c.get<double>("bin_edges", (size_t)nedges, &e_d));
   PRAD_TRY(c.get<int>("bin_top", 1, &top));
-  PRAD_HIP(hipMemcpyAsync(e_d, edges, sizeof(double) * nedges, hipMemcpyHostToDevice, s));
-  PRAD_HIP(hipMemsetAsync(top, 0, sizeof(int), s));
+  // host <-> device traffic of this call through one pinned block: [edges (nedges doubles) | top (8 B) | counts]
+  const size_t pin_bytes = sizeof(double) * ((size_t)nedges + 1) + sizeof(long long) * ((size_t)nedges + 2);
+  void *pin = nullptr;
+  PRAD_TRY(c.get_pinned("digitize_pin", pin_bytes, &pin));
+  double *e_h = (double *)pin;
+  int *top_h = (int *)(e_h + nedges);
+  long long *cnt_h = (long long *)(e_h + nedges + 1);
+  memcpy(e_h, edges, sizeof(double) * nedges);
+  PRAD_HIP(hipMemcpyAsync(e_d, e_h, sizeof(double) * nedges, hipMemcpyHostToDevice, s));
   if (counts) {
-    PRAD_TRY(c.get<unsigned long long>("bin_counts", (size_t)nedges + 1, &cnt_d));
-    PRAD_HIP(hipMemsetAsync(cnt_d, 0, sizeof(unsigned long long) * ((size_t)nedges + 1), s));
+    // counts and the level maximum sit in ONE device block [top | counts]: one memset, one copy back
+    PRAD_TRY(c.get<unsigned long long>("bin_counts", (size_t)nedges + 2, &cnt_d));
+    PRAD_HIP(hipMemsetAsync(cnt_d, 0, sizeof(unsigned long long) * ((size_t)nedges + 2), s));
+    top = (int *)cnt_d;
+    cnt_d += 1;
+  } else {
+    PRAD_HIP(hipMemsetAsync(top, 0, sizeof(int), s));
   }
   switch (dtype) {
     case 0: PRAD_TRY(launch_digitize((const float *)image, mask, n, e_d, nedges, levels, top, cnt_d, s)); break;
@@ -2214,11 +2232,14 @@ int prad_digitize_counts_dev(const void *image, int dtype, const uint8_t *mask, 
     case 3: PRAD_TRY(launch_digitize((const short *)image, mask, n, e_d, nedges, levels, top, cnt_d, s)); break;
     default: return fail(PRAD_E_ARG, "digitize: dtype %d", dtype);
   }
-  int t = 0;
-  PRAD_HIP(hipMemcpyAsync(&t, top, sizeof(int), hipMemcpyDeviceToHost, s));
-  if (counts) PRAD_HIP(hipMemcpyAsync(counts, cnt_d, sizeof(long long) * ((size_t)nedges + 1), hipMemcpyDeviceToHost, s));
+  if (counts) {
+    PRAD_HIP(hipMemcpyAsync(top_h, cnt_d - 1, sizeof(long long) * ((size_t)nedges + 2), hipMemcpyDeviceToHost, s));   // [top | counts]
+  } else {
+    PRAD_HIP(hipMemcpyAsync(top_h, top, sizeof(int), hipMemcpyDeviceToHost, s));
+  }
   PRAD_HIP(hipStreamSynchronize(s));
-  if (max_level) *max_level = t;
+  if (max_level) *max_level = *top_h;
+  if (counts) memcpy(counts, cnt_h, sizeof(long long) * ((size_t)nedges + 1));
   return PRAD_OK;
 }
 
