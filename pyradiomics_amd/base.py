@@ -131,11 +131,18 @@ class RadiomicsFeaturesBase:
         self.enabledFeatures = {}
         self.featureValues = {}
 
+    _feature_names_cache: dict = {}
+
     @classmethod
     def getFeatureNames(cls):
-        return {name[3:-12]: getattr(fn, "_is_deprecated", False)
-                for name, fn in inspect.getmembers(cls)
-                if name.startswith("get") and name.endswith("FeatureValue")}
+        """{feature name: deprecated?} (base.py:221-231); cached per class -- inspect.getmembers cost 3 ms per case"""
+        names = RadiomicsFeaturesBase._feature_names_cache.get(cls)
+        if names is None:
+            names = {name[3:-12]: getattr(fn, "_is_deprecated", False)
+                     for name, fn in inspect.getmembers(cls)
+                     if name.startswith("get") and name.endswith("FeatureValue")}
+            RadiomicsFeaturesBase._feature_names_cache[cls] = names
+        return dict(names)
 
     # -- execution (base.py:181-273) -----------------------------------------------------------------
     def execute(self):
