@@ -33,12 +33,15 @@ struct FwDesc {
   long long sM, sU;  // byte strides of the march and row dimensions in the packed volume
   int CL, pieces;    // march steps per piece (multiple of 8), pieces per walk
   int chunks;        // NU * pieces
+  int dom_kind;      // XCD-aware hand-out (FwSet::xcd): 0 = an XCD owns the pieces p = its id mod 8 (z-march roles: a piece is a
+                     // z-slab), 1 = it owns an eighth of the rows (y-march roles: a row is a z plane)
 };
 struct FwSet {
   int count;         // line angles (roles 0 .. count-1)
   int NX;
   int pitch;         // bytes per row of the packed volume (row r of rowzero[] starts at r * pitch)
   int nrows;         // rows of the packed volume
+  int xcd;           // 1: chunks are handed out per XCD (each XCD's L2 then serves ONE z-slab of the level volume to all roles)
   int first_block[PRAD_MAX_SWEEP + 1];   // role r owns workgroups [first_block[r], first_block[r + 1]) of the 1-D grid
   FwDesc d[PRAD_MAX_SWEEP];
 };
@@ -63,7 +66,8 @@ struct PackJob {
 };
 
 #define PRAD_FW_U 8
-#define PRAD_FW_WORK_STRIDE 64   // ints between the chunk counters of two angles (256 B: a line of their own)
+#define PRAD_FW_WORK_STRIDE 64   // ints between two chunk counters (256 B: a line of their own)
+#define PRAD_FW_DOMAINS 8        // chunk counters per role (one per XCD)
 // The whole layout of kernels_sweep.h (fused table H, long-run table G, dummies) sits Q = 4(Ng+1) bytes into the LDS,
 // because the run state kept here is s = level*P + len*Q with len counted from 1 (the exec-masked step adds Q to every
 // line after the event lanes took their fresh value, see fw_plain_word): the bin of an event is s + cur, as there.
@@ -507,7 +511,7 @@ struct FwWave {
   }
   __device__ __forceinline__ void run(const FwDesc &D, int NX, int pitch, long long nrows, const uint8_t *__restrict__ L,
                                       const uint8_t *__restrict__ rowzero, bool anyzero, int *work, int bx, int nblocks,
-                                      PackWave &pk, const PackJob &pj) {
+                                      PackWave &pk, const PackJob &pj, bool xcd) {
     const int NM = D.NM, NU = D.NU, du = D.du;
     const long long delta = D.sM + (long long)du * D.sU;
     // row numbers of the packed volume (rowzero[r] != 0: row r holds a voxel outside the ROI), wave-uniform like `off`
@@ -528,18 +532,63 @@ struct FwWave {
     // 512^3 -- walks of wrapping rows and of the window edges do not cost the same)
     const int nwaves = (int)(nblocks * (blockDim.x >> 6));      // waves of this role (bx = workgroup index within it)
     const int wid = __builtin_amdgcn_readfirstlane((int)(bx * (blockDim.x >> 6) + (threadIdx.x >> 6)));  // wave-uniform
-    const int static_rounds = 1;
+    // XCD-aware hand-out (xcd): the chunks of a role are split into 8 DOMAINS -- z-march roles by piece (= z-slab), y-march
+    // roles by row (= z plane) -- and a wave serves the domain of its own XCD first, the others once that one is empty.
+    // Every role then walks slab x of the level volume on XCD x at about the same time (chunks are handed out in the
+    // order of the row a line STARTS the piece on), and that XCD's L2 serves the slab to all 12 roles instead of every
+    // role streaming the whole volume through every L2.
+    int dom = 0, tried = 0;
+    const int ndom = xcd ? PRAD_FW_DOMAINS : 1;
+    if (xcd) {
+      int id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+      dom = id & (PRAD_FW_DOMAINS - 1);
+    }
     for (int it = 0;; it++) {
-      int chunk;
-      if (it < static_rounds) {
-        chunk = it * nwaves + wid;
+      int piece, u0;
+      if (!xcd) {
+        int chunk;
+        if (it == 0) {
+          chunk = wid;
+        } else {
+          int grabbed = 0;
+          if (lane == 0) grabbed = atomicAdd(work, 1);
+          chunk = nwaves + __builtin_amdgcn_readfirstlane(grabbed);
+        }
+        if (chunk >= D.chunks) break;
+        piece = chunk / NU;
+        u0 = chunk - piece * NU;  // piece-major: concurrent waves share planes
       } else {
+        // size of domain `dom`
+        int wd = NU, ulo = 0, np = 0;
+        if (D.dom_kind == 0) {
+          np = dom < D.pieces ? (D.pieces - dom + PRAD_FW_DOMAINS - 1) / PRAD_FW_DOMAINS : 0;
+        } else {
+          ulo = (int)((long long)NU * dom / PRAD_FW_DOMAINS);
+          wd = (int)((long long)NU * (dom + 1) / PRAD_FW_DOMAINS) - ulo;
+          np = D.pieces;
+        }
         int grabbed = 0;
-        if (lane == 0) grabbed = atomicAdd(work, 1);
-        chunk = static_rounds * nwaves + __builtin_amdgcn_readfirstlane(grabbed);
+        if (lane == 0) grabbed = atomicAdd(work + dom * PRAD_FW_WORK_STRIDE, 1);
+        const int i = __builtin_amdgcn_readfirstlane(grabbed);
+        if (i >= wd * np) {      // this domain is done: help the next one
+          if (++tried >= ndom) break;
+          dom = (dom + 1) & (PRAD_FW_DOMAINS - 1);
+          continue;
+        }
+        const int pi = i / wd, rs = ulo + (i - pi * wd);
+        if (D.dom_kind == 0) {
+          piece = dom + PRAD_FW_DOMAINS * pi;
+          // rs = the row the line is on HALFWAY through the piece (roles that drift up and roles that drift down then
+          // cover the same band of rows at the same time); its family index u0 = row at march step 0
+          long long u = ((long long)rs - ((long long)piece * D.CL + D.CL / 2) * du) % NU;
+          if (u < 0) u += NU;
+          u0 = (int)u;
+        } else {
+          piece = pi;
+          u0 = rs;
+        }
       }
-      if (chunk >= D.chunks) break;
-      const int piece = chunk / NU, u0 = chunk - piece * NU;  // piece-major: concurrent waves share planes
       const int t0 = piece * D.CL, t1 = min(NM, t0 + D.CL);
       int row = (int)((u0 + (long long)t0 * du) % NU);
       if (row < 0) row += NU;
@@ -835,16 +884,16 @@ __global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, PackJob pj, c
       const FwDesc &D = set.d[role];
       FwTab T;
       T.init(h, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
-      int *wk = work + PRAD_FW_WORK_STRIDE * role;
+      int *wk = work + PRAD_FW_WORK_STRIDE * PRAD_FW_DOMAINS * role;
       if (D.dx == 0) {
         FwWave<LONG, K, 0, HASPAD, PACK> w(T, set.NX);
-        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj);
+        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj, set.xcd != 0);
       } else if (D.dx > 0) {
         FwWave<LONG, K, 1, HASPAD, PACK> w(T, set.NX);
-        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj);
+        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj, set.xcd != 0);
       } else {
         FwWave<LONG, K, -1, HASPAD, PACK> w(T, set.NX);
-        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj);
+        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj, set.xcd != 0);
       }
       flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, D.slot, glcm_acc, glrlm_acc);
     }

@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(1024) sweep_fw2_kernel(FwSet set, const uint8_
   const FwDesc &D = set.d[role];
   Fw2Tab T;
   T.init(Ng, RS2, C, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
-  int *wk = work + PRAD_FW_WORK_STRIDE * role;
+  int *wk = work + PRAD_FW_WORK_STRIDE * PRAD_FW_DOMAINS * role;
   if (D.dx == 0) {
     Fw2Wave<LONG, K, 0, HASPAD> w(T, set.NX);
     w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks);

@@ -486,6 +486,9 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     if (const char *e = getenv("PRAD_FW_PER_WAVE")) per_wave = std::max(1, atoi(e));
     p.fwset.count = p.lines.count;
     p.fwset.NX = p.Nx;
+    // XCD-aware chunk hand-out (kernels_sweepfw.h): volumes whose level bytes outgrow one XCD's L2 several times over
+    p.fwset.xcd = (p.fw && (long long)p.Nz * p.Ny * p.pitch >= (32LL << 20) && p.Nz >= 64) ? 1 : 0;
+    if (const char *e = getenv("PRAD_FW_XCD")) p.fwset.xcd = p.fw && atoi(e) != 0;
     for (int i = 0; i < p.lines.count; i++) {
       const SweepDesc &S = p.lines.d[i];
       FwDesc &D = p.fwset.d[i];
@@ -502,6 +505,9 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
       int pieces = (int)std::max<long long>(1, (want + D.NU - 1) / D.NU);
       int CL = ((D.NM + pieces - 1) / pieces + 7) & ~7;
       CL = std::max(CL, D.NM >= 128 ? 64 : 16);   // (shorter pieces only multiply the piece start / tail overhead)
+      const bool march_z_role = S.sM >= S.sU && p.Nz > 1;
+      D.dom_kind = march_z_role ? 0 : 1;
+      if (p.fwset.xcd && march_z_role) CL = std::max(32, ((D.NM + PRAD_FW_DOMAINS - 1) / PRAD_FW_DOMAINS + 7) & ~7);   // a piece = an XCD's z-slab
       if (const char *e = getenv("PRAD_FW_CL")) CL = std::max(8, atoi(e) & ~7);
       D.CL = CL;
       D.pieces = (D.NM + CL - 1) / CL;
@@ -677,7 +683,7 @@ int vol_prepare(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, doubl
   }
   const size_t nglcm = glcm ? (size_t)k.Na * Ng * Ng : 0, nglrlm = glrlm ? (size_t)k.Na * Ng * Nr : 0;
   // accumulators, then per-angle "multi-element" flags, then per-role work counters of the lines kernels
-  const size_t nctl = 2 * PRAD_MAX_SWEEP + (size_t)PRAD_FW_WORK_STRIDE * (PRAD_MAX_SWEEP + 1);
+  const size_t nctl = 2 * PRAD_MAX_SWEEP + (size_t)PRAD_FW_WORK_STRIDE * (PRAD_FW_DOMAINS * PRAD_MAX_SWEEP + 1);
   PRAD_TRY(c.get<u32>("sweep_acc", nglcm + nglrlm + nctl, &v.acc));
   v.glcm_acc = v.acc;
   v.glrlm_acc = v.acc + nglcm;

@@ -1,0 +1,53 @@
+#!/bin/bash
+# round-3 evidence pack: rocprofv3 kernel stats of the bench command (pipeline mode: every launch of a step on ONE stream, so
+# the averages below ARE what bench.py's roofline block reports), PMC passes (separate, --kernel-trace only) and the counter
+# file bench.py reads (profiles/r03_counters.json).  Everything lands in gpurun_out/r03/ (copy the .md / .json to profiles/).
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r03
+rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+BA="--no-cpu-baseline --no-modes --no-host-boundary"
+{
+echo "# r03 -- rocprofv3 --kernel-trace --stats of bench.py (scripts/prof_r03.sh), final source of round 3"
+echo
+echo "Pipeline mode (default): the launches of a step sit on one stream; 'sweep_fw_kernel<..., true>' is the launch that walks the"
+echo "12 line angles of volume N-1 AND packs volume N (PACK = true); '<..., false>' are the synchronous calls and the flush."
+echo
+} > $O/kernel_stats.md
+for d in uniform smooth; do
+  rocprofv3 --kernel-trace --stats -d $O/stats_$d -o s -- python $R/bench.py --steps 20 --warmup 3 $BA --dist $d > $O/stats_$d.log 2>&1
+  { echo "## bench.py --steps 20 --warmup 3 --dist $d"; tail -1 $O/stats_$d.log | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*\|"rows_ms": [0-9.]*\|"pipeline_ms": [0-9.]*\|"finalize_ms": [0-9.]*' | tr '\n' ' '; echo; echo;
+    python $R/scripts/rocpd_stats.py $O/stats_$d/s_results.db | grep -E "prad|rocclr|kernel \||---"; echo; } >> $O/kernel_stats.md
+done
+rocprofv3 --kernel-trace --stats -d $O/stats_lanes -o s -- python $R/bench.py --steps 20 --warmup 3 $BA --deferred-mode lanes > $O/stats_lanes.log 2>&1
+{ echo "## bench.py --steps 20 --warmup 3 --deferred-mode lanes (two internal streams: launches overlap, durations are not kernel speeds)"; tail -1 $O/stats_lanes.log | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo; echo; python $R/scripts/rocpd_stats.py $O/stats_lanes/s_results.db | grep -E "prad|rocclr|kernel \||---"; echo; } >> $O/kernel_stats.md
+rocprofv3 --kernel-trace --stats -d $O/stats_256 -o s -- python $R/bench.py --steps 20 --warmup 3 $BA --size 256 > $O/stats_256.log 2>&1
+{ echo "## bench.py --size 256"; tail -1 $O/stats_256.log | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo; echo; python $R/scripts/rocpd_stats.py $O/stats_256/s_results.db | grep -E "prad|kernel \||---"; echo; } >> $O/kernel_stats.md
+rocprofv3 --kernel-trace --stats -d $O/stats_ng64 -o s -- python $R/bench.py --steps 20 --warmup 3 $BA --levels 64 > $O/stats_ng64.log 2>&1
+{ echo "## bench.py --levels 64 (two-table fixed-window kernel, 16-bit levels)"; tail -1 $O/stats_ng64.log | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo; echo; python $R/scripts/rocpd_stats.py $O/stats_ng64/s_results.db | grep -E "prad|kernel \||---"; echo; } >> $O/kernel_stats.md
+# PMC (separate passes, kernel-trace only)
+pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc/$name -o $name -- python $R/bench.py --steps 4 --warmup 2 $BA > $O/pmc_$name.log 2>&1; }
+pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU
+pass sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT
+pass tcc1 FETCH_SIZE
+pass tcc2 WRITE_SIZE
+pass grbm GRBM_GUI_ACTIVE
+python $R/scripts/pmc_summary.py $O/pmc > $O/pmc.md
+python - <<PY > $O/counters.json
+import csv, glob, json, collections
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$O/pmc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+def mean(k, c):
+    v = acc.get(k, {}).get(c, [])
+    return sum(v) / len(v) if v else None
+out = {"kernels": {k: {c: mean(k, c) for c in v} for k, v in acc.items() if "prad::" in k}}
+print(json.dumps(out, indent=1))
+PY
+cd $R
+find $O -name "*.db" -delete
+find $O -name "*.csv" -size +200k -delete
+du -sh $O
+cat $O/kernel_stats.md | head -60
