@@ -180,6 +180,182 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
   }
 }
 
+// The same pass without the float64 copy of the causal recursion (8 B written + 8 B read per sample: more than the images
+// themselves).  out[i] = causal[i] + anticausal[i] needs one of the two directions kept, but not sample by sample: sweep 1
+// runs the ANTI-causal recursion from the end of the line and keeps only its state (4 outputs) at every block boundary
+// (32 B per RB samples); sweep 2 walks forward block by block -- causal recursion into registers, then the anti-causal
+// one of the block RECOMPUTED downward from the saved state (same operations on the same operands: the same bits), sum,
+// store.  Traffic per sample: 4 (sweep 1) + 4 (sweep 2) read, 4 written, 2 x 32 / RB of states: 16 B at RB = 16 instead
+// of 36; 256^3: 94 -> see profiles (smoothing pass).  AM: 0 plain float output, 1 first Laplacian term (acc = v / sp2),
+// 2 later term (acc += v / sp2).
+#define PRAD_RG_RB 16
+template <int AM>
+__global__ void __launch_bounds__(256) rgauss_line2_kernel(const float *__restrict__ in, long long outer, int ln,
+                                                           long long inner, RGaussCoef c, double *__restrict__ states,
+                                                           float *__restrict__ out, float *__restrict__ acc, double sp2) {
+#pragma clang fp contract(off)  // ITK's line arithmetic is plain multiply / add; keep the same roundings
+  constexpr int RB = PRAD_RG_RB;
+  const long long lines = outer * inner;
+  const long long line = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (line >= lines) return;
+  const long long base = (line / inner) * ln * inner + (line % inner);
+  const float *d = in + base;
+  const long long st = inner;
+  // blocks [k RB, (k + 1) RB) for k < nb - 1; the last one takes the remainder, 4 .. RB + 3 samples (ln >= 4)
+  const int nb = (ln - 4) / RB + 1;
+  // state of boundary k (1 <= k < nb) = anticausal[k RB .. k RB + 3]: double index ((k - 1) * 4 + j) * lines + line
+  double *sp = states + line;
+  // ---- sweep 1: anti-causal, from the end, states only ----
+  {
+    const double v2 = d[(long long)(ln - 1) * st];
+    const double y1 = d[(long long)(ln - 2) * st], y2 = d[(long long)(ln - 3) * st];
+    double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-1
+    double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-2
+    double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-3
+    double a4 = y2 * c.M1 + y1 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-4
+    a1 -= v2 * c.BM1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+    a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+    a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
+    a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
+    double dp0 = d[(long long)(ln - 4) * st], dp1 = y2, dp2 = y1, dp3 = v2;  // data[i .. i+3] at i = ln-4
+    double q0 = a4, q1 = a3, q2 = a2, q3 = a1;                              // anticausal[i .. i+3]
+    int i = ln - 4;                // the next sample produced is i - 1
+    // (i is a boundary when i % RB == 0 and i >= RB: then q0..q3 = anticausal[i .. i+3] is the state of boundary i / RB)
+    while (i > 0) {
+      if ((i % RB) == 0) {
+        const long long k = i / RB - 1;
+        sp[(k * 4 + 0) * lines] = q0;
+        sp[(k * 4 + 1) * lines] = q1;
+        sp[(k * 4 + 2) * lines] = q2;
+        sp[(k * 4 + 3) * lines] = q3;
+      }
+      const int nstep = min(i, ((i - 1) % RB) + 1);    // down to the next boundary (or to 0)
+      if (nstep == RB) {
+        float buf[RB];
+#pragma unroll
+        for (int k = 0; k < RB; k++) buf[k] = d[(long long)(i - 1 - k) * st];
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
+          double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
+          v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
+          dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = buf[k];
+          q3 = q2; q2 = q1; q1 = q0; q0 = v;
+        }
+      } else {
+        for (int k = 0; k < nstep; k++) {
+          double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
+          v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
+          dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = d[(long long)(i - 1 - k) * st];
+          q3 = q2; q2 = q1; q1 = q0; q0 = v;
+        }
+      }
+      i -= nstep;
+    }
+  }
+  // ---- sweep 2: forward, block by block ----
+  double p1 = 0, p2 = 0, p3 = 0, p4 = 0;        // causal[b-1 .. b-4]
+  double dm1 = 0, dm2 = 0, dm3 = 0;             // data[b-1 .. b-3]
+  for (int kb = 0; kb < nb; kb++) {
+    const int b = kb * RB;
+    const bool lastblk = kb == nb - 1;
+    const int len = lastblk ? ln - b : RB;      // RB, or 4 .. RB + 3 for the last block
+    constexpr int RM = RB + 4;                  // samples held: the block and, for the anti-causal start, the 4 behind it
+    float dv[RM + 0];
+    double cv[RM];
+    // data of the block (+ the first 4 samples of the next block, which the anti-causal recursion starts from)
+#pragma unroll
+    for (int j = 0; j < RM; j++) {
+      const int idx = b + j;
+      dv[j] = idx < ln ? d[(long long)idx * st] : 0.f;
+    }
+    float ab[RM];
+    if (AM == 2) {
+#pragma unroll
+      for (int j = 0; j < RM; j++) ab[j] = (j < len) ? acc[base + (long long)(b + j) * st] : 0.f;
+    }
+    // causal recursion over the block
+    int j0 = 0;
+    if (kb == 0) {
+      const double v1 = dv[0];
+      const double x1 = dv[1], x2 = dv[2], x3 = dv[3];
+      double s0 = v1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+      double s1 = x1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+      double s2 = x2 * c.N0 + x1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+      double s3 = x3 * c.N0 + x2 * c.N1 + x1 * c.N2 + v1 * c.N3;
+      s0 -= v1 * c.BN1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
+      s1 -= s0 * c.D1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
+      s2 -= s1 * c.D1 + s0 * c.D2 + v1 * c.BN3 + v1 * c.BN4;
+      s3 -= s2 * c.D1 + s1 * c.D2 + s0 * c.D3 + v1 * c.BN4;
+      cv[0] = s0; cv[1] = s1; cv[2] = s2; cv[3] = s3;
+      dm1 = x3; dm2 = x2; dm3 = x1;
+      p1 = s3; p2 = s2; p3 = s1; p4 = s0;
+      j0 = 4;
+    }
+#pragma unroll
+    for (int j = 0; j < RM; j++) {
+      if (j >= j0 && j < len) {
+        const double di = dv[j];
+        double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
+        v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
+        cv[j] = v;
+        dm3 = dm2; dm2 = dm1; dm1 = di;
+        p4 = p3; p3 = p2; p2 = p1; p1 = v;
+      }
+    }
+    // anti-causal recursion of the block, downward, from the saved state (or from the end of the line)
+    double q0, q1, q2, q3, e0, e1, e2, e3;      // anticausal[i .. i+3], data[i .. i+3] at i = b + len
+    int jtop = len - 1;                         // block-local index of the first sample still to produce
+    if (lastblk) {
+      const double v2 = dv[len - 1], y1 = dv[len - 2], y2 = dv[len - 3];
+      double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+      double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+      double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+      double a4 = y2 * c.M1 + y1 * c.M2 + v2 * c.M3 + v2 * c.M4;
+      a1 -= v2 * c.BM1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+      a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+      a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
+      a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
+      // the four end samples are final here
+#pragma unroll
+      for (int j = 0; j < RM; j++) {
+        if (j == len - 1) cv[j] += a1;
+        if (j == len - 2) cv[j] += a2;
+        if (j == len - 3) cv[j] += a3;
+        if (j == len - 4) cv[j] += a4;
+      }
+      q0 = a4; q1 = a3; q2 = a2; q3 = a1;
+      e0 = dv[len - 4]; e1 = y2; e2 = y1; e3 = v2;
+      jtop = len - 5;
+    } else {
+      q0 = sp[((long long)kb * 4 + 0) * lines];
+      q1 = sp[((long long)kb * 4 + 1) * lines];
+      q2 = sp[((long long)kb * 4 + 2) * lines];
+      q3 = sp[((long long)kb * 4 + 3) * lines];
+      e0 = dv[RB]; e1 = dv[RB + 1]; e2 = dv[RB + 2]; e3 = dv[RB + 3];
+    }
+#pragma unroll
+    for (int jj = RM - 1; jj >= 0; jj--) {
+      if (jj <= jtop) {
+        double v = e0 * c.M1 + e1 * c.M2 + e2 * c.M3 + e3 * c.M4;
+        v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
+        cv[jj] += v;
+        e3 = e2; e2 = e1; e1 = e0; e0 = dv[jj];
+        q3 = q2; q2 = q1; q1 = q0; q0 = v;
+      }
+    }
+    // store
+#pragma unroll
+    for (int j = 0; j < RM; j++) {
+      if (j < len) {
+        const long long idx = base + (long long)(b + j) * st;
+        const float f = (float)cv[j];
+        if (AM == 0) out[idx] = f;
+        else acc[idx] = (float)((AM == 2 ? (double)ab[j] : 0.0) + (double)f / sp2);     // = rg_store
+      }
+    }
+  }
+}
+
 // The same recursion for the contiguous axis (inner == 1): a lane-per-line walk would read 64 different cache lines
 // per step.  One wave owns 64 consecutive lines and moves them through LDS in 64-sample tiles: every global access is
 // a 256-byte row segment, the lane then walks its own line inside the tile (pitch 65: conflict-free).  Causal tiles

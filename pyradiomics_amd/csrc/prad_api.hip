@@ -1648,6 +1648,15 @@ int log_dev(const float *in, const int *size, int Nd, const double *spacing, dou
           hipLaunchKernelGGL(rgauss_xline_kernel, dim3((unsigned)((lines + PRAD_RG_T - 1) / PRAD_RG_T)), dim3(64), 0, s, cur,
                              lines, g.size[ax], k, scratch, dst, acc, sp2, first ? 1 : 0);
           PRAD_TRY(check_launch("rgauss_xline_kernel"));
+        } else if (!getenv("PRAD_LOG_OLDLINE")) {   // strided axis: no float64 copy of the causal pass (kernels_filters.h)
+          const unsigned gx = (unsigned)((lines + 255) / 256);
+          if (!acc)
+            hipLaunchKernelGGL(rgauss_line2_kernel<0>, dim3(gx), dim3(256), 0, s, cur, outer, g.size[ax], inner, k, scratch, dst, acc, sp2);
+          else if (first)
+            hipLaunchKernelGGL(rgauss_line2_kernel<1>, dim3(gx), dim3(256), 0, s, cur, outer, g.size[ax], inner, k, scratch, dst, acc, sp2);
+          else
+            hipLaunchKernelGGL(rgauss_line2_kernel<2>, dim3(gx), dim3(256), 0, s, cur, outer, g.size[ax], inner, k, scratch, dst, acc, sp2);
+          PRAD_TRY(check_launch("rgauss_line2_kernel"));
         } else {
           if (accload)
             hipLaunchKernelGGL(rgauss_line_kernel<true>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, cur, outer,
