@@ -486,9 +486,10 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     if (const char *e = getenv("PRAD_FW_PER_WAVE")) per_wave = std::max(1, atoi(e));
     p.fwset.count = p.lines.count;
     p.fwset.NX = p.Nx;
-    // XCD-aware chunk hand-out (kernels_sweepfw.h): volumes whose level bytes outgrow one XCD's L2 several times over
-    p.fwset.xcd = (p.fw && (long long)p.Nz * p.Ny * p.pitch >= (32LL << 20) && p.Nz >= 64) ? 1 : 0;
-    if (const char *e = getenv("PRAD_FW_XCD")) p.fwset.xcd = p.fw && atoi(e) != 0;
+    // XCD-aware chunk hand-out (kernels_sweepfw.h): opt-in -- it takes the fabric reads of the level volume from 10.2 to 3.9
+    // per volume at 512^3 but its 8 shorter pieces cost 4 % of time (profiles/r03_probes.md), and time is the metric
+    p.fwset.xcd = 0;
+    if (const char *e = getenv("PRAD_FW_XCD")) p.fwset.xcd = (p.fw && p.Nz >= 64 && atoi(e) != 0) ? 1 : 0;
     for (int i = 0; i < p.lines.count; i++) {
       const SweepDesc &S = p.lines.d[i];
       FwDesc &D = p.fwset.d[i];

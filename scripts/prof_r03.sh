@@ -42,8 +42,22 @@ for f in glob.glob("$O/pmc/**/*counter_collection.csv", recursive=True):
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 def mean(k, c):
     v = acc.get(k, {}).get(c, [])
-    return sum(v) / len(v) if v else None
-out = {"kernels": {k: {c: mean(k, c) for c in v} for k, v in acc.items() if "prad::" in k}}
+    return sum(v) / len(v) if v else 0.0
+KiB = 1024.0
+fused, walk, rows = "prad::sweep_fw_kernel<true, 8, false, true>", "prad::sweep_fw_kernel<true, 8, false, false>", "prad::sweep_fw_rows_kernel<true>"
+# FETCH_SIZE calibration (guide, section HBM + profiles/r02b_ablation.md): 16 B/lane loads count half, the walk's 8 B/lane loads
+# 0.524 (one line angle alone reads the 134.2 MB level volume exactly once and reports 70.4 MB)
+walk_b = mean(walk, "FETCH_SIZE") * KiB / 0.524                     # the 12 line walks' reads of the level volume
+pack_b = max(0.0, mean(fused, "FETCH_SIZE") - mean(walk, "FETCH_SIZE")) * KiB * 2.0     # the side job's int32 + uint8 reads
+fused_w = mean(fused, "WRITE_SIZE") * KiB
+rows_b = mean(rows, "FETCH_SIZE") * KiB * 2.0 + mean(rows, "WRITE_SIZE") * KiB
+fin_b = sum((mean(k, "FETCH_SIZE") + mean(k, "WRITE_SIZE")) * KiB for k in ("prad::finalize_glcm_diag_kernel", "prad::finalize_glrlm_kernel", "prad::multi_check_kernel"))
+out = {"workload": [512, 32, "uniform"], "deferred_mode": "pipeline",
+       "bytes": round(walk_b + pack_b + fused_w + rows_b + fin_b), "kernel_bytes": round(walk_b + pack_b + fused_w),
+       "parts": {"walk_reads": round(walk_b), "pack_reads": round(pack_b), "fused_writes": round(fused_w), "rows_kernel": round(rows_b), "finalize": round(fin_b)},
+       "lds": mean(fused, "SQ_INSTS_LDS"), "valu": mean(fused, "SQ_INSTS_VALU"), "salu": mean(fused, "SQ_INSTS_SALU"),
+       "source": "profiles/r03_pmc.md (rocprofv3 --pmc passes over bench.py, scripts/prof_r03.sh; fabric bytes per volume in pipeline mode: "
+                 "walks + inline pack + x-angle kernel + finalize; kernel_bytes: the fused launch alone)"}
 print(json.dumps(out, indent=1))
 PY
 cd $R
