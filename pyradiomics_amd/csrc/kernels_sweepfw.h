@@ -217,6 +217,7 @@ __device__ __forceinline__ void fw_make_x(const u32 (&P)[K / 4], u32 (&X)[K / 4]
 }
 
 struct __attribute__((packed)) u64_unaligned { unsigned long long v; };
+struct __attribute__((packed)) u128_unaligned_fw { u32 a, b, c, d; };
 template <int KW>
 __device__ __forceinline__ void fw_load(const uint8_t *p, u32 (&v)[KW]) {
 #ifdef PRAD_DBG_NOLOAD  // ablation build: synthetic iid levels 1..32, no memory traffic
@@ -232,7 +233,13 @@ __device__ __forceinline__ void fw_load(const uint8_t *p, u32 (&v)[KW]) {
 #ifdef PRAD_DBG_L2ONLY  // ablation build: every read lands in the first MB of the volume (wrong results, L2-resident traffic)
   p = (const uint8_t *)((size_t)p & ~(size_t)0xFFFFFFF) + ((size_t)p & 0xFFFF8);
 #endif
-  if (KW == 2) {
+  if (KW == 4) {
+    const u128_unaligned_fw q = *reinterpret_cast<const u128_unaligned_fw *>(p);
+    v[0] = q.a;
+    v[KW > 1 ? 1 : 0] = q.b;
+    v[KW > 2 ? 2 : 0] = q.c;
+    v[KW - 1] = q.d;
+  } else if (KW == 2) {
     const unsigned long long q = reinterpret_cast<const u64_unaligned *>(p)->v;
     v[0] = (u32)q;
     v[KW - 1] = (u32)(q >> 32);
@@ -461,6 +468,13 @@ struct FwWave {
       if (DX < 0) rotate_reg<true>(pl[k % K], FW_BYTE(v[k], 0));
 #pragma unroll
       for (int w = 0; w < KW; w++) P[w] = v[k][w];
+    }
+    if (DX != 0 && (U % K) != 0) {   // K = 16: U steps leave the assignment rotated by U registers -- back to register j = column j
+      int tmp[K];
+#pragma unroll
+      for (int j = 0; j < K; j++) tmp[j] = pl[(((j - U * DX) % K) + K) % K];
+#pragma unroll
+      for (int j = 0; j < K; j++) pl[j] = tmp[j];
     }
   }
   // How far the lines of this lane are from needing the checked path, as the largest "bytes into the row" of any open

@@ -404,9 +404,10 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
   }
   p.vec_rows = (p.Nx % 16) == 0;
   // fixed-window kernel: needs the fused table and rows that one wave window (64 lanes x 4 or 8 columns) covers
-  p.fw = p.fused && p.Nx > 64 && p.Nx <= 512 && !getenv("PRAD_NO_FW");
+  p.fw = p.fused && p.Nx > 64 && p.Nx <= 1024 && !getenv("PRAD_NO_FW");
+  if (p.Nx > 512 && getenv("PRAD_NO_FW16")) p.fw = false;
   if (const char *e = getenv("PRAD_FW_MINVOX")) p.fw = p.fw && k.g.n >= atoll(e);
-  p.fwK = p.Nx <= 256 ? 4 : 8;
+  p.fwK = p.Nx <= 256 ? 4 : (p.Nx <= 512 ? 8 : 16);
   if (p.fw2) p.fwK = p.Nx <= 256 ? 4 : 8;
   p.padw = (p.fw || p.fw2) ? 0 : std::min(64 * p.LPL, p.Nx);
   p.pitch16 = 2 * ((p.Nx + 7) & ~7);
@@ -580,6 +581,9 @@ int launch_fw_k(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *l
 // the fixed-window launch of one volume: every line angle and, optionally, the pack of the NEXT volume as a side job
 int launch_fw(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels, const uint8_t *rowzero, int Ng, int Nr,
               u32 *glcm_acc, u32 *glrlm_acc, int *multi, int *flags_d) {
+  if (p.fwK == 16)   // rows of 513 .. 1024 voxels: 16 columns per lane
+    return p.LONGfw ? launch_fw_k<true, 16>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
+                    : launch_fw_k<false, 16>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
   if (p.LONGfw) return p.fwK == 4 ? launch_fw_k<true, 4>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
                                 : launch_fw_k<true, 8>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
   return p.fwK == 4 ? launch_fw_k<false, 4>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)

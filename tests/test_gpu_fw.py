@@ -124,6 +124,17 @@ def test_fw_matches_wrapped_lines_kernel(cm, monkeypatch):
     assert np.array_equal(g0, g1) and np.array_equal(r0, r1)
 
 
+@pytest.mark.parametrize("shape", [(10, 12, 1024), (12, 10, 600), (8, 14, 513), (14, 8, 1000), (20, 9, 768)])
+def test_fw_rows_of_513_to_1024_voxels(cm, checker, shape, monkeypatch):
+    """rows beyond one 512-column window: 16 columns per lane (K = 16); exact fill (1024), ragged, masks, long runs, pieces"""
+    from pyradiomics_amd import _lib
+    for kind, mkind in (("uniform", "full"), ("smooth", "ball"), ("blobs", "random"), ("flat", "full")):
+        _check(cm, checker, _levels(hash(shape) % 983, shape, 32, kind), _mask(5, shape, mkind), 32)
+        assert _lib.last_variant() == "fw"
+    monkeypatch.setenv("PRAD_FW_CL", "8")
+    _check(cm, checker, _levels(3, shape, 32, "smooth"), _mask(6, shape, "ball"), 32)
+
+
 @pytest.mark.parametrize("shape", [(24, 30, 512), (300, 12, 128), (12, 300, 72), (128, 128, 128)])
 @pytest.mark.parametrize("level", [11, 32])
 def test_fw_very_long_runs_of_high_levels(cm, checker, shape, level):
