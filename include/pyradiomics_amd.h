@@ -102,6 +102,21 @@ int prad_set_deferred_mode(int mode);      /* 1 pipeline, 0 lanes, -1 environmen
  * queued on `stream` may read the outputs of those calls; the levels verdict still needs prad_deferred_status */
 int prad_deferred_join(void *stream);
 int prad_deferred_status(void *stream);
+/* Result arena + enqueue-only feature calls (the case pipeline: every matrix and feature kernel of one derived image is
+ * queued before the host waits once).  prad_result_alloc hands out pinned host memory from a per-thread ring of 4 MiB
+ * (64-byte aligned; at most 1 MiB per allocation; an allocation stays untouched until 4 MiB more have been handed out).
+ * In deferred mode (prad_set_deferred(1)):
+ *  - prad_calculate_gldm_dev / prad_calculate_ngtdm_dev in segment mode only enqueue their kernels; a level outside
+ *    [1, Ng] under the mask is latched like the GLCM / GLRLM verdict (prad_deferred_status -> PRAD_E_DEFERRED);
+ *  - prad_glcm_features_dev, prad_zone_matrix_features_dev, prad_ngtdm_features_dev and prad_glcm_mcc_dev whose output
+ *    pointers lie INSIDE the arena enqueue their kernels and the device-to-host copies into those pointers and return:
+ *    the values are valid once the stream has been synchronised (prad_deferred_status, or an event recorded after the
+ *    call).  prad_glcm_mcc_dev then needs room for Na + 1 doubles: out[Na] != 0 says that more than 64 grey levels
+ *    occurred (the synchronous call's PRAD_E_UNSUPPORTED) and out[0..Na) is void.
+ * With outputs outside the arena these calls stay synchronous.  All calls of one pipeline go to ONE stream (the
+ * workspace buffers are recycled in stream order).  No reference analogue (the reference computes the formulas in numpy
+ * from host matrices: glcm.py, glrlm.py, ...). */
+int prad_result_alloc(size_t bytes, void **out);
 
 /* ---- angles: cmatrices.h get_angle_count / build_angles (cmatrices.c:756-892) ------------------- */
 /* returns the number of angles, 0 on invalid distance (as the reference) */

@@ -39,6 +39,7 @@ SYMBOLS = {
     "prad_set_lanes": (C.c_int, [C.c_int]),
     "prad_set_deferred_mode": (C.c_int, [C.c_int]),
     "prad_deferred_join": (C.c_int, [C.c_void_p]),
+    "prad_result_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "prad_deferred_status": (C.c_int, [C.c_void_p]),
     "prad_get_angle_count": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
     "prad_build_angles": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
@@ -133,6 +134,13 @@ def last_variant() -> str:
     return load().prad_last_variant().decode()
 
 
+PRAD_E_DEFERRED = -6
+
+
+class DeferredLevelsError(RuntimeError):
+    """prad_deferred_status: a deferred call met a level outside [1, Ng] under the mask (its outputs are void)"""
+
+
 def raise_for(rc: int, what: str) -> None:
     """Maps a C status to the exception the reference wrapper raises (_cmatrices.c:219,566,714,864...)."""
     if rc == PRAD_OK:
@@ -146,4 +154,6 @@ def raise_for(rc: int, what: str) -> None:
         raise ValueError(msg)
     if rc == PRAD_E_UNSUPPORTED:
         raise NotImplementedError(msg)
+    if rc == PRAD_E_DEFERRED:
+        raise DeferredLevelsError(msg)
     raise RuntimeError(msg)

@@ -202,6 +202,42 @@ class RadiomicsFeaturesBase:
             return None
         return [(True, n, vals[n]) for n in names]
 
+    # -- case pipeline: enqueue now, collect in execute() (no reference analogue) ---------------------------
+    def _segmentRoute(self):
+        """(class key, extra keyword arguments) of the fused segment route this class takes with its current settings,
+        None when it has none"""
+        return None
+
+    def enqueue(self):
+        """Queues this class's segment-mode device work -- matrix and feature kernels -- on the current stream without
+        waiting for it; execute() then only collects the values.  The caller synchronises in between through
+        cMatrices.segment_sync() and calls dropEnqueued() when that reports voided values.  Returns True when work was
+        enqueued (False: execute() computes as usual)."""
+        self._enqueued = None
+        fused = getattr(self.cMatrices, "segment_features_enqueue", None)
+        route = None if (self.voxelBased or not self.deviceResident or fused is None
+                         or not self.settings.get("fusedSegment", True)
+                         or not self.settings.get("enqueueSegment", True)) else self._segmentRoute()
+        if route is None or route[0] not in getattr(self.cMatrices, "ENQUEUE_CLASSES", ()):
+            return False
+        if len(self.enabledFeatures) == 0:
+            self.enableAllFeatures()
+        names = [n for n, on in self.enabledFeatures.items() if on]
+        if not names:
+            return False
+        try:
+            finish = fused(route[0], self.imageArray, self.maskArray, self.coefficients["Ng"], names,
+                           distances=self.settings.get("distances", [1]), force2D=self.settings.get("force2D", False),
+                           force2Ddimension=self.settings.get("force2Ddimension", 0), Ns=self.coefficients.get("Ns"),
+                           **route[1])
+        except NotImplementedError:
+            return False
+        self._enqueued = (tuple(names), finish)
+        return True
+
+    def dropEnqueued(self):
+        self._enqueued = None
+
     def _fusedSegmentFeatures(self, cls, host_only=(), **extra):
         """segment mode on the device-resident route: matrix AND feature formulas on the device when the operator
         backend offers it (only the feature values come back); None otherwise.  Features named in `host_only` (GLCM's
@@ -213,11 +249,15 @@ class RadiomicsFeaturesBase:
                 or not self.settings.get("fusedSegment", True)):
             return None
         dev_names = [n for n in names if n not in host_only]
+        queued, self._enqueued = getattr(self, "_enqueued", None), None
         try:
-            vals = fused(cls, self.imageArray, self.maskArray, self.coefficients["Ng"], dev_names,
-                         distances=self.settings.get("distances", [1]), force2D=self.settings.get("force2D", False),
-                         force2Ddimension=self.settings.get("force2Ddimension", 0), Ns=self.coefficients.get("Ns"),
-                         **extra) if dev_names else {}
+            if queued is not None and queued[0] == tuple(dev_names):
+                vals = queued[1]()
+            else:
+                vals = fused(cls, self.imageArray, self.maskArray, self.coefficients["Ng"], dev_names,
+                             distances=self.settings.get("distances", [1]), force2D=self.settings.get("force2D", False),
+                             force2Ddimension=self.settings.get("force2Ddimension", 0), Ns=self.coefficients.get("Ns"),
+                             **extra) if dev_names else {}
         except NotImplementedError:
             return None
         out = []

@@ -39,8 +39,23 @@ def _memo(image, mask):
     return memo
 
 
-def _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, want):
-    """distance-1 GLCM / GLRLM of device tensors through the fused sweep"""
+class _PairsRuns(dict):
+    """{"glcm_dev", "glrlm_dev", "angles"} + the host copies "glcm" / "glrlm" ([1, Ng, ., Na], the reference's layout),
+    made when somebody asks (the fused segment route never does: a 256^3 GLRLM is 0.8 MB per derived image)"""
+
+    def __missing__(self, key):
+        if key in ("glcm", "glrlm"):
+            dev = self[key + "_dev"]
+            val = None if dev is None else dev.cpu().numpy()[None]
+            self[key] = val
+            return val
+        raise KeyError(key)
+
+
+def _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, want, deferred=False):
+    """distance-1 GLCM / GLRLM of device tensors through the fused sweep.  deferred=True: the kernels are only enqueued
+    on the current stream (engine.glcm_glrlm(deferred=True) + deferred_join); engine.deferred_status() tells afterwards
+    whether the levels were inside [1, Ng]"""
     from . import engine
     f2d = int(force2Ddimension) if force2D else -1
     Nr = int(max(image.shape))
@@ -50,9 +65,11 @@ def _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, want):
         return memo[key]
     both = memo is not None
     g, r, angles = engine.glcm_glrlm(image, mask, int(Ng), Nr, force2D, force2Ddimension,
-                                     want_glcm=both or want == "glcm", want_glrlm=both or want == "glrlm")
-    res = {"glcm": None if g is None else g.cpu().numpy()[None], "glrlm": None if r is None else r.cpu().numpy()[None],
-           "angles": angles, "glcm_dev": g, "glrlm_dev": r}
+                                     want_glcm=both or want == "glcm", want_glrlm=both or want == "glrlm",
+                                     deferred=deferred)
+    if deferred:
+        engine.deferred_join()          # (pipeline mode: the walk of this volume is launched now, not by the next call)
+    res = _PairsRuns({"angles": angles, "glcm_dev": g, "glrlm_dev": r})
     if memo is not None:
         memo[key] = res
     return res
@@ -317,6 +334,31 @@ def segment_features(cls, image, mask, Ng, features, distances=(1,), force2D=Fal
     """-> {feature name: float} of feature class `cls` ("glcm" | "glrlm" | "glszm" | "gldm" | "ngtdm") in segment mode with the
     matrix AND the formulas on the device; image / mask are device tensors (discretised levels, ROI).
     Raises NotImplementedError for features outside the fused set (MCC, deprecated ones)."""
+    return segment_features_enqueue(cls, image, mask, Ng, features, distances, force2D, force2Ddimension, alpha,
+                                    symmetrical, Ns, deferred=False)()
+
+
+def segment_sync():
+    """waits for everything segment_features_enqueue queued on the current stream; False when a queued call met a level
+    outside [1, Ng] under the mask (the values are void: compute synchronously, which raises what the reference raises)"""
+    from . import engine, _lib
+    try:
+        engine.deferred_status()
+    except _lib.DeferredLevelsError:
+        return False
+    return True
+
+
+ENQUEUE_CLASSES = ("glcm", "glrlm", "gldm", "ngtdm")      # (GLSZM's zone list is sized on the host between its kernels)
+
+
+def segment_features_enqueue(cls, image, mask, Ng, features, distances=(1,), force2D=False, force2Ddimension=0, alpha=0,
+                             symmetrical=True, Ns=None, deferred=True):
+    """segment_features in two halves, for the case pipeline (featureextractor.computeFeatures): with deferred=True the
+    matrix and feature kernels of `cls` are only ENQUEUED on the current stream, their values land in the library's
+    result arena; the returned finish() -> {feature name: float} may be called once engine.deferred_status() has
+    synchronised the stream (and not raised: a level outside [1, Ng] voids the values).  GLSZM is computed inside
+    finish().  No reference analogue (the reference evaluates class after class on the host, base.py:181-198)."""
     from . import engine
     dist = [int(d) for d in np.asarray(distances).ravel()]
     if cls == "glcm":
@@ -328,39 +370,56 @@ def segment_features(cls, image, mask, Ng, features, distances=(1,), force2D=Fal
     missing = [f for f in features if f not in table]
     if missing:
         raise NotImplementedError("not available in the fused segment kernels: %s" % ", ".join(missing))
+    dfr = bool(deferred) and cls in ENQUEUE_CLASSES
+
+    def named(vals):
+        return {f: float(vals[table.index(f)]) for f in features}
+
+    def mean_of(pair):
+        return _angle_mean(pair[0], np.asarray(pair[1]) != 0)
+
     if cls == "glcm":
         if dist == [1]:
-            g = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glcm")["glcm_dev"]
+            g = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glcm", deferred=dfr)["glcm_dev"]
         else:
             g, _ = engine.glcm(image, mask, int(Ng), dist, force2D, force2Ddimension)
-        vals = _angle_mean(*engine.glcm_features(g, symmetrical)) if features else []
+        pair = engine.glcm_features(g, symmetrical, deferred=dfr) if features else None
+        mcc = None
         if want_mcc:
-            res = {f: float(vals[table.index(f)]) for f in features}
             try:     # (absent from the result when more than 64 grey levels occur: the caller's host route takes it)
-                with np.errstate(invalid="ignore"):
-                    import warnings
-                    with warnings.catch_warnings():
-                        warnings.simplefilter("ignore", RuntimeWarning)
-                        res["MCC"] = float(np.nanmean(engine.glcm_mcc(g, symmetrical)))
+                mcc = engine.glcm_mcc(g, symmetrical, deferred=dfr)
             except NotImplementedError:
-                pass
+                mcc = None
+
+        def finish():
+            res = named(mean_of(pair)) if features else {}
+            if mcc is not None and not (dfr and mcc[-1] != 0):
+                import warnings
+                with np.errstate(invalid="ignore"), warnings.catch_warnings():
+                    warnings.simplefilter("ignore", RuntimeWarning)
+                    res["MCC"] = float(np.nanmean(mcc[:-1] if dfr else mcc))
             return res
-    elif cls == "glrlm":
-        r = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glrlm")["glrlm_dev"]
-        vals = _angle_mean(*engine.zone_matrix_features(r, np.arange(1, r.shape[1] + 1)))
+        return finish
+    if cls == "glrlm":
+        r = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glrlm", deferred=dfr)["glrlm_dev"]
+        pair = engine.zone_matrix_features(r, np.arange(1, r.shape[1] + 1), deferred=dfr)
     elif cls == "gldm":
-        P = engine.gldm(image, mask, int(Ng), int(alpha), dist, force2D, force2Ddimension)
-        vals = _angle_mean(*engine.zone_matrix_features(P, np.arange(1, P.shape[1] + 1)))
+        P = engine.gldm(image, mask, int(Ng), int(alpha), dist, force2D, force2Ddimension, deferred=dfr)
+        pair = engine.zone_matrix_features(P, np.arange(1, P.shape[1] + 1), deferred=dfr)
     elif cls == "glszm":
-        P, sizes = engine.glszm_compact(image, mask, int(Ng), Ns, force2D, force2Ddimension)
-        if len(sizes) == 0:
-            raise NotImplementedError("no zones")
-        vals = _angle_mean(*engine.zone_matrix_features(P, sizes))
+        def finish():
+            P, sizes = engine.glszm_compact(image, mask, int(Ng), Ns, force2D, force2Ddimension)
+            if len(sizes) == 0:
+                raise NotImplementedError("no zones")
+            return named(mean_of(engine.zone_matrix_features(P, sizes)))
+        return finish
     elif cls == "ngtdm":
-        vals = engine.ngtdm_features(engine.ngtdm(image, mask, int(Ng), dist, force2D, force2Ddimension))
+        vals = engine.ngtdm_features(engine.ngtdm(image, mask, int(Ng), dist, force2D, force2Ddimension, deferred=dfr),
+                                     deferred=dfr)
+        return lambda: named(vals)
     else:
         raise NotImplementedError(cls)
-    return {f: float(vals[table.index(f)]) for f in features}
+    return lambda: named(mean_of(pair))
 
 
 # ---- first-order statistics (no native code in the reference: radiomics/firstorder.py is numpy; here the ROI /

@@ -218,10 +218,13 @@ __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel
   const double eps = PRAD_FEAT_EPS;
   double *pg = scratch + (size_t)a * (Ni + Nj), *pj = pg + Ni;
   auto P = [&](int i, int j) -> double { return counts[i * si + j * sj + a * sa]; };
-  for (int i = t; i < Ni; i += PRAD_FEAT_THREADS) {
+  // row sums: one wave per level row, lanes stride over the sizes, shuffle tree (a GLSZM row has thousands of columns:
+  // one thread per row was 100+ us of dependent loads); the order of the additions is fixed, so runs reproduce
+  for (int i = t >> 6; i < Ni; i += PRAD_FEAT_THREADS >> 6) {
     double s = 0;
-    for (int j = 0; j < Nj; j++) s += P(i, j);
-    pg[i] = s;
+    for (int j = t & 63; j < Nj; j += 64) s += P(i, j);
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((t & 63) == 0) pg[i] = s;
   }
   for (int j = t; j < Nj; j += PRAD_FEAT_THREADS) {
     double s = 0;

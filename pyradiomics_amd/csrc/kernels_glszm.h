@@ -1412,7 +1412,10 @@ __global__ void glszm_gather_zones_kernel(int nvox, int v, int count, const int 
 }
 
 // ---- host drivers --------------------------------------------------------------------------------
-inline unsigned glszm_grid(long long n) { return (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 8192)); }
+inline unsigned glszm_grid(long long n) {
+  static const int cap = getenv("PRAD_GLSZM_BLOCKS") ? atoi(getenv("PRAD_GLSZM_BLOCKS")) : 8192;
+  return (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, cap));
+}
 
 inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *image, const uint8_t *mask,
                        const int *angles_h, int Na, int Ng, int Ns, int Nvox, const int *voxels_dev, int kernelRadius,

@@ -103,7 +103,7 @@ __device__ __forceinline__ unsigned nonzero_bytes3(unsigned w) {  // bit 7 of ev
 }
 
 template <bool NGTDM>
-__global__ void __launch_bounds__(256) neigh4_kernel(RowMasks R, const uint8_t *__restrict__ L, int Nz, int Ny,
+__global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t *__restrict__ L, int Nz, int Ny,
                                                      int Nx, int zlo, int zhi, int Ng, int Na,
                                                      u32 *__restrict__ gldm_acc, u64 *__restrict__ ngtdm_acc,
                                                      const int *__restrict__ flags) {
@@ -120,13 +120,20 @@ __global__ void __launch_bounds__(256) neigh4_kernel(RowMasks R, const uint8_t *
   const int qpr = Nx >> 2;                      // quads per row
   const long long nquads = (long long)zhi * Ny * qpr;   // centres: planes zlo .. zhi-1
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long q = (long long)zlo * Ny * qpr + (long long)blockIdx.x * blockDim.x + threadIdx.x; q < nquads;
-       q += stride) {
-    const long long row = q / qpr;
-    const int x0 = (int)(q - row * qpr) << 2;
+  const int lane = threadIdx.x & 63;
+  // Consecutive lanes hold consecutive quads: the edge bytes x0-1 / x0+4 of a row ARE the last / first byte of the
+  // neighbour lanes' dword of that row (a quad at x0 = 0 / x0 + 4 = Nx has no such neighbour: 0), so only lane 0 / lane 63
+  // load theirs -- 9 dword loads per quad instead of 9 dwords + 18 bytes (the texture-address unit was the bound:
+  // see profiles/r03_probes.md).  Every lane of a wave runs the same trips (the shuffles need them all).
+  const long long q0 = (long long)zlo * Ny * qpr + (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+  for (long long qw = q0; qw < nquads; qw += stride) {
+    const long long q = qw + lane;
+    const bool live = q < nquads;
+    const long long row = live ? q / qpr : 0;
+    const int x0 = live ? (int)(q - row * qpr) << 2 : 0;
     const int z = (int)(row / Ny), y = (int)(row - (long long)z * Ny);
-    const unsigned centre = *reinterpret_cast<const unsigned *>(L + row * Nx + x0);
-    if (!centre) continue;                      // none of the 4 voxels is in the ROI
+    const unsigned centre = live ? *reinterpret_cast<const unsigned *>(L + row * Nx + x0) : 0u;
+    if (__ballot(centre != 0) == 0) continue;   // no ROI voxel in these 256 columns (wave-uniform)
     int sum[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};   // GLDM: cnt = dependence
     unsigned crep[4];
 #pragma unroll
@@ -136,11 +143,14 @@ __global__ void __launch_bounds__(256) neigh4_kernel(RowMasks R, const uint8_t *
       const unsigned wm = R.m[r];
       if (!wm) continue;
       const int zz = z + r / 3 - 1, yy = y + r % 3 - 1;
-      if ((unsigned)zz >= (unsigned)Nz || (unsigned)yy >= (unsigned)Ny) continue;   // row outside the volume: zeros
+      const bool in = live && (unsigned)zz < (unsigned)Nz && (unsigned)yy < (unsigned)Ny;   // row outside the volume: zeros
       const uint8_t *rp = L + ((long long)zz * Ny + yy) * Nx + x0;
-      const unsigned mid = *reinterpret_cast<const unsigned *>(rp);
-      const unsigned left = x0 > 0 ? rp[-1] : 0u;
-      const unsigned right = x0 + 4 < Nx ? rp[4] : 0u;
+      const unsigned mid = in ? *reinterpret_cast<const unsigned *>(rp) : 0u;
+      unsigned left = __shfl_up(mid >> 24, 1), right = __shfl_down(mid & 0xffu, 1);
+      if (lane == 0) left = (in && x0 > 0) ? rp[-1] : 0u;
+      if (lane == 63) right = (in && x0 + 4 < Nx) ? rp[4] : 0u;
+      if (x0 == 0) left = 0u;
+      if (x0 + 4 >= Nx) right = 0u;
       const unsigned lo = left | (mid << 8);          // bytes x0-1 .. x0+2
       const unsigned hi = (mid >> 24) | (right << 8); // bytes x0+3, x0+4
 #pragma unroll
@@ -294,8 +304,13 @@ inline int neigh_accumulate(Context *c, hipStream_t s, const Geo &g, const VoxMo
     RowMasks R;
     // the packed-byte path reads planes z-1 .. z+1 only where the row masks say so, all inside [plo, phi)
     if ((NGTDM || alpha == 0) && (p.Nx & 3) == 0 && row_masks_from(p.set, &R)) {
-      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((ncent >> 2) + 255) / 256, 8192));
-      hipLaunchKernelGGL((neigh4_kernel<NGTDM>), dim3(gx), dim3(256), lds, s, R, levels, p.Nz, p.Ny, p.Nx, zlo, zhi,
+      // 6 workgroups of 8 waves per CU: every workgroup flushes its [Ng][Na+1] table with global atomics, and with one
+      // workgroup per 1024 voxels (8192 of them on a 232^3 volume) those flushes -- ~1e6 atomics on 864 addresses -- were
+      // half of the kernel: 152 / 135 us (GLDM / NGTDM) -> 70 / 68 (profiles/r03_probes.md, section 10)
+      static const int cap = getenv("PRAD_NEIGH_BLOCKS") ? atoi(getenv("PRAD_NEIGH_BLOCKS")) : 1536;
+      static const int bt = getenv("PRAD_NEIGH_THREADS") ? atoi(getenv("PRAD_NEIGH_THREADS")) : 512;
+      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((ncent >> 2) + bt - 1) / bt, cap));
+      hipLaunchKernelGGL((neigh4_kernel<NGTDM>), dim3(gx), dim3(bt), lds, s, R, levels, p.Nz, p.Ny, p.Nx, zlo, zhi,
                          Ng, Na, acc32, acc64, flags_d);
       PRAD_TRY(check_launch("neigh4_kernel"));
     } else {

@@ -332,7 +332,9 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
   // Two-table fixed-window kernel for the line angles when the fused table does not fit (45+ levels): rows that one wave
   // window covers, a level row [Ng + 1 pairs | RS2 lengths] table within the LDS, and the rows kernel (separate tables, here
   // with up to 100 KB for them) for the angle along x
-  if (want_glcm && want_glrlm && !p.fused && Ng >= 40 && p.Nx > 64 && p.Nx <= 512 && !getenv("PRAD_NO_FW2")) {
+  const bool force_fw2 = getenv("PRAD_FORCE_FW2") != nullptr && Ng >= 8;   // experiment: the two-table kernel at any level count
+  if (force_fw2 && want_glcm && want_glrlm && p.Nx > 64 && p.Nx <= 512) p.fused = false;
+  if (want_glcm && want_glrlm && !p.fused && (Ng >= 40 || force_fw2) && p.Nx > 64 && p.Nx <= 512 && !getenv("PRAD_NO_FW2")) {
     // run-length slots per level row and copies of them (lane l adds to copy l mod C): as many copies as leave >= 32 slots
     // (or every length), slots capped at 64 -- longer runs take the checked path, and empty slots cost zeroing and flushing
     const long long maxwords = (158 * 1024) / 4;
@@ -807,6 +809,17 @@ __global__ void latch_flags_kernel(const int *__restrict__ flags, int *__restric
   if (flags[0] || flags[2]) sticky[0] = 1;
 }
 
+// deferred GLDM / NGTDM calls: any flag (levels outside [1, Ng] under the mask, a declined fast path) is a verdict to latch
+__global__ void latch_any_flag_kernel(const int *__restrict__ flags, int *__restrict__ sticky) {
+  if (flags[0] || flags[1] || flags[2]) sticky[0] = 1;
+}
+int latch_neigh(Context &c, Call &k) {
+  int *sticky = nullptr;
+  PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
+  hipLaunchKernelGGL(latch_any_flag_kernel, dim3(1), dim3(1), 0, k.s, (const int *)k.flags_d, sticky);
+  return check_launch("latch_any_flag_kernel");
+}
+
 // u32 accumulators -> float64 matrices in the reference layouts; `sticky` (deferred calls): latch the levels verdict
 int vol_finalize(Call &k, const VolState &v, int *sticky) {
   Context &c = *k.c;
@@ -1022,6 +1035,11 @@ int texture_gldm(const int32_t *image, const uint8_t *mask, const int *size, int
   PRAD_TRY(c.begin_call(s));
   bool done = false;
   PRAD_TRY(neigh_try_gldm(k.c, k.s, k.g, k.vm, k.image, k.mask, k.angles_h, k.Na, Ng, alpha, out, k.flags_d, &done));
+  if (done && c.deferred && !voxels) {   // enqueue only: the flags are latched for prad_deferred_status()
+    PRAD_TRY(latch_neigh(c, k));
+    c.last_path = "neigh";
+    return c.end_call(s);
+  }
   if (done) {
     PRAD_TRY(read_flags(k));
     done = (k.flags_h[0] == 0);
@@ -1049,6 +1067,11 @@ int texture_ngtdm(const int32_t *image, const uint8_t *mask, const int *size, in
   PRAD_TRY(c.begin_call(s));
   bool done = false;
   PRAD_TRY(neigh_try_ngtdm(k.c, k.s, k.g, k.vm, k.image, k.mask, k.angles_h, k.Na, Ng, out, k.flags_d, &done));
+  if (done && c.deferred && !voxels) {   // enqueue only: the flags are latched for prad_deferred_status()
+    PRAD_TRY(latch_neigh(c, k));
+    c.last_path = "neigh";
+    return c.end_call(s);
+  }
   if (done) {
     PRAD_TRY(read_flags(k));
     done = (k.flags_h[0] == 0);
@@ -1709,7 +1732,11 @@ namespace {
 template <typename T>
 int launch_digitize(const T *image, const uint8_t *mask, long long n, const double *e_d, int nedges, int32_t *levels,
                     int *top, unsigned long long *counts_d, hipStream_t s) {
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+  // 4 workgroups per CU: every workgroup ends with global atomics on the same few words (its maximum, its nb counters), and
+  // those serialise in L2 at ~25 ns each -- with 4096 workgroups they were half of the kernel (256^3 float64: 124 -> 57 us;
+  // roi_minmax 59 -> 35 with 512 instead of 2048; profiles/r03_probes.md, section 10)
+  static const int cap = getenv("PRAD_BIN_BLOCKS") ? atoi(getenv("PRAD_BIN_BLOCKS")) : 1024;
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, cap));
   const size_t edge_b = sizeof(double) * (size_t)nedges, cnt_b = 4 * sizeof(unsigned) * ((size_t)nedges + 1);
   const bool lds_edges = edge_b <= 60 * 1024;
   // counts in LDS while edges + four private tables fit 64 KB (nedges <= 2 700), otherwise straight global atomics
@@ -1874,6 +1901,12 @@ int prad_set_deferred_mode(int mode) {
   PRAD_TRY(c.lanes_sync());
   ps.mode = mode;
   return PRAD_OK;
+}
+int prad_result_alloc(size_t bytes, void **out) {
+  if (!out) return fail(PRAD_E_ARG, "result_alloc: out is NULL");
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  return c.arena_alloc(bytes, out);
 }
 int prad_deferred_join(void *stream) {
   Context &c = ctx();
@@ -2125,6 +2158,8 @@ int prad_voxel_glcm_features(const int32_t *image, const uint8_t *mask, const in
   return PRAD_OK;
 }
 
+__global__ void flag_to_double_kernel(const int *__restrict__ flag, double *__restrict__ out) { out[0] = flag[0] ? 1.0 : 0.0; }
+
 int prad_glcm_mcc_dev(const double *glcm, int Ng, int Na, int symmetric, double *out, void *stream) {
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
@@ -2138,7 +2173,7 @@ int prad_glcm_mcc_dev(const double *glcm, int Ng, int Na, int symmetric, double 
   hipStream_t s = (hipStream_t)stream;
   double *d_out = nullptr;
   int *d_flag = nullptr;
-  PRAD_TRY(c.get<double>("mcc_out", (size_t)Na, &d_out));
+  PRAD_TRY(c.get<double>("mcc_out", (size_t)Na + 1, &d_out));
   PRAD_TRY(c.get<int>("mcc_flag", 4, &d_flag));
   PRAD_HIP(hipMemsetAsync(d_flag, 0, sizeof(int) * 4, s));
   {
@@ -2148,10 +2183,21 @@ int prad_glcm_mcc_dev(const double *glcm, int Ng, int Na, int symmetric, double 
     hipLaunchKernelGGL(glcm_matrix_mcc_kernel, dim3(Na), dim3(PRAD_MCC_BT), lds, s, glcm, Ng, Na, symmetric, nmax, staged, d_out, d_flag);
     PRAD_TRY(check_launch("glcm_matrix_mcc_kernel"));
   }
-  int flag = 0;
-  PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * Na, hipMemcpyDeviceToHost, s));
-  PRAD_HIP(hipMemcpyAsync(&flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (c.deferred && c.in_arena(out, sizeof(double) * ((size_t)Na + 1))) {
+    // enqueue only: out[Na] tells afterwards whether more than PRAD_MCC_NMAX levels occurred (then out[0..Na) is void)
+    hipLaunchKernelGGL(flag_to_double_kernel, dim3(1), dim3(1), 0, s, (const int *)d_flag, d_out + Na);
+    PRAD_TRY(check_launch("flag_to_double_kernel"));
+    PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * ((size_t)Na + 1), hipMemcpyDeviceToHost, s));
+    return PRAD_OK;
+  }
+  void *pin = nullptr;
+  PRAD_TRY(c.get_pinned("mcc_pin", sizeof(double) * ((size_t)Na + 2), &pin));
+  hipLaunchKernelGGL(flag_to_double_kernel, dim3(1), dim3(1), 0, s, (const int *)d_flag, d_out + Na);
+  PRAD_TRY(check_launch("flag_to_double_kernel"));
+  PRAD_HIP(hipMemcpyAsync(pin, d_out, sizeof(double) * ((size_t)Na + 1), hipMemcpyDeviceToHost, s));
   PRAD_HIP(hipStreamSynchronize(s));
+  memcpy(out, pin, sizeof(double) * Na);
+  const int flag = ((const double *)pin)[Na] != 0.0;
   if (flag) return fail(PRAD_E_UNSUPPORTED, "glcm_mcc: more than %d grey levels occur; use the host route", PRAD_MCC_NMAX);
   return PRAD_OK;
 }
@@ -2199,7 +2245,8 @@ int prad_roi_minmax_dev(const void *image, int dtype, const uint8_t *mask, long 
   init[0] = ~0ull;
   init[1] = 0ull;
   PRAD_HIP(hipMemcpyAsync(keys, init, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 2048));
+  static const int cap = getenv("PRAD_MINMAX_BLOCKS") ? atoi(getenv("PRAD_MINMAX_BLOCKS")) : 512;
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, cap));
   switch (dtype) {
     case 0: hipLaunchKernelGGL(roi_minmax_kernel<float>, dim3(gx), dim3(256), 0, s, (const float *)image, mask, n, keys); break;
     case 1: hipLaunchKernelGGL(roi_minmax_kernel<double>, dim3(gx), dim3(256), 0, s, (const double *)image, mask, n, keys); break;
@@ -2279,7 +2326,7 @@ int prad_level_counts_dev(const int32_t *levels, const uint8_t *mask, long long 
   PRAD_TRY(c.get<unsigned long long>("level_counts", nb, &d));
   PRAD_HIP(hipMemsetAsync(d, 0, sizeof(unsigned long long) * nb, s));
   // per-block partial sums are 32-bit: a block sees at most n / grid voxels, bounded below 2^32 by the grid size
-  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096));
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, 1024));   // (flush atomics: see launch_digitize)
   const int use_lds = 4 * nb * sizeof(unsigned) <= 48 * 1024;
   hipLaunchKernelGGL(level_counts_kernel, dim3(gx), dim3(256), use_lds ? 4 * nb * sizeof(unsigned) : 0, s, levels, mask,
                      n, Ng, use_lds, d);

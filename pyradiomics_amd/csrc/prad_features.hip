@@ -12,19 +12,30 @@ extern "C" int prad_glcm_features_dev(const double *glcm, int Ng, int Na, int sy
   const size_t lds = sizeof(double) * ((size_t)5 * Ng + 4);
   if (lds > 60 * 1024) return fail(PRAD_E_UNSUPPORTED, "glcm_features: Ng=%d exceeds the LDS marginals", Ng);
   hipStream_t s = (hipStream_t)stream;
+  // values and "empty" flags in ONE device block and one copy into pinned memory (a copy into the caller's pageable array
+  // goes through the runtime's bounce buffer and blocks: 45 such calls per case were ~2 ms)
+  const size_t nout = (size_t)Na * GF_COUNT;
   double *d_out = nullptr;
-  int *d_empty = nullptr;
-  PRAD_TRY(c.get<double>("gf_out", (size_t)Na * GF_COUNT, &d_out));
-  PRAD_TRY(c.get<int>("gf_empty", (size_t)Na, &d_empty));
+  PRAD_TRY(c.get<double>("gf_out", nout + (size_t)(Na + 1) / 2 + 1, &d_out));
+  int *d_empty = reinterpret_cast<int *>(d_out + nout);
+  void *pin = nullptr;
+  PRAD_TRY(c.get_pinned("feat_pin", sizeof(double) * (nout + (size_t)Na + 2), &pin));
   {
     Timed t(c, "features", s);
     hipLaunchKernelGGL(glcm_matrix_features_kernel, dim3(Na), dim3(PRAD_FEAT_THREADS), lds, s, glcm, Ng, Na, symmetric,
                        d_out, d_empty);
     PRAD_TRY(check_launch("glcm_matrix_features_kernel"));
   }
-  PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * Na * GF_COUNT, hipMemcpyDeviceToHost, s));
-  PRAD_HIP(hipMemcpyAsync(empty, d_empty, sizeof(int) * Na, hipMemcpyDeviceToHost, s));
+  if (c.deferred && c.in_arena(out, sizeof(double) * nout) && c.in_arena(empty, sizeof(int) * Na)) {
+    // enqueue only (include/pyradiomics_amd.h, "result arena"): the values arrive with the stream
+    PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * nout, hipMemcpyDeviceToHost, s));
+    PRAD_HIP(hipMemcpyAsync(empty, d_empty, sizeof(int) * Na, hipMemcpyDeviceToHost, s));
+    return PRAD_OK;
+  }
+  PRAD_HIP(hipMemcpyAsync(pin, d_out, sizeof(double) * nout + sizeof(int) * Na, hipMemcpyDeviceToHost, s));
   PRAD_HIP(hipStreamSynchronize(s));
+  memcpy(out, pin, sizeof(double) * nout);
+  memcpy(empty, (const char *)pin + sizeof(double) * nout, sizeof(int) * Na);
   return PRAD_OK;
 }
 
@@ -35,22 +46,34 @@ extern "C" int prad_zone_matrix_features_dev(const double *P, int Ni, int Nj, in
   PRAD_TRY(c.ensure_device());
   if (!P || !jvals || !out || !empty || Ni < 1 || Nj < 1 || Na < 1) return fail(PRAD_E_ARG, "zone_features: bad arguments");
   hipStream_t s = (hipStream_t)stream;
+  const size_t nout = (size_t)Na * ZM_COUNT;
   double *d_out = nullptr, *d_j = nullptr, *d_scr = nullptr;
-  int *d_empty = nullptr;
-  PRAD_TRY(c.get<double>("zf_out", (size_t)Na * ZM_COUNT, &d_out));
-  PRAD_TRY(c.get<int>("zf_empty", (size_t)Na, &d_empty));
+  PRAD_TRY(c.get<double>("zf_out", nout + (size_t)(Na + 1) / 2 + 1, &d_out));
+  int *d_empty = reinterpret_cast<int *>(d_out + nout);
   PRAD_TRY(c.get<double>("zf_jvals", (size_t)Nj, &d_j));
   PRAD_TRY(c.get<double>("zf_scratch", (size_t)Na * ((size_t)Ni + Nj), &d_scr));
-  PRAD_HIP(hipMemcpyAsync(d_j, jvals, sizeof(double) * Nj, hipMemcpyHostToDevice, s));
+  const bool enq = c.deferred && c.in_arena(out, sizeof(double) * nout) && c.in_arena(empty, sizeof(int) * Na);
+  void *pin = nullptr;        // [jvals in | values + flags out], pinned (see prad_glcm_features_dev)
+  if (enq) PRAD_TRY(c.arena_alloc(sizeof(double) * (size_t)Nj, &pin));   // (a staging slot nobody rewrites before the copy ran)
+  else PRAD_TRY(c.get_pinned("zfeat_pin", sizeof(double) * ((size_t)Nj + nout + (size_t)Na + 2), &pin));
+  double *pj = (double *)pin, *pout = pj + Nj;
+  memcpy(pj, jvals, sizeof(double) * Nj);
+  PRAD_HIP(hipMemcpyAsync(d_j, pj, sizeof(double) * Nj, hipMemcpyHostToDevice, s));
   {
     Timed t(c, "features", s);
     hipLaunchKernelGGL(zone_matrix_features_kernel, dim3(Na), dim3(PRAD_FEAT_THREADS), 0, s, P, Ni, Nj, Na, stride_i,
                        stride_j, stride_a, d_j, d_scr, d_out, d_empty);
     PRAD_TRY(check_launch("zone_matrix_features_kernel"));
   }
-  PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * Na * ZM_COUNT, hipMemcpyDeviceToHost, s));
-  PRAD_HIP(hipMemcpyAsync(empty, d_empty, sizeof(int) * Na, hipMemcpyDeviceToHost, s));
+  if (enq) {
+    PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * nout, hipMemcpyDeviceToHost, s));
+    PRAD_HIP(hipMemcpyAsync(empty, d_empty, sizeof(int) * Na, hipMemcpyDeviceToHost, s));
+    return PRAD_OK;
+  }
+  PRAD_HIP(hipMemcpyAsync(pout, d_out, sizeof(double) * nout + sizeof(int) * Na, hipMemcpyDeviceToHost, s));
   PRAD_HIP(hipStreamSynchronize(s));
+  memcpy(out, pout, sizeof(double) * nout);
+  memcpy(empty, (const char *)pout + sizeof(double) * nout, sizeof(int) * Na);
   return PRAD_OK;
 }
 
@@ -68,7 +91,14 @@ extern "C" int prad_ngtdm_features_dev(const double *P, int Ng, double *out, voi
     hipLaunchKernelGGL(ngtdm_matrix_features_kernel, dim3(1), dim3(PRAD_FEAT_THREADS), lds, s, P, Ng, d_out);
     PRAD_TRY(check_launch("ngtdm_matrix_features_kernel"));
   }
-  PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * 5, hipMemcpyDeviceToHost, s));
+  if (c.deferred && c.in_arena(out, sizeof(double) * 5)) {
+    PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * 5, hipMemcpyDeviceToHost, s));
+    return PRAD_OK;
+  }
+  void *pin = nullptr;
+  PRAD_TRY(c.get_pinned("nfeat_pin", sizeof(double) * 8, &pin));
+  PRAD_HIP(hipMemcpyAsync(pin, d_out, sizeof(double) * 5, hipMemcpyDeviceToHost, s));
   PRAD_HIP(hipStreamSynchronize(s));
+  memcpy(out, pin, sizeof(double) * 5);
   return PRAD_OK;
 }

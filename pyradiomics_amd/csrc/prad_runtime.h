@@ -59,6 +59,7 @@ struct KernelTime {
 };
 
 #define PRAD_MAX_LANES 4
+#define PRAD_ARENA_BYTES (4u << 20)
 
 struct Context {
   int device = 0;
@@ -196,6 +197,33 @@ struct Context {
     }
     *out = b.p;
     return PRAD_OK;
+  }
+
+  // ---- result arena ------------------------------------------------------------------------
+  // Pinned host memory handed out as a ring (prad_result_alloc).  A feature call made in deferred mode whose output
+  // pointers lie inside the arena only ENQUEUES its kernels and its device-to-host copies: the values are there once
+  // the stream has been synchronised (prad_deferred_status).  The caller reads its results before it has allocated
+  // another PRAD_ARENA_BYTES (a 256^3 case of 9 derived images uses ~40 KB).
+  char *arena = nullptr;
+  size_t arena_pos = 0;
+  int arena_alloc(size_t bytes, void **out) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    if (bytes > PRAD_ARENA_BYTES / 4) return fail(PRAD_E_ARG, "result arena: %zu bytes in one allocation", bytes);
+    if (!arena) {
+      hipError_t e = hipHostMalloc((void **)&arena, PRAD_ARENA_BYTES, hipHostMallocDefault);
+      if (e != hipSuccess) {
+        arena = nullptr;
+        return fail(PRAD_E_NOMEM, "hipHostMalloc(%zu) for the result arena failed: %s", (size_t)PRAD_ARENA_BYTES, hipGetErrorString(e));
+      }
+    }
+    if (arena_pos + bytes > PRAD_ARENA_BYTES) arena_pos = 0;
+    *out = arena + arena_pos;
+    arena_pos += bytes;
+    return PRAD_OK;
+  }
+  bool in_arena(const void *p, size_t bytes) const {
+    const char *q = (const char *)p;
+    return arena && q >= arena && q + bytes <= arena + PRAD_ARENA_BYTES;
   }
 
   // ---- timing ------------------------------------------------------------------------------

@@ -41,6 +41,34 @@ def _prep(image: torch.Tensor, mask: torch.Tensor):
 _deferred_keep: list = []
 
 
+def result_array(shape, dtype) -> np.ndarray:
+    """numpy array over pinned memory of the library's result arena (prad_result_alloc): an enqueue-only feature call
+    (deferred=True below) copies its values into it asynchronously; read it after deferred_status() / a stream sync, and
+    before 4 MiB more have been allocated (include/pyradiomics_amd.h)"""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
+    p = C.c_void_p()
+    _lib.raise_for(_lib.load().prad_result_alloc(max(n, 1) * dt.itemsize, C.byref(p)), "result arena")
+    buf = (C.c_char * (max(n, 1) * dt.itemsize)).from_address(p.value)
+    return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+
+
+class _Deferred:
+    """`with _Deferred(lib, on):` -- the library's deferred mode around one call"""
+
+    def __init__(self, lib, on):
+        self.lib, self.on = lib, on
+
+    def __enter__(self):
+        if self.on:
+            _lib.raise_for(self.lib.prad_set_deferred(1), "deferred mode")
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.lib.prad_set_deferred(0)
+        return False
+
+
 def glcm_glrlm(image: torch.Tensor, mask: torch.Tensor, Ng: int, Nr: int | None = None, force2D: bool = False,
                force2Ddimension: int = 0, want_glcm: bool = True, want_glrlm: bool = True,
                out_glcm: torch.Tensor | None = None, out_glrlm: torch.Tensor | None = None, angles=None,
@@ -155,32 +183,44 @@ def glcm(image: torch.Tensor, mask: torch.Tensor, Ng: int, distances=(1,), force
     return out, angles
 
 
-def glcm_features(glcm: torch.Tensor, symmetric: bool = True):
+def glcm_features(glcm: torch.Tensor, symmetric: bool = True, deferred: bool = False):
     """the 23 sum-type GLCM features (order of cmatrices.VOXEL_GLCM_FEATURES) per angle from the raw device matrix
-    [Ng, Ng, Na]: (float64 numpy [Na, 23], bool numpy [Na] = angle empty)"""
+    [Ng, Ng, Na]: (float64 numpy [Na, 23], bool numpy [Na] = angle empty).
+    deferred=True only enqueues (kernel + copies into the result arena): returns (values, int32 flags != 0 = empty), both
+    valid after deferred_status() / a synchronisation of the current stream."""
     lib = _lib.load()
     glcm = glcm.contiguous()
     Ng, _, Na = glcm.shape
     lib.prad_set_device(glcm.device.index or 0)
-    out = np.empty((Na, 23), dtype=np.float64)
-    empty = np.empty(Na, dtype=np.intc)
-    rc = lib.prad_glcm_features_dev(C.c_void_p(glcm.data_ptr()), int(Ng), int(Na), 1 if symmetric else 0,
-                                    out.ctypes.data_as(C.POINTER(C.c_double)), _iptr(empty), _stream_ptr())
+    alloc = result_array if deferred else np.empty
+    out = alloc((Na, 23), np.float64)
+    empty = alloc((Na,), np.intc)
+    with _Deferred(lib, deferred):
+        rc = lib.prad_glcm_features_dev(C.c_void_p(glcm.data_ptr()), int(Ng), int(Na), 1 if symmetric else 0,
+                                        out.ctypes.data_as(C.POINTER(C.c_double)), _iptr(empty), _stream_ptr())
     _lib.raise_for(rc, "GLCM features")
+    if deferred:
+        _deferred_keep.append(glcm)
+        return out, empty
     return out, empty != 0
 
 
-def glcm_mcc(glcm: torch.Tensor, symmetric: bool = True):
+def glcm_mcc(glcm: torch.Tensor, symmetric: bool = True, deferred: bool = False):
     """per-angle MCC (glcm.py:665-707) from the raw device matrix [Ng, Ng, Na]: float64 numpy [Na], NaN for an angle
-    without pairs.  Raises NotImplementedError when more than 64 grey levels occur (host route)."""
+    without pairs.  Raises NotImplementedError when more than 64 grey levels occur (host route).
+    deferred=True only enqueues: returns float64 [Na + 1] in the result arena, valid after deferred_status(); its last
+    entry != 0 stands for that NotImplementedError (the values are void then)."""
     lib = _lib.load()
     glcm = glcm.contiguous()
     Ng, _, Na = glcm.shape
     lib.prad_set_device(glcm.device.index or 0)
-    out = np.empty(Na, dtype=np.float64)
-    rc = lib.prad_glcm_mcc_dev(C.c_void_p(glcm.data_ptr()), int(Ng), int(Na), 1 if symmetric else 0,
-                               out.ctypes.data_as(C.POINTER(C.c_double)), _stream_ptr())
+    out = result_array((Na + 1,), np.float64) if deferred else np.empty(Na, dtype=np.float64)
+    with _Deferred(lib, deferred):
+        rc = lib.prad_glcm_mcc_dev(C.c_void_p(glcm.data_ptr()), int(Ng), int(Na), 1 if symmetric else 0,
+                                   out.ctypes.data_as(C.POINTER(C.c_double)), _stream_ptr())
     _lib.raise_for(rc, "GLCM MCC")
+    if deferred:
+        _deferred_keep.append(glcm)
     return out
 
 
@@ -204,9 +244,10 @@ def voxel_glcm_mcc(image: torch.Tensor, mask: torch.Tensor, Ng: int, voxels: tor
     return out
 
 
-def zone_matrix_features(P: torch.Tensor, jvals):
+def zone_matrix_features(P: torch.Tensor, jvals, deferred: bool = False):
     """the 16 features GLRLM / GLSZM / GLDM share, per angle, from a device count matrix [Ni, Nj] or [Ni, Nj, Na] with
-    level values 1..Ni and size values `jvals` [Nj]: (float64 numpy [Na, 16], bool numpy [Na] = matrix empty)"""
+    level values 1..Ni and size values `jvals` [Nj]: (float64 numpy [Na, 16], bool numpy [Na] = matrix empty).
+    deferred=True: enqueue only, see glcm_features."""
     lib = _lib.load()
     if P.dim() == 2:
         P = P.unsqueeze(2)
@@ -216,24 +257,33 @@ def zone_matrix_features(P: torch.Tensor, jvals):
     jv = np.ascontiguousarray(jvals, dtype=np.float64)
     if jv.shape != (Nj,):
         raise ValueError("jvals must have one entry per column")
-    out = np.empty((Na, 16), dtype=np.float64)
-    empty = np.empty(Na, dtype=np.intc)
-    rc = lib.prad_zone_matrix_features_dev(C.c_void_p(P.data_ptr()), int(Ni), int(Nj), int(Na), int(si), int(sj), int(sa),
-                                           jv.ctypes.data_as(C.POINTER(C.c_double)),
-                                           out.ctypes.data_as(C.POINTER(C.c_double)), _iptr(empty), _stream_ptr())
+    alloc = result_array if deferred else np.empty
+    out = alloc((Na, 16), np.float64)
+    empty = alloc((Na,), np.intc)
+    with _Deferred(lib, deferred):
+        rc = lib.prad_zone_matrix_features_dev(C.c_void_p(P.data_ptr()), int(Ni), int(Nj), int(Na), int(si), int(sj),
+                                               int(sa), jv.ctypes.data_as(C.POINTER(C.c_double)),
+                                               out.ctypes.data_as(C.POINTER(C.c_double)), _iptr(empty), _stream_ptr())
     _lib.raise_for(rc, "zone matrix features")
+    if deferred:
+        _deferred_keep.append(P)
+        return out, empty
     return out, empty != 0
 
 
-def ngtdm_features(P: torch.Tensor) -> np.ndarray:
-    """Coarseness, Contrast, Busyness, Complexity, Strength from the device NGTDM [Ng, 3]"""
+def ngtdm_features(P: torch.Tensor, deferred: bool = False) -> np.ndarray:
+    """Coarseness, Contrast, Busyness, Complexity, Strength from the device NGTDM [Ng, 3] (deferred=True: enqueue only,
+    see glcm_features)"""
     lib = _lib.load()
     P = P.contiguous()
     lib.prad_set_device(P.device.index or 0)
-    out = np.empty(5, dtype=np.float64)
-    rc = lib.prad_ngtdm_features_dev(C.c_void_p(P.data_ptr()), int(P.shape[0]), out.ctypes.data_as(C.POINTER(C.c_double)),
-                                     _stream_ptr())
+    out = result_array((5,), np.float64) if deferred else np.empty(5, dtype=np.float64)
+    with _Deferred(lib, deferred):
+        rc = lib.prad_ngtdm_features_dev(C.c_void_p(P.data_ptr()), int(P.shape[0]),
+                                         out.ctypes.data_as(C.POINTER(C.c_double)), _stream_ptr())
     _lib.raise_for(rc, "NGTDM features")
+    if deferred:
+        _deferred_keep.append(P)
     return out
 
 
@@ -294,28 +344,35 @@ def _neigh_common(image, mask, distances, force2D, force2Ddimension):
 
 
 def gldm(image: torch.Tensor, mask: torch.Tensor, Ng: int, alpha: int = 0, distances=(1,), force2D: bool = False,
-         force2Ddimension: int = 0) -> torch.Tensor:
-    """GLDM [Ng, 2*Na+1] float64 on the device (segment mode)."""
+         force2Ddimension: int = 0, deferred: bool = False) -> torch.Tensor:
+    """GLDM [Ng, 2*Na+1] float64 on the device (segment mode).  deferred=True only enqueues the kernels: levels outside
+    [1, Ng] are reported by deferred_status() instead of an exception here."""
     lib, image, mask, size, f2d, angles = _neigh_common(image, mask, list(distances), force2D, force2Ddimension)
     Na, Nd = angles.shape
     out = torch.empty((Ng, 2 * Na + 1), dtype=torch.float64, device=image.device)
-    rc = lib.prad_calculate_gldm_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
-                                     _iptr(angles), Na, int(Ng), int(alpha), 1, None, 0, f2d,
-                                     C.c_void_p(out.data_ptr()), _stream_ptr())
+    with _Deferred(lib, deferred):
+        rc = lib.prad_calculate_gldm_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
+                                         _iptr(angles), Na, int(Ng), int(alpha), 1, None, 0, f2d,
+                                         C.c_void_p(out.data_ptr()), _stream_ptr())
     _lib.raise_for(rc, "GLDM")
+    if deferred:
+        _deferred_keep.append((image, mask, out))
     return out
 
 
 def ngtdm(image: torch.Tensor, mask: torch.Tensor, Ng: int, distances=(1,), force2D: bool = False,
-          force2Ddimension: int = 0) -> torch.Tensor:
-    """NGTDM [Ng, 3] float64 on the device (segment mode)."""
+          force2Ddimension: int = 0, deferred: bool = False) -> torch.Tensor:
+    """NGTDM [Ng, 3] float64 on the device (segment mode); deferred=True: see gldm."""
     lib, image, mask, size, f2d, angles = _neigh_common(image, mask, list(distances), force2D, force2Ddimension)
     Na, Nd = angles.shape
     out = torch.empty((Ng, 3), dtype=torch.float64, device=image.device)
-    rc = lib.prad_calculate_ngtdm_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
-                                      _iptr(angles), Na, int(Ng), 1, None, 0, f2d, C.c_void_p(out.data_ptr()),
-                                      _stream_ptr())
+    with _Deferred(lib, deferred):
+        rc = lib.prad_calculate_ngtdm_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
+                                          _iptr(angles), Na, int(Ng), 1, None, 0, f2d, C.c_void_p(out.data_ptr()),
+                                          _stream_ptr())
     _lib.raise_for(rc, "NGTDM")
+    if deferred:
+        _deferred_keep.append((image, mask, out))
     return out
 
 

@@ -266,12 +266,24 @@ class RadiomicsFeatureExtractor:
         """featureextractor.py:560-604"""
         out = collections.OrderedDict()
         classes = getFeatureClasses()
+        fcs = []
         for cname, fnames in self.enabledFeatures.items():
             if cname not in classes:
                 continue
             fc = classes[cname](image, mask, **kwargs)
             for f in fnames or []:
                 fc.enableFeatureByName(f)
-            for fname, value in fc.execute().items():
+            fcs.append((cname, fc))
+        # Case pipeline: the classes whose matrix AND formulas run on the device (GLCM, GLRLM, GLDM, NGTDM) queue all of
+        # their kernels first; the classes that talk to the host between their kernels (first order, GLSZM) run while
+        # that queue drains; then ONE wait and the queued values are collected.  The reference evaluates class after
+        # class (featureextractor.py:560-604), each with its own round trips.
+        queued = [fc for _, fc in fcs if fc.enqueue()]
+        values = {cname: fc.execute() for cname, fc in fcs if fc not in queued}
+        if queued and not queued[0].cMatrices.segment_sync():
+            for fc in queued:          # a level outside [1, Ng]: the synchronous route raises what the reference raises
+                fc.dropEnqueued()
+        for cname, fc in fcs:
+            for fname, value in (values[cname] if cname in values else fc.execute()).items():
                 out["%s_%s_%s" % (imageTypeName, cname, fname)] = value
         return out

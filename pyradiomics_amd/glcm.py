@@ -58,6 +58,9 @@ class RadiomicsGLCM(RadiomicsFeaturesBase):
         self.coefficients["px"] = self.P_glcm.sum(2, keepdims=True)
         self.coefficients["py"] = self.P_glcm.sum(1, keepdims=True)
 
+    def _segmentRoute(self):
+        return ("glcm", {"symmetrical": self.symmetricalGLCM}) if self.weightingNorm is None else None
+
     def _calculateFeatures(self, voxelCoordinates=None):
         """voxel mode: when the operator backend offers the fused kernel and it covers the request, feature maps
         come straight from the device (no (Nvox, Ng, Ng, Na) intermediate); otherwise the reference's route

@@ -21,6 +21,9 @@ class RadiomicsGLDM(_ZoneLikeFeatures):
     def _P(self):
         return self.P_gldm
 
+    def _segmentRoute(self):
+        return ("gldm", {"alpha": self.gldm_a})
+
     def _calculateFeatures(self, voxelCoordinates=None):
         fused = self._fusedVoxelFeatures("gldm", voxelCoordinates, self.gldm_a)
         if fused is None:

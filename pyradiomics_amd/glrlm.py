@@ -21,6 +21,9 @@ class RadiomicsGLRLM(RadiomicsFeaturesBase):
         self.P_glrlm = None
         self.imageArray = self._applyBinning(self.imageArray)
 
+    def _segmentRoute(self):
+        return ("glrlm", {}) if self.weightingNorm is None else None
+
     def _calculateFeatures(self, voxelCoordinates=None):
         fused = self._fusedVoxelFeatures("glrlm", voxelCoordinates) if self.weightingNorm is None else None
         if fused is None:

@@ -16,6 +16,9 @@ class RadiomicsNGTDM(RadiomicsFeaturesBase):
         self.P_ngtdm = None
         self.imageArray = self._applyBinning(self.imageArray)
 
+    def _segmentRoute(self):
+        return ("ngtdm", {})
+
     def _calculateFeatures(self, voxelCoordinates=None):
         fused = self._fusedVoxelFeatures("ngtdm", voxelCoordinates)
         if fused is None:

@@ -15,3 +15,4 @@ pr = cProfile.Profile(); pr.enable()
 ex.execute(Image(vol), Image(mask)); torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+pstats.Stats(pr).sort_stats("tottime").print_stats(40)

@@ -352,3 +352,49 @@ def test_light_voxel_glcm_kernel_equals_the_general_one(force2D, radius, symmetr
     for k in feats:
         np.testing.assert_allclose(light[k], gen[k], rtol=1e-12, atol=1e-13, equal_nan=True, err_msg=k)
     np.testing.assert_array_equal(one, light["JointEntropy"])
+
+
+@pytest.mark.gpu
+def test_case_pipeline_enqueue_equals_class_by_class():
+    """featureextractor.computeFeatures queues GLCM / GLRLM / GLDM / NGTDM before it waits once (prad_result_alloc +
+    enqueue-only feature calls); `enqueueSegment: False` evaluates class after class as the reference does
+    (featureextractor.py:560-604).  Same values, bit for bit."""
+    import torch
+    from pyradiomics_amd import engine
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(5)
+    N = 48
+    vol = (rng.normal(size=(N, N, N)).cumsum(0).cumsum(1) * 9).astype(np.int16)
+    zz, yy, xx = np.ogrid[:N, :N, :N]
+    mask = (((zz - 24) ** 2 + (yy - 22) ** 2 + (xx - 25) ** 2) < 19 ** 2).astype(np.int16)
+    res = {}
+    for on in (True, False):
+        ex = RadiomicsFeatureExtractor({"setting": {"binCount": 24, "additionalInfo": False, "enqueueSegment": on},
+                                        "imageType": {"Original": {}, "Wavelet": {}}})
+        res[on] = ex.execute(Image(vol), Image(mask))
+    assert list(res[True].keys()) == list(res[False].keys()) and len(res[True]) > 700
+    for k in res[True]:
+        a, b = np.asarray(res[True][k], dtype=float), np.asarray(res[False][k], dtype=float)
+        assert np.array_equal(a, b, equal_nan=True), k
+    # the enqueue-only calls themselves: values arrive in the arena with the stream
+    dev = torch.device("cuda", 0)
+    lev = torch.from_numpy(rng.integers(1, 17, size=(20, 24, 70)).astype(np.int32)).to(dev)
+    msk = torch.ones_like(lev, dtype=torch.uint8)
+    g, r, _ = engine.glcm_glrlm(lev, msk, 16)
+    want = engine.glcm_features(g), engine.zone_matrix_features(r, np.arange(1, r.shape[1] + 1)), engine.glcm_mcc(g)
+    got = (engine.glcm_features(g, deferred=True), engine.zone_matrix_features(r, np.arange(1, r.shape[1] + 1), deferred=True),
+           engine.glcm_mcc(g, deferred=True))
+    engine.deferred_status()
+    assert np.array_equal(got[0][0], want[0][0], equal_nan=True) and np.array_equal(got[0][1] != 0, want[0][1])
+    assert np.array_equal(got[1][0], want[1][0], equal_nan=True) and np.array_equal(got[1][1] != 0, want[1][1])
+    assert got[2][-1] == 0 and np.array_equal(got[2][:-1], want[2], equal_nan=True)
+    # a level outside [1, Ng] under the mask voids a queued GLDM / NGTDM call: reported by the status, not lost
+    bad = lev.clone()
+    bad[3, 4, 5] = 40
+    engine.gldm(bad, msk, 16, deferred=True)
+    with pytest.raises(RuntimeError):
+        engine.deferred_status()
+    engine.deferred_status()                      # (the flag was cleared)
+    with pytest.raises(IndexError):
+        engine.gldm(bad, msk, 16)
