@@ -117,6 +117,11 @@ int prad_deferred_status(void *stream);
  * workspace buffers are recycled in stream order).  No reference analogue (the reference computes the formulas in numpy
  * from host matrices: glcm.py, glrlm.py, ...). */
 int prad_result_alloc(size_t bytes, void **out);
+/* Workspace set of the calling thread (0 = default, 1..7): the library recycles named scratch buffers in stream order, so
+ * a thread that issues calls on a SECOND stream concurrently selects another set for them (and switches back).  The
+ * case pipeline queues its enqueue-only classes on a side stream under set 1 while first order / GLSZM run on the main
+ * stream under set 0. */
+int prad_set_workspace(int id);
 
 /* ---- angles: cmatrices.h get_angle_count / build_angles (cmatrices.c:756-892) ------------------- */
 /* returns the number of angles, 0 on invalid distance (as the reference) */

@@ -40,6 +40,7 @@ SYMBOLS = {
     "prad_set_deferred_mode": (C.c_int, [C.c_int]),
     "prad_deferred_join": (C.c_int, [C.c_void_p]),
     "prad_result_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "prad_set_workspace": (C.c_int, [C.c_int]),
     "prad_deferred_status": (C.c_int, [C.c_void_p]),
     "prad_get_angle_count": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
     "prad_build_angles": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),

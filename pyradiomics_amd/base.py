@@ -4,6 +4,7 @@ pyradiomics_amd.image.Image inputs.  Same constructor signature, same settings k
 from __future__ import annotations
 
 import inspect
+import os
 import logging
 import traceback
 
@@ -11,6 +12,9 @@ import numpy as np
 
 from . import backend, imageoperations
 from .image import Image, as_array, as_image
+
+
+_ENQUEUE_DEFAULT = os.environ.get("PRAD_ENQUEUE_SEGMENT", "1") != "0"     # (A/B switch of the case pipeline, see enqueue())
 
 
 def deprecated(func):
@@ -217,7 +221,7 @@ class RadiomicsFeaturesBase:
         fused = getattr(self.cMatrices, "segment_features_enqueue", None)
         route = None if (self.voxelBased or not self.deviceResident or fused is None
                          or not self.settings.get("fusedSegment", True)
-                         or not self.settings.get("enqueueSegment", True)) else self._segmentRoute()
+                         or not self.settings.get("enqueueSegment", _ENQUEUE_DEFAULT)) else self._segmentRoute()
         if route is None or route[0] not in getattr(self.cMatrices, "ENQUEUE_CLASSES", ()):
             return False
         if len(self.enabledFeatures) == 0:

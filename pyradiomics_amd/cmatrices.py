@@ -339,14 +339,22 @@ def segment_features(cls, image, mask, Ng, features, distances=(1,), force2D=Fal
 
 
 def segment_sync():
-    """waits for everything segment_features_enqueue queued on the current stream; False when a queued call met a level
+    """waits for everything segment_features_enqueue queued (inside segment_queue()); False when a queued call met a level
     outside [1, Ng] under the mask (the values are void: compute synchronously, which raises what the reference raises)"""
     from . import engine, _lib
     try:
-        engine.deferred_status()
+        with engine.side_queue(wait=False):
+            engine.deferred_status()
     except _lib.DeferredLevelsError:
         return False
     return True
+
+
+def segment_queue():
+    """context manager around the segment_features_enqueue calls of one derived image: they go to a side stream
+    (engine.side_queue) so that the classes evaluated synchronously meanwhile do not wait for them"""
+    from . import engine
+    return engine.side_queue()
 
 
 ENQUEUE_CLASSES = ("glcm", "glrlm", "gldm", "ngtdm")      # (GLSZM's zone list is sized on the host between its kernels)

@@ -91,6 +91,10 @@ struct Context {
   // issue-bound sweep of the previous one holds other CUs, launch gaps and kernel tails are filled (512^3: 0.63 ->
   // 0.56 ms per volume, 256^3: 0.167 -> 0.107).  Forcing the sweeps of the two lanes to run one after the other (only
   // the pack underneath) measured slower (0.60 ms).  lane = -1: the caller's stream and the plain workspace.
+  // Workspace set (prad_set_workspace): a caller that drives TWO streams from one thread -- the case pipeline queues the
+  // enqueue-only classes on a side stream while the classes that talk to the host run on the main one -- gives each
+  // stream its own set of workspace buffers, as the lanes do for the library's internal streams.
+  int workspace = 0;
   int lanes = 0;       // 0 = not configured yet (PRAD_LANES, default 2; 1 = off)
   int lane = -1;
   unsigned long long lane_seq = 0;
@@ -119,7 +123,10 @@ struct Context {
   // workspace key: buffers are per device and per lane, except the ones every lane shares ("deferred_*")
   std::string key(const char *name) const {
     std::string k(name);
-    if (lane >= 0 && k.compare(0, 9, "deferred_") != 0) k += "#" + std::to_string(lane);
+    if (k.compare(0, 9, "deferred_") != 0) {
+      if (lane >= 0) k += "#" + std::to_string(lane);
+      if (workspace) k += "~" + std::to_string(workspace);
+    }
     return k + "@" + std::to_string(device);
   }
   bool has(const char *name) const { return bufs.find(key(name)) != bufs.end(); }
@@ -183,7 +190,7 @@ struct Context {
     return rc;
   }
   int get_pinned(const char *name, size_t bytes, void **out) {
-    DevBuf &b = pinned[name];
+    DevBuf &b = pinned[workspace ? std::string(name) + "~" + std::to_string(workspace) : std::string(name)];
     if (b.cap < bytes) {
       if (b.p) (void)hipHostFree(b.p);
       b.p = nullptr;

@@ -53,6 +53,38 @@ def result_array(shape, dtype) -> np.ndarray:
     return np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
 
 
+_side_streams: dict = {}
+
+
+class side_queue:
+    """`with side_queue():` -- calls inside go to a side stream of the current device (one per host thread) that first
+    waits for everything queued on the current stream, under the library's workspace set 1 (prad_set_workspace): the case
+    pipeline queues GLCM / GLRLM / GLDM / NGTDM there while first order and GLSZM, which talk to the host between their
+    kernels, keep the main stream.  wait=False: enter the same stream without the dependency (to synchronise it)."""
+
+    def __init__(self, wait: bool = True):
+        self.wait = wait
+
+    def __enter__(self):
+        import threading
+        dev = torch.cuda.current_device()
+        key = (threading.get_ident(), dev)
+        s = _side_streams.get(key)
+        if s is None:
+            s = _side_streams[key] = torch.cuda.Stream(device=dev)
+        if self.wait:
+            s.wait_stream(torch.cuda.current_stream(dev))
+        self._ctx = torch.cuda.stream(s)
+        self._ctx.__enter__()
+        _lib.raise_for(_lib.load().prad_set_workspace(1), "workspace")
+        return s
+
+    def __exit__(self, *exc):
+        _lib.load().prad_set_workspace(0)
+        self._ctx.__exit__(*exc)
+        return False
+
+
 class _Deferred:
     """`with _Deferred(lib, on):` -- the library's deferred mode around one call"""
 

@@ -11,6 +11,7 @@ computing something else."""
 from __future__ import annotations
 
 import collections
+import contextlib
 import json
 import logging
 import os
@@ -278,7 +279,9 @@ class RadiomicsFeatureExtractor:
         # their kernels first; the classes that talk to the host between their kernels (first order, GLSZM) run while
         # that queue drains; then ONE wait and the queued values are collected.  The reference evaluates class after
         # class (featureextractor.py:560-604), each with its own round trips.
-        queued = [fc for _, fc in fcs if fc.enqueue()]
+        cm = fcs[0][1].cMatrices if fcs else None
+        with (cm.segment_queue() if hasattr(cm, "segment_queue") and fcs[0][1].deviceResident else contextlib.nullcontext()):
+            queued = [fc for _, fc in fcs if fc.enqueue()]
         values = {cname: fc.execute() for cname, fc in fcs if fc not in queued}
         if queued and not queued[0].cMatrices.segment_sync():
             for fc in queued:          # a level outside [1, Ng]: the synchronous route raises what the reference raises
