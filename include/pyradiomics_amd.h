@@ -307,6 +307,19 @@ int prad_voxel_texture_features_dev(int family, const int32_t *image, const uint
 int prad_glcm_features_dev(const double *glcm, int Ng, int Na, int symmetric, double *out, int *empty, void *stream);
 int prad_zone_matrix_features_dev(const double *P, int Ni, int Nj, int Na, long long stride_i, long long stride_j,
                                   long long stride_a, const double *jvals, double *out, int *empty, void *stream);
+/* prad_glszm_features_dev: the GLSZM of a segment (what prad_calculate_glszm_dev + prad_glszm_sizes +
+ *   prad_fill_glszm_compact_dev build, cmatrices.c:294-443 / glszm.py:108-131) AND its 16 features, without a host round
+ *   trip in between: zones, then the distinct zone sizes are ranked on the device, the compact matrix filled, the
+ *   formulas evaluated.  image / mask DEVICE, angles HOST int [Na][Nd] (the bidirectional distance-1 set), Ns = ROI
+ *   voxels.  out: float64 [17] -- the 16 features in the shared numbering, then a verdict: 0 = fine, bit 1 = the zone
+ *   list would overflow the reference's Ns-sized scratch (cmatrices.c:366-373), other bits = the device-side ranking
+ *   declined (levels outside 1..Ng, more than 4096 zones of 8192+ voxels); empty: int [1], 1 = no zone.
+ *   Needs the packed-byte tile kernels (Nd <= 3, full 26- / 8-neighbourhood, Ng <= 255): PRAD_E_UNSUPPORTED otherwise,
+ *   before anything is launched.  In deferred mode with out / empty inside the result arena: enqueue only, the caller
+ *   reads the verdict from out[16] after synchronising; otherwise synchronous, verdict bit 1 -> PRAD_E_INDEX, any other
+ *   bit -> PRAD_E_UNSUPPORTED (take the three-call route). */
+int prad_glszm_features_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                            int Ng, int Ns, double *out, int *empty, void *stream);
 /* NGTDM (ngtdm.py:133-287): P = DEVICE float64 [Ng][3] as prad_calculate_ngtdm_dev leaves it;
  * out: HOST float64 [5] = Coarseness, Contrast, Busyness, Complexity, Strength. */
 int prad_ngtdm_features_dev(const double *P, int Ng, double *out, void *stream);

@@ -357,7 +357,7 @@ def segment_queue():
     return engine.side_queue()
 
 
-ENQUEUE_CLASSES = ("glcm", "glrlm", "gldm", "ngtdm")      # (GLSZM's zone list is sized on the host between its kernels)
+ENQUEUE_CLASSES = ("glcm", "glrlm", "gldm", "ngtdm", "glszm")
 
 
 def segment_features_enqueue(cls, image, mask, Ng, features, distances=(1,), force2D=False, force2Ddimension=0, alpha=0,
@@ -365,8 +365,7 @@ def segment_features_enqueue(cls, image, mask, Ng, features, distances=(1,), for
     """segment_features in two halves, for the case pipeline (featureextractor.computeFeatures): with deferred=True the
     matrix and feature kernels of `cls` are only ENQUEUED on the current stream, their values land in the library's
     result arena; the returned finish() -> {feature name: float} may be called once engine.deferred_status() has
-    synchronised the stream (and not raised: a level outside [1, Ng] voids the values).  GLSZM is computed inside
-    finish().  No reference analogue (the reference evaluates class after class on the host, base.py:181-198)."""
+    synchronised the stream (and not raised: a level outside [1, Ng] voids the values).  No reference analogue (the reference evaluates class after class on the host, base.py:181-198)."""
     from . import engine
     dist = [int(d) for d in np.asarray(distances).ravel()]
     if cls == "glcm":
@@ -415,11 +414,22 @@ def segment_features_enqueue(cls, image, mask, Ng, features, distances=(1,), for
         P = engine.gldm(image, mask, int(Ng), int(alpha), dist, force2D, force2Ddimension, deferred=dfr)
         pair = engine.zone_matrix_features(P, np.arange(1, P.shape[1] + 1), deferred=dfr)
     elif cls == "glszm":
-        def finish():
+        def three_calls():
             P, sizes = engine.glszm_compact(image, mask, int(Ng), Ns, force2D, force2Ddimension)
             if len(sizes) == 0:
                 raise NotImplementedError("no zones")
             return named(mean_of(engine.zone_matrix_features(P, sizes)))
+        try:        # zones, ranked sizes, compact matrix and formulas in one queue (no host round trip in between)
+            vals, none = engine.glszm_features(image, mask, int(Ng), Ns, force2D, force2Ddimension, deferred=dfr)
+        except NotImplementedError:
+            return three_calls
+
+        def finish():
+            if vals[16] != 0:           # the device-side ranking declined / the reference's IndexError: the exact route
+                return three_calls()
+            if none[0] != 0:
+                raise NotImplementedError("no zones")
+            return named(vals[:16])
         return finish
     elif cls == "ngtdm":
         vals = engine.ngtdm_features(engine.ngtdm(image, mask, int(Ng), dist, force2D, force2Ddimension, deferred=dfr),

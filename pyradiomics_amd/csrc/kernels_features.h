@@ -207,14 +207,17 @@ enum { ZM_SmallEmphasis = 0, ZM_LargeEmphasis, ZM_GrayLevelNonUniformity, ZM_Gra
        ZM_Entropy, ZM_LowGrayLevelEmphasis, ZM_HighGrayLevelEmphasis, ZM_SmallLowGrayLevelEmphasis,
        ZM_SmallHighGrayLevelEmphasis, ZM_LargeLowGrayLevelEmphasis, ZM_LargeHighGrayLevelEmphasis, ZM_COUNT };
 
+static_assert(ZM_COUNT == 16, "prad_api.hip (ZM_FEATURES) and include/pyradiomics_amd.h say 16 zone-matrix features");
 // P(i, j, a) = counts[i * si + j * sj + a * sa]; level value = i + 1; size value = jvals[j].
 // scratch: [Na][Ni + Nj] float64 (marginals).  out: [Na][ZM_COUNT]; empty[a] = 1 when the matrix of angle a is all zero.
 __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel(
     const double *__restrict__ counts, int Ni, int Nj, int Na, long long si, long long sj, long long sa,
-    const double *__restrict__ jvals, double *__restrict__ scratch, double *__restrict__ out, int *__restrict__ empty) {
+    const double *__restrict__ jvals, double *__restrict__ scratch, double *__restrict__ out, int *__restrict__ empty,
+    const int *__restrict__ nj_dev = nullptr) {
 #pragma clang fp contract(off)
   __shared__ double sh4[4];
   const int a = blockIdx.x, t = threadIdx.x;
+  if (nj_dev) Nj = min(Nj, nj_dev[0]);      // (the column count was found on the device: glszm_rank_kernel; Nj = capacity)
   const double eps = PRAD_FEAT_EPS;
   double *pg = scratch + (size_t)a * (Ni + Nj), *pj = pg + Ni;
   auto P = [&](int i, int j) -> double { return counts[i * si + j * sj + a * sa]; };

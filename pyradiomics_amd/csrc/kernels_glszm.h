@@ -1204,8 +1204,19 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
                                                                  const int *__restrict__ large_sorted, int nlarge,
                                                                  double *__restrict__ out, int *__restrict__ err,
                                                                  const int *__restrict__ rootlist = nullptr,
-                                                                 const int *__restrict__ rootctl = nullptr) {
+                                                                 const int *__restrict__ rootctl = nullptr,
+                                                                 const int *__restrict__ meta = nullptr, int kstride = 0) {
   extern __shared__ unsigned fh[];
+  // meta (glszm_rank_kernel: the distinct sizes were ranked on the device, the host does not know k): nsmall, nlarge, k
+  // come from there, the rows of `out` are kstride (the capacity) apart; meta[3] != 0: nothing to fill
+  if (meta) {
+    if (meta[3]) return;
+    nsmall = meta[0];
+    nlarge = meta[1];
+    k = meta[2];
+  } else {
+    kstride = k;
+  }
   for (int q = threadIdx.x; q < Ng * RL; q += blockDim.x) fh[q] = 0u;
   __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -1217,7 +1228,7 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
       return;
     }
     if (r < RL) atomicAdd(fh + (gl - 1) * RL + r, 1u);
-    else atomicAdd(out + (size_t)(gl - 1) * k + r, 1.0);
+    else atomicAdd(out + (size_t)(gl - 1) * kstride + r, 1.0);
   };
   if (rootctl && rootctl[1] == 0) {      // the tile-root list (glszm_tile8_kernel)
     const long long m = rootctl[0];
@@ -1241,7 +1252,114 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
   }
   __syncthreads();
   for (int q = threadIdx.x; q < Ng * RL; q += blockDim.x)
-    if (fh[q]) atomicAdd(out + (size_t)(q / RL) * k + (q % RL), (double)fh[q]);
+    if (fh[q]) atomicAdd(out + (size_t)(q / RL) * kstride + (q % RL), (double)fh[q]);
+}
+
+// ---- the distinct zone sizes ranked ON THE DEVICE (the case pipeline: no host round trip between zones and features) ----
+// One workgroup: small sizes from the bitmap (popcount scan), large sizes sorted (bitonic, LDS) and de-duplicated.
+// Writes small_rank[PRAD_SMALL_SIZES], large_sorted[nlarge], jvals[k] (the sizes as doubles, ascending: the columns of the
+// compact matrix) and meta = {nsmall, nlarge, k, problem}; problem != 0: more large zones than PRAD_RANK_LARGE, more
+// distinct sizes than kcap, a zone list beyond the reference's scratch rule (nzones >= 2 Ns: bit 1), irregular levels
+// (bit 0) -- the caller then repeats the call on the synchronous route, which reports what the reference reports.
+#define PRAD_RANK_LARGE 4096
+__global__ void __launch_bounds__(1024) glszm_rank_kernel(const unsigned *__restrict__ small_bits,
+                                                          const int *__restrict__ large_list,
+                                                          const int *__restrict__ large_count, int large_cap,
+                                                          const int *__restrict__ flags,
+                                                          const unsigned long long *__restrict__ nzones, long long Ns2,
+                                                          int kcap, int *__restrict__ small_rank,
+                                                          int *__restrict__ large_sorted, double *__restrict__ jvals,
+                                                          int *__restrict__ meta) {
+  __shared__ int key[PRAD_RANK_LARGE];
+  __shared__ int scan[1024];
+  __shared__ int s_nsmall, s_nlarge;
+  const int t = threadIdx.x;
+  int problem = 0;
+  if (flags && flags[0]) problem |= 1;
+  if ((long long)nzones[0] >= Ns2) problem |= 2;
+  // small sizes: word t of the bitmap (PRAD_SMALL_SIZES / 32 = 256 words)
+  const int nwords = PRAD_SMALL_SIZES / 32;
+  const unsigned w = t < nwords ? small_bits[t] : 0u;
+  scan[t] = __popc(w);
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {          // inclusive Hillis-Steele scan
+    const int v = t >= o ? scan[t - o] : 0;
+    __syncthreads();
+    scan[t] += v;
+    __syncthreads();
+  }
+  if (t == 1023) s_nsmall = scan[t];
+  int base = scan[t] - __popc(w);
+  __syncthreads();
+  const int nsmall = s_nsmall;
+  if (t < nwords) {
+    for (int b = 0; b < 32; b++) {
+      const int sz = t * 32 + b;
+      if (w & (1u << b)) {
+        small_rank[sz] = base;
+        if (base < kcap) jvals[base] = (double)sz;
+        base++;
+      } else {
+        small_rank[sz] = -1;
+      }
+    }
+  }
+  // large sizes
+  int nl = large_count[0];
+  if (nl > large_cap || nl > PRAD_RANK_LARGE) {
+    problem |= 4;
+    nl = 0;
+  }
+  int P = 1;
+  while (P < nl) P <<= 1;
+  for (int i = t; i < P; i += 1024) key[i] = i < nl ? large_list[i] : 0x7fffffff;
+  __syncthreads();
+  for (int kk = 2; kk <= P; kk <<= 1)
+    for (int j = kk >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < P; i += 1024) {
+        const int l = i ^ j;
+        if (l > i) {
+          const int a = key[i], b = key[l];
+          const bool up = (i & kk) == 0;
+          if ((a > b) == up) { key[i] = b; key[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  // unique: element i starts a new value; ranks by a scan over chunks of 1024
+  int running = 0;
+  for (int c0 = 0; c0 < nl; c0 += 1024) {
+    const int i = c0 + t;
+    const int first = (i < nl && (i == 0 || key[i] != key[i - 1])) ? 1 : 0;
+    scan[t] = first;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int v = t >= o ? scan[t - o] : 0;
+      __syncthreads();
+      scan[t] += v;
+      __syncthreads();
+    }
+    if (first) {
+      const int r = running + scan[t] - 1;
+      large_sorted[r] = key[i];
+      if (nsmall + r < kcap) jvals[nsmall + r] = (double)key[i];
+    }
+    running += scan[1023];
+    __syncthreads();
+  }
+  if (t == 0) {
+    s_nlarge = running;
+    if (nsmall + running > kcap) problem |= 4;
+    meta[0] = nsmall;
+    meta[1] = running;
+    meta[2] = nsmall + running;
+    meta[3] = problem;
+  }
+}
+
+// out[16] of the feature block <- verdict (0 = fine): meta[3] of the ranking, the fill's error word
+__global__ void glszm_verdict_kernel(const int *__restrict__ meta, const int *__restrict__ err, double *__restrict__ out) {
+  out[0] = (double)(meta[3] | (err[0] ? 8 : 0));
 }
 
 // ordered zone list (tempData parity): block counts -> scan -> scatter
@@ -1419,7 +1537,9 @@ inline unsigned glszm_grid(long long n) {
 
 inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *image, const uint8_t *mask,
                        const int *angles_h, int Na, int Ng, int Ns, int Nvox, const int *voxels_dev, int kernelRadius,
-                       int force2Ddim, long long *nzones_out) {
+                       int force2Ddim, long long *nzones_out, bool enqueue_only = false) {
+  // enqueue_only (prad_glszm_features_dev): the packed-byte tile path or nothing (PRAD_E_UNSUPPORTED before any launch);
+  // no copy back, no synchronisation -- zone count, largest zone and the flags stay on the device ("glszm_stats", "flags")
   GlszmState &st = glszm_state();
   st.valid = false;
   int *stats = nullptr;
@@ -1482,6 +1602,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
       PRAD_TRY(c.get_pinned("glszm_flags_h", sizeof(int) * 4, &fp));
       flags_h = (int *)fp;
     }
+    if (enqueue_only && !bytes) return fail(PRAD_E_UNSUPPORTED, "GLSZM: the enqueue-only route needs the packed-byte tile kernels");
     for (int attempt = 0; attempt < 2; attempt++) {
       if (tiled) {
         const long long tiles = (long long)((dims3[0] + PRAD_TZ - 1) / PRAD_TZ) * ((dims3[1] + PRAD_TY - 1) / PRAD_TY) *
@@ -1561,7 +1682,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
                          st.sizes, stats, stats64, st.small_bits, st.large_list, st.large_cap, st.large_count,
                          (const int *)(bytes ? flags_d : nullptr), (const int *)st.rootlist, (const int *)st.rootctl);
       PRAD_TRY(check_launch("glszm_stats_kernel"));
-      if (!bytes) break;
+      if (!bytes || enqueue_only) break;
       PRAD_HIP(hipMemcpyAsync(flags_h, flags_d, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
       PRAD_HIP(hipMemcpyAsync(stats_h, stats, sizeof(int) * 8, hipMemcpyDeviceToHost, s));
       PRAD_HIP(hipStreamSynchronize(s));
@@ -1573,6 +1694,12 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
     st.voxel_mode = false;
     st.image = image;
     st.boxmax = g.n;
+    if (enqueue_only) {
+      st.g = g;
+      st.nvox = 1;
+      st.device = c.device;
+      return 0;                  // (st.valid stays false: the host-side follow-ups need the synchronous call)
+    }
   } else {
     if (kernelRadius <= 0) return fail(PRAD_E_ARG, "Expecting kernelRadius > 0");
     VoxMode vm;

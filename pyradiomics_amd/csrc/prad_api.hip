@@ -1728,6 +1728,11 @@ int log_dev(const float *in, const int *size, int Nd, const double *spacing, dou
 // =================================================================================================
 // extern "C"
 // =================================================================================================
+namespace prad {
+int zone_features_launch(Context &c, hipStream_t s, const double *P, int Ni, int Njcap, long long stride_i,
+                         const double *jvals_d, const int *nj_dev, double *out_d, int *empty_d);   // prad_features.hip
+}
+#define ZM_FEATURES 16   // ZM_COUNT of kernels_features.h (static_assert there)
 namespace {
 template <typename T>
 int launch_digitize(const T *image, const uint8_t *mask, long long n, const double *e_d, int nedges, int32_t *levels,
@@ -2113,6 +2118,70 @@ int prad_calculate_glszm_dev(const int32_t *image, const uint8_t *mask, const in
   PRAD_TRY(c.end_call(s));
   PRAD_HIP(hipStreamSynchronize(s));
   return rc;
+}
+int prad_glszm_features_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                            int Ng, int Ns, double *out, int *empty, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  Geo g;
+  PRAD_TRY(make_geo(size, Nd, &g));
+  if (!image || !mask || !angles || !out || !empty || Na < 1 || Ng < 1 || Ns < 1) return fail(PRAD_E_ARG, "bad GLSZM arguments");
+  hipStream_t s = (hipStream_t)stream;
+  PRAD_TRY(c.begin_call(s));
+  {   // (returns the largest zone, 0 here: nothing came back from the device; negative = error)
+    const int zrc = glszm_zones(c, s, g, image, mask, angles, Na, Ng, Ns, 1, nullptr, 0, -1, nullptr, true);
+    if (zrc < 0) return zrc;
+  }
+  GlszmState &st = glszm_state();
+  // distinct sizes sum to at most n voxels, so there are fewer than sqrt(2 n) + 1 of them
+  const int kcap = (int)std::min<long long>(g.n, (long long)std::sqrt(2.0 * (double)g.n) + 2);
+  int *stats = nullptr, *flags_d = nullptr, *large_sorted = nullptr, *meta = nullptr, *err = nullptr;
+  double *jv = nullptr, *P = nullptr, *d_out = nullptr;
+  PRAD_TRY(c.get<int>("glszm_stats", 8, &stats));
+  PRAD_TRY(c.get<int>("flags", 4, &flags_d));
+  PRAD_TRY(c.get<int>("glszm_small_rank", PRAD_SMALL_SIZES, &st.small_rank));
+  PRAD_TRY(c.get<int>("glszm_large_sorted", PRAD_RANK_LARGE + 1, &large_sorted));
+  PRAD_TRY(c.get<int>("glszm_meta", 8, &meta));
+  PRAD_TRY(c.get<int>("glszm_err", 4, &err));
+  PRAD_TRY(c.get<double>("glszm_jvals", (size_t)kcap, &jv));
+  PRAD_TRY(c.get<double>("glszm_compact", (size_t)Ng * kcap, &P));
+  PRAD_TRY(c.get<double>("glszm_feat_out", ZM_FEATURES + 4, &d_out));
+  int *d_empty = reinterpret_cast<int *>(d_out + ZM_FEATURES + 2);
+  PRAD_HIP(hipMemsetAsync(err, 0, sizeof(int) * 4, s));
+  PRAD_HIP(hipMemsetAsync(P, 0, sizeof(double) * (size_t)Ng * kcap, s));
+  {
+    Timed t(c, "glszm", s);
+    hipLaunchKernelGGL(glszm_rank_kernel, dim3(1), dim3(1024), 0, s, (const unsigned *)st.small_bits, (const int *)st.large_list,
+                       (const int *)st.large_count, st.large_cap, (const int *)flags_d,
+                       (const unsigned long long *)(stats + 2), 2LL * Ns, kcap, st.small_rank, large_sorted, jv, meta);
+    PRAD_TRY(check_launch("glszm_rank_kernel"));
+    const int RL = Ng <= 8192 ? std::max(1, std::min(kcap, 8192 / Ng)) : 0;
+    hipLaunchKernelGGL(glszm_fill_compact_kernel, dim3(std::min(glszm_grid(g.n), 2048u)), dim3(256), sizeof(unsigned) * Ng * RL,
+                       s, g.n, st.labels, st.sizes, image, Ng, 0, RL, st.small_rank, 0, large_sorted, 0, P, err,
+                       (const int *)st.rootlist, (const int *)st.rootctl, (const int *)meta, kcap);
+    PRAD_TRY(check_launch("glszm_fill_compact_kernel"));
+  }
+  PRAD_TRY(zone_features_launch(c, s, P, Ng, kcap, (long long)kcap, jv, meta + 2, d_out, d_empty));
+  hipLaunchKernelGGL(glszm_verdict_kernel, dim3(1), dim3(1), 0, s, (const int *)meta, (const int *)err, d_out + ZM_FEATURES);
+  PRAD_TRY(check_launch("glszm_verdict_kernel"));
+  PRAD_TRY(c.end_call(s));
+  c.last_path = "glszm-unionfind";
+  const size_t nb = sizeof(double) * (ZM_FEATURES + 1);
+  if (c.deferred && c.in_arena(out, nb) && c.in_arena(empty, sizeof(int))) {
+    PRAD_HIP(hipMemcpyAsync(out, d_out, nb, hipMemcpyDeviceToHost, s));
+    PRAD_HIP(hipMemcpyAsync(empty, d_empty, sizeof(int), hipMemcpyDeviceToHost, s));
+    return PRAD_OK;
+  }
+  void *pin = nullptr;
+  PRAD_TRY(c.get_pinned("glszm_feat_pin", sizeof(double) * (ZM_FEATURES + 4), &pin));
+  PRAD_HIP(hipMemcpyAsync(pin, d_out, sizeof(double) * (ZM_FEATURES + 3), hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  memcpy(out, pin, nb);
+  memcpy(empty, (const char *)pin + sizeof(double) * (ZM_FEATURES + 2), sizeof(int));
+  const int verdict = (int)out[ZM_FEATURES];
+  if (verdict & 2) return fail(PRAD_E_INDEX, "GLSZM: zone list would overflow the reference's Ns-sized scratch (Ns=%d)", Ns);
+  if (verdict) return fail(PRAD_E_UNSUPPORTED, "GLSZM features: the device-side ranking declined (verdict %d); use prad_calculate_glszm_dev", verdict);
+  return PRAD_OK;
 }
 int prad_calculate_glszm(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
                          int Na, int Ng, int Ns, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,

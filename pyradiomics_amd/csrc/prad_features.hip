@@ -39,6 +39,19 @@ extern "C" int prad_glcm_features_dev(const double *glcm, int Ng, int Na, int sy
   return PRAD_OK;
 }
 
+// launch only, everything on the device (prad_glszm_features_dev: the column values and their number were found there)
+namespace prad {
+int zone_features_launch(Context &c, hipStream_t s, const double *P, int Ni, int Njcap, long long stride_i,
+                         const double *jvals_d, const int *nj_dev, double *out_d, int *empty_d) {
+  double *d_scr = nullptr;
+  PRAD_TRY(c.get<double>("zf_scratch", (size_t)Ni + (size_t)Njcap, &d_scr));
+  Timed t(c, "features", s);
+  hipLaunchKernelGGL(zone_matrix_features_kernel, dim3(1), dim3(PRAD_FEAT_THREADS), 0, s, P, Ni, Njcap, 1, stride_i, 1LL, 0LL,
+                     jvals_d, d_scr, out_d, empty_d, nj_dev);
+  return check_launch("zone_matrix_features_kernel");
+}
+}  // namespace prad
+
 extern "C" int prad_zone_matrix_features_dev(const double *P, int Ni, int Nj, int Na, long long stride_i,
                                              long long stride_j, long long stride_a, const double *jvals, double *out,
                                              int *empty, void *stream) {

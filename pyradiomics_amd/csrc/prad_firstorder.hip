@@ -30,6 +30,28 @@ double lerp_np(double a, double b, double t) {
   return t >= 0.5 ? b - d * (1 - t) : a + d * t;
 }
 
+// the 10 order statistics in ONE copy through pinned memory (ten 8-byte copies into a pageable array were ten blocking
+// round trips per derived image)
+struct FoPick {
+  long long idx[10];
+};
+__global__ void fo_pick_kernel(const double *__restrict__ sorted, FoPick p, double *__restrict__ out) {
+  if (threadIdx.x < 10) out[threadIdx.x] = p.idx[threadIdx.x] >= 0 ? sorted[p.idx[threadIdx.x]] : 0.0;
+}
+int pick_sorted(Context &c, hipStream_t s, const double *sorted, const FoPick &p, double *os) {
+  double *d = nullptr;
+  void *hp = nullptr;
+  PRAD_TRY(c.get<double>("fo_pick", 16, &d));
+  PRAD_TRY(c.get_pinned("fo_pick_h", sizeof(double) * 16, &hp));
+  hipLaunchKernelGGL(fo_pick_kernel, dim3(1), dim3(64), 0, s, sorted, p, d);
+  PRAD_TRY(check_launch("fo_pick_kernel"));
+  PRAD_HIP(hipMemcpyAsync(hp, d, sizeof(double) * 10, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  for (int k = 0; k < 10; k++)
+    if (p.idx[k] >= 0) os[k] = ((const double *)hp)[k];
+  return PRAD_OK;
+}
+
 int sum_partials(Context &c, hipStream_t s, const double *partial_d, int blocks, int width, double *out) {
   void *hp = nullptr;
   PRAD_TRY(c.get_pinned("fo_partials_h", sizeof(double) * PRAD_FO_BLOCKS * 8, &hp));
@@ -280,12 +302,10 @@ extern "C" int prad_firstorder_dev(const void *image, int dtype, const uint8_t *
           PRAD_TRY(check_launch("fo_gather_kernel"));
           PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, gath, gsorted, (int)total, 0, 64, s));
         }
+        FoPick pk;
         for (int k = 0; k < 10; k++)
-          if (!single[which[k]]) {
-            PRAD_HIP(hipMemcpyAsync(os + k, gsorted + gsel.off[gidx[which[k]]] + within[k], sizeof(double),
-                                    hipMemcpyDeviceToHost, s));
-          }
-        PRAD_HIP(hipStreamSynchronize(s));
+          pk.idx[k] = single[which[k]] ? -1 : (long long)gsel.off[gidx[which[k]]] + within[k];
+        PRAD_TRY(pick_sorted(c, s, gsorted, pk, os));
       }
       for (int k = 0; k < 10; k++)
         if (single[which[k]]) os[k] = single_val[which[k]];
@@ -311,9 +331,9 @@ extern "C" int prad_firstorder_dev(const void *image, int dtype, const uint8_t *
       PRAD_TRY(check_launch("fo_compact_kernel"));
       PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, vals, sorted, (int)m, 0, 64, s));
     }
-    for (int k = 0; k < 10; k++)
-      PRAD_HIP(hipMemcpyAsync(os + k, sorted + ranks[k], sizeof(double), hipMemcpyDeviceToHost, s));
-    PRAD_HIP(hipStreamSynchronize(s));
+    FoPick pk;
+    for (int k = 0; k < 10; k++) pk.idx[k] = ranks[k];
+    PRAD_TRY(pick_sorted(c, s, sorted, pk, os));
   }
   double pq[5];
   for (int k = 0; k < 5; k++) pq[k] = lerp_np(os[2 * k], os[2 * k + 1], qp[k].gamma);

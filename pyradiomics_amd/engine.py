@@ -503,6 +503,32 @@ def glszm_compact(image: torch.Tensor, mask: torch.Tensor, Ng: int, Ns: int | No
     return out[:, :k], sizes[:k].copy()
 
 
+def glszm_features(image: torch.Tensor, mask: torch.Tensor, Ng: int, Ns: int | None = None, force2D: bool = False,
+                   force2Ddimension: int = 0, deferred: bool = False):
+    """the 16 GLSZM features of a segment without a host round trip between zone labelling, the compact matrix and the
+    formulas (prad_glszm_features_dev): (float64 numpy [17], int32 numpy [1]) -- values, then the verdict (0 = fine, else
+    take glszm_compact + zone_matrix_features, which raise what the reference raises); flag != 0 = no zone.
+    deferred=True: enqueue only, both arrays live in the result arena and are valid after deferred_status().
+    Raises NotImplementedError when the volume is not one for the packed-byte tile kernels."""
+    lib, image, mask, size, f2d, angles = _neigh_common(image, mask, None, force2D, force2Ddimension)
+    Na, Nd = angles.shape
+    if Ns is None:
+        Ns = int(mask.sum().item())
+    alloc = result_array if deferred else np.empty
+    out = alloc((17,), np.float64)
+    empty = alloc((1,), np.intc)
+    with _Deferred(lib, deferred):
+        rc = lib.prad_glszm_features_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
+                                         _iptr(angles), Na, int(Ng), int(Ns), out.ctypes.data_as(C.POINTER(C.c_double)),
+                                         _iptr(empty), _stream_ptr())
+    if rc == _lib.PRAD_E_INDEX:
+        raise IndexError("Calculation of GLSZM Failed.")
+    _lib.raise_for(rc, "GLSZM features")
+    if deferred:
+        _deferred_keep.append((image, mask))
+    return out, empty
+
+
 def voxel_glcm_features(image: torch.Tensor, mask: torch.Tensor, Ng: int, voxels: torch.Tensor, features,
                         kernelRadius: int = 1, force2D: bool = False, force2Ddimension: int = 0,
                         symmetrical: bool = True, distances=(1,)):

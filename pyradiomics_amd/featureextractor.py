@@ -275,8 +275,8 @@ class RadiomicsFeatureExtractor:
             for f in fnames or []:
                 fc.enableFeatureByName(f)
             fcs.append((cname, fc))
-        # Case pipeline: the classes whose matrix AND formulas run on the device (GLCM, GLRLM, GLDM, NGTDM) queue all of
-        # their kernels first; the classes that talk to the host between their kernels (first order, GLSZM) run while
+        # Case pipeline: the classes whose matrix AND formulas run on the device (GLCM, GLRLM, GLSZM, GLDM, NGTDM) queue all
+        # of their kernels first (on a side stream); first order, which talks to the host between its kernels, runs while
         # that queue drains; then ONE wait and the queued values are collected.  The reference evaluates class after
         # class (featureextractor.py:560-604), each with its own round trips.
         cm = fcs[0][1].cMatrices if fcs else None

@@ -61,6 +61,9 @@ class RadiomicsGLSZM(_ZoneLikeFeatures):
     def _P(self):
         return self.P_glszm
 
+    def _segmentRoute(self):
+        return ("glszm", {})
+
     def _calculateFeatures(self, voxelCoordinates=None):
         fused = self._fusedVoxelFeatures("glszm", voxelCoordinates)
         if fused is None:

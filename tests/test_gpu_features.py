@@ -398,3 +398,49 @@ def test_case_pipeline_enqueue_equals_class_by_class():
     engine.deferred_status()                      # (the flag was cleared)
     with pytest.raises(IndexError):
         engine.gldm(bad, msk, 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,ng,kind", [((40, 48, 64), 16, "smooth"), ((33, 31, 70), 8, "noise"), ((1, 96, 128), 12, "smooth"),
+                                           ((24, 40, 44), 5, "blocks")])
+def test_glszm_features_one_queue_equals_three_calls(shape, ng, kind):
+    """prad_glszm_features_dev (zones -> sizes ranked on the device -> compact matrix -> formulas, no host round trip) against
+    prad_calculate_glszm_dev + prad_glszm_sizes + prad_fill_glszm_compact_dev + prad_zone_matrix_features_dev, synchronous and
+    enqueue-only; zones of 8192+ voxels (the sorted 'large' list) included"""
+    import torch
+    from pyradiomics_amd import engine
+    rng = np.random.default_rng(11)
+    if kind == "noise":
+        lev = rng.integers(1, ng + 1, size=shape)
+    elif kind == "blocks":      # a few huge zones (> 8192 voxels) next to small ones
+        lev = np.ones(shape, dtype=np.int64)
+        lev[:, :20, :] = 2
+        lev[:12, 20:, :22] = 3
+        lev[5:9, 3:9, 3:30] = 4
+        lev[rng.random(shape) < 0.01] = 5
+    else:
+        f = rng.normal(size=shape)
+        for ax in range(3):
+            if shape[ax] > 1:
+                f = np.cumsum(f, axis=ax)
+        lev = np.clip(((f - f.min()) / (np.ptp(f) + 1e-9) * ng).astype(np.int64) + 1, 1, ng)
+    msk = rng.random(shape) < 0.93
+    dev = torch.device("cuda", 0)
+    L = torch.from_numpy(lev.astype(np.int32)).to(dev)
+    M = torch.from_numpy(msk.astype(np.uint8)).to(dev)
+    Ns = int(msk.sum())
+    P, sizes = engine.glszm_compact(L, M, ng, Ns)
+    want, none = engine.zone_matrix_features(P, sizes)
+    got, flag = engine.glszm_features(L, M, ng, Ns)
+    assert got[16] == 0 and flag[0] == 0 and not none[0]
+    assert np.allclose(got[:16], want[0], rtol=1e-12, atol=0, equal_nan=True)
+    got2, flag2 = engine.glszm_features(L, M, ng, Ns, deferred=True)
+    engine.deferred_status()
+    assert np.array_equal(got2, got, equal_nan=True) and flag2[0] == 0
+    # the reference's scratch rule (nzones >= 2 Ns -> IndexError, cmatrices.c:366-373) survives the device-side route
+    if kind == "noise":
+        with pytest.raises(IndexError):
+            engine.glszm_features(L, M, ng, max(1, Ns // 64))
+        v, _ = engine.glszm_features(L, M, ng, max(1, Ns // 64), deferred=True)
+        engine.deferred_status()
+        assert int(v[16]) & 2
