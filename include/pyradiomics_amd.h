@@ -102,6 +102,10 @@ int prad_set_deferred_mode(int mode);      /* 1 pipeline, 0 lanes, -1 environmen
  * queued on `stream` may read the outputs of those calls; the levels verdict still needs prad_deferred_status */
 int prad_deferred_join(void *stream);
 int prad_deferred_status(void *stream);
+/* queues a copy of the sticky verdict word into `flag` (an int inside the result arena) on `stream`: a caller that waits
+ * on an EVENT recorded after this call -- not on the whole stream, so that work queued later keeps running -- reads
+ * *flag != 0 as "a deferred call before the mark saw levels outside [1, Ng]" (then prad_deferred_status clears it) */
+int prad_deferred_mark(int *flag, void *stream);
 /* Result arena + enqueue-only feature calls (the case pipeline: every matrix and feature kernel of one derived image is
  * queued before the host waits once).  prad_result_alloc hands out pinned host memory from a per-thread ring of 4 MiB
  * (64-byte aligned; at most 1 MiB per allocation; an allocation stays untouched until 4 MiB more have been handed out).

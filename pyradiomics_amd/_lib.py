@@ -42,6 +42,7 @@ SYMBOLS = {
     "prad_result_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "prad_set_workspace": (C.c_int, [C.c_int]),
     "prad_deferred_status": (C.c_int, [C.c_void_p]),
+    "prad_deferred_mark": (C.c_int, [C.POINTER(C.c_int), C.c_void_p]),
     "prad_get_angle_count": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
     "prad_build_angles": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
     "prad_calculate_glcm": (C.c_int, _COMMON + [C.c_int] + _VOX + [_vp]),

@@ -350,6 +350,20 @@ def segment_sync():
     return True
 
 
+def segment_mark():
+    """token behind everything queued inside segment_queue() so far (engine.deferred_mark on the side stream)"""
+    from . import engine
+    with engine.side_queue(wait=False):
+        return engine.deferred_mark()
+
+
+def segment_wait(token):
+    """waits for the work in front of the token; False when its values are void (see segment_sync)"""
+    from . import engine
+    with engine.side_queue(wait=False):
+        return engine.deferred_wait(token)
+
+
 def segment_queue():
     """context manager around the segment_features_enqueue calls of one derived image: they go to a side stream
     (engine.side_queue) so that the classes evaluated synchronously meanwhile do not wait for them"""

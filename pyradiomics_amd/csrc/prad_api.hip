@@ -1930,6 +1930,16 @@ int prad_deferred_join(void *stream) {
   }
   return c.lanes_join((hipStream_t)stream);
 }
+int prad_deferred_mark(int *flag, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!flag || !c.in_arena(flag, sizeof(int))) return fail(PRAD_E_ARG, "deferred_mark: flag must lie in the result arena");
+  PRAD_TRY(pipeline_flush(c));
+  int *sticky = nullptr;
+  PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
+  PRAD_HIP(hipMemcpyAsync(flag, sticky, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return PRAD_OK;
+}
 int prad_deferred_status(void *stream) {
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());

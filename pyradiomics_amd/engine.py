@@ -38,7 +38,33 @@ def _prep(image: torch.Tensor, mask: torch.Tensor):
     return lib, image, mask, size
 
 
-_deferred_keep: list = []
+class _KeepList:
+    """tensors the queued (deferred) calls of THIS host thread still use; released by deferred_status / deferred_wait"""
+
+    def __init__(self):
+        import threading
+        self._tls = threading.local()
+
+    def _l(self):
+        l = getattr(self._tls, "l", None)
+        if l is None:
+            l = self._tls.l = []
+        return l
+
+    def append(self, x):
+        self._l().append(x)
+
+    def clear(self):
+        self._l().clear()
+
+    def __iter__(self):
+        return iter(list(self._l()))
+
+    def __len__(self):
+        return len(self._l())
+
+
+_deferred_keep = _KeepList()
 
 
 def result_array(shape, dtype) -> np.ndarray:
@@ -152,6 +178,34 @@ def deferred_status() -> None:
         _lib.raise_for(_lib.load().prad_deferred_status(_stream_ptr()), "deferred GLCM+GLRLM")
     finally:
         _deferred_keep.clear()
+
+
+def deferred_mark():
+    """token for deferred_wait(): everything queued on the current stream so far (a copy of the verdict word behind it, an
+    event behind that); the tensors the queued calls use stay alive with the token"""
+    flag = result_array((1,), np.intc)
+    flag[0] = 0
+    _lib.raise_for(_lib.load().prad_deferred_mark(_iptr(flag), _stream_ptr()), "deferred mark")
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    keep = list(_deferred_keep)
+    _deferred_keep.clear()
+    return flag, ev, keep
+
+
+def deferred_wait(token) -> bool:
+    """waits for the work in front of a deferred_mark() token only (later work on that stream keeps running); False when
+    a deferred call in front of it saw levels outside [1, Ng] (the flag is then cleared through deferred_status)"""
+    flag, ev, keep = token
+    ev.synchronize()
+    keep.clear()
+    if flag[0] != 0:
+        try:
+            deferred_status()
+        except _lib.DeferredLevelsError:
+            pass
+        return False
+    return True
 
 
 def deferred_join() -> None:

@@ -257,15 +257,28 @@ class RadiomicsFeatureExtractor:
             args = s.copy()
             args.update(custom)
             gens = chain(gens, _IMAGE_TYPES[imageType](image, mask, **args))
+        # One derived image of look-ahead: image i+1 is cropped, binned and its device classes QUEUED before the host
+        # collects image i, so the GPU works through a queue while the host does its round trips (first order) and its
+        # Python; results keep the reference's order (featureextractor.py:371-396 evaluates image after image).
+        pending = None
         for derived, typeName, kw in gens:
             cimg, cmask = imageoperations.cropToTumorMask(derived, mask, label, padDistance=kernelRadius,
                                                           deviceResident=on_dev)
-            out.update(self.computeFeatures(cimg, cmask, typeName, **kw))
+            started = self._startFeatures(cimg, cmask, typeName, **kw)
+            if pending is not None:
+                out.update(self._finishFeatures(pending))
+            pending = started
+        if pending is not None:
+            out.update(self._finishFeatures(pending))
         return out
 
     def computeFeatures(self, image, mask, imageTypeName, **kwargs):
         """featureextractor.py:560-604"""
-        out = collections.OrderedDict()
+        return self._finishFeatures(self._startFeatures(image, mask, imageTypeName, **kwargs))
+
+    def _startFeatures(self, image, mask, imageTypeName, **kwargs):
+        """first half of computeFeatures: the feature classes of one derived image constructed (binning), the device
+        classes' kernels queued; -> state for _finishFeatures"""
         classes = getFeatureClasses()
         fcs = []
         for cname, fnames in self.enabledFeatures.items():
@@ -282,8 +295,15 @@ class RadiomicsFeatureExtractor:
         cm = fcs[0][1].cMatrices if fcs else None
         with (cm.segment_queue() if hasattr(cm, "segment_queue") and fcs[0][1].deviceResident else contextlib.nullcontext()):
             queued = [fc for _, fc in fcs if fc.enqueue()]
+        token = cm.segment_mark() if queued else None
+        return fcs, queued, token, imageTypeName
+
+    def _finishFeatures(self, started):
+        """second half of computeFeatures: the host-side classes evaluated, the queued ones waited for and collected"""
+        fcs, queued, token, imageTypeName = started
+        out = collections.OrderedDict()
         values = {cname: fc.execute() for cname, fc in fcs if fc not in queued}
-        if queued and not queued[0].cMatrices.segment_sync():
+        if queued and not queued[0].cMatrices.segment_wait(token):
             for fc in queued:          # a level outside [1, Ng]: the synchronous route raises what the reference raises
                 fc.dropEnqueued()
         for cname, fc in fcs:
