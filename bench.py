@@ -244,8 +244,9 @@ def mode_config3(device, engine, size=256):
         torch.cuda.synchronize()
         t["wavelet_x8"] = (time.perf_counter() - t0) * 1e3
         t0 = time.perf_counter()
-        for s in (1.0, 2.0, 3.0, 4.0, 5.0):
-            derived["log-sigma-%g" % s] = engine.log_image(img, (1.0, 1.0, 1.0), s)
+        sig = (1.0, 2.0, 3.0, 4.0, 5.0)      # (the five sigmas in the same launches, as filters.getLoGImage runs them)
+        for s, d in zip(sig, engine.log_images(img, (1.0, 1.0, 1.0), sig)):
+            derived["log-sigma-%g" % s] = d
         torch.cuda.synchronize()
         t["log_x5"] = (time.perf_counter() - t0) * 1e3
         tb = tm = 0.0

@@ -405,6 +405,11 @@ int prad_log(const float *in, const int *size, int Nd, const double *spacing, do
              float *out);
 int prad_log_dev(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
                  float *out, void *stream);
+/* nsig (1..8) sigmas of ONE input in the same launches (the reference loops over its sigma list, imageoperations.py:
+ * 806-836, one filter run each): a pass of one sigma is bound by the latency of its serial recursion, the waves of the
+ * other sigmas fill the gaps.  outs: HOST array of nsig DEVICE pointers; the same arithmetic per sigma as prad_log_dev. */
+int prad_log_multi_dev(const float *in, const int *size, int Nd, const double *spacing, const double *sigmas, int nsig,
+                       int normalize, float *const *outs, void *stream);
 
 #ifdef __cplusplus
 }

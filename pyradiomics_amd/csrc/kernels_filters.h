@@ -189,10 +189,21 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
 // of 36; 256^3: 94 -> see profiles (smoothing pass).  AM: 0 plain float output, 1 first Laplacian term (acc = v / sp2),
 // 2 later term (acc += v / sp2).
 #define PRAD_RG_RB 16
+// Several sigmas per launch (blockIdx.y): a 256^3 volume has 65 536 lines = ONE wave per SIMD, and a pass is bound by the
+// latency of its serial float64 chain -- the waves of the other sigmas fill the gaps (profiles/r03_probes.md, section 11).
+#define PRAD_LOG_MAXSIG 8
+struct RGMulti {
+  RGaussCoef k[PRAD_LOG_MAXSIG];
+  const float *in[PRAD_LOG_MAXSIG];
+  double *scratch[PRAD_LOG_MAXSIG];
+  float *out[PRAD_LOG_MAXSIG];
+  float *acc[PRAD_LOG_MAXSIG];
+};
+
 template <int AM>
-__global__ void __launch_bounds__(256) rgauss_line2_kernel(const float *__restrict__ in, long long outer, int ln,
-                                                           long long inner, RGaussCoef c, double *__restrict__ states,
-                                                           float *__restrict__ out, float *__restrict__ acc, double sp2) {
+__device__ __forceinline__ void rgauss_line2_body(const float *__restrict__ in, long long outer, int ln,
+                                                  long long inner, const RGaussCoef &c, double *__restrict__ states,
+                                                  float *__restrict__ out, float *__restrict__ acc, double sp2) {
 #pragma clang fp contract(off)  // ITK's line arithmetic is plain multiply / add; keep the same roundings
   constexpr int RB = PRAD_RG_RB;
   const long long lines = outer * inner;
@@ -356,6 +367,12 @@ __global__ void __launch_bounds__(256) rgauss_line2_kernel(const float *__restri
   }
 }
 
+template <int AM>
+__global__ void __launch_bounds__(256) rgauss_line2_kernel(RGMulti M, long long outer, int ln, long long inner, double sp2) {
+  const int sg = blockIdx.y;
+  rgauss_line2_body<AM>(M.in[sg], outer, ln, inner, M.k[sg], M.scratch[sg], M.out[sg], M.acc[sg], sp2);
+}
+
 // The same recursion for the contiguous axis (inner == 1): a lane-per-line walk would read 64 different cache lines
 // per step.  One wave owns 64 consecutive lines and moves them through LDS in 64-sample tiles: every global access is
 // a 256-byte row segment, the lane then walks its own line inside the tile (pitch 65: conflict-free).  Causal tiles
@@ -478,9 +495,9 @@ __global__ void __launch_bounds__(64) rgauss_xline_kernel(const float *__restric
 // TL: lines per wave (64: every lane recurses; 32: half the lanes do, but a row piece is 32 samples = a full 128-byte
 // line per access at the LDS cost of 16-sample tiles, and a 256^3 volume gets 4 096 waves instead of 2 048)
 template <int W, int TL, int AM>
-__global__ void __launch_bounds__(128) rgauss_xline2_kernel(const float *__restrict__ in, long long lines, int ln,
-                                                            RGaussCoef c, double *scratch, float *__restrict__ out,
-                                                            float *__restrict__ acc, double sp2) {
+__device__ __forceinline__ void rgauss_xline2_body(const float *__restrict__ in, long long lines, int ln,
+                                                   const RGaussCoef &c, double *scratch, float *__restrict__ out,
+                                                   float *__restrict__ acc, double sp2) {
 #pragma clang fp contract(off)
   constexpr int RPI = 64 / W;            // rows of W samples per wave instruction
   constexpr int NI = TL * W / 64;        // load / store instructions per tile
@@ -650,6 +667,12 @@ __global__ void __launch_bounds__(128) rgauss_xline2_kernel(const float *__restr
   else backward(Yes{}, 0, m);
 #undef PRAD_XL_FETCH
 #undef PRAD_XL_COMMIT
+}
+
+template <int W, int TL, int AM>
+__global__ void __launch_bounds__(128) rgauss_xline2_kernel(RGMulti M, long long lines, int ln, double sp2) {
+  const int sg = blockIdx.y;
+  rgauss_xline2_body<W, TL, AM>(M.in[sg], lines, ln, M.k[sg], M.scratch[sg], M.out[sg], M.acc[sg], sp2);
 }
 
 }  // namespace prad

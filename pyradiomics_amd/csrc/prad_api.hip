@@ -1618,24 +1618,32 @@ RGaussCoef rgauss_coefficients(double sigma, double spacing, int order, bool nor
   return c;
 }
 
-int log_dev(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize, float *out,
-            hipStream_t s) {
+// nsig sigmas of one input in the same launches (blockIdx.y = sigma): see RGMulti in kernels_filters.h
+int log_multi_dev(const float *in, const int *size, int Nd, const double *spacing, const double *sigmas, int nsig,
+                  int normalize, float *const *outs, hipStream_t s) {
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
   Geo g;
   PRAD_TRY(make_geo(size, Nd, &g));
-  if (!in || !out || !spacing) return fail(PRAD_E_ARG, "log: NULL pointer");
-  if (!(sigma > 0.0)) return fail(PRAD_E_ARG, "log: sigma must be > 0");
+  if (!in || !outs || !spacing || !sigmas) return fail(PRAD_E_ARG, "log: NULL pointer");
+  if (nsig < 1 || nsig > PRAD_LOG_MAXSIG) return fail(PRAD_E_ARG, "log: %d sigmas per call outside [1, %d]", nsig, PRAD_LOG_MAXSIG);
+  for (int q = 0; q < nsig; q++) {
+    if (!(sigmas[q] > 0.0)) return fail(PRAD_E_ARG, "log: sigma must be > 0");
+    if (!outs[q]) return fail(PRAD_E_ARG, "log: NULL output");
+  }
   for (int d = 0; d < Nd; d++)
     if (g.size[d] < 4) return fail(PRAD_E_ARG, "log: axis %d has %d < 4 samples (imageoperations.py:811)", d, g.size[d]);
   PRAD_TRY(c.begin_call(s));
   const size_t n = (size_t)g.n;
-  float *bufA = nullptr, *bufB = nullptr, *bufC = nullptr;
-  double *scratch = nullptr;
-  PRAD_TRY(c.get<float>("log_a", n, &bufA));
-  PRAD_TRY(c.get<float>("log_b", n, &bufB));
-  PRAD_TRY(c.get<float>("log_c", n, &bufC));
-  PRAD_TRY(c.get<double>("log_scratch", n, &scratch));
+  float *bufA[PRAD_LOG_MAXSIG], *bufB[PRAD_LOG_MAXSIG], *bufC[PRAD_LOG_MAXSIG];
+  double *scratch[PRAD_LOG_MAXSIG];
+  for (int q = 0; q < nsig; q++) {
+    const std::string tag = q ? "#s" + std::to_string(q) : "";
+    PRAD_TRY(c.get<float>(("log_a" + tag).c_str(), n, &bufA[q]));
+    PRAD_TRY(c.get<float>(("log_b" + tag).c_str(), n, &bufB[q]));
+    PRAD_TRY(c.get<float>(("log_c" + tag).c_str(), n, &bufC[q]));
+    PRAD_TRY(c.get<double>(("log_scratch" + tag).c_str(), n, &scratch[q]));
+  }
   {
     Timed t(c, "log", s);
     // ITK dimension order x, y, z = array axes Nd-1 .. 0
@@ -1644,25 +1652,34 @@ int log_dev(const float *in, const int *size, int Nd, const double *spacing, dou
     // in ITK's pass order (smoothing passes from the last axis to the first, then the derivative).  The derivative pass
     // accumulates straight into `out` (acc += term / spacing^2, roundings of the separate step).  Two terms begin with
     // the same smoothing pass along the last axis: it is computed once and kept (identical arithmetic, identical bits).
-    float *shared_first = nullptr;   // smoothed-along-the-last-axis copy of the input
+    bool have_shared = false;        // bufC = smoothed-along-the-last-axis copy of the input
     int shared_axis = -1;
     for (int dim = Nd - 1; dim >= 0; dim--) {
-      const float *cur = in;
-      float *pp[2] = {bufA, bufB};
+      const float *cur[PRAD_LOG_MAXSIG];
+      for (int q = 0; q < nsig; q++) cur[q] = in;
       int flip = 0;
-      auto pass = [&](int ax, int order, float *forced_dst, bool accumulate) -> int {
-        const RGaussCoef k = rgauss_coefficients(sigma, spacing[ax], order, normalize != 0);
+      // forced: 0 = ping-pong buffers, 1 = into bufC (the shared first smoothing)
+      auto pass = [&](int ax, int order, int forced, bool accumulate) -> int {
+        RGMulti M;
+        memset(&M, 0, sizeof(M));
+        float *dst[PRAD_LOG_MAXSIG];
+        for (int q = 0; q < nsig; q++) {
+          M.k[q] = rgauss_coefficients(sigmas[q], spacing[ax], order, normalize != 0);
+          dst[q] = forced ? bufC[q] : (flip ? bufB[q] : bufA[q]);
+          M.in[q] = cur[q];
+          M.scratch[q] = scratch[q];
+          M.out[q] = dst[q];
+          M.acc[q] = accumulate ? outs[q] : nullptr;
+        }
         long long outer = 1;
         for (int d = 0; d < ax; d++) outer *= g.size[d];
         const long long inner = g.stride[ax];
         const long long lines = outer * inner;
-        float *dst = forced_dst ? forced_dst : pp[flip];
-        float *acc = accumulate ? out : nullptr;
         const double sp2 = spacing[ax] * spacing[ax];
-        const bool accload = acc != nullptr && !first;
+        const bool accload = accumulate && !first;
         if (inner == 1 && g.size[ax] >= 64 && !getenv("PRAD_LOG_NO_SPLIT")) {   // contiguous axis, two waves per 64 lines (kernels_filters.h)
-#define PRAD_XL2(W, TL, AM) hipLaunchKernelGGL((rgauss_xline2_kernel<W, TL, AM>), dim3((unsigned)((lines + TL - 1) / TL)), dim3(128), 0, s, cur, lines, g.size[ax], k, scratch, dst, acc, sp2)
-#define PRAD_XL2W(W, TL) do { if (!acc) PRAD_XL2(W, TL, 0); else if (first) PRAD_XL2(W, TL, 1); else PRAD_XL2(W, TL, 2); } while (0)
+#define PRAD_XL2(W, TL, AM) hipLaunchKernelGGL((rgauss_xline2_kernel<W, TL, AM>), dim3((unsigned)((lines + TL - 1) / TL), (unsigned)nsig), dim3(128), 0, s, M, lines, g.size[ax], sp2)
+#define PRAD_XL2W(W, TL) do { if (!accumulate) PRAD_XL2(W, TL, 0); else if (first) PRAD_XL2(W, TL, 1); else PRAD_XL2(W, TL, 2); } while (0)
           // tile = 16 samples x 64 lines per wave; measured at 256^3: 176 us, against 191 us for 32 x 64 (50 KB of LDS per
           // workgroup) and 265 us for 32 x 32 (128-byte row pieces, twice the waves, half the lanes recursing)
           static const int xl_mode = getenv("PRAD_LOG_XL") ? atoi(getenv("PRAD_LOG_XL")) : 0;   // tuning override
@@ -1673,47 +1690,50 @@ int log_dev(const float *in, const int *size, int Nd, const double *spacing, dou
 #undef PRAD_XL2
           PRAD_TRY(check_launch("rgauss_xline2_kernel"));
         } else if (inner == 1 && g.size[ax] >= 8) {      // contiguous axis: LDS-tiled walk (see kernels_filters.h; a lane-per-line walk of this axis measured 343 us instead of 294 at 256^3)
-          hipLaunchKernelGGL(rgauss_xline_kernel, dim3((unsigned)((lines + PRAD_RG_T - 1) / PRAD_RG_T)), dim3(64), 0, s, cur,
-                             lines, g.size[ax], k, scratch, dst, acc, sp2, first ? 1 : 0);
+          for (int q = 0; q < nsig; q++)
+            hipLaunchKernelGGL(rgauss_xline_kernel, dim3((unsigned)((lines + PRAD_RG_T - 1) / PRAD_RG_T)), dim3(64), 0, s, M.in[q],
+                               lines, g.size[ax], M.k[q], M.scratch[q], M.out[q], M.acc[q], sp2, first ? 1 : 0);
           PRAD_TRY(check_launch("rgauss_xline_kernel"));
         } else if (!getenv("PRAD_LOG_OLDLINE")) {   // strided axis: no float64 copy of the causal pass (kernels_filters.h)
-          const unsigned gx = (unsigned)((lines + 255) / 256);
-          if (!acc)
-            hipLaunchKernelGGL(rgauss_line2_kernel<0>, dim3(gx), dim3(256), 0, s, cur, outer, g.size[ax], inner, k, scratch, dst, acc, sp2);
+          const dim3 grid((unsigned)((lines + 255) / 256), (unsigned)nsig);
+          if (!accumulate)
+            hipLaunchKernelGGL(rgauss_line2_kernel<0>, grid, dim3(256), 0, s, M, outer, g.size[ax], inner, sp2);
           else if (first)
-            hipLaunchKernelGGL(rgauss_line2_kernel<1>, dim3(gx), dim3(256), 0, s, cur, outer, g.size[ax], inner, k, scratch, dst, acc, sp2);
+            hipLaunchKernelGGL(rgauss_line2_kernel<1>, grid, dim3(256), 0, s, M, outer, g.size[ax], inner, sp2);
           else
-            hipLaunchKernelGGL(rgauss_line2_kernel<2>, dim3(gx), dim3(256), 0, s, cur, outer, g.size[ax], inner, k, scratch, dst, acc, sp2);
+            hipLaunchKernelGGL(rgauss_line2_kernel<2>, grid, dim3(256), 0, s, M, outer, g.size[ax], inner, sp2);
           PRAD_TRY(check_launch("rgauss_line2_kernel"));
         } else {
-          if (accload)
-            hipLaunchKernelGGL(rgauss_line_kernel<true>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, cur, outer,
-                               g.size[ax], inner, k, scratch, dst, acc, sp2, 0);
-          else
-            hipLaunchKernelGGL(rgauss_line_kernel<false>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, cur, outer,
-                               g.size[ax], inner, k, scratch, dst, acc, sp2, first ? 1 : 0);
+          for (int q = 0; q < nsig; q++) {
+            if (accload)
+              hipLaunchKernelGGL(rgauss_line_kernel<true>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, M.in[q], outer,
+                                 g.size[ax], inner, M.k[q], M.scratch[q], M.out[q], M.acc[q], sp2, 0);
+            else
+              hipLaunchKernelGGL(rgauss_line_kernel<false>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, M.in[q], outer,
+                                 g.size[ax], inner, M.k[q], M.scratch[q], M.out[q], M.acc[q], sp2, first ? 1 : 0);
+          }
           PRAD_TRY(check_launch("rgauss_line_kernel"));
         }
-        cur = dst;
-        if (!forced_dst) flip ^= 1;
+        for (int q = 0; q < nsig; q++) cur[q] = dst[q];
+        if (!forced) flip ^= 1;
         return PRAD_OK;
       };
       bool first_pass = true;
       for (int other = Nd - 1; other >= 0; other--) {
         if (other == dim) continue;
         if (first_pass && Nd >= 3 && other == Nd - 1) {     // smoothing of the INPUT along the last axis: shared
-          if (shared_axis != other) {
-            PRAD_TRY(pass(other, 0, bufC, false));
-            shared_first = bufC;
+          if (!have_shared || shared_axis != other) {
+            PRAD_TRY(pass(other, 0, 1, false));
+            have_shared = true;
             shared_axis = other;
           }
-          cur = shared_first;
+          for (int q = 0; q < nsig; q++) cur[q] = bufC[q];
         } else {
-          PRAD_TRY(pass(other, 0, nullptr, false));
+          PRAD_TRY(pass(other, 0, 0, false));
         }
         first_pass = false;
       }
-      PRAD_TRY(pass(dim, 2, nullptr, true));
+      PRAD_TRY(pass(dim, 2, 0, true));
       first = false;
     }
   }
@@ -1721,6 +1741,12 @@ int log_dev(const float *in, const int *size, int Nd, const double *spacing, dou
   PRAD_HIP(hipStreamSynchronize(s));
   c.last_path = "log";
   return PRAD_OK;
+}
+
+int log_dev(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize, float *out,
+            hipStream_t s) {
+  if (!out) return fail(PRAD_E_ARG, "log: NULL pointer");
+  return log_multi_dev(in, size, Nd, spacing, &sigma, 1, normalize, &out, s);
 }
 
 }  // namespace
@@ -2446,6 +2472,10 @@ int prad_swt_level1(const double *in, const int *size, int Nd, const double *dec
   int rc = swt_level1_dev(d_in, size, Nd, dec_lo, dec_hi, flen, axes, naxes, d_out, c.own_stream);
   if (rc != PRAD_OK) return rc;
   return copy_back(c, out, d_out, nout);
+}
+int prad_log_multi_dev(const float *in, const int *size, int Nd, const double *spacing, const double *sigmas, int nsig,
+                       int normalize, float *const *outs, void *stream) {
+  return log_multi_dev(in, size, Nd, spacing, sigmas, nsig, normalize, outs, (hipStream_t)stream);
 }
 int prad_log_dev(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
                  float *out, void *stream) {

@@ -787,6 +787,27 @@ def wavelet_images(image: torch.Tensor, wavelet="coif1"):
     return out
 
 
+def log_images(image: torch.Tensor, spacing_xyz, sigmas, normalize: bool = True) -> list:
+    """log_image for a list of sigmas, up to 8 per launch sequence (prad_log_multi_dev): the same bits per sigma, the
+    sigmas share the GPU (256^3: one sigma is ONE wave per SIMD and latency-bound)"""
+    lib = _lib.load()
+    x = image.to(torch.float32).contiguous()
+    lib.prad_set_device(x.device.index or 0)
+    size = np.array(x.shape, dtype=np.intc)
+    sp = np.array([float(s) for s in spacing_xyz][::-1], dtype=np.float64)
+    outs = []
+    sig = [float(s) for s in sigmas]
+    for lo in range(0, len(sig), 8):
+        part = np.array(sig[lo:lo + 8], dtype=np.float64)
+        res = [torch.empty_like(x) for _ in part]
+        ptrs = (C.c_void_p * len(res))(*[r.data_ptr() for r in res])
+        rc = lib.prad_log_multi_dev(C.c_void_p(x.data_ptr()), _iptr(size), x.dim(), C.c_void_p(sp.ctypes.data),
+                                    C.c_void_p(part.ctypes.data), len(res), 1 if normalize else 0, ptrs, _stream_ptr())
+        _lib.raise_for(rc, "LoG")
+        outs.extend(res)
+    return outs
+
+
 def log_image(image: torch.Tensor, spacing_xyz, sigma: float, normalize: bool = True) -> torch.Tensor:
     """sitk.LaplacianRecursiveGaussianImageFilter on the device: float32 tensor"""
     lib = _lib.load()

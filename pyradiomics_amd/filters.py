@@ -158,13 +158,19 @@ def getLoGImage(inputImage, inputMask, **kwargs):
     if np.min(size) < 4:
         logger.warning("Image too small to apply LoG filter, size: %s", size)
         return
+    ready = {}
+    if on_dev:      # every admissible sigma in the same launches (engine.log_images), yielded in the reference's order below
+        from . import engine
+        ok = [s for s in kwargs.get("sigma", []) if s > 0.0 and np.all(size >= np.ceil(s / spacing) + 1)]
+        ok = list(dict.fromkeys(ok))
+        if ok:
+            ready = dict(zip(ok, engine.log_images(ref.device_tensor(), spacing, ok, True)))
     for sigma in kwargs.get("sigma", []):
         if sigma > 0.0:
             if np.all(size >= np.ceil(sigma / spacing) + 1):
                 name = "log-sigma-%s-mm-3D" % str(sigma).replace(".", "-")
                 if on_dev:
-                    from . import engine
-                    yield ref.like(tensor=engine.log_image(ref.device_tensor(), spacing, sigma, True)), name, kwargs
+                    yield ref.like(tensor=ready[sigma]), name, kwargs
                 else:
                     yield ref.like(laplacian_recursive_gaussian(ref.array, spacing, sigma, True)), name, kwargs
             else:

@@ -26,6 +26,12 @@ engine.swt_level1 = timed("swt", engine.swt_level1)
 engine.bin_image = timed("  (bin_image inside init)", engine.bin_image)
 engine.firstorder_stats = timed("  (firstorder_stats inside execute)", engine.firstorder_stats)
 engine.glszm_compact = timed("  (glszm_compact inside execute)", engine.glszm_compact)
+for fn in ("glcm_glrlm", "deferred_join", "glcm_features", "glcm_mcc", "zone_matrix_features", "gldm", "ngtdm", "ngtdm_features",
+           "glszm_features", "result_array", "deferred_mark", "deferred_wait", "roi_minmax", "_neigh_common", "_prep"):
+    if hasattr(engine, fn):
+        setattr(engine, fn, timed("    engine." + fn, getattr(engine, fn)))
+cmatrices._build_angles = timed("    cmatrices._build_angles", cmatrices._build_angles)
+engine._build_angles = timed("    engine._build_angles", engine._build_angles)
 N = 256
 mask = np.zeros((N, N, N), dtype=np.int16)
 zz, yy, xx = np.ogrid[:N, :N, :N]

@@ -250,3 +250,19 @@ def test_bspline_resample_device_route_clamps_to_the_original_pixel_type(dtype):
     got = dev_i.array.astype(np.int64)
     assert got.min() >= np.iinfo(dtype).min and got.max() <= hi
     assert np.array_equal(got, host_i.array.astype(np.int64)) and np.array_equal(dev_m.array, host_m.array)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,spacing", [((70, 66, 130), (1.0, 1.0, 1.0)), ((9, 14, 16), (1.0, 1.0, 2.5)),
+                                           ((37, 53, 70), (0.7, 0.9, 3.0)), ((5, 4, 9), (1.0, 1.0, 1.0)), ((40, 72), (1.0, 1.5))])
+def test_log_of_several_sigmas_in_one_launch_sequence_equals_one_at_a_time(shape, spacing):
+    """prad_log_multi_dev (blockIdx.y = sigma) leaves the bits of prad_log_dev per sigma; more than 8 sigmas are split
+    (imageoperations.py:806-836 loops over the sigma list one filter run at a time)"""
+    import torch
+    from pyradiomics_amd import engine
+    x = torch.from_numpy(np.random.default_rng(8).integers(-200, 1500, size=shape).astype(np.int16)).cuda()
+    sig = [0.5, 1.0, 1.7, 2.0, 3.0, 4.0, 5.0, 6.5, 2.5, 1.0]
+    many = engine.log_images(x, spacing, sig)
+    assert len(many) == len(sig)
+    for s, got in zip(sig, many):
+        assert torch.equal(got, engine.log_image(x, spacing, s)), s
