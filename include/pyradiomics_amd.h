@@ -194,6 +194,13 @@ int prad_calculate_ngtdm_dev(const int32_t *image, const uint8_t *mask, const in
                              const int *angles, int Na, int Ng,
                              int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
                              double *ngtdm, void *stream);
+/* GLDM (cmatrices.c:568-648) and NGTDM (cmatrices.c:650-745) of one segment from ONE pass over the 26 / 8 neighbours
+ * (both matrices look at the same neighbourhood; the case pipeline asks for both): device pointers, the bidirectional
+ * angle set both classes use, gldm float64 [Ng][2 Na + 1], ngtdm float64 [Ng][3].  Falls back to the two separate calls
+ * where the packed-byte kernel does not apply (alpha != 0, rows not a multiple of 4 voxels, Nd > 3).  Deferred mode:
+ * enqueue only, as prad_calculate_gldm_dev. */
+int prad_calculate_gldm_ngtdm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                                  int Na, int Ng, int alpha, double *gldm, double *ngtdm, void *stream);
 
 /* ---- one large segment over several GPUs: plane-range accumulators of GLDM / NGTDM ------------------
  * (no reference analogue; SURVEY 8e "one exchange step": GLDM / NGTDM histograms are additive over centre

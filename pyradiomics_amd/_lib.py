@@ -79,6 +79,7 @@ SYMBOLS = {
     "prad_zone_matrix_features_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_longlong,
                                                 C.POINTER(C.c_double), C.POINTER(C.c_double), _ip, _vp]),
     "prad_ngtdm_features_dev": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), _vp]),
+    "prad_calculate_gldm_ngtdm_dev": (C.c_int, [_vp, _vp, _ip, C.c_int, _ip, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "prad_glszm_features_dev": (C.c_int, [_vp, _vp, _ip, C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _ip,
                                           _vp]),
     "prad_resample_dev": (C.c_int, [_vp, C.c_int, _ip, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _ip, C.c_int,

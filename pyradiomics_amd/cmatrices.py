@@ -17,6 +17,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -73,6 +75,27 @@ def _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, want, deferred=F
     if memo is not None:
         memo[key] = res
     return res
+
+
+def _dev_gldm_ngtdm(image, mask, Ng, alpha, dist, force2D, force2Ddimension, deferred):
+    """(GLDM, NGTDM) device matrices of a segment.  On tensors pyradiomics_amd.base tagged (all feature classes of one
+    derived image share them) both come from ONE pass over the neighbourhoods (engine.gldm_ngtdm) and are kept for the
+    other class; alpha = None: the caller only wants NGTDM (the fused pass runs with the default alpha 0)"""
+    from . import engine
+    f2d = int(force2Ddimension) if force2D else -1
+    memo = _memo(image, mask)
+    a = 0 if alpha is None else int(alpha)
+    key = ("gldm_ngtdm", int(Ng), f2d, tuple(dist), a)
+    if memo is not None and not os.environ.get("PRAD_NO_FUSED_NEIGH"):
+        for k, v in memo.items():          # NGTDM does not depend on alpha: any fused result of this geometry serves it
+            if isinstance(k, tuple) and k[:4] == key[:4] and (alpha is None or k[4] == a):
+                return v
+        res = engine.gldm_ngtdm(image, mask, int(Ng), a, dist, force2D, force2Ddimension, deferred=deferred)
+        memo[key] = res
+        return res
+    if alpha is None:
+        return None, engine.ngtdm(image, mask, int(Ng), dist, force2D, force2Ddimension, deferred=deferred)
+    return engine.gldm(image, mask, int(Ng), a, dist, force2D, force2Ddimension, deferred=deferred), None
 
 
 def _iptr(a):
@@ -425,7 +448,7 @@ def segment_features_enqueue(cls, image, mask, Ng, features, distances=(1,), for
         r = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glrlm", deferred=dfr)["glrlm_dev"]
         pair = engine.zone_matrix_features(r, np.arange(1, r.shape[1] + 1), deferred=dfr)
     elif cls == "gldm":
-        P = engine.gldm(image, mask, int(Ng), int(alpha), dist, force2D, force2Ddimension, deferred=dfr)
+        P = _dev_gldm_ngtdm(image, mask, Ng, alpha, dist, force2D, force2Ddimension, dfr)[0]
         pair = engine.zone_matrix_features(P, np.arange(1, P.shape[1] + 1), deferred=dfr)
     elif cls == "glszm":
         def three_calls():
@@ -446,7 +469,7 @@ def segment_features_enqueue(cls, image, mask, Ng, features, distances=(1,), for
             return named(vals[:16])
         return finish
     elif cls == "ngtdm":
-        vals = engine.ngtdm_features(engine.ngtdm(image, mask, int(Ng), dist, force2D, force2Ddimension, deferred=dfr),
+        vals = engine.ngtdm_features(_dev_gldm_ngtdm(image, mask, Ng, None, dist, force2D, force2Ddimension, dfr)[1],
                                      deferred=dfr)
         return lambda: named(vals)
     else:

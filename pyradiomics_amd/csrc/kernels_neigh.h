@@ -102,19 +102,21 @@ __device__ __forceinline__ unsigned nonzero_bytes3(unsigned w) {  // bit 7 of ev
   return (((w & 0x7f7f7fu) + 0x7f7f7fu) | w) & 0x808080u;
 }
 
-template <bool NGTDM>
+// MODE: 0 = GLDM (alpha = 0), 1 = NGTDM, 2 = both from the same neighbourhood reads (the case pipeline asks for both)
+template <int MODE>
 __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t *__restrict__ L, int Nz, int Ny,
                                                      int Nx, int zlo, int zhi, int Ng, int Na,
                                                      u32 *__restrict__ gldm_acc, u64 *__restrict__ ngtdm_acc,
                                                      const int *__restrict__ flags) {
   extern __shared__ u64 lds64[];
   if (flags[0]) return;
+  constexpr bool NGTDM = MODE != 0, GLDM = MODE != 1;
   const int W = Na + 1;
-  u32 *h32 = reinterpret_cast<u32 *>(lds64);
   const int nbins = Ng * W;
+  u32 *h32 = reinterpret_cast<u32 *>(MODE == 2 ? lds64 + nbins : lds64);     // (both: u64 table, then the u32 table)
   for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
     if (NGTDM) lds64[i] = 0;
-    else h32[i] = 0;
+    if (GLDM) h32[i] = 0;
   }
   __syncthreads();
   const int qpr = Nx >> 2;                      // quads per row
@@ -134,7 +136,7 @@ __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t 
     const int z = (int)(row / Ny), y = (int)(row - (long long)z * Ny);
     const unsigned centre = live ? *reinterpret_cast<const unsigned *>(L + row * Nx + x0) : 0u;
     if (__ballot(centre != 0) == 0) continue;   // no ROI voxel in these 256 columns (wave-uniform)
-    int sum[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0};   // GLDM: cnt = dependence
+    int sum[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0}, dep[4] = {0, 0, 0, 0};
     unsigned crep[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) crep[k] = ((centre >> (8 * k)) & 0xffu) * 0x010101u;
@@ -159,9 +161,10 @@ __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t 
         if (NGTDM) {
           sum[k] = (int)__builtin_amdgcn_sad_u8(w, 0u, (unsigned)sum[k]);
           cnt[k] += __popc(nonzero_bytes3(w));
-        } else {
+        }
+        if (GLDM) {
           // excluded positions are 0 in w, hence non-zero after the xor with a non-zero centre: never "equal"
-          cnt[k] += 3 - __popc(nonzero_bytes3(w ^ crep[k]));
+          dep[k] += 3 - __popc(nonzero_bytes3(w ^ crep[k]));
         }
       }
     }
@@ -177,9 +180,8 @@ __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t 
           d = d < 0 ? -d : d;
           if (d) atomicAdd(rowp + cnt[k], (u64)d);
         }
-      } else {
-        atomicAdd(&h32[(c - 1) * W + cnt[k]], 1u);
       }
+      if (GLDM) atomicAdd(&h32[(c - 1) * W + dep[k]], 1u);
     }
   }
   __syncthreads();
@@ -187,7 +189,8 @@ __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t 
     if (NGTDM) {
       const u64 v = lds64[i];
       if (v) atomicAdd(ngtdm_acc + i, v);
-    } else {
+    }
+    if (GLDM) {
       const u32 v = h32[i];
       if (v) atomicAdd(gldm_acc + i, v);
     }
@@ -335,6 +338,40 @@ inline int neigh_finalize_ngtdm(Context *c, hipStream_t s, const u64 *acc, int N
   Timed t(*c, "finalize", s);
   hipLaunchKernelGGL(ngtdm_finalize_kernel, dim3((unsigned)((Ng + 63) / 64)), dim3(64), 0, s, acc, Ng, Na, out);
   return check_launch("ngtdm_finalize_kernel");
+}
+
+// GLDM (alpha = 0) and NGTDM of the whole volume from ONE pass over the packed levels; *done = false: not a case for the
+// packed-byte kernel, the caller takes the two separate calls
+inline int neigh_try_both(Context *c, hipStream_t s, const Geo &g, const VoxMode &vm, const int32_t *image,
+                          const uint8_t *mask, const int *angles_h, int Na, int Ng, int alpha, double *gldm_out,
+                          double *ngtdm_out, int *flags_d, bool *done) {
+  *done = false;
+  NeighPlan p = plan_neigh(g, vm, angles_h, Na, Ng, sizeof(u64) + sizeof(u32));
+  RowMasks R;
+  if (!p.ok || alpha != 0 || (p.Nx & 3) != 0 || !row_masks_from(p.set, &R)) return PRAD_OK;
+  uint8_t *levels = nullptr;
+  PRAD_TRY(neigh_pack(c, s, g, p, 0, p.Nz, image, mask, Ng, flags_d, &levels));
+  const size_t nacc = (size_t)Ng * (Na + 1);
+  u32 *acc32 = nullptr;
+  u64 *acc64 = nullptr;
+  PRAD_TRY(c->get<u64>("ngtdm_acc", nacc, &acc64));
+  PRAD_TRY(c->get<u32>("gldm_acc", nacc, &acc32));
+  PRAD_HIP(hipMemsetAsync(acc64, 0, sizeof(u64) * nacc, s));
+  PRAD_HIP(hipMemsetAsync(acc32, 0, sizeof(u32) * nacc, s));
+  {
+    Timed t(*c, "neigh", s);
+    static const int cap = getenv("PRAD_NEIGH_BLOCKS") ? atoi(getenv("PRAD_NEIGH_BLOCKS")) : 1536;
+    static const int bt = getenv("PRAD_NEIGH_THREADS") ? atoi(getenv("PRAD_NEIGH_THREADS")) : 512;
+    const long long ncent = (long long)p.Nz * p.Ny * p.Nx;
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((ncent >> 2) + bt - 1) / bt, cap));
+    hipLaunchKernelGGL((neigh4_kernel<2>), dim3(gx), dim3(bt), (sizeof(u64) + sizeof(u32)) * nacc, s, R, levels, p.Nz, p.Ny,
+                       p.Nx, 0, p.Nz, Ng, Na, acc32, acc64, flags_d);
+    PRAD_TRY(check_launch("neigh4_kernel"));
+  }
+  PRAD_TRY(neigh_finalize_gldm(c, s, acc32, Ng, Na, gldm_out));
+  PRAD_TRY(neigh_finalize_ngtdm(c, s, acc64, Ng, Na, ngtdm_out));
+  *done = true;
+  return PRAD_OK;
 }
 
 inline int neigh_try_gldm(Context *c, hipStream_t s, const Geo &g, const VoxMode &vm, const int32_t *image,

@@ -1087,6 +1087,39 @@ int texture_ngtdm(const int32_t *image, const uint8_t *mask, const int *size, in
   return k.flags_h[1] ? PRAD_INDEX_ERROR : PRAD_OK;
 }
 
+// GLDM and NGTDM of a segment from one pass over the neighbourhoods (segment mode; prad_calculate_gldm_ngtdm_dev)
+int texture_gldm_ngtdm(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
+                       int Ng, int alpha, double *gldm, double *ngtdm, hipStream_t s) {
+  if (!gldm || !ngtdm) return fail(PRAD_E_ARG, "gldm / ngtdm is NULL");
+  if (Ng < 1) return fail(PRAD_E_ARG, "Ng must be >= 1");
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  bool done = false;
+  {
+    Call k;
+    PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, 1, nullptr, 0, -1, s));
+    PRAD_TRY(c.begin_call(s));
+    PRAD_TRY(neigh_try_both(k.c, k.s, k.g, k.vm, k.image, k.mask, k.angles_h, k.Na, Ng, alpha, gldm, ngtdm, k.flags_d, &done));
+    if (done && c.deferred) {   // enqueue only: the flags are latched for prad_deferred_status()
+      PRAD_TRY(latch_neigh(c, k));
+      c.last_path = "neigh";
+      return c.end_call(s);
+    }
+    if (done) {
+      PRAD_TRY(read_flags(k));
+      done = (k.flags_h[0] == 0);
+      if (done) {
+        c.last_path = "neigh";
+        PRAD_TRY(c.end_call(s));
+        return k.flags_h[1] ? PRAD_INDEX_ERROR : PRAD_OK;
+      }
+    }
+  }
+  // not a volume for the packed-byte kernel (or irregular levels: the exact kernels say what the reference says)
+  PRAD_TRY(texture_gldm(image, mask, size, Nd, angles, Na, Ng, alpha, 1, nullptr, 0, -1, gldm, s));
+  return texture_ngtdm(image, mask, size, Nd, angles, Na, Ng, 1, nullptr, 0, -1, ngtdm, s);
+}
+
 // z-slab split of one large segment over several GPUs: integer accumulators of a plane range, summed by the
 // caller across ranks (RCCL all-reduce of [Ng][Na+1] int64), then finalized once
 int neigh_accumulate_i64(int family, const int32_t *image, const uint8_t *mask, const int *size, int Nd,
@@ -2102,6 +2135,11 @@ int prad_calculate_gldm(const int32_t *image, const uint8_t *mask, const int *si
                         force2Ddim, d, c.own_stream);
   if (rc != PRAD_OK) return rc;
   return copy_back(c, gldm, d, n);
+}
+
+int prad_calculate_gldm_ngtdm_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
+                                  int Na, int Ng, int alpha, double *gldm, double *ngtdm, void *stream) {
+  return texture_gldm_ngtdm(image, mask, size, Nd, angles, Na, Ng, alpha, gldm, ngtdm, (hipStream_t)stream);
 }
 
 // ---- NGTDM ----------------------------------------------------------------------------------

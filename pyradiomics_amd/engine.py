@@ -462,6 +462,24 @@ def ngtdm(image: torch.Tensor, mask: torch.Tensor, Ng: int, distances=(1,), forc
     return out
 
 
+def gldm_ngtdm(image: torch.Tensor, mask: torch.Tensor, Ng: int, alpha: int = 0, distances=(1,), force2D: bool = False,
+               force2Ddimension: int = 0, deferred: bool = False):
+    """(GLDM [Ng, 2*Na+1], NGTDM [Ng, 3]) of one segment from ONE pass over the neighbourhoods
+    (prad_calculate_gldm_ngtdm_dev); deferred=True: see gldm"""
+    lib, image, mask, size, f2d, angles = _neigh_common(image, mask, list(distances), force2D, force2Ddimension)
+    Na, Nd = angles.shape
+    g = torch.empty((Ng, 2 * Na + 1), dtype=torch.float64, device=image.device)
+    n = torch.empty((Ng, 3), dtype=torch.float64, device=image.device)
+    with _Deferred(lib, deferred):
+        rc = lib.prad_calculate_gldm_ngtdm_dev(C.c_void_p(image.data_ptr()), C.c_void_p(mask.data_ptr()), _iptr(size), Nd,
+                                               _iptr(angles), Na, int(Ng), int(alpha), C.c_void_p(g.data_ptr()),
+                                               C.c_void_p(n.data_ptr()), _stream_ptr())
+    _lib.raise_for(rc, "GLDM+NGTDM")
+    if deferred:
+        _deferred_keep.append((image, mask, g, n))
+    return g, n
+
+
 NEIGH_GLDM, NEIGH_NGTDM = 0, 1
 
 

@@ -444,3 +444,23 @@ def test_glszm_features_one_queue_equals_three_calls(shape, ng, kind):
         v, _ = engine.glszm_features(L, M, ng, max(1, Ns // 64), deferred=True)
         engine.deferred_status()
         assert int(v[16]) & 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,alpha,f2d", [((20, 24, 64), 0, False), ((7, 33, 40), 0, True), ((12, 18, 30), 0, False),
+                                             ((16, 16, 32), 1, False), ((1, 40, 48), 0, False)])
+def test_gldm_and_ngtdm_from_one_pass_equal_the_separate_calls(shape, alpha, f2d):
+    """prad_calculate_gldm_ngtdm_dev (one pass over the neighbourhoods, neigh4_kernel<2>) against prad_calculate_gldm_dev and
+    prad_calculate_ngtdm_dev, bit for bit; rows that are no multiple of 4 voxels and alpha != 0 take the two calls inside"""
+    import torch
+    from pyradiomics_amd import engine
+    rng = np.random.default_rng(21)
+    dev = torch.device("cuda", 0)
+    lev = torch.from_numpy(rng.integers(1, 13, size=shape).astype(np.int32)).to(dev)
+    msk = torch.from_numpy((rng.random(shape) < 0.8).astype(np.uint8)).to(dev)
+    g, n = engine.gldm_ngtdm(lev, msk, 12, alpha, (1,), f2d, 0)
+    assert torch.equal(g, engine.gldm(lev, msk, 12, alpha, (1,), f2d, 0))
+    assert torch.equal(n, engine.ngtdm(lev, msk, 12, (1,), f2d, 0))
+    g2, n2 = engine.gldm_ngtdm(lev, msk, 12, alpha, (1,), f2d, 0, deferred=True)
+    engine.deferred_status()
+    assert torch.equal(g2, g) and torch.equal(n2, n)
