@@ -134,6 +134,9 @@ def _parse_voxels(voxels, Nd, kernelRadius):
     return v, int(v.shape[1])
 
 
+_angle_memo: dict = {}
+
+
 def _build_angles(size, distances, bidirectional, force2Ddim):
     """_cmatrices.c:926-1021 (build_angles_arr) on prad_get_angle_count / prad_build_angles."""
     lib = _lib.load()
@@ -147,6 +150,10 @@ def _build_angles(size, distances, bidirectional, force2Ddim):
         if dist.ndim != 1:
             raise ValueError("Expecting distances array to be 1-dimensional.")
     Nd = int(size.shape[0])
+    key = (size.tobytes(), dist.tobytes(), bool(bidirectional), int(force2Ddim))
+    hit = _angle_memo.get(key)         # (27 calls per case with 5 distinct answers; the table is never written to)
+    if hit is not None:
+        return hit
     Na = lib.prad_get_angle_count(_iptr(size), _iptr(dist), Nd, int(dist.shape[0]), int(bool(bidirectional)),
                                   int(force2Ddim)) if dist.shape[0] > 0 else 0
     if Na == 0:
@@ -154,6 +161,10 @@ def _build_angles(size, distances, bidirectional, force2Ddim):
     angles = np.empty((Na, Nd), dtype=np.intc)
     if lib.prad_build_angles(_iptr(size), _iptr(dist), Nd, int(dist.shape[0]), int(force2Ddim), Na, _iptr(angles)) > 0:
         raise RuntimeError("Error building angles.")
+    angles.setflags(write=False)
+    if len(_angle_memo) > 256:
+        _angle_memo.clear()
+    _angle_memo[key] = angles
     return angles
 
 
@@ -523,7 +534,7 @@ def generate_angles(size, distances, bidirectional, force2D, force2Ddimension):
     size = np.ascontiguousarray(np.asarray(size).astype(np.intc, copy=False))
     if size.ndim != 1:
         raise ValueError("Expected a 1D array for size")
-    return _build_angles(size, distances, bidirectional, int(force2Ddimension) if force2D else -1)
+    return _build_angles(size, distances, bidirectional, int(force2Ddimension) if force2D else -1).copy()
 
 
 # ---- fused voxel-based GLCM features (no reference analogue: replaces calculate_glcm + numpy feature math in
