@@ -369,6 +369,16 @@ enum { PRAD_FO_NP = 0, PRAD_FO_ENERGY, PRAD_FO_MINIMUM, PRAD_FO_P10, PRAD_FO_P25
        PRAD_FO_MAXIMUM, PRAD_FO_MEAN, PRAD_FO_MAD, PRAD_FO_RMAD, PRAD_FO_M2, PRAD_FO_M3, PRAD_FO_M4, PRAD_FO_COUNT };
 int prad_firstorder_dev(const void *image, int dtype, const uint8_t *mask, long long n, double voxelArrayShift,
                         double *out, void *stream);
+/* The same statistics without a host round trip between the passes (prad_firstorder_dev has five): what the host does
+ * in between -- adding up block partials, placing the quantiles, finding the histogram bins that hold their ranks,
+ * interpolating -- runs in single-workgroup kernels on a device record, the same operations in the same order (the same
+ * bits).  float32 / float64 images with roi_count >= 2^20 ROI voxels (the caller knows the count from the level census);
+ * PRAD_E_UNSUPPORTED otherwise, before anything is launched.  out: 16 doubles -- the PRAD_FO_COUNT statistics, then a
+ * verdict (0 = fine; 1: the ROI holds a different number of voxels, 2: constant or non-finite ROI, 8: the selected
+ * histogram bins hold more than 2^18 voxels).  In deferred mode with `out` inside the result arena: enqueue only;
+ * otherwise synchronous, a non-zero verdict returns PRAD_E_UNSUPPORTED (call prad_firstorder_dev). */
+int prad_firstorder_queue_dev(const void *image, int dtype, const uint8_t *mask, long long n, long long roi_count,
+                              double voxelArrayShift, double *out, void *stream);
 /* Voxel mode (firstorder.py:37-118,104-118): for each of the Nvox centres (`voxels` DEVICE int32 [Nd][Nvox]) the
  * window centre + {offsets of infinity-norm <= kernelRadius} -- per dimension limited to |offset| < bbsize[d] (HOST,
  * the `boundingBoxSize` of firstorder.py:45-58; NULL = no limit) and 0 in the force2D dimension -- is reduced over

@@ -85,6 +85,8 @@ SYMBOLS = {
     "prad_resample_dev": (C.c_int, [_vp, C.c_int, _ip, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _ip, C.c_int,
                                     _vp, _vp]),
     "prad_firstorder_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_double, C.POINTER(C.c_double), _vp]),
+    "prad_firstorder_queue_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_longlong, C.c_double, C.POINTER(C.c_double),
+                                            _vp]),
     "prad_voxel_firstorder_dev": (C.c_int, [_vp, C.c_int, _vp, _vp, _ip, C.c_int, C.c_int, _vp, C.c_int, C.c_int, _ip,
                                             C.c_double, C.c_double, _ip, C.c_int, _vp, _vp]),
     "prad_level_counts_dev": (C.c_int, [_vp, _vp, C.c_longlong, C.c_int, C.POINTER(C.c_longlong), _vp]),

@@ -372,37 +372,50 @@ def segment_features(cls, image, mask, Ng, features, distances=(1,), force2D=Fal
                                     symmetrical, Ns, deferred=False)()
 
 
+SEGMENT_QUEUES = {"glcm": 0, "glrlm": 0, "gldm": 0, "ngtdm": 0, "glszm": 1, "firstorder": 2}
+
+
 def segment_sync():
     """waits for everything segment_features_enqueue queued (inside segment_queue()); False when a queued call met a level
     outside [1, Ng] under the mask (the values are void: compute synchronously, which raises what the reference raises)"""
     from . import engine, _lib
-    try:
-        with engine.side_queue(wait=False):
-            engine.deferred_status()
-    except _lib.DeferredLevelsError:
-        return False
-    return True
+    ok = True
+    for k in sorted(set(SEGMENT_QUEUES.values())):
+        try:
+            with engine.side_queue(k, wait=False):
+                engine.deferred_status()
+        except _lib.DeferredLevelsError:
+            ok = False
+    return ok
 
 
-def segment_mark():
-    """token behind everything queued inside segment_queue() so far (engine.deferred_mark on the side stream)"""
+def segment_mark(classes=None):
+    """token behind everything queued inside segment_queue() so far (engine.deferred_mark on every side stream the
+    classes use)"""
     from . import engine
-    with engine.side_queue(wait=False):
-        return engine.deferred_mark()
+    used = sorted(set(SEGMENT_QUEUES.get(c, 0) for c in (classes or SEGMENT_QUEUES)))
+    marks = []
+    for k in used:
+        with engine.side_queue(k, wait=False):
+            marks.append((k, engine.deferred_mark()))
+    return marks
 
 
 def segment_wait(token):
     """waits for the work in front of the token; False when its values are void (see segment_sync)"""
     from . import engine
-    with engine.side_queue(wait=False):
-        return engine.deferred_wait(token)
+    ok = True
+    for k, mark in token:
+        with engine.side_queue(k, wait=False):
+            ok = engine.deferred_wait(mark) and ok
+    return ok
 
 
-def segment_queue():
-    """context manager around the segment_features_enqueue calls of one derived image: they go to a side stream
+def segment_queue(cls=None):
+    """context manager around the enqueue calls of one feature class of a derived image: they go to the class's side stream
     (engine.side_queue) so that the classes evaluated synchronously meanwhile do not wait for them"""
     from . import engine
-    return engine.side_queue()
+    return engine.side_queue(SEGMENT_QUEUES.get(cls, 0))
 
 
 ENQUEUE_CLASSES = ("glcm", "glrlm", "gldm", "ngtdm", "glszm")
@@ -515,6 +528,22 @@ def firstorder_stats(image, mask, voxelArrayShift=0.0):
     (numpy arrays are uploaded, device tensors used in place)"""
     from . import engine
     return engine.firstorder_stats(_to_device(image), _to_device(mask), voxelArrayShift)
+
+
+def firstorder_stats_enqueue(image, mask, roi_count, voxelArrayShift=0.0):
+    """firstorder_stats in two halves for the case pipeline: the passes are queued on the current stream (no host round
+    trip between them, engine.firstorder_stats_queue); the returned finish() -> dict may be called once the stream has
+    been waited for and falls back to firstorder_stats when the queued chain declined (verdict word).
+    NotImplementedError: not an image for the queue (integer dtype, small ROI)."""
+    from . import engine
+    img, msk = _to_device(image), _to_device(mask)
+    vals = engine.firstorder_stats_queue(img, msk, int(roi_count), voxelArrayShift, deferred=True)
+
+    def finish():
+        if vals[15] != 0:
+            return engine.firstorder_stats(img, msk, voxelArrayShift)
+        return dict(zip(engine.FIRSTORDER_FIELDS, (float(v) for v in vals[:15])))
+    return finish
 
 
 def voxel_firstorder(image, mask, levels, voxels, kernelRadius, bbsize, force2D, force2Ddimension, voxelArrayShift,

@@ -141,9 +141,9 @@ __device__ __forceinline__ int fo_bin(double x, double lo, double scale) {
   return t >= (double)(PRAD_FO_BINS - 1) ? PRAD_FO_BINS - 1 : (int)t;
 }
 template <typename T>
-__global__ void __launch_bounds__(1024) fo_hist_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
-                                                       long long n, double lo, double scale,
-                                                       unsigned *__restrict__ hist) {
+__device__ __forceinline__ void fo_hist_body(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                             long long n, double lo, double scale,
+                                             unsigned *__restrict__ hist) {
   __shared__ unsigned h[PRAD_FO_BINS];
   for (int k = threadIdx.x; k < PRAD_FO_BINS; k += blockDim.x) h[k] = 0u;
   __syncthreads();
@@ -152,6 +152,12 @@ __global__ void __launch_bounds__(1024) fo_hist_kernel(const T *__restrict__ img
   __syncthreads();
   for (int k = threadIdx.x; k < PRAD_FO_BINS; k += blockDim.x)
     if (h[k]) atomicAdd(hist + k, h[k]);
+}
+template <typename T>
+__global__ void __launch_bounds__(1024) fo_hist_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                       long long n, double lo, double scale,
+                                                       unsigned *__restrict__ hist) {
+  fo_hist_body(img, mask, n, lo, scale, hist);
 }
 // Integer images (int16 / int32: CT, MR, level images) whose value range fits the LDS: the EXACT histogram of the ROI,
 // count of every value base .. base + R - 1.  Every first-order statistic is a function of it (sums over values
@@ -226,9 +232,9 @@ __global__ void __launch_bounds__(1024) fo_binrange_kernel(const T *__restrict__
 // their output ranges with ONE global atomic per bin (per-wave atomics on a dozen cursors serialise in L2), then
 // scatters with LDS cursors.  The order inside a bin's segment is irrelevant: the segments are sorted next.
 template <typename T>
-__global__ void __launch_bounds__(1024) fo_gather_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
-                                                         long long n, double lo, double scale, FoSel sel,
-                                                         unsigned *__restrict__ cursors, double *__restrict__ out) {
+__device__ __forceinline__ void fo_gather_body(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                               long long n, double lo, double scale, const FoSel &sel,
+                                               unsigned *__restrict__ cursors, double *__restrict__ out) {
   __shared__ unsigned cnt[PRAD_FO_MAXSEL], base[PRAD_FO_MAXSEL];
   if (threadIdx.x < PRAD_FO_MAXSEL) cnt[threadIdx.x] = 0u;
   __syncthreads();
@@ -257,12 +263,18 @@ __global__ void __launch_bounds__(1024) fo_gather_kernel(const T *__restrict__ i
     if (j >= 0) out[sel.off[j] + base[j] + atomicAdd(&cnt[j], 1u)] = x;
   });
 }
+template <typename T>
+__global__ void __launch_bounds__(1024) fo_gather_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                         long long n, double lo, double scale, FoSel sel,
+                                                         unsigned *__restrict__ cursors, double *__restrict__ out) {
+  fo_gather_body(img, mask, n, lo, scale, sel, cursors, out);
+}
 
 // partial[b][0..3] = sum |d|, d^2, d^3, d^4 with d = x - mu; [4] = count, [5] = sum of x with lo <= x <= hi
 template <typename T>
-__global__ void __launch_bounds__(256) fo_central_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
-                                                         long long n, double mu, double lo, double hi,
-                                                         double *__restrict__ partial) {
+__device__ __forceinline__ void fo_central_body(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                long long n, double mu, double lo, double hi,
+                                                double *__restrict__ partial) {
 #pragma clang fp contract(off)
   __shared__ double sh[4];
   double a1 = 0, a2 = 0, a3 = 0, a4 = 0, bc = 0, bs = 0;
@@ -288,11 +300,17 @@ __global__ void __launch_bounds__(256) fo_central_kernel(const T *__restrict__ i
     p[0] = a1; p[1] = a2; p[2] = a3; p[3] = a4; p[4] = bc; p[5] = bs;
   }
 }
+template <typename T>
+__global__ void __launch_bounds__(256) fo_central_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                         long long n, double mu, double lo, double hi,
+                                                         double *__restrict__ partial) {
+  fo_central_body(img, mask, n, mu, lo, hi, partial);
+}
 
 template <typename T>
-__global__ void __launch_bounds__(256) fo_band_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
-                                                      long long n, double mu, double lo, double hi,
-                                                      double *__restrict__ partial) {
+__device__ __forceinline__ void fo_band_body(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                             long long n, double mu, double lo, double hi,
+                                             double *__restrict__ partial) {
   __shared__ double sh[4];
   double a = 0;
   fo_scan(img, mask, 0, n, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x, [&](double x) {
@@ -300,6 +318,266 @@ __global__ void __launch_bounds__(256) fo_band_kernel(const T *__restrict__ img,
   });
   a = fo_block_sum(a, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = a;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) fo_band_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                      long long n, double mu, double lo, double hi,
+                                                      double *__restrict__ partial) {
+  fo_band_body(img, mask, n, mu, lo, hi, partial);
+}
+
+// ---- the same chain with its scalars in DEVICE memory (prad_firstorder_queue_dev: no host round trip between the passes) --
+// What the host does between the passes of prad_firstorder_dev -- add up the block partials in block order, place the
+// quantiles, find the histogram bins that hold their ranks, interpolate -- is done by single-workgroup glue kernels on an
+// FoDev record; the scan kernels read their parameters from it.  The same operations on the same operands in the same
+// order: the same bits.  `problem` != 0 (ROI count different from the caller's, constant ROI, selected bins above the
+// gather capacity) makes every later kernel a no-op; the caller repeats the image on the synchronous route.
+struct FoDev {
+  double s1, s2, vmin, vmax, cnt, mu, scale;
+  long long m;
+  long long ranks[10];
+  double gamma[5];
+  FoSel sel;
+  long long pick[10];      // index of every order statistic in the sorted gather
+  unsigned total;          // gathered elements
+  int problem;
+  double os[12], pq[5], median;
+  double cen[6], mu_band, band;
+};
+
+// numpy's linear-interpolation quantile position (prad_firstorder.hip quantile_pos) and _lerp
+__device__ __forceinline__ void fo_quantile_pos(long long m, double q, long long *prev, long long *next, double *gamma) {
+#pragma clang fp contract(off)
+  const double virt = (double)(m - 1) * q;
+  long long p = (long long)floor(virt);
+  *gamma = virt - (double)p;
+  if (p < 0) p = 0;
+  if (p > m - 1) p = m - 1;
+  *prev = p;
+  *next = p + 1 > m - 1 ? m - 1 : p + 1;
+}
+__device__ __forceinline__ double fo_lerp_np(double a, double b, double t) {
+#pragma clang fp contract(off)
+  const double d = b - a;
+  return t >= 0.5 ? b - d * (1 - t) : a + d * t;
+}
+
+// after fo_sums_kernel: block partials -> sums, extremes, count, mean, quantile ranks, histogram scale
+__global__ void fo_glue_sums_kernel(const double *__restrict__ partial, int blocks, long long expect_m, FoDev *st) {
+#pragma clang fp contract(off)
+  __shared__ double col[5];
+  __shared__ double stage[PRAD_FO_BLOCKS * 6];     // (a chain of 1024 dependent global loads per column took 167 us)
+  const int t = threadIdx.x;
+  for (int i = t; i < blocks * 5; i += blockDim.x) stage[i] = partial[i];
+  __syncthreads();
+  if (t == 0 || t == 1 || t == 4) {          // wave 0: the three sums, in block order
+    double acc = 0.0;
+    for (int b = 0; b < blocks; b++) acc += stage[b * 5 + t];
+    col[t] = acc;
+  } else if (t == 64) {                      // waves 1 and 2: the extremes (a divergent loop each would triple the chain)
+    double acc = INFINITY;
+    for (int b = 0; b < blocks; b++) acc = fmin(acc, stage[b * 5 + 2]);
+    col[2] = acc;
+  } else if (t == 128) {
+    double acc = -INFINITY;
+    for (int b = 0; b < blocks; b++) acc = fmax(acc, stage[b * 5 + 3]);
+    col[3] = acc;
+  }
+  __syncthreads();
+  if (t == 0) {
+    st->s1 = col[0]; st->s2 = col[1]; st->vmin = col[2]; st->vmax = col[3]; st->cnt = col[4];
+    const long long m = (long long)col[4];
+    st->m = m;
+    int problem = 0;
+    if (m != expect_m || m < 1) problem |= 1;
+    if (!(col[3] > col[2]) || !isfinite(col[2]) || !isfinite(col[3])) problem |= 2;
+    st->mu = m > 0 ? col[0] / (double)m : 0.0;
+    st->scale = (double)PRAD_FO_BINS / (col[3] - col[2]);
+    const double qs[5] = {0.1, 0.25, 0.5, 0.75, 0.9};
+    for (int k = 0; k < 5; k++) {
+      long long p = 0, nx = 0;
+      double g = 0;
+      if (m > 0) fo_quantile_pos(m, qs[k], &p, &nx, &g);
+      st->ranks[2 * k] = p;
+      st->ranks[2 * k + 1] = nx;
+      st->gamma[k] = g;
+    }
+    st->os[10] = col[2];
+    st->os[11] = col[3];
+    st->problem = problem;
+    st->total = 0u;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) fo_hist_dev_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                           long long n, const FoDev *__restrict__ st,
+                                                           unsigned *__restrict__ hist) {
+  if (st->problem) return;
+  fo_hist_body(img, mask, n, st->vmin, st->scale, hist);
+}
+
+// after the histogram: the bin of every rank and the rank's position inside it, the distinct bins with their segment
+// offsets (prad_firstorder_dev's host loop: ranks ascend, so do the bins)
+__global__ void __launch_bounds__(1024) fo_glue_select_kernel(const unsigned *__restrict__ hist, unsigned capacity, FoDev *st) {
+  __shared__ unsigned long long scan[1024];
+  __shared__ int rbin[10];
+  __shared__ long long rwithin[10];
+  const int t = threadIdx.x;
+  if (st->problem) return;
+  constexpr int PER = PRAD_FO_BINS / 1024;
+  unsigned h[PER];
+  unsigned long long mine = 0;
+  for (int j = 0; j < PER; j++) {
+    h[j] = hist[t * PER + j];
+    mine += h[j];
+  }
+  scan[t] = mine;
+  if (t < 10) rbin[t] = -1;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned long long v = t >= o ? scan[t - o] : 0ull;
+    __syncthreads();
+    scan[t] += v;
+    __syncthreads();
+  }
+  unsigned long long below = scan[t] - mine;      // elements in the bins before this thread's
+  for (int j = 0; j < PER; j++) {
+    const unsigned long long upto = below + h[j];
+    if (h[j])
+      for (int k = 0; k < 10; k++) {
+        const unsigned long long r = (unsigned long long)st->ranks[k];
+        if (r >= below && r < upto) {
+          rbin[k] = t * PER + j;
+          rwithin[k] = (long long)(r - below);
+        }
+      }
+    below = upto;
+  }
+  __syncthreads();
+  if (t == 0) {
+    FoSel sel;
+    sel.nsel = 0;
+    int problem = 0;
+    unsigned long long total = 0;
+    int which[10];
+    for (int k = 0; k < 10; k++) {
+      if (rbin[k] < 0) { problem |= 4; break; }
+      if (sel.nsel == 0 || sel.bin[sel.nsel - 1] != rbin[k]) {
+        sel.bin[sel.nsel] = rbin[k];
+        sel.off[sel.nsel] = (unsigned)total;
+        total += hist[rbin[k]];
+        sel.nsel++;
+      }
+      which[k] = sel.nsel - 1;
+    }
+    if (total > capacity) problem |= 8;
+    if (!problem)
+      for (int k = 0; k < 10; k++) st->pick[k] = (long long)sel.off[which[k]] + rwithin[k];
+    for (int q = sel.nsel; q < PRAD_FO_MAXSEL; q++) { sel.bin[q] = 0; sel.off[q] = 0u; }
+    st->sel = sel;
+    st->total = (unsigned)(total > capacity ? 0 : total);
+    st->problem = problem;
+  }
+}
+
+__global__ void fo_fill_inf_kernel(double *__restrict__ p, unsigned n) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = INFINITY;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(1024) fo_gather_dev_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                             long long n, const FoDev *__restrict__ st,
+                                                             unsigned *__restrict__ cursors, double *__restrict__ out) {
+  if (st->problem) return;
+  __shared__ FoSel sel;
+  if (threadIdx.x == 0) sel = st->sel;
+  __syncthreads();
+  fo_gather_body(img, mask, n, st->vmin, st->scale, sel, cursors, out);
+}
+
+// after the sort of the gathered bins: order statistics, interpolated percentiles, median
+__global__ void fo_glue_pick_kernel(const double *__restrict__ sorted, FoDev *st) {
+#pragma clang fp contract(off)
+  if (threadIdx.x != 0 || st->problem) return;
+  for (int k = 0; k < 10; k++) st->os[k] = sorted[st->pick[k]];
+  for (int k = 0; k < 5; k++) st->pq[k] = fo_lerp_np(st->os[2 * k], st->os[2 * k + 1], st->gamma[k]);
+  st->median = (st->m % 2) ? st->os[4] : (st->os[4] + st->os[5]) / 2.0;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) fo_central_dev_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                             long long n, const FoDev *__restrict__ st,
+                                                             double *__restrict__ partial) {
+  if (st->problem) return;
+  fo_central_body(img, mask, n, st->mu, st->pq[0], st->pq[4], partial);
+}
+
+__global__ void fo_glue_central_kernel(const double *__restrict__ partial, int blocks, FoDev *st) {
+#pragma clang fp contract(off)
+  const int t = threadIdx.x;
+  if (st->problem) return;
+  __shared__ double col[6];
+  __shared__ double stage[PRAD_FO_BLOCKS * 6];
+  for (int i = t; i < blocks * 6; i += blockDim.x) stage[i] = partial[i];
+  __syncthreads();
+  if (t < 6) {
+    double acc = 0;
+    for (int b = 0; b < blocks; b++) acc += stage[b * 6 + t];
+    col[t] = acc;
+  }
+  __syncthreads();
+  if (t == 0) {
+    for (int k = 0; k < 6; k++) st->cen[k] = col[k];
+    st->mu_band = col[4] > 0 ? col[5] / col[4] : 0.0;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) fo_band_dev_kernel(const T *__restrict__ img, const uint8_t *__restrict__ mask,
+                                                          long long n, const FoDev *__restrict__ st,
+                                                          double *__restrict__ partial) {
+  if (st->problem) return;
+  if (!(st->cen[4] > 0)) {
+    if (threadIdx.x == 0) partial[blockIdx.x] = 0.0;
+    return;
+  }
+  fo_band_body(img, mask, n, st->mu_band, st->pq[0], st->pq[4], partial);
+}
+
+// the 15 statistics in the order of PRAD_FO_* (include/pyradiomics_amd.h), then the verdict word
+__global__ void fo_glue_final_kernel(const double *__restrict__ partial, int blocks, const FoDev *__restrict__ st,
+                                     double *__restrict__ out) {
+#pragma clang fp contract(off)
+  __shared__ double stage[PRAD_FO_BLOCKS];
+  if (!st->problem)
+    for (int i = threadIdx.x; i < blocks; i += blockDim.x) stage[i] = partial[i];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  out[15] = (double)st->problem;
+  if (st->problem) {
+    for (int k = 0; k < 15; k++) out[k] = 0.0;
+    return;
+  }
+  double band = 0;
+  for (int b = 0; b < blocks; b++) band += stage[b];
+  const double dm = (double)st->m;
+  out[0] = dm;                         // PRAD_FO_NP
+  out[1] = st->s2;                     // ENERGY
+  out[2] = st->os[10];                 // MINIMUM
+  out[3] = st->pq[0];                  // P10
+  out[4] = st->pq[1];                  // P25
+  out[5] = st->median;                 // MEDIAN
+  out[6] = st->pq[3];                  // P75
+  out[7] = st->pq[4];                  // P90
+  out[8] = st->os[11];                 // MAXIMUM
+  out[9] = st->mu;                     // MEAN
+  out[10] = st->cen[0] / dm;           // MAD
+  out[11] = st->cen[4] > 0 ? band / st->cen[4] : __builtin_nan("");   // RMAD
+  out[12] = st->cen[1] / dm;           // M2
+  out[13] = st->cen[2] / dm;           // M3
+  out[14] = st->cen[3] / dm;           // M4
 }
 
 // ---- voxel mode (firstorder.py:37-118): one wave per centre voxel ------------------------------------------------

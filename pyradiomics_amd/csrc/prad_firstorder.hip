@@ -379,6 +379,75 @@ extern "C" int prad_firstorder_dev(const void *image, int dtype, const uint8_t *
   return PRAD_OK;
 }
 
+#define PRAD_FO_QUEUE_CAP (1u << 18)      // gathered elements the queue route sorts (2 MB); more: verdict 8, synchronous route
+
+extern "C" int prad_firstorder_queue_dev(const void *image, int dtype, const uint8_t *mask, long long n, long long roi_count,
+                                         double voxelArrayShift, double *out, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!image || !mask || !out || n < 1) return fail(PRAD_E_ARG, "firstorder: bad arguments");
+  if (n > 2147483647LL) return fail(PRAD_E_UNSUPPORTED, "firstorder: more than 2^31-1 voxels");
+  if (dtype < 0 || dtype > 3) return fail(PRAD_E_ARG, "firstorder: dtype %d", dtype);
+  static const long long select_from = getenv("PRAD_FO_SELECT_MIN") ? atoll(getenv("PRAD_FO_SELECT_MIN")) : (1LL << 20);
+  if (dtype >= 2 || roi_count < select_from)
+    return fail(PRAD_E_UNSUPPORTED, "firstorder queue: float images with %lld+ ROI voxels only (prad_firstorder_dev serves the rest)", select_from);
+  hipStream_t s = (hipStream_t)stream;
+  double *partial = nullptr, *gath = nullptr, *d_out = nullptr;
+  unsigned *hist = nullptr, *cursors = nullptr;
+  FoDev *st = nullptr;
+  const unsigned cap = PRAD_FO_QUEUE_CAP;
+  PRAD_TRY(c.get<double>("fo_partial", (size_t)PRAD_FO_BLOCKS * 8, &partial));
+  PRAD_TRY(c.get<unsigned>("fo_hist", PRAD_FO_BINS, &hist));
+  PRAD_TRY(c.get<unsigned>("fo_cursors", PRAD_FO_MAXSEL, &cursors));
+  PRAD_TRY(c.get<double>("fo_gather_q", (size_t)2 * cap, &gath));
+  PRAD_TRY(c.get<double>("fo_out_q", 16, &d_out));
+  {
+    void *p = nullptr;
+    PRAD_TRY(c.get("fo_state", sizeof(FoDev), &p));
+    st = (FoDev *)p;
+  }
+  double *gsorted = gath + cap;
+  size_t tmp_bytes = 0;
+  PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, gath, gsorted, (int)cap, 0, 64, s));
+  uint8_t *tmp = nullptr;
+  PRAD_TRY(c.get<uint8_t>("fo_sort_tmp_q", tmp_bytes + 16, &tmp));
+  PRAD_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned) * PRAD_FO_BINS, s));
+  PRAD_HIP(hipMemsetAsync(cursors, 0, sizeof(unsigned) * PRAD_FO_MAXSEL, s));
+  const int blocks = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, PRAD_FO_BLOCKS));
+  const unsigned hgx = (unsigned)std::max<long long>(1, std::min<long long>((n + 4095) / 4096, 512));
+  {
+    Timed t(c, "firstorder", s);
+    FO_DISPATCH(fo_sums_kernel, dim3(blocks), dim3(256), voxelArrayShift, partial);
+    hipLaunchKernelGGL(fo_glue_sums_kernel, dim3(1), dim3(256), 0, s, (const double *)partial, blocks, roi_count, st);
+    FO_DISPATCH(fo_hist_dev_kernel, dim3(hgx), dim3(1024), (const FoDev *)st, hist);
+    hipLaunchKernelGGL(fo_glue_select_kernel, dim3(1), dim3(1024), 0, s, (const unsigned *)hist, cap, st);
+    hipLaunchKernelGGL(fo_fill_inf_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, gath, cap);
+    FO_DISPATCH(fo_gather_dev_kernel, dim3(hgx), dim3(1024), (const FoDev *)st, cursors, gath);
+    PRAD_TRY(check_launch("firstorder queue (gather)"));
+    PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, gath, gsorted, (int)cap, 0, 64, s));
+    hipLaunchKernelGGL(fo_glue_pick_kernel, dim3(1), dim3(64), 0, s, (const double *)gsorted, st);
+    FO_DISPATCH(fo_central_dev_kernel, dim3(blocks), dim3(256), (const FoDev *)st, partial);
+    hipLaunchKernelGGL(fo_glue_central_kernel, dim3(1), dim3(256), 0, s, (const double *)partial, blocks, st);
+    FO_DISPATCH(fo_band_dev_kernel, dim3(blocks), dim3(256), (const FoDev *)st, partial);
+    hipLaunchKernelGGL(fo_glue_final_kernel, dim3(1), dim3(256), 0, s, (const double *)partial, blocks, (const FoDev *)st, d_out);
+    PRAD_TRY(check_launch("firstorder queue"));
+  }
+  c.last_path = "firstorder-queue";
+  const size_t nb = sizeof(double) * 16;
+  if (c.deferred && c.in_arena(out, nb)) {
+    PRAD_HIP(hipMemcpyAsync(out, d_out, nb, hipMemcpyDeviceToHost, s));
+    return PRAD_OK;
+  }
+  void *pin = nullptr;
+  PRAD_TRY(c.get_pinned("fo_out_pin", nb, &pin));
+  PRAD_HIP(hipMemcpyAsync(pin, d_out, nb, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  memcpy(out, pin, nb);
+  if (out[15] != 0.0)
+    return fail(PRAD_E_UNSUPPORTED, "firstorder queue: verdict %d (ROI count, constant ROI or gather capacity); use prad_firstorder_dev", (int)out[15]);
+  return PRAD_OK;
+}
+
 extern "C" int prad_voxel_firstorder_dev(const void *image, int dtype, const uint8_t *mask, const int32_t *levels,
                                          const int *size, int Nd, int Nvox, const int *voxels, int kernelRadius,
                                          int force2Ddim, const int *bbsize, double voxelArrayShift, double voxelVolume,

@@ -87,18 +87,20 @@ _side_streams: dict = {}
 
 
 class side_queue:
-    """`with side_queue():` -- calls inside go to a side stream of the current device (one per host thread) that first
-    waits for everything queued on the current stream, under the library's workspace set 1 (prad_set_workspace): the case
-    pipeline queues GLCM / GLRLM / GLDM / NGTDM there while first order and GLSZM, which talk to the host between their
-    kernels, keep the main stream.  wait=False: enter the same stream without the dependency (to synchronise it)."""
+    """`with side_queue(k):` -- calls inside go to side stream k (0..2) of the current device (one set per host thread) that
+    first waits for everything queued on the current stream, under the library's workspace set k + 1 (prad_set_workspace:
+    a second stream of one thread needs scratch buffers of its own).  The case pipeline queues GLCM / GLRLM / GLDM / NGTDM
+    on stream 0, GLSZM on 1 and first order on 2 -- their many small kernels (13-workgroup formula kernels, single-workgroup
+    glue kernels) overlap on the GPU -- while binning and the host-side classes keep the main stream.  wait=False: enter
+    the same stream without the dependency (to mark or synchronise it)."""
 
-    def __init__(self, wait: bool = True):
-        self.wait = wait
+    def __init__(self, which: int = 0, wait: bool = True):
+        self.which, self.wait = int(which), wait
 
     def __enter__(self):
         import threading
         dev = torch.cuda.current_device()
-        key = (threading.get_ident(), dev)
+        key = (threading.get_ident(), dev, self.which)
         s = _side_streams.get(key)
         if s is None:
             s = _side_streams[key] = torch.cuda.Stream(device=dev)
@@ -106,7 +108,7 @@ class side_queue:
             s.wait_stream(torch.cuda.current_stream(dev))
         self._ctx = torch.cuda.stream(s)
         self._ctx.__enter__()
-        _lib.raise_for(_lib.load().prad_set_workspace(1), "workspace")
+        _lib.raise_for(_lib.load().prad_set_workspace(self.which + 1), "workspace")
         _tls.stream_ptr = C.c_void_p(s.cuda_stream)
         return s
 
@@ -735,6 +737,29 @@ def firstorder_stats(image: torch.Tensor, mask: torch.Tensor, voxelArrayShift: f
                                  image.numel(), float(voxelArrayShift), out, _stream_ptr())
     _lib.raise_for(rc, "firstorder")
     return dict(zip(FIRSTORDER_FIELDS, (float(v) for v in out)))
+
+
+def firstorder_stats_queue(image: torch.Tensor, mask: torch.Tensor, roi_count: int, voxelArrayShift: float = 0.0,
+                           deferred: bool = False) -> np.ndarray:
+    """firstorder_stats without host round trips between the passes (prad_firstorder_queue_dev): float64 numpy [16] --
+    the FIRSTORDER_FIELDS values, then a verdict (0 = fine, else call firstorder_stats).  deferred=True: enqueue only,
+    the array lives in the result arena and is valid after deferred_status() / deferred_wait().  NotImplementedError for
+    integer images and ROIs below 2^20 voxels (firstorder_stats serves them with its exact histogram / full sort)."""
+    lib = _lib.load()
+    if image.dtype not in _DTYPE_CODES:
+        image = image.to(torch.float64)
+    image = image.contiguous()
+    mask = _mask_u8(mask)
+    lib.prad_set_device(image.device.index or 0)
+    out = result_array((16,), np.float64) if deferred else np.empty(16, dtype=np.float64)
+    with _Deferred(lib, deferred):
+        rc = lib.prad_firstorder_queue_dev(C.c_void_p(image.data_ptr()), _DTYPE_CODES[image.dtype],
+                                           C.c_void_p(mask.data_ptr()), image.numel(), int(roi_count),
+                                           float(voxelArrayShift), out.ctypes.data_as(C.POINTER(C.c_double)), _stream_ptr())
+    _lib.raise_for(rc, "firstorder queue")
+    if deferred:
+        _deferred_keep.append((image, mask))
+    return out
 
 
 def voxel_firstorder(image: torch.Tensor, mask: torch.Tensor, levels, voxels: torch.Tensor, feature_ids,

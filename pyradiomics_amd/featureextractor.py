@@ -288,14 +288,19 @@ class RadiomicsFeatureExtractor:
             for f in fnames or []:
                 fc.enableFeatureByName(f)
             fcs.append((cname, fc))
-        # Case pipeline: the classes whose matrix AND formulas run on the device (GLCM, GLRLM, GLSZM, GLDM, NGTDM) queue all
-        # of their kernels first (on a side stream); first order, which talks to the host between its kernels, runs while
-        # that queue drains; then ONE wait and the queued values are collected.  The reference evaluates class after
+        # Case pipeline: every class whose work runs on the device without a host round trip (GLCM, GLRLM, GLSZM, GLDM, NGTDM,
+        # first order of float images) queues all of its kernels first, on side streams; the rest (first order of the
+        # int16 original: exact histogram) runs on the main stream while those queues drain; then ONE wait per image.  The reference evaluates class after
         # class (featureextractor.py:560-604), each with its own round trips.
         cm = fcs[0][1].cMatrices if fcs else None
-        with (cm.segment_queue() if hasattr(cm, "segment_queue") and fcs[0][1].deviceResident else contextlib.nullcontext()):
-            queued = [fc for _, fc in fcs if fc.enqueue()]
-        token = cm.segment_mark() if queued else None
+        side = hasattr(cm, "segment_queue") and fcs[0][1].deviceResident
+        queued, names = [], []
+        for cname, fc in fcs:
+            with (cm.segment_queue(cname) if side else contextlib.nullcontext()):
+                if fc.enqueue():
+                    queued.append(fc)
+                    names.append(cname)
+        token = cm.segment_mark(names) if queued else None
         return fcs, queued, token, imageTypeName
 
     def _finishFeatures(self, started):

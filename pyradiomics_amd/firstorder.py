@@ -47,8 +47,27 @@ class RadiomicsFirstOrder(RadiomicsFeaturesBase):
         for n in names:
             yield True, n, vals[n]
 
+    def enqueue(self):
+        """case pipeline (base.enqueue): the statistics' passes are queued now, _initCalculation collects them"""
+        self._queuedStats = None
+        fn = getattr(self.cMatrices, "firstorder_stats_enqueue", None)
+        from .base import _ENQUEUE_DEFAULT
+        if (self.voxelBased or not self.deviceResident or fn is None
+                or not self.settings.get("enqueueSegment", _ENQUEUE_DEFAULT) or "Ns" not in self.coefficients):
+            return False
+        try:
+            self._queuedStats = fn(self.rawImageArray, self.maskArray, self.coefficients["Ns"], self.voxelArrayShift)
+        except NotImplementedError:
+            return False
+        return True
+
+    def dropEnqueued(self):
+        self._queuedStats = None
+
     def _initCalculation(self, voxelCoordinates=None):
-        st = self.cMatrices.firstorder_stats(self.rawImageArray, self.maskArray, self.voxelArrayShift)
+        queued, self._queuedStats = getattr(self, "_queuedStats", None), None
+        st = queued() if queued is not None else self.cMatrices.firstorder_stats(self.rawImageArray, self.maskArray,
+                                                                                  self.voxelArrayShift)
         self.st = {k: np.array([v], dtype=np.float64) for k, v in st.items()}
         counts = self.coefficients["levelCounts"]           # ROI voxels per present grey level, ascending (:99-101)
         p_i = counts.reshape((1, -1)).astype("float")

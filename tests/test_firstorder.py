@@ -197,3 +197,49 @@ def test_voxel_mode_vs_oracle(shape, radius, force2D, masked, dtype, oracle_port
         else:
             scale = np.maximum(np.abs(want[ok]), 1e-9 if k in ("Skewness",) else 1e-300)
             assert np.all(np.abs(got[ok] - want[ok]) <= 1e-9 * scale + 1e-12), (k, np.abs(got[ok] - want[ok]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["float64", "float32", "peaked", "outlier"])
+def test_queue_route_equals_the_synchronous_statistics(kind):
+    """prad_firstorder_queue_dev (the passes' scalars stay in device memory, glue kernels do the host's arithmetic) against
+    prad_firstorder_dev: the same bits; an image the queue declines says so in its verdict word"""
+    import torch
+    from pyradiomics_amd import engine
+    shape = (128, 128, 130)
+    rng = np.random.default_rng(4)
+    if kind in ("float64", "float32"):
+        img, mask = _volume(np.dtype(kind).type, shape, 5, 0.62)
+    elif kind == "peaked":      # a wavelet detail band: most voxels near zero, long tails
+        img, mask = rng.laplace(size=shape) * 20.0, rng.random(shape) < 0.9
+    else:
+        img, mask = rng.standard_normal(shape) + 50.0, rng.random(shape) < 0.8
+        img[3, 4, 5] = 1e9      # nearly everything in the first histogram bin: more than the queue gathers
+        mask[3, 4, 5] = True
+    I = torch.from_numpy(np.ascontiguousarray(img)).cuda()
+    M = torch.from_numpy(mask.astype(np.uint8)).cuda()
+    m = int(mask.sum())
+    for shift in (0.0, 1000.0):
+        want = engine.firstorder_stats(I, M, shift)
+        if kind == "outlier":
+            with pytest.raises(NotImplementedError):
+                engine.firstorder_stats_queue(I, M, m, shift)
+            v = engine.firstorder_stats_queue(I, M, m, shift, deferred=True)
+            engine.deferred_status()
+            assert int(v[15]) & 8
+            continue
+        got = engine.firstorder_stats_queue(I, M, m, shift)
+        assert got[15] == 0
+        for k, f in enumerate(engine.FIRSTORDER_FIELDS):
+            assert np.array_equal(got[k], want[f], equal_nan=True), (f, got[k], want[f])
+        q = engine.firstorder_stats_queue(I, M, m, shift, deferred=True)
+        engine.deferred_status()
+        assert np.array_equal(q, got, equal_nan=True)
+    # a wrong ROI count is a verdict, not a wrong answer; integer images and small ROIs are declined up front
+    v = engine.firstorder_stats_queue(I, M, m - 1, 0.0, deferred=True)
+    engine.deferred_status()
+    assert int(v[15]) & 1
+    with pytest.raises(NotImplementedError):
+        engine.firstorder_stats_queue(I.to(torch.int16), M, m, 0.0)
+    with pytest.raises(NotImplementedError):
+        engine.firstorder_stats_queue(I[:8].contiguous(), M[:8].contiguous(), int(mask[:8].sum()), 0.0)
