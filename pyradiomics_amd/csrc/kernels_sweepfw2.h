@@ -288,23 +288,63 @@ struct Fw2Wave {
     return __ballot(a) != 0;
   }
   __device__ __forceinline__ void run(const FwDesc &D, int NX, int pitch, long long nrows, const uint8_t *__restrict__ L,
-                                      int *work, int bx, int nblocks) {
+                                      int *work, int bx, int nblocks, bool xcd) {
     const int NM = D.NM, NU = D.NU, du = D.du;
     const long long delta = D.sM + (long long)du * D.sU;
     const uint8_t *lpb = L + 2 * (long long)first_col(NX);
     const int nwaves = (int)(nblocks * (blockDim.x >> 6));
     const int wid = __builtin_amdgcn_readfirstlane((int)(bx * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    // XCD-aware hand-out (FwWave::run in kernels_sweepfw.h has the description): at 512^3 the 16-bit level volume (268 MB,
+    // read by 12 roles) does not fit the Infinity Cache -- here the re-reads cost TIME, not only fabric bytes
+    int dom = 0, tried = 0;
+    const int ndom = xcd ? PRAD_FW_DOMAINS : 1;
+    if (xcd) {
+      int id;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+      dom = id & (PRAD_FW_DOMAINS - 1);
+    }
     for (int it = 0;; it++) {
-      int chunk;
-      if (it == 0) {
-        chunk = wid;
+      int piece, u0;
+      if (!xcd) {
+        int chunk;
+        if (it == 0) {
+          chunk = wid;
+        } else {
+          int grabbed = 0;
+          if (lane == 0) grabbed = atomicAdd(work, 1);
+          chunk = nwaves + __builtin_amdgcn_readfirstlane(grabbed);
+        }
+        if (chunk >= D.chunks) break;
+        piece = chunk / NU;
+        u0 = chunk - piece * NU;
       } else {
+        int wd = NU, ulo = 0, np = 0;
+        if (D.dom_kind == 0) {
+          np = dom < D.pieces ? (D.pieces - dom + PRAD_FW_DOMAINS - 1) / PRAD_FW_DOMAINS : 0;
+        } else {
+          ulo = (int)((long long)NU * dom / PRAD_FW_DOMAINS);
+          wd = (int)((long long)NU * (dom + 1) / PRAD_FW_DOMAINS) - ulo;
+          np = D.pieces;
+        }
         int grabbed = 0;
-        if (lane == 0) grabbed = atomicAdd(work, 1);
-        chunk = nwaves + __builtin_amdgcn_readfirstlane(grabbed);
+        if (lane == 0) grabbed = atomicAdd(work + dom * PRAD_FW_WORK_STRIDE, 1);
+        const int i = __builtin_amdgcn_readfirstlane(grabbed);
+        if (i >= wd * np) {      // this domain is done: help the next one
+          if (++tried >= ndom) break;
+          dom = (dom + 1) & (PRAD_FW_DOMAINS - 1);
+          continue;
+        }
+        const int pi = i / wd, rs = ulo + (i - pi * wd);
+        if (D.dom_kind == 0) {
+          piece = dom + PRAD_FW_DOMAINS * pi;
+          long long u = ((long long)rs - ((long long)piece * D.CL + D.CL / 2) * du) % NU;
+          if (u < 0) u += NU;
+          u0 = (int)u;
+        } else {
+          piece = pi;
+          u0 = rs;
+        }
       }
-      if (chunk >= D.chunks) break;
-      const int piece = chunk / NU, u0 = chunk - piece * NU;
       const int t0 = piece * D.CL, t1 = min(NM, t0 + D.CL);
       int row = (int)((u0 + (long long)t0 * du) % NU);
       if (row < 0) row += NU;
@@ -433,13 +473,13 @@ __global__ void __launch_bounds__(1024) sweep_fw2_kernel(FwSet set, const uint8_
   int *wk = work + PRAD_FW_WORK_STRIDE * PRAD_FW_DOMAINS * role;
   if (D.dx == 0) {
     Fw2Wave<LONG, K, 0, HASPAD> w(T, set.NX);
-    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks);
+    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0);
   } else if (D.dx > 0) {
     Fw2Wave<LONG, K, 1, HASPAD> w(T, set.NX);
-    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks);
+    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0);
   } else {
     Fw2Wave<LONG, K, -1, HASPAD> w(T, set.NX);
-    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks);
+    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0);
   }
   fw2_flush(lds, T, D.slot, glcm_acc, glrlm_acc);
 }

@@ -492,7 +492,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     // XCD-aware chunk hand-out (kernels_sweepfw.h): opt-in -- it takes the fabric reads of the level volume from 10.2 to 3.9
     // per volume at 512^3 but its 8 shorter pieces cost 4 % of time (profiles/r03_probes.md), and time is the metric
     p.fwset.xcd = 0;
-    if (const char *e = getenv("PRAD_FW_XCD")) p.fwset.xcd = (p.fw && p.Nz >= 64 && atoi(e) != 0) ? 1 : 0;
+    if (const char *e = getenv("PRAD_FW_XCD")) p.fwset.xcd = ((p.fw || p.fw2) && p.Nz >= 64 && atoi(e) != 0) ? 1 : 0;
     for (int i = 0; i < p.lines.count; i++) {
       const SweepDesc &S = p.lines.d[i];
       FwDesc &D = p.fwset.d[i];
