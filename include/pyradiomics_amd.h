@@ -355,6 +355,15 @@ int prad_level_counts_dev(const int32_t *levels, const uint8_t *mask, long long 
  *                      searched in global memory instead of LDS). */
 int prad_digitize_counts_dev(const void *image, int dtype, const uint8_t *mask, long long n, const double *edges,
                              int nedges, int32_t *levels, int *max_level, long long *counts, void *stream);
+/* binCount discretisation with ONE host synchronisation: ROI min / max, the np.histogram edges built on the device
+ * (np.linspace's arithmetic: i * step + min with two roundings, last edge = max, then + 1 as in imageoperations.py:122-126;
+ * in float32 for a float32 image, as numpy does it, in float64 otherwise), levels, largest level and the level census in
+ * one queue.  dtype as for prad_digitize_dev.  minmax: HOST double [2]; edges:
+ * HOST double [binCount + 1] or NULL (what the device used: bit-identical to getBinEdges on (min, max));
+ * counts: HOST int64 [binCount + 2] as prad_digitize_counts_dev, or NULL.  PRAD_E_UNSUPPORTED for a constant or
+ * non-finite ROI (np.histogram widens the range then): the two-call route with host-built edges serves those. */
+int prad_bincount_dev(const void *image, int dtype, const uint8_t *mask, long long n, int binCount, int32_t *levels,
+                      double *minmax, double *edges, int *max_level, long long *counts, void *stream);
 
 /* ---- first-order statistics of the ROI intensities (radiomics/firstorder.py:33-474; device pointers) -----------
  * Segment mode.  The reference computes these with numpy on image[mask] (firstorder.py:96-101); here the ROI is

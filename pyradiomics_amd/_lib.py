@@ -73,6 +73,8 @@ SYMBOLS = {
     "prad_digitize_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.POINTER(C.c_double), C.c_int, _vp, _ip, _vp]),
     "prad_digitize_counts_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.POINTER(C.c_double), C.c_int, _vp, _ip,
                                           C.POINTER(C.c_longlong), _vp]),
+    "prad_bincount_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_int), C.POINTER(C.c_longlong), _vp]),
     "prad_voxel_texture_features_dev": (C.c_int, [C.c_int, _vp, _vp, _ip, C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.c_int,
                                                   _vp, C.c_int, C.c_int, _ip, C.c_int, _vp, _vp]),
     "prad_glcm_features_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _ip, _vp]),

@@ -193,6 +193,42 @@ __global__ void __launch_bounds__(256) digitize_kernel(const T *__restrict__ x, 
   }
 }
 
+// binCount edges on the device: np.histogram(x, bins=N)[1] is np.linspace(min, max, N + 1) --
+// step = (max - min) / N, edge_i = i * step + min (two roundings, no fused multiply-add), edge_N = max -- and
+// getBinEdges moves the last edge up by 1 (imageoperations.py:122-126).  info[0] = 1 when the ROI is constant / not finite /
+// the step underflows (np.histogram and np.linspace then take other branches: the host route handles those).
+// F32: a float32 image -- numpy then does all of it in float32 (np.histogram's bin_type, np.linspace's dt); integer images take the
+// float64 arithmetic on their exact extremes.
+template <bool F32>
+__global__ void bincount_edges_kernel(const unsigned long long *__restrict__ keys, int N, double *__restrict__ edges,
+                                      int *__restrict__ info) {
+#pragma clang fp contract(off)
+  const double lo = f64_unkey(keys[0]), hi = f64_unkey(keys[1]);
+  bool bad = keys[1] == 0ull || !(hi > lo) || !isfinite(lo) || !isfinite(hi);
+  if (F32) {
+    const float lof = (float)lo, hif = (float)hi;
+    const float delta = hif - lof, step = delta / (float)N;
+    bad = bad || !isfinite(delta) || step == 0.0f;
+    if (threadIdx.x == 0) info[0] = bad ? 1 : 0;
+    for (int i = threadIdx.x; i <= N; i += blockDim.x) {
+      float e = (float)i * step;
+      e = e + lof;
+      if (i == N) e = hif + 1.0f;
+      edges[i] = bad ? (double)i : (double)e;
+    }
+  } else {
+    const double delta = hi - lo, step = delta / (double)N;
+    bad = bad || !isfinite(delta) || step == 0.0;
+    if (threadIdx.x == 0) info[0] = bad ? 1 : 0;
+    for (int i = threadIdx.x; i <= N; i += blockDim.x) {
+      double e = (double)i * step;
+      e = e + lo;
+      if (i == N) e = hi + 1.0;
+      edges[i] = bad ? (double)i : e;       // (ascending placeholders: the digitize pass after it stays well defined)
+    }
+  }
+}
+
 // ROI voxel count per level: per-wave private LDS tables when Ng fits (the common case), global atomics otherwise
 __global__ void __launch_bounds__(256) level_counts_kernel(const int *__restrict__ levels,
                                                            const uint8_t *__restrict__ mask, long long n, int Ng,

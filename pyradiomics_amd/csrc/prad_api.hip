@@ -2464,6 +2464,62 @@ int prad_digitize_counts_dev(const void *image, int dtype, const uint8_t *mask, 
   return PRAD_OK;
 }
 
+int prad_bincount_dev(const void *image, int dtype, const uint8_t *mask, long long n, int binCount, int32_t *levels,
+                      double *minmax, double *edges, int *max_level, long long *counts, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!image || !mask || !levels || !minmax || n < 1) return fail(PRAD_E_ARG, "bincount: bad arguments");
+  if (dtype < 0 || dtype > 3) return fail(PRAD_E_ARG, "bincount: dtype %d", dtype);
+  if (binCount < 1 || binCount > 4096) return fail(PRAD_E_UNSUPPORTED, "bincount: binCount %d outside [1, 4096]", binCount);
+  hipStream_t s = (hipStream_t)stream;
+  const int nedges = binCount + 1;
+  // one device block: [keys (2 u64) | info (8 B) | top (8 B) | counts (nedges + 1) | edges (nedges doubles)] -- one copy back
+  unsigned long long *blk = nullptr;
+  const size_t words = 2 + 1 + 1 + ((size_t)nedges + 1) + (size_t)nedges;
+  PRAD_TRY(c.get<unsigned long long>("bincount_blk", words, &blk));
+  unsigned long long *keys = blk;
+  int *info = (int *)(blk + 2), *top = (int *)(blk + 3);
+  unsigned long long *cnt_d = blk + 4;
+  double *e_d = (double *)(blk + 4 + (size_t)nedges + 1);
+  void *pin = nullptr;
+  PRAD_TRY(c.get_pinned("bincount_pin", sizeof(unsigned long long) * (words + 2), &pin));
+  unsigned long long *h = (unsigned long long *)pin;
+  PRAD_HIP(hipMemsetAsync(blk, 0, sizeof(unsigned long long) * words, s));
+  h[words] = ~0ull;
+  h[words + 1] = 0ull;
+  PRAD_HIP(hipMemcpyAsync(keys, h + words, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+  static const int cap = getenv("PRAD_MINMAX_BLOCKS") ? atoi(getenv("PRAD_MINMAX_BLOCKS")) : 512;
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, cap));
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(roi_minmax_kernel<float>, dim3(gx), dim3(256), 0, s, (const float *)image, mask, n, keys); break;
+    case 1: hipLaunchKernelGGL(roi_minmax_kernel<double>, dim3(gx), dim3(256), 0, s, (const double *)image, mask, n, keys); break;
+    case 2: hipLaunchKernelGGL(roi_minmax_kernel<int>, dim3(gx), dim3(256), 0, s, (const int *)image, mask, n, keys); break;
+    default: hipLaunchKernelGGL(roi_minmax_kernel<short>, dim3(gx), dim3(256), 0, s, (const short *)image, mask, n, keys); break;
+  }
+  if (dtype == 0)
+    hipLaunchKernelGGL(bincount_edges_kernel<true>, dim3(1), dim3(256), 0, s, (const unsigned long long *)keys, binCount, e_d, info);
+  else
+    hipLaunchKernelGGL(bincount_edges_kernel<false>, dim3(1), dim3(256), 0, s, (const unsigned long long *)keys, binCount, e_d, info);
+  PRAD_TRY(check_launch("bincount_edges_kernel"));
+  switch (dtype) {
+    case 0: PRAD_TRY(launch_digitize((const float *)image, mask, n, e_d, nedges, levels, top, cnt_d, s)); break;
+    case 1: PRAD_TRY(launch_digitize((const double *)image, mask, n, e_d, nedges, levels, top, cnt_d, s)); break;
+    case 2: PRAD_TRY(launch_digitize((const int *)image, mask, n, e_d, nedges, levels, top, cnt_d, s)); break;
+    default: PRAD_TRY(launch_digitize((const short *)image, mask, n, e_d, nedges, levels, top, cnt_d, s)); break;
+  }
+  PRAD_HIP(hipMemcpyAsync(h, blk, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost, s));
+  PRAD_HIP(hipStreamSynchronize(s));
+  if (h[1] == 0ull) return fail(PRAD_E_ARG, "roi_minmax: empty ROI");
+  minmax[0] = f64_unkey(h[0]);
+  minmax[1] = f64_unkey(h[1]);
+  if (*(const int *)(h + 2))
+    return fail(PRAD_E_UNSUPPORTED, "bincount: constant or non-finite ROI (np.histogram widens the range: host-built edges)");
+  if (max_level) *max_level = *(const int *)(h + 3);
+  if (counts) memcpy(counts, h + 4, sizeof(long long) * ((size_t)nedges + 1));
+  if (edges) memcpy(edges, h + 4 + (size_t)nedges + 1, sizeof(double) * nedges);
+  return PRAD_OK;
+}
+
 int prad_digitize_dev(const void *image, int dtype, const uint8_t *mask, long long n, const double *edges, int nedges,
                       int32_t *levels, int *max_level, void *stream) {
   return prad_digitize_counts_dev(image, dtype, mask, n, edges, nedges, levels, max_level, nullptr, stream);

@@ -4,6 +4,7 @@ memory and streams.  Used by bench.py, the batch driver and the voxel-map driver
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch  # imported before the HIP library so both share one libamdhip64 instance
@@ -689,6 +690,22 @@ def bin_image(image: torch.Tensor, mask: torch.Tensor, with_counts: bool = False
     rc = lib.prad_set_device(image.device.index or 0)
     mm = (C.c_double * 2)()
     n = image.numel()
+    binCount = kwargs.get("binCount")
+    if binCount is not None and 1 <= int(binCount) <= 4096 and not os.environ.get("PRAD_BIN_TWO_CALLS"):
+        # fixed bin count: edges built on the device, one synchronisation instead of two
+        nb = int(binCount)
+        levels = torch.empty(image.shape, dtype=torch.int32, device=image.device)
+        edges = np.empty(nb + 1, dtype=np.float64)
+        counts = np.zeros(nb + 2, dtype=np.int64)
+        top = C.c_int(0)
+        rc = lib.prad_bincount_dev(C.c_void_p(image.data_ptr()), _DTYPE_CODES[image.dtype], C.c_void_p(mask.data_ptr()), n, nb,
+                                       C.c_void_p(levels.data_ptr()), mm, edges.ctypes.data_as(C.POINTER(C.c_double)),
+                                       C.byref(top), counts.ctypes.data_as(C.POINTER(C.c_longlong)), _stream_ptr())
+        if rc != _lib.PRAD_E_UNSUPPORTED:
+            _lib.raise_for(rc, "bincount")
+            if with_counts:
+                return levels, int(top.value), edges, counts[:int(top.value) + 1]
+            return levels, int(top.value), edges
     rc = lib.prad_roi_minmax_dev(C.c_void_p(image.data_ptr()), _DTYPE_CODES[image.dtype], C.c_void_p(mask.data_ptr()),
                                  n, mm, _stream_ptr())
     _lib.raise_for(rc, "roi_minmax")

@@ -266,3 +266,45 @@ def test_log_of_several_sigmas_in_one_launch_sequence_equals_one_at_a_time(shape
     assert len(many) == len(sig)
     for s, got in zip(sig, many):
         assert torch.equal(got, engine.log_image(x, spacing, s)), s
+
+
+@pytest.mark.gpu
+def test_bincount_edges_built_on_the_device_are_numpys(monkeypatch):
+    """prad_bincount_dev (one host synchronisation: min / max -> np.linspace's arithmetic on the device -> levels + census)
+    against the two-call route with numpy-built edges (np.histogram(x, N)[1], last edge + 1: imageoperations.py:122-126):
+    edges bit for bit, levels, counts; constant ROIs go back to the host route"""
+    import torch
+    from pyradiomics_amd import engine, imageoperations
+    rng = np.random.default_rng(17)
+    for trial in range(40):
+        shape = (int(rng.integers(3, 20)), int(rng.integers(3, 30)), int(rng.integers(4, 70)))
+        scale = 10.0 ** rng.uniform(-6, 9)
+        x = (rng.standard_normal(shape) * scale + rng.uniform(-1, 1) * scale * 3).astype(np.float64)
+        if trial % 7 == 0:
+            x = np.round(x)                      # integer-valued doubles: ties exactly on edges
+        if trial % 4 == 1:
+            x = x.astype(np.float32)             # numpy builds float32 edges for float32 data
+        elif trial % 4 == 2:
+            x = np.clip(np.round(x / scale * 300), -30000, 30000).astype(np.int16)
+        elif trial % 4 == 3 and scale < 1e6:
+            x = np.round(x).astype(np.int32)
+        m = rng.random(shape) < 0.7
+        m[0, 0, 0] = True
+        N = int(rng.choice([1, 2, 7, 16, 32, 33, 47, 48, 64, 100, 255, 1000]))
+        X, M = torch.from_numpy(x).cuda(), torch.from_numpy(m.astype(np.uint8)).cuda()
+        monkeypatch.delenv("PRAD_BIN_TWO_CALLS", raising=False)
+        lv, Ng, edges, cnt = engine.bin_image(X, M, with_counts=True, binCount=N)
+        want_edges = np.asarray(imageoperations.getBinEdges(x[m], binCount=N), dtype=np.float64)
+        assert np.array_equal(edges, want_edges), (trial, N)
+        monkeypatch.setenv("PRAD_BIN_TWO_CALLS", "1")
+        lv2, Ng2, edges2, cnt2 = engine.bin_image(X, M, with_counts=True, binCount=N)
+        assert Ng == Ng2 and torch.equal(lv, lv2) and np.array_equal(cnt, cnt2) and np.array_equal(edges, edges2)
+        want = np.zeros(shape, dtype=np.int64)
+        want[m] = np.digitize(x[m], want_edges)
+        assert np.array_equal(lv.cpu().numpy(), want)
+    monkeypatch.delenv("PRAD_BIN_TWO_CALLS", raising=False)
+    flat = torch.full((6, 8, 12), 3.25, dtype=torch.float64).cuda()
+    ones = torch.ones((6, 8, 12), dtype=torch.uint8).cuda()
+    lv, Ng, edges = engine.bin_image(flat, ones, binCount=8)        # np.histogram widens a constant range: host-built edges
+    assert np.array_equal(edges, np.asarray(imageoperations.getBinEdges(np.full(5, 3.25), binCount=8), dtype=np.float64))
+    assert int(lv.max()) == Ng
