@@ -243,10 +243,14 @@ struct Context {
     *ev = event_pool[events_used++];
     return PRAD_OK;
   }
+  // event brackets cost two hipEventRecord per launch group: enqueue-only (deferred) calls skip them unless somebody
+  // collects (prad_timing_begin) -- a queued derived image of the case pipeline had ~50 of them
+  bool timing_on() const { return !deferred || timing_accumulate; }
   int begin_call(hipStream_t s) {
     times.clear();
     if (!timing_accumulate) events_used = 0;
     call_timed = false;
+    if (!timing_on()) return PRAD_OK;
     int rc;
     if ((rc = new_event(&call_a)) != PRAD_OK) return rc;
     if ((rc = new_event(&call_b)) != PRAD_OK) return rc;
@@ -254,6 +258,7 @@ struct Context {
     return PRAD_OK;
   }
   int end_call(hipStream_t s) {
+    if (!timing_on()) return PRAD_OK;
     PRAD_HIP(hipEventRecord(call_b, s));
     call_timed = true;
     if (timing_accumulate) {
@@ -288,7 +293,7 @@ struct Timed {
   Context &c;
   hipStream_t s;
   bool ok;
-  Timed(Context &c_, const char *family, hipStream_t s_) : c(c_), s(s_) { ok = c.tic(family, s) == PRAD_OK; }
+  Timed(Context &c_, const char *family, hipStream_t s_) : c(c_), s(s_) { ok = c.timing_on() && c.tic(family, s) == PRAD_OK; }
   ~Timed() {
     if (ok) (void)c.toc(s);
   }
