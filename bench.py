@@ -281,7 +281,8 @@ def mode_config3(device, engine, size=256):
 def mode_batch(device, rank: int, cases: int, fence):
     """north_star 'batched mode' (BASELINE config 5 in miniature): whole cases -- a 256^3 volume, ball ROI, Original +
     8 wavelet sub-bands, all six feature classes -- through RadiomicsFeatureExtractor.execute, `cases` per rank,
-    no collective; PRAD_BATCH_THREADS (default 6: 28 / 39 / 45 / 55 / 61 / 49 cases/s at 1 / 2 / 3 / 4 / 6 / 8 threads on one GPU) cases in flight per GPU (batch.run_batch(..., threads=)).  Returns (cases,
+    no collective; PRAD_BATCH_THREADS (default 3: since the case pipeline queues a whole derived image per wait, one thread
+    reaches 62 - 64 cases/s, three 65 - 90, six 46 - 88 -- the spread is run-to-run, profiles/r03_probes.md section 12) cases in flight per GPU (batch.run_batch(..., threads=)).  Returns (cases,
     seconds, features per case)."""
     from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
     from pyradiomics_amd.image import Image
@@ -291,7 +292,7 @@ def mode_batch(device, rank: int, cases: int, fence):
     roi = np.zeros((N, N, N), dtype=np.int16)
     roi[((zz - N / 2) ** 2 + (yy - N / 2) ** 2 + (xx - N / 2) ** 2) < (0.45 * N) ** 2] = 1
     from pyradiomics_amd import batch
-    threads = int(os.environ.get("PRAD_BATCH_THREADS", "6"))
+    threads = int(os.environ.get("PRAD_BATCH_THREADS", "3"))
     ex = RadiomicsFeatureExtractor(params)
     vols = [(make_volume(N, 32, "smooth", 1000 * rank + c, device)[0] * 25).cpu().numpy().astype(np.int16)
             for c in range(cases + 1)]
@@ -487,7 +488,7 @@ def main() -> None:
                     "one_thread_ms_per_case": round(mode_batch.one_thread_ms, 2),
                     "case": "256^3 int16 volume from host memory, ball ROI (38 %% of the box), Original + 8 wavelet "
                             "sub-bands, six feature classes; %s cases in flight per GPU (host threads, "
-                            "batch.run_batch(threads=))" % os.environ.get("PRAD_BATCH_THREADS", "6")}
+                            "batch.run_batch(threads=))" % os.environ.get("PRAD_BATCH_THREADS", "3")}
 
         def voxel_mode(three_d):
             nk, dt_v, kms = mode_voxel(device, rank, world, args.size, fence, three_d)
