@@ -872,16 +872,6 @@ int sweep_glcm_glrlm(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, 
   PRAD_TRY(vol_pack_standalone(k, v));
   PackJob pj;
   memset(&pj, 0, sizeof(pj));
-  if (getenv("PRAD_FUSEPACK_PROTO") && pack_inline_ok(k, v)) {
-    // measurement prototype: the launch packs THIS volume a second time into scratch buffers (results unaffected)
-    VolState scratch = v;
-    PRAD_TRY(c.get<uint8_t>("proto_levels", (size_t)k.g.n + 1024, &scratch.levels));
-    PRAD_TRY(c.get<uint8_t>("proto_rowzero", (size_t)p.Nz * p.Ny + 64, &scratch.rowzero));
-    PRAD_TRY(c.get<int>("proto_flags", 4, &scratch.flags_d));
-    PRAD_HIP(hipMemsetAsync(scratch.rowzero, 0, (size_t)p.Nz * p.Ny, k.s));
-    PRAD_HIP(hipMemsetAsync(scratch.flags_d, 0, sizeof(int) * 4, k.s));
-    pj = make_pack_job(k, scratch, &v);
-  }
   PRAD_TRY(vol_sweep(k, v, pj));
   int *sticky = nullptr;       // deferred calls latch their levels verdict
   if (c.deferred) PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
