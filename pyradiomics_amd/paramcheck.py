@@ -125,7 +125,8 @@ SETTINGS = {
 VOXEL_SETTINGS = {"kernelRadius": _num("int", lo_ex=0), "maskedKernel": _bool, "initValue": _num("float"),
                   "voxelBatch": _num("int", lo_ex=0)}
 # settings of this package (no reference analogue)
-OWN_SETTINGS = {"deviceResident": _bool, "fusedVoxel": _bool, "fusedSegment": _bool, "compactGLSZM": _bool}
+OWN_SETTINGS = {"deviceResident": _bool, "fusedVoxel": _bool, "fusedSegment": _bool, "enqueueSegment": _bool,
+                "compactGLSZM": _bool}
 
 
 def _check_map(where, values, *tables):
