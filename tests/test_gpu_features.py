@@ -464,3 +464,37 @@ def test_gldm_and_ngtdm_from_one_pass_equal_the_separate_calls(shape, alpha, f2d
     g2, n2 = engine.gldm_ngtdm(lev, msk, 12, alpha, (1,), f2d, 0, deferred=True)
     engine.deferred_status()
     assert torch.equal(g2, g) and torch.equal(n2, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("setting,types", [
+    ({"binWidth": 25}, {"Original": {}, "LoG": {"sigma": [1.0, 2.0]}}),
+    ({"binWidth": 10, "force2D": True, "force2Ddimension": 0}, {"Original": {}, "Square": {}}),
+    ({"binCount": 40, "weightingNorm": "euclidean", "gldm_a": 1}, {"Original": {}, "Wavelet": {}}),
+    ({"binCount": 16, "symmetricalGLCM": False, "distances": [1, 2]}, {"Original": {}}),
+])
+def test_case_pipeline_equals_class_by_class_over_settings(setting, types):
+    """the queued route (enqueueSegment, default) against class after class for settings that leave the fused kernels'
+    corner: binWidth binning (two synchronisations), force2D, weighting norms and gldm_a != 0 (classes that decline the
+    queue), asymmetric GLCM, two distances, float32 LoG images, an ROI above 2^20 voxels (first-order queue)"""
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(9)
+    N = 112
+    f = rng.normal(size=(N, N, N))
+    for ax in range(3):
+        f = np.cumsum(f, axis=ax)
+    vol = ((f - f.min()) / np.ptp(f) * 900 + rng.normal(size=f.shape) * 6).astype(np.int16)
+    zz, yy, xx = np.ogrid[:N, :N, :N]
+    mask = (((zz - 56) ** 2 + (yy - 54) ** 2 + (xx - 57) ** 2) < 52 ** 2).astype(np.int16)   # ~589 k voxels
+    if "Wavelet" in types:
+        mask[:] = 1                                                                            # 1.4 M voxels: first-order queue
+    res = {}
+    for on in (True, False):
+        s = dict(setting, additionalInfo=False, enqueueSegment=on)
+        ex = RadiomicsFeatureExtractor({"setting": s, "imageType": types})
+        res[on] = ex.execute(Image(vol, spacing=(1.0, 1.0, 1.0)), Image(mask, spacing=(1.0, 1.0, 1.0)))
+    assert list(res[True].keys()) == list(res[False].keys()) and len(res[True]) >= 90
+    for k in res[True]:
+        a, b = np.asarray(res[True][k], dtype=float), np.asarray(res[False][k], dtype=float)
+        assert np.array_equal(a, b, equal_nan=True), (k, a, b)
