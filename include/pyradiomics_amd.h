@@ -126,6 +126,31 @@ int prad_result_alloc(size_t bytes, void **out);
  * case pipeline queues its enqueue-only classes on a side stream under set 1 while first order / GLSZM run on the main
  * stream under set 0. */
 int prad_set_workspace(int id);
+/* One derived image, every class, one call: the enqueue half of the case pipeline in native code.  levels / mask: DEVICE
+ * (discretised image, ROI); raw: DEVICE undiscretised image of dtype raw_dtype (first order; NULL without that class);
+ * Ns = ROI voxels; classes = sum of PRAD_IMG_* (PRAD_IMG_MCC with PRAD_IMG_GLCM adds the MCC); distance-1 neighbourhoods,
+ * force2Ddim as elsewhere.  Queues, without waiting: GLCM + GLRLM (one sweep), their formulas and the MCC, GLDM + NGTDM (one
+ * pass over the neighbourhoods) and their formulas on an internal stream, GLSZM on a second, first order on a third -- each
+ * stream waits for the work queued on `stream` so far and has its own workspace set -- and a verdict mark + event behind
+ * each.  *results: one block of the result arena; layout[k] (int[16]) = offset of part k in doubles, -1 = not asked for or
+ * declined by the device route (the caller then computes that class on its own):
+ *   0 GLCM values [Na][23], 1 GLCM "angle empty" flags (int [Na]), 2 MCC [Na] + verdict, 3 GLRLM values [Na][16], 4 flags,
+ *   5 GLDM values [16], 6 flag, 7 NGTDM values [5], 8 GLSZM values [16] + verdict, 9 flag, 10 first order [15] + verdict;
+ *   layout[11] = Na, layout[12] = doubles in the block.
+ * prad_image_wait(ticket) waits for the image's work only (later images keep running; up to 4 images may be in flight per
+ * thread) and returns PRAD_OK, or PRAD_E_DEFERRED when a queued call saw levels outside [1, Ng] (values void).  Inputs
+ * must stay alive until then.  No reference analogue (base.py:181-198 evaluates class after class on the host). */
+#define PRAD_IMG_GLCM 1
+#define PRAD_IMG_GLRLM 2
+#define PRAD_IMG_GLDM 4
+#define PRAD_IMG_NGTDM 8
+#define PRAD_IMG_GLSZM 16
+#define PRAD_IMG_FIRSTORDER 32
+#define PRAD_IMG_MCC 64
+int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const void *raw, int raw_dtype, const int *size,
+                           int Nd, int Ng, long long Ns, int classes, int symmetric, int alpha, int force2Ddim,
+                           double voxelArrayShift, double **results, int *layout, int *ticket, void *stream);
+int prad_image_wait(int ticket);
 
 /* ---- angles: cmatrices.h get_angle_count / build_angles (cmatrices.c:756-892) ------------------- */
 /* returns the number of angles, 0 on invalid distance (as the reference) */

@@ -41,6 +41,9 @@ SYMBOLS = {
     "prad_deferred_join": (C.c_int, [C.c_void_p]),
     "prad_result_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "prad_set_workspace": (C.c_int, [C.c_int]),
+    "prad_image_enqueue_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _ip, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, C.c_double, C.POINTER(C.c_void_p), _ip, _ip, _vp]),
+    "prad_image_wait": (C.c_int, [C.c_int]),
     "prad_deferred_status": (C.c_int, [C.c_void_p]),
     "prad_deferred_mark": (C.c_int, [C.POINTER(C.c_int), C.c_void_p]),
     "prad_get_angle_count": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),

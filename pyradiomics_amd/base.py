@@ -242,6 +242,27 @@ class RadiomicsFeaturesBase:
     def dropEnqueued(self):
         self._enqueued = None
 
+    def imageRequest(self):
+        """(class key, request dict) for cMatrices.segment_image_enqueue -- this class's share of the one-call-per-image
+        enqueue -- or None when it has to queue (or compute) on its own"""
+        fused = getattr(self.cMatrices, "segment_image_enqueue", None)
+        if (self.voxelBased or not self.deviceResident or fused is None or not self.settings.get("fusedSegment", True)
+                or not self.settings.get("enqueueSegment", _ENQUEUE_DEFAULT)):
+            return None
+        route = self._segmentRoute()
+        if route is None or [int(d) for d in np.asarray(self.settings.get("distances", [1])).ravel()] != [1]:
+            return None
+        if len(self.enabledFeatures) == 0:
+            self.enableAllFeatures()
+        names = [n for n, on in self.enabledFeatures.items() if on]
+        if not names:
+            return None
+        return route[0], dict(route[1], features=names)
+
+    def takeEnqueued(self, finish):
+        """hands this class the finish() of a queue somebody else filled (featureextractor, one call per image)"""
+        self._enqueued = (tuple(n for n, on in self.enabledFeatures.items() if on), finish)
+
     def _fusedSegmentFeatures(self, cls, host_only=(), **extra):
         """segment mode on the device-resident route: matrix AND feature formulas on the device when the operator
         backend offers it (only the feature values come back); None otherwise.  Features named in `host_only` (GLCM's

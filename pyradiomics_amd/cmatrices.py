@@ -372,6 +372,90 @@ def segment_features(cls, image, mask, Ng, features, distances=(1,), force2D=Fal
                                     symmetrical, Ns, deferred=False)()
 
 
+def segment_image_enqueue(levels, mask, Ng, Ns, requests, force2D=False, force2Ddimension=0):
+    """The enqueue half of segment_features_enqueue / firstorder_stats_enqueue for SEVERAL classes of one derived image in
+    one library call (engine.image_enqueue).  requests: {class key: dict} with "features" (names) and, per class,
+    "symmetrical" (glcm), "alpha" (gldm), "raw" + "shift" (firstorder).  Returns (token, {class key: finish}); finish() as
+    returned by the per-class functions, to be called after segment_image_wait(token).  Classes whose request the fused
+    kernels do not cover are left out of the returned dict (the caller queues them one by one)."""
+    from . import engine
+    bits = {"glcm": engine.IMG_GLCM, "glrlm": engine.IMG_GLRLM, "gldm": engine.IMG_GLDM, "ngtdm": engine.IMG_NGTDM,
+            "glszm": engine.IMG_GLSZM, "firstorder": engine.IMG_FIRSTORDER}
+    classes, take = 0, {}
+    for cls, rq in requests.items():
+        if cls == "firstorder":
+            take[cls] = rq
+            classes |= bits[cls]
+            continue
+        table = VOXEL_GLCM_FEATURES if cls == "glcm" else _ZONE_LIKE[cls][1]
+        feats = [f for f in rq["features"] if not (cls == "glcm" and f == "MCC")]
+        if cls not in bits or any(f not in table for f in feats):
+            continue
+        take[cls] = dict(rq, table=table, feats=feats, mcc=(cls == "glcm" and "MCC" in rq["features"]))
+        classes |= bits[cls] | (engine.IMG_MCC if take[cls]["mcc"] else 0)
+    if not classes:
+        return None, {}
+    fo = take.get("firstorder")
+    tok = engine.image_enqueue(levels, mask, fo["raw"] if fo else None, int(Ng), int(Ns), classes,
+                               symmetric=take.get("glcm", {}).get("symmetrical", True), alpha=int(take.get("gldm", {}).get("alpha", 0)),
+                               force2D=force2D, force2Ddimension=force2Ddimension,
+                               voxelArrayShift=float(fo["shift"]) if fo else 0.0)
+    res, lay, Na = tok["res"], tok["layout"], tok["layout"][11]
+
+    def flags(k, count):
+        return res[lay[k]:lay[k] + (count + 1) // 2 + 1].view(np.int32)[:count]
+
+    def named(rq, vals):
+        return {f: float(vals[rq["table"].index(f)]) for f in rq["feats"]}
+
+    out = {}
+    if "glcm" in take and lay[0] >= 0:
+        rq = take["glcm"]
+
+        def fin_glcm(rq=rq):
+            vals = res[lay[0]:lay[0] + Na * 23].reshape(Na, 23)
+            r = named(rq, _angle_mean(vals, flags(1, Na) != 0)) if rq["feats"] else {}
+            if rq["mcc"] and lay[2] >= 0 and res[lay[2] + Na] == 0:
+                import warnings
+                with np.errstate(invalid="ignore"), warnings.catch_warnings():
+                    warnings.simplefilter("ignore", RuntimeWarning)
+                    r["MCC"] = float(np.nanmean(res[lay[2]:lay[2] + Na]))
+            return r
+        out["glcm"] = fin_glcm
+    if "glrlm" in take and lay[3] >= 0:
+        out["glrlm"] = lambda rq=take["glrlm"]: named(rq, _angle_mean(res[lay[3]:lay[3] + Na * 16].reshape(Na, 16),
+                                                                       flags(4, Na) != 0))
+    if "gldm" in take and lay[5] >= 0:
+        out["gldm"] = lambda rq=take["gldm"]: named(rq, _angle_mean(res[lay[5]:lay[5] + 16].reshape(1, 16), flags(6, 1) != 0))
+    if "ngtdm" in take and lay[7] >= 0:
+        out["ngtdm"] = lambda rq=take["ngtdm"]: named(rq, res[lay[7]:lay[7] + 5])
+    if "glszm" in take and lay[8] >= 0:
+        def fin_glszm(rq=take["glszm"]):
+            vals = res[lay[8]:lay[8] + 17]
+            if vals[16] != 0:       # the device-side ranking declined / the reference's IndexError: the exact route
+                P, sizes = engine.glszm_compact(levels, mask, int(Ng), Ns, force2D, force2Ddimension)
+                if len(sizes) == 0:
+                    raise NotImplementedError("no zones")
+                return named(rq, _angle_mean(*engine.zone_matrix_features(P, sizes)))
+            if flags(9, 1)[0] != 0:
+                raise NotImplementedError("no zones")
+            return named(rq, vals[:16])
+        out["glszm"] = fin_glszm
+    if fo is not None and lay[10] >= 0:
+        def fin_fo():
+            vals = res[lay[10]:lay[10] + 16]
+            if vals[15] != 0:
+                return engine.firstorder_stats(_to_device(fo["raw"]), _to_device(mask), fo["shift"])
+            return dict(zip(engine.FIRSTORDER_FIELDS, (float(v) for v in vals[:15])))
+        out["firstorder"] = fin_fo
+    return tok, out
+
+
+def segment_image_wait(token):
+    from . import engine
+    return engine.image_wait(token)
+
+
 SEGMENT_QUEUES = {"glcm": 0, "glrlm": 0, "gldm": 0, "ngtdm": 0, "glszm": 1, "firstorder": 2}
 
 

@@ -1272,7 +1272,7 @@ __global__ void __launch_bounds__(1024) glszm_rank_kernel(const unsigned *__rest
                                                           int *__restrict__ meta) {
   __shared__ int key[PRAD_RANK_LARGE];
   __shared__ int scan[1024];
-  __shared__ int s_nsmall, s_nlarge;
+  __shared__ int s_nsmall;
   const int t = threadIdx.x;
   int problem = 0;
   if (flags && flags[0]) problem |= 1;
@@ -1348,7 +1348,6 @@ __global__ void __launch_bounds__(1024) glszm_rank_kernel(const unsigned *__rest
     __syncthreads();
   }
   if (t == 0) {
-    s_nlarge = running;
     if (nsmall + running > kcap) problem |= 4;
     meta[0] = nsmall;
     meta[1] = running;

@@ -189,6 +189,46 @@ def deferred_status() -> None:
         _deferred_keep.clear()
 
 
+IMG_GLCM, IMG_GLRLM, IMG_GLDM, IMG_NGTDM, IMG_GLSZM, IMG_FIRSTORDER, IMG_MCC = 1, 2, 4, 8, 16, 32, 64
+
+
+def image_enqueue(levels: torch.Tensor, mask: torch.Tensor, raw, Ng: int, Ns: int, classes: int, symmetric: bool = True,
+                  alpha: int = 0, force2D: bool = False, force2Ddimension: int = 0, voxelArrayShift: float = 0.0):
+    """every requested class (IMG_* bits) of ONE derived image queued by one library call (prad_image_enqueue_dev: sweeps,
+    neighbourhood pass, GLSZM, first order and all formula kernels on the library's three side streams).  Returns a token
+    {"res": float64 view of the result block, "layout": offsets (include/pyradiomics_amd.h), "ticket", "keep"}; the values
+    are valid after image_wait(token)."""
+    lib, levels, mask, size = _prep(levels, mask)
+    code = 0
+    if classes & IMG_FIRSTORDER:
+        if raw.dtype not in _DTYPE_CODES:
+            raw = raw.to(torch.float64)
+        raw = raw.contiguous()
+        code = _DTYPE_CODES[raw.dtype]
+    res_p = C.c_void_p()
+    layout = (C.c_int * 16)()
+    ticket = C.c_int(-1)
+    rc = lib.prad_image_enqueue_dev(C.c_void_p(levels.data_ptr()), C.c_void_p(mask.data_ptr()),
+                                    C.c_void_p(raw.data_ptr()) if classes & IMG_FIRSTORDER else None, code, _iptr(size),
+                                    levels.dim(), int(Ng), int(Ns), int(classes), 1 if symmetric else 0, int(alpha),
+                                    int(force2Ddimension) if force2D else -1, float(voxelArrayShift), C.byref(res_p), layout,
+                                    C.byref(ticket), _stream_ptr())
+    _lib.raise_for(rc, "image enqueue")
+    n = max(int(layout[12]), 8)
+    res = np.frombuffer((C.c_char * (8 * n)).from_address(res_p.value), dtype=np.float64, count=n)
+    return {"res": res, "layout": [int(v) for v in layout], "ticket": int(ticket.value), "keep": (levels, mask, raw)}
+
+
+def image_wait(token) -> bool:
+    """waits for the work of an image_enqueue() token only; False when a queued call saw levels outside [1, Ng] (void)"""
+    rc = _lib.load().prad_image_wait(int(token["ticket"]))
+    token["keep"] = None
+    if rc == _lib.PRAD_E_DEFERRED:
+        return False
+    _lib.raise_for(rc, "image wait")
+    return True
+
+
 def deferred_mark():
     """token for deferred_wait(): everything queued on the current stream so far (a copy of the verdict word behind it, an
     event behind that); the tensors the queued calls use stay alive with the token"""

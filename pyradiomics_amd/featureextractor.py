@@ -295,22 +295,47 @@ class RadiomicsFeatureExtractor:
         cm = fcs[0][1].cMatrices if fcs else None
         side = hasattr(cm, "segment_queue") and fcs[0][1].deviceResident
         queued, names = [], []
+        # one library call queues every class the fused kernels cover (cMatrices.segment_image_enqueue) ...
+        image_token = None
+        if side and hasattr(cm, "segment_image_enqueue"):
+            reqs = {}
+            for cname, fc in fcs:
+                rq = fc.imageRequest() if hasattr(fc, "imageRequest") else None
+                if rq is not None and rq[0] not in reqs:
+                    reqs[rq[0]] = (fc, rq[1])
+            if reqs:
+                any_fc = next(iter(reqs.values()))[0]
+                levels = getattr(any_fc, "discretizedImageArray", any_fc.imageArray)
+                image_token, finishes = cm.segment_image_enqueue(
+                    levels, any_fc.maskArray, any_fc.coefficients["Ng"], any_fc.coefficients["Ns"],
+                    {k: rq for k, (fc, rq) in reqs.items()}, force2D=kwargs.get("force2D", False),
+                    force2Ddimension=kwargs.get("force2Ddimension", 0))
+                for k, fin in finishes.items():
+                    reqs[k][0].takeEnqueued(fin)
+                    queued.append(reqs[k][0])
+        # ... the others queue on their own (or compute in _finishFeatures)
         for cname, fc in fcs:
+            if fc in queued:
+                continue
             with (cm.segment_queue(cname) if side else contextlib.nullcontext()):
                 if fc.enqueue():
                     queued.append(fc)
                     names.append(cname)
-        token = cm.segment_mark(names) if queued else None
-        return fcs, queued, token, imageTypeName
+        token = cm.segment_mark(names) if names else None
+        return fcs, queued, (image_token, token), imageTypeName
 
     def _finishFeatures(self, started):
         """second half of computeFeatures: the host-side classes evaluated, the queued ones waited for and collected"""
-        fcs, queued, token, imageTypeName = started
+        fcs, queued, (image_token, token), imageTypeName = started
         out = collections.OrderedDict()
         values = {cname: fc.execute() for cname, fc in fcs if fc not in queued}
-        if queued and not queued[0].cMatrices.segment_wait(token):
-            for fc in queued:          # a level outside [1, Ng]: the synchronous route raises what the reference raises
-                fc.dropEnqueued()
+        if queued:
+            cm = queued[0].cMatrices
+            ok = cm.segment_image_wait(image_token) if image_token is not None else True
+            ok = (cm.segment_wait(token) if token is not None else True) and ok
+            if not ok:
+                for fc in queued:      # a level outside [1, Ng]: the synchronous route raises what the reference raises
+                    fc.dropEnqueued()
         for cname, fc in fcs:
             for fname, value in (values[cname] if cname in values else fc.execute()).items():
                 out["%s_%s_%s" % (imageTypeName, cname, fname)] = value

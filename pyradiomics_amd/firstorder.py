@@ -64,6 +64,20 @@ class RadiomicsFirstOrder(RadiomicsFeaturesBase):
     def dropEnqueued(self):
         self._queuedStats = None
 
+    def imageRequest(self):
+        from .base import _ENQUEUE_DEFAULT
+        if (self.voxelBased or not self.deviceResident or not hasattr(self.cMatrices, "segment_image_enqueue")
+                or not self.settings.get("enqueueSegment", _ENQUEUE_DEFAULT) or "Ns" not in self.coefficients):
+            return None
+        import torch
+        raw = self.rawImageArray
+        if raw.dtype in (torch.int16, torch.int32) or self.coefficients["Ns"] < (1 << 20):
+            return None         # (exact-histogram / full-sort routes of prad_firstorder_dev: synchronous)
+        return "firstorder", {"raw": raw, "shift": self.voxelArrayShift, "features": None}
+
+    def takeEnqueued(self, finish):
+        self._queuedStats = finish
+
     def _initCalculation(self, voxelCoordinates=None):
         queued, self._queuedStats = getattr(self, "_queuedStats", None), None
         st = queued() if queued is not None else self.cMatrices.firstorder_stats(self.rawImageArray, self.maskArray,
