@@ -281,8 +281,8 @@ def mode_config3(device, engine, size=256):
 def mode_batch(device, rank: int, cases: int, fence):
     """north_star 'batched mode' (BASELINE config 5 in miniature): whole cases -- a 256^3 volume, ball ROI, Original +
     8 wavelet sub-bands, all six feature classes -- through RadiomicsFeatureExtractor.execute, `cases` per rank,
-    no collective; PRAD_BATCH_THREADS (default 3: since the case pipeline queues a whole derived image per wait, one thread
-    reaches 62 - 64 cases/s, three 65 - 90, six 46 - 88 -- the spread is run-to-run, profiles/r03_probes.md section 12) cases in flight per GPU (batch.run_batch(..., threads=)).  Returns (cases,
+    no collective; PRAD_BATCH_THREADS (default 3: one thread reaches 72.6 cases/s, two 89, three ~100, four 104, six 102 --
+    profiles/r03_probes.md section 12) cases in flight per GPU (batch.run_batch(..., threads=)).  Returns (cases,
     seconds, features per case)."""
     from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
     from pyradiomics_amd.image import Image

@@ -21,13 +21,16 @@ for cname, cls in classes.items():
     cls.execute = timed("execute " + cname, cls.execute)
     cls.enqueue = timed("enqueue " + cname, cls.enqueue)
 cmatrices.segment_sync = timed("segment_sync", cmatrices.segment_sync)
+fx.RadiomicsFeatureExtractor._startFeatures = timed("_startFeatures (all)", fx.RadiomicsFeatureExtractor._startFeatures)
+fx.RadiomicsFeatureExtractor._finishFeatures = timed("_finishFeatures (all)", fx.RadiomicsFeatureExtractor._finishFeatures)
 imageoperations.cropToTumorMask = timed("crop", imageoperations.cropToTumorMask)
 engine.swt_level1 = timed("swt", engine.swt_level1)
 engine.bin_image = timed("  (bin_image inside init)", engine.bin_image)
 engine.firstorder_stats = timed("  (firstorder_stats inside execute)", engine.firstorder_stats)
 engine.glszm_compact = timed("  (glszm_compact inside execute)", engine.glszm_compact)
 for fn in ("glcm_glrlm", "deferred_join", "glcm_features", "glcm_mcc", "zone_matrix_features", "gldm", "ngtdm", "ngtdm_features",
-           "glszm_features", "result_array", "deferred_mark", "deferred_wait", "roi_minmax", "_neigh_common", "_prep"):
+           "glszm_features", "result_array", "deferred_mark", "deferred_wait", "roi_minmax", "_neigh_common", "_prep",
+           "image_enqueue", "image_wait"):
     if hasattr(engine, fn):
         setattr(engine, fn, timed("    engine." + fn, getattr(engine, fn)))
 cmatrices._build_angles = timed("    cmatrices._build_angles", cmatrices._build_angles)
