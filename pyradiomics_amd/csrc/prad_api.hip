@@ -2646,6 +2646,8 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
       for (int k = 0; k < 3; k++) PRAD_HIP(hipEventCreateWithFlags(&q.done[t][k], hipEventDisableTiming));
     q.device = c.device;
   }
+  if (q.used[q.seq % PRAD_IMG_TICKETS] != 0)
+    return fail(PRAD_E_ARG, "image_enqueue: %d images are in flight on this thread; prad_image_wait one first", PRAD_IMG_TICKETS);
   PRAD_TRY(prad_set_deferred(1));     // (creates the sticky word on first use)
   struct Restore {
     Context &c;
@@ -2767,7 +2769,7 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
     PRAD_TRY(prad_deferred_mark(q.flag[t][k], q.s[k]));
     PRAD_HIP(hipEventRecord(q.done[t][k], q.s[k]));
   }
-  q.used[t] = used;
+  q.used[t] = used | 0x80000000u;     // (in flight, even when every class was declined)
   *ticket = t;
   return PRAD_OK;
 }

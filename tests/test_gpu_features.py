@@ -498,3 +498,41 @@ def test_case_pipeline_equals_class_by_class_over_settings(setting, types):
     for k in res[True]:
         a, b = np.asarray(res[True][k], dtype=float), np.asarray(res[False][k], dtype=float)
         assert np.array_equal(a, b, equal_nan=True), (k, a, b)
+
+
+@pytest.mark.gpu
+def test_image_enqueue_one_call_equals_the_per_class_calls_and_bounds_its_tickets():
+    """prad_image_enqueue_dev (every class of a derived image queued by one call) against the per-class engine calls; at most
+    four images may be in flight per thread"""
+    import torch
+    from pyradiomics_amd import engine
+    rng = np.random.default_rng(3)
+    shape = (36, 40, 64)
+    dev = torch.device("cuda", 0)
+    f = rng.normal(size=shape).cumsum(0).cumsum(2)
+    raw = torch.from_numpy(f).to(dev)
+    lev = torch.from_numpy(np.clip(((f - f.min()) / np.ptp(f) * 12).astype(np.int32) + 1, 1, 12)).to(dev)
+    msk = torch.from_numpy((rng.random(shape) < 0.9).astype(np.uint8)).to(dev)
+    Ns = int(msk.sum().item())
+    allc = (engine.IMG_GLCM | engine.IMG_MCC | engine.IMG_GLRLM | engine.IMG_GLDM | engine.IMG_NGTDM | engine.IMG_GLSZM)
+    tok = engine.image_enqueue(lev, msk, raw, 12, Ns, allc)
+    assert engine.image_wait(tok)
+    res, lay = tok["res"], tok["layout"]
+    Na = lay[11]
+    g, r, _ = engine.glcm_glrlm(lev, msk, 12)
+    want, empty = engine.glcm_features(g)
+    assert Na == g.shape[2] and np.array_equal(res[lay[0]:lay[0] + Na * 23].reshape(Na, 23), want, equal_nan=True)
+    assert np.array_equal(res[lay[1]:lay[1] + Na].view(np.int32)[:Na] != 0, empty)
+    assert res[lay[2] + Na] == 0 and np.array_equal(res[lay[2]:lay[2] + Na], engine.glcm_mcc(g), equal_nan=True)
+    want, _ = engine.zone_matrix_features(r, np.arange(1, r.shape[1] + 1))
+    assert np.array_equal(res[lay[3]:lay[3] + Na * 16].reshape(Na, 16), want, equal_nan=True)
+    P = engine.gldm(lev, msk, 12)
+    assert np.array_equal(res[lay[5]:lay[5] + 16], engine.zone_matrix_features(P, np.arange(1, P.shape[1] + 1))[0][0], equal_nan=True)
+    assert np.array_equal(res[lay[7]:lay[7] + 5], engine.ngtdm_features(engine.ngtdm(lev, msk, 12)), equal_nan=True)
+    assert np.array_equal(res[lay[8]:lay[8] + 17], engine.glszm_features(lev, msk, 12, Ns)[0], equal_nan=True)
+    assert lay[10] == -1                       # first order was not asked for
+    toks = [engine.image_enqueue(lev, msk, raw, 12, Ns, engine.IMG_NGTDM) for _ in range(4)]
+    with pytest.raises(ValueError):
+        engine.image_enqueue(lev, msk, raw, 12, Ns, engine.IMG_NGTDM)
+    assert all(engine.image_wait(t) for t in toks)
+    assert engine.image_wait(engine.image_enqueue(lev, msk, raw, 12, Ns, engine.IMG_NGTDM))
