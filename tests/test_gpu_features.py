@@ -472,6 +472,8 @@ def test_gldm_and_ngtdm_from_one_pass_equal_the_separate_calls(shape, alpha, f2d
     ({"binWidth": 10, "force2D": True, "force2Ddimension": 0}, {"Original": {}, "Square": {}}),
     ({"binCount": 40, "weightingNorm": "euclidean", "gldm_a": 1}, {"Original": {}, "Wavelet": {}}),
     ({"binCount": 16, "symmetricalGLCM": False, "distances": [1, 2]}, {"Original": {}}),
+    ({"binWidth": 3}, {"Original": {}}),                       # ~300 grey levels: the byte-packed kernels decline
+    ({"binCount": 70}, {"Original": {}, "Exponential": {}}),   # more levels than the device MCC takes
 ])
 def test_case_pipeline_equals_class_by_class_over_settings(setting, types):
     """the queued route (enqueueSegment, default) against class after class for settings that leave the fused kernels'
@@ -536,3 +538,26 @@ def test_image_enqueue_one_call_equals_the_per_class_calls_and_bounds_its_ticket
         engine.image_enqueue(lev, msk, raw, 12, Ns, engine.IMG_NGTDM)
     assert all(engine.image_wait(t) for t in toks)
     assert engine.image_wait(engine.image_enqueue(lev, msk, raw, 12, Ns, engine.IMG_NGTDM))
+
+
+@pytest.mark.gpu
+def test_case_pipeline_on_a_2d_image_and_a_small_roi():
+    """one-call enqueue on a 2-D image (4 / 8 neighbours) and on a ROI far below the first-order queue's threshold"""
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(12)
+    img2 = (rng.normal(size=(96, 128)).cumsum(0).cumsum(1) * 7).astype(np.int16)
+    m2 = np.zeros((96, 128), dtype=np.int16)
+    m2[10:80, 20:110] = 1
+    img3 = (rng.normal(size=(20, 24, 28)).cumsum(2) * 30).astype(np.int16)
+    m3 = np.zeros((20, 24, 28), dtype=np.int16)
+    m3[4:9, 5:11, 6:13] = 1
+    for img, msk in ((img2, m2), (img3, m3)):
+        res = {}
+        for on in (True, False):
+            ex = RadiomicsFeatureExtractor({"setting": {"binWidth": 20, "additionalInfo": False, "enqueueSegment": on},
+                                            "imageType": {"Original": {}, "Square": {}}})
+            res[on] = ex.execute(Image(img), Image(msk))
+        assert list(res[True].keys()) == list(res[False].keys()) and len(res[True]) >= 150
+        for k in res[True]:
+            assert np.array_equal(np.asarray(res[True][k], dtype=float), np.asarray(res[False][k], dtype=float), equal_nan=True), k
