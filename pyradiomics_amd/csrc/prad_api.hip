@@ -2708,15 +2708,16 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   PRAD_HIP(hipEventRecord(q.in, (hipStream_t)stream));
   for (int k = 0; k < 3; k++) PRAD_HIP(hipStreamWaitEvent(q.s[k], q.in, 0));
   unsigned used = 0;
+  // (workspace sets 4, 5, 6: sets 1 - 3 belong to callers that drive side streams of their own, engine.side_queue)
   // ---- side stream 0: GLCM + GLRLM (one sweep), GLDM + NGTDM (one pass over the neighbourhoods) ----
-  c.workspace = 1;
+  c.workspace = 4;
   if (classes & (PRAD_IMG_GLCM | PRAD_IMG_GLRLM)) {
     double *gm = nullptr, *rm = nullptr;
     PRAD_TRY(c.get<double>("img_glcm", (size_t)Ng * Ng * Na, &gm));
     PRAD_TRY(c.get<double>("img_glrlm", (size_t)Ng * Nr * Na, &rm));
     int rc = texture_pairs_runs(levels, mask, size, Nd, ang.data(), Na, Ng, Nr, 1, nullptr, 0, force2Ddim, gm, rm, q.s[0]);
     if (rc != PRAD_OK) return rc;
-    c.workspace = 1;     // (texture_pairs_runs leaves the lane guard's state)
+    c.workspace = 4;     // (texture_pairs_runs leaves the lane guard's state)
     c.deferred = true;
     PRAD_TRY(prad_deferred_join(q.s[0]));
     if (classes & PRAD_IMG_GLCM) {
@@ -2741,7 +2742,7 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
     PRAD_TRY(c.get<double>("img_gldm", (size_t)Ng * W, &dm));
     PRAD_TRY(c.get<double>("img_ngtdm", (size_t)Ng * 3, &nm));
     PRAD_TRY(texture_gldm_ngtdm(levels, mask, size, Nd, angb.data(), Nab, Ng, alpha, dm, nm, q.s[0]));
-    c.workspace = 1;
+    c.workspace = 4;
     c.deferred = true;
     if (classes & PRAD_IMG_GLDM) {
       std::vector<double> jv((size_t)W);
@@ -2753,7 +2754,7 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   }
   // ---- side stream 1: GLSZM ----
   if (classes & PRAD_IMG_GLSZM) {
-    c.workspace = 2;
+    c.workspace = 5;
     const int rc = prad_glszm_features_dev(levels, mask, size, Nd, angb.data(), Nab, Ng, (int)std::min<long long>(Ns, 2147483647LL),
                                            at(8), (int *)at(9), q.s[1]);
     if (rc == PRAD_E_UNSUPPORTED) layout[8] = layout[9] = -1;
@@ -2763,7 +2764,7 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   }
   // ---- side stream 2: first order ----
   if (classes & PRAD_IMG_FIRSTORDER) {
-    c.workspace = 3;
+    c.workspace = 6;
     const int rc = prad_firstorder_queue_dev(raw, raw_dtype, mask, n, Ns, voxelArrayShift, at(10), q.s[2]);
     if (rc == PRAD_E_UNSUPPORTED) layout[10] = -1;
     else if (rc != PRAD_OK) return rc;

@@ -561,3 +561,33 @@ def test_case_pipeline_on_a_2d_image_and_a_small_roi():
         assert list(res[True].keys()) == list(res[False].keys()) and len(res[True]) >= 150
         for k in res[True]:
             assert np.array_equal(np.asarray(res[True][k], dtype=float), np.asarray(res[False][k], dtype=float), equal_nan=True), k
+
+
+@pytest.mark.gpu
+def test_case_pipeline_is_deterministic_under_repetition_and_threads():
+    """the same cases through the pipelined route again and again, on one thread and on three (batch.run_batch): every run
+    gives the same values bit for bit (look-ahead, side streams and workspace sets leave no room for a race)"""
+    from pyradiomics_amd import batch
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(31)
+    N = 72
+    zz, yy, xx = np.ogrid[:N, :N, :N]
+    mask = (((zz - 36) ** 2 + (yy - 35) ** 2 + (xx - 37) ** 2) < 33 ** 2).astype(np.int16)
+    vols = [(rng.normal(size=(N, N, N)).cumsum(i % 3).cumsum((i + 1) % 3) * (5 + i)).astype(np.int16) for i in range(6)]
+    ex = RadiomicsFeatureExtractor({"setting": {"binCount": 24, "additionalInfo": False},
+                                    "imageType": {"Original": {}, "Wavelet": {}, "LoG": {"sigma": [1.0, 3.0]}}})
+
+    def one(v):
+        return ex.execute(Image(v), Image(mask))
+
+    ref = [one(v) for v in vols]
+    for _ in range(3):
+        again = [one(v) for v in vols]
+        par = batch.run_batch(vols, one, threads=3)
+        for a, b, c in zip(ref, again, par):
+            assert list(a.keys()) == list(b.keys()) == list(c.keys())
+            for k in a:
+                x = np.asarray(a[k], dtype=float)
+                assert np.array_equal(x, np.asarray(b[k], dtype=float), equal_nan=True), k
+                assert np.array_equal(x, np.asarray(c[k], dtype=float), equal_nan=True), k
