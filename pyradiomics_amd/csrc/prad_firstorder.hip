@@ -379,7 +379,7 @@ extern "C" int prad_firstorder_dev(const void *image, int dtype, const uint8_t *
   return PRAD_OK;
 }
 
-#define PRAD_FO_QUEUE_CAP (1u << 18)      // gathered elements the queue route sorts (2 MB); more: verdict 8, synchronous route
+#define PRAD_FO_QUEUE_CAP (1u << 18)      // least number of gathered elements the queue route sorts (2 MB)
 
 extern "C" int prad_firstorder_queue_dev(const void *image, int dtype, const uint8_t *mask, long long n, long long roi_count,
                                          double voxelArrayShift, double *out, void *stream) {
@@ -395,7 +395,11 @@ extern "C" int prad_firstorder_queue_dev(const void *image, int dtype, const uin
   double *partial = nullptr, *gath = nullptr, *d_out = nullptr;
   unsigned *hist = nullptr, *cursors = nullptr;
   FoDev *st = nullptr;
-  const unsigned cap = PRAD_FO_QUEUE_CAP;
+  // gather capacity: an eighth of the ROI, between 2^18 and 2^21 elements (the ten selected histogram bins of a sharply peaked
+  // image -- a wavelet detail band -- hold a few per cent of the ROI; beyond the capacity the verdict sends the caller to
+  // the synchronous route)
+  unsigned cap = PRAD_FO_QUEUE_CAP;
+  while (cap < (1u << 21) && (long long)cap < roi_count / 8) cap <<= 1;
   PRAD_TRY(c.get<double>("fo_partial", (size_t)PRAD_FO_BLOCKS * 8, &partial));
   PRAD_TRY(c.get<unsigned>("fo_hist", PRAD_FO_BINS, &hist));
   PRAD_TRY(c.get<unsigned>("fo_cursors", PRAD_FO_MAXSEL, &cursors));
