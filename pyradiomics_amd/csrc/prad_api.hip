@@ -1578,9 +1578,22 @@ int swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_
       for (int d = 0; d < ax; d++) outer *= g.size[d];
       const long long inner = g.stride[ax];
       const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((g.n + 255) / 256, 8192));
+      const int N = g.size[ax];
+      // geometry-indexed kernel when the taps wrap at most once and the grid limits hold; the general kernel otherwise
+      const bool geo_ok = T.F <= N && !getenv("PRAD_SWT_OLD") &&
+                          (inner == 1 ? outer <= 65535LL * 65535LL : (N <= 65535 && outer <= 65535));
       for (int j = 0; j < count; j++) {
-        hipLaunchKernelGGL(swt_axis_kernel, dim3(gx), dim3(256), 0, s, src + (size_t)j * n, outer, g.size[ax], inner, T,
-                           dst + (size_t)(2 * j) * n, dst + (size_t)(2 * j + 1) * n);
+        const double *in = src + (size_t)j * n;
+        double *o_lo = dst + (size_t)(2 * j) * n, *o_hi = dst + (size_t)(2 * j + 1) * n;
+        if (geo_ok && inner == 1) {
+          const dim3 grid((unsigned)((N + 255) / 256), (unsigned)std::min<long long>(outer, 65535), (unsigned)((outer + 65534) / 65535));
+          hipLaunchKernelGGL(swt_axis2_kernel<true>, grid, dim3(256), 0, s, in, outer, N, inner, T, o_lo, o_hi);
+        } else if (geo_ok) {
+          const dim3 grid((unsigned)((inner + 255) / 256), (unsigned)N, (unsigned)outer);
+          hipLaunchKernelGGL(swt_axis2_kernel<false>, grid, dim3(256), 0, s, in, outer, N, inner, T, o_lo, o_hi);
+        } else {
+          hipLaunchKernelGGL(swt_axis_kernel, dim3(gx), dim3(256), 0, s, in, outer, N, inner, T, o_lo, o_hi);
+        }
         PRAD_TRY(check_launch("swt_axis_kernel"));
       }
       src = dst;
