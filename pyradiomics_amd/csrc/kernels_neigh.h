@@ -131,9 +131,13 @@ __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t 
   for (long long qw = q0; qw < nquads; qw += stride) {
     const long long q = qw + lane;
     const bool live = q < nquads;
-    const long long row = live ? q / qpr : 0;
-    const int x0 = live ? (int)(q - row * qpr) << 2 : 0;
-    const int z = (int)(row / Ny), y = (int)(row - (long long)z * Ny);
+    // (32-bit divisions: a volume holds fewer than 2^31 voxels, so quad and row numbers fit; the 64-bit forms were a third
+    // of the instructions of an iteration)
+    const unsigned q32 = live ? (unsigned)q : 0u;
+    const unsigned row32 = q32 / (unsigned)qpr;
+    const long long row = row32;
+    const int x0 = (int)(q32 - row32 * (unsigned)qpr) << 2;
+    const int z = (int)(row32 / (unsigned)Ny), y = (int)(row32 - (unsigned)z * (unsigned)Ny);
     const unsigned centre = live ? *reinterpret_cast<const unsigned *>(L + row * Nx + x0) : 0u;
     if (__ballot(centre != 0) == 0) continue;   // no ROI voxel in these 256 columns (wave-uniform)
     int sum[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0}, dep[4] = {0, 0, 0, 0};
