@@ -1886,6 +1886,9 @@ long long prad_workspace_bytes(void) {
   for (const auto &kv : ctx().bufs) total += (long long)kv.second.cap;
   return total;
 }
+namespace {
+void release_image_queues();     // (prad_image_enqueue_dev's streams and events, defined with it below)
+}
 int prad_release_workspace(void) {
   Context &c = ctx();
   if (pipe_state().pending.valid) {        // the pending volume's buffers are about to go away: retire it first
@@ -1907,6 +1910,10 @@ int prad_release_workspace(void) {
   }
   c.bufs.clear();
   c.pinned.clear();
+  if (c.arena) (void)hipHostFree(c.arena);     // (the result arena: outstanding result views of this thread die with it)
+  c.arena = nullptr;
+  c.arena_pos = 0;
+  release_image_queues();
   c.angles_cached.clear();   // (the cached angle tables and the deferred flag lived in the workspace)
   StageRing &r = stage_ring();
   for (int i = 0; i < kStageRing; i++) {
@@ -2649,9 +2656,24 @@ struct ImageQueues {
   unsigned long long seq = 0;
   int device = -1;
 };
-ImageQueues &image_queues() {
+ImageQueues *image_queue_table() {
   static thread_local ImageQueues q[16];
-  return q[ctx().device & 15];
+  return q;
+}
+ImageQueues &image_queues() { return image_queue_table()[ctx().device & 15]; }
+void release_image_queues() {
+  ImageQueues *tab = image_queue_table();
+  for (int d = 0; d < 16; d++) {
+    ImageQueues &q = tab[d];
+    if (q.device < 0) continue;
+    for (int k = 0; k < 3; k++)
+      if (q.s[k]) (void)hipStreamDestroy(q.s[k]);
+    if (q.in) (void)hipEventDestroy(q.in);
+    for (int t = 0; t < PRAD_IMG_TICKETS; t++)
+      for (int k = 0; k < 3; k++)
+        if (q.done[t][k]) (void)hipEventDestroy(q.done[t][k]);
+    q = ImageQueues();
+  }
 }
 }  // namespace
 extern "C" {
