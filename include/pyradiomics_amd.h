@@ -409,7 +409,7 @@ int prad_firstorder_dev(const void *image, int dtype, const uint8_t *mask, long 
  * bits).  float32 / float64 images with roi_count >= 2^20 ROI voxels (the caller knows the count from the level census);
  * PRAD_E_UNSUPPORTED otherwise, before anything is launched.  out: 16 doubles -- the PRAD_FO_COUNT statistics, then a
  * verdict (0 = fine; 1: the ROI holds a different number of voxels, 2: constant or non-finite ROI, 8: the selected
- * histogram bins hold more than the gather capacity: an eighth of the ROI, at least 2^18 and at most 2^21 voxels).  In deferred mode with `out` inside the result arena: enqueue only;
+ * histogram bins hold more than the gather capacity: half of the ROI, at least 2^18 voxels).  In deferred mode with `out` inside the result arena: enqueue only;
  * otherwise synchronous, a non-zero verdict returns PRAD_E_UNSUPPORTED (call prad_firstorder_dev). */
 int prad_firstorder_queue_dev(const void *image, int dtype, const uint8_t *mask, long long n, long long roi_count,
                               double voxelArrayShift, double *out, void *stream);

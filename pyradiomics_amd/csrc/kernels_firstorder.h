@@ -339,6 +339,8 @@ struct FoDev {
   double gamma[5];
   FoSel sel;
   long long pick[10];      // index of every order statistic in the sorted gather
+  unsigned seg_off[10], seg_cnt[10];   // the gathered segment (one histogram bin) each order statistic lies in ...
+  long long within[10];                // ... and its rank inside that segment
   unsigned total;          // gathered elements
   int problem;
   double os[12], pq[5], median;
@@ -473,17 +475,17 @@ __global__ void __launch_bounds__(1024) fo_glue_select_kernel(const unsigned *__
     }
     if (total > capacity) problem |= 8;
     if (!problem)
-      for (int k = 0; k < 10; k++) st->pick[k] = (long long)sel.off[which[k]] + rwithin[k];
+      for (int k = 0; k < 10; k++) {
+        st->pick[k] = (long long)sel.off[which[k]] + rwithin[k];
+        st->seg_off[k] = sel.off[which[k]];
+        st->seg_cnt[k] = hist[rbin[k]];
+        st->within[k] = rwithin[k];
+      }
     for (int q = sel.nsel; q < PRAD_FO_MAXSEL; q++) { sel.bin[q] = 0; sel.off[q] = 0u; }
     st->sel = sel;
     st->total = (unsigned)(total > capacity ? 0 : total);
     st->problem = problem;
   }
-}
-
-__global__ void fo_fill_inf_kernel(double *__restrict__ p, unsigned n) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = INFINITY;
 }
 
 template <typename T>
@@ -497,11 +499,70 @@ __global__ void __launch_bounds__(1024) fo_gather_dev_kernel(const T *__restrict
   fo_gather_body(img, mask, n, st->vmin, st->scale, sel, cursors, out);
 }
 
-// after the sort of the gathered bins: order statistics, interpolated percentiles, median
-__global__ void fo_glue_pick_kernel(const double *__restrict__ sorted, FoDev *st) {
+// The order statistics straight from the gathered (unsorted) segments: workgroup r finds the element of rank within[r] in
+// its segment by a radix select over the order-preserving 64-bit keys, most significant byte first -- 8 rounds of
+// { count the next byte among the keys that match the prefix so far, pick the byte whose range holds the rank }.  One
+// launch instead of the 16 of a device-wide radix sort of the padded gather, and its cost follows the real segment sizes.
+// Counts go through per-wave tables, a lane merging the consecutive equal bytes it meets first (a bin of equal values --
+// integer-valued images -- would otherwise put every lane on one counter).
+__global__ void __launch_bounds__(1024) fo_rank_select_kernel(const double *__restrict__ gath, FoDev *st) {
+  __shared__ unsigned cnt[16][256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ unsigned long long s_k;
+  if (st->problem) return;
+  const int r = blockIdx.x, t = threadIdx.x, w = t >> 6;
+  const double *seg = gath + st->seg_off[r];
+  const unsigned n = st->seg_cnt[r];
+  if (t == 0) {
+    s_prefix = 0ull;
+    s_k = (unsigned long long)st->within[r];
+  }
+  __syncthreads();
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    for (int i = t; i < 16 * 256; i += 1024) (&cnt[0][0])[i] = 0u;
+    __syncthreads();
+    const unsigned long long prefix = s_prefix;
+    const unsigned long long mask = shift == 56 ? 0ull : (~0ull << (shift + 8));
+    int last = -1;
+    unsigned run = 0;
+    for (unsigned i = t; i < n; i += 1024) {
+      const unsigned long long key = fo_key(seg[i]);
+      if ((key & mask) != (prefix & mask)) continue;
+      const int d = (int)((key >> shift) & 255ull);
+      if (d != last) {
+        if (run) atomicAdd(&cnt[w][last], run);
+        last = d;
+        run = 0;
+      }
+      run++;
+    }
+    if (run) atomicAdd(&cnt[w][last], run);
+    __syncthreads();
+    if (t < 256) {
+      unsigned v = 0;
+      for (int q = 0; q < 16; q++) v += cnt[q][t];
+      cnt[0][t] = v;
+    }
+    __syncthreads();
+    if (t == 0) {
+      unsigned long long k = s_k, cum = 0;
+      int d = 0;
+      for (; d < 255; d++) {
+        if (k < cum + cnt[0][d]) break;
+        cum += cnt[0][d];
+      }
+      s_prefix = prefix | ((unsigned long long)d << shift);
+      s_k = k - cum;
+    }
+    __syncthreads();
+  }
+  if (t == 0) st->os[r] = fo_unkey(s_prefix);
+}
+
+// after fo_rank_select_kernel: interpolated percentiles, median
+__global__ void fo_glue_quantiles_kernel(FoDev *st) {
 #pragma clang fp contract(off)
   if (threadIdx.x != 0 || st->problem) return;
-  for (int k = 0; k < 10; k++) st->os[k] = sorted[st->pick[k]];
   for (int k = 0; k < 5; k++) st->pq[k] = fo_lerp_np(st->os[2 * k], st->os[2 * k + 1], st->gamma[k]);
   st->median = (st->m % 2) ? st->os[4] : (st->os[4] + st->os[5]) / 2.0;
 }

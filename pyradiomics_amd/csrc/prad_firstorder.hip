@@ -395,26 +395,20 @@ extern "C" int prad_firstorder_queue_dev(const void *image, int dtype, const uin
   double *partial = nullptr, *gath = nullptr, *d_out = nullptr;
   unsigned *hist = nullptr, *cursors = nullptr;
   FoDev *st = nullptr;
-  // gather capacity: an eighth of the ROI, between 2^18 and 2^21 elements (the ten selected histogram bins of a sharply peaked
-  // image -- a wavelet detail band -- hold a few per cent of the ROI; beyond the capacity the verdict sends the caller to
-  // the synchronous route)
-  unsigned cap = PRAD_FO_QUEUE_CAP;
-  while (cap < (1u << 21) && (long long)cap < roi_count / 8) cap <<= 1;
+  // gather capacity: half of the ROI, at least 2^18 elements (only memory: the selection's cost follows the real sizes of
+  // the gathered bins; beyond the capacity -- nearly all of the ROI in the ten selected bins -- the verdict sends the
+  // caller to the synchronous route)
+  unsigned cap = (unsigned)std::min<long long>(1LL << 30, std::max<long long>(PRAD_FO_QUEUE_CAP, roi_count / 2));
   PRAD_TRY(c.get<double>("fo_partial", (size_t)PRAD_FO_BLOCKS * 8, &partial));
   PRAD_TRY(c.get<unsigned>("fo_hist", PRAD_FO_BINS, &hist));
   PRAD_TRY(c.get<unsigned>("fo_cursors", PRAD_FO_MAXSEL, &cursors));
-  PRAD_TRY(c.get<double>("fo_gather_q", (size_t)2 * cap, &gath));
+  PRAD_TRY(c.get<double>("fo_gather_q", (size_t)cap, &gath));
   PRAD_TRY(c.get<double>("fo_out_q", 16, &d_out));
   {
     void *p = nullptr;
     PRAD_TRY(c.get("fo_state", sizeof(FoDev), &p));
     st = (FoDev *)p;
   }
-  double *gsorted = gath + cap;
-  size_t tmp_bytes = 0;
-  PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, gath, gsorted, (int)cap, 0, 64, s));
-  uint8_t *tmp = nullptr;
-  PRAD_TRY(c.get<uint8_t>("fo_sort_tmp_q", tmp_bytes + 16, &tmp));
   PRAD_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned) * PRAD_FO_BINS, s));
   PRAD_HIP(hipMemsetAsync(cursors, 0, sizeof(unsigned) * PRAD_FO_MAXSEL, s));
   const int blocks = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, PRAD_FO_BLOCKS));
@@ -425,11 +419,10 @@ extern "C" int prad_firstorder_queue_dev(const void *image, int dtype, const uin
     hipLaunchKernelGGL(fo_glue_sums_kernel, dim3(1), dim3(256), 0, s, (const double *)partial, blocks, roi_count, st);
     FO_DISPATCH(fo_hist_dev_kernel, dim3(hgx), dim3(1024), (const FoDev *)st, hist);
     hipLaunchKernelGGL(fo_glue_select_kernel, dim3(1), dim3(1024), 0, s, (const unsigned *)hist, cap, st);
-    hipLaunchKernelGGL(fo_fill_inf_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, gath, cap);
     FO_DISPATCH(fo_gather_dev_kernel, dim3(hgx), dim3(1024), (const FoDev *)st, cursors, gath);
     PRAD_TRY(check_launch("firstorder queue (gather)"));
-    PRAD_HIP(hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, gath, gsorted, (int)cap, 0, 64, s));
-    hipLaunchKernelGGL(fo_glue_pick_kernel, dim3(1), dim3(64), 0, s, (const double *)gsorted, st);
+    hipLaunchKernelGGL(fo_rank_select_kernel, dim3(10), dim3(1024), 0, s, (const double *)gath, st);
+    hipLaunchKernelGGL(fo_glue_quantiles_kernel, dim3(1), dim3(64), 0, s, st);
     FO_DISPATCH(fo_central_dev_kernel, dim3(blocks), dim3(256), (const FoDev *)st, partial);
     hipLaunchKernelGGL(fo_glue_central_kernel, dim3(1), dim3(256), 0, s, (const double *)partial, blocks, st);
     FO_DISPATCH(fo_band_dev_kernel, dim3(blocks), dim3(256), (const FoDev *)st, partial);

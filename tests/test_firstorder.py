@@ -200,7 +200,7 @@ def test_voxel_mode_vs_oracle(shape, radius, force2D, masked, dtype, oracle_port
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["float64", "float32", "peaked", "outlier"])
+@pytest.mark.parametrize("kind", ["float64", "float32", "peaked", "ties", "outlier"])
 def test_queue_route_equals_the_synchronous_statistics(kind):
     """prad_firstorder_queue_dev (the passes' scalars stay in device memory, glue kernels do the host's arithmetic) against
     prad_firstorder_dev: the same bits; an image the queue declines says so in its verdict word"""
@@ -210,6 +210,8 @@ def test_queue_route_equals_the_synchronous_statistics(kind):
     rng = np.random.default_rng(4)
     if kind in ("float64", "float32"):
         img, mask = _volume(np.dtype(kind).type, shape, 5, 0.62)
+    elif kind == "ties":        # integer-valued doubles: every gathered bin is one value repeated 40 000 times
+        img, mask = rng.integers(0, 51, shape).astype(np.float64), rng.random(shape) < 0.95
     elif kind == "peaked":      # a wavelet detail band: most voxels near zero, long tails
         img, mask = rng.laplace(size=shape) * 20.0, rng.random(shape) < 0.9
     else:
