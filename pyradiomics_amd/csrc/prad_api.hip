@@ -2725,10 +2725,16 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
     off += (doubles + 7) & ~(size_t)7;
   };
   for (int k = 0; k < 16; k++) layout[k] = -1;
-  if (classes & PRAD_IMG_GLCM) { take(0, (size_t)Na * GF_FEATURES); take(1, (size_t)(Na + 1) / 2 + 1); }
+  // (values and their flags back to back: the formula calls then copy both with one transfer)
+  auto take2 = [&](int kv, size_t values, int kf, size_t flags) {
+    layout[kv] = (int)off;
+    layout[kf] = (int)(off + values);
+    off += (values + (flags + 1) / 2 + 1 + 7) & ~(size_t)7;
+  };
+  if (classes & PRAD_IMG_GLCM) take2(0, (size_t)Na * GF_FEATURES, 1, (size_t)Na);
   if ((classes & PRAD_IMG_GLCM) && (classes & PRAD_IMG_MCC)) take(2, (size_t)Na + 1);
-  if (classes & PRAD_IMG_GLRLM) { take(3, (size_t)Na * ZM_FEATURES); take(4, (size_t)(Na + 1) / 2 + 1); }
-  if (classes & PRAD_IMG_GLDM) { take(5, ZM_FEATURES); take(6, 1); }
+  if (classes & PRAD_IMG_GLRLM) take2(3, (size_t)Na * ZM_FEATURES, 4, (size_t)Na);
+  if (classes & PRAD_IMG_GLDM) take2(5, ZM_FEATURES, 6, 1);
   if (classes & PRAD_IMG_NGTDM) take(7, 5);
   if (classes & PRAD_IMG_GLSZM) { take(8, ZM_FEATURES + 1); take(9, 1); }
   if (classes & PRAD_IMG_FIRSTORDER) take(10, 16);

@@ -28,6 +28,10 @@ extern "C" int prad_glcm_features_dev(const double *glcm, int Ng, int Na, int sy
   }
   if (c.deferred && c.in_arena(out, sizeof(double) * nout) && c.in_arena(empty, sizeof(int) * Na)) {
     // enqueue only (include/pyradiomics_amd.h, "result arena"): the values arrive with the stream
+    if ((const void *)empty == (const void *)(out + nout)) {      // flags right behind the values, as on the device: one copy
+      PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * nout + sizeof(int) * Na, hipMemcpyDeviceToHost, s));
+      return PRAD_OK;
+    }
     PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * nout, hipMemcpyDeviceToHost, s));
     PRAD_HIP(hipMemcpyAsync(empty, d_empty, sizeof(int) * Na, hipMemcpyDeviceToHost, s));
     return PRAD_OK;
@@ -79,6 +83,10 @@ extern "C" int prad_zone_matrix_features_dev(const double *P, int Ni, int Nj, in
     PRAD_TRY(check_launch("zone_matrix_features_kernel"));
   }
   if (enq) {
+    if ((const void *)empty == (const void *)(out + nout)) {
+      PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * nout + sizeof(int) * Na, hipMemcpyDeviceToHost, s));
+      return PRAD_OK;
+    }
     PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * nout, hipMemcpyDeviceToHost, s));
     PRAD_HIP(hipMemcpyAsync(empty, d_empty, sizeof(int) * Na, hipMemcpyDeviceToHost, s));
     return PRAD_OK;

@@ -400,8 +400,8 @@ extern "C" int prad_firstorder_queue_dev(const void *image, int dtype, const uin
   // caller to the synchronous route)
   unsigned cap = (unsigned)std::min<long long>(1LL << 30, std::max<long long>(PRAD_FO_QUEUE_CAP, roi_count / 2));
   PRAD_TRY(c.get<double>("fo_partial", (size_t)PRAD_FO_BLOCKS * 8, &partial));
-  PRAD_TRY(c.get<unsigned>("fo_hist", PRAD_FO_BINS, &hist));
-  PRAD_TRY(c.get<unsigned>("fo_cursors", PRAD_FO_MAXSEL, &cursors));
+  PRAD_TRY(c.get<unsigned>("fo_hist_q", PRAD_FO_BINS + PRAD_FO_MAXSEL, &hist));     // [histogram | gather cursors]: one memset
+  cursors = hist + PRAD_FO_BINS;
   PRAD_TRY(c.get<double>("fo_gather_q", (size_t)cap, &gath));
   PRAD_TRY(c.get<double>("fo_out_q", 16, &d_out));
   {
@@ -409,8 +409,7 @@ extern "C" int prad_firstorder_queue_dev(const void *image, int dtype, const uin
     PRAD_TRY(c.get("fo_state", sizeof(FoDev), &p));
     st = (FoDev *)p;
   }
-  PRAD_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned) * PRAD_FO_BINS, s));
-  PRAD_HIP(hipMemsetAsync(cursors, 0, sizeof(unsigned) * PRAD_FO_MAXSEL, s));
+  PRAD_HIP(hipMemsetAsync(hist, 0, sizeof(unsigned) * (PRAD_FO_BINS + PRAD_FO_MAXSEL), s));
   const int blocks = (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, PRAD_FO_BLOCKS));
   const unsigned hgx = (unsigned)std::max<long long>(1, std::min<long long>((n + 4095) / 4096, 512));
   {
