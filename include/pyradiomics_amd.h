@@ -115,7 +115,8 @@ int prad_deferred_mark(int *flag, void *stream);
  *  - prad_glcm_features_dev, prad_zone_matrix_features_dev, prad_ngtdm_features_dev and prad_glcm_mcc_dev whose output
  *    pointers lie INSIDE the arena enqueue their kernels and the device-to-host copies into those pointers and return:
  *    the values are valid once the stream has been synchronised (prad_deferred_status, or an event recorded after the
- *    call).  prad_glcm_mcc_dev then needs room for Na + 1 doubles: out[Na] != 0 says that more than 64 grey levels
+ *    call).  The arena is mapped host memory: the formula kernels store their few values straight into it (no copy
+ *    operation in the stream; PRAD_ZERO_COPY=0 restores device buffer + copy).  prad_glcm_mcc_dev then needs room for Na + 1 doubles: out[Na] != 0 says that more than 64 grey levels
  *    occurred (the synchronous call's PRAD_E_UNSUPPORTED) and out[0..Na) is void.
  * With outputs outside the arena these calls stay synchronous.  All calls of one pipeline go to ONE stream (the
  * workspace buffers are recycled in stream order).  No reference analogue (the reference computes the formulas in numpy

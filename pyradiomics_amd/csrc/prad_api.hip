@@ -2258,13 +2258,17 @@ int prad_glszm_features_dev(const int32_t *image, const uint8_t *mask, const int
                        (const int *)st.rootlist, (const int *)st.rootctl, (const int *)meta, kcap);
     PRAD_TRY(check_launch("glszm_fill_compact_kernel"));
   }
-  PRAD_TRY(zone_features_launch(c, s, P, Ng, kcap, (long long)kcap, jv, meta + 2, d_out, d_empty));
-  hipLaunchKernelGGL(glszm_verdict_kernel, dim3(1), dim3(1), 0, s, (const int *)meta, (const int *)err, d_out + ZM_FEATURES);
+  const size_t nb = sizeof(double) * (ZM_FEATURES + 1);
+  const bool enq = c.deferred && c.in_arena(out, nb) && c.in_arena(empty, sizeof(int));
+  const bool direct = enq && Context::zero_copy();        // values, verdict and flag stored straight into the arena
+  PRAD_TRY(zone_features_launch(c, s, P, Ng, kcap, (long long)kcap, jv, meta + 2, direct ? out : d_out, direct ? empty : d_empty));
+  hipLaunchKernelGGL(glszm_verdict_kernel, dim3(1), dim3(1), 0, s, (const int *)meta, (const int *)err,
+                     (direct ? out : d_out) + ZM_FEATURES);
   PRAD_TRY(check_launch("glszm_verdict_kernel"));
   PRAD_TRY(c.end_call(s));
   c.last_path = "glszm-unionfind";
-  const size_t nb = sizeof(double) * (ZM_FEATURES + 1);
-  if (c.deferred && c.in_arena(out, nb) && c.in_arena(empty, sizeof(int))) {
+  if (direct) return PRAD_OK;
+  if (enq) {
     PRAD_HIP(hipMemcpyAsync(out, d_out, nb, hipMemcpyDeviceToHost, s));
     PRAD_HIP(hipMemcpyAsync(empty, d_empty, sizeof(int), hipMemcpyDeviceToHost, s));
     return PRAD_OK;

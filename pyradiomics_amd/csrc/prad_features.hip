@@ -20,13 +20,16 @@ extern "C" int prad_glcm_features_dev(const double *glcm, int Ng, int Na, int sy
   int *d_empty = reinterpret_cast<int *>(d_out + nout);
   void *pin = nullptr;
   PRAD_TRY(c.get_pinned("feat_pin", sizeof(double) * (nout + (size_t)Na + 2), &pin));
+  const bool enq = c.deferred && c.in_arena(out, sizeof(double) * nout) && c.in_arena(empty, sizeof(int) * Na);
+  const bool direct = enq && Context::zero_copy();      // the kernel stores into the arena itself
   {
     Timed t(c, "features", s);
     hipLaunchKernelGGL(glcm_matrix_features_kernel, dim3(Na), dim3(PRAD_FEAT_THREADS), lds, s, glcm, Ng, Na, symmetric,
-                       d_out, d_empty);
+                       direct ? out : d_out, direct ? empty : d_empty);
     PRAD_TRY(check_launch("glcm_matrix_features_kernel"));
   }
-  if (c.deferred && c.in_arena(out, sizeof(double) * nout) && c.in_arena(empty, sizeof(int) * Na)) {
+  if (direct) return PRAD_OK;
+  if (enq) {
     // enqueue only (include/pyradiomics_amd.h, "result arena"): the values arrive with the stream
     if ((const void *)empty == (const void *)(out + nout)) {      // flags right behind the values, as on the device: one copy
       PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * nout + sizeof(int) * Na, hipMemcpyDeviceToHost, s));
@@ -78,9 +81,11 @@ extern "C" int prad_zone_matrix_features_dev(const double *P, int Ni, int Nj, in
   PRAD_HIP(hipMemcpyAsync(d_j, pj, sizeof(double) * Nj, hipMemcpyHostToDevice, s));
   {
     Timed t(c, "features", s);
+    const bool direct = enq && Context::zero_copy();
     hipLaunchKernelGGL(zone_matrix_features_kernel, dim3(Na), dim3(PRAD_FEAT_THREADS), 0, s, P, Ni, Nj, Na, stride_i,
-                       stride_j, stride_a, d_j, d_scr, d_out, d_empty);
+                       stride_j, stride_a, d_j, d_scr, direct ? out : d_out, direct ? empty : d_empty);
     PRAD_TRY(check_launch("zone_matrix_features_kernel"));
+    if (direct) return PRAD_OK;
   }
   if (enq) {
     if ((const void *)empty == (const void *)(out + nout)) {
@@ -109,8 +114,10 @@ extern "C" int prad_ngtdm_features_dev(const double *P, int Ng, double *out, voi
   PRAD_TRY(c.get<double>("nf_out", 8, &d_out));
   {
     Timed t(c, "features", s);
-    hipLaunchKernelGGL(ngtdm_matrix_features_kernel, dim3(1), dim3(PRAD_FEAT_THREADS), lds, s, P, Ng, d_out);
+    const bool direct = c.deferred && c.in_arena(out, sizeof(double) * 5) && Context::zero_copy();
+    hipLaunchKernelGGL(ngtdm_matrix_features_kernel, dim3(1), dim3(PRAD_FEAT_THREADS), lds, s, P, Ng, direct ? out : d_out);
     PRAD_TRY(check_launch("ngtdm_matrix_features_kernel"));
+    if (direct) return PRAD_OK;
   }
   if (c.deferred && c.in_arena(out, sizeof(double) * 5)) {
     PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(double) * 5, hipMemcpyDeviceToHost, s));

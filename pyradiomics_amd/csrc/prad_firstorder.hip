@@ -425,8 +425,14 @@ extern "C" int prad_firstorder_queue_dev(const void *image, int dtype, const uin
     FO_DISPATCH(fo_central_dev_kernel, dim3(blocks), dim3(256), (const FoDev *)st, partial);
     hipLaunchKernelGGL(fo_glue_central_kernel, dim3(1), dim3(256), 0, s, (const double *)partial, blocks, st);
     FO_DISPATCH(fo_band_dev_kernel, dim3(blocks), dim3(256), (const FoDev *)st, partial);
-    hipLaunchKernelGGL(fo_glue_final_kernel, dim3(1), dim3(256), 0, s, (const double *)partial, blocks, (const FoDev *)st, d_out);
+    const bool direct = c.deferred && c.in_arena(out, sizeof(double) * 16) && Context::zero_copy();
+    hipLaunchKernelGGL(fo_glue_final_kernel, dim3(1), dim3(256), 0, s, (const double *)partial, blocks, (const FoDev *)st,
+                       direct ? out : d_out);
     PRAD_TRY(check_launch("firstorder queue"));
+    if (direct) {
+      c.last_path = "firstorder-queue";
+      return PRAD_OK;
+    }
   }
   c.last_path = "firstorder-queue";
   const size_t nb = sizeof(double) * 16;

@@ -228,6 +228,12 @@ struct Context {
     arena_pos += bytes;
     return PRAD_OK;
   }
+  // the arena is pinned, mapped host memory: a kernel may store its few result values straight into it (no staging
+  // buffer, no copy operation in the stream); PRAD_ZERO_COPY=0 goes back to device buffer + copy
+  static bool zero_copy() {
+    static const bool on = !(getenv("PRAD_ZERO_COPY") && atoi(getenv("PRAD_ZERO_COPY")) == 0);
+    return on;
+  }
   bool in_arena(const void *p, size_t bytes) const {
     const char *q = (const char *)p;
     return arena && q >= arena && q + bytes <= arena + PRAD_ARENA_BYTES;
