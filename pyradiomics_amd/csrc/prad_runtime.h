@@ -217,7 +217,8 @@ struct Context {
     bytes = (bytes + 63) & ~(size_t)63;
     if (bytes > PRAD_ARENA_BYTES / 4) return fail(PRAD_E_ARG, "result arena: %zu bytes in one allocation", bytes);
     if (!arena) {
-      hipError_t e = hipHostMalloc((void **)&arena, PRAD_ARENA_BYTES, hipHostMallocDefault);
+      // (portable + mapped: kernels of whichever device this thread selects later may store into it)
+      hipError_t e = hipHostMalloc((void **)&arena, PRAD_ARENA_BYTES, hipHostMallocPortable | hipHostMallocMapped);
       if (e != hipSuccess) {
         arena = nullptr;
         return fail(PRAD_E_NOMEM, "hipHostMalloc(%zu) for the result arena failed: %s", (size_t)PRAD_ARENA_BYTES, hipGetErrorString(e));
