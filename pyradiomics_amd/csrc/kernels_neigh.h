@@ -201,6 +201,21 @@ __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t 
   }
 }
 
+// Launch geometry of neigh4_kernel: workgroups of 512 threads, ~8 quads (32 voxels) per thread.  Every workgroup flushes its
+// [Ng][Na+1] table with global atomics on the same addresses (they serialise in L2), so a grid sized "one workgroup per
+// 1024 voxels" spent half of a 232^3 launch there (152 -> 66 us with 768 workgroups); at 512^3 the same 768 would leave
+// the main loop 30 % slower than 8192 do (686 -> 512 us): the sweet spot follows the volume (profiles/r03_probes.md, 10).
+inline unsigned neigh_threads() {
+  static const int bt = getenv("PRAD_NEIGH_THREADS") ? atoi(getenv("PRAD_NEIGH_THREADS")) : 512;
+  return (unsigned)bt;
+}
+inline unsigned neigh_blocks(long long nquads, unsigned bt) {
+  static const int fixed = getenv("PRAD_NEIGH_BLOCKS") ? atoi(getenv("PRAD_NEIGH_BLOCKS")) : 0;
+  const long long need = (nquads + bt - 1) / bt;
+  if (fixed > 0) return (unsigned)std::max<long long>(1, std::min<long long>(need, fixed));
+  return (unsigned)std::max<long long>(1, std::min<long long>(need, std::max<long long>(256, std::min<long long>(8192, nquads / (8LL * bt)))));
+}
+
 // the angle set as 9 row masks; false if an offset is outside {-1,0,1}^3 \ {0} or repeated
 inline bool row_masks_from(const NeighSet &A, RowMasks *R) {
   for (int r = 0; r < 9; r++) R->m[r] = 0;
@@ -311,12 +326,9 @@ inline int neigh_accumulate(Context *c, hipStream_t s, const Geo &g, const VoxMo
     RowMasks R;
     // the packed-byte path reads planes z-1 .. z+1 only where the row masks say so, all inside [plo, phi)
     if ((NGTDM || alpha == 0) && (p.Nx & 3) == 0 && row_masks_from(p.set, &R)) {
-      // 6 workgroups of 8 waves per CU: every workgroup flushes its [Ng][Na+1] table with global atomics, and with one
-      // workgroup per 1024 voxels (8192 of them on a 232^3 volume) those flushes -- ~1e6 atomics on 864 addresses -- were
-      // half of the kernel: 152 / 135 us (GLDM / NGTDM) -> 70 / 68 (profiles/r03_probes.md, section 10)
-      static const int cap = getenv("PRAD_NEIGH_BLOCKS") ? atoi(getenv("PRAD_NEIGH_BLOCKS")) : 1536;
-      static const int bt = getenv("PRAD_NEIGH_THREADS") ? atoi(getenv("PRAD_NEIGH_THREADS")) : 512;
-      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((ncent >> 2) + bt - 1) / bt, cap));
+      // (grid: neigh_blocks above)
+      const unsigned bt = neigh_threads();
+      const unsigned gx = neigh_blocks(ncent >> 2, bt);
       hipLaunchKernelGGL((neigh4_kernel<NGTDM>), dim3(gx), dim3(bt), lds, s, R, levels, p.Nz, p.Ny, p.Nx, zlo, zhi,
                          Ng, Na, acc32, acc64, flags_d);
       PRAD_TRY(check_launch("neigh4_kernel"));
@@ -364,10 +376,9 @@ inline int neigh_try_both(Context *c, hipStream_t s, const Geo &g, const VoxMode
   PRAD_HIP(hipMemsetAsync(acc32, 0, sizeof(u32) * nacc, s));
   {
     Timed t(*c, "neigh", s);
-    static const int cap = getenv("PRAD_NEIGH_BLOCKS") ? atoi(getenv("PRAD_NEIGH_BLOCKS")) : 1536;
-    static const int bt = getenv("PRAD_NEIGH_THREADS") ? atoi(getenv("PRAD_NEIGH_THREADS")) : 512;
     const long long ncent = (long long)p.Nz * p.Ny * p.Nx;
-    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>(((ncent >> 2) + bt - 1) / bt, cap));
+    const unsigned bt = neigh_threads();
+    const unsigned gx = neigh_blocks(ncent >> 2, bt);
     hipLaunchKernelGGL((neigh4_kernel<2>), dim3(gx), dim3(bt), (sizeof(u64) + sizeof(u32)) * nacc, s, R, levels, p.Nz, p.Ny,
                        p.Nx, 0, p.Nz, Ng, Na, acc32, acc64, flags_d);
     PRAD_TRY(check_launch("neigh4_kernel"));
