@@ -230,8 +230,7 @@ def mode_config2(device, engine, size=256, levels=32):
 def mode_config3(device, engine, size=256):
     """BASELINE config 3: wavelet (coif1, 8 sub-bands) + LoG (sigma 1..5 mm) of a size^3 int16 volume, every derived
     image re-discretised to 32 levels (binCount) and pushed through GLCM+GLRLM; nothing leaves HBM.  Per-stage wall ms
-    (synchronised per stage) with the stage's algorithmic bytes.  Filter parity is UNPINNED (no PyWavelets / SimpleITK in
-    this run): see DESIGN.md."""
+    (synchronised per stage) with the stage's algorithmic bytes.  Filter parity: tests/test_notebook_pin.py."""
     lv, msk = make_volume(size, 32, "smooth", 0, device)
     img = (lv.to(torch.float32) * 25.0 + 3.0).to(torch.int16)
     n = img.numel()
@@ -274,7 +273,7 @@ def mode_config3(device, engine, size=256):
               "glcm_glrlm_x13": frac_of_hbm(13 * 5.0 * n, t["glcm_glrlm_x13"])}
     total = sum(t.values())
     return {"case": "%d^3 int16 volume -> 8 wavelet sub-bands + 5 LoG images -> binCount 32 -> GLCM+GLRLM, wall ms per "
-                    "stage (one synchronisation per stage / image); filter arithmetic unpinned" % size,
+                    "stage (one synchronisation per stage / image)" % size,
             "stages": stages, "total_ms": round(total, 3), "Mvoxels_s_derived": round(13 * n / (total * 1e-3) / 1e6, 1)}
 
 

@@ -439,7 +439,8 @@ int prad_resample_dev(const void *image, int dtype, const int *size, int Nd, con
 /* ---- filter stack in front of the matrices (radiomics/imageoperations.py:756-970) ---------------------------
  * The arithmetic of both filters lives in third-party wheels (PyWavelets, SimpleITK/ITK) that are not part of
  * the reference tree; these entry points implement their published algorithms (see oracle/filters_oracle.py):
- * parity with those wheels is UNPINNED.
+ * parity is pinned by the 198 brain1 values the reference recorded in notebooks/helloFeatureClass.ipynb
+ * (tests/test_notebook_pin.py).
  *
  * prad_swt_level1: one level of the undecimated (stationary) wavelet transform with periodisation along `axes`
  * (in that order), i.e. pywt.swtn(data, wavelet, level=1, start_level=0, axes) (imageoperations.py:928,935).

@@ -2,13 +2,19 @@
 
 TEST INFRASTRUCTURE ONLY (same rules as texture_oracle.c).
 
-PARITY UNPINNED.  The arithmetic lives in wheels that are neither vendored in /root/reference nor installed here:
+PARITY PINNED by outputs the reference itself recorded: notebooks/helloFeatureClass.ipynb (ipynb:1487-1559, :1609-1772)
+stores 18 first-order values for each of LoG sigma 1 / 3 / 5 mm and the 8 coif1 sub-bands of brain1 as PyWavelets /
+SimpleITK produced them; tests/golden/notebook_brain1.json (generator: tests/golden/make_notebook_golden.py) holds those
+198 numbers and tests/test_notebook_pin.py checks this file against them (wavelet <= 1e-9 relative, LoG <= 1e-6 relative
+or one float32 ulp of the image range for order statistics).
+The arithmetic lives in wheels that are neither vendored in /root/reference nor installed here:
   * wavelet: PyWavelets >= 1.6.0 (pyproject.toml:38); call sites radiomics/imageoperations.py:921-935
              (`pywt.Wavelet`, `pywt.swtn(data, wavelet, level=1, start_level=0, axes=axes)`)
   * LoG:     SimpleITK >= 2.4.0 (pyproject.toml:37); call site imageoperations.py:824-830
              (`sitk.LaplacianRecursiveGaussianImageFilter`, NormalizeAcrossScale, sigma in mm)
-and the reference's own tests hold no usable golden vector for either (tests/test_wavelet.py compares the
-UNFILTERED image, there is no LoG test).  What follows restates the published algorithms:
+and the reference's tests/ hold no usable golden vector for either (tests/test_wavelet.py compares the UNFILTERED image,
+there is no LoG test) -- the notebook outputs above are the pin.  What follows restates the
+published algorithms:
 
   swt (level 1, periodization)   out[o] = sum_k f[k] * x[(o + F/2 - k) mod N]          (PyWavelets
       `downsampling_convolution_periodization` with step 1, as used by `swt_axis` for level 1); sub-band keys are

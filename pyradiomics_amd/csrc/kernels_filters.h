@@ -9,7 +9,8 @@
 //                        anti-causal recursion with edge-replicating boundary initialisation, float64 inside the
 //                        line, float32 images between passes (imageoperations.py:824-830)
 //   log_accumulate_kernel  Laplacian accumulation  acc += d2 / spacing^2
-// Arithmetic of both filters lives in third-party wheels absent from the reference tree: parity unpinned.
+// Arithmetic of both filters lives in third-party wheels absent from the reference tree; pinned by the brain1 outputs the
+// reference recorded in notebooks/helloFeatureClass.ipynb (tests/test_notebook_pin.py).
 #pragma once
 #include <type_traits>
 #include "prad_runtime.h"

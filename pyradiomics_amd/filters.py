@@ -5,8 +5,9 @@ prad_swt_level1 / prad_log (include/pyradiomics_amd.h).
 
 Names follow the reference exactly: "wavelet-LLH" ... "wavelet-LLL" / "wavelet<k>-XYZ" (imageoperations.py:882-893)
 with the first letter belonging to the x axis, and "log-sigma-<sigma with '.'->'-'>-mm-3D" (:827).
-The third-party arithmetic behind both filters is restated from its published algorithms: parity with PyWavelets /
-SimpleITK is unpinned (oracle/filters_oracle.py)."""
+The third-party arithmetic behind both filters (PyWavelets' swtn, ITK's recursive Gaussian) is restated from its
+published algorithms and pinned by the outputs the reference recorded in notebooks/helloFeatureClass.ipynb
+(tests/test_notebook_pin.py: 198 brain1 values, wavelet <= 1e-9, LoG <= 1e-6 relative)."""
 from __future__ import annotations
 
 import ctypes as C

@@ -2,8 +2,8 @@
 """Generator of the golden vectors that PIN the filter stack to the arithmetic the
 reference really executes: PyWavelets' `pywt.swtn` (radiomics/imageoperations.py:899-970) and SimpleITK's
 `LaplacianRecursiveGaussianImageFilter` (:756-836).  Neither wheel is installable in the build container (no
-network), so this script has not run yet and the filters' parity is "unpinned" (oracle/filters_oracle.py header,
-DESIGN.md).  Run it once in ANY environment that has numpy + PyWavelets + SimpleITK:
+network), so this script has not run yet; the filters are pinned meanwhile by the outputs the reference recorded in
+its notebook (tests/golden/make_notebook_golden.py, tests/test_notebook_pin.py) and this file would add volume-level vectors.  Run it once in ANY environment that has numpy + PyWavelets + SimpleITK:
 
     python tests/golden/make_filter_golden.py            # writes tests/golden/filters_golden.npz (a few hundred KB)
 

@@ -1,5 +1,5 @@
 """GPU: wavelet / LoG kernels against the CPU restatement (oracle/filters_oracle.py; parity with PyWavelets / ITK
-itself is unpinned, see its header), plus properties that hold for any correct implementation."""
+itself is pinned by tests/test_notebook_pin.py), plus properties that hold for any correct implementation."""
 import numpy as np
 import pytest
 
@@ -209,7 +209,7 @@ def _filter_golden():
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filters_golden.npz")
     if not os.path.exists(path):
-        pytest.skip("filter parity UNPINNED: tests/golden/filters_golden.npz has not been generated yet "
+        pytest.skip("optional volume-level pin: tests/golden/filters_golden.npz has not been generated "
                     "(tests/golden/make_filter_golden.py needs PyWavelets + SimpleITK, absent from this image)")
     return np.load(path)
 

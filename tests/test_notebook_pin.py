@@ -1,0 +1,201 @@
+"""The filter stack (SURVEY.md section 8 rows a10 wavelet / a11 LoG) pinned to outputs of the REFERENCE ITSELF:
+/root/reference/notebooks/helloFeatureClass.ipynb stores what its maintainers got from
+`imageoperations.getLoGImage(image, mask, sigma=[1, 3, 5])` and `imageoperations.getWaveletImage(image, mask)` on the
+whole brain1 image -> `cropToTumorMask` -> `RadiomicsFirstOrder(...).enableAllFeatures().execute()`
+(imageoperations.py:756-836, :839-970; notebook cells at ipynb:1487-1559 and :1609-1772): 11 derived images x 18
+first-order values = 198 numbers produced by PyWavelets / SimpleITK.  tests/golden/make_notebook_golden.py extracted
+them into tests/golden/notebook_brain1.json; brain1 itself is kept in tests/golden/data/.
+
+CPU tier: oracle/filters_oracle.py (+ oracle/firstorder_oracle.py) must reproduce them -- that is what pins the
+restatement.  GPU tier: the same numbers through the product route, filters.getLoGImage / getWaveletImage (HIP kernels)
++ RadiomicsFirstOrder on the HIP backend.
+
+Tolerance: 1e-6 relative (north_star).  The LoG images are float32 (SimpleITK's real type for an int16 input): their
+order statistics (Minimum, percentiles, ...) ARE float32 values, so one float32 ulp of the image range (~3e-5 at 300)
+can exceed 1e-6 of a small percentile; for those the bound is max(1e-6 relative, 1 ulp(float32) of the image's largest
+magnitude), stated below."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+
+RTOL = 1e-6
+LOG_SIGMAS = [1.0, 3.0, 5.0]
+
+
+def _golden():
+    with open(os.path.join(GOLDEN, "notebook_brain1.json")) as f:
+        return json.load(f)
+
+
+def _brain1():
+    from pyradiomics_amd.image import read_nrrd
+    image = read_nrrd(os.path.join(GOLDEN, "data", "brain1_image.nrrd"))
+    mask = read_nrrd(os.path.join(GOLDEN, "data", "brain1_label.nrrd"))
+    return image, mask
+
+
+def _compare(image_type, got, want, ulp=0.0):
+    assert set(got) == set(want), (image_type, sorted(set(got) ^ set(want)))
+    worst = 0.0
+    for name, ref in want.items():
+        val = float(got[name])
+        tol = max(RTOL * abs(ref), ulp)
+        assert abs(val - ref) <= tol, (image_type, name, val, ref, abs(val - ref) / max(abs(ref), 1e-300))
+        worst = max(worst, abs(val - ref) / max(abs(ref), 1e-300))
+    return worst
+
+
+def _bbox(mask_array):
+    idx = np.nonzero(mask_array)
+    return tuple(slice(int(i.min()), int(i.max()) + 1) for i in idx)
+
+
+def _firstorder_oracle_features(filtered, mask_array, spacing_xyz, names):
+    """firstorder.py on the ROI crop of a filtered image, numpy only (oracle/firstorder_oracle.py); binWidth 25 is the
+    class default the notebook's call ran with (imageoperations.py:119-153 for the edges)"""
+    from oracle import firstorder_oracle as foo
+    bb = _bbox(mask_array)
+    img, roi = filtered[bb], mask_array[bb].astype(bool)
+    st = {k: np.array([v]) for k, v in foo.firstorder_stats(img, roi, 0.0).items()}
+    x = img[roi].astype(np.float64)
+    lo = x.min() - (x.min() % 25)
+    edges = np.arange(lo, x.max() + 2 * 25, 25)
+    levels = np.digitize(x, edges)
+    _, counts = np.unique(levels, return_counts=True)
+    p = (counts / counts.sum()).reshape(1, -1)
+    vol = float(np.prod(spacing_xyz))
+    return {n: float(np.asarray(foo.derive(n, st, p, vol)).ravel()[0]) for n in names}
+
+
+def test_notebook_fixture_is_complete():
+    g = _golden()
+    assert sorted(g["log"]) == ["log-sigma-%d-0-mm-3D" % s for s in (1, 3, 5)]
+    assert sorted(g["wavelet"]) == sorted("wavelet-" + b for b in ("LLH", "LHL", "LHH", "HLL", "HLH", "HHL", "HHH", "LLL"))
+    assert sum(len(v) for v in g["log"].values()) + sum(len(v) for v in g["wavelet"].values()) == 198
+
+
+def test_wavelet_restatement_matches_reference_notebook():
+    """a10: oracle/filters_oracle.swt3 == what pywt.swtn gave the reference (periodization alignment, sub-band naming,
+    odd-size wrap pad), through 18 first-order values per sub-band"""
+    from oracle import filters_oracle as fo
+    g = _golden()
+    image, mask = _brain1()
+    ap, ret = fo.swt3(image.array, "coif1")
+    bands = {"wavelet-" + k: v for k, v in ret[0].items()}
+    bands["wavelet-LLL"] = ap
+    assert set(bands) == set(g["wavelet"])
+    worst = 0.0
+    for name, want in g["wavelet"].items():
+        got = _firstorder_oracle_features(bands[name], mask.array, image.GetSpacing(), list(want))
+        worst = max(worst, _compare(name, got, want))
+    assert worst < 1e-8          # observed 7e-10: float64 end to end
+
+
+def test_log_restatement_matches_reference_notebook():
+    """a11: oracle/filters_oracle.laplacian_recursive_gaussian == what sitk.LaplacianRecursiveGaussianImageFilter gave the
+    reference (Deriche coefficients, sigma in mm, float32 between the passes, NormalizeAcrossScale)"""
+    from oracle import filters_oracle as fo
+    g = _golden()
+    image, mask = _brain1()
+    for sigma in LOG_SIGMAS:
+        name = "log-sigma-%s-mm-3D" % str(sigma).replace(".", "-")
+        out = fo.laplacian_recursive_gaussian(image.array, image.GetSpacing(), sigma)
+        assert out.dtype == np.float32
+        want = g["log"][name]
+        ulp = float(np.spacing(np.float32(max(abs(want["Minimum"]), abs(want["Maximum"])))))
+        got = _firstorder_oracle_features(out, mask.array, image.GetSpacing(), list(want))
+        _compare(name, got, want, ulp)
+
+
+def test_original_crop_features_match_reference_notebook(oracle_port):
+    """the notebook also prints first order Mean, GLCM, GLRLM and GLSZM of the unfiltered crop (binWidth 25): the same
+    numbers the baseline csv pins, checked once more through the class API with the CPU operator"""
+    from pyradiomics_amd import backend, imageoperations
+    from helpers import feature_class
+    g = _golden()["original"]
+    image, mask = _brain1()
+    ci, cm = imageoperations.cropToTumorMask(image, mask, 1)
+    old = backend._cmatrices
+    backend.set(oracle_port)
+    try:
+        for cls in ("firstorder", "glcm", "glrlm", "glszm"):
+            fc = feature_class(cls)(ci, cm, binWidth=25)
+            if cls == "firstorder":
+                fc.disableAllFeatures()
+                fc.enableFeatureByName("Mean", True)
+            got = fc.execute()
+            for name, ref in g[cls].items():
+                assert abs(float(got[name]) - ref) <= RTOL * abs(ref), (cls, name, float(got[name]), ref)
+    finally:
+        backend.set(old)
+
+
+# ---- the product route on the MI355X -----------------------------------------------------------------------------------
+def _firstorder_product(derived, mask, bbmask, settings):
+    from pyradiomics_amd import imageoperations
+    from pyradiomics_amd.firstorder import RadiomicsFirstOrder
+    ci, cm = imageoperations.cropToTumorMask(derived, mask, 1)
+    fc = RadiomicsFirstOrder(ci, cm, **settings)
+    fc.enableAllFeatures()
+    return {k: float(v) for k, v in fc.execute().items()}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_resident", [True, False])
+def test_wavelet_hip_matches_reference_notebook(device_resident):
+    from pyradiomics_amd import filters
+    g = _golden()
+    image, mask = _brain1()
+    seen = []
+    for derived, name, kw in filters.getWaveletImage(image, mask, deviceResident=device_resident):
+        want = g["wavelet"][name]
+        got = _firstorder_product(derived, mask, None, {k: v for k, v in kw.items() if k != "deviceResident"})
+        got = {k: got[k] for k in want}
+        assert _compare(name, got, want) < 1e-8
+        seen.append(name)
+    assert sorted(seen) == sorted(g["wavelet"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_resident", [True, False])
+def test_log_hip_matches_reference_notebook(device_resident):
+    from pyradiomics_amd import filters
+    g = _golden()
+    image, mask = _brain1()
+    seen = []
+    for derived, name, kw in filters.getLoGImage(image, mask, sigma=LOG_SIGMAS, deviceResident=device_resident):
+        want = g["log"][name]
+        assert derived.array.dtype == np.float32          # SimpleITK's real type for an int16 input
+        ulp = float(np.spacing(np.float32(max(abs(want["Minimum"]), abs(want["Maximum"])))))
+        got = _firstorder_product(derived, mask, None, {k: v for k, v in kw.items() if k not in ("deviceResident", "sigma")})
+        got = {k: got[k] for k in want}
+        _compare(name, got, want, ulp)
+        seen.append(name)
+    assert seen == ["log-sigma-1-0-mm-3D", "log-sigma-3-0-mm-3D", "log-sigma-5-0-mm-3D"]
+
+
+@pytest.mark.gpu
+def test_filter_stack_through_the_extractor_matches_reference_notebook():
+    """the same 198 numbers through RadiomicsFeatureExtractor.execute (featureextractor.py:371-395 route: filter the
+    whole image, crop, feature classes), i.e. what a user of the reference's API gets"""
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    g = _golden()
+    image, mask = _brain1()
+    ex = RadiomicsFeatureExtractor(binWidth=25)
+    ex.disableAllImageTypes()
+    ex.enableImageTypeByName("LoG", customArgs={"sigma": LOG_SIGMAS})
+    ex.enableImageTypeByName("Wavelet")
+    ex.disableAllFeatures()
+    ex.enableFeatureClassByName("firstorder")
+    res = ex.execute(image, mask)
+    for group in ("log", "wavelet"):
+        for image_type, want in g[group].items():
+            ulp = 0.0
+            if group == "log":
+                ulp = float(np.spacing(np.float32(max(abs(want["Minimum"]), abs(want["Maximum"])))))
+            got = {k: float(res["%s_firstorder_%s" % (image_type, k)]) for k in want}
+            _compare(image_type, got, want, ulp)

@@ -147,11 +147,11 @@ def test_golden_features(oracle_backend, cfgname):
                 assert abs(val - ref) <= 1e-6 * abs(ref), (cls, name, val, ref)
 
 
-# ---- filter restatements (parity with PyWavelets / SimpleITK is UNPINNED: neither wheel exists here and the reference
+# ---- filter restatements (pinned to PyWavelets / SimpleITK outputs by tests/test_notebook_pin.py; neither wheel exists here and the reference
 # ---- holds no usable golden vector) against independent scipy implementations, as sanity bounds ----------------------
 def test_swt_restatement_is_a_periodic_convolution_with_the_tabulated_filters():
     """every level-1 sub-band must equal the separable periodic (wrap) convolution of the image with dec_lo / dec_hi,
-    up to ONE circular shift per axis that is the same for all sub-bands (the alignment is the unpinned part)"""
+    up to ONE circular shift per axis that is the same for all sub-bands (the alignment itself is pinned by tests/test_notebook_pin.py)"""
     from scipy import ndimage
     from oracle import filters_oracle as fo
     rng = np.random.default_rng(7)
@@ -200,12 +200,13 @@ def test_log_restatement_tracks_the_true_laplacian_of_gaussian():
 
 def test_filters_restatement_matches_wheels():
     """pins oracle/filters_oracle.py to PyWavelets / SimpleITK outputs once tests/golden/make_filter_golden.py has run
-    somewhere those wheels exist; until then the filter oracle is 'parity unpinned' and this test says so"""
+    somewhere those wheels exist -- an optional VOLUME-level pin on top of tests/test_notebook_pin.py (the reference's own
+    recorded outputs, which is what pins the filter oracle today)"""
     import os
     import pytest
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filters_golden.npz")
     if not os.path.exists(path):
-        pytest.skip("filter parity UNPINNED: tests/golden/filters_golden.npz not generated (needs PyWavelets + SimpleITK)")
+        pytest.skip("optional volume-level pin: tests/golden/filters_golden.npz not generated (needs PyWavelets + SimpleITK)")
     from oracle import filters_oracle as fo
     g = np.load(path)
     for name in ("brain1", "seeded"):
