@@ -214,6 +214,45 @@ class CMatricesCPU:
             raise IndexError("Calculation of %s Failed." % what.upper())
         return out
 
+    def glcm_glrlm_angle_sharded(self, image, mask, Ng, Nr, threads=None):
+        """calculate_glcm + calculate_glrlm of a whole segment-mode volume with the 13 (or 4) unidirectional angles dealt to
+        `threads` host threads, one core call per (matrix, angle): the core takes the angle table as an argument
+        (cmatrices.c:4-92, :299-541), every angle writes its own [.., a] column, so the result equals the one-call matrices
+        bit for bit (tests/test_oracle.py checks that) while a 512^3 volume takes seconds instead of half a minute.
+        ctypes releases the GIL for the duration of a foreign call.  -> (glcm [Ng,Ng,Na], glrlm [Ng,Nr,Na], angles,
+        {"wall_s", "cpu_s": sum of the per-call times, "threads"})"""
+        import time
+        from concurrent.futures import ThreadPoolExecutor
+        img, msk, size, strides = self._arrays(image, mask)
+        ang = self._angles(size, None, False, -1)
+        Na, Nd = ang.shape
+        bb = self._bb(0, size, None, 0, -1)
+        if threads is None:
+            threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        glcm = np.zeros((Ng, Ng, Na), dtype=np.float64)
+        glrlm = np.zeros((Ng, Nr, Na), dtype=np.float64)
+
+        def one(job):
+            what, a = job
+            one_angle = np.ascontiguousarray(ang[a:a + 1])
+            out = np.zeros((Ng, Ng if what == "glcm" else Nr, 1), dtype=np.float64)
+            fn = self.L.calculate_glcm if what == "glcm" else self.L.calculate_glrlm
+            extra = (Ng,) if what == "glcm" else (Ng, Nr)
+            t = time.perf_counter()
+            ok = fn(_i(img), msk.ctypes.data_as(C.c_char_p), _i(size), _i(bb), _i(strides), _i(one_angle), 1, Nd,
+                    out.ctypes.data_as(_dp), *extra)
+            if not ok:
+                raise IndexError("Calculation of %s Failed." % what.upper())
+            (glcm if what == "glcm" else glrlm)[:, :, a] = out[:, :, 0]
+            return time.perf_counter() - t
+        jobs = [("glrlm", a) for a in range(Na)] + [("glcm", a) for a in range(Na)]       # the slower calls first
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=max(1, min(threads, len(jobs)))) as pool:
+            cpu_s = sum(pool.map(one, jobs))
+        wall = time.perf_counter() - t0
+        # cmatrices.c:524-534 per angle already handled inside each one-angle call
+        return glcm, glrlm, ang, {"wall_s": wall, "cpu_s": cpu_s, "threads": max(1, min(threads, len(jobs)))}
+
     def generate_angles(self, size, distances, bidirectional, force2D, force2Ddimension):
         size = np.ascontiguousarray(np.asarray(size).astype(np.intc, copy=False))
         if size.ndim != 1:

@@ -143,10 +143,6 @@ def last_path() -> str:
     return load().prad_last_path().decode()
 
 
-def last_variant() -> str:
-    return load().prad_last_variant().decode()
-
-
 PRAD_E_DEFERRED = -6
 
 

@@ -3,7 +3,10 @@ oracle/_ref/libcmatrices_ref.so travelled with the repo (else our C restatement)
   C2  synthetic 256^3 volume, full mask, 32 grey levels, ALL FIVE matrices, iid and smooth levels;
   C4  voxel-based GLCM JointEntropy with the exampleVoxel.yaml window (force2D, kernelRadius 2) on a 512^3 volume:
       >= 10^4 sampled kernel centres, fused device feature vs the reference's per-kernel matrix + the numpy formula
-      of glcm.py:560-576."""
+      of glcm.py:560-576;
+  HEADLINE  the bench volume itself, 512^3 at 32 levels, uniform and smooth: GLCM + GLRLM bit for bit against the
+      reference C run angle by angle over the host's cores (cmatrices.c:4-92, :299-541 take the angle table as an
+      argument), for the synchronous call AND for what the deferred pipeline of bench.py's timed loop leaves behind."""
 import numpy as np
 import pytest
 
@@ -93,3 +96,26 @@ def test_cases_in_flight_on_threads_equal_the_sequential_run():
         for k in a:
             x, y = float(a[k]), float(b[k])
             assert x == y or (np.isnan(x) and np.isnan(y)), k
+
+
+@pytest.mark.parametrize("kind", ["uniform", "smooth"])
+def test_headline_512_bit_exact(kind, checker):
+    """VERDICT r3 'missing #2': the headline configuration at FULL size, not a slab and not only identities"""
+    import torch
+    from bench import headline_loop
+    from pyradiomics_amd import engine
+    n, Ng = 512, 32
+    img_d, msk_d = _volume(n, kind, 0)                       # seed 0 = rank 0's volume in bench.py
+    want_g, want_r, want_ang, info = checker.glcm_glrlm_angle_sharded(img_d.cpu().numpy(), msk_d.cpu().numpy().astype(bool), Ng, n)
+    g, r, ang = engine.glcm_glrlm(img_d, msk_d, Ng, n)       # synchronous
+    assert engine.last_path() == "sweep" and engine.last_variant().startswith("fw")
+    assert np.array_equal(ang, want_ang)
+    assert np.array_equal(g.cpu().numpy(), want_g), "GLCM (synchronous call)"
+    assert np.array_equal(r.cpu().numpy(), want_r), "GLRLM (synchronous call)"
+    # the timed loop of bench.py: deferred steps back to back, the pack of volume N riding in the walk launch of N-1
+    outs = [[None, None] for _ in range(4)]
+    _, _, (gd, rd) = headline_loop(engine, img_d, msk_d, Ng, n, 4, 2, torch.cuda.synchronize, outs)
+    assert np.array_equal(gd.cpu().numpy(), want_g), "GLCM (deferred pipeline)"
+    assert np.array_equal(rd.cpu().numpy(), want_r), "GLRLM (deferred pipeline)"
+    for o in outs:                                            # every volume in flight, not only the last
+        assert np.array_equal(o[0].cpu().numpy(), want_g) and np.array_equal(o[1].cpu().numpy(), want_r)

@@ -222,3 +222,19 @@ def test_filters_restatement_matches_wheels():
             assert np.abs(got - want).max() <= 1e-5 * np.abs(want).max()
     ap, ret = fo.swt3(g["seeded__input"], "db2", level=2)
     np.testing.assert_allclose(ret[1]["LHL"], g["seeded__wavelet_db2_level2_LHL"], rtol=1e-9, atol=1e-9)
+
+
+def test_angle_sharded_checker_equals_one_call(oracle_port, oracle_ref):
+    """the full-size headline parity test (tests/test_gpu_configs.py) and bench.py's cpu_baseline run the reference C one
+    (matrix, angle) at a time over the host's cores: that must equal the reference's one-call matrices bit for bit,
+    including the per-angle 'no line with two ROI voxels' rule of cmatrices.c:524-534"""
+    rng = np.random.default_rng(12)
+    for shape in ((17, 20, 23), (1, 30, 31), (9, 1, 12)):
+        img = rng.integers(1, 7, size=shape).astype(np.int32)
+        img[: shape[0] // 2] = 2
+        msk = rng.random(shape) < 0.85
+        for cpu in (oracle_port, oracle_ref):
+            g, r, ang, info = cpu.glcm_glrlm_angle_sharded(img, msk, 6, max(shape), threads=3)
+            G, A = cpu.calculate_glcm(img, msk, [1], 6, False, 0)
+            R, _ = cpu.calculate_glrlm(img, msk, 6, max(shape), False, 0)
+            assert np.array_equal(ang, A) and np.array_equal(g, G[0]) and np.array_equal(r, R[0]) and info["threads"] == 3
