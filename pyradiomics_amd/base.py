@@ -241,6 +241,12 @@ class RadiomicsFeaturesBase:
 
     def dropEnqueued(self):
         self._enqueued = None
+        # matrices queued with deferred=True were memoised on the shared levels tensor before their verdict was known: a
+        # voided image (level outside [1, Ng]) must not serve them to the synchronous route that raises the reference's error
+        memo = getattr(self.imageArray, "_prad_memo", None)
+        if isinstance(memo, dict):
+            for k in [k for k in memo if k != "mask"]:
+                del memo[k]
 
     def imageRequest(self):
         """(class key, request dict) for cMatrices.segment_image_enqueue -- this class's share of the one-call-per-image

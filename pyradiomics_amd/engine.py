@@ -69,6 +69,7 @@ class _KeepList:
         return len(self._l())
 
 
+_NUMPY2 = int(np.__version__.split(".")[0]) >= 2
 _deferred_keep = _KeepList()
 
 
@@ -731,7 +732,11 @@ def bin_image(image: torch.Tensor, mask: torch.Tensor, with_counts: bool = False
     mm = (C.c_double * 2)()
     n = image.numel()
     binCount = kwargs.get("binCount")
-    if binCount is not None and 1 <= int(binCount) <= 4096 and not os.environ.get("PRAD_BIN_TWO_CALLS"):
+    # float32 images: the device builds np.histogram's edges in float32 arithmetic as NumPy >= 2 does (NEP 50); NumPy 1.x
+    # computes them in float64 and casts, which can differ by one ulp -> the host-built edges serve those installations
+    f32_edges_ok = image.dtype != torch.float32 or _NUMPY2
+    if (binCount is not None and 1 <= int(binCount) <= 4096 and f32_edges_ok
+            and not os.environ.get("PRAD_BIN_TWO_CALLS")):
         # fixed bin count: edges built on the device, one synchronisation instead of two
         nb = int(binCount)
         levels = torch.empty(image.shape, dtype=torch.int32, device=image.device)

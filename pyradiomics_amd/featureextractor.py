@@ -261,16 +261,47 @@ class RadiomicsFeatureExtractor:
         # collects image i, so the GPU works through a queue while the host does its round trips (first order) and its
         # Python; results keep the reference's order (featureextractor.py:371-396 evaluates image after image).
         pending = None
-        for derived, typeName, kw in gens:
-            cimg, cmask = imageoperations.cropToTumorMask(derived, mask, label, padDistance=kernelRadius,
-                                                          deviceResident=on_dev)
-            started = self._startFeatures(cimg, cmask, typeName, **kw)
+        try:
+            for derived, typeName, kw in gens:
+                cimg, cmask = imageoperations.cropToTumorMask(derived, mask, label, padDistance=kernelRadius,
+                                                              deviceResident=on_dev)
+                started = self._startFeatures(cimg, cmask, typeName, **kw)
+                prev, pending = pending, started
+                if prev is not None:
+                    try:
+                        out.update(self._finishFeatures(prev))
+                    except BaseException:
+                        self._abandonFeatures(pending)       # the look-ahead image was queued already
+                        pending = None
+                        raise
             if pending is not None:
-                out.update(self._finishFeatures(pending))
-            pending = started
-        if pending is not None:
-            out.update(self._finishFeatures(pending))
+                last, pending = pending, None
+                out.update(self._finishFeatures(last))
+        except BaseException:
+            # an exception between "queued" and "collected" (the next image's filter / crop / binning, a host class): the
+            # queued image still holds a ticket of the library's in-flight table (4 per thread) and its side streams hold
+            # tensors -- retire them, or every later case on this (persistent batch worker) thread fails
+            if pending is not None:
+                self._abandonFeatures(pending)
+            raise
         return out
+
+    @staticmethod
+    def _abandonFeatures(started):
+        """waits for and discards everything _startFeatures queued for one derived image (never raises)"""
+        fcs, queued, (image_token, token), _name = started
+        cm = queued[0].cMatrices if queued else (fcs[0][1].cMatrices if fcs else None)
+        for tok, wait in ((image_token, "segment_image_wait"), (token, "segment_wait")):
+            if tok is not None and cm is not None:
+                try:
+                    getattr(cm, wait)(tok)
+                except Exception:          # noqa: BLE001 -- the original exception is the one to report
+                    pass
+        for fc in queued:
+            try:
+                fc.dropEnqueued()
+            except Exception:              # noqa: BLE001
+                pass
 
     def computeFeatures(self, image, mask, imageTypeName, **kwargs):
         """featureextractor.py:560-604"""
@@ -294,7 +325,15 @@ class RadiomicsFeatureExtractor:
         # class (featureextractor.py:560-604), each with its own round trips.
         cm = fcs[0][1].cMatrices if fcs else None
         side = hasattr(cm, "segment_queue") and fcs[0][1].deviceResident
-        queued, names = [], []
+        queued, names, ticket = [], [], [None]
+        try:
+            return self._queueFeatures(fcs, cm, side, queued, names, ticket, imageTypeName, kwargs)
+        except BaseException:
+            # a class that fails to queue after the image call went through: retire that call's ticket before re-raising
+            self._abandonFeatures((fcs, queued, (ticket[0], None), imageTypeName))
+            raise
+
+    def _queueFeatures(self, fcs, cm, side, queued, names, ticket, imageTypeName, kwargs):
         # one library call queues every class the fused kernels cover (cMatrices.segment_image_enqueue) ...
         image_token = None
         if side and hasattr(cm, "segment_image_enqueue"):
@@ -310,6 +349,7 @@ class RadiomicsFeatureExtractor:
                     levels, any_fc.maskArray, any_fc.coefficients["Ng"], any_fc.coefficients["Ns"],
                     {k: rq for k, (fc, rq) in reqs.items()}, force2D=kwargs.get("force2D", False),
                     force2Ddimension=kwargs.get("force2Ddimension", 0))
+                ticket[0] = image_token
                 for k, fin in finishes.items():
                     reqs[k][0].takeEnqueued(fin)
                     queued.append(reqs[k][0])
@@ -328,7 +368,11 @@ class RadiomicsFeatureExtractor:
         """second half of computeFeatures: the host-side classes evaluated, the queued ones waited for and collected"""
         fcs, queued, (image_token, token), imageTypeName = started
         out = collections.OrderedDict()
-        values = {cname: fc.execute() for cname, fc in fcs if fc not in queued}
+        try:
+            values = {cname: fc.execute() for cname, fc in fcs if fc not in queued}
+        except BaseException:
+            self._abandonFeatures(started)
+            raise
         if queued:
             cm = queued[0].cMatrices
             ok = cm.segment_image_wait(image_token) if image_token is not None else True

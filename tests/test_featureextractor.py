@@ -478,3 +478,51 @@ def test_check_mask_entry_point():
     sub = Image(m[1:4].copy(), origin=(0.0, 0.0, 1.0))
     bb, corrected = io.checkMask(img, sub, correctMask=True)
     assert list(bb) == [3, 8, 2, 6, 1, 3] and corrected is not None and np.array_equal(corrected.array, m)
+
+
+@pytest.mark.gpu
+def test_exception_between_queue_and_collect_leaves_no_ticket(monkeypatch):
+    """ADVICE r3 (medium): the look-ahead pipeline holds a ticket of the library's 4-slot in-flight table per queued image;
+    an exception raised while the NEXT derived image is prepared (or by a host class) must retire it, or the persistent
+    batch worker thread is poisoned ('4 images are in flight')"""
+    from pyradiomics_amd import backend, cmatrices, imageoperations
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    backend.set(cmatrices)
+    ex = RadiomicsFeatureExtractor(binWidth=25)
+    ex.enableImageTypeByName("Wavelet")
+    want = ex.execute(IMG, LBL)
+    real = imageoperations.cropToTumorMask
+    calls = {"n": 0}
+
+    def flaky(*a, **k):
+        calls["n"] += 1
+        if calls["n"] == 3:                       # image 3 fails while image 2 is queued and image 1 collected
+            raise RuntimeError("injected")
+        return real(*a, **k)
+    for _ in range(6):                             # more failures than the table has slots
+        calls["n"] = 0
+        monkeypatch.setattr(imageoperations, "cropToTumorMask", flaky)
+        with pytest.raises(RuntimeError, match="injected"):
+            ex.execute(IMG, LBL)
+        monkeypatch.setattr(imageoperations, "cropToTumorMask", real)
+    # a host-side class failing in _finishFeatures while its image's device classes are queued
+    from pyradiomics_amd import firstorder
+    real_init = firstorder.RadiomicsFirstOrder._initCalculation
+    boom = {"n": 0}
+
+    def bad(self, *a, **k):
+        boom["n"] += 1
+        if boom["n"] == 2:
+            raise RuntimeError("injected-host")
+        return real_init(self, *a, **k)
+    for _ in range(6):
+        boom["n"] = 0
+        monkeypatch.setattr(firstorder.RadiomicsFirstOrder, "_initCalculation", bad)
+        with pytest.raises(RuntimeError, match="injected-host"):
+            ex.execute(IMG, LBL)
+        monkeypatch.setattr(firstorder.RadiomicsFirstOrder, "_initCalculation", real_init)
+    for _ in range(5):
+        got = ex.execute(IMG, LBL)
+        for k, v in want.items():
+            if not k.startswith("diagnostics"):
+                assert float(got[k]) == float(v), k
