@@ -463,6 +463,15 @@ int prad_log_dev(const float *in, const int *size, int Nd, const double *spacing
  * other sigmas fill the gaps.  outs: HOST array of nsig DEVICE pointers; the same arithmetic per sigma as prad_log_dev. */
 int prad_log_multi_dev(const float *in, const int *size, int Nd, const double *spacing, const double *sigmas, int nsig,
                        int normalize, float *const *outs, void *stream);
+/* The same filter on float64 images: sitk.LaplacianRecursiveGaussianImageFilter keeps the input's real type
+ * (imageoperations.py:824-830), so a float64 input -- e.g. after `normalize: true`, whose output is float64 -- is
+ * filtered with float64 images between the passes and returns float64. */
+int prad_log_f64(const double *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
+                 double *out);
+int prad_log_dev_f64(const double *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
+                     double *out, void *stream);
+int prad_log_multi_dev_f64(const double *in, const int *size, int Nd, const double *spacing, const double *sigmas,
+                           int nsig, int normalize, double *const *outs, void *stream);
 
 #ifdef __cplusplus
 }

@@ -201,25 +201,29 @@ def _filter_lines(data, c):
     return out + s
 
 
-def recursive_gaussian(image_f32, axis, sigma, spacing, order, normalize_across_scale=False):
-    """one 1-D pass: float32 image in, float32 image out, float64 arithmetic inside each line"""
+def recursive_gaussian(image, axis, sigma, spacing, order, normalize_across_scale=False, real=np.float32):
+    """one 1-D pass: image of the filter's real type in and out (float32, or float64 for float64 inputs), float64
+    arithmetic inside each line"""
     c = recursive_gaussian_coefficients(sigma, spacing, order, normalize_across_scale)
-    moved = np.moveaxis(np.asarray(image_f32, dtype=np.float32).astype(np.float64), axis, -1)
-    return np.moveaxis(_filter_lines(moved, c), -1, axis).astype(np.float32)
+    moved = np.moveaxis(np.asarray(image, dtype=real).astype(np.float64), axis, -1)
+    return np.moveaxis(_filter_lines(moved, c), -1, axis).astype(real)
 
 
 def laplacian_recursive_gaussian(array_zyx, spacing_xyz, sigma, normalize_across_scale=True):
-    """ITK LaplacianRecursiveGaussianImageFilter on a numpy (z, y, x) array with SimpleITK (x, y, z) spacing"""
-    img = np.asarray(array_zyx).astype(np.float32)
+    """ITK LaplacianRecursiveGaussianImageFilter on a numpy (z, y, x) array with SimpleITK (x, y, z) spacing.  The images
+    between the passes and the result have the filter's real type: float64 for a float64 input, float32 otherwise
+    (sitk keeps the input's real type, imageoperations.py:824-830)"""
+    real = np.float64 if np.asarray(array_zyx).dtype == np.float64 else np.float32
+    img = np.asarray(array_zyx).astype(real)
     nd = img.ndim
     sp = [float(s) for s in spacing_xyz][::-1]   # per numpy axis
-    acc = np.zeros(img.shape, dtype=np.float32)
+    acc = np.zeros(img.shape, dtype=real)
     # ITK dimension order is x, y, z = numpy axes nd-1 ... 0
     for dim in range(nd - 1, -1, -1):
         cur = img
         for other in range(nd - 1, -1, -1):
             if other != dim:
-                cur = recursive_gaussian(cur, other, sigma, sp[other], 0)
-        cur = recursive_gaussian(cur, dim, sigma, sp[dim], 2, normalize_across_scale)
-        acc = (acc.astype(np.float64) + cur.astype(np.float64) / (sp[dim] * sp[dim])).astype(np.float32)
+                cur = recursive_gaussian(cur, other, sigma, sp[other], 0, real=real)
+        cur = recursive_gaussian(cur, dim, sigma, sp[dim], 2, normalize_across_scale, real=real)
+        acc = (acc.astype(np.float64) + cur.astype(np.float64) / (sp[dim] * sp[dim])).astype(real)
     return acc

@@ -9,7 +9,7 @@ import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libpyradiomics_amd.so")
-SOURCES = ["prad_api.hip", "prad_firstorder.hip", "prad_features.hip", "prad_resample.hip"]
+SOURCES = ["prad_api.hip", "prad_firstorder.hip", "prad_features.hip", "prad_resample.hip", "prad_filters.hip"]
 
 
 def _headers() -> list:

@@ -100,6 +100,9 @@ SYMBOLS = {
     "prad_log": (C.c_int, [_vp, _ip, C.c_int, _vp, C.c_double, C.c_int, _vp]),
     "prad_log_dev": (C.c_int, [_vp, _ip, C.c_int, _vp, C.c_double, C.c_int, _vp, _vp]),
     "prad_log_multi_dev": (C.c_int, [_vp, _ip, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "prad_log_f64": (C.c_int, [_vp, _ip, C.c_int, _vp, C.c_double, C.c_int, _vp]),
+    "prad_log_dev_f64": (C.c_int, [_vp, _ip, C.c_int, _vp, C.c_double, C.c_int, _vp, _vp]),
+    "prad_log_multi_dev_f64": (C.c_int, [_vp, _ip, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
 }
 
 _lib = None

@@ -94,12 +94,13 @@ struct RGaussCoef {
 
 // final store of a pass: plain float image, or (last pass of a Laplacian term) acc = first ? v / sp2 : acc + v / sp2 with the
 // roundings of the separate accumulation step (the term is rounded to float32 first, ITK's image type)
-__device__ __forceinline__ void rg_store(float *__restrict__ o, float *__restrict__ acc, long long idx, double v, double sp2,
+template <typename T>
+__device__ __forceinline__ void rg_store(T *__restrict__ o, T *__restrict__ acc, long long idx, double v, double sp2,
                                          int first) {
-  const float f = (float)v;
+  const T f = (T)v;
   if (acc) {
     const double a = first ? 0.0 : (double)acc[idx];
-    acc[idx] = (float)(a + (double)f / sp2);
+    acc[idx] = (T)(a + (double)f / sp2);
   } else {
     o[idx] = f;
   }
@@ -112,17 +113,17 @@ __device__ __forceinline__ void rg_store(float *__restrict__ o, float *__restric
 // ACCLOAD: the pass accumulates into an image that already holds earlier terms (acc != nullptr, first == 0); a template
 // parameter because a load behind a run-time condition gets its own `s_waitcnt vmcnt(0)` (every step of the
 // derivative passes then waited for its accumulator load alone: 205 us instead of 94)
-template <bool ACCLOAD>
-__global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restrict__ in, long long outer, int ln,
+template <bool ACCLOAD, typename T = float>
+__global__ void __launch_bounds__(256) rgauss_line_kernel(const T *__restrict__ in, long long outer, int ln,
                                                           long long inner, RGaussCoef c,
-                                                          double *__restrict__ scratch, float *__restrict__ out,
-                                                          float *__restrict__ acc, double sp2, int first) {
+                                                          double *__restrict__ scratch, T *__restrict__ out,
+                                                          T *__restrict__ acc, double sp2, int first) {
 #pragma clang fp contract(off)  // ITK's line arithmetic is plain multiply / add; keep the same roundings
   const long long lines = outer * inner;
   const long long line = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (line >= lines) return;
   const long long base = (line / inner) * ln * inner + (line % inner);
-  const float *d = in + base;
+  const T *d = in + base;
   double *s = scratch + base;
   const long long st = inner;
   // causal pass (itkRecursiveSeparableImageFilter.hxx FilterDataArray)
@@ -142,7 +143,7 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
     double p1 = s3, p2 = s2, p3 = s1, p4 = s0; // scratch[i-1..i-4]
     int i = 4;
     for (; i + PRAD_RG_B <= ln; i += PRAD_RG_B) {
-      float buf[PRAD_RG_B];
+      T buf[PRAD_RG_B];
 #pragma unroll
       for (int k = 0; k < PRAD_RG_B; k++) buf[k] = d[(long long)(i + k) * st];
 #pragma unroll
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
     double q0 = a4, q1 = a3, q2 = a2, q3 = a1;                              // scratch[i], [i+1], [i+2], [i+3]
     int i = ln - 4;
     for (; i - PRAD_RG_B >= 0; i -= PRAD_RG_B) {      // produces samples i-1 .. i-B
-      float buf[PRAD_RG_B], ab[PRAD_RG_B];
+      T buf[PRAD_RG_B], ab[PRAD_RG_B];
       double sb[PRAD_RG_B];
 #pragma unroll
       for (int k = 0; k < PRAD_RG_B; k++) {
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
         sb[k] = s[(long long)(i - 1 - k) * st];
         // (the accumulator too: a load right before its store, one per step, left the derivative passes at 205 us
         // against 94 us for the smoothing ones -- the compiler keeps it behind the previous step's store)
-        ab[k] = ACCLOAD ? acc[base + (long long)(i - 1 - k) * st] : 0.f;
+        ab[k] = ACCLOAD ? acc[base + (long long)(i - 1 - k) * st] : (T)0;
       }
 #pragma unroll
       for (int k = 0; k < PRAD_RG_B; k++) {
@@ -201,8 +202,8 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const float *__restric
         v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
         {
           const long long idx = base + (long long)(i - 1 - k) * st;
-          const float f = (float)(sb[k] + v);
-          if (acc) acc[idx] = (float)((double)ab[k] + (double)f / sp2);     // = rg_store
+          const T f = (T)(sb[k] + v);
+          if (acc) acc[idx] = (T)((double)ab[k] + (double)f / sp2);     // = rg_store
           else out[idx] = f;
         }
         dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = buf[k];
@@ -410,6 +411,310 @@ template <int AM>
 __global__ void __launch_bounds__(256) rgauss_line2_kernel(RGMulti M, long long outer, int ln, long long inner, double sp2) {
   const int sg = blockIdx.y;
   rgauss_line2_body<AM>(M.in[sg], outer, ln, inner, M.k[sg], M.scratch[sg], M.out[sg], M.acc[sg], sp2);
+}
+
+// ---- whole lines in LDS (round 4) ---------------------------------------------------------------------------------
+// Every pass above reads its line twice (the two sweeps) and parks float64 partials or block states in HBM: 16..28 B per
+// sample against the 8 B a pass has to move (one read, one write).  Here a wave keeps TL whole lines in LDS: the tile is
+// fetched once with full-width coalesced loads, both sweeps of the recursion read it from LDS (one lane per line), the
+// result replaces the input sample in place, and the tile is written back with full-width stores -- 8 B per sample and
+// pass (12 when the pass adds into the Laplacian).  The arithmetic per line is rgauss_line2_body's, operation for
+// operation (anti-causal states every RB samples, forward sweep with the block's anti-causal part recomputed), so the
+// outputs are the same bits.  One wave per workgroup; a 256-sample float line group of 32 lines is 33 KB + 7 KB of states:
+// four waves per CU, one per SIMD.
+//   T        image type between the passes: float (ITK's real type for integer and float32 inputs) or double (float64 inputs)
+//   TL       lines per wave (a power of two <= 64; the lanes beyond TL only help to move the tile)
+//   CONTIG   the filtered axis is the contiguous one: the tile is one contiguous piece of memory, element (line t, sample j)
+//            sits at LDS element t * PT + j (PT odd: the lanes' reads spread over the banks); otherwise lines are TL
+//            neighbouring inner positions, element j * TL + t
+//   AM       0 plain output, 1 first Laplacian term (acc = v / sp2), 2 later term (acc += v / sp2)
+template <typename T>
+struct RGMultiT {
+  RGaussCoef k[PRAD_LOG_MAXSIG];
+  const T *in[PRAD_LOG_MAXSIG];
+  T *out[PRAD_LOG_MAXSIG];
+  T *acc[PRAD_LOG_MAXSIG];
+};
+template <typename T> struct RGVec;
+template <> struct RGVec<float> { typedef float4 type; };
+template <> struct RGVec<double> { typedef double2 type; };
+#define PRAD_RGT_RB 16
+
+template <typename T, int TL, bool CONTIG, int AM>
+__global__ void __launch_bounds__(64) rgauss_tile_kernel(RGMultiT<T> M, long long outer, int ln, long long inner, double sp2,
+                                                         int PT, int vec) {
+#pragma clang fp contract(off)  // ITK's line arithmetic is plain multiply / add; keep the same roundings
+  extern __shared__ __align__(16) unsigned char rg_smem[];
+  constexpr int RB = PRAD_RGT_RB;
+  constexpr int V = 16 / (int)sizeof(T);
+  typedef typename RGVec<T>::type VT;
+  const int lane = threadIdx.x;
+  const int sg = blockIdx.y;
+  const RGaussCoef &c = M.k[sg];
+  const T *__restrict__ in = M.in[sg];
+  T *tile = reinterpret_cast<T *>(rg_smem);
+  const long long tile_elems = CONTIG ? (long long)TL * PT : (long long)ln * TL;
+  double *states = reinterpret_cast<double *>(rg_smem + ((tile_elems * sizeof(T) + 15) & ~(size_t)15));
+  long long gbase;
+  int nl;
+  if (CONTIG) {
+    const long long l0 = (long long)blockIdx.x * TL;
+    nl = (int)min((long long)TL, outer - l0);
+    gbase = l0 * ln;
+  } else {
+    const long long nchunk = (inner + TL - 1) / TL;
+    const long long o = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
+    nl = (int)min((long long)TL, inner - ch * TL);
+    gbase = o * ln * inner + ch * TL;
+  }
+  // ---- tile in ----
+  if (CONTIG) {
+    if (vec) {
+      const int nq = nl * ln / V;
+#pragma unroll 8
+      for (int q = lane; q < nq; q += 64) {
+        const VT v = *reinterpret_cast<const VT *>(in + gbase + (long long)q * V);
+        const int e = q * V, t = e / ln, j = e - t * ln;
+        const T *pv = reinterpret_cast<const T *>(&v);
+#pragma unroll
+        for (int i = 0; i < V; i++) tile[t * PT + j + i] = pv[i];
+      }
+    } else {
+      const int ne = nl * ln;
+#pragma unroll 8
+      for (int e = lane; e < ne; e += 64) {
+        const int t = e / ln, j = e - t * ln;
+        tile[t * PT + j] = in[gbase + e];
+      }
+    }
+  } else {
+    if (vec) {
+      constexpr int QR = TL / V > 0 ? TL / V : 1;
+      const int nq = ln * QR;
+#pragma unroll 8
+      for (int q = lane; q < nq; q += 64) {
+        const int j = q / QR, t = (q % QR) * V;
+        if (t < nl) *reinterpret_cast<VT *>(tile + j * TL + t) = *reinterpret_cast<const VT *>(in + gbase + (long long)j * inner + t);
+      }
+    } else {
+      const int ne = ln * TL;
+#pragma unroll 8
+      for (int e = lane; e < ne; e += 64) {
+        const int j = e / TL, t = e % TL;
+        if (t < nl) tile[e] = in[gbase + (long long)j * inner + t];
+      }
+    }
+  }
+  __syncthreads();
+#define PRAD_RGT_AT(j) tile[CONTIG ? lane * PT + (j) : (j) * TL + lane]
+  if (lane < nl) {
+    const int nb = (ln - 4) / RB + 1;      // blocks [k RB, (k + 1) RB) for k < nb - 1; the last takes the remainder (4 .. RB + 3)
+    double *sp = states + lane;            // boundary k (1 <= k < nb), value i: sp[((k - 1) * 4 + i) * TL]
+    // ---- sweep 1: anti-causal, from the end, states only ----
+    {
+      const double v2 = PRAD_RGT_AT(ln - 1);
+      const double y1 = PRAD_RGT_AT(ln - 2), y2 = PRAD_RGT_AT(ln - 3);
+      double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-1
+      double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-2
+      double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-3
+      double a4 = y2 * c.M1 + y1 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-4
+      a1 -= v2 * c.BM1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+      a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+      a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
+      a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
+      double dp0 = PRAD_RGT_AT(ln - 4), dp1 = y2, dp2 = y1, dp3 = v2;    // data[i .. i+3] at i = ln-4
+      double q0 = a4, q1 = a3, q2 = a2, q3 = a1;                          // anticausal[i .. i+3]
+      int i = ln - 4;                // the next sample produced is i - 1
+      while (i > 0) {
+        if ((i % RB) == 0) {
+          const int k = i / RB - 1;
+          sp[(k * 4 + 0) * TL] = q0;
+          sp[(k * 4 + 1) * TL] = q1;
+          sp[(k * 4 + 2) * TL] = q2;
+          sp[(k * 4 + 3) * TL] = q3;
+        }
+        const int nstep = min(i, ((i - 1) % RB) + 1);    // down to the next boundary (or to 0)
+        if (nstep == RB) {
+          T buf[RB];
+#pragma unroll
+          for (int k = 0; k < RB; k++) buf[k] = PRAD_RGT_AT(i - 1 - k);
+#pragma unroll
+          for (int k = 0; k < RB; k++) {
+            double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
+            v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
+            dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = buf[k];
+            q3 = q2; q2 = q1; q1 = q0; q0 = v;
+          }
+        } else {
+          for (int k = 0; k < nstep; k++) {
+            double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
+            v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
+            dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = PRAD_RGT_AT(i - 1 - k);
+            q3 = q2; q2 = q1; q1 = q0; q0 = v;
+          }
+        }
+        i -= nstep;
+      }
+    }
+    // ---- sweep 2: forward, block by block; the result replaces the input in the tile ----
+    double p1 = 0, p2 = 0, p3 = 0, p4 = 0;        // causal[b-1 .. b-4]
+    double dm1 = 0, dm2 = 0, dm3 = 0;             // data[b-1 .. b-3]
+    for (int kb = 0; kb < nb; kb++) {
+      const int b = kb * RB;
+      const bool lastblk = kb == nb - 1;
+      const int len = lastblk ? ln - b : RB;      // RB, or 4 .. RB + 3 for the last block
+      constexpr int RM = RB + 4;                  // samples held: the block and, for the anti-causal start, the 4 behind it
+      T dv[RM];
+      double cv[RM];
+#pragma unroll
+      for (int j = 0; j < RM; j++) {
+        const int idx = b + j;
+        dv[j] = idx < ln ? PRAD_RGT_AT(idx) : (T)0;
+      }
+      int j0 = 0;
+      if (kb == 0) {
+        const double v1 = dv[0];
+        const double x1 = dv[1], x2 = dv[2], x3 = dv[3];
+        double s0 = v1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+        double s1 = x1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+        double s2 = x2 * c.N0 + x1 * c.N1 + v1 * c.N2 + v1 * c.N3;
+        double s3 = x3 * c.N0 + x2 * c.N1 + x1 * c.N2 + v1 * c.N3;
+        s0 -= v1 * c.BN1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
+        s1 -= s0 * c.D1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
+        s2 -= s1 * c.D1 + s0 * c.D2 + v1 * c.BN3 + v1 * c.BN4;
+        s3 -= s2 * c.D1 + s1 * c.D2 + s0 * c.D3 + v1 * c.BN4;
+        cv[0] = s0; cv[1] = s1; cv[2] = s2; cv[3] = s3;
+        dm1 = x3; dm2 = x2; dm3 = x1;
+        p1 = s3; p2 = s2; p3 = s1; p4 = s0;
+        j0 = 4;
+      }
+#pragma unroll
+      for (int j = 0; j < RM; j++) {
+        if (j >= j0 && j < len) {
+          const double di = dv[j];
+          double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
+          v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
+          cv[j] = v;
+          dm3 = dm2; dm2 = dm1; dm1 = di;
+          p4 = p3; p3 = p2; p2 = p1; p1 = v;
+        }
+      }
+      double q0, q1, q2, q3, e0, e1, e2, e3;      // anticausal[i .. i+3], data[i .. i+3] at i = b + len
+      int jtop = len - 1;                         // block-local index of the first sample still to produce
+      if (lastblk) {
+        double v2 = 0, y1 = 0, y2 = 0, y3 = 0;
+#pragma unroll
+        for (int j = 0; j < RM; j++) {            // (register array: compile-time indices only)
+          if (j == len - 1) v2 = dv[j];
+          if (j == len - 2) y1 = dv[j];
+          if (j == len - 3) y2 = dv[j];
+          if (j == len - 4) y3 = dv[j];
+        }
+        double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+        double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+        double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
+        double a4 = y2 * c.M1 + y1 * c.M2 + v2 * c.M3 + v2 * c.M4;
+        a1 -= v2 * c.BM1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+        a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
+        a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
+        a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
+#pragma unroll
+        for (int j = 0; j < RM; j++) {
+          if (j == len - 1) cv[j] += a1;
+          if (j == len - 2) cv[j] += a2;
+          if (j == len - 3) cv[j] += a3;
+          if (j == len - 4) cv[j] += a4;
+        }
+        q0 = a4; q1 = a3; q2 = a2; q3 = a1;
+        e0 = y3; e1 = y2; e2 = y1; e3 = v2;
+        jtop = len - 5;
+      } else {
+        q0 = sp[(kb * 4 + 0) * TL];
+        q1 = sp[(kb * 4 + 1) * TL];
+        q2 = sp[(kb * 4 + 2) * TL];
+        q3 = sp[(kb * 4 + 3) * TL];
+        e0 = dv[RB]; e1 = dv[RB + 1]; e2 = dv[RB + 2]; e3 = dv[RB + 3];
+      }
+#pragma unroll
+      for (int jj = RM - 1; jj >= 0; jj--) {
+        if (jj <= jtop) {
+          double v = e0 * c.M1 + e1 * c.M2 + e2 * c.M3 + e3 * c.M4;
+          v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
+          cv[jj] += v;
+          e3 = e2; e2 = e1; e1 = e0; e0 = dv[jj];
+          q3 = q2; q2 = q1; q1 = q0; q0 = v;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RM; j++)
+        if (j < len) PRAD_RGT_AT(b + j) = (T)cv[j];
+    }
+  }
+#undef PRAD_RGT_AT
+  __syncthreads();
+  // ---- tile out ----
+  T *__restrict__ dst = AM == 0 ? M.out[sg] : M.acc[sg];
+  auto fin = [&](T f, T a) -> T {       // = rg_store
+    if (AM == 0) return f;
+    return (T)((AM == 2 ? (double)a : 0.0) + (double)f / sp2);
+  };
+  if (CONTIG) {
+    if (vec) {
+      const int nq = nl * ln / V;
+#pragma unroll 4
+      for (int q = lane; q < nq; q += 64) {
+        const int e = q * V, t = e / ln, j = e - t * ln;
+        VT a;
+        if (AM == 2) a = *reinterpret_cast<const VT *>(dst + gbase + (long long)q * V);
+        VT r;
+        T *pr = reinterpret_cast<T *>(&r);
+        const T *pa = reinterpret_cast<const T *>(&a);
+#pragma unroll
+        for (int i = 0; i < V; i++) pr[i] = fin(tile[t * PT + j + i], AM == 2 ? pa[i] : (T)0);
+        *reinterpret_cast<VT *>(dst + gbase + (long long)q * V) = r;
+      }
+    } else {
+      const int ne = nl * ln;
+#pragma unroll 4
+      for (int e = lane; e < ne; e += 64) {
+        const int t = e / ln, j = e - t * ln;
+        const T a = AM == 2 ? dst[gbase + e] : (T)0;
+        dst[gbase + e] = fin(tile[t * PT + j], a);
+      }
+    }
+  } else {
+    if (vec) {
+      constexpr int QR = TL / V > 0 ? TL / V : 1;
+      const int nq = ln * QR;
+#pragma unroll 4
+      for (int q = lane; q < nq; q += 64) {
+        const int j = q / QR, t = (q % QR) * V;
+        if (t < nl) {
+          const long long gi = gbase + (long long)j * inner + t;
+          VT a;
+          if (AM == 2) a = *reinterpret_cast<const VT *>(dst + gi);
+          const VT f = *reinterpret_cast<const VT *>(tile + j * TL + t);
+          VT r;
+          T *pr = reinterpret_cast<T *>(&r);
+          const T *pa = reinterpret_cast<const T *>(&a), *pf = reinterpret_cast<const T *>(&f);
+#pragma unroll
+          for (int i = 0; i < V; i++) pr[i] = fin(pf[i], AM == 2 ? pa[i] : (T)0);
+          *reinterpret_cast<VT *>(dst + gi) = r;
+        }
+      }
+    } else {
+      const int ne = ln * TL;
+#pragma unroll 4
+      for (int e = lane; e < ne; e += 64) {
+        const int j = e / TL, t = e % TL;
+        if (t < nl) {
+          const long long gi = gbase + (long long)j * inner + t;
+          const T a = AM == 2 ? dst[gi] : (T)0;
+          dst[gi] = fin(tile[e], a);
+        }
+      }
+    }
+  }
 }
 
 // The same recursion for the contiguous axis (inner == 1): a lane-per-line walk would read 64 different cache lines

@@ -15,7 +15,6 @@
 #include "kernels_sweepfw2.h"
 #include "kernels_neigh.h"
 #include "kernels_glszm.h"
-#include "kernels_filters.h"
 #include "kernels_voxel.h"
 #include "kernels_mcc.h"
 #include "kernels_voxtex.h"
@@ -1542,262 +1541,6 @@ int voxel_texture_features_dev(int family, const int32_t *image, const uint8_t *
   return PRAD_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// filters
-// ------------------------------------------------------------------------------------------------
-int swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi, int flen,
-                   const int *axes, int naxes, double *out, hipStream_t s) {
-  Context &c = ctx();
-  PRAD_TRY(c.ensure_device());
-  Geo g;
-  PRAD_TRY(make_geo(size, Nd, &g));
-  if (!in || !out || !dec_lo || !dec_hi || !axes) return fail(PRAD_E_ARG, "swt: NULL pointer");
-  if (flen < 2 || flen > PRAD_MAX_TAPS) return fail(PRAD_E_ARG, "swt: filter length %d outside [2,%d]", flen, PRAD_MAX_TAPS);
-  if (naxes < 1 || naxes > Nd) return fail(PRAD_E_ARG, "swt: naxes=%d", naxes);
-  FilterTaps T;
-  T.F = flen;
-  for (int k = 0; k < flen; k++) { T.lo[k] = dec_lo[k]; T.hi[k] = dec_hi[k]; }
-  for (int a = 0; a < naxes; a++) {
-    if (axes[a] < 0 || axes[a] >= Nd) return fail(PRAD_E_ARG, "swt: axis %d out of range", axes[a]);
-    if (g.size[axes[a]] % 2) return fail(PRAD_E_ARG, "swt: axis %d has odd length %d (pad first, imageoperations.py:914-919)", axes[a], g.size[axes[a]]);
-  }
-  PRAD_TRY(c.begin_call(s));
-  // stage k holds 2^k arrays; stages alternate between two workspaces, the last stage writes `out`
-  double *ws[2] = {nullptr, nullptr};
-  const size_t n = (size_t)g.n;
-  if (naxes >= 2) PRAD_TRY(c.get<double>("swt_a", n * ((size_t)1 << (naxes - 1)), &ws[0]));
-  if (naxes >= 3) PRAD_TRY(c.get<double>("swt_b", n * ((size_t)1 << (naxes - 2)), &ws[1]));
-  const double *src = in;
-  {
-    Timed t(c, "swt", s);
-    for (int a = 0; a < naxes; a++) {
-      const int count = 1 << a;
-      double *dst = (a == naxes - 1) ? out : ws[(naxes - 2 - a) & 1];
-      const int ax = axes[a];
-      long long outer = 1;
-      for (int d = 0; d < ax; d++) outer *= g.size[d];
-      const long long inner = g.stride[ax];
-      const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((g.n + 255) / 256, 8192));
-      const int N = g.size[ax];
-      // geometry-indexed kernel when the taps wrap at most once and the grid limits hold; the general kernel otherwise
-      const bool geo_ok = T.F <= N && !getenv("PRAD_SWT_OLD") &&
-                          (inner == 1 ? outer <= 65535LL * 65535LL : (N <= 65535 && outer <= 65535));
-      for (int j = 0; j < count; j++) {
-        const double *in = src + (size_t)j * n;
-        double *o_lo = dst + (size_t)(2 * j) * n, *o_hi = dst + (size_t)(2 * j + 1) * n;
-        if (geo_ok && inner == 1) {
-          const dim3 grid((unsigned)((N + 255) / 256), (unsigned)std::min<long long>(outer, 65535), (unsigned)((outer + 65534) / 65535));
-          hipLaunchKernelGGL(swt_axis2_kernel<true>, grid, dim3(256), 0, s, in, outer, N, inner, T, o_lo, o_hi);
-        } else if (geo_ok) {
-          const dim3 grid((unsigned)((inner + 255) / 256), (unsigned)N, (unsigned)outer);
-          hipLaunchKernelGGL(swt_axis2_kernel<false>, grid, dim3(256), 0, s, in, outer, N, inner, T, o_lo, o_hi);
-        } else {
-          hipLaunchKernelGGL(swt_axis_kernel, dim3(gx), dim3(256), 0, s, in, outer, N, inner, T, o_lo, o_hi);
-        }
-        PRAD_TRY(check_launch("swt_axis_kernel"));
-      }
-      src = dst;
-    }
-  }
-  PRAD_TRY(c.end_call(s));
-  PRAD_HIP(hipStreamSynchronize(s));
-  c.last_path = "swt";
-  return PRAD_OK;
-}
-
-// ITK itkRecursiveGaussianImageFilter.hxx SetUp / ComputeNCoefficients / ComputeDCoefficients /
-// ComputeRemainingCoefficients (symmetric orders 0 and 2)
-void rgauss_n(double sigmad, double A1, double B1, double A2, double B2, double N[4], double &SN, double &DN, double &EN) {
-  const double W1 = 0.6681, L1 = -1.3932, W2 = 2.0787, L2 = -1.3732;
-  const double s1 = sin(W1 / sigmad), s2 = sin(W2 / sigmad), c1 = cos(W1 / sigmad), c2 = cos(W2 / sigmad);
-  const double e1 = exp(L1 / sigmad), e2 = exp(L2 / sigmad);
-  N[0] = A1 + A2;
-  N[1] = e2 * (B2 * s2 - (A2 + 2 * A1) * c2);
-  N[1] += e1 * (B1 * s1 - (A1 + 2 * A2) * c1);
-  N[2] = (A1 + A2) * c2 * c1;
-  N[2] -= B1 * c2 * s1 + B2 * c1 * s2;
-  N[2] *= 2 * e1 * e2;
-  N[2] += A2 * e1 * e1 + A1 * e2 * e2;
-  N[3] = e2 * e1 * e1 * (B2 * s2 - A2 * c2);
-  N[3] += e1 * e2 * e2 * (B1 * s1 - A1 * c1);
-  SN = N[0] + N[1] + N[2] + N[3];
-  DN = N[1] + 2 * N[2] + 3 * N[3];
-  EN = N[1] + 4 * N[2] + 9 * N[3];
-}
-
-RGaussCoef rgauss_coefficients(double sigma, double spacing, int order, bool normalize) {
-  const double W1 = 0.6681, L1 = -1.3932, W2 = 2.0787, L2 = -1.3732;
-  const double A1[3] = {1.3530, -0.6724, -1.3563}, B1[3] = {1.8151, -3.4327, 5.2318};
-  const double A2[3] = {-0.3531, 0.6724, 0.3446}, B2[3] = {0.0902, 0.6100, -2.2355};
-  const double sigmad = sigma / fabs(spacing);
-  const double c1 = cos(W1 / sigmad), c2 = cos(W2 / sigmad), e1 = exp(L1 / sigmad), e2 = exp(L2 / sigmad);
-  double D[4];
-  D[3] = e1 * e1 * e2 * e2;
-  D[2] = -2 * c1 * e1 * e2 * e2;
-  D[2] += -2 * c2 * e2 * e1 * e1;
-  D[1] = 4 * c2 * c1 * e1 * e2;
-  D[1] += e1 * e1 + e2 * e2;
-  D[0] = -2 * (e2 * c2 + e1 * c1);
-  const double SD = 1.0 + D[0] + D[1] + D[2] + D[3];
-  const double DD = D[0] + 2 * D[1] + 3 * D[2] + 4 * D[3];
-  const double ED = D[0] + 4 * D[1] + 9 * D[2] + 16 * D[3];
-  double N[4], SN, DN, EN;
-  if (order == 0) {
-    rgauss_n(sigmad, A1[0], B1[0], A2[0], B2[0], N, SN, DN, EN);
-    const double alpha0 = 2 * SN / SD - N[0];
-    for (int i = 0; i < 4; i++) N[i] /= alpha0;
-  } else {
-    const double scale = normalize ? sigma * sigma : 1.0;
-    double N0s[4], N2s[4], SN0, DN0, EN0, SN2, DN2, EN2;
-    rgauss_n(sigmad, A1[0], B1[0], A2[0], B2[0], N0s, SN0, DN0, EN0);
-    rgauss_n(sigmad, A1[2], B1[2], A2[2], B2[2], N2s, SN2, DN2, EN2);
-    const double beta = -(2 * SN2 - SD * N2s[0]) / (2 * SN0 - SD * N0s[0]);
-    for (int i = 0; i < 4; i++) N[i] = N2s[i] + beta * N0s[i];
-    SN = SN2 + beta * SN0; DN = DN2 + beta * DN0; EN = EN2 + beta * EN0;
-    const double alpha2 = (EN * SD * SD - ED * SN * SD - 2 * DN * DD * SD + 2 * DD * DD * SN) / (SD * SD * SD);
-    for (int i = 0; i < 4; i++) N[i] = N[i] * scale / alpha2;
-  }
-  RGaussCoef c;
-  c.N0 = N[0]; c.N1 = N[1]; c.N2 = N[2]; c.N3 = N[3];
-  c.D1 = D[0]; c.D2 = D[1]; c.D3 = D[2]; c.D4 = D[3];
-  c.M1 = N[1] - D[0] * N[0]; c.M2 = N[2] - D[1] * N[0]; c.M3 = N[3] - D[2] * N[0]; c.M4 = -D[3] * N[0];
-  const double SNn = c.N0 + c.N1 + c.N2 + c.N3, SM = c.M1 + c.M2 + c.M3 + c.M4, SDd = 1.0 + D[0] + D[1] + D[2] + D[3];
-  c.BN1 = D[0] * SNn / SDd; c.BN2 = D[1] * SNn / SDd; c.BN3 = D[2] * SNn / SDd; c.BN4 = D[3] * SNn / SDd;
-  c.BM1 = D[0] * SM / SDd; c.BM2 = D[1] * SM / SDd; c.BM3 = D[2] * SM / SDd; c.BM4 = D[3] * SM / SDd;
-  return c;
-}
-
-// nsig sigmas of one input in the same launches (blockIdx.y = sigma): see RGMulti in kernels_filters.h
-int log_multi_dev(const float *in, const int *size, int Nd, const double *spacing, const double *sigmas, int nsig,
-                  int normalize, float *const *outs, hipStream_t s) {
-  Context &c = ctx();
-  PRAD_TRY(c.ensure_device());
-  Geo g;
-  PRAD_TRY(make_geo(size, Nd, &g));
-  if (!in || !outs || !spacing || !sigmas) return fail(PRAD_E_ARG, "log: NULL pointer");
-  if (nsig < 1 || nsig > PRAD_LOG_MAXSIG) return fail(PRAD_E_ARG, "log: %d sigmas per call outside [1, %d]", nsig, PRAD_LOG_MAXSIG);
-  for (int q = 0; q < nsig; q++) {
-    if (!(sigmas[q] > 0.0)) return fail(PRAD_E_ARG, "log: sigma must be > 0");
-    if (!outs[q]) return fail(PRAD_E_ARG, "log: NULL output");
-  }
-  for (int d = 0; d < Nd; d++)
-    if (g.size[d] < 4) return fail(PRAD_E_ARG, "log: axis %d has %d < 4 samples (imageoperations.py:811)", d, g.size[d]);
-  PRAD_TRY(c.begin_call(s));
-  const size_t n = (size_t)g.n;
-  float *bufA[PRAD_LOG_MAXSIG], *bufB[PRAD_LOG_MAXSIG], *bufC[PRAD_LOG_MAXSIG];
-  double *scratch[PRAD_LOG_MAXSIG];
-  for (int q = 0; q < nsig; q++) {
-    const std::string tag = q ? "#s" + std::to_string(q) : "";
-    PRAD_TRY(c.get<float>(("log_a" + tag).c_str(), n, &bufA[q]));
-    PRAD_TRY(c.get<float>(("log_b" + tag).c_str(), n, &bufB[q]));
-    PRAD_TRY(c.get<float>(("log_c" + tag).c_str(), n, &bufC[q]));
-    PRAD_TRY(c.get<double>(("log_scratch" + tag).c_str(), n, &scratch[q]));
-  }
-  {
-    Timed t(c, "log", s);
-    // ITK dimension order x, y, z = array axes Nd-1 .. 0
-    bool first = true;
-    // Laplacian term of dimension dim = second derivative along dim of the image smoothed along the other dimensions,
-    // in ITK's pass order (smoothing passes from the last axis to the first, then the derivative).  The derivative pass
-    // accumulates straight into `out` (acc += term / spacing^2, roundings of the separate step).  Two terms begin with
-    // the same smoothing pass along the last axis: it is computed once and kept (identical arithmetic, identical bits).
-    bool have_shared = false;        // bufC = smoothed-along-the-last-axis copy of the input
-    int shared_axis = -1;
-    for (int dim = Nd - 1; dim >= 0; dim--) {
-      const float *cur[PRAD_LOG_MAXSIG];
-      for (int q = 0; q < nsig; q++) cur[q] = in;
-      int flip = 0;
-      // forced: 0 = ping-pong buffers, 1 = into bufC (the shared first smoothing)
-      auto pass = [&](int ax, int order, int forced, bool accumulate) -> int {
-        RGMulti M;
-        memset(&M, 0, sizeof(M));
-        float *dst[PRAD_LOG_MAXSIG];
-        for (int q = 0; q < nsig; q++) {
-          M.k[q] = rgauss_coefficients(sigmas[q], spacing[ax], order, normalize != 0);
-          dst[q] = forced ? bufC[q] : (flip ? bufB[q] : bufA[q]);
-          M.in[q] = cur[q];
-          M.scratch[q] = scratch[q];
-          M.out[q] = dst[q];
-          M.acc[q] = accumulate ? outs[q] : nullptr;
-        }
-        long long outer = 1;
-        for (int d = 0; d < ax; d++) outer *= g.size[d];
-        const long long inner = g.stride[ax];
-        const long long lines = outer * inner;
-        const double sp2 = spacing[ax] * spacing[ax];
-        const bool accload = accumulate && !first;
-        if (inner == 1 && g.size[ax] >= 64 && !getenv("PRAD_LOG_NO_SPLIT")) {   // contiguous axis, two waves per 64 lines (kernels_filters.h)
-#define PRAD_XL2(W, TL, AM) hipLaunchKernelGGL((rgauss_xline2_kernel<W, TL, AM>), dim3((unsigned)((lines + TL - 1) / TL), (unsigned)nsig), dim3(128), 0, s, M, lines, g.size[ax], sp2)
-#define PRAD_XL2W(W, TL) do { if (!accumulate) PRAD_XL2(W, TL, 0); else if (first) PRAD_XL2(W, TL, 1); else PRAD_XL2(W, TL, 2); } while (0)
-          // tile = 16 samples x 64 lines per wave; measured at 256^3: 176 us, against 191 us for 32 x 64 (50 KB of LDS per
-          // workgroup) and 265 us for 32 x 32 (128-byte row pieces, twice the waves, half the lanes recursing)
-          static const int xl_mode = getenv("PRAD_LOG_XL") ? atoi(getenv("PRAD_LOG_XL")) : 0;   // tuning override
-          if (xl_mode == 2) PRAD_XL2W(32, 64);
-          else if (xl_mode == 3) PRAD_XL2W(32, 32);
-          else PRAD_XL2W(16, 64);
-#undef PRAD_XL2W
-#undef PRAD_XL2
-          PRAD_TRY(check_launch("rgauss_xline2_kernel"));
-        } else if (inner == 1 && g.size[ax] >= 8) {      // contiguous axis: LDS-tiled walk (see kernels_filters.h; a lane-per-line walk of this axis measured 343 us instead of 294 at 256^3)
-          for (int q = 0; q < nsig; q++)
-            hipLaunchKernelGGL(rgauss_xline_kernel, dim3((unsigned)((lines + PRAD_RG_T - 1) / PRAD_RG_T)), dim3(64), 0, s, M.in[q],
-                               lines, g.size[ax], M.k[q], M.scratch[q], M.out[q], M.acc[q], sp2, first ? 1 : 0);
-          PRAD_TRY(check_launch("rgauss_xline_kernel"));
-        } else if (!getenv("PRAD_LOG_OLDLINE")) {   // strided axis: no float64 copy of the causal pass (kernels_filters.h)
-          const dim3 grid((unsigned)((lines + 255) / 256), (unsigned)nsig);
-          if (!accumulate)
-            hipLaunchKernelGGL(rgauss_line2_kernel<0>, grid, dim3(256), 0, s, M, outer, g.size[ax], inner, sp2);
-          else if (first)
-            hipLaunchKernelGGL(rgauss_line2_kernel<1>, grid, dim3(256), 0, s, M, outer, g.size[ax], inner, sp2);
-          else
-            hipLaunchKernelGGL(rgauss_line2_kernel<2>, grid, dim3(256), 0, s, M, outer, g.size[ax], inner, sp2);
-          PRAD_TRY(check_launch("rgauss_line2_kernel"));
-        } else {
-          for (int q = 0; q < nsig; q++) {
-            if (accload)
-              hipLaunchKernelGGL(rgauss_line_kernel<true>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, M.in[q], outer,
-                                 g.size[ax], inner, M.k[q], M.scratch[q], M.out[q], M.acc[q], sp2, 0);
-            else
-              hipLaunchKernelGGL(rgauss_line_kernel<false>, dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, M.in[q], outer,
-                                 g.size[ax], inner, M.k[q], M.scratch[q], M.out[q], M.acc[q], sp2, first ? 1 : 0);
-          }
-          PRAD_TRY(check_launch("rgauss_line_kernel"));
-        }
-        for (int q = 0; q < nsig; q++) cur[q] = dst[q];
-        if (!forced) flip ^= 1;
-        return PRAD_OK;
-      };
-      bool first_pass = true;
-      for (int other = Nd - 1; other >= 0; other--) {
-        if (other == dim) continue;
-        if (first_pass && Nd >= 3 && other == Nd - 1) {     // smoothing of the INPUT along the last axis: shared
-          if (!have_shared || shared_axis != other) {
-            PRAD_TRY(pass(other, 0, 1, false));
-            have_shared = true;
-            shared_axis = other;
-          }
-          for (int q = 0; q < nsig; q++) cur[q] = bufC[q];
-        } else {
-          PRAD_TRY(pass(other, 0, 0, false));
-        }
-        first_pass = false;
-      }
-      PRAD_TRY(pass(dim, 2, 0, true));
-      first = false;
-    }
-  }
-  PRAD_TRY(c.end_call(s));
-  PRAD_HIP(hipStreamSynchronize(s));
-  c.last_path = "log";
-  return PRAD_OK;
-}
-
-int log_dev(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize, float *out,
-            hipStream_t s) {
-  if (!out) return fail(PRAD_E_ARG, "log: NULL pointer");
-  return log_multi_dev(in, size, Nd, spacing, &sigma, 1, normalize, &out, s);
-}
-
 }  // namespace
 
 // =================================================================================================
@@ -2570,54 +2313,6 @@ int prad_level_counts_dev(const int32_t *levels, const uint8_t *mask, long long 
   PRAD_TRY(check_launch("level_counts_kernel"));
   PRAD_HIP(hipMemcpyAsync(counts, d, sizeof(long long) * nb, hipMemcpyDeviceToHost, s));
   PRAD_HIP(hipStreamSynchronize(s));
-  return PRAD_OK;
-}
-
-// ---- filters ---------------------------------------------------------------------------------
-int prad_swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi,
-                        int flen, const int *axes, int naxes, double *out, void *stream) {
-  return swt_level1_dev(in, size, Nd, dec_lo, dec_hi, flen, axes, naxes, out, (hipStream_t)stream);
-}
-int prad_swt_level1(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi, int flen,
-                    const int *axes, int naxes, double *out) {
-  Context &c = ctx();
-  PRAD_TRY(c.ensure_device());
-  Geo g;
-  PRAD_TRY(make_geo(size, Nd, &g));
-  if (!in || !out || naxes < 1 || naxes > Nd) return fail(PRAD_E_ARG, "swt: bad arguments");
-  const size_t n = (size_t)g.n, nout = n << naxes;
-  double *d_in = nullptr, *d_out = nullptr;
-  PRAD_TRY(c.get<double>("swt_in", n, &d_in));
-  PRAD_TRY(c.get<double>("swt_out", nout, &d_out));
-  PRAD_HIP(hipMemcpyAsync(d_in, in, sizeof(double) * n, hipMemcpyHostToDevice, c.own_stream));
-  int rc = swt_level1_dev(d_in, size, Nd, dec_lo, dec_hi, flen, axes, naxes, d_out, c.own_stream);
-  if (rc != PRAD_OK) return rc;
-  return copy_back(c, out, d_out, nout);
-}
-int prad_log_multi_dev(const float *in, const int *size, int Nd, const double *spacing, const double *sigmas, int nsig,
-                       int normalize, float *const *outs, void *stream) {
-  return log_multi_dev(in, size, Nd, spacing, sigmas, nsig, normalize, outs, (hipStream_t)stream);
-}
-int prad_log_dev(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
-                 float *out, void *stream) {
-  return log_dev(in, size, Nd, spacing, sigma, normalize, out, (hipStream_t)stream);
-}
-int prad_log(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
-             float *out) {
-  Context &c = ctx();
-  PRAD_TRY(c.ensure_device());
-  Geo g;
-  PRAD_TRY(make_geo(size, Nd, &g));
-  if (!in || !out) return fail(PRAD_E_ARG, "log: NULL pointer");
-  const size_t n = (size_t)g.n;
-  float *d_in = nullptr, *d_out = nullptr;
-  PRAD_TRY(c.get<float>("log_in", n, &d_in));
-  PRAD_TRY(c.get<float>("log_out", n, &d_out));
-  PRAD_HIP(hipMemcpyAsync(d_in, in, sizeof(float) * n, hipMemcpyHostToDevice, c.own_stream));
-  int rc = log_dev(d_in, size, Nd, spacing, sigma, normalize, d_out, c.own_stream);
-  if (rc != PRAD_OK) return rc;
-  PRAD_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * n, hipMemcpyDeviceToHost, c.own_stream));
-  PRAD_HIP(hipStreamSynchronize(c.own_stream));
   return PRAD_OK;
 }
 

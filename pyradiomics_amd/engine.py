@@ -898,11 +898,18 @@ def wavelet_images(image: torch.Tensor, wavelet="coif1"):
     return out
 
 
+def _log_real(image: torch.Tensor) -> torch.Tensor:
+    """the filter's real image type: float64 inputs stay float64, everything else is float32 (SimpleITK's real type of the
+    input, imageoperations.py:824-830)"""
+    return image.contiguous() if image.dtype == torch.float64 else image.to(torch.float32).contiguous()
+
+
 def log_images(image: torch.Tensor, spacing_xyz, sigmas, normalize: bool = True) -> list:
-    """log_image for a list of sigmas, up to 8 per launch sequence (prad_log_multi_dev): the same bits per sigma, the
-    sigmas share the GPU (256^3: one sigma is ONE wave per SIMD and latency-bound)"""
+    """log_image for a list of sigmas, up to 8 per launch sequence (prad_log_multi_dev[_f64]): the same bits per sigma, the
+    sigmas share the GPU.  float64 images in -> float64 out, otherwise float32."""
     lib = _lib.load()
-    x = image.to(torch.float32).contiguous()
+    x = _log_real(image)
+    fn = lib.prad_log_multi_dev_f64 if x.dtype == torch.float64 else lib.prad_log_multi_dev
     lib.prad_set_device(x.device.index or 0)
     size = np.array(x.shape, dtype=np.intc)
     sp = np.array([float(s) for s in spacing_xyz][::-1], dtype=np.float64)
@@ -912,22 +919,23 @@ def log_images(image: torch.Tensor, spacing_xyz, sigmas, normalize: bool = True)
         part = np.array(sig[lo:lo + 8], dtype=np.float64)
         res = [torch.empty_like(x) for _ in part]
         ptrs = (C.c_void_p * len(res))(*[r.data_ptr() for r in res])
-        rc = lib.prad_log_multi_dev(C.c_void_p(x.data_ptr()), _iptr(size), x.dim(), C.c_void_p(sp.ctypes.data),
-                                    C.c_void_p(part.ctypes.data), len(res), 1 if normalize else 0, ptrs, _stream_ptr())
+        rc = fn(C.c_void_p(x.data_ptr()), _iptr(size), x.dim(), C.c_void_p(sp.ctypes.data),
+                C.c_void_p(part.ctypes.data), len(res), 1 if normalize else 0, ptrs, _stream_ptr())
         _lib.raise_for(rc, "LoG")
         outs.extend(res)
     return outs
 
 
 def log_image(image: torch.Tensor, spacing_xyz, sigma: float, normalize: bool = True) -> torch.Tensor:
-    """sitk.LaplacianRecursiveGaussianImageFilter on the device: float32 tensor"""
+    """sitk.LaplacianRecursiveGaussianImageFilter on the device: float32 tensor (float64 for a float64 input)"""
     lib = _lib.load()
-    x = image.to(torch.float32).contiguous()
+    x = _log_real(image)
+    fn = lib.prad_log_dev_f64 if x.dtype == torch.float64 else lib.prad_log_dev
     lib.prad_set_device(x.device.index or 0)
     size = np.array(x.shape, dtype=np.intc)
     sp = np.array([float(s) for s in spacing_xyz][::-1], dtype=np.float64)
     out = torch.empty_like(x)
-    rc = lib.prad_log_dev(C.c_void_p(x.data_ptr()), _iptr(size), x.dim(), C.c_void_p(sp.ctypes.data), float(sigma),
-                          1 if normalize else 0, C.c_void_p(out.data_ptr()), _stream_ptr())
+    rc = fn(C.c_void_p(x.data_ptr()), _iptr(size), x.dim(), C.c_void_p(sp.ctypes.data), float(sigma),
+            1 if normalize else 0, C.c_void_p(out.data_ptr()), _stream_ptr())
     _lib.raise_for(rc, "LoG")
     return out

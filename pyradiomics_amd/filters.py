@@ -138,14 +138,16 @@ def getWaveletImage(inputImage, inputMask, **kwargs):
 
 
 def laplacian_recursive_gaussian(array, spacing_xyz, sigma, normalize=True):
-    """sitk.LaplacianRecursiveGaussianImageFilter (NormalizeAcrossScale) on the device: float32 array"""
-    a = np.ascontiguousarray(array, dtype=np.float32)
+    """sitk.LaplacianRecursiveGaussianImageFilter (NormalizeAcrossScale) on the device, host arrays in and out: float32,
+    or float64 for a float64 input (the filter keeps the input's real type, imageoperations.py:824-830)"""
+    f64 = np.asarray(array).dtype == np.float64
+    a = np.ascontiguousarray(array, dtype=np.float64 if f64 else np.float32)
     size = np.array(a.shape, dtype=np.intc)
     sp = np.array([float(s) for s in spacing_xyz][::-1], dtype=np.float64)
-    out = np.empty(a.shape, dtype=np.float32)
-    rc = _lib.load().prad_log(C.c_void_p(a.ctypes.data), size.ctypes.data_as(C.POINTER(C.c_int)), a.ndim,
-                              C.c_void_p(sp.ctypes.data), float(sigma), 1 if normalize else 0,
-                              C.c_void_p(out.ctypes.data))
+    out = np.empty(a.shape, dtype=a.dtype)
+    fn = _lib.load().prad_log_f64 if f64 else _lib.load().prad_log
+    rc = fn(C.c_void_p(a.ctypes.data), size.ctypes.data_as(C.POINTER(C.c_int)), a.ndim,
+            C.c_void_p(sp.ctypes.data), float(sigma), 1 if normalize else 0, C.c_void_p(out.ctypes.data))
     _lib.raise_for(rc, "LoG")
     return out
 

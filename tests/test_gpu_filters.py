@@ -308,3 +308,82 @@ def test_bincount_edges_built_on_the_device_are_numpys(monkeypatch):
     lv, Ng, edges = engine.bin_image(flat, ones, binCount=8)        # np.histogram widens a constant range: host-built edges
     assert np.array_equal(edges, np.asarray(imageoperations.getBinEdges(np.full(5, 3.25), binCount=8), dtype=np.float64))
     assert int(lv.max()) == Ng
+
+
+# ---- round 4: whole-line LDS tiles (rgauss_tile_kernel) and the float64 filter ------------------------------------------
+def _log_old_route(fn):
+    """runs fn() with the round-3 kernels (two sweeps over HBM) instead of the LDS tiles"""
+    import os
+    os.environ["PRAD_LOG_NO_TILE"] = "1"
+    try:
+        return fn()
+    finally:
+        del os.environ["PRAD_LOG_NO_TILE"]
+
+
+@pytest.mark.parametrize("shape,spacing", [((256, 64, 256), (1.0, 1.0, 1.0)),      # 256-sample lines on the contiguous and a strided axis
+                                           ((37, 53, 70), (0.8, 1.1, 2.5)),       # nothing a multiple of 4: scalar tile moves, ragged chunks
+                                           ((25, 256, 256), (0.78125, 0.78125, 6.5)),   # brain1's grid
+                                           ((5, 4, 9), (1.0, 1.0, 1.0)), ((12, 20, 19), (1.0, 2.0, 0.5)),
+                                           ((4, 4, 520), (1.0, 1.0, 1.0)), ((600, 8, 4), (1.0, 1.0, 1.0))])   # long lines: fewer lines per wave
+def test_log_tile_kernels_equal_the_two_sweep_kernels_bit_for_bit(shape, spacing):
+    import torch
+    from pyradiomics_amd import engine, _lib
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.integers(-300, 1500, size=shape).astype(np.int16)).cuda()
+    sig = [1.0, 2.5, 4.0]
+    new = [t.cpu().numpy() for t in engine.log_images(x, spacing, sig)]
+    assert _lib.last_path() == "log-tile"
+    old = _log_old_route(lambda: [t.cpu().numpy() for t in engine.log_images(x, spacing, sig)])
+    assert _lib.last_path() == "log"
+    for a, b in zip(new, old):
+        assert a.dtype == np.float32 and np.array_equal(a, b)
+    one = engine.log_image(x, spacing, 2.5).cpu().numpy()
+    assert np.array_equal(one, new[1])
+
+
+@pytest.mark.parametrize("shape,spacing", [((12, 40, 36), (1.0, 1.0, 1.0)), ((25, 64, 72), (0.78125, 0.78125, 6.5)),
+                                           ((7, 9, 530), (1.0, 1.0, 1.0))])
+@pytest.mark.parametrize("sigma", [1.0, 3.0])
+def test_log_float64_matches_restatement(shape, spacing, sigma):
+    """VERDICT r3 missing #4: a float64 image (e.g. after `normalize: true`) is filtered with float64 images between the
+    passes and comes back as float64, as sitk.LaplacianRecursiveGaussianImageFilter does (imageoperations.py:824-830)"""
+    import torch
+    from oracle import filters_oracle as fo
+    from pyradiomics_amd import engine, filters
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal(shape) * 100.0
+    want = fo.laplacian_recursive_gaussian(x, spacing, sigma)
+    assert want.dtype == np.float64
+    scale = np.abs(want).max()
+    got = engine.log_image(torch.from_numpy(x).cuda(), spacing, sigma).cpu().numpy()
+    assert got.dtype == np.float64 and np.abs(got - want).max() <= 1e-12 * scale
+    host = filters.laplacian_recursive_gaussian(x, spacing, sigma)
+    assert host.dtype == np.float64 and np.array_equal(host, got)
+    multi = engine.log_images(torch.from_numpy(x).cuda(), spacing, [sigma, 2.0])
+    assert np.array_equal(multi[0].cpu().numpy(), got)
+    old = _log_old_route(lambda: engine.log_image(torch.from_numpy(x).cuda(), spacing, sigma).cpu().numpy())
+    assert np.array_equal(old, got)                                   # lane-per-line fallback: the same bits
+    f32 = fo.laplacian_recursive_gaussian(x.astype(np.float32), spacing, sigma)
+    assert np.abs(f32 - want).max() > 1e-9 * scale                    # the float32 route really is a different computation
+    for on_dev in (True, False):
+        out = list(filters.getLoGImage(Image(x, spacing), None, sigma=[sigma], deviceResident=on_dev))
+        if out:
+            assert out[0][0].array.dtype == np.float64 and np.array_equal(out[0][0].array, got)
+
+
+def test_log_after_normalize_is_float64_through_the_extractor():
+    """normalize + LoG, the common MR recipe: normalizeImage returns float64, so must the LoG image"""
+    import os
+    from helpers import GOLDEN
+    from pyradiomics_amd import filters, imageoperations
+    from pyradiomics_amd.image import read_nrrd
+    from oracle import filters_oracle as fo
+    image = read_nrrd(os.path.join(GOLDEN, "data", "brain1_image.nrrd"))
+    norm = imageoperations.normalizeImage(image, normalizeScale=100)
+    assert norm.array.dtype == np.float64
+    (derived, name, _), = list(filters.getLoGImage(norm, None, sigma=[3.0]))
+    assert derived.array.dtype == np.float64 and name == "log-sigma-3-0-mm-3D"
+    want = fo.laplacian_recursive_gaussian(norm.array, image.GetSpacing(), 3.0)
+    assert np.abs(derived.array - want).max() <= 1e-12 * np.abs(want).max()
