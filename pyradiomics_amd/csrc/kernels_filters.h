@@ -92,32 +92,26 @@ struct RGaussCoef {
   double N0, N1, N2, N3, D1, D2, D3, D4, M1, M2, M3, M4, BN1, BN2, BN3, BN4, BM1, BM2, BM3, BM4;
 };
 
-// final store of a pass: plain float image, or (last pass of a Laplacian term) acc = first ? v / sp2 : acc + v / sp2 with the
-// roundings of the separate accumulation step (the term is rounded to float32 first, ITK's image type)
+// Several sigmas per launch (blockIdx.y): a 256^3 volume has 65 536 lines = ONE wave per SIMD; the waves of the other sigmas
+// fill the machine (profiles/r03_probes.md section 11, profiles/r04_probes.md).
+#define PRAD_LOG_MAXSIG 8
+// T = image type between the passes: float (ITK's real type for integer and float32 inputs) or double (float64 inputs)
 template <typename T>
-__device__ __forceinline__ void rg_store(T *__restrict__ o, T *__restrict__ acc, long long idx, double v, double sp2,
-                                         int first) {
-  const T f = (T)v;
-  if (acc) {
-    const double a = first ? 0.0 : (double)acc[idx];
-    acc[idx] = (T)(a + (double)f / sp2);
-  } else {
-    o[idx] = f;
-  }
-}
+struct RGMultiT {
+  RGaussCoef k[PRAD_LOG_MAXSIG];
+  const T *in[PRAD_LOG_MAXSIG];
+  double *scratch[PRAD_LOG_MAXSIG];     // block states (rgauss_pass_kernel) / float64 causal pass (rgauss_line_kernel)
+  T *out[PRAD_LOG_MAXSIG];
+};
 
-// data viewed as [outer][ln][inner]; lane = (outer index, inner index); scratch holds the causal pass in float64.
-// A lane walks its line serially, so memory parallelism has to come from the lane itself: samples are fetched in
-// batches of PRAD_RG_B independent loads ahead of the recursion that consumes them.
-#define PRAD_RG_B 8
-// ACCLOAD: the pass accumulates into an image that already holds earlier terms (acc != nullptr, first == 0); a template
-// parameter because a load behind a run-time condition gets its own `s_waitcnt vmcnt(0)` (every step of the
-// derivative passes then waited for its accumulator load alone: 205 us instead of 94)
-template <bool ACCLOAD, typename T = float>
+// ---- reference pass: one lane per line, the causal recursion parked in a float64 scratch image ------------------------
+// data viewed as [outer][ln][inner]; lane = (outer index, inner index).  The plainest statement of ITK's
+// RecursiveSeparableImageFilter::FilterDataArray on the device: kept as the checker of the fast kernel below
+// (PRAD_LOG_OLDLINE=1, tests/test_gpu_filters.py) -- 36 B of traffic per sample.
+template <typename T>
 __global__ void __launch_bounds__(256) rgauss_line_kernel(const T *__restrict__ in, long long outer, int ln,
                                                           long long inner, RGaussCoef c,
-                                                          double *__restrict__ scratch, T *__restrict__ out,
-                                                          T *__restrict__ acc, double sp2, int first) {
+                                                          double *__restrict__ scratch, T *__restrict__ out) {
 #pragma clang fp contract(off)  // ITK's line arithmetic is plain multiply / add; keep the same roundings
   const long long lines = outer * inner;
   const long long line = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -125,6 +119,7 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const T *__restrict__ 
   const long long base = (line / inner) * ln * inner + (line % inner);
   const T *d = in + base;
   double *s = scratch + base;
+  T *o = out + base;
   const long long st = inner;
   // causal pass (itkRecursiveSeparableImageFilter.hxx FilterDataArray)
   const double v1 = d[0];
@@ -141,22 +136,7 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const T *__restrict__ 
   {
     double dm1 = x3, dm2 = x2, dm3 = x1;       // data[i-1], [i-2], [i-3]
     double p1 = s3, p2 = s2, p3 = s1, p4 = s0; // scratch[i-1..i-4]
-    int i = 4;
-    for (; i + PRAD_RG_B <= ln; i += PRAD_RG_B) {
-      T buf[PRAD_RG_B];
-#pragma unroll
-      for (int k = 0; k < PRAD_RG_B; k++) buf[k] = d[(long long)(i + k) * st];
-#pragma unroll
-      for (int k = 0; k < PRAD_RG_B; k++) {
-        const double di = buf[k];
-        double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
-        v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
-        s[(long long)(i + k) * st] = v;
-        dm3 = dm2; dm2 = dm1; dm1 = di;
-        p4 = p3; p3 = p2; p2 = p1; p1 = v;
-      }
-    }
-    for (; i < ln; i++) {
+    for (int i = 4; i < ln; i++) {
       const double di = d[(long long)i * st];
       double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
       v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
@@ -176,90 +156,207 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const T *__restrict__ 
   a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
   a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
   a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
-  rg_store(out, acc, base + (long long)(ln - 1) * st, s[(long long)(ln - 1) * st] + a1, sp2, first);
-  rg_store(out, acc, base + (long long)(ln - 2) * st, s[(long long)(ln - 2) * st] + a2, sp2, first);
-  rg_store(out, acc, base + (long long)(ln - 3) * st, s[(long long)(ln - 3) * st] + a3, sp2, first);
-  rg_store(out, acc, base + (long long)(ln - 4) * st, s[(long long)(ln - 4) * st] + a4, sp2, first);
+  o[(long long)(ln - 1) * st] = (T)(s[(long long)(ln - 1) * st] + a1);
+  o[(long long)(ln - 2) * st] = (T)(s[(long long)(ln - 2) * st] + a2);
+  o[(long long)(ln - 3) * st] = (T)(s[(long long)(ln - 3) * st] + a3);
+  o[(long long)(ln - 4) * st] = (T)(s[(long long)(ln - 4) * st] + a4);
   {
     // scratch[i-1] = data[i]*M1 + data[i+1]*M2 + data[i+2]*M3 + data[i+3]*M4 - (scratch[i]*D1 + ... + scratch[i+3]*D4)
     double dp0 = d[(long long)(ln - 4) * st], dp1 = y2, dp2 = y1, dp3 = v2;  // data[i], [i+1], [i+2], [i+3] at i = ln-4
     double q0 = a4, q1 = a3, q2 = a2, q3 = a1;                              // scratch[i], [i+1], [i+2], [i+3]
-    int i = ln - 4;
-    for (; i - PRAD_RG_B >= 0; i -= PRAD_RG_B) {      // produces samples i-1 .. i-B
-      T buf[PRAD_RG_B], ab[PRAD_RG_B];
-      double sb[PRAD_RG_B];
-#pragma unroll
-      for (int k = 0; k < PRAD_RG_B; k++) {
-        buf[k] = d[(long long)(i - 1 - k) * st];
-        sb[k] = s[(long long)(i - 1 - k) * st];
-        // (the accumulator too: a load right before its store, one per step, left the derivative passes at 205 us
-        // against 94 us for the smoothing ones -- the compiler keeps it behind the previous step's store)
-        ab[k] = ACCLOAD ? acc[base + (long long)(i - 1 - k) * st] : (T)0;
-      }
-#pragma unroll
-      for (int k = 0; k < PRAD_RG_B; k++) {
-        double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
-        v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
-        {
-          const long long idx = base + (long long)(i - 1 - k) * st;
-          const T f = (T)(sb[k] + v);
-          if (acc) acc[idx] = (T)((double)ab[k] + (double)f / sp2);     // = rg_store
-          else out[idx] = f;
-        }
-        dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = buf[k];
-        q3 = q2; q2 = q1; q1 = q0; q0 = v;
-      }
-    }
-    for (; i > 0; i--) {
+    for (int i = ln - 4; i > 0; i--) {
       double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
       v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
-      rg_store(out, acc, base + (long long)(i - 1) * st, s[(long long)(i - 1) * st] + v, sp2, first);
+      o[(long long)(i - 1) * st] = (T)(s[(long long)(i - 1) * st] + v);
       dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = d[(long long)(i - 1) * st];
       q3 = q2; q2 = q1; q1 = q0; q0 = v;
     }
   }
 }
 
-// The same pass without the float64 copy of the causal recursion (8 B written + 8 B read per sample: more than the images
-// themselves).  out[i] = causal[i] + anticausal[i] needs one of the two directions kept, but not sample by sample: sweep 1
-// runs the ANTI-causal recursion from the end of the line and keeps only its state (4 outputs) at every block boundary
-// (32 B per RB samples); sweep 2 walks forward block by block -- causal recursion into registers, then the anti-causal
-// one of the block RECOMPUTED downward from the saved state (same operations on the same operands: the same bits), sum,
-// store.  Traffic per sample: 4 (sweep 1) + 4 (sweep 2) read, 4 written, 2 x 32 / RB of states: 16 B at RB = 16 instead
-// of 36; 256^3: 94 -> see profiles (smoothing pass).  AM: 0 plain float output, 1 first Laplacian term (acc = v / sp2),
-// 2 later term (acc += v / sp2).
-#define PRAD_RG_RB 16
-// Several sigmas per launch (blockIdx.y): a 256^3 volume has 65 536 lines = ONE wave per SIMD, and a pass is bound by the
-// latency of its serial float64 chain -- the waves of the other sigmas fill the gaps (profiles/r03_probes.md, section 11).
-#define PRAD_LOG_MAXSIG 8
-struct RGMulti {
-  RGaussCoef k[PRAD_LOG_MAXSIG];
-  const float *in[PRAD_LOG_MAXSIG];
-  double *scratch[PRAD_LOG_MAXSIG];
-  float *out[PRAD_LOG_MAXSIG];
-  float *acc[PRAD_LOG_MAXSIG];
+// ---- the pass the filter runs -----------------------------------------------------------------------------------------
+// out[i] = causal[i] + anticausal[i] needs one direction kept while the other runs, but not sample by sample: sweep 1 runs
+// the ANTI-causal recursion from the end of the line and keeps only its state (4 outputs) at every block boundary (32 B
+// per RB samples); sweep 2 walks forward block by block -- causal recursion into registers, then the anti-causal one of
+// the block RECOMPUTED downward from the saved state (same operations on the same operands: the same bits), sum, store.
+// Traffic per sample: 4 (sweep 1) + 4 (sweep 2) read, 4 written, 2 x 32 / RB of states = 16 B at RB = 16.
+//   CONTIG = false (strided axis): lane = line, neighbouring lanes are neighbouring inner positions: every access of the
+//            wave is one row segment.
+//   CONTIG = true (the contiguous axis, inner == 1): a wave owns 64 consecutive lines; a lane-per-line walk would touch 64
+//            different cache lines per step, so every block goes through a per-wave LDS tile [64 lines][RB + 4 samples]:
+//            the wave fetches the block of all its lines with coalesced loads (80-byte row pieces), each lane then takes
+//            its own row (pitch 21: conflict-free); results return the same way.  Same sweeps, same arithmetic, same
+//            16 B per sample (round 3's kernel for this axis parked float64 partials in HBM: 28 B, 180 us instead of
+//            ~65 per sigma at 256^3).
+// The Laplacian's  acc += term / spacing^2  is not part of the pass (the accumulating instantiation of round 3 needed 308
+// VGPRs = one wave per SIMD and ran at a third of the speed): log_combine_kernel below.
+// One step of the 4th-order recursion  y[k] = n[k] - (((y[k-1] D1 + y[k-2] D2) + y[k-3] D3) + y[k-4] D4),
+// n[k] = ((w0 A1 + w1 A2) + w2 A3) + w3 A4  over the data window, in exactly that association (ITK's source order).  Only
+// five of its sixteen float64 operations hang on the fresh y[k-1]: y[k-1] D1, three adds, the subtraction.  Left to the
+// compiler every operation is issued right behind the one it depends on, and a dependent float64 operation waits ~20 cycles
+// on this chip: ~300 cycles per step with one wave per SIMD, a third of the float64 issue rate with two (the register
+// budget of the kernel allows no more).  Here the step is issued in a fixed order (volatile asm statements keep their order)
+// with the numerator of the NEXT step and the products y D2, y D3, y D4 of the already known outputs placed between the
+// five dependent operations.  Same operations, same operands, same roundings: bit-identical to the plain loop (the GPU
+// tests compare the two kernels).
+#define PRAD_DMUL_S(r, a, sc) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(sc))
+#define PRAD_DADD(r, a, b) asm volatile("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b))
+#define PRAD_DSUB(r, a, b) asm volatile("v_add_f64 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b))
+struct RGChain {
+  double y1, y2, y3;      // the last three outputs, newest first
+  double e2, e3, e4;      // y[k-2] D2, y[k-3] D3, y[k-4] D4 of the coming step
+  double n;               // numerator of the coming step
+  double w0, w1, w2;      // the three newest samples of the data window
+  // A1..A4: numerator coefficients in window order (newest sample first); window = (x0, x1, x2, x3) newest first
+  __device__ __forceinline__ void enter(double o1, double o2, double o3, double o4, double x0, double x1, double x2, double x3,
+                                        double A1, double A2, double A3, double A4, double D2, double D3, double D4) {
+#pragma clang fp contract(off)
+    y1 = o1; y2 = o2; y3 = o3;
+    e2 = o2 * D2; e3 = o3 * D3; e4 = o4 * D4;
+    n = x0 * A1 + x1 * A2 + x2 * A3 + x3 * A4;
+    w0 = x0; w1 = x1; w2 = x2;
+  }
+  // produces the next output; `next` enters the window (NEXT = false: the last step of a stretch, no numerator prepared)
+  template <bool NEXT>
+  __device__ __forceinline__ double step(double next, double A1, double A2, double A3, double A4, double D1, double D2, double D3,
+                                         double D4) {
+    double m1, t1, t2, t3, t4, u1, u2, nn, b2, b3, b4, s1, s2, s3, y0;
+    PRAD_DMUL_S(m1, y1, D1);
+    if (NEXT) PRAD_DMUL_S(t1, next, A1);
+    if (NEXT) PRAD_DMUL_S(t2, w0, A2);
+    PRAD_DMUL_S(b2, y1, D2);
+    PRAD_DADD(s1, m1, e2);
+    if (NEXT) PRAD_DMUL_S(t3, w1, A3);
+    if (NEXT) PRAD_DADD(u1, t1, t2);
+    if (NEXT) PRAD_DMUL_S(t4, w2, A4);
+    PRAD_DMUL_S(b3, y2, D3);
+    PRAD_DADD(s2, s1, e3);
+    PRAD_DMUL_S(b4, y3, D4);
+    if (NEXT) PRAD_DADD(u2, u1, t3);
+    PRAD_DADD(s3, s2, e4);
+    if (NEXT) PRAD_DADD(nn, u2, t4);
+    PRAD_DSUB(y0, n, s3);
+    y3 = y2; y2 = y1; y1 = y0;
+    e2 = b2; e3 = b3; e4 = b4;
+    if (NEXT) {
+      n = nn;
+      w2 = w1; w1 = w0; w0 = next;
+    }
+    return y0;
+  }
 };
 
-template <int AM>
-__device__ __forceinline__ void rgauss_line2_body(const float *__restrict__ in, long long outer, int ln,
-                                                  long long inner, const RGaussCoef &c, double *__restrict__ states,
-                                                  float *__restrict__ out, float *__restrict__ acc, double sp2) {
+#define PRAD_RG_RB 16
+// PRAD_RG_PREFETCH = 1 starts the loads of the next block before the current one is recursed; measured at 256^3, five sigmas
+// per launch: 294 instead of 281 us on the strided axes, 541 instead of 430 on the contiguous one (20 more live registers);
+// the causal block values in LDS instead of 40 VGPRs: 405 us.  The pass moves 16 B per sample at 4.8 TB/s (the copy rate of
+// this GPU is 5.5): it is bound by those bytes, not by latencies (profiles/r04_probes.md).
+#ifndef PRAD_RG_PREFETCH
+#define PRAD_RG_PREFETCH 0
+#endif
+#ifndef PRAD_RG_WAVES
+#define PRAD_RG_WAVES 2
+#endif
+template <typename T, bool CONTIG, bool PLAIN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRAD_RG_WAVES, PRAD_RG_WAVES))) rgauss_pass_kernel(RGMultiT<T> M, long long outer, int ln, long long inner) {
 #pragma clang fp contract(off)  // ITK's line arithmetic is plain multiply / add; keep the same roundings
   constexpr int RB = PRAD_RG_RB;
-  const long long lines = outer * inner;
+  constexpr int RM = RB + 4;                  // samples held: the block and, for the anti-causal start, the 4 behind it
+  static_assert(RB == 16, "the staging loops move 16 + 4 columns");
+  constexpr int TP = RM + 1;                  // LDS pitch (odd)
+  __shared__ T stage_[CONTIG ? 4 : 1][CONTIG ? 64 : 1][TP];
+  const int sg = blockIdx.y;
+  const RGaussCoef &c = M.k[sg];
+  const T *__restrict__ in = M.in[sg];
+  T *__restrict__ out = M.out[sg];
+  const long long lines = CONTIG ? outer : outer * inner;
   const long long line = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (line >= lines) return;
-  const long long base = (line / inner) * ln * inner + (line % inner);
-  const float *d = in + base;
-  const long long st = inner;
+  const bool mine = line < lines;
+  const int lane = threadIdx.x & 63;
+  T(*tile)[TP] = stage_[CONTIG ? (threadIdx.x >> 6) : 0];
+  const long long wl0 = line - lane;                       // first line of this wave (CONTIG)
+  if (!CONTIG && !mine) return;
+  if (CONTIG && wl0 >= lines) return;
+  const long long lc = mine ? line : lines - 1;           // (idle lanes of a ragged last wave shadow the last line)
+  const long long base = CONTIG ? lc * ln : (lc / inner) * ln * inner + (lc % inner);
+  const T *d = in + base;
+  const long long st = CONTIG ? 1 : inner;
+  const int nwl = CONTIG ? (int)min((long long)64, lines - wl0) : 0;
+  // block [b, b + w) of every line of the wave -> dst[0 .. w)   (w <= RM), in two halves so that the loads of the NEXT block
+  // are in flight while the current one is recursed (a wave that loads, waits, computes leaves the memory system idle
+  // half of the time at two waves per SIMD): issue() starts the global loads into pf[], commit() hands every lane its row.
+  // WF > 0: the width is the compile-time constant WF (16 = a full block in sweep 1, 20 = block + look-ahead in sweep 2):
+  // no predicate on the loads.
+  auto issue = [&](auto wf_tag, int b, int w, T *pf) __attribute__((always_inline)) {
+    constexpr int WF = decltype(wf_tag)::value;
+    if (WF > 0) w = WF;
+    if (CONTIG) {
+      // 16 columns as 4 lines x 64-byte pieces per wave instruction, the (up to 4) columns behind them as 16 lines x 16 bytes
+      if (nwl == 64 && WF > 0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) pf[k] = in[(wl0 + k * 4 + (lane >> 4)) * ln + b + (lane & 15)];
+        if (WF > 16) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) pf[16 + k] = in[(wl0 + k * 16 + (lane >> 2)) * ln + b + 16 + (lane & 3)];
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          const int t = k * 4 + (lane >> 4), cc = lane & 15;
+          pf[k] = (t < nwl && cc < w) ? in[(wl0 + t) * ln + b + cc] : (T)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int t = k * 16 + (lane >> 2), cc = 16 + (lane & 3);
+          pf[16 + k] = (t < nwl && cc < w) ? in[(wl0 + t) * ln + b + cc] : (T)0;
+        }
+      }
+    } else {
+      const T *p = d + (long long)b * st;
+#pragma unroll
+      for (int j = 0; j < RM; j++) pf[j] = (WF > 0 ? j < WF : j < w) ? p[(long long)j * st] : (T)0;
+    }
+  };
+  auto commit = [&](const T *pf, T *dst) __attribute__((always_inline)) {
+    if (CONTIG) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 16; k++) tile[k * 4 + (lane >> 4)][lane & 15] = pf[k];
+#pragma unroll
+      for (int k = 0; k < 4; k++) tile[k * 16 + (lane >> 2)][16 + (lane & 3)] = pf[16 + k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < RM; j++) dst[j] = tile[lane][j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < RM; j++) dst[j] = pf[j];
+    }
+  };
+  using W0 = std::integral_constant<int, 0>;
+  using W16 = std::integral_constant<int, 16>;
+  using W20 = std::integral_constant<int, 20>;
+  const long long nlines_all = lines;
   // blocks [k RB, (k + 1) RB) for k < nb - 1; the last one takes the remainder, 4 .. RB + 3 samples (ln >= 4)
   const int nb = (ln - 4) / RB + 1;
   // state of boundary k (1 <= k < nb) = anticausal[k RB .. k RB + 3]: double index ((k - 1) * 4 + j) * lines + line
-  double *sp = states + line;
+  double *sp = M.scratch[sg] + lc;
   // ---- sweep 1: anti-causal, from the end, states only ----
   {
-    const double v2 = d[(long long)(ln - 1) * st];
-    const double y1 = d[(long long)(ln - 2) * st], y2 = d[(long long)(ln - 3) * st];
+    const int bl = (nb - 1) * RB, ll = ln - bl;          // last block: 4 .. RB + 3 samples
+    T dv[RM], pf[RM];
+    issue(W0{}, bl, ll, pf);
+    commit(pf, dv);
+    if (PRAD_RG_PREFETCH && nb >= 3) issue(W16{}, (nb - 2) * RB, RB, pf);          // (block 0 is not walked in sweep 1)
+    double v2 = 0, y1 = 0, y2 = 0, y3 = 0;
+#pragma unroll
+    for (int j = 0; j < RM; j++) {                        // (register array: compile-time indices only)
+      if (j == ll - 1) v2 = dv[j];
+      if (j == ll - 2) y1 = dv[j];
+      if (j == ll - 3) y2 = dv[j];
+      if (j == ll - 4) y3 = dv[j];
+    }
     double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-1
     double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-2
     double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-3
@@ -268,62 +365,71 @@ __device__ __forceinline__ void rgauss_line2_body(const float *__restrict__ in, 
     a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
     a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
     a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
-    double dp0 = d[(long long)(ln - 4) * st], dp1 = y2, dp2 = y1, dp3 = v2;  // data[i .. i+3] at i = ln-4
-    double q0 = a4, q1 = a3, q2 = a2, q3 = a1;                              // anticausal[i .. i+3]
-    int i = ln - 4;                // the next sample produced is i - 1
-    // (i is a boundary when i % RB == 0 and i >= RB: then q0..q3 = anticausal[i .. i+3] is the state of boundary i / RB)
-    while (i > 0) {
-      if ((i % RB) == 0) {
-        const long long k = i / RB - 1;
-        sp[(k * 4 + 0) * lines] = q0;
-        sp[(k * 4 + 1) * lines] = q1;
-        sp[(k * 4 + 2) * lines] = q2;
-        sp[(k * 4 + 3) * lines] = q3;
+    double dp0 = y3, dp1 = y2, dp2 = y1, dp3 = v2;                   // data[i .. i+3] at i = ln-4
+    double q0 = a4, q1 = a3, q2 = a2, q3 = a1;                       // anticausal[i .. i+3]
+    // the rest of the last block, downward: samples bl + ll - 5 .. bl
+#pragma unroll
+    for (int jj = RM - 1; jj >= 0; jj--) {
+      if (jj <= ll - 5) {
+        double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
+        v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
+        dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = dv[jj];
+        q3 = q2; q2 = q1; q1 = q0; q0 = v;
       }
-      const int nstep = min(i, ((i - 1) % RB) + 1);    // down to the next boundary (or to 0)
-      if (nstep == RB) {
-        float buf[RB];
+    }
+    // full blocks nb - 2 .. 0: q0..q3 = anticausal[(kb + 1) RB .. + 3] is the state of boundary kb + 1
+    for (int kb = nb - 2; kb >= 0; kb--) {
+      if (mine) {
+        sp[((long long)kb * 4 + 0) * nlines_all] = q0;
+        sp[((long long)kb * 4 + 1) * nlines_all] = q1;
+        sp[((long long)kb * 4 + 2) * nlines_all] = q2;
+        sp[((long long)kb * 4 + 3) * nlines_all] = q3;
+      }
+      if (kb == 0) break;                                  // block 0's anti-causal part is recomputed in sweep 2
+      if (!PRAD_RG_PREFETCH) issue(W16{}, kb * RB, RB, pf);
+      commit(pf, dv);
+      if (PRAD_RG_PREFETCH && kb >= 2) issue(W16{}, (kb - 1) * RB, RB, pf);
+      if (PLAIN) {
 #pragma unroll
-        for (int k = 0; k < RB; k++) buf[k] = d[(long long)(i - 1 - k) * st];
-#pragma unroll
-        for (int k = 0; k < RB; k++) {
+        for (int jj = RB - 1; jj >= 0; jj--) {
           double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
           v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
-          dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = buf[k];
+          dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = dv[jj];
           q3 = q2; q2 = q1; q1 = q0; q0 = v;
         }
       } else {
-        for (int k = 0; k < nstep; k++) {
-          double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
-          v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
-          dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = d[(long long)(i - 1 - k) * st];
-          q3 = q2; q2 = q1; q1 = q0; q0 = v;
+        RGChain ch;
+        ch.enter(q0, q1, q2, q3, dp0, dp1, dp2, dp3, c.M1, c.M2, c.M3, c.M4, c.D2, c.D3, c.D4);
+        double o4 = q2, o5 = q3;
+#pragma unroll
+        for (int jj = RB - 1; jj >= 0; jj--) {
+          o5 = o4; o4 = ch.y3;
+          ch.step<true>((double)dv[jj], c.M1, c.M2, c.M3, c.M4, c.D1, c.D2, c.D3, c.D4);
         }
+        (void)o5;
+        q0 = ch.y1; q1 = ch.y2; q2 = ch.y3; q3 = o4;
+        dp0 = ch.w0; dp1 = ch.w1; dp2 = ch.w2; dp3 = (double)dv[3];
       }
-      i -= nstep;
     }
   }
   // ---- sweep 2: forward, block by block ----
   double p1 = 0, p2 = 0, p3 = 0, p4 = 0;        // causal[b-1 .. b-4]
   double dm1 = 0, dm2 = 0, dm3 = 0;             // data[b-1 .. b-3]
+  T pf2[RM];
+  auto issue2 = [&](int b) __attribute__((always_inline)) {   // block + the 4 samples behind it (the anti-causal start)
+    if (b + RM <= ln) issue(W20{}, b, RM, pf2);
+    else issue(W0{}, b, ln - b, pf2);
+  };
+  if (PRAD_RG_PREFETCH) issue2(0);
   for (int kb = 0; kb < nb; kb++) {
     const int b = kb * RB;
     const bool lastblk = kb == nb - 1;
     const int len = lastblk ? ln - b : RB;      // RB, or 4 .. RB + 3 for the last block
-    constexpr int RM = RB + 4;                  // samples held: the block and, for the anti-causal start, the 4 behind it
-    float dv[RM + 0];
+    T dv[RM];
     double cv[RM];
-    // data of the block (+ the first 4 samples of the next block, which the anti-causal recursion starts from)
-#pragma unroll
-    for (int j = 0; j < RM; j++) {
-      const int idx = b + j;
-      dv[j] = idx < ln ? d[(long long)idx * st] : 0.f;
-    }
-    float ab[RM];
-    if (AM == 2) {
-#pragma unroll
-      for (int j = 0; j < RM; j++) ab[j] = (j < len) ? acc[base + (long long)(b + j) * st] : 0.f;
-    }
+    if (!PRAD_RG_PREFETCH) issue2(b);
+    commit(pf2, dv);
+    if (PRAD_RG_PREFETCH && !lastblk) issue2(b + RB);
     // causal recursion over the block
     int j0 = 0;
     if (kb == 0) {
@@ -342,22 +448,48 @@ __device__ __forceinline__ void rgauss_line2_body(const float *__restrict__ in, 
       p1 = s3; p2 = s2; p3 = s1; p4 = s0;
       j0 = 4;
     }
+    if (PLAIN || len != RB) {
 #pragma unroll
-    for (int j = 0; j < RM; j++) {
-      if (j >= j0 && j < len) {
-        const double di = dv[j];
-        double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
-        v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
-        cv[j] = v;
-        dm3 = dm2; dm2 = dm1; dm1 = di;
-        p4 = p3; p3 = p2; p2 = p1; p1 = v;
+      for (int j = 0; j < RM; j++) {
+        if (j >= j0 && j < len) {
+          const double di = dv[j];
+          double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
+          v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
+          cv[j] = v;
+          dm3 = dm2; dm2 = dm1; dm1 = di;
+          p4 = p3; p3 = p2; p2 = p1; p1 = v;
+        }
       }
+    } else {
+      // a full block: samples j0 .. RB - 1 on the scheduled chain (the numerator of sample j uses dv[j] itself: it is prepared
+      // one step ahead, the first one on entry)
+      RGChain ch;
+      auto run = [&](auto j0_tag) __attribute__((always_inline)) {
+        constexpr int J0 = decltype(j0_tag)::value;
+        ch.enter(p1, p2, p3, p4, (double)dv[J0], dm1, dm2, dm3, c.N0, c.N1, c.N2, c.N3, c.D2, c.D3, c.D4);
+#pragma unroll
+        for (int j = J0; j < RB; j++) {
+          if (j < RB - 1) cv[j] = ch.step<true>((double)dv[j + 1], c.N0, c.N1, c.N2, c.N3, c.D1, c.D2, c.D3, c.D4);
+          else cv[j] = ch.step<false>(0.0, c.N0, c.N1, c.N2, c.N3, c.D1, c.D2, c.D3, c.D4);
+        }
+      };
+      if (kb == 0) run(std::integral_constant<int, 4>{});
+      else run(std::integral_constant<int, 0>{});
+      p1 = cv[RB - 1]; p2 = cv[RB - 2]; p3 = cv[RB - 3]; p4 = cv[RB - 4];
+      dm1 = dv[RB - 1]; dm2 = dv[RB - 2]; dm3 = dv[RB - 3];
     }
     // anti-causal recursion of the block, downward, from the saved state (or from the end of the line)
     double q0, q1, q2, q3, e0, e1, e2, e3;      // anticausal[i .. i+3], data[i .. i+3] at i = b + len
     int jtop = len - 1;                         // block-local index of the first sample still to produce
     if (lastblk) {
-      const double v2 = dv[len - 1], y1 = dv[len - 2], y2 = dv[len - 3];
+      double v2 = 0, y1 = 0, y2 = 0, y3 = 0;
+#pragma unroll
+      for (int j = 0; j < RM; j++) {
+        if (j == len - 1) v2 = dv[j];
+        if (j == len - 2) y1 = dv[j];
+        if (j == len - 3) y2 = dv[j];
+        if (j == len - 4) y3 = dv[j];
+      }
       double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
       double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
       double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
@@ -375,266 +507,16 @@ __device__ __forceinline__ void rgauss_line2_body(const float *__restrict__ in, 
         if (j == len - 4) cv[j] += a4;
       }
       q0 = a4; q1 = a3; q2 = a2; q3 = a1;
-      e0 = dv[len - 4]; e1 = y2; e2 = y1; e3 = v2;
+      e0 = y3; e1 = y2; e2 = y1; e3 = v2;
       jtop = len - 5;
     } else {
-      q0 = sp[((long long)kb * 4 + 0) * lines];
-      q1 = sp[((long long)kb * 4 + 1) * lines];
-      q2 = sp[((long long)kb * 4 + 2) * lines];
-      q3 = sp[((long long)kb * 4 + 3) * lines];
+      q0 = sp[((long long)kb * 4 + 0) * nlines_all];
+      q1 = sp[((long long)kb * 4 + 1) * nlines_all];
+      q2 = sp[((long long)kb * 4 + 2) * nlines_all];
+      q3 = sp[((long long)kb * 4 + 3) * nlines_all];
       e0 = dv[RB]; e1 = dv[RB + 1]; e2 = dv[RB + 2]; e3 = dv[RB + 3];
     }
-#pragma unroll
-    for (int jj = RM - 1; jj >= 0; jj--) {
-      if (jj <= jtop) {
-        double v = e0 * c.M1 + e1 * c.M2 + e2 * c.M3 + e3 * c.M4;
-        v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
-        cv[jj] += v;
-        e3 = e2; e2 = e1; e1 = e0; e0 = dv[jj];
-        q3 = q2; q2 = q1; q1 = q0; q0 = v;
-      }
-    }
-    // store
-#pragma unroll
-    for (int j = 0; j < RM; j++) {
-      if (j < len) {
-        const long long idx = base + (long long)(b + j) * st;
-        const float f = (float)cv[j];
-        if (AM == 0) out[idx] = f;
-        else acc[idx] = (float)((AM == 2 ? (double)ab[j] : 0.0) + (double)f / sp2);     // = rg_store
-      }
-    }
-  }
-}
-
-template <int AM>
-__global__ void __launch_bounds__(256) rgauss_line2_kernel(RGMulti M, long long outer, int ln, long long inner, double sp2) {
-  const int sg = blockIdx.y;
-  rgauss_line2_body<AM>(M.in[sg], outer, ln, inner, M.k[sg], M.scratch[sg], M.out[sg], M.acc[sg], sp2);
-}
-
-// ---- whole lines in LDS (round 4) ---------------------------------------------------------------------------------
-// Every pass above reads its line twice (the two sweeps) and parks float64 partials or block states in HBM: 16..28 B per
-// sample against the 8 B a pass has to move (one read, one write).  Here a wave keeps TL whole lines in LDS: the tile is
-// fetched once with full-width coalesced loads, both sweeps of the recursion read it from LDS (one lane per line), the
-// result replaces the input sample in place, and the tile is written back with full-width stores -- 8 B per sample and
-// pass (12 when the pass adds into the Laplacian).  The arithmetic per line is rgauss_line2_body's, operation for
-// operation (anti-causal states every RB samples, forward sweep with the block's anti-causal part recomputed), so the
-// outputs are the same bits.  One wave per workgroup; a 256-sample float line group of 32 lines is 33 KB + 7 KB of states:
-// four waves per CU, one per SIMD.
-//   T        image type between the passes: float (ITK's real type for integer and float32 inputs) or double (float64 inputs)
-//   TL       lines per wave (a power of two <= 64; the lanes beyond TL only help to move the tile)
-//   CONTIG   the filtered axis is the contiguous one: the tile is one contiguous piece of memory, element (line t, sample j)
-//            sits at LDS element t * PT + j (PT odd: the lanes' reads spread over the banks); otherwise lines are TL
-//            neighbouring inner positions, element j * TL + t
-//   AM       0 plain output, 1 first Laplacian term (acc = v / sp2), 2 later term (acc += v / sp2)
-template <typename T>
-struct RGMultiT {
-  RGaussCoef k[PRAD_LOG_MAXSIG];
-  const T *in[PRAD_LOG_MAXSIG];
-  T *out[PRAD_LOG_MAXSIG];
-  T *acc[PRAD_LOG_MAXSIG];
-};
-template <typename T> struct RGVec;
-template <> struct RGVec<float> { typedef float4 type; };
-template <> struct RGVec<double> { typedef double2 type; };
-#define PRAD_RGT_RB 16
-
-template <typename T, int TL, bool CONTIG, int AM>
-__global__ void __launch_bounds__(64) rgauss_tile_kernel(RGMultiT<T> M, long long outer, int ln, long long inner, double sp2,
-                                                         int PT, int vec) {
-#pragma clang fp contract(off)  // ITK's line arithmetic is plain multiply / add; keep the same roundings
-  extern __shared__ __align__(16) unsigned char rg_smem[];
-  constexpr int RB = PRAD_RGT_RB;
-  constexpr int V = 16 / (int)sizeof(T);
-  typedef typename RGVec<T>::type VT;
-  const int lane = threadIdx.x;
-  const int sg = blockIdx.y;
-  const RGaussCoef &c = M.k[sg];
-  const T *__restrict__ in = M.in[sg];
-  T *tile = reinterpret_cast<T *>(rg_smem);
-  const long long tile_elems = CONTIG ? (long long)TL * PT : (long long)ln * TL;
-  double *states = reinterpret_cast<double *>(rg_smem + ((tile_elems * sizeof(T) + 15) & ~(size_t)15));
-  long long gbase;
-  int nl;
-  if (CONTIG) {
-    const long long l0 = (long long)blockIdx.x * TL;
-    nl = (int)min((long long)TL, outer - l0);
-    gbase = l0 * ln;
-  } else {
-    const long long nchunk = (inner + TL - 1) / TL;
-    const long long o = blockIdx.x / nchunk, ch = blockIdx.x % nchunk;
-    nl = (int)min((long long)TL, inner - ch * TL);
-    gbase = o * ln * inner + ch * TL;
-  }
-  // ---- tile in ----
-  if (CONTIG) {
-    if (vec) {
-      const int nq = nl * ln / V;
-#pragma unroll 8
-      for (int q = lane; q < nq; q += 64) {
-        const VT v = *reinterpret_cast<const VT *>(in + gbase + (long long)q * V);
-        const int e = q * V, t = e / ln, j = e - t * ln;
-        const T *pv = reinterpret_cast<const T *>(&v);
-#pragma unroll
-        for (int i = 0; i < V; i++) tile[t * PT + j + i] = pv[i];
-      }
-    } else {
-      const int ne = nl * ln;
-#pragma unroll 8
-      for (int e = lane; e < ne; e += 64) {
-        const int t = e / ln, j = e - t * ln;
-        tile[t * PT + j] = in[gbase + e];
-      }
-    }
-  } else {
-    if (vec) {
-      constexpr int QR = TL / V > 0 ? TL / V : 1;
-      const int nq = ln * QR;
-#pragma unroll 8
-      for (int q = lane; q < nq; q += 64) {
-        const int j = q / QR, t = (q % QR) * V;
-        if (t < nl) *reinterpret_cast<VT *>(tile + j * TL + t) = *reinterpret_cast<const VT *>(in + gbase + (long long)j * inner + t);
-      }
-    } else {
-      const int ne = ln * TL;
-#pragma unroll 8
-      for (int e = lane; e < ne; e += 64) {
-        const int j = e / TL, t = e % TL;
-        if (t < nl) tile[e] = in[gbase + (long long)j * inner + t];
-      }
-    }
-  }
-  __syncthreads();
-#define PRAD_RGT_AT(j) tile[CONTIG ? lane * PT + (j) : (j) * TL + lane]
-  if (lane < nl) {
-    const int nb = (ln - 4) / RB + 1;      // blocks [k RB, (k + 1) RB) for k < nb - 1; the last takes the remainder (4 .. RB + 3)
-    double *sp = states + lane;            // boundary k (1 <= k < nb), value i: sp[((k - 1) * 4 + i) * TL]
-    // ---- sweep 1: anti-causal, from the end, states only ----
-    {
-      const double v2 = PRAD_RGT_AT(ln - 1);
-      const double y1 = PRAD_RGT_AT(ln - 2), y2 = PRAD_RGT_AT(ln - 3);
-      double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-1
-      double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-2
-      double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-3
-      double a4 = y2 * c.M1 + y1 * c.M2 + v2 * c.M3 + v2 * c.M4;     // index ln-4
-      a1 -= v2 * c.BM1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
-      a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
-      a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
-      a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
-      double dp0 = PRAD_RGT_AT(ln - 4), dp1 = y2, dp2 = y1, dp3 = v2;    // data[i .. i+3] at i = ln-4
-      double q0 = a4, q1 = a3, q2 = a2, q3 = a1;                          // anticausal[i .. i+3]
-      int i = ln - 4;                // the next sample produced is i - 1
-      while (i > 0) {
-        if ((i % RB) == 0) {
-          const int k = i / RB - 1;
-          sp[(k * 4 + 0) * TL] = q0;
-          sp[(k * 4 + 1) * TL] = q1;
-          sp[(k * 4 + 2) * TL] = q2;
-          sp[(k * 4 + 3) * TL] = q3;
-        }
-        const int nstep = min(i, ((i - 1) % RB) + 1);    // down to the next boundary (or to 0)
-        if (nstep == RB) {
-          T buf[RB];
-#pragma unroll
-          for (int k = 0; k < RB; k++) buf[k] = PRAD_RGT_AT(i - 1 - k);
-#pragma unroll
-          for (int k = 0; k < RB; k++) {
-            double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
-            v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
-            dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = buf[k];
-            q3 = q2; q2 = q1; q1 = q0; q0 = v;
-          }
-        } else {
-          for (int k = 0; k < nstep; k++) {
-            double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
-            v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
-            dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = PRAD_RGT_AT(i - 1 - k);
-            q3 = q2; q2 = q1; q1 = q0; q0 = v;
-          }
-        }
-        i -= nstep;
-      }
-    }
-    // ---- sweep 2: forward, block by block; the result replaces the input in the tile ----
-    double p1 = 0, p2 = 0, p3 = 0, p4 = 0;        // causal[b-1 .. b-4]
-    double dm1 = 0, dm2 = 0, dm3 = 0;             // data[b-1 .. b-3]
-    for (int kb = 0; kb < nb; kb++) {
-      const int b = kb * RB;
-      const bool lastblk = kb == nb - 1;
-      const int len = lastblk ? ln - b : RB;      // RB, or 4 .. RB + 3 for the last block
-      constexpr int RM = RB + 4;                  // samples held: the block and, for the anti-causal start, the 4 behind it
-      T dv[RM];
-      double cv[RM];
-#pragma unroll
-      for (int j = 0; j < RM; j++) {
-        const int idx = b + j;
-        dv[j] = idx < ln ? PRAD_RGT_AT(idx) : (T)0;
-      }
-      int j0 = 0;
-      if (kb == 0) {
-        const double v1 = dv[0];
-        const double x1 = dv[1], x2 = dv[2], x3 = dv[3];
-        double s0 = v1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
-        double s1 = x1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
-        double s2 = x2 * c.N0 + x1 * c.N1 + v1 * c.N2 + v1 * c.N3;
-        double s3 = x3 * c.N0 + x2 * c.N1 + x1 * c.N2 + v1 * c.N3;
-        s0 -= v1 * c.BN1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
-        s1 -= s0 * c.D1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
-        s2 -= s1 * c.D1 + s0 * c.D2 + v1 * c.BN3 + v1 * c.BN4;
-        s3 -= s2 * c.D1 + s1 * c.D2 + s0 * c.D3 + v1 * c.BN4;
-        cv[0] = s0; cv[1] = s1; cv[2] = s2; cv[3] = s3;
-        dm1 = x3; dm2 = x2; dm3 = x1;
-        p1 = s3; p2 = s2; p3 = s1; p4 = s0;
-        j0 = 4;
-      }
-#pragma unroll
-      for (int j = 0; j < RM; j++) {
-        if (j >= j0 && j < len) {
-          const double di = dv[j];
-          double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
-          v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
-          cv[j] = v;
-          dm3 = dm2; dm2 = dm1; dm1 = di;
-          p4 = p3; p3 = p2; p2 = p1; p1 = v;
-        }
-      }
-      double q0, q1, q2, q3, e0, e1, e2, e3;      // anticausal[i .. i+3], data[i .. i+3] at i = b + len
-      int jtop = len - 1;                         // block-local index of the first sample still to produce
-      if (lastblk) {
-        double v2 = 0, y1 = 0, y2 = 0, y3 = 0;
-#pragma unroll
-        for (int j = 0; j < RM; j++) {            // (register array: compile-time indices only)
-          if (j == len - 1) v2 = dv[j];
-          if (j == len - 2) y1 = dv[j];
-          if (j == len - 3) y2 = dv[j];
-          if (j == len - 4) y3 = dv[j];
-        }
-        double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
-        double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
-        double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
-        double a4 = y2 * c.M1 + y1 * c.M2 + v2 * c.M3 + v2 * c.M4;
-        a1 -= v2 * c.BM1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
-        a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
-        a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
-        a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
-#pragma unroll
-        for (int j = 0; j < RM; j++) {
-          if (j == len - 1) cv[j] += a1;
-          if (j == len - 2) cv[j] += a2;
-          if (j == len - 3) cv[j] += a3;
-          if (j == len - 4) cv[j] += a4;
-        }
-        q0 = a4; q1 = a3; q2 = a2; q3 = a1;
-        e0 = y3; e1 = y2; e2 = y1; e3 = v2;
-        jtop = len - 5;
-      } else {
-        q0 = sp[(kb * 4 + 0) * TL];
-        q1 = sp[(kb * 4 + 1) * TL];
-        q2 = sp[(kb * 4 + 2) * TL];
-        q3 = sp[(kb * 4 + 3) * TL];
-        e0 = dv[RB]; e1 = dv[RB + 1]; e2 = dv[RB + 2]; e3 = dv[RB + 3];
-      }
+    if (PLAIN || lastblk) {
 #pragma unroll
       for (int jj = RM - 1; jj >= 0; jj--) {
         if (jj <= jtop) {
@@ -645,378 +527,71 @@ __global__ void __launch_bounds__(64) rgauss_tile_kernel(RGMultiT<T> M, long lon
           q3 = q2; q2 = q1; q1 = q0; q0 = v;
         }
       }
+    } else {
+      RGChain ch;
+      ch.enter(q0, q1, q2, q3, e0, e1, e2, e3, c.M1, c.M2, c.M3, c.M4, c.D2, c.D3, c.D4);
+#pragma unroll
+      for (int jj = RB - 1; jj >= 0; jj--) {
+        double v;
+        if (jj > 0) v = ch.step<true>((double)dv[jj], c.M1, c.M2, c.M3, c.M4, c.D1, c.D2, c.D3, c.D4);
+        else v = ch.step<false>(0.0, c.M1, c.M2, c.M3, c.M4, c.D1, c.D2, c.D3, c.D4);
+        cv[jj] += v;
+      }
+    }
+    // store
+    if (CONTIG) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int j = 0; j < RM; j++)
-        if (j < len) PRAD_RGT_AT(b + j) = (T)cv[j];
-    }
-  }
-#undef PRAD_RGT_AT
-  __syncthreads();
-  // ---- tile out ----
-  T *__restrict__ dst = AM == 0 ? M.out[sg] : M.acc[sg];
-  auto fin = [&](T f, T a) -> T {       // = rg_store
-    if (AM == 0) return f;
-    return (T)((AM == 2 ? (double)a : 0.0) + (double)f / sp2);
-  };
-  if (CONTIG) {
-    if (vec) {
-      const int nq = nl * ln / V;
-#pragma unroll 4
-      for (int q = lane; q < nq; q += 64) {
-        const int e = q * V, t = e / ln, j = e - t * ln;
-        VT a;
-        if (AM == 2) a = *reinterpret_cast<const VT *>(dst + gbase + (long long)q * V);
-        VT r;
-        T *pr = reinterpret_cast<T *>(&r);
-        const T *pa = reinterpret_cast<const T *>(&a);
+        if (j < len) tile[lane][j] = (T)cv[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < V; i++) pr[i] = fin(tile[t * PT + j + i], AM == 2 ? pa[i] : (T)0);
-        *reinterpret_cast<VT *>(dst + gbase + (long long)q * V) = r;
+      for (int k = 0; k < 16; k++) {
+        const int t = k * 4 + (lane >> 4), cc = lane & 15;
+        if (t < nwl && cc < len) out[(wl0 + t) * ln + b + cc] = tile[t][cc];
       }
-    } else {
-      const int ne = nl * ln;
-#pragma unroll 4
-      for (int e = lane; e < ne; e += 64) {
-        const int t = e / ln, j = e - t * ln;
-        const T a = AM == 2 ? dst[gbase + e] : (T)0;
-        dst[gbase + e] = fin(tile[t * PT + j], a);
-      }
-    }
-  } else {
-    if (vec) {
-      constexpr int QR = TL / V > 0 ? TL / V : 1;
-      const int nq = ln * QR;
-#pragma unroll 4
-      for (int q = lane; q < nq; q += 64) {
-        const int j = q / QR, t = (q % QR) * V;
-        if (t < nl) {
-          const long long gi = gbase + (long long)j * inner + t;
-          VT a;
-          if (AM == 2) a = *reinterpret_cast<const VT *>(dst + gi);
-          const VT f = *reinterpret_cast<const VT *>(tile + j * TL + t);
-          VT r;
-          T *pr = reinterpret_cast<T *>(&r);
-          const T *pa = reinterpret_cast<const T *>(&a), *pf = reinterpret_cast<const T *>(&f);
+      if (len > 16) {
 #pragma unroll
-          for (int i = 0; i < V; i++) pr[i] = fin(pf[i], AM == 2 ? pa[i] : (T)0);
-          *reinterpret_cast<VT *>(dst + gi) = r;
+        for (int k = 0; k < 4; k++) {
+          const int t = k * 16 + (lane >> 2), cc = 16 + (lane & 3);
+          if (t < nwl && cc < len) out[(wl0 + t) * ln + b + cc] = tile[t][cc];
         }
       }
     } else {
-      const int ne = ln * TL;
-#pragma unroll 4
-      for (int e = lane; e < ne; e += 64) {
-        const int j = e / TL, t = e % TL;
-        if (t < nl) {
-          const long long gi = gbase + (long long)j * inner + t;
-          const T a = AM == 2 ? dst[gi] : (T)0;
-          dst[gi] = fin(tile[e], a);
-        }
-      }
-    }
-  }
-}
-
-// The same recursion for the contiguous axis (inner == 1): a lane-per-line walk would read 64 different cache lines
-// per step.  One wave owns 64 consecutive lines and moves them through LDS in 64-sample tiles: every global access is
-// a 256-byte row segment, the lane then walks its own line inside the tile (pitch 65: conflict-free).  Causal tiles
-// run from the start of the line, anti-causal tiles from its end, so each direction's 4 boundary samples sit in
-// its first tile.
-#define PRAD_RG_T 64     // lines per workgroup (one lane each)
-#define PRAD_RG_W 32     // samples per tile: 25 KB of LDS per wave instead of 50, twice the waves per CU
-__global__ void __launch_bounds__(64) rgauss_xline_kernel(const float *__restrict__ in, long long lines, int ln,
-                                                          RGaussCoef c, double *__restrict__ scratch,
-                                                          float *__restrict__ out, float *__restrict__ acc, double sp2,
-                                                          int first) {
-#pragma clang fp contract(off)
-  __shared__ float tin[PRAD_RG_T][PRAD_RG_W + 1];
-  __shared__ double tsc[PRAD_RG_T][PRAD_RG_W + 1];
-  const int lane = threadIdx.x;
-  const long long l0 = (long long)blockIdx.x * PRAD_RG_T;
-  const int nl = (int)min((long long)PRAD_RG_T, lines - l0);
-  const bool mine = lane < nl;
-  // ---- causal ----
-  double dm1 = 0, dm2 = 0, dm3 = 0, p1 = 0, p2 = 0, p3 = 0, p4 = 0, v1 = 0;
-  for (int c0 = 0; c0 < ln; c0 += PRAD_RG_W) {
-    const int w = min(PRAD_RG_W, ln - c0);
-    __syncthreads();
-    for (int t = 0; t < nl; t += 2) {      // two rows of 32 samples per wave instruction
-      const int tt = t + (lane >> 5), cc = lane & 31;
-      if (tt < nl && cc < w) tin[tt][cc] = in[(l0 + tt) * ln + c0 + cc];
-    }
-    __syncthreads();
-    if (mine) {
-      int j = 0;
-      if (c0 == 0) {
-        v1 = tin[lane][0];
-        const double x1 = tin[lane][1], x2 = tin[lane][2], x3 = tin[lane][3];
-        double s0 = v1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
-        double s1 = x1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
-        double s2 = x2 * c.N0 + x1 * c.N1 + v1 * c.N2 + v1 * c.N3;
-        double s3 = x3 * c.N0 + x2 * c.N1 + x1 * c.N2 + v1 * c.N3;
-        s0 -= v1 * c.BN1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
-        s1 -= s0 * c.D1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
-        s2 -= s1 * c.D1 + s0 * c.D2 + v1 * c.BN3 + v1 * c.BN4;
-        s3 -= s2 * c.D1 + s1 * c.D2 + s0 * c.D3 + v1 * c.BN4;
-        tsc[lane][0] = s0; tsc[lane][1] = s1; tsc[lane][2] = s2; tsc[lane][3] = s3;
-        dm1 = x3; dm2 = x2; dm3 = x1;
-        p1 = s3; p2 = s2; p3 = s1; p4 = s0;
-        j = 4;
-      }
-      for (; j < w; j++) {
-        const double di = tin[lane][j];
-        double v = di * c.N0 + dm1 * c.N1 + dm2 * c.N2 + dm3 * c.N3;
-        v -= p1 * c.D1 + p2 * c.D2 + p3 * c.D3 + p4 * c.D4;
-        tsc[lane][j] = v;
-        dm3 = dm2; dm2 = dm1; dm1 = di;
-        p4 = p3; p3 = p2; p2 = p1; p1 = v;
-      }
-    }
-    __syncthreads();
-    for (int t = 0; t < nl; t += 2) {
-      const int tt = t + (lane >> 5), cc = lane & 31;
-      if (tt < nl && cc < w) scratch[(l0 + tt) * ln + c0 + cc] = tsc[tt][cc];
-    }
-  }
-  // ---- anti-causal: tiles [e - w, e) walking down from e = ln ----
-  double dp0 = 0, dp1 = 0, dp2 = 0, dp3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-  for (int e = ln; e > 0; e -= PRAD_RG_W) {
-    const int b = max(e - PRAD_RG_W, 0), w = e - b;
-    __syncthreads();
-    for (int t = 0; t < nl; t += 2) {
-      const int tt = t + (lane >> 5), cc = lane & 31;
-      if (tt < nl && cc < w) {
-        tin[tt][cc] = in[(l0 + tt) * ln + b + cc];
-        tsc[tt][cc] = scratch[(l0 + tt) * ln + b + cc];
-      }
-    }
-    __syncthreads();
-    if (mine) {
-      int j = w - 1;                         // tile-local index of the sample being produced
-      if (e == ln) {
-        const double v2 = tin[lane][w - 1], y1 = tin[lane][w - 2], y2 = tin[lane][w - 3];
-        double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
-        double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
-        double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
-        double a4 = y2 * c.M1 + y1 * c.M2 + v2 * c.M3 + v2 * c.M4;
-        a1 -= v2 * c.BM1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
-        a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
-        a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
-        a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
-        tsc[lane][w - 1] += a1; tsc[lane][w - 2] += a2; tsc[lane][w - 3] += a3; tsc[lane][w - 4] += a4;
-        dp0 = tin[lane][w - 4]; dp1 = y2; dp2 = y1; dp3 = v2;
-        q0 = a4; q1 = a3; q2 = a2; q3 = a1;
-        j = w - 5;
-      }
-      for (; j >= 0; j--) {
-        double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
-        v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
-        dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = tin[lane][j];
-        tsc[lane][j] += v;
-        q3 = q2; q2 = q1; q1 = q0; q0 = v;
-      }
-    }
-    __syncthreads();
-    for (int t = 0; t < nl; t += 2) {
-      const int tt = t + (lane >> 5), cc = lane & 31;
-      if (tt < nl && cc < w) rg_store(out, acc, (l0 + tt) * ln + b + cc, tsc[tt][cc], sp2, first);
-    }
-  }
-}
-
-// The same pass with the line cut in two and both directions of the recursion in flight: a 256^3 volume has 65 536
-// lines = 1 024 waves of 64 lines, one per SIMD of the GPU, each alternating load / recurse / store with nothing to
-// hide the latencies behind (290 us per pass, against 125 us for the strided axes).  Here a workgroup is two waves on
-// the same 64 lines.  Phase 1: the forward wave runs the causal recursion over [0, m), the backward wave the
-// anti-causal one over [m, ln); each leaves its float64 partial in `scratch`.  Phase 2: each continues into the other
-// half, adds its value to the partial stored there (causal + anti-causal, the same sum in either order) and stores the
-// result.  Twice the waves, half the dependent chain, the same traffic; the next tile is fetched into registers while
-// the current one is recursed.  Waves only share LDS with themselves (no workgroup barrier but the one between the
-// phases).
-// AM: 0 = plain float output, 1 = first Laplacian term (acc = v / sp2), 2 = later term (acc += v / sp2).  The phase
-// (partial into scratch / final) and AM are compile-time in every loop: with run-time flags the tile loop was a maze
-// of branches, each load group followed by its own wait.
-// TL: lines per wave (64: every lane recurses; 32: half the lanes do, but a row piece is 32 samples = a full 128-byte
-// line per access at the LDS cost of 16-sample tiles, and a 256^3 volume gets 4 096 waves instead of 2 048)
-template <int W, int TL, int AM>
-__device__ __forceinline__ void rgauss_xline2_body(const float *__restrict__ in, long long lines, int ln,
-                                                   const RGaussCoef &c, double *scratch, float *__restrict__ out,
-                                                   float *__restrict__ acc, double sp2) {
-#pragma clang fp contract(off)
-  constexpr int RPI = 64 / W;            // rows of W samples per wave instruction
-  constexpr int NI = TL * W / 64;        // load / store instructions per tile
-  __shared__ float tin_[2][TL][W + 1];
-  __shared__ double tsc_[2][TL][W + 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float(*tin)[W + 1] = tin_[wave];
-  double(*tsc)[W + 1] = tsc_[wave];
-  const long long l0 = (long long)blockIdx.x * TL;
-  const int nl = (int)min((long long)TL, lines - l0);
-  const bool mine = lane < nl;
-  const int m = (((ln + W - 1) / W) / 2) * W;      // the split (4 <= m <= ln - 4: the caller guarantees ln >= 2 W)
-  const int rr = lane / W, cc = lane % W;
-  // global index of this lane's k-th element of the tile at column c0 (clamped: loads are never conditional)
-  auto gidx = [&](int k, int c0, int w) __attribute__((always_inline)) -> long long {
-    return (l0 + min(k * RPI + rr, nl - 1)) * ln + c0 + min(cc, w - 1);
-  };
-  // (macros, not lambdas taking the arrays by reference: those left all four arrays in scratch memory)
-#define PRAD_XL_FETCH(PF, PS, C0, WW)                                                                     \
-  {                                                                                                       \
-    const int c0_ = (C0), w_ = (WW);                                                                      \
-    _Pragma("unroll") for (int k = 0; k < NI; k++) PF[k] = in[gidx(k, c0_, w_)];                          \
-    if (FIN) {                                                                                            \
-      _Pragma("unroll") for (int k = 0; k < NI; k++)                                                      \
-          PS[k] = __hip_atomic_load(scratch + gidx(k, c0_, w_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-    }                                                                                                     \
-  }
-#define PRAD_XL_COMMIT(PF, PS)                                                                            \
-  {                                                                                                       \
-    _Pragma("unroll") for (int k = 0; k < NI; k++) {                                                      \
-      tin[k * RPI + rr][cc] = PF[k];                                                                      \
-      if (FIN) tsc[k * RPI + rr][cc] = PS[k];                                                             \
-    }                                                                                                     \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                \
-    __builtin_amdgcn_wave_barrier();                                                                      \
-  }
-  auto put = [&](auto fin_tag, int c0, int w) __attribute__((always_inline)) {     // tile results (tsc) -> scratch / the output image, coalesced
-    constexpr bool FIN = decltype(fin_tag)::value;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    float ab[NI];
-    if (FIN && AM == 2) {              // all accumulator loads first
 #pragma unroll
-      for (int k = 0; k < NI; k++) ab[k] = acc[gidx(k, c0, w)];
+      for (int j = 0; j < RM; j++)
+        if (j < len) out[base + (long long)(b + j) * st] = (T)cv[j];
     }
-#pragma unroll
-    for (int k = 0; k < NI; k++) {
-      const int tt = k * RPI + rr;
-      if (tt < nl && cc < w) {
-        const long long idx = (l0 + tt) * ln + c0 + cc;
-        if (FIN) {
-          const float f = (float)tsc[tt][cc];
-          if (AM == 0) out[idx] = f;
-          else acc[idx] = (float)((AM == 2 ? (double)ab[k] : 0.0) + (double)f / sp2);   // = rg_store
-        } else {
-          scratch[idx] = tsc[tt][cc];
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  };
-  double t1 = 0, t2 = 0, t3 = 0, u1 = 0, u2 = 0, u3 = 0, u4 = 0;   // recursion state: 3 (4) data samples, 4 outputs
-  auto forward = [&](auto fin_tag, int r0, int r1) __attribute__((always_inline)) {
-    constexpr bool FIN = decltype(fin_tag)::value;
-    float pfA[NI], pfB[NI];      // two tiles in flight ahead of the recursion (a 256^3 volume only has 2 048 such waves:
-    double psA[NI], psB[NI];     // one tile each left ~4 MB in flight on the whole GPU, 178 us per pass)
-    PRAD_XL_FETCH(pfA, psA, r0, min(W, r1 - r0));
-    if (r0 + W < r1) PRAD_XL_FETCH(pfB, psB, r0 + W, min(W, r1 - r0 - W));
-    int par = 0;
-    for (int c0 = r0; c0 < r1; c0 += W, par ^= 1) {
-      const int w = min(W, r1 - c0);
-      if (par == 0) {
-        PRAD_XL_COMMIT(pfA, psA);
-        if (c0 + 2 * W < r1) PRAD_XL_FETCH(pfA, psA, c0 + 2 * W, min(W, r1 - c0 - 2 * W));
-      } else {
-        PRAD_XL_COMMIT(pfB, psB);
-        if (c0 + 2 * W < r1) PRAD_XL_FETCH(pfB, psB, c0 + 2 * W, min(W, r1 - c0 - 2 * W));
-      }
-#ifndef PRAD_DBG_XL_NOCOMPUTE
-      if (mine) {
-        int j = 0;
-        if (c0 == 0) {
-          const double v1 = tin[lane][0];
-          const double x1 = tin[lane][1], x2 = tin[lane][2], x3 = tin[lane][3];
-          double s0 = v1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
-          double s1 = x1 * c.N0 + v1 * c.N1 + v1 * c.N2 + v1 * c.N3;
-          double s2 = x2 * c.N0 + x1 * c.N1 + v1 * c.N2 + v1 * c.N3;
-          double s3 = x3 * c.N0 + x2 * c.N1 + x1 * c.N2 + v1 * c.N3;
-          s0 -= v1 * c.BN1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
-          s1 -= s0 * c.D1 + v1 * c.BN2 + v1 * c.BN3 + v1 * c.BN4;
-          s2 -= s1 * c.D1 + s0 * c.D2 + v1 * c.BN3 + v1 * c.BN4;
-          s3 -= s2 * c.D1 + s1 * c.D2 + s0 * c.D3 + v1 * c.BN4;
-          tsc[lane][0] = s0; tsc[lane][1] = s1; tsc[lane][2] = s2; tsc[lane][3] = s3;   // (c0 == 0 is never final)
-          t1 = x3; t2 = x2; t3 = x1;
-          u1 = s3; u2 = s2; u3 = s1; u4 = s0;
-          j = 4;
-        }
-        for (; j < w; j++) {
-          const double di = tin[lane][j];
-          double v = di * c.N0 + t1 * c.N1 + t2 * c.N2 + t3 * c.N3;
-          v -= u1 * c.D1 + u2 * c.D2 + u3 * c.D3 + u4 * c.D4;
-          tsc[lane][j] = FIN ? v + tsc[lane][j] : v;
-          t3 = t2; t2 = t1; t1 = di;
-          u4 = u3; u3 = u2; u2 = u1; u1 = v;
-        }
-      }
-#endif
-      put(fin_tag, c0, w);
-    }
-  };
-  double t0 = 0;   // (backward: t0..t3 = data[i], [i+1], [i+2], [i+3]; u1..u4 = outputs [i], [i+1], [i+2], [i+3])
-  auto backward = [&](auto fin_tag, int r0, int r1) __attribute__((always_inline)) {
-    constexpr bool FIN = decltype(fin_tag)::value;
-    float pfA[NI], pfB[NI];      // two tiles in flight ahead of the recursion (a 256^3 volume only has 2 048 such waves:
-    double psA[NI], psB[NI];     // one tile each left ~4 MB in flight on the whole GPU, 178 us per pass)
-    auto tile_b = [&](int e) { return max(e - W, r0); };       // tile [tile_b(e), e)
-    PRAD_XL_FETCH(pfA, psA, tile_b(r1), r1 - tile_b(r1));
-    if (tile_b(r1) > r0) PRAD_XL_FETCH(pfB, psB, tile_b(r1 - W), r1 - W - tile_b(r1 - W));
-    int par = 0;
-    for (int e = r1; e > r0; e -= W, par ^= 1) {
-      const int b = tile_b(e), w = e - b;
-      const int e2 = e - 2 * W;                                 // end of the tile after next
-      if (par == 0) {
-        PRAD_XL_COMMIT(pfA, psA);
-        if (e2 > r0) PRAD_XL_FETCH(pfA, psA, tile_b(e2), e2 - tile_b(e2));
-      } else {
-        PRAD_XL_COMMIT(pfB, psB);
-        if (e2 > r0) PRAD_XL_FETCH(pfB, psB, tile_b(e2), e2 - tile_b(e2));
-      }
-#ifndef PRAD_DBG_XL_NOCOMPUTE
-      if (mine) {
-        int j = w - 1;
-        if (e == ln) {
-          const double v2 = tin[lane][w - 1], y1 = tin[lane][w - 2], y2 = tin[lane][w - 3];
-          double a1 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
-          double a2 = v2 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
-          double a3 = y1 * c.M1 + v2 * c.M2 + v2 * c.M3 + v2 * c.M4;
-          double a4 = y2 * c.M1 + y1 * c.M2 + v2 * c.M3 + v2 * c.M4;
-          a1 -= v2 * c.BM1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
-          a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
-          a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
-          a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
-          tsc[lane][w - 1] = a1; tsc[lane][w - 2] = a2; tsc[lane][w - 3] = a3; tsc[lane][w - 4] = a4;   // (never final)
-          t0 = tin[lane][w - 4]; t1 = y2; t2 = y1; t3 = v2;
-          u1 = a4; u2 = a3; u3 = a2; u4 = a1;
-          j = w - 5;
-        }
-        for (; j >= 0; j--) {
-          double v = t0 * c.M1 + t1 * c.M2 + t2 * c.M3 + t3 * c.M4;
-          v -= u1 * c.D1 + u2 * c.D2 + u3 * c.D3 + u4 * c.D4;
-          t3 = t2; t2 = t1; t1 = t0; t0 = tin[lane][j];
-          tsc[lane][j] = FIN ? tsc[lane][j] + v : v;
-          u4 = u3; u3 = u2; u2 = u1; u1 = v;
-        }
-      }
-#endif
-      put(fin_tag, b, w);
-    }
-  };
-  using No = std::integral_constant<bool, false>;
-  using Yes = std::integral_constant<bool, true>;
-  if (wave == 0) forward(No{}, 0, m);
-  else backward(No{}, m, ln);
-  __threadfence();
-  __syncthreads();
-  if (wave == 0) forward(Yes{}, m, ln);
-  else backward(Yes{}, 0, m);
-#undef PRAD_XL_FETCH
-#undef PRAD_XL_COMMIT
+  }
 }
 
-template <int W, int TL, int AM>
-__global__ void __launch_bounds__(128) rgauss_xline2_kernel(RGMulti M, long long lines, int ln, double sp2) {
-  const int sg = blockIdx.y;
-  rgauss_xline2_body<W, TL, AM>(M.in[sg], lines, ln, M.k[sg], M.scratch[sg], M.out[sg], M.acc[sg], sp2);
+// Laplacian = sum over the dimensions of (second-derivative image) / spacing^2, accumulated in ITK's order and with the
+// roundings of its separate accumulation step: acc = (T)((double)acc + (double)term / spacing^2), starting from 0
+// (itkLaplacianRecursiveGaussianImageFilter.hxx).  out may alias term[0].
+#define PRAD_LOG_MAXTERMS 8
+template <typename T>
+struct LogTerms {
+  const T *term[PRAD_LOG_MAXTERMS];
+  double sp2[PRAD_LOG_MAXTERMS];
+  int n;
+};
+template <typename T>
+__global__ void __launch_bounds__(256) log_combine_kernel(LogTerms<T> L, long long n, T *out) {
+#pragma clang fp contract(off)
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    T acc = (T)0;
+#pragma unroll
+    for (int k = 0; k < PRAD_LOG_MAXTERMS; k++) {
+      if (k < L.n) {
+        const T f = L.term[k][i];
+        acc = (T)((double)acc + (double)f / L.sp2[k]);
+      }
+    }
+    out[i] = acc;
+  }
 }
 
 }  // namespace prad

@@ -4,6 +4,7 @@
 #include "prad_runtime.h"
 #include "kernels_filters.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -145,78 +146,7 @@ RGaussCoef rgauss_coefficients(double sigma, double spacing, int order, bool nor
   return c;
 }
 
-// ---- whole-line LDS tiles (rgauss_tile_kernel): plan and launch ----------------------------------------------------------
-struct RGTilePlan {
-  int TL = 0;          // lines per wave; 0 = the tile route does not fit this axis
-  int PT = 0, vec = 0;
-  size_t lds = 0;
-};
-template <typename T>
-RGTilePlan rg_tile_plan(int ln, long long inner, bool aligned) {
-  RGTilePlan best;
-  if (ln < 4 || getenv("PRAD_LOG_NO_TILE")) return best;
-  const bool contig = inner == 1;
-  const int V = 16 / (int)sizeof(T);
-  const long long nb = (ln - 4) / PRAD_RGT_RB + 1;
-  static const int forced = getenv("PRAD_LOG_TL") ? atoi(getenv("PRAD_LOG_TL")) : 0;   // tuning override
-  // the largest tile that still leaves four waves per CU (one per SIMD), else two, else one
-  const size_t budgets[3] = {160 * 1024 / 4, 160 * 1024 / 2, 160 * 1024};
-  for (size_t budget : budgets) {
-    for (int TL : {64, 32, 16}) {
-      if (forced && TL != forced) continue;
-      const int PT = contig ? (ln | 1) : 0;
-      const size_t tile = (contig ? (size_t)TL * PT : (size_t)ln * TL) * sizeof(T);
-      const size_t lds = ((tile + 15) & ~(size_t)15) + (size_t)(nb - 1) * 4 * TL * sizeof(double);
-      if (lds > budget) continue;
-      best.TL = TL;
-      best.PT = PT;
-      best.lds = lds;
-      best.vec = aligned && (contig ? ln % V == 0 : inner % V == 0);
-      return best;
-    }
-  }
-  return best;
-}
-template <typename T, int TL, bool CONTIG, int AM>
-int rg_tile_launch_am(const RGMultiT<T> &M, int nsig, long long outer, int ln, long long inner, double sp2, const RGTilePlan &p,
-                      hipStream_t s) {
-  static size_t granted = 0;       // (per instantiation)
-  if (p.lds > 48 * 1024 && p.lds > granted) {
-    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&rgauss_tile_kernel<T, TL, CONTIG, AM>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-    granted = p.lds;
-  }
-  const long long groups = CONTIG ? (outer + TL - 1) / TL : outer * ((inner + TL - 1) / TL);
-  if (groups > 0x7fffffffLL) return fail(PRAD_E_UNSUPPORTED, "log: %lld line groups", groups);
-  hipLaunchKernelGGL((rgauss_tile_kernel<T, TL, CONTIG, AM>), dim3((unsigned)groups, (unsigned)nsig), dim3(64), p.lds, s, M, outer, ln,
-                     inner, sp2, p.PT, p.vec);
-  return check_launch("rgauss_tile_kernel");
-}
-template <typename T, int TL, bool CONTIG>
-int rg_tile_launch_tl(const RGMultiT<T> &M, int nsig, long long outer, int ln, long long inner, double sp2, int am,
-                      const RGTilePlan &p, hipStream_t s) {
-  if (am == 0) return rg_tile_launch_am<T, TL, CONTIG, 0>(M, nsig, outer, ln, inner, sp2, p, s);
-  if (am == 1) return rg_tile_launch_am<T, TL, CONTIG, 1>(M, nsig, outer, ln, inner, sp2, p, s);
-  return rg_tile_launch_am<T, TL, CONTIG, 2>(M, nsig, outer, ln, inner, sp2, p, s);
-}
-template <typename T>
-int rg_tile_launch(const RGMultiT<T> &M, int nsig, long long outer, int ln, long long inner, double sp2, int am,
-                   const RGTilePlan &p, hipStream_t s) {
-  const bool contig = inner == 1;
-#define PRAD_RGT_CASE(TLV)                                                                                   \
-  case TLV:                                                                                                  \
-    return contig ? rg_tile_launch_tl<T, TLV, true>(M, nsig, outer, ln, inner, sp2, am, p, s)                \
-                  : rg_tile_launch_tl<T, TLV, false>(M, nsig, outer, ln, inner, sp2, am, p, s);
-  switch (p.TL) {
-    PRAD_RGT_CASE(64)
-    PRAD_RGT_CASE(32)
-    PRAD_RGT_CASE(16)
-  }
-#undef PRAD_RGT_CASE
-  return fail(PRAD_E_UNSUPPORTED, "log: no tile plan");
-}
-
-// nsig sigmas of one input in the same launches (blockIdx.y = sigma): see RGMulti in kernels_filters.h.
+// nsig sigmas of one input in the same launches (blockIdx.y = sigma): see RGMultiT in kernels_filters.h.
 // T = float: ITK's real image type for integer and float32 inputs; T = double: float64 inputs keep float64 images between
 // the passes (sitk.LaplacianRecursiveGaussianImageFilter returns the input's real type, imageoperations.py:824-830).
 template <typename T>
@@ -228,135 +158,80 @@ int log_multi_dev(const T *in, const int *size, int Nd, const double *spacing, c
   PRAD_TRY(make_geo(size, Nd, &g));
   if (!in || !outs || !spacing || !sigmas) return fail(PRAD_E_ARG, "log: NULL pointer");
   if (nsig < 1 || nsig > PRAD_LOG_MAXSIG) return fail(PRAD_E_ARG, "log: %d sigmas per call outside [1, %d]", nsig, PRAD_LOG_MAXSIG);
-  bool aligned = ((uintptr_t)in % 16) == 0;
+  if (Nd > PRAD_LOG_MAXTERMS) return fail(PRAD_E_UNSUPPORTED, "log: %d dimensions", Nd);
   for (int q = 0; q < nsig; q++) {
     if (!(sigmas[q] > 0.0)) return fail(PRAD_E_ARG, "log: sigma must be > 0");
     if (!outs[q]) return fail(PRAD_E_ARG, "log: NULL output");
-    aligned = aligned && ((uintptr_t)outs[q] % 16) == 0;
   }
   for (int d = 0; d < Nd; d++)
     if (g.size[d] < 4) return fail(PRAD_E_ARG, "log: axis %d has %d < 4 samples (imageoperations.py:811)", d, g.size[d]);
   PRAD_TRY(c.begin_call(s));
   const size_t n = (size_t)g.n;
-  constexpr bool IS_F32 = std::is_same<T, float>::value;
-  const char *sfx = IS_F32 ? "" : "64";
-  RGTilePlan plan[PRAD_MAX_ND];
-  bool need_scratch = false;
-  for (int d = 0; d < Nd; d++) {
-    plan[d] = rg_tile_plan<T>(g.size[d], g.stride[d], aligned);
-    need_scratch = need_scratch || plan[d].TL == 0;
-  }
+  const char *sfx = std::is_same<T, float>::value ? "" : "64";
+  const bool reference_kernel = getenv("PRAD_LOG_OLDLINE") != nullptr;     // one lane per line, float64 scratch image
+  const bool plain_steps = getenv("PRAD_LOG_PLAIN") != nullptr;
   T *bufA[PRAD_LOG_MAXSIG], *bufB[PRAD_LOG_MAXSIG], *bufC[PRAD_LOG_MAXSIG];
+  T *term[PRAD_LOG_MAXTERMS][PRAD_LOG_MAXSIG];       // second-derivative image of every dimension (the first lives in outs)
   double *scratch[PRAD_LOG_MAXSIG];
   for (int q = 0; q < nsig; q++) {
     const std::string tag = sfx + (q ? "#s" + std::to_string(q) : std::string());
     PRAD_TRY(c.get<T>(("log_a" + tag).c_str(), n, &bufA[q]));
     PRAD_TRY(c.get<T>(("log_b" + tag).c_str(), n, &bufB[q]));
     PRAD_TRY(c.get<T>(("log_c" + tag).c_str(), n, &bufC[q]));
-    scratch[q] = nullptr;
-    if (need_scratch) PRAD_TRY(c.get<double>(("log_scratch" + tag).c_str(), n, &scratch[q]));
+    term[0][q] = outs[q];
+    for (int k = 1; k < Nd; k++) PRAD_TRY(c.get<T>(("log_t" + std::to_string(k) + tag).c_str(), n, &term[k][q]));
+    // block states of rgauss_pass_kernel: 4 doubles per PRAD_RG_RB samples (n / 4 + a line's worth); the reference kernel
+    // parks the whole causal pass
+    PRAD_TRY(c.get<double>(("log_scratch" + tag).c_str(), reference_kernel ? n : n / 4 + 4 * (n / g.size[Nd - 1]) + 64, &scratch[q]));
   }
   {
     Timed t(c, "log", s);
-    // ITK dimension order x, y, z = array axes Nd-1 .. 0
-    bool first = true;
+    // ITK dimension order x, y, z = array axes Nd-1 .. 0.
     // Laplacian term of dimension dim = second derivative along dim of the image smoothed along the other dimensions,
-    // in ITK's pass order (smoothing passes from the last axis to the first, then the derivative).  The derivative pass
-    // accumulates straight into `out` (acc += term / spacing^2, roundings of the separate step).  Two terms begin with
+    // in ITK's pass order (smoothing passes from the last axis to the first, then the derivative).  Two terms begin with
     // the same smoothing pass along the last axis: it is computed once and kept (identical arithmetic, identical bits).
     bool have_shared = false;        // bufC = smoothed-along-the-last-axis copy of the input
     int shared_axis = -1;
+    int nterm = 0;
+    double term_sp2[PRAD_LOG_MAXTERMS];
     for (int dim = Nd - 1; dim >= 0; dim--) {
       const T *cur[PRAD_LOG_MAXSIG];
       for (int q = 0; q < nsig; q++) cur[q] = in;
       int flip = 0;
-      // forced: 0 = ping-pong buffers, 1 = into bufC (the shared first smoothing)
-      auto pass = [&](int ax, int order, int forced, bool accumulate) -> int {
+      // where: 0 = ping-pong buffers, 1 = into bufC (the shared first smoothing), 2 = the term image of this dimension
+      auto pass = [&](int ax, int order, int where) -> int {
+        RGMultiT<T> M;
+        memset(&M, 0, sizeof(M));
         T *dst[PRAD_LOG_MAXSIG];
-        RGaussCoef K[PRAD_LOG_MAXSIG];
         for (int q = 0; q < nsig; q++) {
-          K[q] = rgauss_coefficients(sigmas[q], spacing[ax], order, normalize != 0);
-          dst[q] = forced ? bufC[q] : (flip ? bufB[q] : bufA[q]);
+          M.k[q] = rgauss_coefficients(sigmas[q], spacing[ax], order, normalize != 0);
+          dst[q] = where == 1 ? bufC[q] : where == 2 ? term[nterm][q] : (flip ? bufB[q] : bufA[q]);
+          M.in[q] = cur[q];
+          M.scratch[q] = scratch[q];
+          M.out[q] = dst[q];
         }
         long long outer = 1;
         for (int d = 0; d < ax; d++) outer *= g.size[d];
         const long long inner = g.stride[ax];
         const long long lines = outer * inner;
-        const double sp2 = spacing[ax] * spacing[ax];
-        const bool accload = accumulate && !first;
-        const int am = !accumulate ? 0 : (first ? 1 : 2);
-        if (plan[ax].TL) {           // whole lines in LDS: one read and one write per sample (kernels_filters.h)
-          RGMultiT<T> MT;
-          memset(&MT, 0, sizeof(MT));
-          for (int q = 0; q < nsig; q++) {
-            MT.k[q] = K[q];
-            MT.in[q] = cur[q];
-            MT.out[q] = dst[q];
-            MT.acc[q] = accumulate ? outs[q] : nullptr;
-          }
-          PRAD_TRY(rg_tile_launch<T>(MT, nsig, outer, g.size[ax], inner, sp2, am, plan[ax], s));
-        } else if constexpr (IS_F32) {
-          RGMulti M;
-          memset(&M, 0, sizeof(M));
-          for (int q = 0; q < nsig; q++) {
-            M.k[q] = K[q];
-            M.in[q] = cur[q];
-            M.scratch[q] = scratch[q];
-            M.out[q] = dst[q];
-            M.acc[q] = accumulate ? outs[q] : nullptr;
-          }
-          if (inner == 1 && g.size[ax] >= 64 && !getenv("PRAD_LOG_NO_SPLIT")) {   // contiguous axis, two waves per 64 lines (kernels_filters.h)
-#define PRAD_XL2(W, TL, AM) hipLaunchKernelGGL((rgauss_xline2_kernel<W, TL, AM>), dim3((unsigned)((lines + TL - 1) / TL), (unsigned)nsig), dim3(128), 0, s, M, lines, g.size[ax], sp2)
-#define PRAD_XL2W(W, TL) do { if (!accumulate) PRAD_XL2(W, TL, 0); else if (first) PRAD_XL2(W, TL, 1); else PRAD_XL2(W, TL, 2); } while (0)
-            // tile = 16 samples x 64 lines per wave; measured at 256^3: 176 us, against 191 us for 32 x 64 (50 KB of LDS per
-            // workgroup) and 265 us for 32 x 32 (128-byte row pieces, twice the waves, half the lanes recursing)
-            static const int xl_mode = getenv("PRAD_LOG_XL") ? atoi(getenv("PRAD_LOG_XL")) : 0;   // tuning override
-            if (xl_mode == 2) PRAD_XL2W(32, 64);
-            else if (xl_mode == 3) PRAD_XL2W(32, 32);
-            else PRAD_XL2W(16, 64);
-#undef PRAD_XL2W
-#undef PRAD_XL2
-            PRAD_TRY(check_launch("rgauss_xline2_kernel"));
-          } else if (inner == 1 && g.size[ax] >= 8) {      // contiguous axis: LDS-tiled walk (see kernels_filters.h; a lane-per-line walk of this axis measured 343 us instead of 294 at 256^3)
-            for (int q = 0; q < nsig; q++)
-              hipLaunchKernelGGL(rgauss_xline_kernel, dim3((unsigned)((lines + PRAD_RG_T - 1) / PRAD_RG_T)), dim3(64), 0, s, M.in[q],
-                                 lines, g.size[ax], M.k[q], M.scratch[q], M.out[q], M.acc[q], sp2, first ? 1 : 0);
-            PRAD_TRY(check_launch("rgauss_xline_kernel"));
-          } else if (!getenv("PRAD_LOG_OLDLINE")) {   // strided axis: no float64 copy of the causal pass (kernels_filters.h)
-            const dim3 grid((unsigned)((lines + 255) / 256), (unsigned)nsig);
-            if (!accumulate)
-              hipLaunchKernelGGL(rgauss_line2_kernel<0>, grid, dim3(256), 0, s, M, outer, g.size[ax], inner, sp2);
-            else if (first)
-              hipLaunchKernelGGL(rgauss_line2_kernel<1>, grid, dim3(256), 0, s, M, outer, g.size[ax], inner, sp2);
-            else
-              hipLaunchKernelGGL(rgauss_line2_kernel<2>, grid, dim3(256), 0, s, M, outer, g.size[ax], inner, sp2);
-            PRAD_TRY(check_launch("rgauss_line2_kernel"));
-          } else {
-            for (int q = 0; q < nsig; q++) {
-              if (accload)
-                hipLaunchKernelGGL((rgauss_line_kernel<true, float>), dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, M.in[q], outer,
-                                   g.size[ax], inner, M.k[q], M.scratch[q], M.out[q], M.acc[q], sp2, 0);
-              else
-                hipLaunchKernelGGL((rgauss_line_kernel<false, float>), dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, M.in[q], outer,
-                                   g.size[ax], inner, M.k[q], M.scratch[q], M.out[q], M.acc[q], sp2, first ? 1 : 0);
-            }
-            PRAD_TRY(check_launch("rgauss_line_kernel"));
-          }
-        } else {
-          // float64 images whose lines do not fit the LDS tiles: the plain lane-per-line walk (any axis)
-          for (int q = 0; q < nsig; q++) {
-            T *acc = accumulate ? outs[q] : nullptr;
-            if (accload)
-              hipLaunchKernelGGL((rgauss_line_kernel<true, T>), dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, cur[q], outer,
-                                 g.size[ax], inner, K[q], scratch[q], dst[q], acc, sp2, 0);
-            else
-              hipLaunchKernelGGL((rgauss_line_kernel<false, T>), dim3((unsigned)((lines + 255) / 256)), dim3(256), 0, s, cur[q], outer,
-                                 g.size[ax], inner, K[q], scratch[q], dst[q], acc, sp2, first ? 1 : 0);
-          }
+        if (lines > 0x7fffffffLL * 256) return fail(PRAD_E_UNSUPPORTED, "log: %lld lines", lines);
+        const dim3 grid((unsigned)((lines + 255) / 256), (unsigned)nsig);
+        if (reference_kernel) {
+          for (int q = 0; q < nsig; q++)
+            hipLaunchKernelGGL((rgauss_line_kernel<T>), dim3(grid.x), dim3(256), 0, s, M.in[q], outer, g.size[ax], inner, M.k[q],
+                               M.scratch[q], M.out[q]);
           PRAD_TRY(check_launch("rgauss_line_kernel"));
+        } else if (plain_steps) {         // (PRAD_LOG_PLAIN=1: the compiler's own order of the recursion step, for A/B runs)
+          if (inner == 1) hipLaunchKernelGGL((rgauss_pass_kernel<T, true, true>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
+          else hipLaunchKernelGGL((rgauss_pass_kernel<T, false, true>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
+          PRAD_TRY(check_launch("rgauss_pass_kernel"));
+        } else {
+          if (inner == 1) hipLaunchKernelGGL((rgauss_pass_kernel<T, true, false>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
+          else hipLaunchKernelGGL((rgauss_pass_kernel<T, false, false>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
+          PRAD_TRY(check_launch("rgauss_pass_kernel"));
         }
         for (int q = 0; q < nsig; q++) cur[q] = dst[q];
-        if (!forced) flip ^= 1;
+        if (where == 0) flip ^= 1;
         return PRAD_OK;
       };
       bool first_pass = true;
@@ -364,23 +239,37 @@ int log_multi_dev(const T *in, const int *size, int Nd, const double *spacing, c
         if (other == dim) continue;
         if (first_pass && Nd >= 3 && other == Nd - 1) {     // smoothing of the INPUT along the last axis: shared
           if (!have_shared || shared_axis != other) {
-            PRAD_TRY(pass(other, 0, 1, false));
+            PRAD_TRY(pass(other, 0, 1));
             have_shared = true;
             shared_axis = other;
           }
           for (int q = 0; q < nsig; q++) cur[q] = bufC[q];
         } else {
-          PRAD_TRY(pass(other, 0, 0, false));
+          PRAD_TRY(pass(other, 0, 0));
         }
         first_pass = false;
       }
-      PRAD_TRY(pass(dim, 2, 0, true));
-      first = false;
+      PRAD_TRY(pass(dim, 2, 2));
+      term_sp2[nterm] = spacing[dim] * spacing[dim];
+      nterm++;
     }
+    // acc = sum of term / spacing^2 in ITK's order (x, y, z) with the roundings of its separate accumulation step
+    for (int q = 0; q < nsig; q++) {
+      LogTerms<T> L;
+      memset(&L, 0, sizeof(L));
+      L.n = nterm;
+      for (int k = 0; k < nterm; k++) {
+        L.term[k] = term[k][q];
+        L.sp2[k] = term_sp2[k];
+      }
+      const unsigned blocks = (unsigned)std::min<long long>((g.n + 255) / 256, 256LL * 32);
+      hipLaunchKernelGGL((log_combine_kernel<T>), dim3(blocks), dim3(256), 0, s, L, g.n, outs[q]);
+    }
+    PRAD_TRY(check_launch("log_combine_kernel"));
   }
   PRAD_TRY(c.end_call(s));
   PRAD_HIP(hipStreamSynchronize(s));
-  c.last_path = plan[Nd - 1].TL ? "log-tile" : "log";
+  c.last_path = reference_kernel ? "log-reference" : "log";
   return PRAD_OK;
 }
 

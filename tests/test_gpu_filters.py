@@ -310,32 +310,34 @@ def test_bincount_edges_built_on_the_device_are_numpys(monkeypatch):
     assert int(lv.max()) == Ng
 
 
-# ---- round 4: whole-line LDS tiles (rgauss_tile_kernel) and the float64 filter ------------------------------------------
+# ---- round 4: one pass kernel for every axis (rgauss_pass_kernel), the Laplacian sum as its own kernel, float64 filter ----
 def _log_old_route(fn):
-    """runs fn() with the round-3 kernels (two sweeps over HBM) instead of the LDS tiles"""
+    """runs fn() with the reference kernel of the library: one lane per line, the causal recursion parked in a float64
+    scratch image (rgauss_line_kernel) -- the plainest statement of ITK's FilterDataArray on the device"""
     import os
-    os.environ["PRAD_LOG_NO_TILE"] = "1"
+    os.environ["PRAD_LOG_OLDLINE"] = "1"
     try:
         return fn()
     finally:
-        del os.environ["PRAD_LOG_NO_TILE"]
+        del os.environ["PRAD_LOG_OLDLINE"]
 
 
 @pytest.mark.parametrize("shape,spacing", [((256, 64, 256), (1.0, 1.0, 1.0)),      # 256-sample lines on the contiguous and a strided axis
                                            ((37, 53, 70), (0.8, 1.1, 2.5)),       # nothing a multiple of 4: scalar tile moves, ragged chunks
                                            ((25, 256, 256), (0.78125, 0.78125, 6.5)),   # brain1's grid
                                            ((5, 4, 9), (1.0, 1.0, 1.0)), ((12, 20, 19), (1.0, 2.0, 0.5)),
-                                           ((4, 4, 520), (1.0, 1.0, 1.0)), ((600, 8, 4), (1.0, 1.0, 1.0))])   # long lines: fewer lines per wave
-def test_log_tile_kernels_equal_the_two_sweep_kernels_bit_for_bit(shape, spacing):
+                                           ((4, 4, 520), (1.0, 1.0, 1.0)), ((600, 8, 4), (1.0, 1.0, 1.0)),
+                                           ((3 * 16 + 4, 70, 2 * 16 + 19), (1.0, 1.0, 1.0)), ((20, 5, 23), (1.0, 1.0, 1.0))])   # block-edge cases
+def test_log_pass_kernel_equals_the_reference_kernel_bit_for_bit(shape, spacing):
     import torch
     from pyradiomics_amd import engine, _lib
     rng = np.random.default_rng(5)
     x = torch.from_numpy(rng.integers(-300, 1500, size=shape).astype(np.int16)).cuda()
     sig = [1.0, 2.5, 4.0]
     new = [t.cpu().numpy() for t in engine.log_images(x, spacing, sig)]
-    assert _lib.last_path() == "log-tile"
-    old = _log_old_route(lambda: [t.cpu().numpy() for t in engine.log_images(x, spacing, sig)])
     assert _lib.last_path() == "log"
+    old = _log_old_route(lambda: [t.cpu().numpy() for t in engine.log_images(x, spacing, sig)])
+    assert _lib.last_path() == "log-reference"
     for a, b in zip(new, old):
         assert a.dtype == np.float32 and np.array_equal(a, b)
     one = engine.log_image(x, spacing, 2.5).cpu().numpy()
@@ -364,7 +366,7 @@ def test_log_float64_matches_restatement(shape, spacing, sigma):
     multi = engine.log_images(torch.from_numpy(x).cuda(), spacing, [sigma, 2.0])
     assert np.array_equal(multi[0].cpu().numpy(), got)
     old = _log_old_route(lambda: engine.log_image(torch.from_numpy(x).cuda(), spacing, sigma).cpu().numpy())
-    assert np.array_equal(old, got)                                   # lane-per-line fallback: the same bits
+    assert np.array_equal(old, got)                                   # reference kernel: the same bits
     f32 = fo.laplacian_recursive_gaussian(x.astype(np.float32), spacing, sigma)
     assert np.abs(f32 - want).max() > 1e-9 * scale                    # the float32 route really is a different computation
     for on_dev in (True, False):
