@@ -39,6 +39,26 @@ def have_ref() -> bool:
     return os.path.exists(REF_SO)
 
 
+REF_WRAPPER_SO = os.path.join(_HERE, "_ref", "_cmatrices.so")
+
+
+def have_ref_wrapper() -> bool:
+    return os.path.exists(REF_WRAPPER_SO)
+
+
+def ref_wrapper():
+    """The reference's own CPython extension module `_cmatrices` (radiomics/src/_cmatrices.c + cmatrices.c compiled unmodified
+    by oracle/Makefile): exactly the object the reference binds as `radiomics.cMatrices` -- argument parsing, dtype coercion,
+    set_bb, exception mapping and output allocation included."""
+    import importlib.machinery
+    import importlib.util
+    loader = importlib.machinery.ExtensionFileLoader("_cmatrices", REF_WRAPPER_SO)
+    spec = importlib.util.spec_from_loader("_cmatrices", loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    return mod
+
+
 def _i(a):
     return a.ctypes.data_as(_ip)
 

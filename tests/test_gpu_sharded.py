@@ -128,3 +128,25 @@ def test_single_rank_call_and_errors():
         engine.neigh_accumulate(engine.NEIGH_NGTDM, img_t[0].contiguous(), msk_t[0].contiguous(), Ng, 0, 1)
     with pytest.raises(IndexError):
         batch.segment_matrices_sharded(img_t, torch.zeros_like(msk_t), Ng, classes=("glszm",))
+
+
+def test_bench_under_torchrun_with_rccl_one_rank():
+    """keeps the multi-GPU launch path exercised on the one-GPU box: the driver starts N > 1 runs as
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N`; the same
+    launch with N = 1 goes through RCCL init (backend nccl), the barrier + max-over-ranks all_reduce and the rank-aware
+    sharded modes, and must print one JSON line"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29731", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--size", "256",
+           "--no-modes", "--no-cpu-baseline", "--no-host-boundary", "--backend", "nccl"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["scaling"] == "weak" and rec["value"] > 0 and rec["roofline"]["frac"] > 0
