@@ -256,8 +256,77 @@ def mode_config2(device, engine, size=256, levels=32):
             total += best_wall
         res["total_wall_ms"] = round(total, 4)
         res["Mvoxels_s_all_five"] = round(n / (total * 1e-3) / 1e6, 1)
+        # GLDM and NGTDM from ONE pass over the neighbourhoods (prad_calculate_gldm_ngtdm_dev): what the two feature classes
+        # of a derived image share in the product route
+        fn = lambda: engine.gldm_ngtdm(img, msk, levels, 0)
+        fn()
+        best_dev, best_wall = 1e9, 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            best_wall = min(best_wall, (time.perf_counter() - t0) * 1e3)
+            best_dev = min(best_dev, engine.last_device_ms())
+        res["gldm_ngtdm_one_pass"] = dict(frac_of_hbm(ALG_BYTES_PER_VOXEL * n, best_dev), wall_ms=round(best_wall, 4))
+        # THE PRODUCT ROUTE (featureextractor._startFeatures): every class of the image -- the five matrices AND their feature
+        # formulas -- queued by one prad_image_enqueue_dev call on the library's side streams, one wait per image, the next
+        # image queued before the previous one is collected.  Wall ms per image over a run of 8 images.
+        classes = engine.IMG_GLCM | engine.IMG_GLRLM | engine.IMG_GLDM | engine.IMG_NGTDM | engine.IMG_GLSZM
+
+        def enqueued_run(k):
+            pending = None
+            for _ in range(k):
+                tok = engine.image_enqueue(img, msk, None, levels, n, classes)
+                if pending is not None:
+                    assert engine.image_wait(pending)
+                pending = tok
+            assert engine.image_wait(pending)
+        enqueued_run(2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enqueued_run(8)
+        torch.cuda.synchronize()
+        enq = (time.perf_counter() - t0) * 1e3 / 8
+        res["enqueued_ms"] = round(enq, 4)
+        res["enqueued"] = dict(frac_of_hbm(ALG_BYTES_PER_VOXEL * n, enq),
+                               what="all five matrices + their feature formulas of one image, one library call, wall per image")
         out[dist] = res
     return out
+
+
+def mode_fallback(device, engine, size=256):
+    """the exact generic kernels the fast paths fall back to (kernels_generic.h, the int32 GLSZM path, the wrapped-lines
+    sweeps): distances [1, 2], 300 grey levels.  Parity of these paths is tested (tests/test_gpu_parity.py, test_gpu_fuzz.py);
+    this line gives them a number."""
+    g = torch.Generator(device=device)
+    g.manual_seed(11)
+    shape = (size, size, size)
+    img = torch.randint(1, 301, shape, generator=g, device=device, dtype=torch.int32)
+    msk = torch.ones(shape, dtype=torch.uint8, device=device)
+    n = img.numel()
+    jobs = {"glcm_d12_Ng300": lambda: engine.glcm(img, msk, 300, (1, 2)),
+            "glcm_glrlm_Ng300": lambda: engine.glcm_glrlm(img, msk, 300, size),
+            "gldm_d12_Ng300": lambda: engine.gldm(img, msk, 300, 0, (1, 2)),
+            "ngtdm_d12_Ng300": lambda: engine.ngtdm(img, msk, 300, (1, 2)),
+            "glszm_Ng300": lambda: engine.glszm_compact(img, msk, 300, n)}
+    res = {"case": "%d^3 int32 volume, 300 iid grey levels, full mask, distances [1, 2] where the class takes distances; "
+                   "device ms of the synchronous call" % size}
+    for name, fn in jobs.items():
+        try:
+            fn()
+            best_dev, best_wall = 1e9, 1e9
+            for _ in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                best_wall = min(best_wall, (time.perf_counter() - t0) * 1e3)
+                best_dev = min(best_dev, engine.last_device_ms())
+            res[name] = dict(frac_of_hbm(ALG_BYTES_PER_VOXEL * n, best_dev), wall_ms=round(best_wall, 4), path=engine.last_path())
+        except Exception as e:                  # noqa: BLE001
+            res[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return res
 
 
 def mode_config3(device, engine, size=256):
@@ -296,8 +365,31 @@ def mode_config3(device, engine, size=256):
         t["glcm_glrlm_x13"] = tm
         return t
 
+    def run_product():
+        """the route featureextractor.execute takes: filters, then per derived image binCount + ONE enqueue call for GLCM and
+        GLRLM (matrices and feature formulas), the next image queued before the previous one is collected; one clock around
+        everything"""
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        derived = engine.wavelet_images(img)
+        sig = (1.0, 2.0, 3.0, 4.0, 5.0)
+        for s, d in zip(sig, engine.log_images(img, (1.0, 1.0, 1.0), sig)):
+            derived["log-sigma-%g" % s] = d
+        pending = None
+        for name, d in derived.items():
+            levels, Ng, _, _ = engine.bin_image(d, msk, with_counts=True, binCount=32)
+            tok = engine.image_enqueue(levels, msk, None, Ng, n, engine.IMG_GLCM | engine.IMG_GLRLM)
+            if pending is not None:
+                assert engine.image_wait(pending)
+            pending = tok
+        assert engine.image_wait(pending)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3
+
     run()
     t = run()
+    run_product()
+    product_ms = min(run_product() for _ in range(2))
     # algorithmic bytes: wavelet 8 B in + 8 x 8 B out per voxel (float64); LoG 4 B in + 4 B out per sigma (float32); binning
     # per image: min/max pass (dtype + 1) + digitize pass (dtype + 1 in, 4 out); matrices 5 B per voxel and image
     bin_bytes = 8 * (2 * 9 + 4) + 5 * (2 * 5 + 4)
@@ -307,7 +399,12 @@ def mode_config3(device, engine, size=256):
     total = sum(t.values())
     return {"case": "%d^3 int16 volume -> 8 wavelet sub-bands + 5 LoG images -> binCount 32 -> GLCM+GLRLM, wall ms per "
                     "stage (one synchronisation per stage / image)" % size,
-            "stages": stages, "total_ms": round(total, 3), "Mvoxels_s_derived": round(13 * n / (total * 1e-3) / 1e6, 1)}
+            "stages": stages, "staged_total_ms": round(total, 3),
+            "total_ms": round(product_ms, 3),
+            "total_is": "the product route: filters, binCount, one enqueue call per derived image (GLCM + GLRLM matrices and "
+                        "formulas), look-ahead of one image, one clock around the whole case; staged_total_ms = the sum of "
+                        "the per-stage figures above (one synchronisation per stage / image)",
+            "Mvoxels_s_derived": round(13 * n / (product_ms * 1e-3) / 1e6, 1)}
 
 
 def mode_batch(device, rank: int, cases: int, fence):
@@ -512,6 +609,7 @@ def main() -> None:
             guarded("smooth", smooth)
             guarded("config2", lambda: mode_config2(device, engine))
             guarded("config3", lambda: mode_config3(device, engine))
+            guarded("fallback", lambda: mode_fallback(device, engine))
 
         def batch_mode():
             nc, dt_b, nfeat = mode_batch(device, rank, 36, fence)
