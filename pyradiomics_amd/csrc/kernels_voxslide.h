@@ -1,0 +1,304 @@
+// kernels_voxslide.h -- voxel-based GLCM feature MAPS with a sliding window (round 4).
+//
+// kernels_voxel.h builds every kernel window from scratch: one wave per centre, three passes over the window's pairs per
+// angle.  Neighbouring centres of a row share all but one plane of their windows: moving the centre by one voxel along x
+// retires the pairs that touch the plane leaving the window and adds the pairs that touch the plane entering it -- 482
+// updates instead of 3 x 1036 pair visits for a 5^3 window and 13 angles (34 instead of 3 x 72 for the 5 x 5 window of
+// exampleVoxel.yaml).  The reference has no analogue: it materialises P[Nvox][Ng][Ng][Na] and evaluates the formulas with
+// numpy (glcm.py:145-205, base.py:200-245); the values produced here are the same features of the same matrices.
+//
+// Work decomposition: a LANE owns ONE ANGLE of one row of centres and keeps that angle's co-occurrence counts in a private
+// LDS table for the whole run of centres: symmetric counts m(lo, hi) of the unordered level pair, one byte each (a window
+// of radius <= 2 holds at most 100 pairs per angle), Ng (Ng + 1) / 2 <= 528 bytes.  Nothing is shared between lanes, so the
+// per-angle sums need no wave reduction: each lane carries
+//     S   = sum over matrix entries of n log2 n   (n = 2 m on the diagonal, m elsewhere and there twice), as a 2^-40
+//           fixed-point integer built from table DIFFERENCES g(c) = f(c + 1) - f(c): the sum telescopes, so S is exactly
+//           the sum of the rounded f over the current counts whatever the history of the window -- no drift along a run,
+//           results independent of where a run starts
+//     nnz = non-zero entries, E2 = sum of n^2, P = pairs, IJ = sum of (i + j) over the pairs
+// and JointEntropy = log2 T - S / T - nnz eps / ln 2 (the first-order expansion of -sum p log2(p + eps), p = n / T,
+// T = 2 P; the neglected term is < 1e-28), JointEnergy = E2 / T^2, JointAverage = IJ / T follow per angle; the mean over
+// the non-empty angles of a centre (np.nanmean, glcm.py:260-887) is a sum over the 16 (3-D, 13 angles) or 4 (2-D window,
+// 4 angles) lanes of a group.  A wave holds 4 (16) groups = 4 (16) neighbouring rows.
+// The levels a group needs -- its row's planes of (2R+1)^2 (2R+1) voxels per x -- are staged once per run into LDS, a
+// plane per 32 (8) bytes; a run starts 2R+1 planes early with an empty table (planes only enter).
+//
+// Covered: 3 image dimensions, symmetrical GLCM, distance 1, kernelRadius 1 or 2, Ng <= 32, full 3-D windows or force2D
+// along the first (slice) axis, the features above.  Everything else stays on kernels_voxel.h (also the checker of this
+// file: tests/test_gpu_features.py).
+#pragma once
+#include "prad_runtime.h"
+#include "kernels_voxel.h"
+
+namespace prad {
+
+#define PRAD_VS_TB 544            // bytes of a lane's count table (528 used at Ng = 32; dword-aligned)
+#define PRAD_VS_FIX 40            // fixed-point fraction bits of S
+#define PRAD_VS_LUT 256
+
+struct VoxSlideLut {             // built once on the host (prad_api.hip), lives in global memory, copied to LDS per workgroup
+  long long g_off[PRAD_VS_LUT];  // 2 (f(c+1) - f(c)),  f(c) = round(c log2 c * 2^40): an off-diagonal pair fills two entries
+  long long g_dia[PRAD_VS_LUT];  // f(2c+2) - f(2c): a diagonal pair adds 2 to its entry
+  double lg2T[PRAD_VS_LUT];      // log2(2 P) for P pairs
+};
+
+// sum over the lanes of a group of GS (4 or 16) neighbouring lanes, result in every lane of the group
+template <int GS>
+__device__ __forceinline__ int group_sum_i32(int v) {
+  v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);      // quad_perm [2,3,0,1]
+  if (GS == 16) {
+    v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);   // row_half_mirror
+    v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true);   // row_mirror
+  }
+  return v;
+}
+template <int GS>
+__device__ __forceinline__ double group_sum_f64(double v) {
+  auto sh = [](double x, const int ctrl) __attribute__((always_inline)) {
+    const long long b = __double_as_longlong(x);
+    int lo = (int)b, hi = (int)(b >> 32);
+    lo = ctrl == 0 ? __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xf, 0xf, true)
+       : ctrl == 1 ? __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xf, 0xf, true)
+       : ctrl == 2 ? __builtin_amdgcn_mov_dpp(lo, 0x141, 0xf, 0xf, true)
+                   : __builtin_amdgcn_mov_dpp(lo, 0x140, 0xf, 0xf, true);
+    hi = ctrl == 0 ? __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xf, 0xf, true)
+       : ctrl == 1 ? __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xf, 0xf, true)
+       : ctrl == 2 ? __builtin_amdgcn_mov_dpp(hi, 0x141, 0xf, 0xf, true)
+                   : __builtin_amdgcn_mov_dpp(hi, 0x140, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+  };
+  v += sh(v, 0);
+  v += sh(v, 1);
+  if (GS == 16) {
+    v += sh(v, 2);
+    v += sh(v, 3);
+  }
+  return v;
+}
+
+// R: kernel radius (1, 2); TWO_D: the window has no extent along z (force2D on the slice axis, or a single slice)
+// RUN: centres per run.  Grid: x = runs along x, y = groups of rows, z = slices; a workgroup = 4 (2-D windows: 3) waves =
+// consecutive runs -- what 160 KB of LDS hold: 13 x 4 (64) tables of 544 B and 4 (16) rows of staged planes per wave.
+// maps: [nmaps][Nz][Ny][Nx] float64 (slot < 0: feature not requested); empty: [Nz][Ny][Nx] angle bits without a pair.
+template <int R, bool TWO_D, int RUN>
+constexpr size_t voxel_glcm_slide_lds() {
+  return 3 * PRAD_VS_LUT * 8 + (size_t)(TWO_D ? 3 : 4) * ((TWO_D ? 64 : 13 * (64 / 16)) * PRAD_VS_TB + (64 / (TWO_D ? 4 : 16)) * (RUN + 2 * R) * (TWO_D ? 8 : 32));
+}
+template <int R, bool TWO_D, int RUN>
+__global__ void __launch_bounds__(TWO_D ? 192 : 256) voxel_glcm_slide_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx, VoxAngles A,
+                                                              int Ng, const VoxSlideLut *__restrict__ lut_g, int slot_ent,
+                                                              int slot_en, int slot_ja, double *__restrict__ maps,
+                                                              unsigned *__restrict__ empty, const int *__restrict__ flags, int z_begin) {
+  constexpr int D = 2 * R + 1;
+  constexpr int PZ = TWO_D ? 1 : D;            // plane extent along z
+  constexpr int NP = PZ * D;                   // voxels of a plane
+  constexpr int PB = TWO_D ? 8 : 32;           // bytes of a staged plane
+  constexpr int GS = TWO_D ? 4 : 16;           // lanes per group (>= angles)
+  constexpr int NGR = 64 / GS;                 // groups (rows) per wave
+  constexpr int XL = RUN + 2 * R;              // planes a run needs
+  constexpr int WAVES = TWO_D ? 3 : 4;         // waves per workgroup
+  constexpr int NT = TWO_D ? 64 : 13 * NGR;    // count tables per wave (3-D: the 13 angle lanes of each group)
+  static_assert(NP <= PB, "plane does not fit its slot");
+  extern __shared__ __align__(16) unsigned char vs_smem[];
+  if (flags[0]) return;                        // a level outside [1, Ng]: the caller reruns on the matrix path
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // workgroup LDS: the LUTs, then per wave: tables [64][TB], planes [NGR][XL][PB]
+  long long *g_off = reinterpret_cast<long long *>(vs_smem);
+  long long *g_dia = g_off + PRAD_VS_LUT;
+  double *lg2T = reinterpret_cast<double *>(g_dia + PRAD_VS_LUT);
+  constexpr int WAVE_BYTES = NT * PRAD_VS_TB + NGR * XL * PB;
+  unsigned char *wbase = vs_smem + 3 * PRAD_VS_LUT * 8 + (size_t)wave * WAVE_BYTES;
+  unsigned char *planes = wbase + NT * PRAD_VS_TB;
+  for (int i = threadIdx.x; i < PRAD_VS_LUT; i += blockDim.x) {
+    g_off[i] = lut_g->g_off[i];
+    g_dia[i] = lut_g->g_dia[i];
+    lg2T[i] = lut_g->lg2T[i];
+  }
+  // this wave's run
+  const int nruns = (Nx + RUN - 1) / RUN;
+  const int run = blockIdx.x * WAVES + wave;
+  const int y0 = blockIdx.y * NGR, z = blockIdx.z + z_begin;
+  const bool live = run < nruns;               // (all waves reach the barrier below)
+  const int x0 = run * RUN;
+  const int grp = lane / GS, a = lane % GS;
+  const int y = y0 + grp;
+  const bool has_angle = a < A.na && a < (TWO_D ? 4 : 13);
+  unsigned char *tbl = wbase + (TWO_D ? lane : grp * 13 + min(a, 12)) * PRAD_VS_TB;
+  const int dz = has_angle ? A.o[a][0] : 0, dy = has_angle ? A.o[a][1] : 0, dx = has_angle ? A.o[a][2] : 0;
+  if (live) {
+    // clear the tables (wave-private: 64 x TB bytes)
+    for (int i = lane; i < NT * PRAD_VS_TB / 16; i += 64) reinterpret_cast<uint4 *>(wbase)[i] = make_uint4(0, 0, 0, 0);
+    // stage the planes: slab x index k <-> global x0 - R + k; plane byte p = pz * D + py <-> (z - R + pz (TWO_D: z), y - R + py)
+    for (int e = lane; e < NGR * XL * NP; e += 64) {
+      const int p = e % NP, r = e / NP, k = r % XL, g = r / XL;
+      const int pz = p / D, py = p % D;
+      const int gz = TWO_D ? z : z - R + pz, gy = y0 + g - R + py, gx = x0 - R + k;
+      unsigned char v = 0;
+      if ((unsigned)gz < (unsigned)Nz && (unsigned)gy < (unsigned)Ny && (unsigned)gx < (unsigned)Nx)
+        v = L[((long long)gz * Ny + gy) * Nx + gx];
+      planes[(g * XL + k) * PB + p] = v;
+    }
+  }
+  __syncthreads();
+  if (!live) return;
+  const unsigned char *gp = planes + grp * XL * PB;     // this group's planes
+  // the plane positions this lane's angle pairs up: p = (pz, py) with q = (pz + dz, py + dy) inside the plane
+  const int pz_lo = max(0, -dz), pz_hi = min(PZ, PZ - dz), py_lo = max(0, -dy), py_hi = min(D, D - dy);
+  const int qoff = dz * D + dy;                          // byte offset of q relative to p inside a plane
+  long long S = 0;
+  int nnz = 0, E2 = 0, P = 0, IJ = 0;
+  // The pairs between plane kp (the p side) and plane kq (the q side) enter (SIGN = +1) or leave (-1) this lane's table.
+  // Straight-line code in four stages per chunk of positions -- level reads, table atomics, LUT reads, accumulation -- with
+  // predication instead of branches: a pair at a time under its own branch left every LDS round trip exposed (three per
+  // pair, ~14 000 cycles per step of a 5^3 window; profiles/r04_probes.md).
+  unsigned vmask = 0;                                    // positions of the plane this lane's angle pairs up
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    const int pz = p / D, py = p % D;
+    if (has_angle && pz >= pz_lo && pz < pz_hi && py >= py_lo && py < py_hi) vmask |= 1u << p;
+  }
+  unsigned *tbl32 = reinterpret_cast<unsigned *>(tbl);
+  using Plus = std::integral_constant<int, 1>;
+  using Minus = std::integral_constant<int, -1>;
+  auto plane_pairs = [&](int kp, int kq, auto sign_tag, bool on) __attribute__((always_inline)) {
+    constexpr int SIGN = decltype(sign_tag)::value;
+    constexpr int CH = NP > 9 ? 9 : NP;                  // positions in flight
+    const unsigned char *pp = gp + kp * PB, *pq = gp + kq * PB;
+    const unsigned vm = on ? vmask : 0u;
+#pragma unroll
+    for (int c0 = 0; c0 < NP; c0 += CH) {
+      int l1[CH], l2[CH], shf[CH];
+      unsigned old[CH];
+      bool ok[CH], dg[CH];
+      long long g[CH];
+      // 1: levels (an invalid position reads its own p for q: any in-range address)
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        const int p = c0 + k;
+        if (p < NP) {
+          const bool v = (vm >> p) & 1u;
+          l1[k] = pp[p];
+          l2[k] = pq[v ? p + qoff : p];
+          ok[k] = v;
+        }
+      }
+      // 2: table updates (an absent pair adds 0 to word 0)
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        if (c0 + k < NP) {
+          ok[k] = ok[k] && l1[k] != 0 && l2[k] != 0;
+          const int lo = min(l1[k], l2[k]) - 1, hi = max(l1[k], l2[k]) - 1;
+          const int idx = ok[k] ? (hi * (hi + 1) >> 1) + lo : 0;
+          dg[k] = lo == hi;
+          shf[k] = (idx & 3) * 8;
+          const unsigned inc = ok[k] ? (SIGN > 0 ? (1u << shf[k]) : (0u - (1u << shf[k]))) : 0u;
+          old[k] = __hip_atomic_fetch_add(tbl32 + (idx >> 2), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      // 3: g(c), c = the smaller of the counts before / after
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        if (c0 + k < NP) {
+          const int c = ok[k] ? (int)((old[k] >> shf[k]) & 255u) - (SIGN > 0 ? 0 : 1) : 0;
+          shf[k] = c;                                      // (reuse: the count)
+          g[k] = (dg[k] ? g_dia : g_off)[c];
+        }
+      }
+      // 4: the lane's sums
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        if (c0 + k < NP) {
+          const int c = shf[k];
+          const long long gg = ok[k] ? g[k] : 0;
+          const int e2 = ok[k] ? (dg[k] ? 4 : 2) * (2 * c + 1) : 0;
+          const int nz = ok[k] && c == 0 ? (dg[k] ? 1 : 2) : 0;
+          const int one = ok[k] ? 1 : 0, ij = ok[k] ? l1[k] + l2[k] : 0;
+          if (SIGN > 0) { S += gg; E2 += e2; nnz += nz; P += one; IJ += ij; }
+          else { S -= gg; E2 -= e2; nnz -= nz; P -= one; IJ -= ij; }
+        }
+      }
+    }
+  };
+  const double eps_ln2 = 2.220446049250313e-16 / 0.6931471805599453;
+  const double fix = 1.0 / (double)(1LL << PRAD_VS_FIX);
+  const double nan = __longlong_as_double(0x7ff8000000000000LL);
+  for (int s = 0; s < XL; s++) {
+    {
+      // plane s enters: pairs inside it (dx = 0) or with plane s - 1 (p side for dx > 0, q side for dx < 0)
+      const int sm = max(s - 1, 0);
+      plane_pairs(dx > 0 ? sm : s, dx < 0 ? sm : s, Plus{}, dx == 0 || s >= 1);
+      // plane s - D leaves: pairs inside it or with plane s - D + 1
+      if (s >= D) {                                        // (wave-uniform)
+        const int o = s - D;
+        plane_pairs(dx < 0 ? o + 1 : o, dx > 0 ? o + 1 : o, Minus{}, true);
+      }
+    }
+    if (s < 2 * R) continue;
+    // centre: slab x index s - R
+    const int gx = x0 + s - 2 * R;
+    const bool nonempty = has_angle && P > 0;
+    const int pc = nonempty ? P : 1;
+    const double T = (double)(2 * pc), iT = 1.0 / T;
+    double h = 0, en = 0, ja = 0;
+    if (nonempty) {
+      if (slot_ent >= 0) h = lg2T[pc] - ((double)S * fix) * iT - (double)nnz * eps_ln2;
+      if (slot_en >= 0) en = (double)E2 * iT * iT;
+      if (slot_ja >= 0) ja = (double)IJ * iT;
+    }
+    const int na = group_sum_i32<GS>(nonempty ? 1 : 0);
+    const int em = group_sum_i32<GS>(has_angle && !nonempty ? (1 << a) : 0);
+    const double inv = na ? 1.0 / (double)na : nan;
+    if (slot_ent >= 0) h = group_sum_f64<GS>(h) * inv;
+    if (slot_en >= 0) en = group_sum_f64<GS>(en) * inv;
+    if (slot_ja >= 0) ja = group_sum_f64<GS>(ja) * inv;
+    if (a == 0 && y < Ny && gx < Nx) {
+      const long long vi = ((long long)z * Ny + y) * Nx + gx, n = (long long)Nz * Ny * Nx;
+      if (slot_ent >= 0) maps[(long long)slot_ent * n + vi] = h;
+      if (slot_en >= 0) maps[(long long)slot_en * n + vi] = en;
+      if (slot_ja >= 0) maps[(long long)slot_ja * n + vi] = ja;
+      empty[vi] = (unsigned)em;
+    }
+  }
+}
+
+// smallest and largest slice index of the requested centres (the map is only built for those slices): zr[0] = min, zr[1] = max
+__global__ void __launch_bounds__(256) voxel_zrange_kernel(const int *__restrict__ voxels, int nvox, int *__restrict__ zr) {
+  int lo = 0x7fffffff, hi = -1;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += gridDim.x * blockDim.x) {
+    const int z = voxels[v];
+    lo = min(lo, z);
+    hi = max(hi, z);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    lo = min(lo, __shfl_xor(lo, o));
+    hi = max(hi, __shfl_xor(hi, o));
+  }
+  if ((threadIdx.x & 63) == 0 && hi >= 0) {
+    atomicMin(&zr[0], lo);
+    atomicMax(&zr[1], hi);
+  }
+}
+
+// out[f][v] = maps[f][voxel v]; empty_mask[v]; any_nonempty |= the angle bits that hold a pair somewhere
+__global__ void __launch_bounds__(256) voxel_map_gather_kernel(const double *__restrict__ maps, const unsigned *__restrict__ empty,
+                                                              int Nz, int Ny, int Nx, int nfeat, int nvox,
+                                                              const int *__restrict__ voxels, unsigned allbits,
+                                                              double *__restrict__ out, unsigned *__restrict__ empty_mask,
+                                                              unsigned *__restrict__ any_nonempty) {
+  const long long n = (long long)Nz * Ny * Nx;
+  unsigned seen = 0;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += gridDim.x * blockDim.x) {
+    const long long vi = ((long long)voxels[v] * Ny + voxels[(long long)nvox + v]) * Nx + voxels[2LL * nvox + v];
+    for (int f = 0; f < nfeat; f++) out[(long long)f * nvox + v] = maps[(long long)f * n + vi];
+    const unsigned em = empty[vi];
+    empty_mask[v] = em;
+    seen |= ~em & allbits;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) seen |= __shfl_xor(seen, o);
+  if ((threadIdx.x & 63) == 0 && seen) atomicOr(any_nonempty, seen);
+}
+
+}  // namespace prad

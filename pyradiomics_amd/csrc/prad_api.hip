@@ -16,6 +16,7 @@
 #include "kernels_neigh.h"
 #include "kernels_glszm.h"
 #include "kernels_voxel.h"
+#include "kernels_voxslide.h"
 #include "kernels_mcc.h"
 #include "kernels_voxtex.h"
 #include "kernels_binning.h"
@@ -1367,6 +1368,7 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
   PRAD_HIP(hipMemsetAsync(an, 0, sizeof(unsigned), s));
   uint8_t *levels = nullptr;
   PRAD_TRY(neigh_pack(&c, s, g, image, mask, Ng, flags, &levels));
+  bool slide_taken = false;
   {
     Timed t(c, "voxel", s);
     const size_t lds = sizeof(u32) * PRAD_VOX_WAVES * ((size_t)Ng * Ng + 5 * (size_t)Ng + 1);
@@ -1375,7 +1377,86 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
     long long wmax = 1;                       // largest window of the call
     for (int d = 0; d < 3; d++)
       if (d != f2d3 && d >= 3 - Nd) wmax *= std::min(2 * kernelRadius + 1, dims[d]);
-    if ((fmask & ~PRAD_VF_LIGHT) == 0 && wmax <= 64 && !getenv("PRAD_VOX_NO_LIGHT")) {
+    // Sliding-window maps (kernels_voxslide.h): a dense map of the whole volume, the requested centres gathered from it.
+    // Taken when the request is what that kernel covers and the centres are dense enough to pay for a whole-volume map.
+    const unsigned slide_feats = (1u << VF_JointEntropy) | (1u << VF_JointEnergy) | (1u << VF_JointAverage);
+    const bool std13 = Nd == 3 && Na == 13 && f2d3 < 0 && dims[0] > 1 && dims[1] > 1 && dims[2] > 1;
+    const bool std4 = Nd == 3 && Na == 4 && (f2d3 == 0 || dims[0] == 1) && dims[1] > 1 && dims[2] > 1;
+    bool slide = (std13 || std4) && symmetric && Ng <= 32 && (kernelRadius == 1 || kernelRadius == 2) &&
+                 (fmask & ~slide_feats) == 0 && (long long)Nvox * 64 >= g.n && !getenv("PRAD_VOX_NO_SLIDE");
+    if (slide) {
+      // the kernel's lanes assume the reference's angle order: dx in {-1, 0, 1}, and for the 2-D window no z component
+      for (int a = 0; a < Na && slide; a++)
+        slide = std::abs(A.o[a][0]) <= 1 && std::abs(A.o[a][1]) <= 1 && std::abs(A.o[a][2]) <= 1 && (std13 || A.o[a][0] == 0);
+    }
+    int z_begin = 0, z_end = -1;
+    if (slide) {
+      // the slices the centres lie in (one rank of a sharded map owns a z-slab of them: batch.voxel_maps_sharded)
+      int *zr_d = nullptr;
+      void *zr_h = nullptr;
+      PRAD_TRY(c.get<int>("voxslide_zr", 2, &zr_d));
+      PRAD_TRY(c.get_pinned("voxslide_zr_h", sizeof(int) * 2, &zr_h));
+      ((int *)zr_h)[0] = 0x7fffffff;
+      ((int *)zr_h)[1] = -1;
+      PRAD_HIP(hipMemcpyAsync(zr_d, zr_h, sizeof(int) * 2, hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(voxel_zrange_kernel, dim3((unsigned)std::min<long long>(((long long)Nvox + 255) / 256, 1024)), dim3(256), 0, s,
+                         voxels, Nvox, zr_d);
+      PRAD_TRY(check_launch("voxel_zrange_kernel"));
+      PRAD_HIP(hipMemcpyAsync(zr_h, zr_d, sizeof(int) * 2, hipMemcpyDeviceToHost, s));
+      PRAD_HIP(hipStreamSynchronize(s));
+      z_begin = std::max(0, ((int *)zr_h)[0]);
+      z_end = std::min(dims[0] - 1, ((int *)zr_h)[1]);
+      // dense enough inside its slab to pay for a map of the slab?
+      if (z_end < z_begin || (long long)Nvox * 8 < (long long)(z_end - z_begin + 1) * dims[1] * dims[2]) slide = false;
+    }
+    if (slide) {
+      slide_taken = true;
+      static const VoxSlideLut lut_h = [] {
+        VoxSlideLut t;
+        auto f = [](int cnt) -> long long {
+          if (cnt <= 1) return 0;
+          return (long long)std::llround((double)cnt * std::log2((double)cnt) * (double)(1LL << PRAD_VS_FIX));
+        };
+        for (int k = 0; k < PRAD_VS_LUT; k++) {
+          t.g_off[k] = 2 * (f(k + 1) - f(k));
+          t.g_dia[k] = f(2 * k + 2) - f(2 * k);
+          t.lg2T[k] = k ? std::log2(2.0 * k) : 0.0;
+        }
+        return t;
+      }();
+      VoxSlideLut *lut_dev = nullptr;
+      PRAD_TRY(c.get<VoxSlideLut>("voxslide_lut", 1, &lut_dev));
+      PRAD_HIP(hipMemcpyAsync(lut_dev, &lut_h, sizeof(lut_h), hipMemcpyHostToDevice, s));
+      double *maps = nullptr;
+      unsigned *emap = nullptr;
+      PRAD_TRY(c.get<double>("voxslide_maps", (size_t)nfeat * g.n, &maps));
+      PRAD_TRY(c.get<unsigned>("voxslide_empty", (size_t)g.n, &emap));
+      const int s_ent = (fmask >> VF_JointEntropy) & 1 ? slot[VF_JointEntropy] : -1;
+      const int s_en = (fmask >> VF_JointEnergy) & 1 ? slot[VF_JointEnergy] : -1;
+      const int s_ja = (fmask >> VF_JointAverage) & 1 ? slot[VF_JointAverage] : -1;
+#define PRAD_SLIDE(RR, TWOD, RUNL)                                                                                          \
+  do {                                                                                                                      \
+    constexpr size_t lds_s = voxel_glcm_slide_lds<RR, TWOD, RUNL>();                                                        \
+    static_assert(lds_s <= 160 * 1024, "LDS");                                                                              \
+    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_slide_kernel<RR, TWOD, RUNL>),                  \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                                  \
+    const int wv = TWOD ? 3 : 4, rows = TWOD ? 16 : 4;                                                                      \
+    const int nruns = (dims[2] + RUNL - 1) / RUNL;                                                                          \
+    hipLaunchKernelGGL((voxel_glcm_slide_kernel<RR, TWOD, RUNL>), dim3((nruns + wv - 1) / wv, (dims[1] + rows - 1) / rows, z_end - z_begin + 1), \
+                       dim3(64 * wv), lds_s, s, levels, dims[0], dims[1], dims[2], A, Ng, lut_dev, s_ent, s_en, s_ja, maps, emap, flags, z_begin); \
+  } while (0)
+      if (std13 && kernelRadius == 2) PRAD_SLIDE(2, false, 64);
+      else if (std13) PRAD_SLIDE(1, false, 64);
+      else if (kernelRadius == 2) PRAD_SLIDE(2, true, 64);
+      else PRAD_SLIDE(1, true, 64);
+#undef PRAD_SLIDE
+      PRAD_TRY(check_launch("voxel_glcm_slide_kernel"));
+      const unsigned allbits = (1u << Na) - 1u;
+      const unsigned gb = (unsigned)std::min<long long>(((long long)Nvox + 255) / 256, (long long)cu_count() * 16);
+      hipLaunchKernelGGL(voxel_map_gather_kernel, dim3(gb), dim3(256), 0, s, maps, emap, dims[0], dims[1], dims[2], nfeat, Nvox,
+                         voxels, allbits, out, em, an);
+      PRAD_TRY(check_launch("voxel_map_gather_kernel"));
+    } else if ((fmask & ~PRAD_VF_LIGHT) == 0 && wmax <= 64 && !getenv("PRAD_VOX_NO_LIGHT")) {
       const size_t lds2 = sizeof(double) * 2 * 257 + sizeof(u32) * PRAD_VOX_WAVES * (size_t)Ng * Ng;
       PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_light_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
@@ -1401,6 +1482,7 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
   PRAD_HIP(hipStreamSynchronize(s));
   if (((int *)fh)[0]) return fail(PRAD_E_UNSUPPORTED, "voxel_glcm: masked levels outside [1, Ng]; use the matrix path");
   c.last_path = "voxel-fused";
+  c.last_variant = slide_taken ? "slide" : "window";
   return PRAD_OK;
 }
 

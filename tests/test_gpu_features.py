@@ -336,6 +336,7 @@ def test_light_voxel_glcm_kernel_equals_the_general_one(force2D, radius, symmetr
     with holes (empty angles, partial windows at the border)"""
     import torch
     from pyradiomics_amd import engine
+    monkeypatch.setenv("PRAD_VOX_NO_SLIDE", "1")     # (this test is about the two from-scratch window kernels)
     rng = np.random.default_rng(11)
     shape = (18, 40, 44)
     img = rng.integers(1, 17, shape).astype(np.int32)
@@ -591,3 +592,67 @@ def test_case_pipeline_is_deterministic_under_repetition_and_threads():
                 x = np.asarray(a[k], dtype=float)
                 assert np.array_equal(x, np.asarray(b[k], dtype=float), equal_nan=True), k
                 assert np.array_equal(x, np.asarray(c[k], dtype=float), equal_nan=True), k
+
+
+# ---- round 4: sliding-window voxel maps (kernels_voxslide.h) against the from-scratch window kernel --------------------
+def _slide_vs_window(img, msk, Ng, vox, feats, **kw):
+    import os
+    import torch
+    from pyradiomics_amd import engine
+    dev = torch.device("cuda", 0)
+    args = (torch.from_numpy(img).to(dev), torch.from_numpy(msk).to(dev), Ng, torch.from_numpy(vox).to(dev), feats)
+    new = {k: v.cpu().numpy() for k, v in engine.voxel_glcm_features(*args, **kw).items()}
+    variant = engine.last_variant()
+    os.environ["PRAD_VOX_NO_SLIDE"] = "1"
+    try:
+        old = {k: v.cpu().numpy() for k, v in engine.voxel_glcm_features(*args, **kw).items()}
+        assert engine.last_variant() == "window"
+    finally:
+        del os.environ["PRAD_VOX_NO_SLIDE"]
+    return new, old, variant
+
+
+@pytest.mark.parametrize("shape", [(9, 37, 70), (5, 16, 130), (1, 40, 66), (23, 5, 9)])
+@pytest.mark.parametrize("radius,force2D", [(2, False), (1, False), (2, True), (1, True)])
+@pytest.mark.parametrize("Ng", [32, 7])
+def test_sliding_window_maps_equal_the_window_kernel(shape, radius, force2D, Ng):
+    """every centre of the volume, partial mask (holes, empty border rows): JointEntropy / JointEnergy / JointAverage from
+    the incrementally updated tables == the from-scratch kernel, NaN patterns included (centres without any pair, the
+    plain-mean NaN rule of JointAverage)"""
+    rng = np.random.default_rng(hash((shape, radius, force2D, Ng)) % (2 ** 32))
+    img = rng.integers(1, Ng + 1, size=shape).astype(np.int32)
+    img[:, : shape[1] // 2] = (img[:, : shape[1] // 2] + 3) // 4 + 1          # a smoother half: repeated pairs, larger counts
+    msk = rng.random(shape) < 0.85
+    msk[:, -3:, :] = False                                                    # centres whose window is nearly empty
+    hole = msk[:, :, shape[2] // 2: shape[2] // 2 + 7]
+    hole &= rng.random(hole.shape) < 0.1
+    vox = np.array(np.nonzero(np.ones(shape, bool))).astype(np.int32)        # every voxel a centre, ROI or not
+    feats = ["JointEntropy", "JointEnergy", "JointAverage"]
+    new, old, variant = _slide_vs_window(img, msk, Ng, vox, feats, kernelRadius=radius, force2D=force2D, force2Ddimension=0)
+    assert variant == "slide"
+    for f in feats:
+        a, b = new[f], old[f]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f
+        ok = ~np.isnan(a)
+        assert ok.sum() > 0
+        np.testing.assert_allclose(a[ok], b[ok], rtol=1e-12 if f != "JointEntropy" else 1e-11, atol=1e-13, err_msg=f)
+
+
+def test_sliding_window_maps_are_only_taken_where_they_apply():
+    rng = np.random.default_rng(3)
+    shape = (8, 20, 40)
+    img = rng.integers(1, 9, size=shape).astype(np.int32)
+    msk = np.ones(shape, bool)
+    vox = np.array(np.nonzero(msk)).astype(np.int32)
+    for feats, kw, want in ((["JointEntropy"], dict(kernelRadius=2), "slide"),
+                            (["JointEntropy", "Contrast"], dict(kernelRadius=2), "window"),        # a feature it does not carry
+                            (["JointEntropy"], dict(kernelRadius=3), "window"),                    # counts beyond a byte
+                            (["JointEntropy"], dict(kernelRadius=2, symmetrical=False), "window"),
+                            (["JointEntropy"], dict(kernelRadius=2, force2D=True, force2Ddimension=1), "window")):
+        new, old, variant = _slide_vs_window(img, msk, 8, vox, feats, **kw)
+        assert variant == want, (feats, kw, variant)
+        for f in feats:
+            np.testing.assert_allclose(new[f], old[f], rtol=1e-11, atol=1e-13, equal_nan=True)
+    few = vox[:, ::50]                                                               # sparse centres: not worth a whole map
+    _, _, variant = _slide_vs_window(img, msk, 8, np.ascontiguousarray(few), ["JointEntropy"], kernelRadius=2)
+    assert variant == "window"
