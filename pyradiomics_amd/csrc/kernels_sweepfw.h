@@ -315,16 +315,35 @@ struct PackWave {
       const int lv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
       const u32 mw[4] = {m.x, m.y, m.z, m.w};
       u32 ow[4];
+      // Four voxels at a time with packed-byte arithmetic (the per-voxel form cost ~12 VALU per voxel on a kernel that is
+      // bound by its instruction issue, profiles/r03_probes.md section 3): low bytes of the four levels gathered by three
+      // v_perm, mask bytes widened to 0xff, "level > Ng" and "level 0 under the mask" as any-byte tests.  Whatever is not the
+      // plain case -- a level with bits beyond its low byte, an irregular level under the mask -- takes the exact per-voxel
+      // form below (a rare, divergent branch): the results are the same in every case.
+      const u32 ngadd = (0x7fu - (u32)J.Ng) * 0x01010101u;        // (Ng <= 44 on this path)
 #pragma unroll
       for (int w = 0; w < 4; w++) {
-        u32 o = 0;
+        const u32 l0 = (u32)lv[w * 4], l1 = (u32)lv[w * 4 + 1], l2 = (u32)lv[w * 4 + 2], l3 = (u32)lv[w * 4 + 3];
+        const u32 wide = (l0 | l1 | l2 | l3) & 0xffffff00u;
+        const u32 p01 = __builtin_amdgcn_perm(l1, l0, 0x0c0c0400u), p23 = __builtin_amdgcn_perm(l3, l2, 0x0c0c0400u);
+        const u32 pk = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+        const u32 nz = (((mw[w] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | mw[w]) & 0x80808080u;   // bit 7 of every non-zero mask byte
+        const u32 m8 = (nz >> 7) * 0xffu;
+        const u32 lvm = pk & m8;                                                         // levels under the mask, 0 elsewhere
+        const u32 gt = (((lvm & 0x7f7f7f7fu) + ngadd) | lvm) & 0x80808080u;              // a byte > Ng
+        const u32 t = pk | ~m8;
+        const u32 zero_in = (t - 0x01010101u) & ~t & 0x80808080u;                        // != 0 iff a masked voxel has level 0
+        u32 o = lvm << PRAD_FUSED_SHIFT;
+        if (wide | gt | zero_in) {
+          o = 0;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-          const bool in = (mw[w] >> (8 * b)) & 0xffu;
-          const int l = lv[w * 4 + b];
-          const bool regular = in && l >= 1 && l <= J.Ng;
-          bad |= in && !regular;
-          o |= (regular ? ((u32)l << PRAD_FUSED_SHIFT) : 0u) << (8 * b);   // (an irregular level packs as 0: never a table index)
+          for (int b = 0; b < 4; b++) {
+            const bool in = (mw[w] >> (8 * b)) & 0xffu;
+            const int l = lv[w * 4 + b];
+            const bool regular = in && l >= 1 && l <= J.Ng;
+            bad |= in && !regular;
+            o |= (regular ? ((u32)l << PRAD_FUSED_SHIFT) : 0u) << (8 * b);   // (an irregular level packs as 0: never a table index)
+          }
         }
         ow[w] = o;
       }

@@ -295,6 +295,53 @@ def test_pipeline_packs_inside_the_previous_walk_and_flushes(cm, checker):
         engine.set_deferred_mode(-1)
 
 
+@pytest.mark.parametrize("odd", [0, 33, 300, -1, 70000])
+def test_side_job_pack_handles_odd_level_words(cm, checker, odd):
+    """the pack that rides in the previous volume's walk converts four voxels at a time with packed-byte arithmetic; whatever
+    is not the plain case takes the exact per-voxel form: levels with bits beyond the low byte OUTSIDE the mask (ignored,
+    like the reference: cmatrices.c:61-64 tests the mask first), and an irregular level UNDER the mask (the call reports
+    it, the synchronous route raises the reference's IndexError)"""
+    import torch
+    from pyradiomics_amd import engine, _lib
+    shape, Ng = (24, 30, 512), 32
+    engine.set_deferred_mode(1)
+    try:
+        base = _levels(5, shape, Ng, "uniform")
+        mask = _mask(6, shape, "random")
+        junk = base.copy()
+        rng = np.random.default_rng(7)
+        out = ~mask.astype(bool)
+        junk[out] = rng.choice(np.array([0, -5, 255, 256, 1 << 20, -(1 << 30), 33, 44], dtype=np.int32), size=int(out.sum()))
+        vols = [(base, mask), (junk, mask), (base, mask)]
+        dev = [(torch.from_numpy(i).cuda(), torch.from_numpy(m.astype(np.uint8)).cuda()) for i, m in vols]
+        got = [engine.glcm_glrlm(i, m, Ng, 512, deferred=True) for i, m in dev]      # volumes 2 and 3 pack as side jobs
+        engine.deferred_status()
+        eg, _ = checker.calculate_glcm(base, mask, [1], Ng, False, 0)
+        er, _ = checker.calculate_glrlm(base, mask, Ng, 512, False, 0)
+        for g, r, _ in got:                                     # junk outside the mask changes nothing
+            assert np.array_equal(g.cpu().numpy(), eg[0]) and np.array_equal(r.cpu().numpy(), er[0])
+        bad = base.copy()
+        zz, yy, xx = np.nonzero(mask)
+        k = len(zz) // 2
+        bad[zz[k], yy[k], xx[k]] = odd                          # one irregular voxel under the mask
+        devbad = torch.from_numpy(bad).cuda()
+        engine.glcm_glrlm(dev[0][0], dev[0][1], Ng, 512, deferred=True)
+        engine.glcm_glrlm(devbad, dev[0][1], Ng, 512, deferred=True)               # packed by the side job
+        engine.glcm_glrlm(dev[0][0], dev[0][1], Ng, 512, deferred=True)
+        with pytest.raises(_lib.DeferredLevelsError):
+            engine.deferred_status()
+        engine.deferred_status()
+        try:
+            want = checker.calculate_glcm(bad, mask, [1], Ng, False, 0)
+        except IndexError:
+            with pytest.raises(IndexError):
+                cm.calculate_glcm(bad, mask, [1], Ng, False, 0)
+        else:                                                   # (the reference aliases some out-of-range levels silently)
+            assert np.array_equal(cm.calculate_glcm(bad, mask, [1], Ng, False, 0)[0], want[0])
+    finally:
+        engine.set_deferred_mode(-1)
+
+
 # ---- the two-table fixed-window kernel (csrc/kernels_sweepfw2.h): 45+ grey levels ------------------------------------------
 def _check2(cm, checker, img, mask, Ng):
     from pyradiomics_amd import _lib
