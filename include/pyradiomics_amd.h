@@ -71,8 +71,14 @@ double prad_last_kernel_ms(const char *kernel_family);
 /* Accumulated timing over many calls (the per-call figures above need the call to have finished, i.e. one host
  * synchronisation per call).  prad_timing_begin: start keeping the event brackets of every following call of this
  * thread; prad_timing_ms: sum of the brackets of a kernel family (NULL: whole calls) since then, in ms -- synchronises
- * on the last recorded event; prad_timing_calls: calls recorded; prad_timing_end: stop and drop the records. */
+ * on the last recorded event; prad_timing_calls: calls recorded; prad_timing_end: stop and drop the records.
+ * prad_timing_begin_only(family): as prad_timing_begin, but ONLY the launches of that kernel family are bracketed (no call
+ * brackets either) -- two event records per call instead of ten: a timed loop that wants the duration of its dominant
+ * kernel without paying for the rest (each record costs the stream 3 - 6 us; bench.py).  prad_timing_count(family): how
+ * many brackets of the family were recorded (NULL: calls). */
 int prad_timing_begin(void);
+int prad_timing_begin_only(const char *kernel_family);
+int prad_timing_count(const char *kernel_family);
 double prad_timing_ms(const char *kernel_family);
 int prad_timing_calls(void);
 int prad_timing_end(void);

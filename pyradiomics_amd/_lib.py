@@ -32,6 +32,8 @@ SYMBOLS = {
     "prad_last_device_ms": (C.c_double, []),
     "prad_last_kernel_ms": (C.c_double, [C.c_char_p]),
     "prad_timing_begin": (C.c_int, []),
+    "prad_timing_begin_only": (C.c_int, [C.c_char_p]),
+    "prad_timing_count": (C.c_int, [C.c_char_p]),
     "prad_timing_ms": (C.c_double, [C.c_char_p]),
     "prad_timing_calls": (C.c_int, []),
     "prad_timing_end": (C.c_int, []),

@@ -1750,14 +1750,29 @@ int prad_release_workspace(void) {
 
 int prad_timing_begin(void) {
   Context &c = ctx();
+  c.timing_only.clear();
   c.timing_accumulate = true;
   c.all_times.clear();
   c.all_calls.clear();
   c.events_used = 0;
   return PRAD_OK;
 }
+int prad_timing_begin_only(const char *kernel_family) {
+  if (!kernel_family || !*kernel_family) return fail(PRAD_E_ARG, "timing: no kernel family named");
+  int rc = prad_timing_begin();
+  ctx().timing_only = kernel_family;
+  return rc;
+}
+int prad_timing_count(const char *kernel_family) {
+  Context &c = ctx();
+  if (!kernel_family) return (int)c.all_calls.size();
+  int n = 0;
+  for (auto &t : c.all_times) n += t.family == kernel_family;
+  return n;
+}
 int prad_timing_end(void) {
   Context &c = ctx();
+  c.timing_only.clear();
   c.timing_accumulate = false;
   c.all_times.clear();
   c.all_calls.clear();

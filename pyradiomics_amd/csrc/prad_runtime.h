@@ -80,6 +80,7 @@ struct Context {
   bool deferred = false;
   // accumulated timing (prad_timing_begin): events are not recycled between calls, every bracket is kept
   bool timing_accumulate = false;
+  std::string timing_only;     // prad_timing_begin_only: bracket this kernel family alone (no call brackets): two events per step
   std::vector<KernelTime> all_times;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> all_calls;
   // last angle table uploaded (skips the pageable host-to-device copy when a caller repeats the same angles), per
@@ -244,7 +245,7 @@ struct Context {
   int new_event(hipEvent_t *ev) {
     if (events_used == event_pool.size()) {
       hipEvent_t e;
-      PRAD_HIP(hipEventCreate(&e));
+      PRAD_HIP(hipEventCreateWithFlags(&e, hipEventReleaseToDevice));   // (timing events: no system-scope cache release per record)
       event_pool.push_back(e);
     }
     *ev = event_pool[events_used++];
@@ -257,7 +258,7 @@ struct Context {
     times.clear();
     if (!timing_accumulate) events_used = 0;
     call_timed = false;
-    if (!timing_on()) return PRAD_OK;
+    if (!timing_on() || !timing_only.empty()) return PRAD_OK;
     int rc;
     if ((rc = new_event(&call_a)) != PRAD_OK) return rc;
     if ((rc = new_event(&call_b)) != PRAD_OK) return rc;
@@ -266,6 +267,10 @@ struct Context {
   }
   int end_call(hipStream_t s) {
     if (!timing_on()) return PRAD_OK;
+    if (!timing_only.empty()) {            // family-only mode: keep the family brackets, there is no call bracket
+      if (timing_accumulate) all_times.insert(all_times.end(), times.begin(), times.end());
+      return PRAD_OK;
+    }
     PRAD_HIP(hipEventRecord(call_b, s));
     call_timed = true;
     if (timing_accumulate) {
@@ -275,6 +280,7 @@ struct Context {
     return PRAD_OK;
   }
   int tic(const char *family, hipStream_t s) {
+    if (!timing_only.empty() && timing_only != family) return PRAD_E_UNSUPPORTED;   // (Timed: not bracketed, no error recorded)
     KernelTime t;
     t.family = family;
     int rc;

@@ -275,8 +275,18 @@ def set_deferred_mode(mode: int) -> None:
     _lib.raise_for(_lib.load().prad_set_deferred_mode(int(mode)), "deferred mode")
 
 
-def timing_begin() -> None:
-    _lib.load().prad_timing_begin()
+def timing_begin(only: str | None = None) -> None:
+    """start keeping the HIP-event brackets of every following call of this thread; only="sweep": bracket that kernel family
+    alone (two event records per call instead of ten -- every record costs the stream a few microseconds)"""
+    if only:
+        _lib.raise_for(_lib.load().prad_timing_begin_only(only.encode()), "timing")
+    else:
+        _lib.load().prad_timing_begin()
+
+
+def timing_count(family: str | None = None) -> int:
+    """brackets recorded for a kernel family since timing_begin (None: calls)"""
+    return int(_lib.load().prad_timing_count(family.encode() if family else None))
 
 
 def timing_ms(family: str | None = None) -> float:
