@@ -460,6 +460,12 @@ int prad_swt_level1(const double *in, const int *size, int Nd, const double *dec
                     const int *axes, int naxes, double *out);
 int prad_swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi,
                         int flen, const int *axes, int naxes, double *out, void *stream);
+/* The same with the image in its own element type (dtype codes as prad_roi_minmax_dev: 0 float32, 1 float64, 2 int32,
+ * 3 int16): the float64 copy the reference makes first (imageoperations.py:914-922) is folded into the fused 3-D kernel.
+ * PRAD_E_UNSUPPORTED when the call is not a 3-D transform over axes (2, 1, 0) with 2 / 4 / 6 taps: convert and use
+ * prad_swt_level1_dev. */
+int prad_swt_level1_any_dev(const void *in, int dtype, const int *size, int Nd, const double *dec_lo,
+                            const double *dec_hi, int flen, const int *axes, int naxes, double *out, void *stream);
 int prad_log(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
              float *out);
 int prad_log_dev(const float *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,

@@ -99,6 +99,7 @@ SYMBOLS = {
     "prad_level_counts_dev": (C.c_int, [_vp, _vp, C.c_longlong, C.c_int, C.POINTER(C.c_longlong), _vp]),
     "prad_swt_level1": (C.c_int, [_vp, _ip, C.c_int, _vp, _vp, C.c_int, _ip, C.c_int, _vp]),
     "prad_swt_level1_dev": (C.c_int, [_vp, _ip, C.c_int, _vp, _vp, C.c_int, _ip, C.c_int, _vp, _vp]),
+    "prad_swt_level1_any_dev": (C.c_int, [_vp, C.c_int, _ip, C.c_int, _vp, _vp, C.c_int, _ip, C.c_int, _vp, _vp]),
     "prad_log": (C.c_int, [_vp, _ip, C.c_int, _vp, C.c_double, C.c_int, _vp]),
     "prad_log_dev": (C.c_int, [_vp, _ip, C.c_int, _vp, C.c_double, C.c_int, _vp, _vp]),
     "prad_log_multi_dev": (C.c_int, [_vp, _ip, C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),

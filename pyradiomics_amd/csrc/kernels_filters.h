@@ -88,6 +88,96 @@ __global__ void __launch_bounds__(256) swt_axis2_kernel(const double *__restrict
   hi[idx] = sh;
 }
 
+// The three axis passes of a 3-D level-1 transform in ONE kernel (round 4).  The separate passes move 168 B per voxel (x: 8 in,
+// 16 out; y: 16 in, 32 out; z: 32 in, 64 out); the eight sub-bands themselves are 64 B.  Here a workgroup of 256 lanes owns
+// a column of 8 x 32 (y, x) outputs and streams along z: each input plane of the column (with its F - 1 halo rows and columns,
+// periodic) is staged in LDS, the x pass leaves lo / hi rows in LDS, every lane runs the y pass for its own (y, x) and keeps
+// the four y-bands of the last F planes in REGISTERS, from which the z pass produces the eight outputs of a finished
+// plane.  72 B per voxel reach HBM.  Every 1-D sum is the one of swt_axis_kernel -- taps in ascending k from 0.0, unfused
+// multiply / add, float64 intermediates -- so the sub-bands are the same bits (tests/test_gpu_filters.py).
+// Output order as swt_level1_dev builds it for axes (2, 1, 0): band index = (bx * 2 + by) * 2 + bz.
+#define PRAD_SWT3_TY 8
+#define PRAD_SWT3_TX 32
+// TIN: the image as it is (int16 / int32 / float32 / float64): converted to float64 when staged (exact), which is what the
+// reference does before the transform (imageoperations.py:914-922 work on a float64 copy) without a pass of its own.
+template <int F, typename TIN>
+__global__ void __launch_bounds__(256) swt3_fused_kernel(const TIN *__restrict__ x, int Nz, int Ny, int Nx, FilterTaps T,
+                                                         int CZ, double *__restrict__ out) {
+  constexpr int TY = PRAD_SWT3_TY, TX = PRAD_SWT3_TX;
+  constexpr int HY = TY + F - 1, HX = TX + F - 1, LOH = F - 1 - F / 2;
+  __shared__ double S0[HY][HX + 1];
+  __shared__ double AD[2][HY][TX + 1];
+  const int tid = threadIdx.x, tx = tid & (TX - 1), ty = tid / TX;
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY, zc0 = blockIdx.z * CZ, zc1 = min(Nz, zc0 + CZ);
+  const long long n = (long long)Nz * Ny * Nx;
+  const bool mine = (y0 + ty) < Ny && (x0 + tx) < Nx;
+  double r[4][F];                      // the y-bands (aa, ad, da, dd) of the last F planes at this lane's (y, x); [0] = newest
+#pragma unroll
+  for (int b = 0; b < 4; b++)
+#pragma unroll
+    for (int k = 0; k < F; k++) r[b][k] = 0.0;
+  const int steps = (zc1 - zc0) + F - 1;
+  for (int s = 0; s < steps; s++) {
+    int zp = (zc0 - LOH + s) % Nz;
+    if (zp < 0) zp += Nz;
+    const TIN *plane = x + (long long)zp * Ny * Nx;
+    for (int e = tid; e < HY * HX; e += 256) {
+      const int iy = e / HX, ix = e - iy * HX;
+      int gy = y0 - LOH + iy, gx = x0 - LOH + ix;
+      gy = gy < 0 ? gy + Ny : (gy >= Ny ? gy - Ny : gy);
+      gx = gx < 0 ? gx + Nx : (gx >= Nx ? gx - Nx : gx);
+      gy = gy >= Ny ? gy % Ny : gy;       // (ragged last tiles reach further than one period; their outputs are not stored)
+      gx = gx >= Nx ? gx % Nx : gx;
+      S0[iy][ix] = (double)plane[(long long)gy * Nx + gx];
+    }
+    __syncthreads();
+    for (int e = tid; e < HY * TX; e += 256) {
+      const int iy = e / TX, ox = e - iy * TX;
+      double sl = 0.0, sh = 0.0;
+#pragma unroll
+      for (int k = 0; k < F; k++) {
+        const double v = S0[iy][ox + F - 1 - k];
+        sl = __dadd_rn(sl, __dmul_rn(T.lo[k], v));
+        sh = __dadd_rn(sh, __dmul_rn(T.hi[k], v));
+      }
+      AD[0][iy][ox] = sl;
+      AD[1][iy][ox] = sh;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+      for (int k = F - 1; k >= 1; k--) r[b][k] = r[b][k - 1];
+    {
+      double aa = 0.0, ad = 0.0, da = 0.0, dd = 0.0;
+#pragma unroll
+      for (int k = 0; k < F; k++) {
+        const double va = AD[0][ty + F - 1 - k][tx], vd = AD[1][ty + F - 1 - k][tx];
+        aa = __dadd_rn(aa, __dmul_rn(T.lo[k], va));
+        ad = __dadd_rn(ad, __dmul_rn(T.hi[k], va));
+        da = __dadd_rn(da, __dmul_rn(T.lo[k], vd));
+        dd = __dadd_rn(dd, __dmul_rn(T.hi[k], vd));
+      }
+      r[0][0] = aa; r[1][0] = ad; r[2][0] = da; r[3][0] = dd;
+    }
+    if (s >= F - 1 && mine) {
+      const int oz = zc0 + s - (F - 1);
+      const long long vi = ((long long)oz * Ny + (y0 + ty)) * Nx + (x0 + tx);
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        double sl = 0.0, sh = 0.0;
+#pragma unroll
+        for (int k = 0; k < F; k++) {
+          sl = __dadd_rn(sl, __dmul_rn(T.lo[k], r[b][k]));
+          sh = __dadd_rn(sh, __dmul_rn(T.hi[k], r[b][k]));
+        }
+        out[(long long)(2 * b) * n + vi] = sl;
+        out[(long long)(2 * b + 1) * n + vi] = sh;
+      }
+    }
+  }
+}
+
 struct RGaussCoef {
   double N0, N1, N2, N3, D1, D2, D3, D4, M1, M2, M3, M4, BN1, BN2, BN3, BN4, BM1, BM2, BM3, BM4;
 };

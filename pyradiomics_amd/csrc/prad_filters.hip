@@ -15,6 +15,17 @@ using namespace prad;
 
 namespace {
 
+int cu_count() {
+  static thread_local int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+  }
+  return cus;
+}
+
 int copy_back(Context &c, double *host, const double *dev, size_t count) {
   PRAD_HIP(hipMemcpyAsync(host, dev, sizeof(double) * count, hipMemcpyDeviceToHost, c.own_stream));
   PRAD_HIP(hipStreamSynchronize(c.own_stream));
@@ -24,13 +35,17 @@ int copy_back(Context &c, double *host, const double *dev, size_t count) {
 // ------------------------------------------------------------------------------------------------
 // filters
 // ------------------------------------------------------------------------------------------------
-int swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi, int flen,
+// dtype: the image's element type (include/pyradiomics_amd.h: 0 float32, 1 float64, 2 int32, 3 int16); anything but float64 is
+// only taken by the fused 3-D kernel (PRAD_E_UNSUPPORTED otherwise: the caller converts and calls again)
+int swt_level1_dev(const void *in_any, int dtype, const int *size, int Nd, const double *dec_lo, const double *dec_hi, int flen,
                    const int *axes, int naxes, double *out, hipStream_t s) {
+  const double *in = static_cast<const double *>(in_any);
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
   Geo g;
   PRAD_TRY(make_geo(size, Nd, &g));
   if (!in || !out || !dec_lo || !dec_hi || !axes) return fail(PRAD_E_ARG, "swt: NULL pointer");
+  if (dtype < 0 || dtype > 3) return fail(PRAD_E_ARG, "swt: dtype code %d", dtype);
   if (flen < 2 || flen > PRAD_MAX_TAPS) return fail(PRAD_E_ARG, "swt: filter length %d outside [2,%d]", flen, PRAD_MAX_TAPS);
   if (naxes < 1 || naxes > Nd) return fail(PRAD_E_ARG, "swt: naxes=%d", naxes);
   FilterTaps T;
@@ -41,6 +56,40 @@ int swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_
     if (g.size[axes[a]] % 2) return fail(PRAD_E_ARG, "swt: axis %d has odd length %d (pad first, imageoperations.py:914-919)", axes[a], g.size[axes[a]]);
   }
   PRAD_TRY(c.begin_call(s));
+  // 3-D transform over all three axes in x, y, z order (what getWaveletImage asks for): one fused kernel (kernels_filters.h)
+  if (Nd == 3 && naxes == 3 && axes[0] == 2 && axes[1] == 1 && axes[2] == 0 && (flen == 2 || flen == 4 || flen == 6) &&
+      g.size[0] >= flen && g.size[1] >= flen && g.size[2] >= flen && !getenv("PRAD_SWT_NOFUSE")) {
+    {
+      Timed t(c, "swt", s);
+      const int Nz = g.size[0], Ny = g.size[1], Nx = g.size[2];
+      const int tiles = ((Nx + PRAD_SWT3_TX - 1) / PRAD_SWT3_TX) * ((Ny + PRAD_SWT3_TY - 1) / PRAD_SWT3_TY);
+      // z chunks: enough workgroups for ~4 per CU, each chunk long against its F - 1 warm-up planes
+      int nzc = std::max(1, std::min((4 * cu_count() + tiles - 1) / tiles, Nz / 32));
+      const int CZ = (Nz + nzc - 1) / nzc;
+      nzc = (Nz + CZ - 1) / CZ;
+      const dim3 grid((Nx + PRAD_SWT3_TX - 1) / PRAD_SWT3_TX, (Ny + PRAD_SWT3_TY - 1) / PRAD_SWT3_TY, nzc);
+#define PRAD_SWT3(FF)                                                                                                            \
+  do {                                                                                                                           \
+    if (dtype == 1) hipLaunchKernelGGL((swt3_fused_kernel<FF, double>), grid, dim3(256), 0, s, (const double *)in_any, Nz, Ny, Nx, T, CZ, out); \
+    else if (dtype == 0) hipLaunchKernelGGL((swt3_fused_kernel<FF, float>), grid, dim3(256), 0, s, (const float *)in_any, Nz, Ny, Nx, T, CZ, out); \
+    else if (dtype == 2) hipLaunchKernelGGL((swt3_fused_kernel<FF, int>), grid, dim3(256), 0, s, (const int *)in_any, Nz, Ny, Nx, T, CZ, out); \
+    else hipLaunchKernelGGL((swt3_fused_kernel<FF, short>), grid, dim3(256), 0, s, (const short *)in_any, Nz, Ny, Nx, T, CZ, out); \
+  } while (0)
+      if (flen == 6) PRAD_SWT3(6);
+      else if (flen == 4) PRAD_SWT3(4);
+      else PRAD_SWT3(2);
+#undef PRAD_SWT3
+      PRAD_TRY(check_launch("swt3_fused_kernel"));
+    }
+    PRAD_TRY(c.end_call(s));
+    PRAD_HIP(hipStreamSynchronize(s));
+    c.last_path = "swt-fused";
+    return PRAD_OK;
+  }
+  if (dtype != 1) {
+    PRAD_TRY(c.end_call(s));
+    return fail(PRAD_E_UNSUPPORTED, "swt: only the fused 3-D transform takes images that are not float64");
+  }
   // stage k holds 2^k arrays; stages alternate between two workspaces, the last stage writes `out`
   double *ws[2] = {nullptr, nullptr};
   const size_t n = (size_t)g.n;
@@ -309,7 +358,11 @@ extern "C" {
 // ---- filters ---------------------------------------------------------------------------------
 int prad_swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi,
                         int flen, const int *axes, int naxes, double *out, void *stream) {
-  return swt_level1_dev(in, size, Nd, dec_lo, dec_hi, flen, axes, naxes, out, (hipStream_t)stream);
+  return swt_level1_dev(in, 1, size, Nd, dec_lo, dec_hi, flen, axes, naxes, out, (hipStream_t)stream);
+}
+int prad_swt_level1_any_dev(const void *in, int dtype, const int *size, int Nd, const double *dec_lo, const double *dec_hi,
+                            int flen, const int *axes, int naxes, double *out, void *stream) {
+  return swt_level1_dev(in, dtype, size, Nd, dec_lo, dec_hi, flen, axes, naxes, out, (hipStream_t)stream);
 }
 int prad_swt_level1(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi, int flen,
                     const int *axes, int naxes, double *out) {
@@ -323,7 +376,7 @@ int prad_swt_level1(const double *in, const int *size, int Nd, const double *dec
   PRAD_TRY(c.get<double>("swt_in", n, &d_in));
   PRAD_TRY(c.get<double>("swt_out", nout, &d_out));
   PRAD_HIP(hipMemcpyAsync(d_in, in, sizeof(double) * n, hipMemcpyHostToDevice, c.own_stream));
-  int rc = swt_level1_dev(d_in, size, Nd, dec_lo, dec_hi, flen, axes, naxes, d_out, c.own_stream);
+  int rc = swt_level1_dev(d_in, 1, size, Nd, dec_lo, dec_hi, flen, axes, naxes, d_out, c.own_stream);
   if (rc != PRAD_OK) return rc;
   return copy_back(c, out, d_out, nout);
 }

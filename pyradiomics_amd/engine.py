@@ -865,15 +865,25 @@ def voxel_firstorder(image: torch.Tensor, mask: torch.Tensor, levels, voxels: to
 
 
 def swt_level1(data: torch.Tensor, lo: np.ndarray, hi: np.ndarray, axes) -> torch.Tensor:
-    """pywt.swtn(level=1) on the device: float64 tensor [2^len(axes), *data.shape], sub-bands in key order"""
+    """pywt.swtn(level=1) on the device: float64 tensor [2^len(axes), *data.shape], sub-bands in key order.  The image goes
+    in as it is when the fused 3-D kernel takes the call (its float64 copy is made while the planes are staged), as a
+    float64 copy otherwise"""
     lib = _lib.load()
-    data = data.to(torch.float64).contiguous()
     lib.prad_set_device(data.device.index or 0)
     size = np.array(data.shape, dtype=np.intc)
     ax = np.array(axes, dtype=np.intc)
     lo = np.ascontiguousarray(lo, dtype=np.float64)
     hi = np.ascontiguousarray(hi, dtype=np.float64)
     out = torch.empty((1 << len(ax),) + tuple(data.shape), dtype=torch.float64, device=data.device)
+    if data.dtype in _DTYPE_CODES and data.dtype != torch.float64:
+        raw = data.contiguous()
+        rc = lib.prad_swt_level1_any_dev(C.c_void_p(raw.data_ptr()), _DTYPE_CODES[raw.dtype], _iptr(size), raw.dim(),
+                                         C.c_void_p(lo.ctypes.data), C.c_void_p(hi.ctypes.data), len(lo), _iptr(ax), len(ax),
+                                         C.c_void_p(out.data_ptr()), _stream_ptr())
+        if rc != _lib.PRAD_E_UNSUPPORTED:
+            _lib.raise_for(rc, "swt")
+            return out
+    data = data.to(torch.float64).contiguous()
     rc = lib.prad_swt_level1_dev(C.c_void_p(data.data_ptr()), _iptr(size), data.dim(), C.c_void_p(lo.ctypes.data),
                                  C.c_void_p(hi.ctypes.data), len(lo), _iptr(ax), len(ax), C.c_void_p(out.data_ptr()),
                                  _stream_ptr())
@@ -885,7 +895,7 @@ def wavelet_images(image: torch.Tensor, wavelet="coif1"):
     """the 8 (2^Nd) level-1 sub-bands of getWaveletImage as {name: float64 tensor}, yield order of the reference"""
     from .filters import wavelet_filters
     lo, hi = wavelet_filters(wavelet)
-    x = image.to(torch.float64)
+    x = image if image.dtype in _DTYPE_CODES else image.to(torch.float64)
     shape = x.shape
     for d, s in enumerate(shape):          # np.pad(..., 'wrap') by one sample on odd axes
         if s % 2:

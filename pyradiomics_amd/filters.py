@@ -95,7 +95,8 @@ def _swt3_device(x, axes, **kwargs):
     level = kwargs.get("level", 1)
     start_level = kwargs.get("start_level", 0)
     shape = tuple(x.shape)
-    data = x.to(torch.float64)
+    from .engine import _DTYPE_CODES
+    data = x if x.dtype in _DTYPE_CODES else x.to(torch.float64)    # (engine.swt_level1 makes the float64 copy, or fuses it)
     for d, n in enumerate(shape):                      # np.pad(..., 'wrap') by one sample on odd axes
         if n % 2:
             data = torch.cat([data, data.narrow(d, 0, 1)], dim=d)

@@ -389,3 +389,24 @@ def test_log_after_normalize_is_float64_through_the_extractor():
     assert derived.array.dtype == np.float64 and name == "log-sigma-3-0-mm-3D"
     want = fo.laplacian_recursive_gaussian(norm.array, image.GetSpacing(), 3.0)
     assert np.abs(derived.array - want).max() <= 1e-12 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 64), (18, 40, 44), (6, 8, 10), (70, 12, 130), (8, 6, 34)])
+@pytest.mark.parametrize("wavelet", ["coif1", "db2", "haar"])
+def test_fused_swt_kernel_equals_the_axis_passes_bit_for_bit(shape, wavelet, monkeypatch):
+    """the 3-D transform as one kernel (x pass through LDS, y pass per lane, z pass from a register ring) against the three
+    separate axis passes: the same float64 bits in all eight sub-bands, ragged tiles and short axes included"""
+    import torch
+    from pyradiomics_amd import engine, _lib
+    from pyradiomics_amd.filters import wavelet_filters
+    lo, hi = wavelet_filters(wavelet)
+    x = torch.from_numpy(np.random.default_rng(21).standard_normal(shape) * 300).cuda()
+    fused = engine.swt_level1(x, lo, hi, (2, 1, 0)).cpu().numpy()
+    assert _lib.last_path() == "swt-fused"
+    monkeypatch.setenv("PRAD_SWT_NOFUSE", "1")
+    plain = engine.swt_level1(x, lo, hi, (2, 1, 0)).cpu().numpy()
+    assert _lib.last_path() == "swt"
+    assert fused.shape == plain.shape == (8,) + shape and np.array_equal(fused, plain)
+    monkeypatch.delenv("PRAD_SWT_NOFUSE")
+    other = engine.swt_level1(x, lo, hi, (1, 2)).cpu().numpy()         # any other axis list: the separate passes
+    assert _lib.last_path() == "swt" and other.shape == (4,) + shape
