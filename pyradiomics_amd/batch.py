@@ -127,6 +127,9 @@ class _WorkerPool:
 _POOLS: dict = {}
 
 
+_ATEXIT: list = []
+
+
 def shutdown_pools() -> None:
     """ends the worker threads of every pool (each frees the native workspace it held)"""
     for key in list(_POOLS):
@@ -141,9 +144,14 @@ def _pool(threads: int):
         dev = None
     key = (dev, max(1, threads))
     if key not in _POOLS:
-        if not _POOLS:
+        if not _POOLS and not _ATEXIT:
             import atexit
             atexit.register(shutdown_pools)
+            _ATEXIT.append(True)
+        # one pool per GPU: a call with another thread count retires the old pool (its threads free the native workspaces they
+        # held -- hundreds of MB per worker at 256^3) instead of keeping both alive
+        for old in [k for k in _POOLS if k[0] == dev]:
+            _POOLS.pop(old).shutdown()
         _POOLS[key] = _WorkerPool(key[1], dev)
     return _POOLS[key]
 

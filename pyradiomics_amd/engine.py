@@ -217,11 +217,15 @@ def image_enqueue(levels: torch.Tensor, mask: torch.Tensor, raw, Ng: int, Ns: in
     _lib.raise_for(rc, "image enqueue")
     n = max(int(layout[12]), 8)
     res = np.frombuffer((C.c_char * (8 * n)).from_address(res_p.value), dtype=np.float64, count=n)
-    return {"res": res, "layout": [int(v) for v in layout], "ticket": int(ticket.value), "keep": (levels, mask, raw)}
+    return {"res": res, "layout": [int(v) for v in layout], "ticket": int(ticket.value), "keep": (levels, mask, raw),
+            "generation": _arena_gen.value}
 
 
 def image_wait(token) -> bool:
     """waits for the work of an image_enqueue() token only; False when a queued call saw levels outside [1, Ng] (void)"""
+    if token.get("generation", _arena_gen.value) != _arena_gen.value:
+        token["keep"] = None
+        raise RuntimeError("release_workspace() was called while this image was queued: its result block is gone")
     rc = _lib.load().prad_image_wait(int(token["ticket"]))
     token["keep"] = None
     if rc == _lib.PRAD_E_DEFERRED:
@@ -460,8 +464,17 @@ def workspace_bytes() -> int:
     return int(_lib.load().prad_workspace_bytes())
 
 
+class _Generation(threading.local):      # (the library's workspace is per host thread, so is its generation)
+    value = 0
+
+
+_arena_gen = _Generation()   # bumped by release_workspace(): result-arena views and image tickets issued before are void
+
+
 def release_workspace() -> None:
-    """free the library's cached scratch buffers (they are re-created on demand)"""
+    """free the library's cached scratch buffers (they are re-created on demand).  Whatever was queued and not yet collected
+    -- image_enqueue tokens, result_array views -- is void afterwards: image_wait() on such a token raises"""
+    _arena_gen.value += 1
     _lib.raise_for(_lib.load().prad_release_workspace(), "release_workspace")
 
 
