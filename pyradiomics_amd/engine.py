@@ -5,6 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import numpy as np
 import torch  # imported before the HIP library so both share one libamdhip64 instance
