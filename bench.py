@@ -425,12 +425,8 @@ def mode_config3(device, engine, size=256):
             "Mvoxels_s_derived": round(13 * n / (product_ms * 1e-3) / 1e6, 1)}
 
 
-def mode_batch(device, rank: int, cases: int, fence):
-    """north_star 'batched mode' (BASELINE config 5 in miniature): whole cases -- a 256^3 volume, ball ROI, Original +
-    8 wavelet sub-bands, all six feature classes -- through RadiomicsFeatureExtractor.execute, `cases` per rank,
-    no collective; PRAD_BATCH_THREADS (default 3: one thread reaches 72.6 cases/s, two 89, three ~100, four 104, six 102 --
-    profiles/r03_probes.md section 12) cases in flight per GPU (batch.run_batch(..., threads=)).  Returns (cases,
-    seconds, features per case)."""
+def _batch_case_setup(device, seed_base: int, ncases: int):
+    """the extractor, ROI and synthetic volumes of batch mode (shared by the parent and its worker processes)"""
     from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
     from pyradiomics_amd.image import Image
     N = 256
@@ -438,26 +434,97 @@ def mode_batch(device, rank: int, cases: int, fence):
     zz, yy, xx = np.ogrid[:N, :N, :N]
     roi = np.zeros((N, N, N), dtype=np.int16)
     roi[((zz - N / 2) ** 2 + (yy - N / 2) ** 2 + (xx - N / 2) ** 2) < (0.45 * N) ** 2] = 1
-    from pyradiomics_amd import batch
-    threads = int(os.environ.get("PRAD_BATCH_THREADS", "3"))
     ex = RadiomicsFeatureExtractor(params)
-    vols = [(make_volume(N, 32, "smooth", 1000 * rank + c, device)[0] * 25).cpu().numpy().astype(np.int16)
-            for c in range(cases + 1)]
-    ex.execute(Image(vols[0]), Image(roi))          # warm-up: code objects, workspace
+    vols = [(make_volume(N, 32, "smooth", seed_base + c, device)[0] * 25).cpu().numpy().astype(np.int16) for c in range(ncases)]
+    return ex, vols, lambda c: ex.execute(Image(vols[c]), Image(roi))
 
-    def one(c):
-        return ex.execute(Image(vols[c]), Image(roi))
 
-    if threads > 1:                                       # every worker thread warms its own workspace
+def batch_child(argv) -> None:
+    """one worker PROCESS of batch mode: `bench.py --batch-child <device index> <cases> <threads> <seed base>`.  Builds its
+    cases, warms up, prints `ready`, waits for a line on stdin (all workers start together), runs its cases through
+    RadiomicsFeatureExtractor.execute and prints `<cases> <seconds> <features per case>`"""
+    from pyradiomics_amd import batch
+    dev_index, ncases, threads, seed = (int(a) for a in argv[:4])
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    ex, vols, one = _batch_case_setup(device, seed, ncases + 1)
+    one(0)
+    one(0)
+    if threads > 1:
         batch.warm_threads(lambda: one(0), threads)
-    fence()
+    torch.cuda.synchronize()
+    print("ready", flush=True)
+    sys.stdin.readline()
     t0 = time.perf_counter()
     if threads > 1:
-        res = batch._run_threaded(list(range(cases)), list(range(1, cases + 1)), one, threads)
+        res = batch._run_threaded(list(range(ncases)), list(range(1, ncases + 1)), one, threads)
     else:
-        res = {i: one(i + 1) for i in range(cases)}
-    fence()
-    dt = time.perf_counter() - t0
+        res = {i: one(i + 1) for i in range(ncases)}
+    torch.cuda.synchronize()
+    print("%d %.6f %d" % (ncases, time.perf_counter() - t0, len(res[0])), flush=True)
+
+
+def mode_batch(device, rank: int, cases: int, fence):
+    """north_star 'batched mode' (BASELINE config 5 in miniature): whole cases -- a 256^3 volume, ball ROI, Original +
+    8 wavelet sub-bands, all six feature classes -- through RadiomicsFeatureExtractor.execute, `cases` per rank, no
+    collective.  The cases of a rank are dealt to PRAD_BATCH_PROCS worker processes on the rank's GPU (default 4), each with
+    PRAD_BATCH_THREADS host threads (default 1) -- what `python -m pyradiomics_amd batch.csv --jobs N` does with N workers
+    per GPU, and what the reference does with multiprocessing.Pool over cores (scripts/__init__.py:387-416).  A case is
+    bound by its host thread (~870 HIP calls); host threads of ONE process share the runtime's locks and the GIL (the GPU
+    is busy 55 % of the time with three threads: scripts/r04_batch_busy.sh), worker processes do not: one process with
+    three threads 115 cases/s, four processes 128 (scripts/r04_batch_procs.py).  PRAD_BATCH_PROCS=0: threads of this
+    process only (batch.run_batch(threads=), PRAD_BATCH_THREADS default 3 then).  Returns (cases, seconds, features per case)."""
+    import subprocess
+    from pyradiomics_amd import batch
+    procs = int(os.environ.get("PRAD_BATCH_PROCS", "4"))
+    threads = int(os.environ.get("PRAD_BATCH_THREADS", "1" if procs > 0 else "3"))
+    ex, vols, one = _batch_case_setup(device, 1000 * rank, min(cases, 5) + 1 if procs > 0 else cases + 1)
+    one(0)                                                # warm-up: code objects, workspace
+    if procs > 0:
+        per = [cases // procs + (1 if i < cases % procs else 0) for i in range(procs)]
+        per = [p for p in per if p > 0]
+        kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--batch-child", str(device.index or 0), str(p),
+                                  str(threads), str(1000 * rank + 100 * (i + 1))], cwd=ROOT, stdin=subprocess.PIPE,
+                                 stdout=subprocess.PIPE, text=True) for i, p in enumerate(per)]
+        try:
+            for k in kids:
+                line = k.stdout.readline().strip()
+                if line != "ready":
+                    raise RuntimeError("batch worker failed to start: %r" % line)
+            fence()
+            t0 = time.perf_counter()
+            for k in kids:
+                k.stdin.write("go\n")
+                k.stdin.flush()
+            done, nfeat = 0, 0
+            for k in kids:
+                n, _, nf = k.stdout.readline().split()
+                done += int(n)
+                nfeat = int(nf)
+            fence()
+            dt = time.perf_counter() - t0
+        finally:
+            for k in kids:
+                if k.poll() is None:
+                    try:
+                        k.wait(timeout=30)
+                    except subprocess.TimeoutExpired:
+                        k.kill()
+        assert done == cases
+        mode_batch.how = "%d worker processes x %d thread(s) on the GPU" % (len(per), threads)
+    else:
+        if threads > 1:                                   # every worker thread warms its own workspace
+            batch.warm_threads(lambda: one(0), threads)
+        fence()
+        t0 = time.perf_counter()
+        if threads > 1:
+            res = batch._run_threaded(list(range(cases)), list(range(1, cases + 1)), one, threads)
+        else:
+            res = {i: one(i + 1) for i in range(cases)}
+        fence()
+        dt = time.perf_counter() - t0
+        nfeat = len(res[0])
+        mode_batch.how = "%d host thread(s) of one process (batch.run_batch(threads=))" % threads
     lat = []                                              # one case at a time on this thread (the case pipeline's latency)
     for c in range(1, min(cases, 5) + 1):
         fence()
@@ -466,7 +533,7 @@ def mode_batch(device, rank: int, cases: int, fence):
         fence()
         lat.append((time.perf_counter() - t1) * 1e3)
     mode_batch.one_thread_ms = sorted(lat)[len(lat) // 2]
-    return cases, dt, len(res[0])
+    return cases, dt, nfeat
 
 
 def mode_voxel(device, rank: int, world: int, size: int, fence, three_d: bool = False):
@@ -524,6 +591,9 @@ def respawn_under_torchrun(n: int) -> None:
 
 
 def main() -> None:
+    if len(sys.argv) > 1 and sys.argv[1] == "--batch-child":
+        batch_child(sys.argv[2:])
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -636,8 +706,7 @@ def main() -> None:
                     "ms_per_case_per_gpu": round(dt_b / nc * 1e3, 2),
                     "one_thread_ms_per_case": round(mode_batch.one_thread_ms, 2),
                     "case": "256^3 int16 volume from host memory, ball ROI (38 %% of the box), Original + 8 wavelet "
-                            "sub-bands, six feature classes; %s cases in flight per GPU (host threads, "
-                            "batch.run_batch(threads=))" % os.environ.get("PRAD_BATCH_THREADS", "3")}
+                            "sub-bands, six feature classes; %s" % mode_batch.how}
 
         def voxel_mode(three_d):
             nk, dt_v, kms = mode_voxel(device, rank, world, args.size, fence, three_d)
