@@ -410,3 +410,10 @@ def test_fused_swt_kernel_equals_the_axis_passes_bit_for_bit(shape, wavelet, mon
     monkeypatch.delenv("PRAD_SWT_NOFUSE")
     other = engine.swt_level1(x, lo, hi, (1, 2)).cpu().numpy()         # any other axis list: the separate passes
     assert _lib.last_path() == "swt" and other.shape == (4,) + shape
+    # the image in its own element type: the float64 copy is made while the planes are staged (exact for every type)
+    for dt in (torch.int16, torch.int32, torch.float32):
+        xi = (x * 3).to(dt)
+        a = engine.swt_level1(xi, lo, hi, (2, 1, 0)).cpu().numpy()
+        assert _lib.last_path() == "swt-fused"
+        b = engine.swt_level1(xi.to(torch.float64), lo, hi, (2, 1, 0)).cpu().numpy()
+        assert np.array_equal(a, b), dt
