@@ -159,9 +159,14 @@ struct Offsets3 {
   signed char o[32][4];   // backward neighbours only (linear offset < 0), embedded in 3-D
 };
 
-__device__ __forceinline__ int lds_find(volatile int *lab, int i) {
+// `lab` is a __shared__ array.  The loads are typed as LDS loads: through a generic `volatile int *` the compiler emits
+// flat_load ... sc0 sc1 (system scope, the flat path's latency) for every hop of the pointer chase -- 64 M of them per
+// 512^3 volume in glszm_tile8_kernel, 2/3 of its time (profiles/r04_probes.md section 11).
+typedef __attribute__((address_space(3))) int lds_int_t;
+__device__ __forceinline__ int lds_find(int *lab, int i) {
+  volatile lds_int_t *l = (volatile lds_int_t *)lab;
   int p;
-  while ((p = lab[i]) != i) i = p;
+  while ((p = l[i]) != i) i = p;
   return i;
 }
 __device__ __forceinline__ void lds_union(int *lab, int a, int b) {
@@ -454,6 +459,14 @@ __device__ __forceinline__ unsigned t8_select(unsigned S) {
   return sel;
 }
 
+// One neighbour per 26-adjacency CLUSTER of the same-level backward neighbours (scripts/gen_glszm_sel13.py has the
+// argument): on structured volumes nearly all 13 neighbours of a voxel have its level and form one cluster -- one union
+// instead of the two (own plane, plane above) t8_select asks for, and none at all for a voxel whose left neighbour in
+// its own quad has its level (bit 12 represents its cluster; the tile kernel ties the two through the initial label).
+__device__ const unsigned short t8_sel13[1 << 13] = {
+#include "glszm_sel13.inc"
+};
+
 template <int MODE>
 __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx,
                                                           int *__restrict__ labels, unsigned *__restrict__ sizes,
@@ -485,8 +498,15 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
     }
     cw[q] = w;
     lev[((lz + 1) * (PRAD_TY + 2) + (ly + 1)) * PRAD_T8_ROWDW + 1 + lx4] = w;
+    // a voxel with the level of its left neighbour in the quad starts with that neighbour's label (= the first voxel of
+    // the run inside the quad): that union is made here, by a plain store
+    int first = quad * 4;
 #pragma unroll
-    for (int b = 0; b < 4; b++) lab[quad * 4 + b] = quad * 4 + b;
+    for (int b = 0; b < 4; b++) {
+      const unsigned lv = (w >> (8 * b)) & 0xffu;
+      if (b == 0 || lv == 0u || lv != ((w >> (b ? 8 * b - 8 : 0)) & 0xffu)) first = quad * 4 + b;
+      lab[quad * 4 + b] = first;
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -521,8 +541,17 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
       const unsigned c = (centre >> (8 * k)) & 0xffu;
       unsigned S = t8_flags3(e[0][k]) | ((((lo0 >> (8 * k)) & 0xffu) == c) ? 0x1000u : 0u);
       if (MODE == 1) S |= (t8_flags3(e[1][k]) << 3) | (t8_flags3(e[2][k]) << 6) | (t8_flags3(e[3][k]) << 9);
+#ifdef PRAD_GLSZM_OLD_SELECT
       todo |= (unsigned long long)(c ? t8_select<MODE>(S) : 0u) << (16 * k);
+#else
+      unsigned sel = c ? (unsigned)t8_sel13[S] : 0u;
+      if (k > 0) sel &= ~0x1000u;                               // (tied through the initial label)
+      todo |= (unsigned long long)sel << (16 * k);
+#endif
     }
+#if defined(PRAD_DBG_T8) && PRAD_DBG_T8 >= 1
+    if (todo == 0x123456789abcdefull) lab[0] = 1;   // (ablation build: no unions)
+#else
     while (todo) {
       const int bit = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
@@ -531,6 +560,7 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
       const int idx = quad * 4 + (bit >> 4);
       lds_union(lab, idx, idx + dz * (PRAD_TX * PRAD_TY) + dy * PRAD_TX + dx);
     }
+#endif
   }
   __syncthreads();
   int root[QPT][4];
@@ -539,7 +569,11 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int idx = (threadIdx.x + q * 256) * 4 + k;
+#if defined(PRAD_DBG_T8) && PRAD_DBG_T8 >= 2
+      root[q][k] = ((cw[q] >> (8 * k)) & 0xffu) ? idx : -1;             // (ablation build: every voxel its own root)
+#else
       root[q][k] = ((cw[q] >> (8 * k)) & 0xffu) ? lds_find(lab, idx) : -1;
+#endif
     }
   __syncthreads();
   unsigned *cnt = reinterpret_cast<unsigned *>(lab);          // the roots are in registers: lab becomes the counts
