@@ -43,8 +43,12 @@ struct GlszmState {
   const int32_t *image = nullptr;  // segment mode: levels are read from the image at fill time
   int *labels = nullptr;           // segment: [n] root label or -1
   unsigned *sizes = nullptr;       // segment: [n] zone size at root index
-  int *rootlist = nullptr;         // segment, byte path: tile roots (glszm_tile8_kernel); rootctl[0] entries, valid
-  int *rootctl = nullptr;          //   while rootctl[1] == 0 (nullptr: the consumers scan the label volume)
+  // segment, packed-byte path = the dense model (glszm_tile8_kernel): labels[] is vid[] (voxel -> dense id of its tile
+  // root), sizes[] is tsize[] (indexed by dense id); parent == nullptr: the label volume model of the int32 kernels
+  int *parent = nullptr;           // [n] dense union-find, flat after glszm_rootsum_dense_kernel
+  unsigned *tinfo = nullptr;       // [n] dense id -> voxels of the tile component | grey level << 16
+  bool published = false;          // the ordered zone list turned labels[] (vid[]) into its label-volume view
+  int *rootctl = nullptr;          // [0] tile roots, [2] pairs in the work list, [3] work list overflow
   int *zones = nullptr;            // voxel: [boxmax][2][nvox] (level,size) interleaved by kernel
   int *zone_count = nullptr;       // voxel: [nvox]
 };
@@ -166,7 +170,17 @@ typedef __attribute__((address_space(3))) int lds_int_t;
 __device__ __forceinline__ int lds_find(int *lab, int i) {
   volatile lds_int_t *l = (volatile lds_int_t *)lab;
   int p;
+#ifdef PRAD_T8_HALVE
+  p = l[i];
+  while (p != i) {             // (probe build: path halving -- a label only ever moves to a smaller ancestor)
+    const int g = l[p];
+    if (g != p) l[i] = g;
+    i = p;
+    p = g;
+  }
+#else
   while ((p = l[i]) != i) i = p;
+#endif
   return i;
 }
 __device__ __forceinline__ void lds_union(int *lab, int a, int b) {
@@ -467,37 +481,74 @@ __device__ const unsigned short t8_sel13[1 << 13] = {
 #include "glszm_sel13.inc"
 };
 
+// The neighbours (13 bits, numbering above) that are members of T or 26-adjacent to a member of T: rows r0..r2 see each
+// other and r2 sees r3 at |dx| <= 1, the voxel to the left (bit 12) sees dx = -1 and 0 of every row.
+__device__ __forceinline__ unsigned t8_closed_nbhd(unsigned T) {
+  const unsigned W = T & 0xfffu;
+  const unsigned U = W | ((W << 1) & 0xdb6u) | ((W >> 1) & 0x6dbu);            // |dx| <= 1 inside every row
+  const unsigned g3 = (U >> 9) & 7u, g2 = (U >> 6) & 7u, a = (U | (U >> 3) | (U >> 6)) & 7u;
+  unsigned N = a | (a << 3) | ((a | g3) << 6) | ((g2 | g3) << 9);
+  if (T & 0x1000u) N |= 0x16dbu;
+  if (W & 0x6dbu) N |= 0x1000u;
+  return N;
+}
+
+// ---- the dense model of the packed-byte path ------------------------------------------------------------------------
+// The tile is loaded WITH its halo of real levels, so a voxel sees the same-level backward neighbours S it has in the
+// whole volume.  Those inside the tile (IN) are united here, in LDS.  A neighbour in another tile only matters when its
+// 26-adjacency cluster of S has no member inside the tile: the members of a cluster are tied to each other by their own
+// (earlier) unions, and the voxel reaches a cluster with a member in the tile through that member.  Clusters of S made of
+// other-tile voxels only are components of Y = (S outside the tile) minus everything adjacent to IN; one representative
+// of every component of Y goes to the work list (a component of Y that belongs to a cluster reached otherwise costs a
+// redundant union, never a wrong one).
+//
+// Every tile-local component (a "tile root") gets a DENSE id -- its position in the list of tile roots:
+//     vid[voxel]   = dense id of the voxel's tile root, -1 outside the ROI      (int32 [n], the only per-voxel output)
+//     tinfo[id]    = voxels of the tile component (<= 4096) | grey level << 16   (ONE store per root)
+//     worklist     = pairs (dense id of a voxel's tile root, linear index of a same-level neighbour in another tile)
+// and glszm_dense_init_kernel, a stream over the ids, sets parent[id] = id and zsize[id] = the component's voxels
+// so that what follows -- uniting tile roots across tile faces (glszm_pairs_kernel), folding the counts into the zone
+// roots, zone statistics, the fill -- chases pointers in arrays of ~7 M entries (512^3 smooth: 30 MB, cache resident)
+// instead of the 537 MB label volume: 18 M pairs x ~7 dependent 4-byte reads were 1.4 - 1.7 ms of random sectors there.
+// rootctl[0] = tile roots, rootctl[2] = pairs written, rootctl[3] != 0: the work list was too small and
+// glszm_border8d_kernel scans the tile faces instead.
 template <int MODE>
 __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx,
-                                                          int *__restrict__ labels, unsigned *__restrict__ sizes,
-                                                          int *__restrict__ flags, int *__restrict__ rootlist,
-                                                          int *__restrict__ rootctl) {
+                                                          int *__restrict__ vid, const int *__restrict__ flags,
+                                                          int *__restrict__ rootctl, unsigned *__restrict__ tinfo,
+                                                          int2 *__restrict__ worklist, int workcap) {
   __shared__ unsigned lev[PRAD_T8_DW];
   __shared__ int lab[PRAD_TVOX];
+  __shared__ int lcount, lbase, wcount, wbase;
   if (flags[0]) return;   // a masked level outside 1..Ng: the int32 kernels redo this call
   const int tx = (Nx + PRAD_TX - 1) / PRAD_TX, ty = (Ny + PRAD_TY - 1) / PRAD_TY;
   const int bz = blockIdx.x / (ty * tx), br = blockIdx.x % (ty * tx);
   const int z0 = bz * PRAD_TZ, y0 = (br / tx) * PRAD_TY, x0 = (br % tx) * PRAD_TX;
-  for (int i = threadIdx.x; i < PRAD_T8_DW; i += blockDim.x) lev[i] = 0u;
-  __syncthreads();
-  const bool vec = (Nx & 3) == 0;   // every quad is a 4-byte aligned dword of the volume (and of labels / sizes rows)
-  constexpr int QPT = PRAD_TVOX / 4 / 256;   // quads per lane
-  unsigned cw[QPT];
-#pragma unroll
-  for (int q = 0; q < QPT; q++) {
-    const int quad = threadIdx.x + q * 256;
-    const int lx4 = quad & 15, ly = (quad >> 4) % PRAD_TY, lz = quad / (16 * PRAD_TY);
-    const int z = z0 + lz, y = y0 + ly, x = x0 + 4 * lx4;
+  const bool vec = (Nx & 3) == 0;   // every quad is a 4-byte aligned dword of the volume (and of the vid rows)
+  if (threadIdx.x == 0) lcount = wcount = 0;
+  for (int i = threadIdx.x; i < PRAD_T8_DW; i += blockDim.x) {
+    const int c = i % PRAD_T8_ROWDW, rw = (i / PRAD_T8_ROWDW) % (PRAD_TY + 2), pl = i / (PRAD_T8_ROWDW * (PRAD_TY + 2));
+    const int z = z0 + pl - 1, y = y0 + rw - 1, x = x0 + 4 * (c - 1);
     unsigned w = 0u;
-    if (z < Nz && y < Ny && x < Nx) {
+    if ((MODE == 1 || pl > 0) && (unsigned)z < (unsigned)Nz && (unsigned)y < (unsigned)Ny && x >= 0 && x < Nx) {
       const long long gi = ((long long)z * Ny + y) * Nx + x;
       if (vec) w = *reinterpret_cast<const unsigned *>(L + gi);
       else
         for (int b = 0; b < 4; b++)
           if (x + b < Nx) w |= (unsigned)L[gi + b] << (8 * b);
     }
+    lev[i] = w;
+  }
+  __syncthreads();
+  constexpr int QPT = PRAD_TVOX / 4 / 256;   // quads per lane
+  unsigned cw[QPT];
+  unsigned long long btodo[QPT];             // bit 16k + n of [q]: voxel k of quad q goes to the work list with its neighbour n
+#pragma unroll
+  for (int q = 0; q < QPT; q++) {
+    const int quad = threadIdx.x + q * 256;
+    const int lx4 = quad & 15, ly = (quad >> 4) % PRAD_TY, lz = quad / (16 * PRAD_TY);
+    const unsigned w = lev[((lz + 1) * (PRAD_TY + 2) + (ly + 1)) * PRAD_T8_ROWDW + 1 + lx4];
     cw[q] = w;
-    lev[((lz + 1) * (PRAD_TY + 2) + (ly + 1)) * PRAD_T8_ROWDW + 1 + lx4] = w;
     // a voxel with the level of its left neighbour in the quad starts with that neighbour's label (= the first voxel of
     // the run inside the quad): that union is made here, by a plain store
     int first = quad * 4;
@@ -512,6 +563,7 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
 #pragma unroll
   for (int q = 0; q < QPT; q++) {
     const unsigned centre = cw[q];
+    btodo[q] = 0ull;
     if (!centre) continue;
     const int quad = threadIdx.x + q * 256;
     const int lx4 = quad & 15, ly = (quad >> 4) % PRAD_TY, lz = quad / (16 * PRAD_TY);
@@ -536,22 +588,24 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
     }
     const unsigned lo0 = (row0[0] >> 24) | (centre << 8);      // bytes x-1 of the 4 voxels, own row
     unsigned long long todo = 0ull;                            // bit 16k + n: unite voxel k with its neighbour n
+    // the neighbours of this row that lie in another tile
+    const unsigned rowcross = (lz == 0 ? 0xff8u : 0u) | (ly == 0 ? 0x3fu : 0u) | (ly == PRAD_TY - 1 ? 0xe00u : 0u);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const unsigned c = (centre >> (8 * k)) & 0xffu;
       unsigned S = t8_flags3(e[0][k]) | ((((lo0 >> (8 * k)) & 0xffu) == c) ? 0x1000u : 0u);
       if (MODE == 1) S |= (t8_flags3(e[1][k]) << 3) | (t8_flags3(e[2][k]) << 6) | (t8_flags3(e[3][k]) << 9);
-#ifdef PRAD_GLSZM_OLD_SELECT
-      todo |= (unsigned long long)(c ? t8_select<MODE>(S) : 0u) << (16 * k);
-#else
+      const unsigned cross = rowcross | ((k == 0 && lx4 == 0) ? 0x1249u : 0u) | ((k == 3 && lx4 == 15) ? 0x924u : 0u);
+      const unsigned X = c ? (S & cross) : 0u;
+      S &= ~cross;
+      if (X) {
+        const unsigned Y = X & ~t8_closed_nbhd(S);
+        btodo[q] |= (unsigned long long)t8_sel13[Y] << (16 * k);
+      }
       unsigned sel = c ? (unsigned)t8_sel13[S] : 0u;
       if (k > 0) sel &= ~0x1000u;                               // (tied through the initial label)
       todo |= (unsigned long long)sel << (16 * k);
-#endif
     }
-#if defined(PRAD_DBG_T8) && PRAD_DBG_T8 >= 1
-    if (todo == 0x123456789abcdefull) lab[0] = 1;   // (ablation build: no unions)
-#else
     while (todo) {
       const int bit = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
@@ -560,7 +614,6 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
       const int idx = quad * 4 + (bit >> 4);
       lds_union(lab, idx, idx + dz * (PRAD_TX * PRAD_TY) + dy * PRAD_TX + dx);
     }
-#endif
   }
   __syncthreads();
   int root[QPT][4];
@@ -569,11 +622,7 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int idx = (threadIdx.x + q * 256) * 4 + k;
-#if defined(PRAD_DBG_T8) && PRAD_DBG_T8 >= 2
-      root[q][k] = ((cw[q] >> (8 * k)) & 0xffu) ? idx : -1;             // (ablation build: every voxel its own root)
-#else
       root[q][k] = ((cw[q] >> (8 * k)) & 0xffu) ? lds_find(lab, idx) : -1;
-#endif
     }
   __syncthreads();
   unsigned *cnt = reinterpret_cast<unsigned *>(lab);          // the roots are in registers: lab becomes the counts
@@ -596,7 +645,46 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
     if (prev >= 0) atomicAdd(cnt + prev, run);
   }
   __syncthreads();
-  int nroots = 0;     // tile-local components of this lane's voxels (flags[3] += their number: picks the border kernel)
+  // dense ids: the roots this lane owns, a block of the tile-root list for the tile, a block of the work list
+  int nroots = 0, npairs = 0;
+#pragma unroll
+  for (int q = 0; q < QPT; q++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) nroots += root[q][k] == (threadIdx.x + q * 256) * 4 + k ? 1 : 0;
+    npairs += __popcll(btodo[q]);
+  }
+  int mypos = nroots ? atomicAdd(&lcount, nroots) : 0;
+  int wpos = npairs ? atomicAdd(&wcount, npairs) : 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    lbase = lcount > 0 ? atomicAdd(rootctl, lcount) : 0;       // (the list holds n entries: it cannot overflow)
+    wbase = -1;
+    if (wcount > 0 && !__builtin_nontemporal_load(rootctl + 3)) {       // (workcap <= 2^30: the counter cannot wrap)
+      const int at = atomicAdd(rootctl + 2, wcount);
+      if (at < 0 || at > workcap - wcount) atomicOr(rootctl + 3, 1);     // (the list is full: glszm_border8d_kernel takes over)
+      else wbase = at;
+    }
+  }
+  __syncthreads();
+  if (nroots) {
+    int id = lbase + mypos;
+#pragma unroll
+    for (int q = 0; q < QPT; q++) {
+      const int quad = threadIdx.x + q * 256;
+      const int lx4 = quad & 15, ly = (quad >> 4) % PRAD_TY, lz = quad / (16 * PRAD_TY);
+      const long long gi = ((long long)(z0 + lz) * Ny + (y0 + ly)) * Nx + (x0 + 4 * lx4);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (root[q][k] == quad * 4 + k) {
+          const unsigned sz = cnt[quad * 4 + k];             // <= 4096
+          tinfo[id] = sz | (((cw[q] >> (8 * k)) & 0xffu) << 16);     // (one store per root: four cost 0.75 ms on 512^3 noise)
+          lab[quad * 4 + k] = id;                              // (its count is in the dense array now)
+          id++;
+        }
+    }
+  }
+  __syncthreads();
+  const int plane = Ny * Nx;
 #pragma unroll
   for (int q = 0; q < QPT; q++) {
     const int quad = threadIdx.x + q * 256;
@@ -605,63 +693,108 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
     if (z >= Nz || y >= Ny || x >= Nx) continue;
     const long long gi = ((long long)z * Ny + y) * Nx + x;
     int lb[4];
-    unsigned sz[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int r = root[q][k];
-      if (r < 0) { lb[k] = -1; sz[k] = 0u; continue; }
-      const int rx = r % PRAD_TX, ry = (r / PRAD_TX) % PRAD_TY, rz = r / (PRAD_TX * PRAD_TY);
-      lb[k] = (int)(((long long)(z0 + rz) * Ny + (y0 + ry)) * Nx + (x0 + rx));
-      sz[k] = r == quad * 4 + k ? cnt[r] : 0u;
-      nroots += r == quad * 4 + k ? 1 : 0;
-    }
+    for (int k = 0; k < 4; k++) lb[k] = root[q][k] >= 0 ? lab[root[q][k]] : -1;
     if (vec) {
-      *reinterpret_cast<int4 *>(labels + gi) = make_int4(lb[0], lb[1], lb[2], lb[3]);
-      *reinterpret_cast<uint4 *>(sizes + gi) = make_uint4(sz[0], sz[1], sz[2], sz[3]);
+      *reinterpret_cast<int4 *>(vid + gi) = make_int4(lb[0], lb[1], lb[2], lb[3]);
     } else {
       for (int k = 0; k < 4; k++)
-        if (x + k < Nx) { labels[gi + k] = lb[k]; sizes[gi + k] = sz[k]; }
+        if (x + k < Nx) vid[gi + k] = lb[k];
     }
-  }
-  // The tile roots of the volume as a list (rootlist, rootctl[0] entries): what comes after the unions -- folding the
-  // tile counts into the zone roots, zone statistics, the fill -- only concerns them, ~1 M entries on a structured
-  // 512^3 volume against 134 M voxels to scan.  A tile with more than PRAD_GZ_TILE_ROOTS roots (noise) gives up and
-  // raises rootctl[1]: the consumers then scan the label volume as before.
-  __shared__ int lcount, lbase;
-  if (threadIdx.x == 0) lcount = 0;
-  __syncthreads();
-  int mypos = nroots ? atomicAdd(&lcount, nroots) : 0;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    lbase = -1;
-    if (lcount > PRAD_GZ_TILE_ROOTS) atomicOr(rootctl + 1, 1);
-    else if (lcount > 0) lbase = atomicAdd(rootctl, lcount);
-  }
-  __syncthreads();
-  if (lbase >= 0 && nroots) {
-#pragma unroll
-    for (int q = 0; q < QPT; q++) {
-      const int quad = threadIdx.x + q * 256;
-      const int lx4 = quad & 15, ly = (quad >> 4) % PRAD_TY, lz = quad / (16 * PRAD_TY);
-      const int z = z0 + lz, y = y0 + ly, x = x0 + 4 * lx4;
-      if (z >= Nz || y >= Ny || x >= Nx) continue;
-      const long long gi = ((long long)z * Ny + y) * Nx + x;
-#pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (root[q][k] == quad * 4 + k) rootlist[lbase + mypos++] = (int)(gi + k);
+    unsigned long long b = btodo[q];
+    if (wbase < 0) b = 0ull;
+    while (b) {
+      const int bit = __ffsll((long long)b) - 1;
+      b &= b - 1;
+      int dz, dy, dx;
+      t8_offset(bit & 15, dz, dy, dx);
+      worklist[wbase + wpos++] = make_int2(lb[bit >> 4], (int)gi + (bit >> 4) + dz * plane + dy * Nx + dx);
     }
-  }
-  if ((blockIdx.x & 63) == 0) {   // a sample of the tiles is enough (one atomic per wave of EVERY tile cost 0.6 - 1 ms)
-    for (int o = 32; o > 0; o >>= 1) nroots += __shfl_xor(nroots, o);
-    if ((threadIdx.x & 63) == 0 && nroots) atomicAdd(flags + 3, nroots);
   }
 }
 
-// glszm_border_full_kernel on the packed levels: one byte load per neighbour instead of mask + int32 level
+// find / union in the dense parent array (smaller id = closer to the root, as in the label volume)
+#ifndef PRAD_DN_LOAD
+#define PRAD_DN_LOAD 2
+#endif
+__device__ __forceinline__ int dn_load(const int *p) {
+#if PRAD_DN_LOAD == 1      // (probe builds) device-scope load: past this XCD's L2
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif PRAD_DN_LOAD == 2    // plain load
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#else
+  return __builtin_nontemporal_load(p);
+#endif
+}
+#ifdef PRAD_DN_NOHALVE
+#define PRAD_DN_HALVE(stmt)
+#else
+#define PRAD_DN_HALVE(stmt) stmt
+#endif
+__device__ __forceinline__ int dn_find(int *parent, int i) {
+  int p = dn_load(parent + i);
+  while (p != i) {
+    const int g = dn_load(parent + p);
+    if (g != p) parent[i] = g;
+    i = p;
+    p = g;
+  }
+  return i;
+}
+__device__ __forceinline__ void dn_union(int *parent, int a, int b) {     // both finds in flight together
+  while (true) {
+    int pa = dn_load(parent + a), pb = dn_load(parent + b);
+    while (pa != a || pb != b) {
+      const int ga = dn_load(parent + pa), gb = dn_load(parent + pb);
+      if (pa != a) {
+        PRAD_DN_HALVE(if (ga != pa) parent[a] = ga;)
+        a = pa;
+        pa = ga;
+      }
+      if (pb != b) {
+        PRAD_DN_HALVE(if (gb != pb) parent[b] = gb;)
+        b = pb;
+        pb = gb;
+      }
+    }
+    if (a == b) return;
+    if (a < b) { int t = a; a = b; b = t; }
+    const int old = atomicMin(parent + a, b);
+    if (old == a) return;
+    a = old;
+  }
+}
+
+// The work list: one lane per pair.  A pair of tile roots that repeats the previous lane's (neighbouring voxels of the
+// same two tile components) is skipped.
+__global__ void __launch_bounds__(256) glszm_pairs_kernel(const int2 *__restrict__ worklist,
+                                                          const int *__restrict__ rootctl, const int *__restrict__ vid,
+                                                          int *__restrict__ parent, const int *__restrict__ flags) {
+  if (flags[0] || rootctl[3]) return;
+  const int total = rootctl[2];
+  const int stride = gridDim.x * blockDim.x;
+  const int lane = threadIdx.x & 63;
+  for (int j0 = blockIdx.x * blockDim.x; j0 < total; j0 += stride) {      // (whole waves stay in the loop: shuffles)
+    const int j = j0 + threadIdx.x;
+    int a = -1, b = -1;
+    if (j < total) {
+      const int2 p = worklist[j];
+      a = p.x;
+      b = vid[p.y];
+    }
+    const int pa = __shfl_up(a, 1), pb = __shfl_up(b, 1);
+    if (a >= 0 && a != b && !(lane > 0 && pa == a && pb == b)) dn_union(parent, a, b);
+  }
+}
+
+// The route of a full work list: the faces of the tiles scanned on the level volume, one voxel per lane, the redundancy
+// rules of glszm_border_full_kernel on GLOBAL sameness (a superset of what the work list would have held).
 template <int MODE>
-__global__ void __launch_bounds__(256) glszm_border8_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx,
-                                                            int *__restrict__ labels, const int *__restrict__ flags) {
-  if (flags[0]) return;
+__global__ void __launch_bounds__(256) glszm_border8d_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx,
+                                                             const int *__restrict__ vid, int *__restrict__ parent,
+                                                             const int *__restrict__ flags,
+                                                             const int *__restrict__ rootctl) {
+  if (flags[0] || !rootctl[3]) return;
   const int lane = threadIdx.x & 63;
   const long long nrows = (long long)Nz * Ny;
   const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -679,7 +812,7 @@ __global__ void __launch_bounds__(256) glszm_border8_kernel(const uint8_t *__res
       int gl = 0, li = -1;
       if (x >= 0 && x < Nx) {
         gl = L[rbase + x];
-        if (gl) li = labels[rbase + x];
+        if (gl) li = vid[rbase + x];
       }
       if (__ballot(li >= 0) == 0ull) continue;
       auto same = [&](int dz, int dy, int dx) -> long long {
@@ -693,10 +826,10 @@ __global__ void __launch_bounds__(256) glszm_border8_kernel(const uint8_t *__res
         if (j >= 0) {
           const int qz = z + dz, qy = y + dy, qx = x + dx;
           const bool same_tile = qz / PRAD_TZ == z / PRAD_TZ && qy / PRAD_TY == y / PRAD_TY && qx / PRAD_TX == x / PRAD_TX;
-          if (!same_tile) lj = labels[j];
+          if (!same_tile) lj = vid[j];
         }
         const int pi = __shfl_up(li, 1), pj = __shfl_up(lj, 1);
-        if (lj >= 0 && !(lane > 0 && pi == li && pj == lj)) uf_union(labels, li, lj);
+        if (lj >= 0 && !(lane > 0 && pi == li && pj == lj)) dn_union(parent, li, lj);
       };
       const bool live = li >= 0;
       const long long jb = live ? same(0, -1, 0) : -1;
@@ -727,342 +860,77 @@ __global__ void __launch_bounds__(256) glszm_border8_kernel(const uint8_t *__res
   }
 }
 
-// Border scan on the packed levels, 4 voxels per lane (Nx % 4 == 0).  Two loops over the rows (z, y):
-//   A  rows on a z- or y-face of their tile: a lane takes 4 x-adjacent voxels, gets the "same level" flags of all
-//      their backward neighbours from 3 loads per neighbour row (as glszm_tile8_kernel, but on global memory),
-//      applies the redundancy rules to GLOBAL sameness (see glszm_border_full_kernel) and unites only the selected
-//      pairs that straddle a tile boundary; a pair (root, root) that repeats the previous one of the lane is skipped;
-//   B  all other rows: only the voxels on the two x-faces of every tile (x mod 64 in {0, 63}) can have a backward
-//      neighbour in another tile; they are enumerated densely over the lanes (several rows per wave).
-template <int MODE>
-__global__ void __launch_bounds__(256) glszm_border8q_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx,
-                                                             int *__restrict__ labels, const int *__restrict__ flags,
-                                                             long long strips_below) {
+__global__ void __launch_bounds__(256) glszm_dense_init_kernel(const int *__restrict__ rootctl, const unsigned *__restrict__ tinfo,
+                                                               int *__restrict__ parent, unsigned *__restrict__ zsize,
+                                                               const int *__restrict__ flags) {
   if (flags[0]) return;
-  if (flags[3] < strips_below) return;       // glszm_border8s_kernel took this volume (0: this kernel always runs)
-  const int lane = threadIdx.x & 63;
-  const long long nrows = (long long)Nz * Ny;
-  const long long wave0 = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6);
-  const long long plane = (long long)Ny * Nx;
-  // ---- loop A
-  for (long long row = wave0; row < nrows; row += nwaves) {
-    const int z = (int)(row / Ny), y = (int)(row - (long long)z * Ny);
-    const bool zedge = MODE == 1 && (z % PRAD_TZ == 0), y0edge = (y % PRAD_TY == 0);
-    const bool y7edge = MODE == 1 && (y % PRAD_TY == PRAD_TY - 1);
-    if (!(zedge || y0edge || y7edge)) continue;
-    const long long rbase = row * Nx;
-    for (int x = 4 * lane; x < Nx; x += 256) {
-      const unsigned centre = *reinterpret_cast<const unsigned *>(L + rbase + x);
-      if (!centre) continue;
-      unsigned crep[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) crep[k] = ((centre >> (8 * k)) & 0xffu) * 0x010101u;
-      unsigned e[4][4];
-#pragma unroll
-      for (int r = 0; r < (MODE == 1 ? 4 : 1); r++) {
-        const int dz = r == 0 ? 0 : -1, dy = r == 0 ? -1 : r - 2;
-        const int qz = z + dz, qy = y + dy;
-        unsigned lo = 0u, hi = 0u;
-        if ((unsigned)qz < (unsigned)Nz && (unsigned)qy < (unsigned)Ny) {
-          const uint8_t *rp = L + rbase + dz * plane + (long long)dy * Nx + x;
-          const unsigned mid = *reinterpret_cast<const unsigned *>(rp);
-          const unsigned left = x > 0 ? rp[-1] : 0u, right = x + 4 < Nx ? rp[4] : 0u;
-          lo = left | (mid << 8);
-          hi = (mid >> 24) | (right << 8);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const unsigned w = __builtin_amdgcn_alignbyte(hi, lo, k) & 0xffffffu;
-          e[r][k] = t8_nonzero3(w ^ crep[k]) ^ 0x808080u;
-        }
-      }
-      const unsigned lo0 = (x > 0 ? (unsigned)L[rbase + x - 1] : 0u) | (centre << 8);
-      // neighbours that lie in another tile: by row (wave-uniform) and by the voxel's position on an x-face
-      const unsigned rowcross = (zedge ? 0xff8u : 0u) | (y0edge ? 0x3fu : 0u) | (y7edge ? 0xe00u : 0u);
-      unsigned long long todo = 0ull;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const unsigned c = (centre >> (8 * k)) & 0xffu;
-        unsigned S = t8_flags3(e[0][k]) | ((((lo0 >> (8 * k)) & 0xffu) == c) ? 0x1000u : 0u);
-        if (MODE == 1) S |= (t8_flags3(e[1][k]) << 3) | (t8_flags3(e[2][k]) << 6) | (t8_flags3(e[3][k]) << 9);
-        const int xx = x + k;
-        const unsigned cross = rowcross | ((xx % PRAD_TX) == 0 ? 0x1249u : 0u) | ((xx % PRAD_TX) == PRAD_TX - 1 ? 0x924u : 0u);
-        todo |= (unsigned long long)(c ? (t8_select<MODE>(S) & cross) : 0u) << (16 * k);
-      }
-      int pli = -1, plj = -1, lk = -1, li = -1;
-      while (todo) {
-        const int bit = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int k = bit >> 4;
-        int dz, dy, dx;
-        t8_offset(bit & 15, dz, dy, dx);
-        const long long i = rbase + x + k;
-        if (k != lk) { li = labels[i]; lk = k; }
-        const int lj = labels[i + dz * plane + (long long)dy * Nx + dx];
-        if (li == pli && lj == plj) continue;      // the same two tile components as the previous pair
-        pli = li;
-        plj = lj;
-        uf_union(labels, li, lj);
-      }
-    }
-  }
-  // ---- loop B: x-faces of the tiles in the remaining rows
-  const int xtiles = (Nx + PRAD_TX - 1) / PRAD_TX;
-  const int cpr = 2 * xtiles;                        // candidates per row
-  const long long ncand = nrows * cpr;
-  const long long tid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, nthreads = (long long)gridDim.x * blockDim.x;
-  for (long long id = tid0; id < ncand; id += nthreads) {
-    const long long row = id / cpr;
-    const int cnd = (int)(id - row * cpr);
-    const int z = (int)(row / Ny), y = (int)(row - (long long)z * Ny);
-    if ((MODE == 1 && z % PRAD_TZ == 0) || (y % PRAD_TY == 0) || (MODE == 1 && y % PRAD_TY == PRAD_TY - 1)) continue;
-    const int x = (cnd >> 1) * PRAD_TX + ((cnd & 1) ? PRAD_TX - 1 : 0);
-    if (x >= Nx) continue;
-    const long long i = row * Nx + x;
-    const int gl = L[i];
-    if (!gl) continue;
-    const int dxc = (cnd & 1) ? 1 : -1;              // the only dx that leaves the tile from this face
-    if ((unsigned)(x + dxc) >= (unsigned)Nx) continue;
-    auto same = [&](int dz, int dy, int dx) -> bool {
-      const int qz = z + dz, qy = y + dy, qx = x + dx;
-      if ((unsigned)qz >= (unsigned)Nz || (unsigned)qy >= (unsigned)Ny || (unsigned)qx >= (unsigned)Nx) return false;
-      return L[i + dz * plane + (long long)dy * Nx + dx] == gl;
-    };
-    int li = -1;
-    auto pair = [&](int dz, int dy, int dx) {
-      if (dx != dxc) return;                          // stays inside the tile (this row is on no z- / y-face)
-      if (li < 0) li = labels[i];
-      uf_union(labels, li, labels[i + dz * plane + (long long)dy * Nx + dx]);
-    };
-    // the rules need the sameness of the neighbours that can make a cross-tile pair redundant
-    if (!same(0, -1, 0)) {
-      if (dxc > 0) { if (same(0, -1, 1)) pair(0, -1, 1); }
-      else {
-        if (same(0, -1, -1)) pair(0, -1, -1);
-        else if (same(0, 0, -1)) pair(0, 0, -1);
-      }
-    }
-    if (MODE == 1 && !same(-1, 0, 0)) {
-      const bool e1 = same(-1, -1, 0), e2 = same(-1, 1, 0);
-      if (dxc < 0) {
-        const bool e3 = same(-1, 0, -1);
-        if (e3) pair(-1, 0, -1);
-        if (!e1 && !e3 && same(-1, -1, -1)) pair(-1, -1, -1);
-        if (!e2 && !e3 && same(-1, 1, -1)) pair(-1, 1, -1);
-      } else {
-        const bool e4 = same(-1, 0, 1);
-        if (e4) pair(-1, 0, 1);
-        if (!e1 && !e4 && same(-1, -1, 1)) pair(-1, -1, 1);
-        if (!e2 && !e4 && same(-1, 1, 1)) pair(-1, 1, 1);
-      }
-    }
+  const int m = rootctl[0];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+    parent[j] = j;
+    zsize[j] = tinfo[j] & 0xffffu;
   }
 }
 
-// The same scan, one workgroup per STRIP of tiles (the x-row of tiles at one (z-tile, y-tile)), with the unions made
-// wide instead of deep.  On smooth volumes a zone crosses a tile face along a curve of tens of voxels, every voxel of
-// it asking for the same union of two tile roots; a lane that walks its <= 52 pairs one after the other pays the
-// dependent loads of two finds + an atomic for each, with the rest of the wave waiting on the slowest lane (3.8 of
-// the 4.5 ms of glszm_border8q_kernel at 512^3 smooth).  Here the (root, root) pairs of the strip go into an LDS hash
-// set first (64-bit compare-and-swap, linear probing); afterwards every lane takes ONE distinct pair from the set and
-// unites it, so the finds of a wave are independent chains in flight together.  A full table falls back to the
-// direct union (always correct).
-#define PRAD_BS_SLOTS 4096
-#define PRAD_BS_LIST 2048
-template <int MODE>
-__global__ void __launch_bounds__(256) glszm_border8s_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx,
-                                                             int *__restrict__ labels, const int *__restrict__ flags,
-                                                             long long strips_below) {
-  if (flags[0]) return;
-  if (flags[3] >= strips_below) return;      // a volume of tiny zones: glszm_border8q_kernel takes it
-  __shared__ unsigned long long tab[PRAD_BS_SLOTS];
-  __shared__ unsigned long long list[PRAD_BS_LIST];   // the distinct pairs in the order they were met (dense: every lane
-  __shared__ int nlist;                               // of the union phase has work, neighbours hold nearby labels)
-  const unsigned long long EMPTY = ~0ull;
-  for (int i = threadIdx.x; i < PRAD_BS_SLOTS; i += blockDim.x) tab[i] = EMPTY;
-  if (threadIdx.x == 0) nlist = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int ytiles = (Ny + PRAD_TY - 1) / PRAD_TY;
-  const int tz = blockIdx.x / ytiles, ty = blockIdx.x - tz * ytiles;
-  const int z0 = tz * PRAD_TZ, y0 = ty * PRAD_TY;
-  const long long plane = (long long)Ny * Nx;
-  auto emit = [&](int li, int lj) {
-    if (li == lj) return;
-    const unsigned a = (unsigned)max(li, lj), b = (unsigned)min(li, lj);
-    const unsigned long long key = ((unsigned long long)a << 32) | b;
-    unsigned h = (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u);
-    h = (h ^ (h >> 15)) & (PRAD_BS_SLOTS - 1);
-    for (int probe = 0; probe < 16; probe++) {
-      const unsigned long long old = atomicCAS(&tab[h], EMPTY, key);
-      if (old == EMPTY) {
-        const int at = atomicAdd(&nlist, 1);
-        if (at < PRAD_BS_LIST) list[at] = key;
-        else uf_union(labels, li, lj);     // (list full)
-        return;
-      }
-      if (old == key) return;
-      h = (h + 1) & (PRAD_BS_SLOTS - 1);
-    }
-    uf_union(labels, li, lj);    // (crowded table)
-  };
-  auto flush = [&]() {      // the distinct pairs, one per lane
-    __syncthreads();
-    const int n = min(nlist, PRAD_BS_LIST);
-#ifndef PRAD_DBG_NOUNION
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const unsigned long long key = list[i];
-      uf_union_wide(labels, (int)(key >> 32), (int)(key & 0xffffffffu));
-    }
-#endif
-  };
-  // ---- face rows of the strip (loop A of glszm_border8q_kernel)
-  {
-  for (int rr = wave; rr < PRAD_TZ * PRAD_TY; rr += nw) {
-    const int zz = rr / PRAD_TY, yy = rr - zz * PRAD_TY;
-    const int z = z0 + zz, y = y0 + yy;
-    if (z >= Nz || y >= Ny) continue;
-    const bool zedge = MODE == 1 && zz == 0, y0edge = yy == 0, y7edge = MODE == 1 && yy == PRAD_TY - 1;
-    if (!(zedge || y0edge || y7edge)) continue;
-    const long long rbase = ((long long)z * Ny + y) * Nx;
-    for (int x = 4 * lane; x < Nx; x += 256) {
-      const unsigned centre = *reinterpret_cast<const unsigned *>(L + rbase + x);
-      if (!centre) continue;
-      unsigned crep[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) crep[k] = ((centre >> (8 * k)) & 0xffu) * 0x010101u;
-      unsigned e[4][4];
-#pragma unroll
-      for (int r = 0; r < (MODE == 1 ? 4 : 1); r++) {
-        const int dz = r == 0 ? 0 : -1, dy = r == 0 ? -1 : r - 2;
-        const int qz = z + dz, qy = y + dy;
-        unsigned lo = 0u, hi = 0u;
-        if ((unsigned)qz < (unsigned)Nz && (unsigned)qy < (unsigned)Ny) {
-          const uint8_t *rp = L + rbase + dz * plane + (long long)dy * Nx + x;
-          const unsigned mid = *reinterpret_cast<const unsigned *>(rp);
-          const unsigned left = x > 0 ? rp[-1] : 0u, right = x + 4 < Nx ? rp[4] : 0u;
-          lo = left | (mid << 8);
-          hi = (mid >> 24) | (right << 8);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const unsigned w = __builtin_amdgcn_alignbyte(hi, lo, k) & 0xffffffu;
-          e[r][k] = t8_nonzero3(w ^ crep[k]) ^ 0x808080u;
-        }
-      }
-      const unsigned lo0 = (x > 0 ? (unsigned)L[rbase + x - 1] : 0u) | (centre << 8);
-      const unsigned rowcross = (zedge ? 0xff8u : 0u) | (y0edge ? 0x3fu : 0u) | (y7edge ? 0xe00u : 0u);
-      unsigned long long todo = 0ull;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const unsigned c = (centre >> (8 * k)) & 0xffu;
-        unsigned S = t8_flags3(e[0][k]) | ((((lo0 >> (8 * k)) & 0xffu) == c) ? 0x1000u : 0u);
-        if (MODE == 1) S |= (t8_flags3(e[1][k]) << 3) | (t8_flags3(e[2][k]) << 6) | (t8_flags3(e[3][k]) << 9);
-        const int xx = x + k;
-        const unsigned cross = rowcross | ((xx % PRAD_TX) == 0 ? 0x1249u : 0u) | ((xx % PRAD_TX) == PRAD_TX - 1 ? 0x924u : 0u);
-        todo |= (unsigned long long)(c ? (t8_select<MODE>(S) & cross) : 0u) << (16 * k);
-      }
-      int pli = -1, plj = -1, lk = -1, li = -1;
-      while (todo) {
-        const int bit = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int k = bit >> 4;
-        int dz, dy, dx;
-        t8_offset(bit & 15, dz, dy, dx);
-        const long long i = rbase + x + k;
-        if (k != lk) { li = labels[i]; lk = k; }
-        const int lj = labels[i + dz * plane + (long long)dy * Nx + dx];
-        if (li == pli && lj == plj) continue;      // the same two tile components as the previous pair
-        pli = li;
-        plj = lj;
-        emit(li, lj);
-      }
-    }
-  }
-  }
-  // ---- x-faces of the tiles in the other rows of the strip (loop B)
-  const int xtiles = (Nx + PRAD_TX - 1) / PRAD_TX;
-  const int cpr = 2 * xtiles;
-  for (int id = threadIdx.x; id < PRAD_TZ * PRAD_TY * cpr; id += blockDim.x) {
-    const int rr = id / cpr, cnd = id - rr * cpr;
-    const int zz = rr / PRAD_TY, yy = rr - zz * PRAD_TY;
-    const int z = z0 + zz, y = y0 + yy;
-    if (z >= Nz || y >= Ny) continue;
-    if ((MODE == 1 && zz == 0) || yy == 0 || (MODE == 1 && yy == PRAD_TY - 1)) continue;
-    const int x = (cnd >> 1) * PRAD_TX + ((cnd & 1) ? PRAD_TX - 1 : 0);
-    if (x >= Nx) continue;
-    const long long i = ((long long)z * Ny + y) * Nx + x;
-    const int gl = L[i];
-    if (!gl) continue;
-    const int dxc = (cnd & 1) ? 1 : -1;
-    if ((unsigned)(x + dxc) >= (unsigned)Nx) continue;
-    auto same = [&](int dz, int dy, int dx) -> bool {
-      const int qz = z + dz, qy = y + dy, qx = x + dx;
-      if ((unsigned)qz >= (unsigned)Nz || (unsigned)qy >= (unsigned)Ny || (unsigned)qx >= (unsigned)Nx) return false;
-      return L[i + dz * plane + (long long)dy * Nx + dx] == gl;
-    };
-    int li = -1;
-    auto pair = [&](int dz, int dy, int dx) {
-      if (dx != dxc) return;
-      if (li < 0) li = labels[i];
-      emit(li, labels[i + dz * plane + (long long)dy * Nx + dx]);
-    };
-    if (!same(0, -1, 0)) {
-      if (dxc > 0) { if (same(0, -1, 1)) pair(0, -1, 1); }
-      else {
-        if (same(0, -1, -1)) pair(0, -1, -1);
-        else if (same(0, 0, -1)) pair(0, 0, -1);
-      }
-    }
-    if (MODE == 1 && !same(-1, 0, 0)) {
-      const bool e1 = same(-1, -1, 0), e2 = same(-1, 1, 0);
-      if (dxc < 0) {
-        const bool e3 = same(-1, 0, -1);
-        if (e3) pair(-1, 0, -1);
-        if (!e1 && !e3 && same(-1, -1, -1)) pair(-1, -1, -1);
-        if (!e2 && !e3 && same(-1, 1, -1)) pair(-1, 1, -1);
-      } else {
-        const bool e4 = same(-1, 0, 1);
-        if (e4) pair(-1, 0, 1);
-        if (!e1 && !e4 && same(-1, -1, 1)) pair(-1, -1, 1);
-        if (!e2 && !e4 && same(-1, 1, 1)) pair(-1, 1, 1);
-      }
-    }
-  }
-  flush();
-}
-
-// tiled path: sizes[] holds the voxel count of every tile-local component at its tile root; fold the counts of
-// tile roots that were linked elsewhere into their global root.  One find per (zone, tile) instead of per voxel.
-// A zone that spans thousands of tiles would otherwise receive thousands of atomics on one address, so every block
-// owns a CONTIGUOUS slab of voxels and first combines contributions to the same root in an LDS hash table.
+// Counts of the tile components folded into their zone roots: one find per tile root in the dense array; contributions
+// to the same zone root are combined in an LDS hash table first (a zone that spans thousands of tiles would otherwise
+// receive thousands of atomics on one address).  parent[] is flat afterwards (every entry points at its zone root).
 #define PRAD_RS_SLOTS 1024
-#ifndef PRAD_RS_CHUNK
-#define PRAD_RS_CHUNK (64 * 256)       // voxels per block (256^3: 1024 blocks; with 65536 the kernel ran 256 blocks, 3x slower)
-#endif
-__global__ void __launch_bounds__(256) glszm_rootsum_kernel(long long n, int *__restrict__ labels,
-                                                            unsigned *__restrict__ sizes,
-                                                            const int *__restrict__ flags,
-                                                            const int *__restrict__ rootlist,
-                                                            const int *__restrict__ rootctl) {
+__global__ void __launch_bounds__(256) glszm_rootsum_dense_kernel(const int *__restrict__ rootctl, int *__restrict__ parent,
+                                                                  unsigned *__restrict__ tsize,
+                                                                  const int *__restrict__ flags) {
   __shared__ int hkey[PRAD_RS_SLOTS];
   __shared__ unsigned hval[PRAD_RS_SLOTS];
-  if (flags && flags[0]) return;   // the packed-byte kernels did not run: labels are not valid
-  const bool listmode = rootctl && rootctl[1] == 0;
-  const long long total = listmode ? (long long)rootctl[0] : n;
-  // (list mode: the entries are spread over the whole grid, 1024 or more per block -- slabs of PRAD_RS_CHUNK would
-  // leave a 256^3 volume with 37 busy workgroups)
-  const long long per = listmode ? max(1024LL, (total + gridDim.x - 1) / gridDim.x) : (long long)PRAD_RS_CHUNK;
-  const long long lo = (long long)blockIdx.x * per, hi = min(total, lo + per);
+  if (flags[0]) return;
+  const int total = rootctl[0];
+  const int per = max(1024, (total + (int)gridDim.x - 1) / (int)gridDim.x);
+  const long long lo = (long long)blockIdx.x * per, hi = min((long long)total, lo + per);
   if (lo >= hi) return;
   for (int k = threadIdx.x; k < PRAD_RS_SLOTS; k += blockDim.x) {
     hkey[k] = -1;
     hval[k] = 0u;
   }
   __syncthreads();
-  for (long long j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-    const long long i = listmode ? (long long)rootlist[j] : j;
+  for (int j = (int)lo + threadIdx.x; j < (int)hi; j += blockDim.x) {
+    const int p = parent[j];
+    if (p == j) continue;
+    const int r = dn_find(parent, p);
+    parent[j] = r;
+    const unsigned sz = tsize[j];
+    unsigned slot = ((unsigned)r * 2654435761u) >> 22;          // 10 bits
+    bool done = false;
+    for (int probe = 0; probe < 8 && !done; probe++, slot = (slot + 1) & (PRAD_RS_SLOTS - 1)) {
+      const int old = atomicCAS(hkey + slot, -1, r);
+      if (old == -1 || old == r) {
+        atomicAdd(hval + slot, sz);
+        done = true;
+      }
+    }
+    if (!done) atomicAdd(tsize + r, sz);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < PRAD_RS_SLOTS; k += blockDim.x)
+    if (hkey[k] >= 0 && hval[k]) atomicAdd(tsize + hkey[k], hval[k]);
+}
+
+// int32 tile path: sizes[] holds the voxel count of every tile-local component at its tile root; fold the counts of
+// tile roots that were linked elsewhere into their global root.  One find per (zone, tile) instead of per voxel.
+// A zone that spans thousands of tiles would otherwise receive thousands of atomics on one address, so every block
+// owns a CONTIGUOUS slab of voxels and first combines contributions to the same root in an LDS hash table.
+#ifndef PRAD_RS_CHUNK
+#define PRAD_RS_CHUNK (64 * 256)       // voxels per block (256^3: 1024 blocks; with 65536 the kernel ran 256 blocks, 3x slower)
+#endif
+__global__ void __launch_bounds__(256) glszm_rootsum_kernel(long long n, int *__restrict__ labels,
+                                                            unsigned *__restrict__ sizes) {
+  __shared__ int hkey[PRAD_RS_SLOTS];
+  __shared__ unsigned hval[PRAD_RS_SLOTS];
+  const long long lo = (long long)blockIdx.x * PRAD_RS_CHUNK, hi = min(n, lo + PRAD_RS_CHUNK);
+  if (lo >= hi) return;
+  for (int k = threadIdx.x; k < PRAD_RS_SLOTS; k += blockDim.x) {
+    hkey[k] = -1;
+    hval[k] = 0u;
+  }
+  __syncthreads();
+  for (long long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const unsigned sz = sizes[i];
     if (sz == 0u) continue;
     const int l = labels[i];
@@ -1124,8 +992,10 @@ __global__ void __launch_bounds__(256) glszm_stats_kernel(long long n, const int
                                                           unsigned *__restrict__ small_bits, int *__restrict__ large_list,
                                                           int large_cap, int *__restrict__ large_count,
                                                           const int *__restrict__ flags,
-                                                          const int *__restrict__ rootlist = nullptr,
+                                                          const int *__restrict__ parent = nullptr,
                                                           const int *__restrict__ rootctl = nullptr) {
+  // parent != nullptr: the dense model (glszm_tile8_kernel) -- entry j < rootctl[0] is a zone root when parent[j] == j and
+  // `sizes` is tsize[]; otherwise the zone roots are the voxels with labels[i] == i
   __shared__ unsigned bits[PRAD_SMALL_SIZES / 32];
   __shared__ unsigned smx;
   __shared__ unsigned long long scnt;
@@ -1148,12 +1018,10 @@ __global__ void __launch_bounds__(256) glszm_stats_kernel(long long n, const int
       if (pos < large_cap) large_list[pos] = (int)sz;
     }
   };
-  if (rootctl && rootctl[1] == 0) {      // the tile-root list: a zone root is a tile root that kept its label
+  if (parent) {
     const long long m = rootctl[0];
-    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
-      const int i = rootlist[j];
-      if (labels[i] == i) root(i);
-    }
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride)
+      if (parent[j] == (int)j) root(j);
   } else {
     // the scan is a stream over the labels: 16 B per lane and load
     const long long n4 = n >> 2;
@@ -1205,15 +1073,19 @@ __global__ void __launch_bounds__(256) glszm_fill_segment_kernel(long long n, co
                                                                  const unsigned *__restrict__ sizes,
                                                                  const int *__restrict__ image, int Ng, int maxRegion,
                                                                  int RL, double *__restrict__ out,
-                                                                 int *__restrict__ err) {
+                                                                 int *__restrict__ err,
+                                                                 const int *__restrict__ parent = nullptr,
+                                                                 const int *__restrict__ rootctl = nullptr,
+                                                                 const unsigned *__restrict__ tinfo = nullptr) {
   extern __shared__ unsigned fh[];
   for (int k = threadIdx.x; k < Ng * RL; k += blockDim.x) fh[k] = 0u;
   __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
   const unsigned long long idx_max = (unsigned long long)Ng * maxRegion;
+  if (parent) n = rootctl[0];            // the dense model: entries of the tile-root list, levels from tinfo[]
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    if (labels[i] != (int)i) continue;
-    const int gl = image[i];
+    if ((parent ? parent[i] : labels[i]) != (int)i) continue;
+    const int gl = parent ? (int)(tinfo[i] >> 16) : image[i];
     const unsigned sz = sizes[i];
     const unsigned long long idx = (unsigned long long)((long long)(gl - 1) * maxRegion + (long long)sz - 1);
     if (gl <= 0 || idx >= idx_max) {  // cmatrices.c:290-291
@@ -1237,9 +1109,10 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
                                                                  const int *__restrict__ small_rank, int nsmall,
                                                                  const int *__restrict__ large_sorted, int nlarge,
                                                                  double *__restrict__ out, int *__restrict__ err,
-                                                                 const int *__restrict__ rootlist = nullptr,
+                                                                 const int *__restrict__ parent = nullptr,
                                                                  const int *__restrict__ rootctl = nullptr,
-                                                                 const int *__restrict__ meta = nullptr, int kstride = 0) {
+                                                                 const int *__restrict__ meta = nullptr, int kstride = 0,
+                                                                 const unsigned *__restrict__ tinfo = nullptr) {
   extern __shared__ unsigned fh[];
   // meta (glszm_rank_kernel: the distinct sizes were ranked on the device, the host does not know k): nsmall, nlarge, k
   // come from there, the rows of `out` are kstride (the capacity) apart; meta[3] != 0: nothing to fill
@@ -1255,7 +1128,7 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
   __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
   auto root = [&](long long i) {
-    const int gl = image[i];
+    const int gl = parent ? (int)(tinfo[i] >> 16) : image[i];
     const int r = glszm_rank(sizes[i], small_rank, nsmall, large_sorted, nlarge);
     if (gl <= 0 || gl > Ng || r < 0 || r >= k) {
       *err = 1;
@@ -1264,12 +1137,10 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
     if (r < RL) atomicAdd(fh + (gl - 1) * RL + r, 1u);
     else atomicAdd(out + (size_t)(gl - 1) * kstride + r, 1.0);
   };
-  if (rootctl && rootctl[1] == 0) {      // the tile-root list (glszm_tile8_kernel)
+  if (parent) {      // the dense model (glszm_tile8_kernel): `sizes` is tsize[]
     const long long m = rootctl[0];
-    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
-      const int i = rootlist[j];
-      if (labels[i] == i) root(i);
-    }
+    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride)
+      if (parent[j] == (int)j) root(j);
   } else {
     const long long n4 = n >> 2;
     const int4 *lab4 = reinterpret_cast<const int4 *>(labels);
@@ -1393,6 +1264,29 @@ __global__ void __launch_bounds__(1024) glszm_rank_kernel(const unsigned *__rest
 // out[16] of the feature block <- verdict (0 = fine): meta[3] of the ranking, the fill's error word
 __global__ void glszm_verdict_kernel(const int *__restrict__ meta, const int *__restrict__ err, double *__restrict__ out) {
   out[0] = (double)(meta[3] | (err[0] ? 8 : 0));
+}
+
+// dense model -> the label-volume view the ordered zone list needs: the first voxel of every zone (a scan of vid[])
+__global__ void __launch_bounds__(256) glszm_zmin_kernel(long long n, const int *__restrict__ vid, const int *__restrict__ parent,
+                                                         int *__restrict__ zmin) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += stride) {
+    const int id = vid[v];
+    if (id < 0) continue;
+    const int r = parent[id];
+    if (zmin[r] > (int)v) atomicMin(zmin + r, (int)v);
+  }
+}
+__global__ void __launch_bounds__(256) glszm_publish_kernel(const int *__restrict__ rootctl, const int *__restrict__ parent,
+                                                            const unsigned *__restrict__ tsize, const int *__restrict__ zmin,
+                                                            int *__restrict__ labels, unsigned *__restrict__ zsz) {
+  const int m = rootctl[0];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x)
+    if (parent[j] == j) {
+      const int v = zmin[j];
+      labels[v] = v;
+      zsz[v] = tsize[j];
+    }
 }
 
 // ordered zone list (tempData parity): block counts -> scan -> scatter
@@ -1575,6 +1469,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
   // no copy back, no synchronisation -- zone count, largest zone and the flags stay on the device ("glszm_stats", "flags")
   GlszmState &st = glszm_state();
   st.valid = false;
+  st.published = false;
   int *stats = nullptr;
   PRAD_TRY(c.get<int>("glszm_stats", 8, &stats));
   unsigned long long *stats64 = (unsigned long long *)(stats + 2);
@@ -1641,52 +1536,41 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
         const long long tiles = (long long)((dims3[0] + PRAD_TZ - 1) / PRAD_TZ) * ((dims3[1] + PRAD_TY - 1) / PRAD_TY) *
                                 ((dims3[2] + PRAD_TX - 1) / PRAD_TX);
         const dim3 bgrid((unsigned)std::min<long long>(((long long)dims3[0] * dims3[1] + 3) / 4, 16384));
-        const dim3 sgrid((unsigned)(((dims3[0] + PRAD_TZ - 1) / PRAD_TZ) * ((dims3[1] + PRAD_TY - 1) / PRAD_TY)));
         if (bytes) {
+          // the dense model: glszm_tile8_kernel lists the cross-tile pairs (it holds the levels with their halo in LDS),
+          // glszm_pairs_kernel unites the tile roots; a full work list (decided on the device: rootctl[3]) sends the
+          // call through glszm_border8d_kernel instead.  PRAD_GLSZM_WORKCAP: a test hook -- a tiny list forces that route.
           uint8_t *levels = nullptr;
+          const char *wcap = getenv("PRAD_GLSZM_WORKCAP");
+          const int workcap = wcap ? std::max(1, atoi(wcap)) : (int)std::min<long long>(1LL << 30, std::max<long long>(g.n, 65536));
+          int2 *work = nullptr;
           PRAD_HIP(hipMemsetAsync(flags_d, 0, sizeof(int) * 4, s));
-          PRAD_TRY(c.get<int>("glszm_rootlist", (size_t)tiles * PRAD_GZ_TILE_ROOTS, &st.rootlist));
+          PRAD_TRY(c.get<int>("glszm_parent", (size_t)g.n, &st.parent));
+          PRAD_TRY(c.get<unsigned>("glszm_tinfo", (size_t)g.n, &st.tinfo));
           PRAD_TRY(c.get<int>("glszm_rootctl", 4, &st.rootctl));
+          PRAD_TRY(c.get<int2>("glszm_worklist", (size_t)workcap, &work));
           PRAD_HIP(hipMemsetAsync(st.rootctl, 0, sizeof(int) * 4, s));
           PRAD_TRY(neigh_pack(&c, s, g, image, mask, Ng, flags_d, &levels));
-          if (mode == 1) {
-            hipLaunchKernelGGL(glszm_tile8_kernel<1>, dim3((unsigned)tiles), dim3(256), 0, s, levels, dims3[0], dims3[1],
-                               dims3[2], st.labels, st.sizes, flags_d, st.rootlist, st.rootctl);
-            if ((dims3[2] & 3) == 0) {
-              // Both are launched, the device picks: flags[3] = number of tile-local components in every 64th tile (glszm_tile8_kernel).
-              // Many voxels per component (structured images) -> the strip kernel with its de-duplicated wide
-              // unions (512^3 smooth 4.6 -> 1.7 ms); iid levels make every pair distinct and the hash set pure
-              // overhead (0.67 -> 1.09 ms), they stay on the row scan.
-              const long long strips_below = getenv("PRAD_GLSZM_NO_STRIPS") ? 0 : std::max<long long>(1, ((tiles + 63) / 64) * PRAD_TVOX / 8);
-              hipLaunchKernelGGL(glszm_border8s_kernel<1>, sgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],
-                                 st.labels, flags_d, strips_below);
-              hipLaunchKernelGGL(glszm_border8q_kernel<1>, bgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],
-                                 st.labels, flags_d, strips_below);
-            }
-            else
-              hipLaunchKernelGGL(glszm_border8_kernel<1>, bgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],
-                                 st.labels, flags_d);
-          } else {
-            hipLaunchKernelGGL(glszm_tile8_kernel<2>, dim3((unsigned)tiles), dim3(256), 0, s, levels, dims3[0], dims3[1],
-                               dims3[2], st.labels, st.sizes, flags_d, st.rootlist, st.rootctl);
-            if ((dims3[2] & 3) == 0) {
-              // Both are launched, the device picks: flags[3] = number of tile-local components in every 64th tile (glszm_tile8_kernel).
-              // Many voxels per component (structured images) -> the strip kernel with its de-duplicated wide
-              // unions (512^3 smooth 4.6 -> 1.7 ms); iid levels make every pair distinct and the hash set pure
-              // overhead (0.67 -> 1.09 ms), they stay on the row scan.
-              const long long strips_below = getenv("PRAD_GLSZM_NO_STRIPS") ? 0 : std::max<long long>(1, ((tiles + 63) / 64) * PRAD_TVOX / 8);
-              hipLaunchKernelGGL(glszm_border8s_kernel<2>, sgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],
-                                 st.labels, flags_d, strips_below);
-              hipLaunchKernelGGL(glszm_border8q_kernel<2>, bgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],
-                                 st.labels, flags_d, strips_below);
-            }
-            else
-              hipLaunchKernelGGL(glszm_border8_kernel<2>, bgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],
-                                 st.labels, flags_d);
-          }
-          PRAD_TRY(check_launch("glszm_tile8/border8_kernel"));
+#define PRAD_GLSZM_LAUNCH(M)                                                                                                 \
+          do {                                                                                                               \
+            hipLaunchKernelGGL(glszm_tile8_kernel<M>, dim3((unsigned)tiles), dim3(256), 0, s, levels, dims3[0], dims3[1],    \
+                               dims3[2], st.labels, (const int *)flags_d, st.rootctl, st.tinfo, work, workcap);              \
+            hipLaunchKernelGGL(glszm_dense_init_kernel, dim3(2048), dim3(256), 0, s, (const int *)st.rootctl,                \
+                               (const unsigned *)st.tinfo, st.parent, st.sizes, (const int *)flags_d);                       \
+            hipLaunchKernelGGL(glszm_pairs_kernel, dim3(2048), dim3(256), 0, s, (const int2 *)work, (const int *)st.rootctl, \
+                               (const int *)st.labels, st.parent, (const int *)flags_d);                                     \
+            hipLaunchKernelGGL(glszm_border8d_kernel<M>, bgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],       \
+                               (const int *)st.labels, st.parent, (const int *)flags_d, (const int *)st.rootctl);            \
+          } while (0)
+          if (mode == 1) PRAD_GLSZM_LAUNCH(1);
+          else PRAD_GLSZM_LAUNCH(2);
+#undef PRAD_GLSZM_LAUNCH
+          hipLaunchKernelGGL(glszm_rootsum_dense_kernel, dim3(2048), dim3(256), 0, s, (const int *)st.rootctl, st.parent,
+                             st.sizes, (const int *)flags_d);
+          PRAD_TRY(check_launch("glszm_tile8/pairs/rootsum_kernel"));
         } else {
-          st.rootlist = st.rootctl = nullptr;
+          st.parent = st.rootctl = nullptr;
+          st.tinfo = nullptr;
           hipLaunchKernelGGL(glszm_tile_kernel, dim3((unsigned)tiles), dim3(256), 0, s, A3, mode, image, mask, dims3[0],
                              dims3[1], dims3[2], st.labels, st.sizes);
           PRAD_TRY(check_launch("glszm_tile_kernel"));
@@ -1698,12 +1582,14 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
             hipLaunchKernelGGL(glszm_border_kernel, bgrid, dim3(256), 0, s, A3, image, mask, dims3[0], dims3[1], dims3[2], st.labels);
           PRAD_TRY(check_launch("glszm_border_kernel"));
         }
-        hipLaunchKernelGGL(glszm_rootsum_kernel, dim3((unsigned)((g.n + PRAD_RS_CHUNK - 1) / PRAD_RS_CHUNK)), dim3(256), 0, s,
-                           g.n, st.labels, st.sizes, (const int *)(bytes ? flags_d : nullptr), (const int *)st.rootlist,
-                           (const int *)st.rootctl);
-        PRAD_TRY(check_launch("glszm_rootsum_kernel"));
+        if (!bytes) {
+          hipLaunchKernelGGL(glszm_rootsum_kernel, dim3((unsigned)((g.n + PRAD_RS_CHUNK - 1) / PRAD_RS_CHUNK)), dim3(256), 0, s,
+                             g.n, st.labels, st.sizes);
+          PRAD_TRY(check_launch("glszm_rootsum_kernel"));
+        }
       } else {
-        st.rootlist = st.rootctl = nullptr;
+        st.parent = st.rootctl = nullptr;
+        st.tinfo = nullptr;
         hipLaunchKernelGGL(glszm_init_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, mask, g.n, st.labels, st.sizes);
         PRAD_TRY(check_launch("glszm_init_kernel"));
         hipLaunchKernelGGL(glszm_merge_kernel, dim3(glszm_grid(g.n)), dim3(256), 0, s, g, angles_d, Na, image, mask, st.labels);
@@ -1713,7 +1599,8 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
       }
       hipLaunchKernelGGL(glszm_stats_kernel, dim3(std::min(glszm_grid(g.n), 1024u)), dim3(256), 0, s, g.n, st.labels,
                          st.sizes, stats, stats64, st.small_bits, st.large_list, st.large_cap, st.large_count,
-                         (const int *)(bytes ? flags_d : nullptr), (const int *)st.rootlist, (const int *)st.rootctl);
+                         (const int *)(bytes ? flags_d : nullptr), (const int *)(bytes ? st.parent : nullptr),
+                         (const int *)st.rootctl);
       PRAD_TRY(check_launch("glszm_stats_kernel"));
       if (!bytes || enqueue_only) break;
       PRAD_HIP(hipMemcpyAsync(flags_h, flags_d, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
@@ -1795,7 +1682,7 @@ inline int glszm_fill(Context &c, hipStream_t s, double *out_dev, int Nvox, int 
     const int RL = Ng <= 8192 ? std::max(1, std::min(maxRegion, 8192 / Ng)) : 0;
     hipLaunchKernelGGL(glszm_fill_segment_kernel, dim3(std::min(glszm_grid(st.g.n), 2048u)), dim3(256),
                        sizeof(unsigned) * Ng * RL, s, st.g.n, st.labels, st.sizes, st.image, Ng, maxRegion, RL, out_dev,
-                       err);
+                       err, (const int *)st.parent, (const int *)st.rootctl, (const unsigned *)st.tinfo);
     PRAD_TRY(check_launch("glszm_fill_segment_kernel"));
   } else {
     const long long threads = (long long)st.nvox * st.boxmax;
@@ -1871,7 +1758,8 @@ inline int glszm_fill_compact(Context &c, hipStream_t s, double *out_dev, int Ng
     const int RL = Ng <= 8192 ? std::max(1, std::min(k, 8192 / Ng)) : 0;
     hipLaunchKernelGGL(glszm_fill_compact_kernel, dim3(std::min(glszm_grid(st.g.n), 2048u)), dim3(256),
                        sizeof(unsigned) * Ng * RL, s, st.g.n, st.labels, st.sizes, st.image, Ng, k, RL, st.small_rank,
-                       st.nsmall, large_d, st.nlarge, out_dev, err, (const int *)st.rootlist, (const int *)st.rootctl);
+                       st.nsmall, large_d, st.nlarge, out_dev, err, (const int *)st.parent, (const int *)st.rootctl,
+                       (const int *)nullptr, 0, (const unsigned *)st.tinfo);
     PRAD_TRY(check_launch("glszm_fill_compact_kernel"));
   }
   void *hp = nullptr;
@@ -1908,11 +1796,30 @@ inline long long glszm_copy_zones(Context &c, int v, int *tempData, long long ca
     PRAD_TRY(c.get<unsigned>("glszm_bcounts", (size_t)nblocks, &counts));
     PRAD_TRY(c.get<unsigned long long>("glszm_boffsets", (size_t)nblocks, &offsets));
     PRAD_TRY(c.get<int>("glszm_pairs", (size_t)count * 2 + 2, &pairs));
+    const unsigned *vsizes = st.sizes;
+    if (st.parent) {
+      // the dense model: vid[] has done its work (the unions are over) -- the label volume becomes the view this scan needs:
+      // labels[v] == v at the first voxel v of every zone, -1 elsewhere, the zone sizes in a voxel-indexed scratch array
+      int *zmin = nullptr;
+      unsigned *zsz = nullptr;
+      PRAD_TRY(c.get<int>("glszm_zmin", (size_t)n, &zmin));
+      PRAD_TRY(c.get<unsigned>("glszm_zsz", (size_t)n, &zsz));
+      if (!st.published) {                       // (st.labels is vid[] only until the first call)
+        PRAD_HIP(hipMemsetAsync(zmin, 0x7f, sizeof(int) * (size_t)n, s));
+        hipLaunchKernelGGL(glszm_zmin_kernel, dim3(2048), dim3(256), 0, s, n, (const int *)st.labels, (const int *)st.parent, zmin);
+        st.published = true;
+      }
+      PRAD_HIP(hipMemsetAsync(st.labels, 0xff, sizeof(int) * (size_t)n, s));
+      hipLaunchKernelGGL(glszm_publish_kernel, dim3(1024), dim3(256), 0, s, (const int *)st.rootctl, (const int *)st.parent,
+                         (const unsigned *)st.sizes, (const int *)zmin, st.labels, zsz);
+      PRAD_TRY(check_launch("glszm_publish_kernel"));
+      vsizes = zsz;
+    }
     hipLaunchKernelGGL(glszm_root_count_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, n, st.labels, counts);
     PRAD_TRY(check_launch("glszm_root_count_kernel"));
     hipLaunchKernelGGL(glszm_scan_kernel, dim3(1), dim3(1024), 0, s, nblocks, counts, offsets);
     PRAD_TRY(check_launch("glszm_scan_kernel"));
-    hipLaunchKernelGGL(glszm_root_scatter_kernel, dim3((unsigned)nblocks), dim3(64), 0, s, n, st.labels, st.sizes,
+    hipLaunchKernelGGL(glszm_root_scatter_kernel, dim3((unsigned)nblocks), dim3(64), 0, s, n, st.labels, vsizes,
                        st.image, offsets, pairs);
     PRAD_TRY(check_launch("glszm_root_scatter_kernel"));
   }

@@ -246,6 +246,28 @@ def test_glszm_compact_equals_dense(shape, smooth):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("route", ["worklist", "worklist_full"])
+def test_glszm_border_routes_agree_with_the_reference(cm, checker, route, monkeypatch):
+    """Cross-tile zone pairs: the work list of the tile kernel (default) and the scan of the tile faces that takes over
+    when the list is too small (PRAD_GLSZM_WORKCAP) -- both against cmatrices.c:94-297, 26- and 8-neighbourhoods, row
+    lengths with and without whole quads, several tiles per axis"""
+    import scipy.ndimage as ndi
+    if route == "worklist_full":
+        monkeypatch.setenv("PRAD_GLSZM_WORKCAP", "37")
+    rng = np.random.default_rng(101)
+    for shape, sigma, ng in (((21, 30, 136), 1.5, 5), ((17, 19, 131), 0.0, 3), ((9, 70, 200), 2.5, 4), ((3, 9, 260), 1.0, 2)):
+        f = rng.standard_normal(shape)
+        if sigma:
+            f = ndi.gaussian_filter(f, sigma)
+        img = (1 + np.floor((f - f.min()) / (np.ptp(f) + 1e-9) * ng * 0.999)).astype(np.int32)
+        mask = rng.random(shape) < 0.93
+        Ns = int(mask.sum())
+        for force2D, f2d in ((False, 0), (True, 0)):
+            want = checker.calculate_glszm(img, mask, ng, Ns, force2D, f2d)
+            assert np.array_equal(cm.calculate_glszm(img, mask, ng, Ns, force2D, f2d), want), (shape, force2D)
+
+
+@pytest.mark.gpu
 def test_level_counts_and_tensor_inputs_of_the_operator_module():
     import torch
     from pyradiomics_amd import engine, cmatrices
