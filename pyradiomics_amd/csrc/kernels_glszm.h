@@ -47,6 +47,7 @@ struct GlszmState {
   // root), sizes[] is tsize[] (indexed by dense id); parent == nullptr: the label volume model of the int32 kernels
   int *parent = nullptr;           // [n] dense union-find, flat after glszm_rootsum_dense_kernel
   unsigned *tinfo = nullptr;       // [n] dense id -> voxels of the tile component | grey level << 16
+  size_t idcap = 0;                // entries the dense arrays hold (ids come in chunks: holes)
   bool published = false;          // the ordered zone list turned labels[] (vid[]) into its label-volume view
   int *rootctl = nullptr;          // [0] tile roots, [2] pairs in the work list, [3] work list overflow
   int *zones = nullptr;            // voxel: [boxmax][2][nvox] (level,size) interleaved by kernel
@@ -493,6 +494,40 @@ __device__ __forceinline__ unsigned t8_closed_nbhd(unsigned T) {
   return N;
 }
 
+// t8_closed_nbhd of two sets at once (13-bit fields at bits 0 and 16 of T)
+__device__ __forceinline__ unsigned t8_closed_nbhd2(unsigned T) {
+  const unsigned W = T & 0x0fff0fffu;
+  const unsigned U = W | ((W << 1) & 0x0db60db6u) | ((W >> 1) & 0x06db06dbu);
+  const unsigned a = (U | (U >> 3) | (U >> 6)) & 0x00070007u, g3 = (U >> 9) & 0x00070007u, g2 = (U >> 6) & 0x00070007u;
+  unsigned N = a | (a << 3) | ((a | g3) << 6) | ((g2 | g3) << 9);
+  N |= ((T >> 12) & 0x00010001u) * 0x16dbu;                                   // the voxel to the left sees dx = -1, 0 of every row
+  N |= (((W & 0x06db06dbu) + 0x7fff7fffu) & 0x80008000u) >> 3;                // ... and they see it
+  return N;
+}
+
+#ifndef PRAD_T8_JUMPS
+#define PRAD_T8_JUMPS 3
+#endif
+#ifndef PRAD_T8_FLOOD
+#define PRAD_T8_FLOOD 2
+#endif
+#ifdef PRAD_T8_PROF
+__device__ unsigned long long prad_t8_prof[16];
+__global__ void glszm_t8_prof_kernel() {
+  unsigned long long tot = 0;
+  for (int i = 0; i < 12; i++) tot += prad_t8_prof[i];
+  for (int i = 0; i < 12; i++) printf("phase %d: %5.1f %%\n", i, 100.0 * prad_t8_prof[i] / (double)tot);
+  for (int i = 0; i < 16; i++) prad_t8_prof[i] = 0;
+}
+#define PRAD_T8_TICK(i)                                                       \
+  do {                                                                        \
+    const unsigned long long now_ = __builtin_readcyclecounter();            \
+    if (threadIdx.x == 0) atomicAdd(&prad_t8_prof[i], now_ - tick_);          \
+    tick_ = now_;                                                             \
+  } while (0)
+#else
+#define PRAD_T8_TICK(i)
+#endif
 // ---- the dense model of the packed-byte path ------------------------------------------------------------------------
 // The tile is loaded WITH its halo of real levels, so a voxel sees the same-level backward neighbours S it has in the
 // whole volume.  Those inside the tile (IN) are united here, in LDS.  A neighbour in another tile only matters when its
@@ -520,7 +555,16 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
   __shared__ unsigned lev[PRAD_T8_DW];
   __shared__ int lab[PRAD_TVOX];
   __shared__ int lcount, lbase, wcount, wbase;
+  __shared__ int offt[16];                   // in-tile index offset of neighbour n (t8_offset)
   if (flags[0]) return;   // a masked level outside 1..Ng: the int32 kernels redo this call
+  if (threadIdx.x < 16) {
+    int dz, dy, dx;
+    t8_offset(threadIdx.x, dz, dy, dx);
+    offt[threadIdx.x] = threadIdx.x < 13 ? dz * (PRAD_TX * PRAD_TY) + dy * PRAD_TX + dx : 0;
+  }
+#ifdef PRAD_T8_PROF
+  unsigned long long tick_ = __builtin_readcyclecounter();
+#endif
   const int tx = (Nx + PRAD_TX - 1) / PRAD_TX, ty = (Ny + PRAD_TY - 1) / PRAD_TY;
   const int bz = blockIdx.x / (ty * tx), br = blockIdx.x % (ty * tx);
   const int z0 = bz * PRAD_TZ, y0 = (br / tx) * PRAD_TY, x0 = (br % tx) * PRAD_TX;
@@ -540,6 +584,7 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
     lev[i] = w;
   }
   __syncthreads();
+  PRAD_T8_TICK(0);
   constexpr int QPT = PRAD_TVOX / 4 / 256;   // quads per lane
   unsigned cw[QPT];
   unsigned long long btodo[QPT];             // bit 16k + n of [q]: voxel k of quad q goes to the work list with its neighbour n
@@ -549,85 +594,153 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
     const int lx4 = quad & 15, ly = (quad >> 4) % PRAD_TY, lz = quad / (16 * PRAD_TY);
     const unsigned w = lev[((lz + 1) * (PRAD_TY + 2) + (ly + 1)) * PRAD_T8_ROWDW + 1 + lx4];
     cw[q] = w;
-    // a voxel with the level of its left neighbour in the quad starts with that neighbour's label (= the first voxel of
-    // the run inside the quad): that union is made here, by a plain store
-    int first = quad * 4;
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-      const unsigned lv = (w >> (8 * b)) & 0xffu;
-      if (b == 0 || lv == 0u || lv != ((w >> (b ? 8 * b - 8 : 0)) & 0xffu)) first = quad * 4 + b;
-      lab[quad * 4 + b] = first;
-    }
   }
-  __syncthreads();
+  // ---- selection.  Every voxel takes ONE of the neighbours it has to be united with (one per 26-adjacency cluster of its
+  // same-level backward neighbours inside the tile: t8_sel13) as its initial label -- a plain store to its own cell, links
+  // only go to smaller indices -- and keeps the others (`todo`: 0.13 per voxel on smooth volumes where uniting with every
+  // representative took 0.78 finds + atomics) for the union phase.
+  unsigned long long todo[QPT];              // bit 16k + n of [q]: unite voxel k of quad q with its neighbour n
 #pragma unroll
   for (int q = 0; q < QPT; q++) {
     const unsigned centre = cw[q];
     btodo[q] = 0ull;
-    if (!centre) continue;
+    todo[q] = 0ull;
+    const int quad0 = threadIdx.x + q * 256;
+    if (!centre) {
+      *reinterpret_cast<int4 *>(lab + quad0 * 4) = make_int4(quad0 * 4, quad0 * 4 + 1, quad0 * 4 + 2, quad0 * 4 + 3);
+      continue;
+    }
     const int quad = threadIdx.x + q * 256;
     const int lx4 = quad & 15, ly = (quad >> 4) % PRAD_TY, lz = quad / (16 * PRAD_TY);
     const unsigned *row0 = lev + ((lz + 1) * (PRAD_TY + 2) + (ly + 1)) * PRAD_T8_ROWDW + lx4;   // [0] left, [1] mid, [2] right
-    // e[r][k]: bits 7 / 15 / 23 = voxel k has the level of its neighbour at dx = -1 / 0 / +1 in backward row r
-    //   r = 0: (dz 0, dy -1)   1: (dz -1, dy -1)   2: (dz -1, dy 0)   3: (dz -1, dy +1)
-    unsigned e[4][4];
-    unsigned crep[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) crep[k] = ((centre >> (8 * k)) & 0xffu) * 0x010101u;
+    // "Same level" flags of the 4 voxels against one neighbour direction at a time, packed-byte arithmetic on the whole
+    // dword (bit 7 of byte k: voxel k has the level of that neighbour), gathered into Wlo / Whi: byte k of Wlo = bits 0..7,
+    // byte k of Whi = bits 8..12 of voxel k's set S (numbering of t8_offset).  ~30 VALU per voxel where the per-voxel
+    // 3-byte windows took ~60; the kernel is bound by instruction issue (4 000 instructions per wave and tile).
+    auto eq4 = [](unsigned a, unsigned b) -> unsigned {
+      const unsigned x = a ^ b;
+      return ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & 0x80808080u;
+    };
+    unsigned Wlo = 0u, Whi = 0u;
 #pragma unroll
     for (int r = 0; r < (MODE == 1 ? 4 : 1); r++) {
       const int dz = r == 0 ? 0 : -1, dy = r == 0 ? -1 : r - 2;
       const unsigned *rp = row0 + (dz * (PRAD_TY + 2) + dy) * PRAD_T8_ROWDW;
       const unsigned left = rp[0], mid = rp[1], right = rp[2];
-      const unsigned lo = (left >> 24) | (mid << 8), hi = (mid >> 24) | (right << 8);
+      const unsigned em = eq4(centre, __builtin_amdgcn_alignbyte(mid, left, 3));    // dx = -1
+      const unsigned e0 = eq4(centre, mid);
+      const unsigned ep = eq4(centre, __builtin_amdgcn_alignbyte(right, mid, 1));   // dx = +1
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const unsigned w = __builtin_amdgcn_alignbyte(hi, lo, k) & 0xffffffu;
-        e[r][k] = t8_nonzero3(w ^ crep[k]) ^ 0x808080u;
+      for (int d = 0; d < 3; d++) {
+        const int n = 3 * r + d;
+        const unsigned e = d == 0 ? em : (d == 1 ? e0 : ep);
+        if (n < 8) Wlo |= e >> (7 - n);
+        else Whi |= e >> (7 - (n - 8));
       }
     }
-    const unsigned lo0 = (row0[0] >> 24) | (centre << 8);      // bytes x-1 of the 4 voxels, own row
-    unsigned long long todo = 0ull;                            // bit 16k + n: unite voxel k with its neighbour n
+    Whi |= eq4(centre, __builtin_amdgcn_alignbyte(centre, row0[0], 3)) >> 3;        // n = 12: the voxel to the left
+    {
+      const unsigned nz = (((centre & 0x7f7f7f7fu) + 0x7f7f7f7fu) | centre) & 0x80808080u;
+      const unsigned inroi = (nz >> 7) * 0xffu;                  // 0xff in the bytes of voxels inside the ROI
+      Wlo &= inroi;
+      Whi &= inroi;
+    }
     // the neighbours of this row that lie in another tile
     const unsigned rowcross = (lz == 0 ? 0xff8u : 0u) | (ly == 0 ? 0x3fu : 0u) | (ly == PRAD_TY - 1 ? 0xe00u : 0u);
+    unsigned IN[4], X[4];
+    int ilab[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const unsigned c = (centre >> (8 * k)) & 0xffu;
-      unsigned S = t8_flags3(e[0][k]) | ((((lo0 >> (8 * k)) & 0xffu) == c) ? 0x1000u : 0u);
-      if (MODE == 1) S |= (t8_flags3(e[1][k]) << 3) | (t8_flags3(e[2][k]) << 6) | (t8_flags3(e[3][k]) << 9);
+      const unsigned S = __builtin_amdgcn_ubfe(Wlo, 8 * k, 8) | (__builtin_amdgcn_ubfe(Whi, 8 * k, 5) << 8);
       const unsigned cross = rowcross | ((k == 0 && lx4 == 0) ? 0x1249u : 0u) | ((k == 3 && lx4 == 15) ? 0x924u : 0u);
-      const unsigned X = c ? (S & cross) : 0u;
-      S &= ~cross;
-      if (X) {
-        const unsigned Y = X & ~t8_closed_nbhd(S);
-        btodo[q] |= (unsigned long long)t8_sel13[Y] << (16 * k);
-      }
-      unsigned sel = c ? (unsigned)t8_sel13[S] : 0u;
-      if (k > 0) sel &= ~0x1000u;                               // (tied through the initial label)
-      todo |= (unsigned long long)sel << (16 * k);
+      X[k] = S & cross;
+      IN[k] = S & ~cross;
+      unsigned sel = (unsigned)t8_sel13[IN[k]];
+      // the initial label: the voxel to the left when it is one of them (runs along x become chains the jumping rounds
+      // flatten), else the first in bit order
+      const unsigned pick = (sel & 0x1000u) ? 0x1000u : (sel & (0u - sel));
+      ilab[k] = quad * 4 + k + (pick ? offt[__ffs((int)pick) - 1] : 0);
+      todo[q] |= (unsigned long long)(sel ^ pick) << (16 * k);
     }
-    while (todo) {
-      const int bit = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      int dz, dy, dx;
-      t8_offset(bit & 15, dz, dy, dx);
-      const int idx = quad * 4 + (bit >> 4);
-      lds_union(lab, idx, idx + dz * (PRAD_TX * PRAD_TY) + dy * PRAD_TX + dx);
+    *reinterpret_cast<int4 *>(lab + quad * 4) = make_int4(ilab[0], ilab[1], ilab[2], ilab[3]);
+#if !(defined(PRAD_DBG_T8) && (PRAD_DBG_T8 & 1))     // (ablation builds: bit 0 no work list, 1 no unions, 2 no finds, 3 no stores)
+    // the work list: Y = X minus everything adjacent to IN, two voxels per word (fields at bits 0 and 16)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      // (PRAD_T8_FLOOD rounds of "grow through S": 1 = everything adjacent to IN, 4 = the exact clusters)
+      const unsigned S2 = (IN[2 * h] | X[2 * h]) | ((IN[2 * h + 1] | X[2 * h + 1]) << 16);
+      unsigned N2 = IN[2 * h] | (IN[2 * h + 1] << 16);
+#pragma unroll
+      for (int r = 0; r < PRAD_T8_FLOOD; r++) N2 = S2 & t8_closed_nbhd2(N2);
+      const unsigned Ya = X[2 * h] & ~N2, Yb = X[2 * h + 1] & ~(N2 >> 16);
+      btodo[q] |= ((unsigned long long)t8_sel13[Ya] << (32 * h)) | ((unsigned long long)t8_sel13[Yb] << (32 * h + 16));
+    }
+#endif
+  }
+  __syncthreads();
+  PRAD_T8_TICK(1);
+  // ---- pointer jumping: label <- label of the label, every voxel, PRAD_T8_JUMPS rounds (any interleaving of these
+  // stores is valid: a label only moves to a smaller member of the same component)
+#pragma unroll 1
+  for (int round = 0; round < PRAD_T8_JUMPS; round++) {
+#pragma unroll
+    for (int q = 0; q < QPT; q++) {
+      if (!cw[q]) continue;
+      int4 *cell = reinterpret_cast<int4 *>(lab + (threadIdx.x + q * 256) * 4);
+      const int4 p = *cell;
+      volatile lds_int_t *l = (volatile lds_int_t *)lab;
+      *cell = make_int4(l[p.x], l[p.y], l[p.z], l[p.w]);
     }
   }
   __syncthreads();
-  int root[QPT][4];
+  PRAD_T8_TICK(10);
+  // ---- the unions that are left
 #pragma unroll
-  for (int q = 0; q < QPT; q++)
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int idx = (threadIdx.x + q * 256) * 4 + k;
-      root[q][k] = ((cw[q] >> (8 * k)) & 0xffu) ? lds_find(lab, idx) : -1;
+  for (int q = 0; q < QPT; q++) {
+    const int quad = threadIdx.x + q * 256;
+    unsigned long long t = todo[q];
+    while (t) {
+      const int bit = __ffsll((long long)t) - 1;
+      t &= t - 1;
+      const int idx = quad * 4 + (bit >> 4);
+      lds_union(lab, idx, idx + offt[bit & 15]);
     }
+  }
   __syncthreads();
+  PRAD_T8_TICK(2);
+  // roots of the 16 voxels of the lane, all chases in flight together
+  int root[QPT][4];
+  {
+    volatile lds_int_t *l = (volatile lds_int_t *)lab;
+#pragma unroll
+    for (int q = 0; q < QPT; q++) {
+      const int4 p = *reinterpret_cast<const int4 *>(lab + (threadIdx.x + q * 256) * 4);
+      root[q][0] = p.x; root[q][1] = p.y; root[q][2] = p.z; root[q][3] = p.w;
+    }
+    bool moving = true;
+    while (__any(moving)) {
+      moving = false;
+#pragma unroll
+      for (int q = 0; q < QPT; q++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int nx = l[root[q][k]];
+          moving = moving || nx != root[q][k];
+          root[q][k] = nx;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QPT; q++)
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (!((cw[q] >> (8 * k)) & 0xffu)) root[q][k] = -1;
+  }
+  __syncthreads();
+  PRAD_T8_TICK(3);
   unsigned *cnt = reinterpret_cast<unsigned *>(lab);          // the roots are in registers: lab becomes the counts
   for (int k = threadIdx.x; k < PRAD_TVOX; k += blockDim.x) cnt[k] = 0u;
   __syncthreads();
+  PRAD_T8_TICK(4);
 #pragma unroll
   for (int q = 0; q < QPT; q++) {
     int prev = -1;
@@ -645,6 +758,7 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
     if (prev >= 0) atomicAdd(cnt + prev, run);
   }
   __syncthreads();
+  PRAD_T8_TICK(5);
   // dense ids: the roots this lane owns, a block of the tile-root list for the tile, a block of the work list
   int nroots = 0, npairs = 0;
 #pragma unroll
@@ -656,8 +770,12 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
   int mypos = nroots ? atomicAdd(&lcount, nroots) : 0;
   int wpos = npairs ? atomicAdd(&wcount, npairs) : 0;
   __syncthreads();
+  PRAD_T8_TICK(6);
+  // (one atomic per tile and list on one address each: 65 k at 512^3.  They are only harmless behind __syncthreads(), which
+  // also waits for the wave's global stores -- with a barrier that orders LDS traffic alone, or with workgroups that walk
+  // many tiles, the same atomics took 3.6 ms; profiles/r04_probes.md section 11)
   if (threadIdx.x == 0) {
-    lbase = lcount > 0 ? atomicAdd(rootctl, lcount) : 0;       // (the list holds n entries: it cannot overflow)
+    lbase = lcount > 0 ? atomicAdd(rootctl, lcount) : 0;       // (the arrays hold n entries: no overflow)
     wbase = -1;
     if (wcount > 0 && !__builtin_nontemporal_load(rootctl + 3)) {       // (workcap <= 2^30: the counter cannot wrap)
       const int at = atomicAdd(rootctl + 2, wcount);
@@ -666,6 +784,7 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
     }
   }
   __syncthreads();
+  PRAD_T8_TICK(7);
   if (nroots) {
     int id = lbase + mypos;
 #pragma unroll
@@ -684,6 +803,7 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
     }
   }
   __syncthreads();
+  PRAD_T8_TICK(8);
   const int plane = Ny * Nx;
 #pragma unroll
   for (int q = 0; q < QPT; q++) {
@@ -695,6 +815,10 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
     int lb[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) lb[k] = root[q][k] >= 0 ? lab[root[q][k]] : -1;
+#if defined(PRAD_DBG_T8) && (PRAD_DBG_T8 & 8)
+    if (lb[0] == 0x12345678) vid[gi] = 0;
+    else if (false)
+#endif
     if (vec) {
       *reinterpret_cast<int4 *>(vid + gi) = make_int4(lb[0], lb[1], lb[2], lb[3]);
     } else {
@@ -711,6 +835,7 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
       worklist[wbase + wpos++] = make_int2(lb[bit >> 4], (int)gi + (bit >> 4) + dz * plane + dy * Nx + dx);
     }
   }
+  PRAD_T8_TICK(9);
 }
 
 // find / union in the dense parent array (smaller id = closer to the root, as in the label volume)
@@ -1486,6 +1611,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
     PRAD_HIP(hipMemcpyAsync(angles_d, angles_h, sizeof(int) * Na * g.nd, hipMemcpyHostToDevice, s));
     PRAD_TRY(c.get<int>("glszm_labels", (size_t)g.n, &st.labels));
     PRAD_TRY(c.get<unsigned>("glszm_sizes", (size_t)g.n, &st.sizes));
+    st.idcap = (size_t)g.n;
     st.large_cap = (int)(g.n / PRAD_SMALL_SIZES + 2);
     PRAD_TRY(c.get<unsigned>("glszm_small_bits", PRAD_SMALL_SIZES / 32, &st.small_bits));
     PRAD_TRY(c.get<int>("glszm_large_list", (size_t)st.large_cap, &st.large_list));
@@ -1565,6 +1691,9 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
           if (mode == 1) PRAD_GLSZM_LAUNCH(1);
           else PRAD_GLSZM_LAUNCH(2);
 #undef PRAD_GLSZM_LAUNCH
+#ifdef PRAD_T8_PROF
+          hipLaunchKernelGGL(glszm_t8_prof_kernel, dim3(1), dim3(1), 0, s);
+#endif
           hipLaunchKernelGGL(glszm_rootsum_dense_kernel, dim3(2048), dim3(256), 0, s, (const int *)st.rootctl, st.parent,
                              st.sizes, (const int *)flags_d);
           PRAD_TRY(check_launch("glszm_tile8/pairs/rootsum_kernel"));
@@ -1802,10 +1931,10 @@ inline long long glszm_copy_zones(Context &c, int v, int *tempData, long long ca
       // labels[v] == v at the first voxel v of every zone, -1 elsewhere, the zone sizes in a voxel-indexed scratch array
       int *zmin = nullptr;
       unsigned *zsz = nullptr;
-      PRAD_TRY(c.get<int>("glszm_zmin", (size_t)n, &zmin));
+      PRAD_TRY(c.get<int>("glszm_zmin", st.idcap, &zmin));
       PRAD_TRY(c.get<unsigned>("glszm_zsz", (size_t)n, &zsz));
       if (!st.published) {                       // (st.labels is vid[] only until the first call)
-        PRAD_HIP(hipMemsetAsync(zmin, 0x7f, sizeof(int) * (size_t)n, s));
+        PRAD_HIP(hipMemsetAsync(zmin, 0x7f, sizeof(int) * st.idcap, s));
         hipLaunchKernelGGL(glszm_zmin_kernel, dim3(2048), dim3(256), 0, s, n, (const int *)st.labels, (const int *)st.parent, zmin);
         st.published = true;
       }
