@@ -851,10 +851,12 @@ __device__ __forceinline__ int dn_load(const int *p) {
   return __builtin_nontemporal_load(p);
 #endif
 }
-#ifdef PRAD_DN_NOHALVE
-#define PRAD_DN_HALVE(stmt)
-#else
+// (dn_union does not halve the paths it walks: with thousands of lanes in the same trees the halving stores cost more
+// than the shorter chains gain -- 676 -> 612 us at 512^3 smooth; glszm_rootsum_dense_kernel flattens afterwards)
+#ifdef PRAD_DN_HALVING
 #define PRAD_DN_HALVE(stmt) stmt
+#else
+#define PRAD_DN_HALVE(stmt)
 #endif
 __device__ __forceinline__ int dn_find(int *parent, int i) {
   int p = dn_load(parent + i);
@@ -890,6 +892,47 @@ __device__ __forceinline__ void dn_union(int *parent, int a, int b) {     // bot
   }
 }
 
+#ifdef PRAD_PAIRS_STATS
+__device__ unsigned long long prad_pairs_dbg[16];
+__global__ void glszm_pairs_dbg_kernel() {
+  printf("pairs %llu unions %llu same-root %llu hops %llu atomics %llu links %llu maxhops %llu maxtries %llu cycles/union avg %llu max %llu\n",
+         prad_pairs_dbg[0], prad_pairs_dbg[1], prad_pairs_dbg[2], prad_pairs_dbg[3], prad_pairs_dbg[4], prad_pairs_dbg[5],
+         prad_pairs_dbg[6], prad_pairs_dbg[7], prad_pairs_dbg[1] ? prad_pairs_dbg[8] / prad_pairs_dbg[1] : 0ull, prad_pairs_dbg[9]);
+  for (int i = 0; i < 16; i++) prad_pairs_dbg[i] = 0;
+}
+__device__ __forceinline__ void dn_union_dbg(int *parent, int a, int b) {
+  unsigned hops = 0, atom = 0, links = 0, same = 0;
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  while (true) {
+    int pa = dn_load(parent + a), pb = dn_load(parent + b);
+    while (pa != a || pb != b) {
+      const int ga = dn_load(parent + pa), gb = dn_load(parent + pb);
+      hops++;
+      if (pa != a) { if (ga != pa) parent[a] = ga; a = pa; pa = ga; }
+      if (pb != b) { if (gb != pb) parent[b] = gb; b = pb; pb = gb; }
+    }
+    if (a == b) { same = atom == 0; break; }
+    if (a < b) { int t = a; a = b; b = t; }
+    const int old = atomicMin(parent + a, b);
+    atom++;
+    if (old == a) { links++; break; }
+    a = old;
+  }
+  const unsigned long long dt = __builtin_readcyclecounter() - t0;
+  atomicAdd(&prad_pairs_dbg[1], 1ull);
+  atomicAdd(&prad_pairs_dbg[2], same);
+  atomicAdd(&prad_pairs_dbg[3], hops);
+  atomicAdd(&prad_pairs_dbg[4], atom);
+  atomicAdd(&prad_pairs_dbg[5], links);
+  atomicMax(&prad_pairs_dbg[6], (unsigned long long)hops);
+  atomicMax(&prad_pairs_dbg[7], (unsigned long long)atom);
+  atomicAdd(&prad_pairs_dbg[8], dt);
+  atomicMax(&prad_pairs_dbg[9], dt);
+}
+#define PRAD_DN_UNION dn_union_dbg
+#else
+#define PRAD_DN_UNION dn_union
+#endif
 // The work list: one lane per pair.  A pair of tile roots that repeats the previous lane's (neighbouring voxels of the
 // same two tile components) is skipped.
 __global__ void __launch_bounds__(256) glszm_pairs_kernel(const int2 *__restrict__ worklist,
@@ -899,16 +942,28 @@ __global__ void __launch_bounds__(256) glszm_pairs_kernel(const int2 *__restrict
   const int total = rootctl[2];
   const int stride = gridDim.x * blockDim.x;
   const int lane = threadIdx.x & 63;
+  // the pair of the NEXT round is fetched (list entry, then the neighbour's id: two dependent loads) while this round's
+  // union chases its pointers: the kernel is a chain of memory latencies, 97 % of its wave cycles are waits
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int a = -1, b = -1;
+  if (j < total) {
+    const int2 p = worklist[j];
+    a = p.x;
+    b = vid[p.y];
+  }
   for (int j0 = blockIdx.x * blockDim.x; j0 < total; j0 += stride) {      // (whole waves stay in the loop: shuffles)
-    const int j = j0 + threadIdx.x;
-    int a = -1, b = -1;
-    if (j < total) {
-      const int2 p = worklist[j];
-      a = p.x;
-      b = vid[p.y];
+    const int jn = j + stride;
+    int an = -1, bn = -1;
+    if (jn < total) {
+      const int2 p = worklist[jn];
+      an = p.x;
+      bn = vid[p.y];
     }
     const int pa = __shfl_up(a, 1), pb = __shfl_up(b, 1);
-    if (a >= 0 && a != b && !(lane > 0 && pa == a && pb == b)) dn_union(parent, a, b);
+    if (a >= 0 && a != b && !(lane > 0 && pa == a && pb == b)) PRAD_DN_UNION(parent, a, b);
+    j = jn;
+    a = an;
+    b = bn;
   }
 }
 
@@ -1670,6 +1725,10 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
           const char *wcap = getenv("PRAD_GLSZM_WORKCAP");
           const int workcap = wcap ? std::max(1, atoi(wcap)) : (int)std::min<long long>(1LL << 30, std::max<long long>(g.n, 65536));
           int2 *work = nullptr;
+          // lanes of glszm_pairs_kernel: MORE of them are slower on structured volumes (they collide in the trees of the
+          // large zones: 256^3 smooth 273 us with 2048 workgroups, 121 with 384; 512^3 790 / 612 with 768)
+          static const int pgrid_env = getenv("PRAD_GLSZM_PGRID") ? atoi(getenv("PRAD_GLSZM_PGRID")) : 0;
+          const int pgrid = pgrid_env > 0 ? pgrid_env : (int)std::min(2048.0, std::max(64.0, 1.5 * std::cbrt((double)g.n)));
           PRAD_HIP(hipMemsetAsync(flags_d, 0, sizeof(int) * 4, s));
           PRAD_TRY(c.get<int>("glszm_parent", (size_t)g.n, &st.parent));
           PRAD_TRY(c.get<unsigned>("glszm_tinfo", (size_t)g.n, &st.tinfo));
@@ -1683,7 +1742,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
                                dims3[2], st.labels, (const int *)flags_d, st.rootctl, st.tinfo, work, workcap);              \
             hipLaunchKernelGGL(glszm_dense_init_kernel, dim3(2048), dim3(256), 0, s, (const int *)st.rootctl,                \
                                (const unsigned *)st.tinfo, st.parent, st.sizes, (const int *)flags_d);                       \
-            hipLaunchKernelGGL(glszm_pairs_kernel, dim3(2048), dim3(256), 0, s, (const int2 *)work, (const int *)st.rootctl, \
+            hipLaunchKernelGGL(glszm_pairs_kernel, dim3(pgrid), dim3(256), 0, s, (const int2 *)work, (const int *)st.rootctl, \
                                (const int *)st.labels, st.parent, (const int *)flags_d);                                     \
             hipLaunchKernelGGL(glszm_border8d_kernel<M>, bgrid, dim3(256), 0, s, levels, dims3[0], dims3[1], dims3[2],       \
                                (const int *)st.labels, st.parent, (const int *)flags_d, (const int *)st.rootctl);            \
@@ -1693,6 +1752,9 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
 #undef PRAD_GLSZM_LAUNCH
 #ifdef PRAD_T8_PROF
           hipLaunchKernelGGL(glszm_t8_prof_kernel, dim3(1), dim3(1), 0, s);
+#endif
+#ifdef PRAD_PAIRS_STATS
+          hipLaunchKernelGGL(glszm_pairs_dbg_kernel, dim3(1), dim3(1), 0, s);
 #endif
           hipLaunchKernelGGL(glszm_rootsum_dense_kernel, dim3(2048), dim3(256), 0, s, (const int *)st.rootctl, st.parent,
                              st.sizes, (const int *)flags_d);
