@@ -20,23 +20,36 @@ enum { GF_Autocorrelation = 0, GF_JointAverage, GF_ClusterProminence, GF_Cluster
        GF_JointEntropy, GF_Imc1, GF_Imc2, GF_Idm, GF_Idmn, GF_Id, GF_Idn, GF_InverseVariance, GF_MaximumProbability,
        GF_SumAverage, GF_SumEntropy, GF_SumSquares, GF_COUNT };
 
-#define PRAD_FEAT_THREADS 256
+#ifndef PRAD_FEAT_THREADS
+#define PRAD_FEAT_THREADS 256      // (1024 lanes per angle were measured: zone 40 -> 68 us, glcm 44 -> 161 us -- the kernels are
+#endif                             // chains of block reductions, not loops over the entries)
+#define PRAD_FEAT_WAVES (PRAD_FEAT_THREADS / 64)
 #define PRAD_FEAT_EPS 2.220446049250313e-16
 
-// deterministic block sum: per-wave shuffle tree, then the 4 wave results in lane order
-__device__ __forceinline__ double feat_block_sum(double v, double *sh4) {
+// deterministic block sum: per-wave shuffle tree, then the wave results in a fixed pairwise order
+__device__ __forceinline__ double feat_block_sum(double v, double *shw) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = v;
   __syncthreads();
-  return (sh4[0] + sh4[1]) + (sh4[2] + sh4[3]);
+  double r[PRAD_FEAT_WAVES];
+#pragma unroll
+  for (int w = 0; w < PRAD_FEAT_WAVES; w++) r[w] = shw[w];
+#pragma unroll
+  for (int h = PRAD_FEAT_WAVES / 2; h > 0; h >>= 1)
+#pragma unroll
+    for (int w = 0; w < h; w++) r[w] = r[2 * w] + r[2 * w + 1];
+  return r[0];
 }
-__device__ __forceinline__ double feat_block_max(double v, double *sh4) {
+__device__ __forceinline__ double feat_block_max(double v, double *shw) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = v;
   __syncthreads();
-  return fmax(fmax(sh4[0], sh4[1]), fmax(sh4[2], sh4[3]));
+  double r = shw[0];
+#pragma unroll
+  for (int w = 1; w < PRAD_FEAT_WAVES; w++) r = fmax(r, shw[w]);
+  return r;
 }
 
 // counts: [Ng][Ng][Na] float64 (reference layout).  out: [Na][GF_COUNT]; empty[a] = 1 when the angle has no pair.
@@ -215,7 +228,7 @@ __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel
     const double *__restrict__ jvals, double *__restrict__ scratch, double *__restrict__ out, int *__restrict__ empty,
     const int *__restrict__ nj_dev = nullptr) {
 #pragma clang fp contract(off)
-  __shared__ double sh4[4];
+  __shared__ double sh4[PRAD_FEAT_WAVES];
   const int a = blockIdx.x, t = threadIdx.x;
   if (nj_dev) Nj = min(Nj, nj_dev[0]);      // (the column count was found on the device: glszm_rank_kernel; Nj = capacity)
   const double eps = PRAD_FEAT_EPS;

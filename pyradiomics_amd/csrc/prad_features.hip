@@ -9,7 +9,7 @@ extern "C" int prad_glcm_features_dev(const double *glcm, int Ng, int Na, int sy
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
   if (!glcm || !out || !empty || Ng < 1 || Na < 1) return fail(PRAD_E_ARG, "glcm_features: bad arguments");
-  const size_t lds = sizeof(double) * ((size_t)5 * Ng + 4);
+  const size_t lds = sizeof(double) * ((size_t)5 * Ng + PRAD_FEAT_WAVES);
   if (lds > 60 * 1024) return fail(PRAD_E_UNSUPPORTED, "glcm_features: Ng=%d exceeds the LDS marginals", Ng);
   hipStream_t s = (hipStream_t)stream;
   // values and "empty" flags in ONE device block and one copy into pinned memory (a copy into the caller's pageable array
@@ -107,7 +107,7 @@ extern "C" int prad_ngtdm_features_dev(const double *P, int Ng, double *out, voi
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
   if (!P || !out || Ng < 1) return fail(PRAD_E_ARG, "ngtdm_features: bad arguments");
-  const size_t lds = sizeof(double) * ((size_t)3 * Ng + 4);
+  const size_t lds = sizeof(double) * ((size_t)3 * Ng + PRAD_FEAT_WAVES);
   if (lds > 60 * 1024) return fail(PRAD_E_UNSUPPORTED, "ngtdm_features: Ng=%d exceeds the LDS level table", Ng);
   hipStream_t s = (hipStream_t)stream;
   double *d_out = nullptr;
