@@ -41,6 +41,32 @@ __device__ __forceinline__ double feat_block_sum(double v, double *shw) {
     for (int w = 0; w < h; w++) r[w] = r[2 * w] + r[2 * w + 1];
   return r[0];
 }
+// N independent block sums behind ONE pair of barriers (each of these kernels is a chain of reductions: 16 of them, one
+// after the other, were most of the 40 us of the zone kernel); shw: N * PRAD_FEAT_WAVES doubles; same order of additions
+// per value as feat_block_sum
+template <int N>
+__device__ __forceinline__ void feat_block_sum_n(double (&v)[N], double *shw) {
+#pragma unroll
+  for (int k = 0; k < N; k++)
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < N; k++) shw[k * PRAD_FEAT_WAVES + (threadIdx.x >> 6)] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    double r[PRAD_FEAT_WAVES];
+#pragma unroll
+    for (int w = 0; w < PRAD_FEAT_WAVES; w++) r[w] = shw[k * PRAD_FEAT_WAVES + w];
+#pragma unroll
+    for (int h = PRAD_FEAT_WAVES / 2; h > 0; h >>= 1)
+#pragma unroll
+      for (int w = 0; w < h; w++) r[w] = r[2 * w] + r[2 * w + 1];
+    v[k] = r[0];
+  }
+}
 __device__ __forceinline__ double feat_block_max(double v, double *shw) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
   __syncthreads();
@@ -229,6 +255,7 @@ __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel
     const int *__restrict__ nj_dev = nullptr) {
 #pragma clang fp contract(off)
   __shared__ double sh4[PRAD_FEAT_WAVES];
+  __shared__ double shn[13 * PRAD_FEAT_WAVES];
   const int a = blockIdx.x, t = threadIdx.x;
   if (nj_dev) Nj = min(Nj, nj_dev[0]);      // (the column count was found on the device: glszm_rank_kernel; Nj = capacity)
   const double eps = PRAD_FEAT_EPS;
@@ -244,7 +271,15 @@ __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel
   }
   for (int j = t; j < Nj; j += PRAD_FEAT_THREADS) {
     double s = 0;
-    for (int i = 0; i < Ni; i++) s += P(i, j);
+    int i = 0;
+    for (; i + 8 <= Ni; i += 8) {            // eight loads in flight, added in row order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = P(i + u, j);
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; i < Ni; i++) s += P(i, j);
     pj[j] = s;
   }
   __syncthreads();
@@ -265,10 +300,6 @@ __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel
     inv_i2 += g / (iv * iv);
     mg += g * g;
   }
-  i1 = feat_block_sum(i1, sh4);
-  i2 = feat_block_sum(i2, sh4);
-  inv_i2 = feat_block_sum(inv_i2, sh4);
-  mg = feat_block_sum(mg, sh4);
   double j1 = 0, j2 = 0, inv_j2 = 0, mj = 0;
   for (int j = t; j < Nj; j += PRAD_FEAT_THREADS) {
     const double s = pj[j], jv = jvals[j];
@@ -277,10 +308,28 @@ __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel
     inv_j2 += s / (jv * jv);
     mj += s * s;
   }
-  j1 = feat_block_sum(j1, sh4);
-  j2 = feat_block_sum(j2, sh4);
-  inv_j2 = feat_block_sum(inv_j2, sh4);
-  mj = feat_block_sum(mj, sh4);
+  // the entries, spread over all lanes (a lane that walks a whole column makes the kernel as long as its log2 / division
+  // chain: 32 rows x ~300 instructions); 1 / n once, 1 / i^2 from a table
+  double ent = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+  const double rn = 1.0 / n;
+  const long long nij = (long long)Ni * Nj;
+  for (long long e = t; e < nij; e += PRAD_FEAT_THREADS) {
+    const int i = (int)(e / Nj), j = (int)(e - (long long)i * Nj);
+    const double v = P(i, j);
+    if (v == 0) continue;
+    const double iv = i + 1, jv = jvals[j], i2v = iv * iv, j2v = jv * jv, ri2 = 1.0 / i2v, rj2 = 1.0 / j2v, p = v * rn;
+    ent += p * log2(p + eps);
+    c1 += v * (ri2 * rj2);
+    c2 += v * (i2v * rj2);
+    c3 += v * (j2v * ri2);
+    c4 += v * (i2v * j2v);
+  }
+  {
+    double r[13] = {i1, i2, inv_i2, mg, j1, j2, inv_j2, mj, ent, c1, c2, c3, c4};
+    feat_block_sum_n(r, shn);
+    i1 = r[0]; i2 = r[1]; inv_i2 = r[2]; mg = r[3]; j1 = r[4]; j2 = r[5]; inv_j2 = r[6]; mj = r[7];
+    ent = -r[8]; c1 = r[9]; c2 = r[10]; c3 = r[11]; c4 = r[12];
+  }
   const double ui = i1 / n, uj = j1 / n;
   double vi = 0, vj = 0;
   for (int i = t; i < Ni; i += PRAD_FEAT_THREADS) {
@@ -291,26 +340,11 @@ __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel
     const double d = jvals[j] - uj;
     vj += (pj[j] / n) * (d * d);
   }
-  vi = feat_block_sum(vi, sh4);
-  vj = feat_block_sum(vj, sh4);
-  double ent = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
-  const long long nij = (long long)Ni * Nj;
-  for (long long e = t; e < nij; e += PRAD_FEAT_THREADS) {
-    const int i = (int)(e / Nj), j = (int)(e - (long long)i * Nj);
-    const double v = P(i, j);
-    if (v == 0) continue;
-    const double iv = i + 1, jv = jvals[j], i2v = iv * iv, j2v = jv * jv, p = v / n;
-    ent += p * log2(p + eps);
-    c1 += v / (i2v * j2v);
-    c2 += v * i2v / j2v;
-    c3 += v * j2v / i2v;
-    c4 += v * (i2v * j2v);
+  {
+    double r[2] = {vi, vj};
+    feat_block_sum_n(r, shn);
+    vi = r[0]; vj = r[1];
   }
-  ent = -feat_block_sum(ent, sh4);
-  c1 = feat_block_sum(c1, sh4);
-  c2 = feat_block_sum(c2, sh4);
-  c3 = feat_block_sum(c3, sh4);
-  c4 = feat_block_sum(c4, sh4);
   if (t == 0) {
     double *o = out + (size_t)a * ZM_COUNT;
     o[ZM_SmallEmphasis] = inv_j2 / n;

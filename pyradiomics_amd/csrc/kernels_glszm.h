@@ -1304,6 +1304,16 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
   } else {
     kstride = k;
   }
+  // (dense ids: every workgroup takes a contiguous block of at least 4096 of them, the ones left without any return before
+  // they touch their 32 KB histogram -- a structured volume has a few hundred thousand ids, noise has millions)
+  long long dlo = 0, dhi = 0;
+  if (parent) {
+    const long long m = rootctl[0];
+    const long long per = max(4096LL, (m + gridDim.x - 1) / gridDim.x);
+    dlo = (long long)blockIdx.x * per;
+    dhi = min(m, dlo + per);
+    if (dlo >= dhi) return;
+  }
   for (int q = threadIdx.x; q < Ng * RL; q += blockDim.x) fh[q] = 0u;
   __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -1318,8 +1328,7 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
     else atomicAdd(out + (size_t)(gl - 1) * kstride + r, 1.0);
   };
   if (parent) {      // the dense model (glszm_tile8_kernel): `sizes` is tsize[]
-    const long long m = rootctl[0];
-    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride)
+    for (long long j = dlo + threadIdx.x; j < dhi; j += blockDim.x)
       if (parent[j] == (int)j) root(j);
   } else {
     const long long n4 = n >> 2;
@@ -1637,6 +1646,12 @@ __global__ void glszm_gather_zones_kernel(int nvox, int v, int count, const int 
 }
 
 // ---- host drivers --------------------------------------------------------------------------------
+// workgroups of the compact fill over the dense ids: every one of them zeroes and flushes a 32 KB LDS histogram, the ids
+// are a fraction of the voxels (PRAD_GLSZM_FILLBLOCKS: probe)
+inline unsigned glszm_fill_blocks() {
+  static const int b = getenv("PRAD_GLSZM_FILLBLOCKS") ? atoi(getenv("PRAD_GLSZM_FILLBLOCKS")) : 2048;
+  return (unsigned)std::max(1, b);
+}
 inline unsigned glszm_grid(long long n) {
   static const int cap = getenv("PRAD_GLSZM_BLOCKS") ? atoi(getenv("PRAD_GLSZM_BLOCKS")) : 8192;
   return (unsigned)std::max<long long>(1, std::min<long long>((n + 255) / 256, cap));
@@ -1947,7 +1962,7 @@ inline int glszm_fill_compact(Context &c, hipStream_t s, double *out_dev, int Ng
   PRAD_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)Ng * std::max(k, 1), s));
   if (k) {
     const int RL = Ng <= 8192 ? std::max(1, std::min(k, 8192 / Ng)) : 0;
-    hipLaunchKernelGGL(glszm_fill_compact_kernel, dim3(std::min(glszm_grid(st.g.n), 2048u)), dim3(256),
+    hipLaunchKernelGGL(glszm_fill_compact_kernel, dim3(std::min(glszm_grid(st.g.n), st.parent ? glszm_fill_blocks() : 2048u)), dim3(256),
                        sizeof(unsigned) * Ng * RL, s, st.g.n, st.labels, st.sizes, st.image, Ng, k, RL, st.small_rank,
                        st.nsmall, large_d, st.nlarge, out_dev, err, (const int *)st.parent, (const int *)st.rootctl,
                        (const int *)nullptr, 0, (const unsigned *)st.tinfo);

@@ -2093,7 +2093,7 @@ int prad_glszm_features_dev(const int32_t *image, const uint8_t *mask, const int
                        (const unsigned long long *)(stats + 2), 2LL * Ns, kcap, st.small_rank, large_sorted, jv, meta);
     PRAD_TRY(check_launch("glszm_rank_kernel"));
     const int RL = Ng <= 8192 ? std::max(1, std::min(kcap, 8192 / Ng)) : 0;
-    hipLaunchKernelGGL(glszm_fill_compact_kernel, dim3(std::min(glszm_grid(g.n), 2048u)), dim3(256), sizeof(unsigned) * Ng * RL,
+    hipLaunchKernelGGL(glszm_fill_compact_kernel, dim3(std::min(glszm_grid(g.n), st.parent ? glszm_fill_blocks() : 2048u)), dim3(256), sizeof(unsigned) * Ng * RL,
                        s, g.n, st.labels, st.sizes, image, Ng, 0, RL, st.small_rank, 0, large_sorted, 0, P, err,
                        (const int *)st.parent, (const int *)st.rootctl, (const int *)meta, kcap, (const unsigned *)st.tinfo);
     PRAD_TRY(check_launch("glszm_fill_compact_kernel"));
