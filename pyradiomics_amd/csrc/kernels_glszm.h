@@ -655,7 +655,10 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
       const unsigned cross = rowcross | ((k == 0 && lx4 == 0) ? 0x1249u : 0u) | ((k == 3 && lx4 == 15) ? 0x924u : 0u);
       X[k] = S & cross;
       IN[k] = S & ~cross;
-      unsigned sel = (unsigned)t8_sel13[IN[k]];
+      // (a set of at most one neighbour is its own selection: only the lanes with two or more go to the table -- a gather
+      // from global memory costs the vector L1 one tag look-up per active lane)
+      unsigned sel = IN[k];
+      if (sel & (sel - 1u)) sel = (unsigned)t8_sel13[sel];
       // the initial label: the voxel to the left when it is one of them (runs along x become chains the jumping rounds
       // flatten), else the first in bit order
       const unsigned pick = (sel & 0x1000u) ? 0x1000u : (sel & (0u - sel));
@@ -673,7 +676,10 @@ __global__ void __launch_bounds__(256) glszm_tile8_kernel(const uint8_t *__restr
 #pragma unroll
       for (int r = 0; r < PRAD_T8_FLOOD; r++) N2 = S2 & t8_closed_nbhd2(N2);
       const unsigned Ya = X[2 * h] & ~N2, Yb = X[2 * h + 1] & ~(N2 >> 16);
-      btodo[q] |= ((unsigned long long)t8_sel13[Ya] << (32 * h)) | ((unsigned long long)t8_sel13[Yb] << (32 * h + 16));
+      unsigned sa = Ya, sb = Yb;
+      if (sa & (sa - 1u)) sa = (unsigned)t8_sel13[sa];
+      if (sb & (sb - 1u)) sb = (unsigned)t8_sel13[sb];
+      btodo[q] |= ((unsigned long long)sa << (32 * h)) | ((unsigned long long)sb << (32 * h + 16));
     }
 #endif
   }
