@@ -1050,8 +1050,14 @@ __global__ void __launch_bounds__(256) glszm_dense_init_kernel(const int *__rest
                                                                int *__restrict__ parent, unsigned *__restrict__ zsize,
                                                                const int *__restrict__ flags) {
   if (flags[0]) return;
-  const int m = rootctl[0];
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m; j += gridDim.x * blockDim.x) {
+  const int m = rootctl[0], m4 = m >> 2;           // 16 B per lane and access (the streams over the ids: noise has 85 M of them)
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (int q = gid; q < m4; q += stride) {
+    const uint4 ti = reinterpret_cast<const uint4 *>(tinfo)[q];
+    reinterpret_cast<int4 *>(parent)[q] = make_int4(4 * q, 4 * q + 1, 4 * q + 2, 4 * q + 3);
+    reinterpret_cast<uint4 *>(zsize)[q] = make_uint4(ti.x & 0xffffu, ti.y & 0xffffu, ti.z & 0xffffu, ti.w & 0xffffu);
+  }
+  for (int j = 4 * m4 + gid; j < m; j += stride) {
     parent[j] = j;
     zsize[j] = tinfo[j] & 0xffffu;
   }
@@ -1061,6 +1067,9 @@ __global__ void __launch_bounds__(256) glszm_dense_init_kernel(const int *__rest
 // to the same zone root are combined in an LDS hash table first (a zone that spans thousands of tiles would otherwise
 // receive thousands of atomics on one address).  parent[] is flat afterwards (every entry points at its zone root).
 #define PRAD_RS_SLOTS 1024
+#ifndef PRAD_RS_PROBES
+#define PRAD_RS_PROBES 2      // (dense kernel; on noise the table fills up and every further probe is a wasted LDS atomic)
+#endif
 __global__ void __launch_bounds__(256) glszm_rootsum_dense_kernel(const int *__restrict__ rootctl, int *__restrict__ parent,
                                                                   unsigned *__restrict__ tsize,
                                                                   const int *__restrict__ flags) {
@@ -1068,7 +1077,7 @@ __global__ void __launch_bounds__(256) glszm_rootsum_dense_kernel(const int *__r
   __shared__ unsigned hval[PRAD_RS_SLOTS];
   if (flags[0]) return;
   const int total = rootctl[0];
-  const int per = max(1024, (total + (int)gridDim.x - 1) / (int)gridDim.x);
+  const int per = (max(1024, (total + (int)gridDim.x - 1) / (int)gridDim.x) + 3) & ~3;
   const long long lo = (long long)blockIdx.x * per, hi = min((long long)total, lo + per);
   if (lo >= hi) return;
   for (int k = threadIdx.x; k < PRAD_RS_SLOTS; k += blockDim.x) {
@@ -1076,15 +1085,14 @@ __global__ void __launch_bounds__(256) glszm_rootsum_dense_kernel(const int *__r
     hval[k] = 0u;
   }
   __syncthreads();
-  for (int j = (int)lo + threadIdx.x; j < (int)hi; j += blockDim.x) {
-    const int p = parent[j];
-    if (p == j) continue;
+  auto fold = [&](int j, int p) {
+    if (p == j) return;
     const int r = dn_find(parent, p);
     parent[j] = r;
     const unsigned sz = tsize[j];
     unsigned slot = ((unsigned)r * 2654435761u) >> 22;          // 10 bits
     bool done = false;
-    for (int probe = 0; probe < 8 && !done; probe++, slot = (slot + 1) & (PRAD_RS_SLOTS - 1)) {
+    for (int probe = 0; probe < PRAD_RS_PROBES && !done; probe++, slot = (slot + 1) & (PRAD_RS_SLOTS - 1)) {
       const int old = atomicCAS(hkey + slot, -1, r);
       if (old == -1 || old == r) {
         atomicAdd(hval + slot, sz);
@@ -1092,7 +1100,10 @@ __global__ void __launch_bounds__(256) glszm_rootsum_dense_kernel(const int *__r
       }
     }
     if (!done) atomicAdd(tsize + r, sz);
-  }
+  };
+  // (one id per lane and round: four per lane -- a 16-byte load -- made the kernel slower, 509 -> 628 us on 512^3 noise: the
+  // finds and hash updates of a lane's four ids run one after the other)
+  for (int j = (int)lo + threadIdx.x; j < (int)hi; j += blockDim.x) fold(j, parent[j]);
   __syncthreads();
   for (int k = threadIdx.x; k < PRAD_RS_SLOTS; k += blockDim.x)
     if (hkey[k] >= 0 && hval[k]) atomicAdd(tsize + hkey[k], hval[k]);
@@ -1192,8 +1203,7 @@ __global__ void __launch_bounds__(256) glszm_stats_kernel(long long n, const int
   const long long stride = (long long)gridDim.x * blockDim.x;
   unsigned mx = 0;
   unsigned long long cnt = 0;
-  auto root = [&](long long i) {
-    const unsigned sz = sizes[i];
+  auto rootsz = [&](unsigned sz) {
     cnt++;
     mx = max(mx, sz);
     if (sz < PRAD_SMALL_SIZES) {
@@ -1204,9 +1214,21 @@ __global__ void __launch_bounds__(256) glszm_stats_kernel(long long n, const int
       if (pos < large_cap) large_list[pos] = (int)sz;
     }
   };
+  auto root = [&](long long i) { rootsz(sizes[i]); };
   if (parent) {
-    const long long m = rootctl[0];
-    for (long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride)
+    const long long m = rootctl[0], m4 = m >> 2;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < m4; q += stride) {
+      const int4 p = reinterpret_cast<const int4 *>(parent)[q];
+      const int j = (int)(q << 2);
+      if (p.x == j || p.y == j + 1 || p.z == j + 2 || p.w == j + 3) {
+        const uint4 z = reinterpret_cast<const uint4 *>(sizes)[q];
+        if (p.x == j) rootsz(z.x);
+        if (p.y == j + 1) rootsz(z.y);
+        if (p.z == j + 2) rootsz(z.z);
+        if (p.w == j + 3) rootsz(z.w);
+      }
+    }
+    for (long long j = (m4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride)
       if (parent[j] == (int)j) root(j);
   } else {
     // the scan is a stream over the labels: 16 B per lane and load
@@ -1315,7 +1337,7 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
   long long dlo = 0, dhi = 0;
   if (parent) {
     const long long m = rootctl[0];
-    const long long per = max(4096LL, (m + gridDim.x - 1) / gridDim.x);
+    const long long per = (max(4096LL, (m + gridDim.x - 1) / gridDim.x) + 3) & ~3LL;
     dlo = (long long)blockIdx.x * per;
     dhi = min(m, dlo + per);
     if (dlo >= dhi) return;
@@ -1323,9 +1345,8 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
   for (int q = threadIdx.x; q < Ng * RL; q += blockDim.x) fh[q] = 0u;
   __syncthreads();
   const long long stride = (long long)gridDim.x * blockDim.x;
-  auto root = [&](long long i) {
-    const int gl = parent ? (int)(tinfo[i] >> 16) : image[i];
-    const int r = glszm_rank(sizes[i], small_rank, nsmall, large_sorted, nlarge);
+  auto rootls = [&](int gl, unsigned sz) {
+    const int r = glszm_rank(sz, small_rank, nsmall, large_sorted, nlarge);
     if (gl <= 0 || gl > Ng || r < 0 || r >= k) {
       *err = 1;
       return;
@@ -1333,8 +1354,21 @@ __global__ void __launch_bounds__(256) glszm_fill_compact_kernel(long long n, co
     if (r < RL) atomicAdd(fh + (gl - 1) * RL + r, 1u);
     else atomicAdd(out + (size_t)(gl - 1) * kstride + r, 1.0);
   };
-  if (parent) {      // the dense model (glszm_tile8_kernel): `sizes` is tsize[]
-    for (long long j = dlo + threadIdx.x; j < dhi; j += blockDim.x)
+  auto root = [&](long long i) { rootls(parent ? (int)(tinfo[i] >> 16) : image[i], sizes[i]); };
+  if (parent) {      // the dense model (glszm_tile8_kernel): `sizes` is tsize[]; four ids per lane and load
+    const long long q1 = dhi >> 2;
+    for (long long q = (dlo >> 2) + threadIdx.x; q < q1; q += blockDim.x) {
+      const int4 p = reinterpret_cast<const int4 *>(parent)[q];
+      const int j = (int)(q << 2);
+      if (p.x == j || p.y == j + 1 || p.z == j + 2 || p.w == j + 3) {
+        const uint4 z = reinterpret_cast<const uint4 *>(sizes)[q], ti = reinterpret_cast<const uint4 *>(tinfo)[q];
+        if (p.x == j) rootls((int)(ti.x >> 16), z.x);
+        if (p.y == j + 1) rootls((int)(ti.y >> 16), z.y);
+        if (p.z == j + 2) rootls((int)(ti.z >> 16), z.z);
+        if (p.w == j + 3) rootls((int)(ti.w >> 16), z.w);
+      }
+    }
+    for (long long j = (q1 << 2) + threadIdx.x; j < dhi; j += blockDim.x)
       if (parent[j] == (int)j) root(j);
   } else {
     const long long n4 = n >> 2;
