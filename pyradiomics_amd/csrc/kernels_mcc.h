@@ -165,7 +165,9 @@ __device__ double wave_mcc(Acc C, int Ng, double tot, MccScratch S, int nmax, in
 // The same routine for a whole workgroup (segment mode: one matrix per angle, 13 matrices in all -- a single wave per
 // matrix spent ~1 ms in the latency chain of ~250 Jacobi steps, each two passes of 8 dependent LDS round trips per lane;
 // with PRAD_MCC_BT threads a pass is 2 round trips).  Same arithmetic, same order of the rotations: same bits.
+#ifndef PRAD_MCC_BT
 #define PRAD_MCC_BT 256
+#endif
 __device__ __forceinline__ double block_sum_f64(double v, double *red) {    // every thread gets the sum
   v = wave_sum_f64(v);
   __syncthreads();
@@ -236,87 +238,96 @@ __device__ double block_mcc(Acc C, int Ng, double tot, MccScratch S, int nmax, i
   // reference side).  ~40 us per matrix at n = 32; the cyclic Jacobi iteration this replaces (kept in wave_mcc for the
   // voxel maps, whose matrices are tiny) needed ~280 rotation steps of 4 barriers each: 0.6 ms.
   double *dg = S.px, *sd = S.py;              // diagonal / sub-diagonal of T (the marginals are not needed any more)
-  double *u = S.A, *pv = S.A + nmax + 1, *hk = red;   // reflector, M u / h (A is free: nmax (nmax + 1) >= 2 (nmax + 1)), {h, K, u_l}
+  double *u = S.A, *pv = S.A + nmax + 1;      // scratch of the bracket search, M u / h (A is free: nmax (nmax + 1) >= 2 (nmax + 1))
+  // (every wave works out the reflector's scalars for itself -- same instructions, same bits -- and reads the reflector
+  // from row i of M, which no later update touches: two barriers per reflection instead of five)
+  const int lane = tid & 63;
   for (int i = n - 1; i >= 1; i--) {
     const int l = i - 1;                      // the reflector annihilates M[i][0 .. l-1]
-    if (tid < 64) {
-      double v = 0;
-      if (l >= 1) {
-        for (int k = tid; k <= l; k += 64) v += S.M[i * np + k] * S.M[i * np + k];
-        v = wave_sum_f64(v);
-      }
-      if (tid == 0) {
-        const double f = S.M[i * np + l];
-        if (l == 0 || v == 0.0 || v == f * f) {      // nothing to annihilate
-          sd[i] = f;
-          hk[0] = 0.0;
-        } else {
-          const double g = f >= 0 ? -sqrt(v) : sqrt(v);
-          sd[i] = g;
-          hk[0] = v - f * g;
-          hk[2] = f - g;
-        }
-      }
-    }
-    __syncthreads();
-    const double h = hk[0];
-    if (h == 0.0) continue;                   // (uniform: hk[0] is not rewritten before the next barrier)
-    for (int k = tid; k <= l; k += NT) u[k] = k == l ? hk[2] : S.M[i * np + k];
-    __syncthreads();
-    for (int j = tid; j <= l; j += NT) {
-      double acc = 0;
-      for (int k = 0; k <= l; k++) acc += S.M[j * np + k] * u[k];
-      pv[j] = acc / h;
-    }
-    __syncthreads();
-    if (tid < 64) {
-      double v = 0;
-      for (int k = tid; k <= l; k += 64) v += u[k] * pv[k];
+    const double *rowi = S.M + i * np;
+    double v = 0;
+    if (l >= 1) {
+      for (int k = lane; k <= l; k += 64) v += rowi[k] * rowi[k];
       v = wave_sum_f64(v);
-      if (tid == 0) hk[1] = v / (h + h);
+    }
+    const double f = rowi[l];
+    if (l == 0 || v == 0.0 || v == f * f) {          // nothing to annihilate
+      if (tid == 0) sd[i] = f;
+      continue;
+    }
+    const double g = f >= 0 ? -sqrt(v) : sqrt(v), h = v - f * g, ul = f - g;
+    if (tid == 0) sd[i] = g;
+    auto uk = [&](int k) -> double { return k == l ? ul : rowi[k]; };
+    {
+      // M u over the whole workgroup: LPR lanes per row, every lane a strided part of the row, shuffle tree (a lane per row
+      // was a chain of l + 1 dependent LDS reads with 32 of the 256 lanes busy: a quarter of the kernel)
+      const int LPR = l < 32 ? 8 : 4, j = tid / LPR, part = tid % LPR;
+      double acc = 0;
+      if (j <= l)
+        for (int k = part; k <= l; k += LPR) acc += S.M[j * np + k] * uk(k);
+      for (int o = 1; o < LPR; o <<= 1) acc += __shfl_xor(acc, o);
+      if (j <= l && part == 0) pv[j] = acc / h;
     }
     __syncthreads();
-    const double K = hk[1];
+    double w = 0;
+    for (int k = lane; k <= l; k += 64) w += uk(k) * pv[k];
+    const double K = wave_sum_f64(w) / (h + h);
     for (int e = tid; e < (l + 1) * (l + 1); e += NT) {
       const int j = e / (l + 1), k = e - j * (l + 1);
-      const double qj = pv[j] - K * u[j], qk = pv[k] - K * u[k];
-      S.M[j * np + k] -= u[j] * qk + qj * u[k];
+      const double uj = uk(j), ukk = uk(k);
+      const double qj = pv[j] - K * uj, qk = pv[k] - K * ukk;
+      S.M[j * np + k] -= uj * qk + qj * ukk;
     }
     __syncthreads();
   }
   for (int i = tid; i < n; i += NT) dg[i] = S.M[i * np + i];
   if (tid == 0) sd[0] = 0.0;
   __syncthreads();
-  double second = 0;
-  if (tid < 64) {
-    // Gershgorin bracket, then multisection on N(x) = #{eigenvalues < x}: lambda_(n-1) = sup{x : N(x) <= n - 2}
-    double lo = 1e300, hi = -1e300;
-    for (int i = tid; i < n; i += 64) {
-      const double r = fabs(sd[i]) + (i + 1 < n ? fabs(sd[i + 1]) : 0.0);
-      lo = fmin(lo, dg[i] - r);
-      hi = fmax(hi, dg[i] + r);
-    }
-    lo = -wave_max_f64(-lo);
-    hi = wave_max_f64(hi);
-    const double tiny = 1e-300;
-    for (int round = 0; round < 14 && hi > lo; round++) {
-      const double x = lo + (hi - lo) * (double)(tid + 1) / 65.0;
-      double q = dg[0] - x;
-      int cnt = q < 0;
-      for (int i = 1; i < n; i++) {
-        if (q == 0.0) q = tiny;
-        q = dg[i] - x - sd[i] * sd[i] / q;
-        cnt += q < 0;
-      }
-      const unsigned long long below = __ballot(cnt <= n - 2);      // a prefix of the lanes (N is monotone)
-      const int nb = __popcll(below);
-      const double nlo = nb > 0 ? __shfl(x, nb - 1) : lo, nhi = nb < 64 ? __shfl(x, nb) : hi;
-      if (nlo == lo && nhi == hi) break;
-      lo = nlo;
-      hi = nhi;
-    }
-    second = 0.5 * (lo + hi);
+  // Gershgorin bracket, then multisection on N(x) = #{eigenvalues < x}: lambda_(n-1) = sup{x : N(x) <= n - 2}; one shift per
+  // thread, every round narrows the bracket (NT + 1)-fold.  The Sturm recurrence is a chain of n divisions: v_rcp_f64 and
+  // one Newton step instead of the IEEE division (a count can only differ where q is within an ulp of zero, i.e. the
+  // eigenvalue moves by its own rounding error)
+  double lo = 1e300, hi = -1e300;
+  for (int i = tid; i < n; i += NT) {
+    const double r = fabs(sd[i]) + (i + 1 < n ? fabs(sd[i + 1]) : 0.0);
+    lo = fmin(lo, dg[i] - r);
+    hi = fmax(hi, dg[i] + r);
   }
+  lo = -wave_max_f64(-lo);
+  hi = wave_max_f64(hi);
+  __syncthreads();
+  if ((tid & 63) == 0) { red[tid >> 6] = lo; u[tid >> 6] = hi; }     // (u: free again)
+  __syncthreads();
+  for (int w = 0; w < NT / 64; w++) { lo = fmin(lo, red[w]); hi = fmax(hi, u[w]); }
+  __syncthreads();
+  for (int i = tid; i < n; i += NT) pv[i] = sd[i] * sd[i];
+  __syncthreads();
+  const double tiny = 1e-300;
+  int *cntw = reinterpret_cast<int *>(red);
+  for (int round = 0; round < 12 && hi > lo; round++) {
+    const double step = (hi - lo) / (double)(NT + 1);
+    const double x = lo + step * (double)(tid + 1);
+    double q = dg[0] - x;
+    int cnt = q < 0;
+    for (int i = 1; i < n; i++) {
+      if (q == 0.0) q = tiny;
+      double r = __builtin_amdgcn_rcp(q);
+      r = r * (2.0 - q * r);
+      q = dg[i] - x - pv[i] * r;
+      cnt += q < 0;
+    }
+    const unsigned long long below = __ballot(cnt <= n - 2);      // a prefix of the threads (N is monotone)
+    __syncthreads();
+    if ((tid & 63) == 0) cntw[tid >> 6] = __popcll(below);
+    __syncthreads();
+    int nb = 0;
+    for (int w = 0; w < NT / 64; w++) nb += cntw[w];
+    const double nlo = nb > 0 ? lo + step * (double)nb : lo, nhi = nb < NT ? lo + step * (double)(nb + 1) : hi;
+    if (nlo == lo && nhi == hi) break;
+    lo = nlo;
+    hi = nhi;
+  }
+  const double second = 0.5 * (lo + hi);
   return sqrt(fmax(second, 0.0));
 }
 
