@@ -1,14 +1,22 @@
 // kernels_glszm.h -- grey-level size-zone matrix on gfx950 (cmatrices.c:94-297).
 //
-// Segment mode (one box = the whole array): zones are the connected components of equal-level masked voxels
-// under the angle set, found by label-equivalence union-find in HBM:
-//     init     label[i] = i (masked) | -1
-//     merge    for each masked voxel and each "backward" neighbour (linear offset < 0) of equal level:
-//              union by atomicMin on the larger root (the returned old value keeps the structure consistent
-//              when views are stale, so no inter-workgroup fence is needed inside the kernel)
-//     flatten  label[i] = root(i);   count  size[root] += 1;   stats  maxRegion, nzones
-// The root of a zone is its smallest linear index = the voxel where the reference's raster scan discovers the
-// zone, so listing roots in index order reproduces the reference's tempData order exactly (cmatrices.c:255-258).
+// Segment mode (one box = the whole array): zones are the connected components of equal-level masked voxels under the
+// angle set.  Two models:
+//   * packed-byte path (<= 3-D, the full 26- or in-plane 8-neighbourhood, levels 1..255) -- the DENSE model:
+//       glszm_tile8_kernel        zones labelled inside 8 x 8 x 64 tiles in LDS (union-find over in-tile indices); every tile
+//                                 component gets a dense id; vid[voxel] = id of its tile component; the same-level
+//                                 neighbours in OTHER tiles that no in-tile neighbour already ties to the voxel go to a
+//                                 work list of pairs
+//       glszm_dense_init_kernel   parent[id] = id, zsize[id] = voxels of the tile component
+//       glszm_pairs_kernel        union-find over the dense ids along the work list (atomicMin on the larger root)
+//       glszm_rootsum_dense_kernel  counts folded into the zone roots, parent[] flattened
+//       glszm_stats / fill kernels  walk the ids (a zone = an id with parent[id] == id; level in tinfo[id] >> 16)
+//     The ordered zone list (tempData parity, cmatrices.c:255-258) needs the first voxel of every zone: a scan of vid[]
+//     (glszm_zmin_kernel), on demand.
+//   * any other call -- the label-volume model: label[i] = i (masked) | -1, unions by atomicMin on the larger root (the
+//     returned old value keeps the structure consistent when views are stale), flatten, count; the root of a zone is its
+//     smallest linear index = the voxel where the reference's raster scan discovers the zone, so listing roots in index
+//     order reproduces the reference's tempData order exactly.
 //
 // Voxel mode (many small boxes): one lane per kernel runs the reference's raster-order flood fill inside its
 // box with a private visited map / stack (interleaved [slot][kernel] so neighbouring lanes touch neighbouring
