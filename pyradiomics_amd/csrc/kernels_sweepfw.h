@@ -435,7 +435,8 @@ struct FwWave {
   __device__ __forceinline__ void rotate_reg(int &r, int xlevel) {
     if (!haspad) {
       if (PLAIN) {
-#ifndef PRAD_FW_NOASM
+#if defined(PRAD_DBG_NOEDGE)   // ablation build (wrong results): the line that leaves the row is not closed
+#elif !defined(PRAD_FW_NOASM)
         const unsigned long long em = DX > 0 ? 0x8000000000000000ull : 1ull;   // lane 63 / lane 0
         asm volatile("s_mov_b64 exec, %[m]\n\tds_add_u32 %[r], %[one]\n\ts_mov_b64 exec, -1" ::[m] "s"(em), [r] "v"(r), [one] "v"(one) : "memory");
 #else
@@ -584,9 +585,13 @@ struct FwWave {
         if (it == 0) {
           chunk = wid;
         } else {
+#ifdef PRAD_DBG_NOGRAB      // ablation build: static round-robin hand-out, no dequeue atomics
+          chunk = wid + it * nwaves;
+#else
           int grabbed = 0;
           if (lane == 0) grabbed = atomicAdd(work, 1);
           chunk = nwaves + __builtin_amdgcn_readfirstlane(grabbed);
+#endif
         }
         if (chunk >= D.chunks) break;
         piece = chunk / NU;
@@ -687,7 +692,11 @@ struct FwWave {
           if (LONG && za) calm_zero();   // (without LONG every length a line can reach has its slot)
           if (grp && safe == 0) {
             calm_padding();
+#ifdef PRAD_DBG_NOMARGIN   // ablation build (wrong on long runs): no margin checks
+            if (true) {
+#else
             if (!LONG && !maybe_dead) {
+#endif
               safe = 2;   // every run length has its slot and no line is dead
             } else {
               const unsigned m = young > 0 ? margin<true>() : margin<false>();
