@@ -317,44 +317,65 @@ struct PackWave {
       u32 ow[4];
       // Four voxels at a time with packed-byte arithmetic (the per-voxel form cost ~12 VALU per voxel on a kernel that is
       // bound by its instruction issue, profiles/r03_probes.md section 3): low bytes of the four levels gathered by three
-      // v_perm, mask bytes widened to 0xff, "level > Ng" and "level 0 under the mask" as any-byte tests.  Whatever is not the
-      // plain case -- a level with bits beyond its low byte, an irregular level under the mask -- takes the exact per-voxel
-      // form below (a rare, divergent branch): the results are the same in every case.
-      const u32 ngadd = (0x7fu - (u32)J.Ng) * 0x01010101u;        // (Ng <= 44 on this path)
+      // v_perm.  FAST PATH, decided once for the 16 voxels of the piece: every voxel lies inside the mask and every level
+      // is regular (1..Ng, no bits beyond the low byte) -- then the packed bytes are the levels and nothing is outside the
+      // ROI.  With q = pk - 0x01010101 and r = q + (0x80 - Ng) * 0x01010101, bit 7 of some byte of pk | q | r is set iff
+      // some byte of pk is 0 or > Ng (the lowest irregular byte sees no borrow / carry from below; Ng <= 44 on this path).
+      const u32 K80 = 0x80808080u, K7F = 0x7f7f7f7fu, K01 = 0x01010101u;
+      const u32 radd = (0x80u - (u32)J.Ng) * K01;
+      u32 pk[4], nzw[4], badbits = 0, wideall = 0, nzall = K80;
 #pragma unroll
       for (int w = 0; w < 4; w++) {
         const u32 l0 = (u32)lv[w * 4], l1 = (u32)lv[w * 4 + 1], l2 = (u32)lv[w * 4 + 2], l3 = (u32)lv[w * 4 + 3];
-        const u32 wide = (l0 | l1 | l2 | l3) & 0xffffff00u;
+        wideall |= l0 | l1 | l2 | l3;
         const u32 p01 = __builtin_amdgcn_perm(l1, l0, 0x0c0c0400u), p23 = __builtin_amdgcn_perm(l3, l2, 0x0c0c0400u);
-        const u32 pk = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
-        const u32 nz = (((mw[w] & 0x7f7f7f7fu) + 0x7f7f7f7fu) | mw[w]) & 0x80808080u;   // bit 7 of every non-zero mask byte
-        const u32 m8 = (nz >> 7) * 0xffu;
-        const u32 lvm = pk & m8;                                                         // levels under the mask, 0 elsewhere
-        const u32 gt = (((lvm & 0x7f7f7f7fu) + ngadd) | lvm) & 0x80808080u;              // a byte > Ng
-        const u32 t = pk | ~m8;
-        const u32 zero_in = (t - 0x01010101u) & ~t & 0x80808080u;                        // != 0 iff a masked voxel has level 0
-        u32 o = lvm << PRAD_FUSED_SHIFT;
-        if (wide | gt | zero_in) {
-          o = 0;
-#pragma unroll
-          for (int b = 0; b < 4; b++) {
-            const bool in = (mw[w] >> (8 * b)) & 0xffu;
-            const int l = lv[w * 4 + b];
-            const bool regular = in && l >= 1 && l <= J.Ng;
-            bad |= in && !regular;
-            o |= (regular ? ((u32)l << PRAD_FUSED_SHIFT) : 0u) << (8 * b);   // (an irregular level packs as 0: never a table index)
-          }
-        }
-        ow[w] = o;
+        pk[w] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+        nzw[w] = ((mw[w] & K7F) + K7F) | mw[w];                 // bit 7 of every non-zero mask byte
+        nzall &= nzw[w];
+        const u32 q = pk[w] - K01;
+        badbits |= pk[w] | q | (q + radd);
       }
-      u32 zb = 0;
+      if ((((badbits | ~nzall) & K80) | (wideall & 0xffffff00u)) == 0) {
 #pragma unroll
-      for (int w = 0; w < 4; w++) zb |= (ow[w] - 0x01010101u) & ~ow[w] & 0x80808080u;
-      if (zb) {   // the piece holds a voxel outside the ROI: flag its row(s) (a 16-voxel piece spans at most two rows)
-        J.flags[3] = 1;
-        const unsigned e0 = (unsigned)(lev - (unsigned long long)(size_t)J.levels);       // (volumes stay below 2^31 voxels)
-        J.rowzero[e0 / (unsigned)J.NX] = 1;
-        J.rowzero[(e0 + 15u) / (unsigned)J.NX] = 1;
+        for (int w = 0; w < 4; w++) ow[w] = pk[w] << PRAD_FUSED_SHIFT;
+      } else {
+        // the general form, word by word: mask bytes widened to 0xff, "level > Ng" and "level 0 under the mask" as any-byte
+        // tests; a word that is not plain -- a level with bits beyond its low byte, an irregular level under the mask --
+        // takes the exact per-voxel form (a rare, divergent branch): the results are the same in every case
+        const u32 ngadd = (0x7fu - (u32)J.Ng) * K01;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          const u32 l0 = (u32)lv[w * 4], l1 = (u32)lv[w * 4 + 1], l2 = (u32)lv[w * 4 + 2], l3 = (u32)lv[w * 4 + 3];
+          const u32 wide = (l0 | l1 | l2 | l3) & 0xffffff00u;
+          const u32 nz = nzw[w] & K80;
+          const u32 m8 = (nz << 1) - (nz >> 7);                                            // 0xff for every non-zero mask byte
+          const u32 lvm = pk[w] & m8;                                                      // levels under the mask, 0 elsewhere
+          const u32 gt = (((lvm & K7F) + ngadd) | lvm) & K80;                              // a byte > Ng
+          const u32 t = pk[w] | ~m8;
+          const u32 zero_in = (t - K01) & ~t & K80;                                        // != 0 iff a masked voxel has level 0
+          u32 o = lvm << PRAD_FUSED_SHIFT;
+          if (wide | gt | zero_in) {
+            o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+              const bool in = (mw[w] >> (8 * b)) & 0xffu;
+              const int l = lv[w * 4 + b];
+              const bool regular = in && l >= 1 && l <= J.Ng;
+              bad |= in && !regular;
+              o |= (regular ? ((u32)l << PRAD_FUSED_SHIFT) : 0u) << (8 * b);   // (an irregular level packs as 0: never a table index)
+            }
+          }
+          ow[w] = o;
+        }
+        u32 zb = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) zb |= (ow[w] - K01) & ~ow[w] & K80;
+        if (zb) {   // the piece holds a voxel outside the ROI: flag its row(s) (a 16-voxel piece spans at most two rows)
+          J.flags[3] = 1;
+          const unsigned e0 = (unsigned)(lev - (unsigned long long)(size_t)J.levels);       // (volumes stay below 2^31 voxels)
+          J.rowzero[e0 / (unsigned)J.NX] = 1;
+          J.rowzero[(e0 + 15u) / (unsigned)J.NX] = 1;
+        }
       }
       *reinterpret_cast<uint4 *>((size_t)lev) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
     }
@@ -764,6 +785,11 @@ struct FwWave {
 // (z, y)), stages 64 x 64-voxel tiles through LDS (16 B per lane coalesced in, one row per lane out) and every lane walks
 // its own row, four voxels (one staged word) per asm block.  Table layout and run state as above.
 // ---------------------------------------------------------------------------------------------------------------
+// ZA (zero aware): a stretch of voxels outside the ROI never touches the table (second compare: event lanes whose previous
+// voxel is 0 drop out before the ds_add).  Without ZA -- the pack saw no voxel outside the ROI, flags[3] == 0 -- the only
+// previous level 0 is the one in front of a row's first voxel, whose event (state 0) lands in the scratch words in front of
+// the table: 4 VALU per voxel instead of 5.
+template <bool ZA>
 __device__ __forceinline__ void fw_row_word(const FwTab &T, u32 one, int &s, u32 c, u32 x) {
   int t;
 #define PRAD_FW_RCOL(J)                                                                                          \
@@ -774,17 +800,32 @@ __device__ __forceinline__ void fw_row_word(const FwTab &T, u32 one, int &s, u32
   "ds_add_u32 %[t], %[one]\n\t"                                                                                  \
   "s_mov_b64 exec, -1\n\t"                                                                                       \
   "v_add_u32 %[s], %[Q], %[s]\n\t"
-  u32 z = 0;      // zero aware: a stretch of unmasked voxels never touches the table
-  asm volatile("" : "+v"(z));
-  asm volatile(PRAD_FW_RCOL(0) PRAD_FW_RCOL(1) PRAD_FW_RCOL(2) PRAD_FW_RCOL(3)
-               : [s] "+v"(s), [t] "=&v"(t)
-               : [c] "v"(c), [x] "v"(x), [one] "v"(one), [P4] "s"(T.P4), [Q] "s"(T.Q), [z] "v"(z)
-               : "vcc", "memory");
+#define PRAD_FW_RCOL_NZ(J)                                                                                       \
+  "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:BYTE_" #J " src1_sel:BYTE_" #J "\n\t"                             \
+  "v_add_u32_sdwa %[t], %[s], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t"   \
+  "ds_add_u32 %[t], %[one]\n\t"                                                                                  \
+  "v_mul_u32_u24_sdwa %[s], %[P4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t" \
+  "s_mov_b64 exec, -1\n\t"                                                                                       \
+  "v_add_u32 %[s], %[Q], %[s]\n\t"
+  if (ZA) {
+    u32 z = 0;      // zero aware: a stretch of unmasked voxels never touches the table
+    asm volatile("" : "+v"(z));
+    asm volatile(PRAD_FW_RCOL(0) PRAD_FW_RCOL(1) PRAD_FW_RCOL(2) PRAD_FW_RCOL(3)
+                 : [s] "+v"(s), [t] "=&v"(t)
+                 : [c] "v"(c), [x] "v"(x), [one] "v"(one), [P4] "s"(T.P4), [Q] "s"(T.Q), [z] "v"(z)
+                 : "vcc", "memory");
+  } else {
+    asm volatile(PRAD_FW_RCOL_NZ(0) PRAD_FW_RCOL_NZ(1) PRAD_FW_RCOL_NZ(2) PRAD_FW_RCOL_NZ(3)
+                 : [s] "+v"(s), [t] "=&v"(t)
+                 : [c] "v"(c), [x] "v"(x), [one] "v"(one), [P4] "s"(T.P4), [Q] "s"(T.Q)
+                 : "vcc", "memory");
+  }
 #undef PRAD_FW_RCOL
+#undef PRAD_FW_RCOL_NZ
 }
 
 // the walk along x for workgroup bx of nblocks; the LDS table (layout h, zeroed by the caller) sits at address 0
-template <bool LONG>
+template <bool LONG, bool ZA>
 __device__ __forceinline__ void fw_rows_role(const HistLayout &h, const FwTab &T, u32 *lds, const uint8_t *__restrict__ L,
                                              long long nrows, int NX, int pitch, int bx, int nblocks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -855,14 +896,14 @@ __device__ __forceinline__ void fw_rows_role(const HistLayout &h, const FwTab &T
 #pragma unroll
               for (int b = 0; b < 4; b++) fw_checked<LONG>(T, dummy, s, (int)((x >> (8 * b)) & 0xffu), (int)((c >> (8 * b)) & 0xffu), false);
             } else {
-              fw_row_word(T, one, s, c, x);
+              fw_row_word<ZA>(T, one, s, c, x);
             }
             pw = c;
           }
         } else {
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            fw_row_word(T, one, s, wds[k], __builtin_amdgcn_alignbyte(wds[k], pw, 3));
+            fw_row_word<ZA>(T, one, s, wds[k], __builtin_amdgcn_alignbyte(wds[k], pw, 3));
             pw = wds[k];
           }
         }
@@ -892,7 +933,8 @@ __global__ void __launch_bounds__(512) sweep_fw_rows_kernel(const uint8_t *__res
   __syncthreads();
   FwTab T;
   T.init(h, Nr, glrlm_acc + (size_t)slot * Ng * Nr);
-  fw_rows_role<LONG>(h, T, lds, L, nrows, NX, pitch, (int)blockIdx.x, (int)gridDim.x);
+  if (flags[3] != 0) fw_rows_role<LONG, true>(h, T, lds, L, nrows, NX, pitch, (int)blockIdx.x, (int)gridDim.x);
+  else fw_rows_role<LONG, false>(h, T, lds, L, nrows, NX, pitch, (int)blockIdx.x, (int)gridDim.x);   // (no voxel outside the ROI)
   flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, slot, glcm_acc, glrlm_acc);
 }
 
