@@ -849,10 +849,9 @@ __global__ void finalize_glcm_kernel(const u32 *__restrict__ acc, const u32 *__r
 
 // The two GLCM post-passes as one launch (five tiny kernels per volume were 17 % of a 256^3 call): the first nb1
 // workgroups convert the off-diagonal counts, the others resolve the diagonal from the runs, one wave per (level, angle).
-__global__ void __launch_bounds__(256) finalize_glcm_diag_kernel(const u32 *__restrict__ glcm_acc,
-                                                                 const u32 *__restrict__ glrlm_acc, int Ng, int Nr, int Na,
-                                                                 int nb1, double *__restrict__ glcm_out,
-                                                                 int *__restrict__ multi) {
+__global__ void __launch_bounds__(256) finalize_glcm_diag_kernel(const u32 *__restrict__ glcm_acc, u32 *glrlm_acc, int Ng, int Nr,
+                                                                 int Na, int nb1, double *__restrict__ glcm_out,
+                                                                 int *__restrict__ multi, int restore_from = -1) {
   if ((int)blockIdx.x < nb1) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)Ng * Ng * Na;
@@ -867,12 +866,13 @@ __global__ void __launch_bounds__(256) finalize_glcm_diag_kernel(const u32 *__re
   const int pair = ((int)blockIdx.x - nb1) * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (pair >= Ng * Na) return;
   const int i = pair % Ng, a = pair / Ng;
-  const u32 *row = glrlm_acc + ((size_t)a * Ng + i) * Nr;
-  unsigned long long pairs = 0;
+  u32 *row = glrlm_acc + ((size_t)a * Ng + i) * Nr;
+  unsigned long long pairs = 0, longer = 0;   // sum (len-1) * runs; runs of length >= 2
   int found = 0;
   for (int r = lane; r < Nr; r += 64) {
     const u32 v = row[r];
     pairs += (unsigned long long)r * v;
+    if (r > 0) longer += v;
     found |= (r > 0 && v != 0);
   }
   const u32 *grow = glcm_acc + ((size_t)a * Ng + i) * Ng;
@@ -880,6 +880,20 @@ __global__ void __launch_bounds__(256) finalize_glcm_diag_kernel(const u32 *__re
   for (int o = 32; o > 0; o >>= 1) pairs += __shfl_xor(pairs, o);
   if (lane == 0) glcm_out[((size_t)i * Ng + i) * Na + a] = (double)pairs;
   if (__ballot(found) != 0 && lane == 0) multi[a] = 1;
+  // restore_from >= 0 (two-table walk with SKIP1, kernels_sweepfw2.h): the line angles did not record their runs of length
+  // 1.  Every voxel of level i lies on exactly one line of every angle, so sum_len len * GLRLM_a[i][len] is the same number
+  // N_i for all angles; the angle along x (slot restore_from) recorded all of its runs:
+  //   GLRLM_a[i][1] = N_i - sum_{len >= 2} len * GLRLM_a[i][len] = N_i - (pairs + longer)
+  if (restore_from >= 0 && a != restore_from) {
+    const u32 *xrow = glrlm_acc + ((size_t)restore_from * Ng + i) * Nr;
+    unsigned long long nvox = 0;
+    for (int r = lane; r < Nr; r += 64) nvox += (unsigned long long)(r + 1) * xrow[r];
+    for (int o = 32; o > 0; o >>= 1) {
+      nvox += __shfl_xor(nvox, o);
+      longer += __shfl_xor(longer, o);
+    }
+    if (lane == 0) row[0] = (u32)(nvox - (pairs + longer));
+  }
 }
 
 // flags / sticky (deferred calls, both may be null): the levels verdict of the call is latched by this launch too

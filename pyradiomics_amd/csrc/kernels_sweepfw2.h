@@ -56,7 +56,8 @@ __device__ __noinline__ void fw2_long_event(const Fw2Tab &T, int lv, int idx) {
 }
 
 // One voxel-step of one line, every case handled.  x, c = level*4 of the previous / current voxel.
-template <bool LONG>
+//   SKIP1: runs of length 1 are NOT recorded (the caller restores GLRLM[.][1] from the level counts: Fw2Wave::SKIP1)
+template <bool LONG, bool SKIP1>
 __device__ __forceinline__ void fw2_checked(const Fw2Tab &T, int k1, int dummy, int &p, int &q, int x, int c, bool tail) {
   const bool chg = c != x;
   const bool alive = p >= T.S;
@@ -64,7 +65,7 @@ __device__ __forceinline__ void fw2_checked(const Fw2Tab &T, int k1, int dummy, 
   const int lb = q - p - k1;                   // 4 len (k1: this lane's K1 + offset of its B copy)
   const bool inlds = !LONG || lb <= T.lenlim;
   lds_bump(ev ? p + c : dummy);                // the pair (cur = 0: the run ended at a line end / outside the ROI: ignored)
-  lds_bump((ev && inlds) ? q : dummy);         // the run
+  lds_bump((ev && inlds && !(SKIP1 && lb == 4)) ? q : dummy);   // the run
   if (LONG && ev && !inlds) fw2_long_event(T, x >> PRAD_FUSED_SHIFT, (lb >> 2) - 1);
   const int fp = tail ? 0 : __mul24(c, T.S4);
   const int grown = alive ? q + 4 : min(q + 4, k1 + T.lenlim);   // (a level-0 line's cursor stops at the last slot)
@@ -74,22 +75,56 @@ __device__ __forceinline__ void fw2_checked(const Fw2Tab &T, int k1, int dummy, 
 
 // The plain step of the two lines whose levels are the 16-bit halves of c (current) and x (previous); exec-masked like
 // fw_plain_word.  Only valid while no run can outgrow its length slots (margin()).
-__device__ __forceinline__ void fw2_plain_word(const Fw2Tab &T, int k1, u32 one, int &p0, int &q0, int &p1, int &q1, u32 c, u32 x) {
+template <bool SKIP1>
+__device__ __forceinline__ void fw2_plain_word(const Fw2Tab &T, int k1, int k14, u32 one, int &p0, int &q0, int &p1, int &q1, u32 c, u32 x) {
   int t;
+#ifdef PRAD_DBG_FW2_NOPAIR    // ablation builds (wrong results): the step without its pair / run atomic
+#define PRAD_FW2_DSA ""
+#else
+#define PRAD_FW2_DSA "ds_add_u32 %[t], %[one]\n\t"
+#endif
+#ifdef PRAD_DBG_FW2_NORUN
+#define PRAD_FW2_DSB(QJ) ""
+#else
+#define PRAD_FW2_DSB(QJ) "ds_add_u32 %[" QJ "], %[one]\n\t"
+#endif
 #define PRAD_FW2_COL(J, PJ, QJ)                                                                                          \
   "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:WORD_" #J " src1_sel:WORD_" #J "\n\t"                                     \
   "v_add_u32_sdwa %[t], %[" PJ "], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #J "\n\t"       \
-  "ds_add_u32 %[t], %[one]\n\t"                                                                                          \
-  "ds_add_u32 %[" QJ "], %[one]\n\t"                                                                                     \
+  PRAD_FW2_DSA PRAD_FW2_DSB(QJ)                                                                                          \
   "v_mul_u32_u24_sdwa %[" PJ "], %[S4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #J "\n\t" \
   "v_add_u32 %[" QJ "], %[K1], %[" PJ "]\n\t"                                                                            \
   "s_mov_b64 exec, -1\n\t"                                                                                               \
   "v_add_u32 %[" QJ "], 4, %[" QJ "]\n\t"
-  asm volatile(PRAD_FW2_COL(0, "p0", "q0") PRAD_FW2_COL(1, "p1", "q1")
-               : [p0] "+v"(p0), [q0] "+v"(q0), [p1] "+v"(p1), [q1] "+v"(q1), [t] "=&v"(t)
-               : [c] "v"(c), [x] "v"(x), [one] "v"(one), [S4] "s"(T.S4), [K1] "v"(k1)
-               : "vcc", "memory");
+// SKIP1: among the event lanes only those whose run is longer than one voxel (cursor - row != K1 + 4) add to B; vcc keeps
+// the event lanes for the state update behind it.  On iid levels 31 of 32 runs have length 1: the second ds_add of the
+// step, which made the two-table walk LDS-bound (0.73 -> 0.44 ms per 512^3 volume without it), goes out almost empty.
+#define PRAD_FW2_COL_S(J, PJ, QJ)                                                                                        \
+  "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:WORD_" #J " src1_sel:WORD_" #J "\n\t"                                     \
+  "v_add_u32_sdwa %[t], %[" PJ "], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #J "\n\t"       \
+  PRAD_FW2_DSA                                                                                                           \
+  "v_sub_u32 %[t], %[" QJ "], %[" PJ "]\n\t"                                                                             \
+  "v_mul_u32_u24_sdwa %[" PJ "], %[S4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #J "\n\t" \
+  "v_cmpx_ne_u32_e64 %[sm], %[t], %[K14]\n\t"                                                                            \
+  PRAD_FW2_DSB(QJ)                                                                                                       \
+  "s_mov_b64 exec, vcc\n\t"                                                                                              \
+  "v_add_u32 %[" QJ "], %[K1], %[" PJ "]\n\t"                                                                            \
+  "s_mov_b64 exec, -1\n\t"                                                                                               \
+  "v_add_u32 %[" QJ "], 4, %[" QJ "]\n\t"
+  if (SKIP1) {
+    unsigned long long sm;
+    asm volatile(PRAD_FW2_COL_S(0, "p0", "q0") PRAD_FW2_COL_S(1, "p1", "q1")
+                 : [p0] "+v"(p0), [q0] "+v"(q0), [p1] "+v"(p1), [q1] "+v"(q1), [t] "=&v"(t), [sm] "=&s"(sm)
+                 : [c] "v"(c), [x] "v"(x), [one] "v"(one), [S4] "s"(T.S4), [K1] "v"(k1), [K14] "v"(k14)
+                 : "vcc", "memory");
+  } else {
+    asm volatile(PRAD_FW2_COL(0, "p0", "q0") PRAD_FW2_COL(1, "p1", "q1")
+                 : [p0] "+v"(p0), [q0] "+v"(q0), [p1] "+v"(p1), [q1] "+v"(q1), [t] "=&v"(t)
+                 : [c] "v"(c), [x] "v"(x), [one] "v"(one), [S4] "s"(T.S4), [K1] "v"(k1)
+                 : "vcc", "memory");
+  }
 #undef PRAD_FW2_COL
+#undef PRAD_FW2_COL_S
 }
 
 struct __attribute__((packed)) u128_unaligned { u32 a, b, c, d; };
@@ -130,13 +165,17 @@ __device__ __forceinline__ void fw2_make_x(const u32 (&P)[K / 2], u32 (&X)[K / 2
 
 #define FW2_EL(W, j) ((int)__builtin_amdgcn_ubfe((W)[(j) >> 1], 16 * ((j) & 1), 16))
 
-template <bool LONG, int K, int DX, bool HASPAD>
+// SKIP1: runs of length 1 are not recorded by the walk.  Every ROI voxel lies on exactly one line of an angle, so
+// sum_len len * GLRLM_a[g][len] = N_g (the voxels of level g) for EVERY angle a; the x angle's kernel records all of its runs,
+// and the finalize step sets GLRLM_a[g][1] = N_g - sum_{len >= 2} len * GLRLM_a[g][len] (exact integers).
+template <bool LONG, int K, int DX, bool HASPAD, bool SKIP1>
 struct Fw2Wave {
   static constexpr int KW = K / 2;
   static constexpr int U = PRAD_FW_U;
   const Fw2Tab &T;
   int dummy, lane, edge_lane;
   int k1v;         // K1 + byte offset of this lane's B copy
+  int k14;         // k1v + 4: cursor - row of a run of length 1
   int kdelta;      // k1v minus the k1v of the lane a drifting line comes from (lane 0 / 63: the line comes from outside, k1v)
   u32 one;
   static constexpr bool haspad = HASPAD;
@@ -156,7 +195,8 @@ struct Fw2Wave {
       const int src = lane - (DX > 0 ? 1 : -1);
       kdelta = (DX == 0 || src < 0 || src > 63) ? k1v : ((lane % T.C) - (src % T.C)) * T.lenlim;
     }
-    asm volatile("" : "+v"(k1v), "+v"(kdelta));
+    k14 = k1v + 4;
+    asm volatile("" : "+v"(k1v), "+v"(kdelta), "+v"(k14));
     const int col0 = first_col(NX);
 #pragma unroll
     for (int w = 0; w < KW; w++) {
@@ -195,9 +235,16 @@ struct Fw2Wave {
     if (!haspad) {
       if (PLAIN) {
         const unsigned long long em = DX > 0 ? 0x8000000000000000ull : 1ull;   // lane 63 / lane 0
-        asm volatile("s_mov_b64 exec, %[m]\n\tds_add_u32 %[r], %[one]\n\ts_mov_b64 exec, -1" ::[m] "s"(em), [r] "v"(rq), [one] "v"(one) : "memory");
+        if (SKIP1) {
+          int t;
+          asm volatile("v_sub_u32 %[t], %[r], %[p]\n\tv_cmp_ne_u32 vcc, %[t], %[K14]\n\ts_and_b64 exec, vcc, %[m]\n\t"
+                       "ds_add_u32 %[r], %[one]\n\ts_mov_b64 exec, -1"
+                       : [t] "=&v"(t) : [m] "s"(em), [r] "v"(rq), [p] "v"(rp), [one] "v"(one), [K14] "v"(k14) : "vcc", "memory");
+        } else {
+          asm volatile("s_mov_b64 exec, %[m]\n\tds_add_u32 %[r], %[one]\n\ts_mov_b64 exec, -1" ::[m] "s"(em), [r] "v"(rq), [one] "v"(one) : "memory");
+        }
       } else if (lane == edge_lane) {
-        fw2_checked<LONG>(T, k1v, dummy, rp, rq, xlevel, 0, false);
+        fw2_checked<LONG, SKIP1>(T, k1v, dummy, rp, rq, xlevel, 0, false);
       }
     }
     rp = (int)(DX > 0 ? fw_shr1((u32)rp) : fw_shl1((u32)rp));
@@ -208,7 +255,7 @@ struct Fw2Wave {
     u32 X[KW];
     fw2_make_x<K, DX>(P, X);
 #pragma unroll
-    for (int j = 0; j < K; j++) fw2_checked<LONG>(T, k1v, dummy, lp[j], lq[j], FW2_EL(X, j), FW2_EL(C, j), tail);
+    for (int j = 0; j < K; j++) fw2_checked<LONG, SKIP1>(T, k1v, dummy, lp[j], lq[j], FW2_EL(X, j), FW2_EL(C, j), tail);
     if (DX > 0) {
       rotate_reg<false>(lp[K - 1], lq[K - 1], FW2_EL(C, K - 1));
       const int ip = lp[K - 1], iq = lq[K - 1];
@@ -242,7 +289,7 @@ struct Fw2Wave {
 #pragma unroll
       for (int w = 0; w < KW; w++) {
         const int r0 = (((2 * w + 0 - k * DX) % K) + K) % K, r1 = (((2 * w + 1 - k * DX) % K) + K) % K;
-        fw2_plain_word(T, k1v, one, lp[r0], lq[r0], lp[r1], lq[r1], v[k][w], X[w]);
+        fw2_plain_word<SKIP1>(T, k1v, k14, one, lp[r0], lq[r0], lp[r1], lq[r1], v[k][w], X[w]);
       }
       if (DX > 0) {
         const int r = (((K - 1 - k) % K) + K) % K;
@@ -451,7 +498,7 @@ __device__ __forceinline__ void fw2_flush(const u32 *lds, const Fw2Tab &T, int s
   }
 }
 
-template <bool LONG, int K, bool HASPAD>
+template <bool LONG, int K, bool HASPAD, bool SKIP1>
 __global__ void __launch_bounds__(1024) sweep_fw2_kernel(FwSet set, const uint8_t *__restrict__ L, int Ng, int Nr, int RS2, int C,
                                                          u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
                                                          int *__restrict__ work, int *__restrict__ flags) {
@@ -472,13 +519,13 @@ __global__ void __launch_bounds__(1024) sweep_fw2_kernel(FwSet set, const uint8_
   T.init(Ng, RS2, C, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
   int *wk = work + PRAD_FW_WORK_STRIDE * PRAD_FW_DOMAINS * role;
   if (D.dx == 0) {
-    Fw2Wave<LONG, K, 0, HASPAD> w(T, set.NX);
+    Fw2Wave<LONG, K, 0, HASPAD, SKIP1> w(T, set.NX);
     w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0);
   } else if (D.dx > 0) {
-    Fw2Wave<LONG, K, 1, HASPAD> w(T, set.NX);
+    Fw2Wave<LONG, K, 1, HASPAD, SKIP1> w(T, set.NX);
     w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0);
   } else {
-    Fw2Wave<LONG, K, -1, HASPAD> w(T, set.NX);
+    Fw2Wave<LONG, K, -1, HASPAD, SKIP1> w(T, set.NX);
     w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0);
   }
   fw2_flush(lds, T, D.slot, glcm_acc, glrlm_acc);

@@ -247,6 +247,7 @@ struct SweepPlan {
   int Nz = 1, Ny = 1, Nx = 1;  // volume embedded in 3-D
   SweepSet lines;              // angles marching along z or y
   int row_slot = -1;           // slot of the angle along x, or -1
+  bool skip1 = false;          // two-table walk: runs of length 1 are not recorded, finalize restores them from the x angle's runs
   bool fused = false;          // one [prev][len][cur] table instead of separate GLCM / GLRLM tables
   int LPL = 1;                 // lines per lane of the lines kernel (1, 2, 4)
   int pitch = 0, padw = 0;     // row pitch / periodic pad of the packed level volume
@@ -356,6 +357,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     const int rsr = fit_rs(true, true, false, Ng, Nr, 116 * 1024);   // (+ 40 KB of staging tiles: within the 160 KB)
     if ((rs2 >= 24 || rs2 >= Nr) && rs2 >= 1 && rsr >= std::min(Nr, 4)) {
       p.fw2 = true;
+      p.skip1 = getenv("PRAD_FW2_NOSKIP1") == nullptr;   // (needs the x angle in the call: cleared below when it is not)
       p.RS2 = (int)rs2;
       p.LONGfw2 = rs2 < Nr;
       p.fw2_copies = copies;
@@ -523,6 +525,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     p.fw = false;
     if (p.fw2) return SweepPlan();   // (only the x angle was asked for: not worth a plan of its own) -> generic path
   }
+  if (p.row_slot < 0) p.skip1 = false;   // no x angle in this call: nothing to restore the runs of length 1 from
   p.ok = true;
   return p;
 }
@@ -592,22 +595,24 @@ int launch_fw(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *lev
                     : launch_fw_k<false, 8>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
 }
 
+template <bool LNG, int K, bool HASPAD, bool SKIP1>
+int launch_fw2_khs(Call &k, const SweepPlan &p, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *work,
+                   int *flags_d) {
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw2_kernel<LNG, K, HASPAD, SKIP1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw2));
+  hipLaunchKernelGGL((sweep_fw2_kernel<LNG, K, HASPAD, SKIP1>), dim3(p.fw_blocks), dim3(1024), p.lds_fw2, k.s, p.fwset, levels16, Ng,
+                     Nr, p.RS2, p.fw2_copies, glcm_acc, glrlm_acc, work, flags_d);
+  return check_launch("sweep_fw2_kernel");
+}
 template <bool LNG, int K>
 int launch_fw2_k(Call &k, const SweepPlan &p, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *multi,
                  int *flags_d) {
   int *work = multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE;
-  if (p.Nx != 64 * K) {
-    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw2_kernel<LNG, K, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw2));
-    hipLaunchKernelGGL((sweep_fw2_kernel<LNG, K, true>), dim3(p.fw_blocks), dim3(1024), p.lds_fw2, k.s, p.fwset, levels16, Ng, Nr,
-                       p.RS2, p.fw2_copies, glcm_acc, glrlm_acc, work, flags_d);
-  } else {
-    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw2_kernel<LNG, K, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw2));
-    hipLaunchKernelGGL((sweep_fw2_kernel<LNG, K, false>), dim3(p.fw_blocks), dim3(1024), p.lds_fw2, k.s, p.fwset, levels16, Ng, Nr,
-                       p.RS2, p.fw2_copies, glcm_acc, glrlm_acc, work, flags_d);
-  }
-  return check_launch("sweep_fw2_kernel");
+  if (p.Nx != 64 * K)
+    return p.skip1 ? launch_fw2_khs<LNG, K, true, true>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d)
+                   : launch_fw2_khs<LNG, K, true, false>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d);
+  return p.skip1 ? launch_fw2_khs<LNG, K, false, true>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d)
+                 : launch_fw2_khs<LNG, K, false, false>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d);
 }
 int launch_fw2(Call &k, const SweepPlan &p, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *multi,
                int *flags_d) {
@@ -833,7 +838,7 @@ int vol_finalize(Call &k, const VolState &v, int *sticky) {
     if (glcm && glrlm && runs_diag) {
       const int nb1 = (int)blocks_for((long long)Ng * Ng * Na), nb2 = (Ng * Na + 3) / 4;
       hipLaunchKernelGGL(finalize_glcm_diag_kernel, dim3(nb1 + nb2), dim3(256), 0, k.s, v.glcm_acc, v.glrlm_acc, Ng, Nr, Na, nb1,
-                         glcm, v.multi);
+                         glcm, v.multi, (p.fw2 && p.skip1 && p.lines.count > 0) ? p.row_slot : -1);
       PRAD_TRY(check_launch("finalize_glcm_diag_kernel"));
     } else if (glcm) {
       hipLaunchKernelGGL(finalize_glcm_kernel, dim3(blocks_for((long long)Ng * Ng * Na)), dim3(256), 0, k.s,
