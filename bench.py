@@ -695,6 +695,22 @@ def main() -> None:
                         "job_frac": round(ALG_BYTES_PER_VOXEL * nvox / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                         "case": "the headline on low-pass filtered noise (SURVEY 8d C2(ii)): same size / levels / steps"}
             guarded("smooth", smooth)
+
+            def levels64():
+                # the headline loop at 64 grey levels: 16-bit level volume, two-table walk (kernels_sweepfw2.h)
+                out = {}
+                for d in ("uniform", "smooth"):
+                    im2, mk2 = make_volume(args.size, 64, d, seed=rank, device=device)
+                    el, f2, _ = headline_loop(engine, im2, mk2, 64, Nr, args.steps, args.warmup, fence, [[None, None] for _ in range(4)])
+                    ms2 = el / args.steps * 1e3
+                    out[d] = {"value": round(nvox * args.steps / el / 1e6, 1), "unit": "Mvoxels/s", "ms_per_step": round(ms2, 4),
+                              "vs_32_levels": round(ms2 / (elapsed / args.steps * 1e3), 3) if d == "uniform" else None,
+                              "variant": engine.last_variant()}
+                    del im2, mk2
+                out["case"] = "the headline loop at 64 grey levels (same size / steps), deferred calls"
+                return out
+            if args.levels == 32:
+                guarded("levels64", levels64)
             guarded("config2", lambda: mode_config2(device, engine))
             guarded("config3", lambda: mode_config3(device, engine))
             guarded("fallback", lambda: mode_fallback(device, engine))
