@@ -24,7 +24,7 @@ rocprofv3 --kernel-trace --stats -d $O/stats_lanes -o s -- python $R/bench.py --
 rocprofv3 --kernel-trace --stats -d $O/stats_256 -o s -- python $R/bench.py --steps 20 --warmup 3 $BA --size 256 > $O/stats_256.log 2>&1
 { echo "## bench.py --size 256"; tail -1 $O/stats_256.log | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo; echo; python $R/scripts/rocpd_stats.py $O/stats_256/s_results.db | grep -E "prad|kernel \||---"; echo; } >> $O/kernel_stats.md
 rocprofv3 --kernel-trace --stats -d $O/stats_ng64 -o s -- python $R/bench.py --steps 20 --warmup 3 $BA --levels 64 > $O/stats_ng64.log 2>&1
-{ echo "## bench.py --levels 64 (two-table fixed-window kernel, 16-bit levels)"; tail -1 $O/stats_ng64.log | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo; echo; python $R/scripts/rocpd_stats.py $O/stats_ng64/s_results.db | grep -E "prad|kernel \||---"; echo; } >> $O/kernel_stats.md
+{ echo "## bench.py --levels 64 (two-table fixed-window kernel, 16-bit levels; deferred calls of this path run on two streams, so launches overlap and these durations are NOT kernel speeds: event-timed numbers in r04_probes.md section 16)"; tail -1 $O/stats_ng64.log | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo; echo; python $R/scripts/rocpd_stats.py $O/stats_ng64/s_results.db | grep -E "prad|kernel \||---"; echo; } >> $O/kernel_stats.md
 # the other kernels this round touched: LoG + wavelet (config 3 stages), voxel maps (config 4)
 cat > /tmp/r04_others.py <<PY
 import sys; sys.path.insert(0, "$R")
