@@ -102,57 +102,71 @@ __device__ __forceinline__ unsigned nonzero_bytes3(unsigned w) {  // bit 7 of ev
   return (((w & 0x7f7f7fu) + 0x7f7f7fu) | w) & 0x808080u;
 }
 
+__device__ __forceinline__ unsigned neigh_from_lower_lane(unsigned v) {  // lane i <- lane i-1, lane 0 <- 0 (one DPP move)
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned neigh_from_upper_lane(unsigned v) {  // lane i <- lane i+1, lane 63 <- 0
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+}
+
 // MODE: 0 = GLDM (alpha = 0), 1 = NGTDM, 2 = both from the same neighbourhood reads (the case pipeline asks for both)
+// LDS tables are u32 ([Ng][Na+1] NGTDM sums, then [Ng][Na+1] GLDM counts): a workgroup sees 2^18 voxels or fewer
+// (2^19 at most: neigh_blocks) and a voxel adds at most 26 * 255, so the per-workgroup sums stay below 2^32; the flush widens to the
+// u64 global accumulators.  With both tables (MODE 2) the voxel count of a level -- NGTDM slot 0 -- is the sum of its GLDM
+// row and is only formed in the flush: one LDS atomic per voxel less (the one with the fewest distinct addresses).
 template <int MODE>
 __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t *__restrict__ L, int Nz, int Ny,
                                                      int Nx, int zlo, int zhi, int Ng, int Na,
                                                      u32 *__restrict__ gldm_acc, u64 *__restrict__ ngtdm_acc,
                                                      const int *__restrict__ flags) {
-  extern __shared__ u64 lds64[];
+  extern __shared__ u32 lds32[];
   if (flags[0]) return;
   constexpr bool NGTDM = MODE != 0, GLDM = MODE != 1;
   const int W = Na + 1;
   const int nbins = Ng * W;
-  u32 *h32 = reinterpret_cast<u32 *>(MODE == 2 ? lds64 + nbins : lds64);     // (both: u64 table, then the u32 table)
-  for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
-    if (NGTDM) lds64[i] = 0;
-    if (GLDM) h32[i] = 0;
-  }
+  u32 *hn = lds32;                                   // NGTDM sums (slot 0: voxels of the level, MODE 1 only)
+  u32 *h32 = MODE == 2 ? lds32 + nbins : lds32;      // GLDM counts
+  for (int i = threadIdx.x; i < (MODE == 2 ? 2 : 1) * nbins; i += blockDim.x) lds32[i] = 0;
   __syncthreads();
   const int qpr = Nx >> 2;                      // quads per row
   const long long nquads = (long long)zhi * Ny * qpr;   // centres: planes zlo .. zhi-1
   const long long stride = (long long)gridDim.x * blockDim.x;
   const int lane = threadIdx.x & 63;
+  // byte offset of the (dz, dy) row relative to the centre row (rows are Nx bytes apart, planes Ny rows: wave-uniform)
+  int rowoff[9];
+#pragma unroll
+  for (int r = 0; r < 9; r++) rowoff[r] = ((r / 3 - 1) * Ny + (r % 3 - 1)) * Nx;
   // Consecutive lanes hold consecutive quads: the edge bytes x0-1 / x0+4 of a row ARE the last / first byte of the
   // neighbour lanes' dword of that row (a quad at x0 = 0 / x0 + 4 = Nx has no such neighbour: 0), so only lane 0 / lane 63
   // load theirs -- 9 dword loads per quad instead of 9 dwords + 18 bytes (the texture-address unit was the bound:
-  // see profiles/r03_probes.md).  Every lane of a wave runs the same trips (the shuffles need them all).
+  // see profiles/r03_probes.md).  Every lane of a wave runs the same trips (the lane moves need them all).
   const long long q0 = (long long)zlo * Ny * qpr + (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
   for (long long qw = q0; qw < nquads; qw += stride) {
     const long long q = qw + lane;
     const bool live = q < nquads;
-    // (32-bit divisions: a volume holds fewer than 2^31 voxels, so quad and row numbers fit; the 64-bit forms were a third
-    // of the instructions of an iteration)
+    // (32-bit arithmetic: a volume holds fewer than 2^31 voxels, so quad numbers, row numbers and byte offsets fit; the
+    // 64-bit forms -- four quarter-rate multiplies per neighbour row -- were a quarter of an iteration's issue time)
     const unsigned q32 = live ? (unsigned)q : 0u;
     const unsigned row32 = q32 / (unsigned)qpr;
-    const long long row = row32;
     const int x0 = (int)(q32 - row32 * (unsigned)qpr) << 2;
     const int z = (int)(row32 / (unsigned)Ny), y = (int)(row32 - (unsigned)z * (unsigned)Ny);
-    const unsigned centre = live ? *reinterpret_cast<const unsigned *>(L + row * Nx + x0) : 0u;
+    const unsigned base = q32 << 2;             // byte offset of the quad (rows are Nx = 4 qpr bytes)
+    const unsigned centre = live ? *reinterpret_cast<const unsigned *>(L + base) : 0u;
     if (__ballot(centre != 0) == 0) continue;   // no ROI voxel in these 256 columns (wave-uniform)
     int sum[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0}, dep[4] = {0, 0, 0, 0};
     unsigned crep[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) crep[k] = ((centre >> (8 * k)) & 0xffu) * 0x010101u;
+    for (int k = 0; k < 4; k++) crep[k] = __umul24((centre >> (8 * k)) & 0xffu, 0x010101u);
 #pragma unroll
     for (int r = 0; r < 9; r++) {
       const unsigned wm = R.m[r];
       if (!wm) continue;
       const int zz = z + r / 3 - 1, yy = y + r % 3 - 1;
       const bool in = live && (unsigned)zz < (unsigned)Nz && (unsigned)yy < (unsigned)Ny;   // row outside the volume: zeros
-      const uint8_t *rp = L + ((long long)zz * Ny + yy) * Nx + x0;
+      const unsigned off = in ? base + (unsigned)rowoff[r] : 0u;
+      const uint8_t *rp = L + off;
       const unsigned mid = in ? *reinterpret_cast<const unsigned *>(rp) : 0u;
-      unsigned left = __shfl_up(mid >> 24, 1), right = __shfl_down(mid & 0xffu, 1);
+      unsigned left = neigh_from_lower_lane(mid >> 24), right = neigh_from_upper_lane(mid & 0xffu);
       if (lane == 0) left = (in && x0 > 0) ? rp[-1] : 0u;
       if (lane == 63) right = (in && x0 + 4 < Nx) ? rp[4] : 0u;
       if (x0 == 0) left = 0u;
@@ -177,21 +191,25 @@ __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t 
       const int c = (int)((centre >> (8 * k)) & 0xffu);
       if (!c) continue;
       if (NGTDM) {
-        u64 *rowp = lds64 + (c - 1) * W;
-        atomicAdd(rowp, 1ull);
+        u32 *rowp = hn + __mul24(c - 1, W);
+        if (MODE == 1) atomicAdd(rowp, 1u);
         if (cnt[k]) {
-          int d = cnt[k] * c - sum[k];
+          int d = __mul24(cnt[k], c) - sum[k];
           d = d < 0 ? -d : d;
-          if (d) atomicAdd(rowp + cnt[k], (u64)d);
+          if (d) atomicAdd(rowp + cnt[k], (u32)d);
         }
       }
-      if (GLDM) atomicAdd(&h32[(c - 1) * W + dep[k]], 1u);
+      if (GLDM) atomicAdd(&h32[__mul24(c - 1, W) + dep[k]], 1u);
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
     if (NGTDM) {
-      const u64 v = lds64[i];
+      u64 v = hn[i];
+      if (MODE == 2 && i % W == 0) {      // slot 0 of level i / W: its voxels = the sum of its GLDM row
+        v = 0;
+        for (int d = 0; d < W; d++) v += h32[i + d];
+      }
       if (v) atomicAdd(ngtdm_acc + i, v);
     }
     if (GLDM) {
@@ -212,8 +230,10 @@ inline unsigned neigh_threads() {
 inline unsigned neigh_blocks(long long nquads, unsigned bt) {
   static const int fixed = getenv("PRAD_NEIGH_BLOCKS") ? atoi(getenv("PRAD_NEIGH_BLOCKS")) : 0;
   const long long need = (nquads + bt - 1) / bt;
-  if (fixed > 0) return (unsigned)std::max<long long>(1, std::min<long long>(need, fixed));
-  return (unsigned)std::max<long long>(1, std::min<long long>(need, std::max<long long>(256, std::min<long long>(8192, nquads / (8LL * bt)))));
+  // the kernel's u32 LDS sums hold 26 * 255 per voxel: never more than 2^19 voxels (2^17 quads) per workgroup
+  const long long floor32 = (nquads + (1LL << 17) - 1) >> 17;
+  if (fixed > 0) return (unsigned)std::max<long long>(1, std::min<long long>(need, std::max<long long>(fixed, floor32)));
+  return (unsigned)std::max<long long>(1, std::min<long long>(need, std::max<long long>(std::max<long long>(256, floor32), std::min<long long>(8192, nquads / (8LL * bt)))));
 }
 
 // the angle set as 9 row masks; false if an offset is outside {-1,0,1}^3 \ {0} or repeated
