@@ -399,3 +399,31 @@ def test_fw2_equals_the_lines_kernels_and_serves_deferred_calls(cm, monkeypatch)
     g0, r0, _ = engine.glcm_glrlm(img, mask, Ng, 512)
     assert engine.last_variant() == "lines"
     assert torch.equal(g0, g1) and torch.equal(r0, r1)
+
+
+@pytest.mark.parametrize("Ng", [64, 100])
+def test_fw2_runs_of_length_one_are_derived_exactly(cm, checker, Ng, monkeypatch):
+    """the two-table walk does not record runs of length 1 when the x angle is in the call: the finalize step restores
+    GLRLM_a[g][1] = N_g - sum_{len >= 2} len * GLRLM_a[g][len] from the x angle's runs (kernels_sweepfw2.h, SKIP1).  Cases that
+    lean on it: iid levels (31 of 32 runs have length 1), sparse masks whose voxels are isolated along some angles (the
+    reference's rule cmatrices.c:524-534 then clears that angle's length-1 column AFTER the restore), a call without the x
+    angle (force2D across x: every run is recorded), and the recording path forced by PRAD_FW2_NOSKIP1"""
+    from pyradiomics_amd import _lib
+    shape = (22, 26, 512)
+    img = _levels(123 + Ng, shape, Ng, "uniform")
+    rng = np.random.default_rng(5)
+    sparse = rng.random(shape) < 0.004           # nearly every ROI voxel isolated
+    three = np.zeros(shape, bool)
+    three[3, 4, 5] = three[3, 4, 6] = three[10, 20, 300] = True      # one pair along x, one lone voxel
+    for mask in (_mask(1, shape, "full"), _mask(8, shape, "random"), sparse, three):
+        _check2(cm, checker, img, mask, Ng)
+    Nr = int(max(shape))
+    for dim in (0, 1, 2):                        # in-plane angle lists; dim 2 drops every angle with an x component
+        g, r, ang = cm.calculate_glcm_glrlm(img, sparse | _mask(2, shape, "ball"), Ng, Nr, True, dim)
+        assert _lib.last_path() == "sweep"
+        eg, eang = checker.calculate_glcm(img, sparse | _mask(2, shape, "ball"), [1], Ng, True, dim)
+        er, _ = checker.calculate_glrlm(img, sparse | _mask(2, shape, "ball"), Ng, Nr, True, dim)
+        assert np.array_equal(ang, eang) and np.array_equal(g, eg) and np.array_equal(r, er), dim
+    monkeypatch.setenv("PRAD_FW2_NOSKIP1", "1")
+    _check2(cm, checker, img, _mask(8, shape, "random"), Ng)
+    _check2(cm, checker, _levels(7, shape, Ng, "smooth"), sparse, Ng)
