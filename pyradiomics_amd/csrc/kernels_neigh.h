@@ -101,6 +101,9 @@ struct RowMasks {
 __device__ __forceinline__ unsigned nonzero_bytes3(unsigned w) {  // bit 7 of every non-zero byte (exact, no carries)
   return (((w & 0x7f7f7fu) + 0x7f7f7fu) | w) & 0x808080u;
 }
+__device__ __forceinline__ unsigned nonzero_bytes4(unsigned w) {  // bit 0 of every non-zero byte of the whole word
+  return ((((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w) >> 7) & 0x01010101u;
+}
 
 __device__ __forceinline__ unsigned neigh_from_lower_lane(unsigned v) {  // lane i <- lane i-1, lane 0 <- 0 (one DPP move)
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
@@ -114,7 +117,10 @@ __device__ __forceinline__ unsigned neigh_from_upper_lane(unsigned v) {  // lane
 // (2^19 at most: neigh_blocks) and a voxel adds at most 26 * 255, so the per-workgroup sums stay below 2^32; the flush widens to the
 // u64 global accumulators.  With both tables (MODE 2) the voxel count of a level -- NGTDM slot 0 -- is the sum of its GLDM
 // row and is only formed in the flush: one LDS atomic per voxel less (the one with the fewest distinct addresses).
-template <int MODE>
+// FULL26: the angle set is the whole 3 x 3 x 3 neighbourhood (the default of the classes in 3-D): the row masks are known
+// at compile time -- no branch between the rows of an iteration (the scalar branches of the general form keep the
+// compiler from overlapping a row's loads with the arithmetic of the row before).
+template <int MODE, bool FULL26>
 __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t *__restrict__ L, int Nz, int Ny,
                                                      int Nx, int zlo, int zhi, int Ng, int Na,
                                                      u32 *__restrict__ gldm_acc, u64 *__restrict__ ngtdm_acc,
@@ -153,14 +159,12 @@ __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t 
     const unsigned base = q32 << 2;             // byte offset of the quad (rows are Nx = 4 qpr bytes)
     const unsigned centre = live ? *reinterpret_cast<const unsigned *>(L + base) : 0u;
     if (__ballot(centre != 0) == 0) continue;   // no ROI voxel in these 256 columns (wave-uniform)
-    int sum[4] = {0, 0, 0, 0}, cnt[4] = {0, 0, 0, 0}, dep[4] = {0, 0, 0, 0};
-    unsigned crep[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) crep[k] = __umul24((centre >> (8 * k)) & 0xffu, 0x010101u);
+    int sum[4] = {0, 0, 0, 0};
+    unsigned cnt4 = 0, neq4 = 0;   // per voxel of the quad, one byte each: valid neighbours / neighbours of another level
 #pragma unroll
     for (int r = 0; r < 9; r++) {
-      const unsigned wm = R.m[r];
-      if (!wm) continue;
+      const unsigned wm = FULL26 ? (r == 4 ? 0xff00ffu : 0xffffffu) : R.m[r];
+      if (!FULL26 && !wm) continue;
       const int zz = z + r / 3 - 1, yy = y + r % 3 - 1;
       const bool in = live && (unsigned)zz < (unsigned)Nz && (unsigned)yy < (unsigned)Ny;   // row outside the volume: zeros
       const unsigned off = in ? base + (unsigned)rowoff[r] : 0u;
@@ -173,17 +177,29 @@ __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t 
       if (x0 + 4 >= Nx) right = 0u;
       const unsigned lo = left | (mid << 8);          // bytes x0-1 .. x0+2
       const unsigned hi = (mid >> 24) | (right << 8); // bytes x0+3, x0+4
+      // Counts for the four voxels of the quad at once: the row's neighbours dx = -1, 0, +1 of voxel x0+k are byte k of the
+      // shifted words wL, wC (= mid), wR; "byte != 0" as bit 0 of every byte (nonzero_bytes4), summed in packed bytes
+      // (at most 26 per byte).  The three-byte window per voxel is only kept for the level sums (v_sad_u8).
+      const bool mL = FULL26 || (wm & 0xffu) != 0, mC = FULL26 ? r != 4 : (wm & 0xff00u) != 0,
+                 mR = FULL26 || (wm & 0xff0000u) != 0;   // (wave-uniform; constants with FULL26)
+      if (NGTDM) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const unsigned w = __builtin_amdgcn_alignbyte(hi, lo, k) & wm;   // neighbours x-1, x, x+1 of voxel x0+k
-        if (NGTDM) {
+        for (int k = 0; k < 4; k++) {
+          unsigned w = __builtin_amdgcn_alignbyte(hi, lo, k);   // neighbours x-1, x, x+1 of voxel x0+k (+ one byte beyond)
+          if (FULL26 && r != 4) w &= 0xffffffu;
+          else w &= wm;
           sum[k] = (int)__builtin_amdgcn_sad_u8(w, 0u, (unsigned)sum[k]);
-          cnt[k] += __popc(nonzero_bytes3(w));
         }
-        if (GLDM) {
-          // excluded positions are 0 in w, hence non-zero after the xor with a non-zero centre: never "equal"
-          dep[k] += 3 - __popc(nonzero_bytes3(w ^ crep[k]));
-        }
+        const unsigned nzm = nonzero_bytes4(mid);
+        if (mL) cnt4 += min(left, 1u) | (nzm << 8);
+        if (mC) cnt4 += nzm;
+        if (mR) cnt4 += (nzm >> 8) | (min(right, 1u) << 24);
+      }
+      if (GLDM) {
+        // (a neighbour outside the volume or the ROI is 0, hence never equal to a non-zero centre)
+        if (mL) neq4 += nonzero_bytes4(lo ^ centre);
+        if (mC) neq4 += nonzero_bytes4(mid ^ centre);
+        if (mR) neq4 += nonzero_bytes4(__builtin_amdgcn_alignbyte(hi, lo, 2) ^ centre);
       }
     }
 #pragma unroll
@@ -193,13 +209,14 @@ __global__ void __launch_bounds__(1024) neigh4_kernel(RowMasks R, const uint8_t 
       if (NGTDM) {
         u32 *rowp = hn + __mul24(c - 1, W);
         if (MODE == 1) atomicAdd(rowp, 1u);
-        if (cnt[k]) {
-          int d = __mul24(cnt[k], c) - sum[k];
+        const int cn = (int)((cnt4 >> (8 * k)) & 0xffu);
+        if (cn) {
+          int d = __mul24(cn, c) - sum[k];
           d = d < 0 ? -d : d;
-          if (d) atomicAdd(rowp + cnt[k], (u32)d);
+          if (d) atomicAdd(rowp + cn, (u32)d);
         }
       }
-      if (GLDM) atomicAdd(&h32[__mul24(c - 1, W) + dep[k]], 1u);
+      if (GLDM) atomicAdd(&h32[__mul24(c - 1, W) + Na - (int)((neq4 >> (8 * k)) & 0xffu)], 1u);
     }
   }
   __syncthreads();
@@ -247,6 +264,12 @@ inline bool row_masks_from(const NeighSet &A, RowMasks *R) {
     if (m & bit) return false;
     m |= bit;
   }
+  return true;
+}
+
+inline bool row_masks_full26(const RowMasks &R) {
+  for (int r = 0; r < 9; r++)
+    if (R.m[r] != (r == 4 ? 0xff00ffu : 0xffffffu)) return false;
   return true;
 }
 
@@ -349,8 +372,12 @@ inline int neigh_accumulate(Context *c, hipStream_t s, const Geo &g, const VoxMo
       // (grid: neigh_blocks above)
       const unsigned bt = neigh_threads();
       const unsigned gx = neigh_blocks(ncent >> 2, bt);
-      hipLaunchKernelGGL((neigh4_kernel<NGTDM>), dim3(gx), dim3(bt), lds, s, R, levels, p.Nz, p.Ny, p.Nx, zlo, zhi,
-                         Ng, Na, acc32, acc64, flags_d);
+      if (row_masks_full26(R))
+        hipLaunchKernelGGL((neigh4_kernel<NGTDM, true>), dim3(gx), dim3(bt), lds, s, R, levels, p.Nz, p.Ny, p.Nx, zlo, zhi,
+                           Ng, Na, acc32, acc64, flags_d);
+      else
+        hipLaunchKernelGGL((neigh4_kernel<NGTDM, false>), dim3(gx), dim3(bt), lds, s, R, levels, p.Nz, p.Ny, p.Nx, zlo, zhi,
+                           Ng, Na, acc32, acc64, flags_d);
       PRAD_TRY(check_launch("neigh4_kernel"));
     } else {
       const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((ncent + 255) / 256, 4096));
@@ -399,8 +426,12 @@ inline int neigh_try_both(Context *c, hipStream_t s, const Geo &g, const VoxMode
     const long long ncent = (long long)p.Nz * p.Ny * p.Nx;
     const unsigned bt = neigh_threads();
     const unsigned gx = neigh_blocks(ncent >> 2, bt);
-    hipLaunchKernelGGL((neigh4_kernel<2>), dim3(gx), dim3(bt), (sizeof(u64) + sizeof(u32)) * nacc, s, R, levels, p.Nz, p.Ny,
-                       p.Nx, 0, p.Nz, Ng, Na, acc32, acc64, flags_d);
+    if (row_masks_full26(R))
+      hipLaunchKernelGGL((neigh4_kernel<2, true>), dim3(gx), dim3(bt), (sizeof(u64) + sizeof(u32)) * nacc, s, R, levels, p.Nz, p.Ny,
+                         p.Nx, 0, p.Nz, Ng, Na, acc32, acc64, flags_d);
+    else
+      hipLaunchKernelGGL((neigh4_kernel<2, false>), dim3(gx), dim3(bt), (sizeof(u64) + sizeof(u32)) * nacc, s, R, levels, p.Nz, p.Ny,
+                         p.Nx, 0, p.Nz, Ng, Na, acc32, acc64, flags_d);
     PRAD_TRY(check_launch("neigh4_kernel"));
   }
   PRAD_TRY(neigh_finalize_gldm(c, s, acc32, Ng, Na, gldm_out));
