@@ -345,7 +345,7 @@ int prad_voxel_texture_features_dev(int family, const int32_t *image, const uint
  *   plain sums (ids = VOXEL_GLCM_FEATURES order; MCC excluded).  out: HOST float64 [Na][23]; empty: HOST int [Na],
  *   1 where the angle holds no pair (its row of `out` is NaN; glcm.py:186-198 drops such angles).
  * prad_zone_matrix_features_dev: P(i, j, a) = P[i*stride_i + j*stride_j + a*stride_a] DEVICE float64 counts with level
- *   value i + 1 and size value jvals[j] (HOST float64 [Nj]: run lengths / zone sizes / dependence counts + 1);
+ *   value i + 1 and size value jvals[j] (HOST float64 [Nj]: run lengths / zone sizes / dependence counts + 1; NULL: j + 1);
  *   out: HOST float64 [Na][16] in the shared numbering of prad_voxel_texture_features_dev; empty as above. */
 int prad_glcm_features_dev(const double *glcm, int Ng, int Na, int symmetric, double *out, int *empty, void *stream);
 int prad_zone_matrix_features_dev(const double *P, int Ni, int Nj, int Na, long long stride_i, long long stride_j,

@@ -247,7 +247,7 @@ enum { ZM_SmallEmphasis = 0, ZM_LargeEmphasis, ZM_GrayLevelNonUniformity, ZM_Gra
        ZM_SmallHighGrayLevelEmphasis, ZM_LargeLowGrayLevelEmphasis, ZM_LargeHighGrayLevelEmphasis, ZM_COUNT };
 
 static_assert(ZM_COUNT == 16, "prad_api.hip (ZM_FEATURES) and include/pyradiomics_amd.h say 16 zone-matrix features");
-// P(i, j, a) = counts[i * si + j * sj + a * sa]; level value = i + 1; size value = jvals[j].
+// P(i, j, a) = counts[i * si + j * sj + a * sa]; level value = i + 1; size value = jvals[j] (jvals == NULL: j + 1).
 // scratch: [Na][Ni + Nj] float64 (marginals).  out: [Na][ZM_COUNT]; empty[a] = 1 when the matrix of angle a is all zero.
 __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel(
     const double *__restrict__ counts, int Ni, int Nj, int Na, long long si, long long sj, long long sa,
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel
   }
   double j1 = 0, j2 = 0, inv_j2 = 0, mj = 0;
   for (int j = t; j < Nj; j += PRAD_FEAT_THREADS) {
-    const double s = pj[j], jv = jvals[j];
+    const double s = pj[j], jv = jvals ? jvals[j] : (double)(j + 1);
     j1 += s * jv;
     j2 += s * (jv * jv);
     inv_j2 += s / (jv * jv);
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel
     const int i = (int)(e / Nj), j = (int)(e - (long long)i * Nj);
     const double v = P(i, j);
     if (v == 0) continue;
-    const double iv = i + 1, jv = jvals[j], i2v = iv * iv, j2v = jv * jv, ri2 = 1.0 / i2v, rj2 = 1.0 / j2v, p = v * rn;
+    const double iv = i + 1, jv = jvals ? jvals[j] : (double)(j + 1), i2v = iv * iv, j2v = jv * jv, ri2 = 1.0 / i2v, rj2 = 1.0 / j2v, p = v * rn;
     ent += p * log2(p + eps);
     c1 += v * (ri2 * rj2);
     c2 += v * (i2v * rj2);
@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(PRAD_FEAT_THREADS) zone_matrix_features_kernel
     vi += (pg[i] / n) * (d * d);
   }
   for (int j = t; j < Nj; j += PRAD_FEAT_THREADS) {
-    const double d = jvals[j] - uj;
+    const double d = (jvals ? jvals[j] : (double)(j + 1)) - uj;
     vj += (pj[j] / n) * (d * d);
   }
   {

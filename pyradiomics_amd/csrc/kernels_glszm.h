@@ -1734,8 +1734,7 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
     PRAD_TRY(c.get<unsigned>("glszm_small_bits", PRAD_SMALL_SIZES / 32, &st.small_bits));
     PRAD_TRY(c.get<int>("glszm_large_list", (size_t)st.large_cap, &st.large_list));
     PRAD_TRY(c.get<int>("glszm_large_count", 1, &st.large_count));
-    PRAD_HIP(hipMemsetAsync(st.small_bits, 0, PRAD_SMALL_SIZES / 8, s));
-    PRAD_HIP(hipMemsetAsync(st.large_count, 0, sizeof(int), s));
+    PRAD_TRY(ZeroBatch().add(st.small_bits, PRAD_SMALL_SIZES / 8).add(st.large_count, sizeof(int)).launch(s));
     Timed t(c, "glszm", s);
     // tiled path for <= 3-D volumes whose neighbour offsets are unit steps; generic union-find otherwise
     Offsets3 A3;
@@ -1792,12 +1791,11 @@ inline int glszm_zones(Context &c, hipStream_t s, const Geo &g, const int32_t *i
           // large zones: 256^3 smooth 273 us with 2048 workgroups, 121 with 384; 512^3 790 / 612 with 768)
           static const int pgrid_env = getenv("PRAD_GLSZM_PGRID") ? atoi(getenv("PRAD_GLSZM_PGRID")) : 0;
           const int pgrid = pgrid_env > 0 ? pgrid_env : (int)std::min(2048.0, std::max(64.0, 1.5 * std::cbrt((double)g.n)));
-          PRAD_HIP(hipMemsetAsync(flags_d, 0, sizeof(int) * 4, s));
           PRAD_TRY(c.get<int>("glszm_parent", (size_t)g.n, &st.parent));
           PRAD_TRY(c.get<unsigned>("glszm_tinfo", (size_t)g.n, &st.tinfo));
           PRAD_TRY(c.get<int>("glszm_rootctl", 4, &st.rootctl));
           PRAD_TRY(c.get<int2>("glszm_worklist", (size_t)workcap, &work));
-          PRAD_HIP(hipMemsetAsync(st.rootctl, 0, sizeof(int) * 4, s));
+          PRAD_TRY(ZeroBatch().add(flags_d, sizeof(int) * 4).add(st.rootctl, sizeof(int) * 4).launch(s));
           PRAD_TRY(neigh_pack(&c, s, g, image, mask, Ng, flags_d, &levels));
 #define PRAD_GLSZM_LAUNCH(M)                                                                                                 \
           do {                                                                                                               \
@@ -2006,8 +2004,7 @@ inline int glszm_fill_compact(Context &c, hipStream_t s, double *out_dev, int Ng
   int *err = nullptr, *large_d = nullptr;
   PRAD_TRY(c.get<int>("glszm_err", 4, &err));
   PRAD_TRY(c.get<int>("glszm_large_sorted", (size_t)st.nlarge + 1, &large_d));
-  PRAD_HIP(hipMemsetAsync(err, 0, sizeof(int) * 4, s));
-  PRAD_HIP(hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)Ng * std::max(k, 1), s));
+  PRAD_TRY(ZeroBatch().add(err, sizeof(int) * 4).add(out_dev, sizeof(double) * (size_t)Ng * std::max(k, 1)).launch(s));
   if (k) {
     const int RL = Ng <= 8192 ? std::max(1, std::min(k, 8192 / Ng)) : 0;
     hipLaunchKernelGGL(glszm_fill_compact_kernel, dim3(std::min(glszm_grid(st.g.n), st.parent ? glszm_fill_blocks() : 2048u)), dim3(256),

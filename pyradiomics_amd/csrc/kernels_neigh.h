@@ -419,8 +419,7 @@ inline int neigh_try_both(Context *c, hipStream_t s, const Geo &g, const VoxMode
   u64 *acc64 = nullptr;
   PRAD_TRY(c->get<u64>("ngtdm_acc", nacc, &acc64));
   PRAD_TRY(c->get<u32>("gldm_acc", nacc, &acc32));
-  PRAD_HIP(hipMemsetAsync(acc64, 0, sizeof(u64) * nacc, s));
-  PRAD_HIP(hipMemsetAsync(acc32, 0, sizeof(u32) * nacc, s));
+  PRAD_TRY(ZeroBatch().add(acc64, sizeof(u64) * nacc).add(acc32, sizeof(u32) * nacc).launch(s));
   {
     Timed t(*c, "neigh", s);
     const long long ncent = (long long)p.Nz * p.Ny * p.Nx;

@@ -2089,8 +2089,7 @@ int prad_glszm_features_dev(const int32_t *image, const uint8_t *mask, const int
   PRAD_TRY(c.get<double>("glszm_compact", (size_t)Ng * kcap, &P));
   PRAD_TRY(c.get<double>("glszm_feat_out", ZM_FEATURES + 4, &d_out));
   int *d_empty = reinterpret_cast<int *>(d_out + ZM_FEATURES + 2);
-  PRAD_HIP(hipMemsetAsync(err, 0, sizeof(int) * 4, s));
-  PRAD_HIP(hipMemsetAsync(P, 0, sizeof(double) * (size_t)Ng * kcap, s));
+  PRAD_TRY(ZeroBatch().add(err, sizeof(int) * 4).add(P, sizeof(double) * (size_t)Ng * kcap).launch(s));
   {
     Timed t(c, "glszm", s);
     hipLaunchKernelGGL(glszm_rank_kernel, dim3(1), dim3(1024), 0, s, (const unsigned *)st.small_bits, (const int *)st.large_list,
@@ -2571,10 +2570,8 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
       }
     }
     if (classes & PRAD_IMG_GLRLM) {
-      std::vector<double> jv((size_t)Nr);
-      for (int j = 0; j < Nr; j++) jv[j] = (double)(j + 1);
-      PRAD_TRY(prad_zone_matrix_features_dev(rm, Ng, Nr, Na, (long long)Nr * Na, (long long)Na, 1LL, jv.data(), at(3),
-                                             (int *)at(4), q.s[0]));
+      PRAD_TRY(prad_zone_matrix_features_dev(rm, Ng, Nr, Na, (long long)Nr * Na, (long long)Na, 1LL, nullptr, at(3),
+                                             (int *)at(4), q.s[0]));     // (size values 1 .. Nr: no table)
     }
     used |= 1u;
   }
@@ -2587,9 +2584,7 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
     c.workspace = 4;
     c.deferred = true;
     if (classes & PRAD_IMG_GLDM) {
-      std::vector<double> jv((size_t)W);
-      for (int j = 0; j < W; j++) jv[j] = (double)(j + 1);
-      PRAD_TRY(prad_zone_matrix_features_dev(dm, Ng, W, 1, (long long)W, 1LL, 0LL, jv.data(), at(5), (int *)at(6), q.s[0]));
+      PRAD_TRY(prad_zone_matrix_features_dev(dm, Ng, W, 1, (long long)W, 1LL, 0LL, nullptr, at(5), (int *)at(6), q.s[0]));
     }
     if (classes & PRAD_IMG_NGTDM) PRAD_TRY(prad_ngtdm_features_dev(nm, Ng, at(7), q.s[0]));
     used |= 1u;

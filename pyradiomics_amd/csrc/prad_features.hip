@@ -64,7 +64,7 @@ extern "C" int prad_zone_matrix_features_dev(const double *P, int Ni, int Nj, in
                                              int *empty, void *stream) {
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
-  if (!P || !jvals || !out || !empty || Ni < 1 || Nj < 1 || Na < 1) return fail(PRAD_E_ARG, "zone_features: bad arguments");
+  if (!P || !out || !empty || Ni < 1 || Nj < 1 || Na < 1) return fail(PRAD_E_ARG, "zone_features: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   const size_t nout = (size_t)Na * ZM_COUNT;
   double *d_out = nullptr, *d_j = nullptr, *d_scr = nullptr;
@@ -74,11 +74,18 @@ extern "C" int prad_zone_matrix_features_dev(const double *P, int Ni, int Nj, in
   PRAD_TRY(c.get<double>("zf_scratch", (size_t)Na * ((size_t)Ni + Nj), &d_scr));
   const bool enq = c.deferred && c.in_arena(out, sizeof(double) * nout) && c.in_arena(empty, sizeof(int) * Na);
   void *pin = nullptr;        // [jvals in | values + flags out], pinned (see prad_glcm_features_dev)
-  if (enq) PRAD_TRY(c.arena_alloc(sizeof(double) * (size_t)Nj, &pin));   // (a staging slot nobody rewrites before the copy ran)
-  else PRAD_TRY(c.get_pinned("zfeat_pin", sizeof(double) * ((size_t)Nj + nout + (size_t)Na + 2), &pin));
-  double *pj = (double *)pin, *pout = pj + Nj;
-  memcpy(pj, jvals, sizeof(double) * Nj);
-  PRAD_HIP(hipMemcpyAsync(d_j, pj, sizeof(double) * Nj, hipMemcpyHostToDevice, s));
+  if (enq) {
+    if (jvals) PRAD_TRY(c.arena_alloc(sizeof(double) * (size_t)Nj, &pin));   // (a staging slot nobody rewrites before the copy ran)
+  } else {
+    PRAD_TRY(c.get_pinned("zfeat_pin", sizeof(double) * ((size_t)Nj + nout + (size_t)Na + 2), &pin));
+  }
+  double *pj = (double *)pin, *pout = pin ? pj + Nj : nullptr;
+  if (jvals) {      // (NULL: the size values are 1 .. Nj -- run lengths, dependence counts + 1 -- and no table travels)
+    memcpy(pj, jvals, sizeof(double) * Nj);
+    PRAD_HIP(hipMemcpyAsync(d_j, pj, sizeof(double) * Nj, hipMemcpyHostToDevice, s));
+  } else {
+    d_j = nullptr;
+  }
   {
     Timed t(c, "features", s);
     const bool direct = enq && Context::zero_copy();

@@ -324,6 +324,44 @@ inline int check_launch(const char *what) {
     if (rc_ != PRAD_OK) return rc_; \
   } while (0)
 
+// Several small zero fills as ONE launch: every hipMemsetAsync is a launch of its own (a runtime call on the host, a fill
+// kernel and a dependent-launch gap on the stream); a 256^3 case queued 129 of them (profiles/r04_probes.md section 18).
+// Ranges are 4-byte aligned and whole words.
+struct ZeroRanges {
+  unsigned *p[6];
+  unsigned long long words[6];
+  int count;
+};
+static __global__ void __launch_bounds__(256) zero_ranges_kernel(ZeroRanges z) {
+  unsigned *p = z.p[blockIdx.y];
+  const unsigned long long n = z.words[blockIdx.y];
+  for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (unsigned long long)gridDim.x * blockDim.x)
+    p[i] = 0u;
+}
+struct ZeroBatch {
+  ZeroRanges z;
+  ZeroBatch() { z.count = 0; }
+  // bytes: a multiple of 4 (every caller zeroes int / unsigned / double / 64-bit arrays)
+  ZeroBatch &add(void *ptr, size_t bytes) {
+    if (bytes >= 4 && z.count < 6) {
+      z.p[z.count] = (unsigned *)ptr;
+      z.words[z.count] = bytes / 4;
+      z.count++;
+    }
+    return *this;
+  }
+  int launch(hipStream_t s) {
+    if (z.count == 0) return PRAD_OK;
+    unsigned long long most = 0;
+    for (int i = 0; i < z.count; i++) most = z.words[i] > most ? z.words[i] : most;
+    const unsigned long long need = (most + 255) / 256;
+    const unsigned gx = (unsigned)(need > 1024 ? 1024 : (need ? need : 1));
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(gx, (unsigned)z.count), dim3(256), 0, s, z);
+    return check_launch("zero_ranges_kernel");
+  }
+};
+
 // ---------------------------------------------------------------------------------------------
 // geometry shared by host and device code
 // ---------------------------------------------------------------------------------------------
