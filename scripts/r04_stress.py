@@ -1,0 +1,119 @@
+"""round 4: seeded random stress of the kernels this round touched, against the reference C (oracle/_ref) or our C port:
+the two-table walk with derived length-1 runs (45..160 levels, rows of 66..512 voxels, sparse / dense masks, force2D), the
+fused walk with its pack fast path (junk outside the mask, ragged rows), the GLDM / NGTDM kernel (packed counts, every
+neighbourhood force2D can ask for).  usage: python scripts/r04_stress.py [seconds] [seed]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import binding
+from pyradiomics_amd import cmatrices as cm, _lib
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+ck = binding.ref() if binding.have_ref() else binding.port()
+rng = np.random.default_rng(seed)
+t0 = time.time()
+n = {"fw2": 0, "fw": 0, "neigh": 0}
+
+
+def levels(shape, Ng, kind):
+    if kind == "uniform":
+        return rng.integers(1, Ng + 1, size=shape, dtype=np.int32)
+    f = rng.random(shape)
+    for ax in range(3):
+        f = f + np.roll(f, 1, ax) + np.roll(f, -1, ax) + (np.roll(f, 2, ax) if kind == "smooth2" else 0)
+    if kind == "plateau":
+        f = np.round(f * 2)
+    f = (f - f.min()) / (np.ptp(f) + 1e-12)
+    return np.minimum(Ng, 1 + np.floor(f * Ng)).astype(np.int32)
+
+
+def mask_of(shape, kind):
+    if kind == "full":
+        return np.ones(shape, bool)
+    if kind == "sparse":
+        return rng.random(shape) < rng.choice([0.002, 0.02, 0.1])
+    if kind == "ball":
+        zz, yy, xx = np.meshgrid(*[np.linspace(-1, 1, s) for s in shape], indexing="ij")
+        return (zz ** 2 + yy ** 2 + xx ** 2) < 0.8
+    return rng.random(shape) < rng.choice([0.5, 0.7, 0.95])
+
+
+it = 0
+while time.time() - t0 < budget:
+    it += 1
+    which = ["fw2", "fw", "neigh"][it % 3]
+    if which in ("fw2", "fw"):
+        Ng = int(rng.choice([45, 50, 64, 77, 100, 128, 160])) if which == "fw2" else int(rng.choice([8, 16, 32, 33, 44]))
+        nx = int(rng.choice([66, 100, 128, 130, 200, 255, 256, 257, 300, 500, 511, 512]))
+        shape = (int(rng.integers(1, 40)), int(rng.integers(2, 40)), nx)
+        img = levels(shape, Ng, rng.choice(["uniform", "smooth", "smooth2", "plateau"]))
+        mask = mask_of(shape, rng.choice(["full", "random", "sparse", "ball"]))
+        if not mask.any():
+            mask[0, 0, 0] = True
+        if rng.random() < 0.3:                      # junk outside the mask (ignored by the reference: it tests the mask first)
+            img = img.copy()
+            img[~mask] = rng.choice(np.array([0, -3, 255, 256, 1 << 20, Ng + 1], dtype=np.int32), size=int((~mask).sum()))
+        f2 = bool(rng.random() < 0.3)
+        dim = int(rng.integers(0, 3)) if f2 else 0
+        Nr = max(shape)
+        tag = "%s shape %s Ng %d force2D %s/%d" % (which, shape, Ng, f2, dim)
+        try:
+            eg, eang = ck.calculate_glcm(img, mask, [1], Ng, f2, dim)
+        except (RuntimeError, IndexError):
+            continue
+        er, _ = ck.calculate_glrlm(img, mask, Ng, Nr, f2, dim)
+        g, r, ang = cm.calculate_glcm_glrlm(img, mask, Ng, Nr, f2, dim)
+        assert np.array_equal(ang, eang) and np.array_equal(g, eg), "GLCM " + tag
+        assert np.array_equal(r, er), "GLRLM " + tag + " variant " + _lib.last_variant()
+        n[which] += 1
+    else:
+        Ng = int(rng.choice([2, 16, 32, 64, 127, 128, 200, 255]))
+        shape = (int(rng.integers(1, 30)), int(rng.integers(1, 40)), int(rng.choice([4, 8, 12, 36, 64, 100, 128, 232, 256])))
+        img = levels(shape, Ng, rng.choice(["uniform", "smooth", "plateau"]))
+        mask = mask_of(shape, rng.choice(["full", "random", "sparse", "ball"]))
+        if not mask.any():
+            mask[0, 0, 0] = True
+        f2 = bool(rng.random() < 0.3)
+        dim = int(rng.integers(0, 3)) if f2 else 0
+        tag = "neigh shape %s Ng %d force2D %s/%d" % (shape, Ng, f2, dim)
+        try:
+            ed = ck.calculate_gldm(img, mask, [1], Ng, 0, f2, dim)
+        except (RuntimeError, IndexError):
+            continue
+        en = ck.calculate_ngtdm(img, mask, [1], Ng, f2, dim)
+        assert np.array_equal(cm.calculate_gldm(img, mask, [1], Ng, 0, f2, dim), ed), "GLDM " + tag
+        got = cm.calculate_ngtdm(img, mask, [1], Ng, f2, dim)
+        assert np.array_equal(got[..., 0], en[..., 0]) and np.allclose(got[..., 1:], en[..., 1:], rtol=1e-12, atol=0), "NGTDM " + tag
+        n["neigh"] += 1
+# the pack that rides in the previous volume's walk (deferred pipeline): consecutive volumes of one shape, masks and junk mixed
+import torch
+from pyradiomics_amd import engine
+engine.set_deferred_mode(1)
+n["pipeline"] = 0
+t1 = time.time()
+while time.time() - t1 < budget / 3:
+    Ng = int(rng.choice([8, 32, 44]))
+    shape = (int(rng.integers(2, 24)), int(rng.integers(2, 30)), int(rng.choice([80, 128, 256, 400, 512])))
+    vols = []
+    for k in range(5):
+        img = levels(shape, Ng, rng.choice(["uniform", "smooth", "plateau"]))
+        mask = mask_of(shape, rng.choice(["full", "full", "random", "sparse", "ball"]))
+        if not mask.any():
+            mask[0, 0, 0] = True
+        if rng.random() < 0.4:
+            img = img.copy()
+            img[~mask] = rng.choice(np.array([0, -3, 255, 256, 1 << 20, Ng + 1], dtype=np.int32), size=int((~mask).sum()))
+        vols.append((img, mask))
+    dev = [(torch.from_numpy(i).cuda(), torch.from_numpy(m.astype(np.uint8)).cuda()) for i, m in vols]
+    Nr = max(shape)
+    got = [engine.glcm_glrlm(i, m, Ng, Nr, deferred=True) for i, m in dev]
+    engine.deferred_status()
+    for (img, mask), (g, r, _) in zip(vols, got):
+        eg, _a = ck.calculate_glcm(img, mask, [1], Ng, False, 0)
+        er, _a = ck.calculate_glrlm(img, mask, Ng, Nr, False, 0)
+        assert np.array_equal(g.cpu().numpy(), eg[0] if eg.ndim == 4 else eg), "pipeline GLCM shape %s Ng %d" % (shape, Ng)
+        assert np.array_equal(r.cpu().numpy(), er[0] if er.ndim == 4 else er), "pipeline GLRLM shape %s Ng %d" % (shape, Ng)
+        n["pipeline"] += 1
+engine.set_deferred_mode(-1)
+print("stress ok: %s cases in %.0f s (seed %d)" % (n, time.time() - t0, seed))
