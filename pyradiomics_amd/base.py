@@ -3,6 +3,8 @@ pyradiomics_amd.image.Image inputs.  Same constructor signature, same settings k
 `get<Name>FeatureValue` reflection (base.py:163-179), same segment / voxel-based execution (base.py:181-273)."""
 from __future__ import annotations
 
+import sys as _sys
+
 import inspect
 import os
 import logging
@@ -12,6 +14,15 @@ import numpy as np
 
 from . import backend, imageoperations
 from .image import Image, as_array, as_image
+
+
+def _engine():
+    """the device engine (imports torch), loaded on first use: a function-level `from . import engine` goes through
+    importlib's locked lookup on every call (11 us each, 54 of them per 256^3 case); sys.modules is a dict lookup"""
+    m = _sys.modules.get("pyradiomics_amd.engine")
+    if m is None:
+        from . import engine as m
+    return m
 
 
 _ENQUEUE_DEFAULT = os.environ.get("PRAD_ENQUEUE_SEGMENT", "1") != "0"     # (A/B switch of the case pipeline, see enqueue())
@@ -86,7 +97,7 @@ class RadiomicsFeaturesBase:
         """binImage + grey-level bookkeeping in HBM (prad_roi_minmax_dev, then levels and the level census in one pass:
         prad_digitize_counts_dev).
         All feature classes of one derived image share the result: the reference re-bins per class (base.py:119-125)."""
-        from . import engine
+        engine = _engine()
         key = ("levels", self.settings.get("binWidth", 25), self.settings.get("binCount"), id(self.maskArray))
         memo = self.inputImage._derived
         if key not in memo:
@@ -160,7 +171,8 @@ class RadiomicsFeaturesBase:
 
     def _calculateSegment(self):
         for _ok, name, value in self._calculateFeatures():
-            self.featureValues[name] = np.squeeze(value)
+            # (numpy.squeeze of the reference, base.py:209; a 0-d array -- what the device formulas hand over -- is its own squeeze)
+            self.featureValues[name] = value if type(value) is np.ndarray and value.ndim == 0 else np.squeeze(value)
 
     def _calculateVoxels(self):
         initValue = self.settings.get("initValue", 0)

@@ -15,6 +15,8 @@ lower-level device-resident entry points live in pyradiomics_amd.engine.
 """
 from __future__ import annotations
 
+import sys as _sys
+
 import ctypes as C
 
 import os
@@ -24,6 +26,15 @@ import numpy as np
 from . import _lib
 
 _ip = C.POINTER(C.c_int)
+
+def _engine():
+    """the device engine (imports torch), loaded on first use: a function-level `from . import engine` goes through
+    importlib's locked lookup on every call (11 us each, 54 of them per 256^3 case); sys.modules is a dict lookup"""
+    m = _sys.modules.get("pyradiomics_amd.engine")
+    if m is None:
+        from . import engine as m
+    return m
+
 
 DEVICE_TENSORS = True     # calculate_* accept device tensors in segment mode (checked by pyradiomics_amd.base)
 
@@ -58,7 +69,7 @@ def _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, want, deferred=F
     """distance-1 GLCM / GLRLM of device tensors through the fused sweep.  deferred=True: the kernels are only enqueued
     on the current stream (engine.glcm_glrlm(deferred=True) + deferred_join); engine.deferred_status() tells afterwards
     whether the levels were inside [1, Ng]"""
-    from . import engine
+    engine = _engine()
     f2d = int(force2Ddimension) if force2D else -1
     Nr = int(max(image.shape))
     memo = _memo(image, mask)
@@ -81,7 +92,7 @@ def _dev_gldm_ngtdm(image, mask, Ng, alpha, dist, force2D, force2Ddimension, def
     """(GLDM, NGTDM) device matrices of a segment.  On tensors pyradiomics_amd.base tagged (all feature classes of one
     derived image share them) both come from ONE pass over the neighbourhoods (engine.gldm_ngtdm) and are kept for the
     other class; alpha = None: the caller only wants NGTDM (the fused pass runs with the default alpha 0)"""
-    from . import engine
+    engine = _engine()
     f2d = int(force2Ddimension) if force2D else -1
     memo = _memo(image, mask)
     a = 0 if alpha is None else int(alpha)
@@ -179,7 +190,7 @@ def _common(image, mask, distances, bidirectional, force2D, force2Ddimension, ke
 def calculate_glcm(image, mask, distances, Ng, force2D, force2Ddimension, kernelRadius=0, voxels=None):
     """-> (P float64 [Nvox, Ng, Ng, Na], angles int32 [Na, Nd]);  _cmatrices.c:84-233"""
     if _on_device(image) and voxels is None:
-        from . import engine
+        engine = _engine()
         dist = [int(d) for d in np.asarray(distances).ravel()]
         if dist == [1]:
             res = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glcm")
@@ -202,7 +213,7 @@ def calculate_glrlm(image, mask, Ng, Nr, force2D, force2Ddimension, kernelRadius
         if int(Nr) == int(max(image.shape)):
             res = _dev_pairs_runs(image, mask, Ng, force2D, force2Ddimension, "glrlm")
             return res["glrlm"], res["angles"]
-        from . import engine
+        engine = _engine()
         _, r, angles = engine.glcm_glrlm(image, mask, int(Ng), int(Nr), force2D, force2Ddimension, want_glcm=False)
         return r.cpu().numpy()[None], angles
     img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, None, False, force2D, force2Ddimension,
@@ -233,7 +244,7 @@ def calculate_glcm_glrlm(image, mask, Ng, Nr, force2D, force2Ddimension, kernelR
 def calculate_gldm(image, mask, distances, Ng, alpha, force2D, force2Ddimension, kernelRadius=0, voxels=None):
     """-> P float64 [Nvox, Ng, 2*Na+1] (Na = bidirectional angle count);  _cmatrices.c:731-880"""
     if _on_device(image) and voxels is None:
-        from . import engine
+        engine = _engine()
         return engine.gldm(image, mask, int(Ng), int(alpha), [int(d) for d in np.asarray(distances).ravel()], force2D,
                            force2Ddimension).cpu().numpy()[None]
     img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, distances, True, force2D, force2Ddimension,
@@ -249,7 +260,7 @@ def calculate_gldm(image, mask, distances, Ng, alpha, force2D, force2Ddimension,
 def calculate_ngtdm(image, mask, distances, Ng, force2D, force2Ddimension, kernelRadius=0, voxels=None):
     """-> P float64 [Nvox, Ng, 3];  _cmatrices.c:583-729"""
     if _on_device(image) and voxels is None:
-        from . import engine
+        engine = _engine()
         return engine.ngtdm(image, mask, int(Ng), [int(d) for d in np.asarray(distances).ravel()], force2D,
                             force2Ddimension).cpu().numpy()[None]
     img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, distances, True, force2D, force2Ddimension,
@@ -266,7 +277,7 @@ def calculate_glszm(image, mask, Ng, Ns, force2D, force2Ddimension, kernelRadius
     """-> P float64 [Nvox, Ng, maxRegion], last axis cropped to the largest zone found (>= 1);
     _cmatrices.c:235-430.  The input mask is not modified (the reference works on a private copy)."""
     if _on_device(image) and voxels is None:
-        from . import engine
+        engine = _engine()
         return engine.glszm(image, mask, int(Ng), int(Ns), force2D, force2Ddimension).cpu().numpy()[None]
     img, msk, size, vox, Nvox, f2d, angles = _common(image, mask, None, True, force2D, force2Ddimension,
                                                      kernelRadius, voxels)
@@ -293,7 +304,7 @@ def calculate_glszm_compact(image, mask, Ng, Ns, force2D, force2Ddimension):
     the matrix glszm.py:118-131 ends up with).  -> (P float64 [1, Ng, k], sizes int32 [k] ascending).
     Host arrays are uploaded; device tensors are used in place."""
     import torch
-    from . import engine
+    engine = _engine()
     if not _on_device(image):
         img, msk, _ = _parse_arrays(image, mask)
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -334,7 +345,7 @@ def voxel_texture_features(cls, image, mask, distances, Ng, force2D, force2Ddime
     centred on `voxels` (int [Nd, Nvox]).  Raises NotImplementedError when the fused kernels do not cover the request
     (unknown / deprecated feature, Ng > 255, more than 32 angles, kernels above 512 voxels): the caller then builds
     the matrices with calculate_* and uses the numpy formulas."""
-    from . import engine
+    engine = _engine()
     family, table = _ZONE_LIKE[cls]
     missing = [f for f in features if f not in table]
     if missing:
@@ -378,7 +389,7 @@ def segment_image_enqueue(levels, mask, Ng, Ns, requests, force2D=False, force2D
     "symmetrical" (glcm), "alpha" (gldm), "raw" + "shift" (firstorder).  Returns (token, {class key: finish}); finish() as
     returned by the per-class functions, to be called after segment_image_wait(token).  Classes whose request the fused
     kernels do not cover are left out of the returned dict (the caller queues them one by one)."""
-    from . import engine
+    engine = _engine()
     bits = {"glcm": engine.IMG_GLCM, "glrlm": engine.IMG_GLRLM, "gldm": engine.IMG_GLDM, "ngtdm": engine.IMG_NGTDM,
             "glszm": engine.IMG_GLSZM, "firstorder": engine.IMG_FIRSTORDER}
     classes, take = 0, {}
@@ -452,7 +463,7 @@ def segment_image_enqueue(levels, mask, Ng, Ns, requests, force2D=False, force2D
 
 
 def segment_image_wait(token):
-    from . import engine
+    engine = _engine()
     return engine.image_wait(token)
 
 
@@ -462,7 +473,8 @@ SEGMENT_QUEUES = {"glcm": 0, "glrlm": 0, "gldm": 0, "ngtdm": 0, "glszm": 1, "fir
 def segment_sync():
     """waits for everything segment_features_enqueue queued (inside segment_queue()); False when a queued call met a level
     outside [1, Ng] under the mask (the values are void: compute synchronously, which raises what the reference raises)"""
-    from . import engine, _lib
+    engine = _engine()
+    from . import _lib
     ok = True
     for k in sorted(set(SEGMENT_QUEUES.values())):
         try:
@@ -476,7 +488,7 @@ def segment_sync():
 def segment_mark(classes=None):
     """token behind everything queued inside segment_queue() so far (engine.deferred_mark on every side stream the
     classes use)"""
-    from . import engine
+    engine = _engine()
     used = sorted(set(SEGMENT_QUEUES.get(c, 0) for c in (classes or SEGMENT_QUEUES)))
     marks = []
     for k in used:
@@ -487,7 +499,7 @@ def segment_mark(classes=None):
 
 def segment_wait(token):
     """waits for the work in front of the token; False when its values are void (see segment_sync)"""
-    from . import engine
+    engine = _engine()
     ok = True
     for k, mark in token:
         with engine.side_queue(k, wait=False):
@@ -498,7 +510,7 @@ def segment_wait(token):
 def segment_queue(cls=None):
     """context manager around the enqueue calls of one feature class of a derived image: they go to the class's side stream
     (engine.side_queue) so that the classes evaluated synchronously meanwhile do not wait for them"""
-    from . import engine
+    engine = _engine()
     return engine.side_queue(SEGMENT_QUEUES.get(cls, 0))
 
 
@@ -511,7 +523,7 @@ def segment_features_enqueue(cls, image, mask, Ng, features, distances=(1,), for
     matrix and feature kernels of `cls` are only ENQUEUED on the current stream, their values land in the library's
     result arena; the returned finish() -> {feature name: float} may be called once engine.deferred_status() has
     synchronised the stream (and not raised: a level outside [1, Ng] voids the values).  No reference analogue (the reference evaluates class after class on the host, base.py:181-198)."""
-    from . import engine
+    engine = _engine()
     dist = [int(d) for d in np.asarray(distances).ravel()]
     if cls == "glcm":
         table = VOXEL_GLCM_FEATURES
@@ -610,7 +622,7 @@ def _to_device(a, integer=False):
 def firstorder_stats(image, mask, voxelArrayShift=0.0):
     """-> {Np, Energy, Minimum, P10, P25, Median, P75, P90, Maximum, Mean, MAD, rMAD, m2, m3, m4} of image[mask]
     (numpy arrays are uploaded, device tensors used in place)"""
-    from . import engine
+    engine = _engine()
     return engine.firstorder_stats(_to_device(image), _to_device(mask), voxelArrayShift)
 
 
@@ -619,7 +631,7 @@ def firstorder_stats_enqueue(image, mask, roi_count, voxelArrayShift=0.0):
     trip between them, engine.firstorder_stats_queue); the returned finish() -> dict may be called once the stream has
     been waited for and falls back to firstorder_stats when the queued chain declined (verdict word).
     NotImplementedError: not an image for the queue (integer dtype, small ROI)."""
-    from . import engine
+    engine = _engine()
     img, msk = _to_device(image), _to_device(mask)
     vals = engine.firstorder_stats_queue(img, msk, int(roi_count), voxelArrayShift, deferred=True)
 
@@ -633,7 +645,7 @@ def firstorder_stats_enqueue(image, mask, roi_count, voxelArrayShift=0.0):
 def voxel_firstorder(image, mask, levels, voxels, kernelRadius, bbsize, force2D, force2Ddimension, voxelArrayShift,
                      voxelVolume, features):
     """-> {feature name: float64 [Nvox]} for the kernels centred on `voxels` (int [Nd, Nvox])"""
-    from . import engine
+    engine = _engine()
     ids = [FIRSTORDER_FEATURES.index(f) for f in features]
     vox = _to_device(np.ascontiguousarray(np.asarray(voxels).astype(np.intc, copy=False))) if not _on_device(voxels) else voxels
     out = engine.voxel_firstorder(_to_device(image), _to_device(mask), _to_device(levels, integer=True), vox, ids,

@@ -31,12 +31,20 @@ _IMAGE_TYPES = {"Original": filters.getOriginalImage, "Wavelet": filters.getWave
                 "Gradient": filters.getGradientImage}
 
 
+_feature_classes = None
+
+
 def getFeatureClasses():
-    """name -> class (radiomics/__init__.py:64-117), restricted to the classes on the accelerated path"""
-    import importlib
-    names = {"firstorder": "RadiomicsFirstOrder"}
-    return {n: getattr(importlib.import_module("pyradiomics_amd." + n), names.get(n, "Radiomics" + n.upper()))
-            for n in _FEATURE_CLASSES}
+    """name -> class (radiomics/__init__.py:64-117), restricted to the classes on the accelerated path.  Built once:
+    the reference caches its dictionary too (`_featureClasses`), and six importlib lookups per derived image were 0.6 ms
+    of a 10 ms case."""
+    global _feature_classes
+    if _feature_classes is None:
+        import importlib
+        names = {"firstorder": "RadiomicsFirstOrder"}
+        _feature_classes = {n: getattr(importlib.import_module("pyradiomics_amd." + n), names.get(n, "Radiomics" + n.upper()))
+                            for n in _FEATURE_CLASSES}
+    return dict(_feature_classes)
 
 
 def getImageTypes():

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .base import RadiomicsFeaturesBase, deprecated
+from .base import RadiomicsFeaturesBase, deprecated, _ENQUEUE_DEFAULT
 from .image import as_array
 
 
@@ -51,7 +51,6 @@ class RadiomicsFirstOrder(RadiomicsFeaturesBase):
         """case pipeline (base.enqueue): the statistics' passes are queued now, _initCalculation collects them"""
         self._queuedStats = None
         fn = getattr(self.cMatrices, "firstorder_stats_enqueue", None)
-        from .base import _ENQUEUE_DEFAULT
         if (self.voxelBased or not self.deviceResident or fn is None
                 or not self.settings.get("enqueueSegment", _ENQUEUE_DEFAULT) or "Ns" not in self.coefficients):
             return False
@@ -65,7 +64,6 @@ class RadiomicsFirstOrder(RadiomicsFeaturesBase):
         self._queuedStats = None
 
     def imageRequest(self):
-        from .base import _ENQUEUE_DEFAULT
         if (self.voxelBased or not self.deviceResident or not hasattr(self.cMatrices, "segment_image_enqueue")
                 or not self.settings.get("enqueueSegment", _ENQUEUE_DEFAULT) or "Ns" not in self.coefficients):
             return None

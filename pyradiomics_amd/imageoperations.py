@@ -4,6 +4,8 @@ feature classes run (cropToTumorMask, imageoperations.py:407-445).  The wavelet 
 pyradiomics_amd.filters.  One numpy pass each; not part of the measured kernel path."""
 from __future__ import annotations
 
+import sys as _sys
+
 import logging
 
 import numpy as np
@@ -11,6 +13,15 @@ import numpy as np
 from .image import Image, as_array, as_image
 
 logger = logging.getLogger(__name__)
+
+
+def _engine():
+    """the device engine (imports torch), loaded on first use: a function-level `from . import engine` goes through
+    importlib's locked lookup on every call (11 us each, 54 of them per 256^3 case); sys.modules is a dict lookup"""
+    m = _sys.modules.get("pyradiomics_amd.engine")
+    if m is None:
+        from . import engine as m
+    return m
 
 
 def getBinEdges(parameterValues, **kwargs):
@@ -226,7 +237,7 @@ def resampleImage(image, mask, **kwargs):
         raise NotImplementedError("interpolator %r" % (interpolator,))
     if (kwargs.get("deviceResident", False) or img.on_device) and nd <= 3:
         # same arithmetic in the same order on the device (prad_resample_dev): bit-identical to the numpy route below
-        from . import engine
+        engine = _engine()
         step = (new / old)[::-1]
         ri = engine.resample(img.device_tensor(), start[::-1], step, newsize[::-1], codes[str(interpolator)])
         rm = engine.resample(msk.device_tensor(), start[::-1], step, newsize[::-1], 0)
