@@ -76,7 +76,8 @@ __device__ __forceinline__ void fw2_checked(const Fw2Tab &T, int k1, int dummy, 
 // The plain step of the two lines whose levels are the 16-bit halves of c (current) and x (previous); exec-masked like
 // fw_plain_word.  Only valid while no run can outgrow its length slots (margin()).
 template <bool SKIP1>
-__device__ __forceinline__ void fw2_plain_word(const Fw2Tab &T, int k1, int k14, u32 one, int &p0, int &q0, int &p1, int &q1, u32 c, u32 x) {
+__device__ __forceinline__ void fw2_plain_word(const Fw2Tab &T, int k1, int k14, u32 one, int &p0, int &q0, int &p1, int &q1, u32 c, u32 x,
+                                               unsigned long long &ev0, unsigned long long &ev1) {
   int t;
 #ifdef PRAD_DBG_FW2_NOPAIR    // ablation builds (wrong results): the step without its pair / run atomic
 #define PRAD_FW2_DSA ""
@@ -111,12 +112,33 @@ __device__ __forceinline__ void fw2_plain_word(const Fw2Tab &T, int k1, int k14,
   "v_add_u32 %[" QJ "], %[K1], %[" PJ "]\n\t"                                                                            \
   "s_mov_b64 exec, -1\n\t"                                                                                               \
   "v_add_u32 %[" QJ "], 4, %[" QJ "]\n\t"
+#define PRAD_FW2_COL_M(J, PJ, QJ, EV)                                                                                    \
+  "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:WORD_" #J " src1_sel:WORD_" #J "\n\t"                                     \
+  "v_add_u32_sdwa %[t], %[" PJ "], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #J "\n\t"       \
+  PRAD_FW2_DSA                                                                                                           \
+  "s_andn2_b64 exec, vcc, %[" EV "]\n\t"                                                                                 \
+  PRAD_FW2_DSB(QJ)                                                                                                       \
+  "s_mov_b64 exec, vcc\n\t"                                                                                              \
+  "v_mul_u32_u24_sdwa %[" PJ "], %[S4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #J "\n\t" \
+  "v_add_u32 %[" QJ "], %[K1], %[" PJ "]\n\t"                                                                            \
+  "s_mov_b64 %[" EV "], vcc\n\t"                                                                                         \
+  "s_mov_b64 exec, -1\n\t"                                                                                               \
+  "v_add_u32 %[" QJ "], 4, %[" QJ "]\n\t"
   if (SKIP1) {
+#ifdef PRAD_FW2_SKIP_BY_STATE   // A/B build: "length 1" read from the line's state (v_sub + v_cmpx) instead of the event masks
     unsigned long long sm;
     asm volatile(PRAD_FW2_COL_S(0, "p0", "q0") PRAD_FW2_COL_S(1, "p1", "q1")
                  : [p0] "+v"(p0), [q0] "+v"(q0), [p1] "+v"(p1), [q1] "+v"(q1), [t] "=&v"(t), [sm] "=&s"(sm)
                  : [c] "v"(c), [x] "v"(x), [one] "v"(one), [S4] "s"(T.S4), [K1] "v"(k1), [K14] "v"(k14)
                  : "vcc", "memory");
+#else
+    // A line's run has length 1 exactly when the line had an event at its previous step: the event lanes of the previous
+    // step (ev, a scalar mask that travels with the line's registers) leave before the run atomic -- no vector instruction
+    asm volatile(PRAD_FW2_COL_M(0, "p0", "q0", "ev0") PRAD_FW2_COL_M(1, "p1", "q1", "ev1")
+                 : [p0] "+v"(p0), [q0] "+v"(q0), [p1] "+v"(p1), [q1] "+v"(q1), [t] "=&v"(t), [ev0] "+s"(ev0), [ev1] "+s"(ev1)
+                 : [c] "v"(c), [x] "v"(x), [one] "v"(one), [S4] "s"(T.S4), [K1] "v"(k1)
+                 : "vcc", "scc", "memory");     // (s_andn2 writes SCC)
+#endif
   } else {
     asm volatile(PRAD_FW2_COL(0, "p0", "q0") PRAD_FW2_COL(1, "p1", "q1")
                  : [p0] "+v"(p0), [q0] "+v"(q0), [p1] "+v"(p1), [q1] "+v"(q1), [t] "=&v"(t)
@@ -125,6 +147,7 @@ __device__ __forceinline__ void fw2_plain_word(const Fw2Tab &T, int k1, int k14,
   }
 #undef PRAD_FW2_COL
 #undef PRAD_FW2_COL_S
+#undef PRAD_FW2_COL_M
 }
 
 struct __attribute__((packed)) u128_unaligned { u32 a, b, c, d; };
@@ -182,6 +205,7 @@ struct Fw2Wave {
   u32 cmask[KW];   // halves of this lane's window columns that lie inside the row
   u32 calm[KW];    // halves of window columns no line can be open on
   int lp[K], lq[K];   // A row / B cursor of the line that arrives at column j at the next step
+  unsigned long long ev[K];   // SKIP1, inside a plain group: lanes whose line (register j) had an event at its previous step
   u32 P[KW];       // levels of the previous row (this lane's columns)
 
   __device__ __forceinline__ Fw2Wave(const Fw2Tab &T_, int NX) : T(T_) {
@@ -231,15 +255,21 @@ struct Fw2Wave {
   // cross-lane move of the one line that changes lane, after the line that leaves the row was closed (its run is recorded:
   // B[prev][len]; there is no pair across the row's edge)
   template <bool PLAIN>
-  __device__ __forceinline__ void rotate_reg(int &rp, int &rq, int xlevel) {
+  __device__ __forceinline__ void rotate_reg(int &rp, int &rq, int xlevel, unsigned long long &rev) {
+    if (PLAIN && SKIP1 && haspad) (void)rev;
     if (!haspad) {
       if (PLAIN) {
         const unsigned long long em = DX > 0 ? 0x8000000000000000ull : 1ull;   // lane 63 / lane 0
         if (SKIP1) {
+#ifdef PRAD_FW2_SKIP_BY_STATE
           int t;
           asm volatile("v_sub_u32 %[t], %[r], %[p]\n\tv_cmp_ne_u32 vcc, %[t], %[K14]\n\ts_and_b64 exec, vcc, %[m]\n\t"
                        "ds_add_u32 %[r], %[one]\n\ts_mov_b64 exec, -1"
-                       : [t] "=&v"(t) : [m] "s"(em), [r] "v"(rq), [p] "v"(rp), [one] "v"(one), [K14] "v"(k14) : "vcc", "memory");
+                       : [t] "=&v"(t) : [m] "s"(em), [r] "v"(rq), [p] "v"(rp), [one] "v"(one), [K14] "v"(k14) : "vcc", "scc", "memory");
+#else
+          asm volatile("s_andn2_b64 exec, %[m], %[e]\n\tds_add_u32 %[r], %[one]\n\ts_mov_b64 exec, -1"
+                       :: [m] "s"(em), [e] "s"(rev), [r] "v"(rq), [one] "v"(one) : "scc", "memory");
+#endif
         } else {
           asm volatile("s_mov_b64 exec, %[m]\n\tds_add_u32 %[r], %[one]\n\ts_mov_b64 exec, -1" ::[m] "s"(em), [r] "v"(rq), [one] "v"(one) : "memory");
         }
@@ -250,6 +280,7 @@ struct Fw2Wave {
     rp = (int)(DX > 0 ? fw_shr1((u32)rp) : fw_shl1((u32)rp));
     rq = (int)(DX > 0 ? fw_shr1((u32)rq) : fw_shl1((u32)rq)) + kdelta;   // (the cursor moves to this lane's copy of the slots;
                                                                            //  the line that enters from outside: level 0, length 0)
+    if (PLAIN && SKIP1) rev = DX > 0 ? rev << 1 : rev >> 1;                // (its event bit travels with it; the entering line: none)
   }
   __device__ __forceinline__ void single_step(const u32 (&C)[KW], bool tail) {
     u32 X[KW];
@@ -257,7 +288,7 @@ struct Fw2Wave {
 #pragma unroll
     for (int j = 0; j < K; j++) fw2_checked<LONG, SKIP1>(T, k1v, dummy, lp[j], lq[j], FW2_EL(X, j), FW2_EL(C, j), tail);
     if (DX > 0) {
-      rotate_reg<false>(lp[K - 1], lq[K - 1], FW2_EL(C, K - 1));
+      rotate_reg<false>(lp[K - 1], lq[K - 1], FW2_EL(C, K - 1), ev[0]);
       const int ip = lp[K - 1], iq = lq[K - 1];
 #pragma unroll
       for (int j = K - 1; j >= 1; j--) {
@@ -267,7 +298,7 @@ struct Fw2Wave {
       lp[0] = ip;
       lq[0] = iq;
     } else if (DX < 0) {
-      rotate_reg<false>(lp[0], lq[0], FW2_EL(C, 0));
+      rotate_reg<false>(lp[0], lq[0], FW2_EL(C, 0), ev[0]);
       const int ip = lp[0], iq = lq[0];
 #pragma unroll
       for (int j = 0; j < K - 1; j++) {
@@ -282,6 +313,10 @@ struct Fw2Wave {
   }
   // U plain steps with renamed registers
   __device__ __forceinline__ void plain_group(const u32 (&v)[U][KW]) {
+    if (SKIP1) {   // the event masks from the lines' states: a run has length 1 exactly behind an event
+#pragma unroll
+      for (int j = 0; j < K; j++) ev[j] = __ballot(lq[j] - lp[j] == k14);
+    }
 #pragma unroll
     for (int k = 0; k < U; k++) {
       u32 X[KW];
@@ -289,15 +324,15 @@ struct Fw2Wave {
 #pragma unroll
       for (int w = 0; w < KW; w++) {
         const int r0 = (((2 * w + 0 - k * DX) % K) + K) % K, r1 = (((2 * w + 1 - k * DX) % K) + K) % K;
-        fw2_plain_word<SKIP1>(T, k1v, k14, one, lp[r0], lq[r0], lp[r1], lq[r1], v[k][w], X[w]);
+        fw2_plain_word<SKIP1>(T, k1v, k14, one, lp[r0], lq[r0], lp[r1], lq[r1], v[k][w], X[w], ev[r0], ev[r1]);
       }
       if (DX > 0) {
         const int r = (((K - 1 - k) % K) + K) % K;
-        rotate_reg<true>(lp[r], lq[r], FW2_EL(v[k], K - 1));
+        rotate_reg<true>(lp[r], lq[r], FW2_EL(v[k], K - 1), ev[r]);
       }
       if (DX < 0) {
         const int r = k % K;
-        rotate_reg<true>(lp[r], lq[r], FW2_EL(v[k], 0));
+        rotate_reg<true>(lp[r], lq[r], FW2_EL(v[k], 0), ev[r]);
       }
 #pragma unroll
       for (int w = 0; w < KW; w++) P[w] = v[k][w];
