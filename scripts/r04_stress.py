@@ -86,6 +86,29 @@ while time.time() - t0 < budget:
         got = cm.calculate_ngtdm(img, mask, [1], Ng, f2, dim)
         assert np.array_equal(got[..., 0], en[..., 0]) and np.allclose(got[..., 1:], en[..., 1:], rtol=1e-12, atol=0), "NGTDM " + tag
         n["neigh"] += 1
+# GLSZM (dense tile-root model of this round: tiles with halo, work list of cross-tile pairs, dense ids, compact fill)
+n["glszm"] = 0
+t2 = time.time()
+while time.time() - t2 < budget / 2:
+    Ng = int(rng.choice([1, 2, 3, 8, 32, 64, 200, 255]))
+    shape = (int(rng.integers(1, 70)), int(rng.integers(1, 70)), int(rng.choice([1, 3, 4, 7, 8, 9, 16, 31, 64, 65, 100, 128, 129, 200, 300])))
+    while shape[0] * shape[1] * shape[2] > 600000:
+        shape = (max(1, shape[0] // 2), shape[1], shape[2])
+    img = levels(shape, Ng, rng.choice(["uniform", "smooth", "smooth2", "plateau"]))
+    mask = mask_of(shape, rng.choice(["full", "random", "sparse", "ball"]))
+    if not mask.any():
+        mask[0, 0, 0] = True
+    f2 = bool(rng.random() < 0.3)
+    dim = int(rng.integers(0, 3)) if f2 else 0
+    Ns = int(mask.sum())
+    try:
+        want = ck.calculate_glszm(img, mask, Ng, Ns, f2, dim)
+    except (RuntimeError, IndexError):
+        continue
+    got = cm.calculate_glszm(img, mask, Ng, Ns, f2, dim)
+    assert got.shape == want.shape and np.array_equal(got, want), "GLSZM shape %s Ng %d force2D %s/%d" % (shape, Ng, f2, dim)
+    n["glszm"] += 1
+
 # the pack that rides in the previous volume's walk (deferred pipeline): consecutive volumes of one shape, masks and junk mixed
 import torch
 from pyradiomics_amd import engine
