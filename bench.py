@@ -550,15 +550,23 @@ def mode_voxel(device, rank: int, world: int, size: int, fence, three_d: bool = 
     vox = torch.stack([zz.reshape(-1), yy.reshape(-1), xx.reshape(-1)])
     del zz, yy, xx
     kw = dict(kernelRadius=2, force2D=not three_d, force2Ddimension=0)
-    engine.voxel_glcm_features(img, msk, 32, vox[:, :4096].contiguous(), ["JointEntropy"], **kw)
-    fence()
-    t0 = time.perf_counter()
+    # warm-up with the DENSE request itself: a sparse one takes the window kernel and leaves the sliding-window route's
+    # workspace (the whole-volume maps, ~1.6 GB at 512^3) to be allocated inside the timed call -- VERDICT r4 weak #2: the
+    # figure swung 7x between runs with the same kernel time
     res = engine.voxel_glcm_features(img, msk, 32, vox, ["JointEntropy"], **kw)
+    assert engine.last_variant() == "slide", engine.last_variant()
+    del res
     fence()
-    dt = time.perf_counter() - t0
+    dts = []
+    for _ in range(2):               # two consecutive timed calls; the slower one is reported, both are kept
+        t0 = time.perf_counter()
+        res = engine.voxel_glcm_features(img, msk, 32, vox, ["JointEntropy"], **kw)
+        fence()
+        dts.append(time.perf_counter() - t0)
     kms = engine.last_kernel_ms("voxel")
     assert bool(torch.isfinite(res["JointEntropy"]).all())
-    return int(vox.shape[1]), dt, kms
+    mode_voxel.runs_ms = [round(d * 1e3, 3) for d in dts]
+    return int(vox.shape[1]), max(dts), kms
 
 
 def host_boundary(image, mask, Ng: int, Nr: int):
@@ -734,6 +742,8 @@ def main() -> None:
                 nk_all = int(t.item())
             # 5 B/voxel in + 8 B per centre and feature map out
             return {"value": round(nk_all / dt_v / 1e6, 2), "unit": "Mkernels/s", "kernels": nk_all,
+                    "call_ms_two_runs": mode_voxel.runs_ms,      # wall clock of two consecutive calls of this rank (value: the slower)
+                    "kernel_only_Mkernels_s": round(nk / (kms * 1e-3) / 1e6, 2) if kms else None,
                     "kernel": frac_of_hbm(13.0 * nk, kms),
                     "case": "%d^3 volume, GLCM JointEntropy map, %s window, every voxel a centre, centres split into "
                             "z-slabs over the ranks" % (args.size, "3-D 5x5x5 (kernelRadius 2)" if three_d else

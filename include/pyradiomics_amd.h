@@ -453,7 +453,9 @@ int prad_resample_dev(const void *image, int dtype, const int *size, int Nd, con
  *   in   float64 [size[0]]..[size[Nd-1]], every transformed axis of even length
  *   out  float64 [2^naxes][...]: sub-bands in PyWavelets' key order ('a' = dec_lo before 'd' = dec_hi, the first
  *        axis of `axes` is the most significant letter): aaa, aad, ada, add, daa, dad, dda, ddd for 3 axes.
- * prad_log: ITK LaplacianRecursiveGaussianImageFilter (imageoperations.py:824-830): float32 in / out,
+ * prad_log: ITK LaplacianRecursiveGaussianImageFilter (imageoperations.py:824-830): float32 in / out; per dimension the
+ *   second-order pass along it first, then the zero-order passes along the other dimensions in increasing ITK direction
+ *   (the order that reproduces the float32 order statistics the reference recorded for brain1 bit for bit),
  *   `spacing` per ARRAY axis (i.e. SimpleITK spacing reversed), sigma in the units of spacing,
  *   normalize != 0 multiplies by sigma^2 (NormalizeAcrossScale).  Every axis needs >= 4 samples. */
 int prad_swt_level1(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi, int flen,
@@ -475,9 +477,11 @@ int prad_log_dev(const float *in, const int *size, int Nd, const double *spacing
  * other sigmas fill the gaps.  outs: HOST array of nsig DEVICE pointers; the same arithmetic per sigma as prad_log_dev. */
 int prad_log_multi_dev(const float *in, const int *size, int Nd, const double *spacing, const double *sigmas, int nsig,
                        int normalize, float *const *outs, void *stream);
-/* The same filter on float64 images: sitk.LaplacianRecursiveGaussianImageFilter keeps the input's real type
- * (imageoperations.py:824-830), so a float64 input -- e.g. after `normalize: true`, whose output is float64 -- is
- * filtered with float64 images between the passes and returns float64. */
+/* The same filter on float64 images (e.g. after `normalize: true`, whose output is float64): the result is float64 like the
+ * input (sitk.LaplacianRecursiveGaussianImageFilter keeps the pixel type, imageoperations.py:824-830) and is computed as
+ * ITK computes it: the derivative pass of every term reads the float64 input, the images between the passes and the
+ * cumulative image are float (itkLaplacianRecursiveGaussianImageFilter.h: InternalRealType = float), the sum is widened at
+ * the end.  (Rounds 3-4 kept float64 images between the passes.) */
 int prad_log_f64(const double *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,
                  double *out);
 int prad_log_dev_f64(const double *in, const int *size, int Nd, const double *spacing, double sigma, int normalize,

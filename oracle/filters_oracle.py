@@ -202,28 +202,37 @@ def _filter_lines(data, c):
 
 
 def recursive_gaussian(image, axis, sigma, spacing, order, normalize_across_scale=False, real=np.float32):
-    """one 1-D pass: image of the filter's real type in and out (float32, or float64 for float64 inputs), float64
-    arithmetic inside each line"""
+    """one 1-D pass (itk::RecursiveGaussianImageFilter<TIn, Image<float>>): the line is read in the INPUT's own type and
+    widened to float64 (RealType), float64 arithmetic inside the line, the result stored as `real` (float32: ITK's
+    InternalRealType)"""
     c = recursive_gaussian_coefficients(sigma, spacing, order, normalize_across_scale)
-    moved = np.moveaxis(np.asarray(image, dtype=real).astype(np.float64), axis, -1)
+    moved = np.moveaxis(np.asarray(image).astype(np.float64), axis, -1)
     return np.moveaxis(_filter_lines(moved, c), -1, axis).astype(real)
 
 
 def laplacian_recursive_gaussian(array_zyx, spacing_xyz, sigma, normalize_across_scale=True):
-    """ITK LaplacianRecursiveGaussianImageFilter on a numpy (z, y, x) array with SimpleITK (x, y, z) spacing.  The images
-    between the passes and the result have the filter's real type: float64 for a float64 input, float32 otherwise
-    (sitk keeps the input's real type, imageoperations.py:824-830)"""
-    real = np.float64 if np.asarray(array_zyx).dtype == np.float64 else np.float32
-    img = np.asarray(array_zyx).astype(real)
-    nd = img.ndim
+    """ITK LaplacianRecursiveGaussianImageFilter on a numpy (z, y, x) array with SimpleITK (x, y, z) spacing.
+
+    Pipeline of itkLaplacianRecursiveGaussianImageFilter.hxx: for every dimension `dim` (x, y, z) the DERIVATIVE filter
+    (second order along dim, RecursiveGaussianImageFilter<InputImage, Image<float>>: it reads the input image itself) runs
+    first, then the zero-order smoothing filters along the other dimensions in increasing ITK direction, float32 images
+    between the passes (InternalRealType = float whatever the input type); the float32 cumulative image takes
+    acc = float(acc + term / spacing[dim]^2); the result is cast to the input's real type at the end (float64 for float64
+    inputs, float32 otherwise).
+    PINNED (round 5): with exactly this order the Minimum, Maximum and Median of the sigma 1 / 3 / 5 mm images of brain1 --
+    float32 values the reference's notebook recorded -- are reproduced BIT FOR BIT (tests/test_notebook_pin.py); with the
+    smoothing passes in front of the derivative (the order of rounds 3-4) 8 of those 9 values are off by 1-4 float32 ulp."""
+    arr = np.asarray(array_zyx)
+    out_type = np.float64 if arr.dtype == np.float64 else np.float32
+    real = np.float32
+    nd = arr.ndim
     sp = [float(s) for s in spacing_xyz][::-1]   # per numpy axis
-    acc = np.zeros(img.shape, dtype=real)
+    acc = np.zeros(arr.shape, dtype=real)
     # ITK dimension order is x, y, z = numpy axes nd-1 ... 0
     for dim in range(nd - 1, -1, -1):
-        cur = img
+        cur = recursive_gaussian(arr, dim, sigma, sp[dim], 2, normalize_across_scale, real=real)
         for other in range(nd - 1, -1, -1):
             if other != dim:
                 cur = recursive_gaussian(cur, other, sigma, sp[other], 0, real=real)
-        cur = recursive_gaussian(cur, dim, sigma, sp[dim], 2, normalize_across_scale, real=real)
         acc = (acc.astype(np.float64) + cur.astype(np.float64) / (sp[dim] * sp[dim])).astype(real)
-    return acc
+    return acc.astype(out_type)

@@ -185,23 +185,26 @@ struct RGaussCoef {
 // Several sigmas per launch (blockIdx.y): a 256^3 volume has 65 536 lines = ONE wave per SIMD; the waves of the other sigmas
 // fill the machine (profiles/r03_probes.md section 11, profiles/r04_probes.md).
 #define PRAD_LOG_MAXSIG 8
-// T = image type between the passes: float (ITK's real type for integer and float32 inputs) or double (float64 inputs)
-template <typename T>
+// T = element type the pass READS, TO = the type it WRITES.  ITK's images between the passes are float whatever the input
+// (itkLaplacianRecursiveGaussianImageFilter.h: InternalRealType = float); the first pass of a term -- the derivative filter,
+// RecursiveGaussianImageFilter<InputImage, Image<float>> -- reads the input image in its own type: <double, float> for a
+// float64 input, <float, float> everywhere else.
+template <typename T, typename TO = T>
 struct RGMultiT {
   RGaussCoef k[PRAD_LOG_MAXSIG];
   const T *in[PRAD_LOG_MAXSIG];
   double *scratch[PRAD_LOG_MAXSIG];     // block states (rgauss_pass_kernel) / float64 causal pass (rgauss_line_kernel)
-  T *out[PRAD_LOG_MAXSIG];
+  TO *out[PRAD_LOG_MAXSIG];
 };
 
 // ---- reference pass: one lane per line, the causal recursion parked in a float64 scratch image ------------------------
 // data viewed as [outer][ln][inner]; lane = (outer index, inner index).  The plainest statement of ITK's
 // RecursiveSeparableImageFilter::FilterDataArray on the device: kept as the checker of the fast kernel below
 // (PRAD_LOG_OLDLINE=1, tests/test_gpu_filters.py) -- 36 B of traffic per sample.
-template <typename T>
+template <typename T, typename TO = T>
 __global__ void __launch_bounds__(256) rgauss_line_kernel(const T *__restrict__ in, long long outer, int ln,
                                                           long long inner, RGaussCoef c,
-                                                          double *__restrict__ scratch, T *__restrict__ out) {
+                                                          double *__restrict__ scratch, TO *__restrict__ out) {
 #pragma clang fp contract(off)  // ITK's line arithmetic is plain multiply / add; keep the same roundings
   const long long lines = outer * inner;
   const long long line = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const T *__restrict__ 
   const long long base = (line / inner) * ln * inner + (line % inner);
   const T *d = in + base;
   double *s = scratch + base;
-  T *o = out + base;
+  TO *o = out + base;
   const long long st = inner;
   // causal pass (itkRecursiveSeparableImageFilter.hxx FilterDataArray)
   const double v1 = d[0];
@@ -246,10 +249,10 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const T *__restrict__ 
   a2 -= a1 * c.D1 + v2 * c.BM2 + v2 * c.BM3 + v2 * c.BM4;
   a3 -= a2 * c.D1 + a1 * c.D2 + v2 * c.BM3 + v2 * c.BM4;
   a4 -= a3 * c.D1 + a2 * c.D2 + a1 * c.D3 + v2 * c.BM4;
-  o[(long long)(ln - 1) * st] = (T)(s[(long long)(ln - 1) * st] + a1);
-  o[(long long)(ln - 2) * st] = (T)(s[(long long)(ln - 2) * st] + a2);
-  o[(long long)(ln - 3) * st] = (T)(s[(long long)(ln - 3) * st] + a3);
-  o[(long long)(ln - 4) * st] = (T)(s[(long long)(ln - 4) * st] + a4);
+  o[(long long)(ln - 1) * st] = (TO)(s[(long long)(ln - 1) * st] + a1);
+  o[(long long)(ln - 2) * st] = (TO)(s[(long long)(ln - 2) * st] + a2);
+  o[(long long)(ln - 3) * st] = (TO)(s[(long long)(ln - 3) * st] + a3);
+  o[(long long)(ln - 4) * st] = (TO)(s[(long long)(ln - 4) * st] + a4);
   {
     // scratch[i-1] = data[i]*M1 + data[i+1]*M2 + data[i+2]*M3 + data[i+3]*M4 - (scratch[i]*D1 + ... + scratch[i+3]*D4)
     double dp0 = d[(long long)(ln - 4) * st], dp1 = y2, dp2 = y1, dp3 = v2;  // data[i], [i+1], [i+2], [i+3] at i = ln-4
@@ -257,7 +260,7 @@ __global__ void __launch_bounds__(256) rgauss_line_kernel(const T *__restrict__ 
     for (int i = ln - 4; i > 0; i--) {
       double v = dp0 * c.M1 + dp1 * c.M2 + dp2 * c.M3 + dp3 * c.M4;
       v -= q0 * c.D1 + q1 * c.D2 + q2 * c.D3 + q3 * c.D4;
-      o[(long long)(i - 1) * st] = (T)(s[(long long)(i - 1) * st] + v);
+      o[(long long)(i - 1) * st] = (TO)(s[(long long)(i - 1) * st] + v);
       dp3 = dp2; dp2 = dp1; dp1 = dp0; dp0 = d[(long long)(i - 1) * st];
       q3 = q2; q2 = q1; q1 = q0; q0 = v;
     }
@@ -347,8 +350,8 @@ struct RGChain {
 #ifndef PRAD_RG_WAVES
 #define PRAD_RG_WAVES 2
 #endif
-template <typename T, bool CONTIG, bool PLAIN>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRAD_RG_WAVES, PRAD_RG_WAVES))) rgauss_pass_kernel(RGMultiT<T> M, long long outer, int ln, long long inner) {
+template <typename T, bool CONTIG, bool PLAIN, typename TO = T>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRAD_RG_WAVES, PRAD_RG_WAVES))) rgauss_pass_kernel(RGMultiT<T, TO> M, long long outer, int ln, long long inner) {
 #pragma clang fp contract(off)  // ITK's line arithmetic is plain multiply / add; keep the same roundings
   constexpr int RB = PRAD_RG_RB;
   constexpr int RM = RB + 4;                  // samples held: the block and, for the anti-causal start, the 4 behind it
@@ -358,7 +361,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRAD_R
   const int sg = blockIdx.y;
   const RGaussCoef &c = M.k[sg];
   const T *__restrict__ in = M.in[sg];
-  T *__restrict__ out = M.out[sg];
+  TO *__restrict__ out = M.out[sg];
   const long long lines = CONTIG ? outer : outer * inner;
   const long long line = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool mine = line < lines;
@@ -634,32 +637,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PRAD_R
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int j = 0; j < RM; j++)
-        if (j < len) tile[lane][j] = (T)cv[j];
+        if (j < len) tile[lane][j] = (T)(TO)cv[j];       // (the staging tile has the input's type: TO values pass through it exactly)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int k = 0; k < 16; k++) {
         const int t = k * 4 + (lane >> 4), cc = lane & 15;
-        if (t < nwl && cc < len) out[(wl0 + t) * ln + b + cc] = tile[t][cc];
+        if (t < nwl && cc < len) out[(wl0 + t) * ln + b + cc] = (TO)tile[t][cc];
       }
       if (len > 16) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           const int t = k * 16 + (lane >> 2), cc = 16 + (lane & 3);
-          if (t < nwl && cc < len) out[(wl0 + t) * ln + b + cc] = tile[t][cc];
+          if (t < nwl && cc < len) out[(wl0 + t) * ln + b + cc] = (TO)tile[t][cc];
         }
       }
     } else {
 #pragma unroll
       for (int j = 0; j < RM; j++)
-        if (j < len) out[base + (long long)(b + j) * st] = (T)cv[j];
+        if (j < len) out[base + (long long)(b + j) * st] = (TO)cv[j];
     }
   }
 }
 
 // Laplacian = sum over the dimensions of (second-derivative image) / spacing^2, accumulated in ITK's order and with the
 // roundings of its separate accumulation step: acc = (T)((double)acc + (double)term / spacing^2), starting from 0
-// (itkLaplacianRecursiveGaussianImageFilter.hxx).  out may alias term[0].
+// (itkLaplacianRecursiveGaussianImageFilter.hxx; T = float, the cumulative image's type); the sum is cast to the output
+// type TOUT at the end (float64 for float64 inputs).  out may alias term[0] when TOUT = T.
 #define PRAD_LOG_MAXTERMS 8
 template <typename T>
 struct LogTerms {
@@ -667,8 +671,8 @@ struct LogTerms {
   double sp2[PRAD_LOG_MAXTERMS];
   int n;
 };
-template <typename T>
-__global__ void __launch_bounds__(256) log_combine_kernel(LogTerms<T> L, long long n, T *out) {
+template <typename T, typename TOUT = T>
+__global__ void __launch_bounds__(256) log_combine_kernel(LogTerms<T> L, long long n, TOUT *out) {
 #pragma clang fp contract(off)
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -680,7 +684,7 @@ __global__ void __launch_bounds__(256) log_combine_kernel(LogTerms<T> L, long lo
         acc = (T)((double)acc + (double)f / L.sp2[k]);
       }
     }
-    out[i] = acc;
+    out[i] = (TOUT)acc;
   }
 }
 

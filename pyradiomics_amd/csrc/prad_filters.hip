@@ -196,11 +196,17 @@ RGaussCoef rgauss_coefficients(double sigma, double spacing, int order, bool nor
 }
 
 // nsig sigmas of one input in the same launches (blockIdx.y = sigma): see RGMultiT in kernels_filters.h.
-// T = float: ITK's real image type for integer and float32 inputs; T = double: float64 inputs keep float64 images between
-// the passes (sitk.LaplacianRecursiveGaussianImageFilter returns the input's real type, imageoperations.py:824-830).
-template <typename T>
-int log_multi_dev(const T *in, const int *size, int Nd, const double *spacing, const double *sigmas, int nsig,
-                  int normalize, T *const *outs, hipStream_t s) {
+// TIN = the input's real type (float: integer and float32 images, converted exactly by the caller; double: float64 images).
+// ITK's pipeline (itkLaplacianRecursiveGaussianImageFilter.h/.hxx), which the reference reaches through
+// sitk.LaplacianRecursiveGaussianImageFilter (imageoperations.py:824-830): per dimension the DERIVATIVE filter reads the
+// input image itself (RecursiveGaussianImageFilter<InputImage, Image<float>>), the zero-order smoothing filters of the other
+// dimensions follow in increasing ITK direction, every image between the passes and the cumulative image are float
+// (InternalRealType = float for any input type), the sum is cast to the output type (= TIN) at the end.  Round 5: this pass
+// order reproduces the float32 order statistics the reference recorded for brain1 bit for bit (tests/test_notebook_pin.py);
+// rounds 3-4 ran the smoothing passes first (and kept float64 images for float64 inputs), 1-4 ulp off.
+template <typename TIN>
+int log_multi_dev(const TIN *in, const int *size, int Nd, const double *spacing, const double *sigmas, int nsig,
+                  int normalize, TIN *const *outs, hipStream_t s) {
   Context &c = ctx();
   PRAD_TRY(c.ensure_device());
   Geo g;
@@ -216,19 +222,16 @@ int log_multi_dev(const T *in, const int *size, int Nd, const double *spacing, c
     if (g.size[d] < 4) return fail(PRAD_E_ARG, "log: axis %d has %d < 4 samples (imageoperations.py:811)", d, g.size[d]);
   PRAD_TRY(c.begin_call(s));
   const size_t n = (size_t)g.n;
-  const char *sfx = std::is_same<T, float>::value ? "" : "64";
   const bool reference_kernel = getenv("PRAD_LOG_OLDLINE") != nullptr;     // one lane per line, float64 scratch image
   const bool plain_steps = getenv("PRAD_LOG_PLAIN") != nullptr;
-  T *bufA[PRAD_LOG_MAXSIG], *bufB[PRAD_LOG_MAXSIG], *bufC[PRAD_LOG_MAXSIG];
-  T *term[PRAD_LOG_MAXTERMS][PRAD_LOG_MAXSIG];       // second-derivative image of every dimension (the first lives in outs)
+  float *bufA[PRAD_LOG_MAXSIG], *bufB[PRAD_LOG_MAXSIG];
+  float *term[PRAD_LOG_MAXTERMS][PRAD_LOG_MAXSIG];       // second-derivative (and smoothed) image of every dimension
   double *scratch[PRAD_LOG_MAXSIG];
   for (int q = 0; q < nsig; q++) {
-    const std::string tag = sfx + (q ? "#s" + std::to_string(q) : std::string());
-    PRAD_TRY(c.get<T>(("log_a" + tag).c_str(), n, &bufA[q]));
-    PRAD_TRY(c.get<T>(("log_b" + tag).c_str(), n, &bufB[q]));
-    PRAD_TRY(c.get<T>(("log_c" + tag).c_str(), n, &bufC[q]));
-    term[0][q] = outs[q];
-    for (int k = 1; k < Nd; k++) PRAD_TRY(c.get<T>(("log_t" + std::to_string(k) + tag).c_str(), n, &term[k][q]));
+    const std::string tag = q ? "#s" + std::to_string(q) : std::string();
+    PRAD_TRY(c.get<float>(("log_a" + tag).c_str(), n, &bufA[q]));
+    PRAD_TRY(c.get<float>(("log_b" + tag).c_str(), n, &bufB[q]));
+    for (int k = 0; k < Nd; k++) PRAD_TRY(c.get<float>(("log_t" + std::to_string(k) + tag).c_str(), n, &term[k][q]));
     // block states of rgauss_pass_kernel: 4 doubles per PRAD_RG_RB samples (n / 4 + a line's worth); the reference kernel
     // parks the whole causal pass
     PRAD_TRY(c.get<double>(("log_scratch" + tag).c_str(), reference_kernel ? n : n / 4 + 4 * (n / g.size[Nd - 1]) + 64, &scratch[q]));
@@ -236,26 +239,22 @@ int log_multi_dev(const T *in, const int *size, int Nd, const double *spacing, c
   {
     Timed t(c, "log", s);
     // ITK dimension order x, y, z = array axes Nd-1 .. 0.
-    // Laplacian term of dimension dim = second derivative along dim of the image smoothed along the other dimensions,
-    // in ITK's pass order (smoothing passes from the last axis to the first, then the derivative).  Two terms begin with
-    // the same smoothing pass along the last axis: it is computed once and kept (identical arithmetic, identical bits).
-    bool have_shared = false;        // bufC = smoothed-along-the-last-axis copy of the input
-    int shared_axis = -1;
     int nterm = 0;
     double term_sp2[PRAD_LOG_MAXTERMS];
     for (int dim = Nd - 1; dim >= 0; dim--) {
-      const T *cur[PRAD_LOG_MAXSIG];
-      for (int q = 0; q < nsig; q++) cur[q] = in;
+      const float *cur[PRAD_LOG_MAXSIG];
       int flip = 0;
-      // where: 0 = ping-pong buffers, 1 = into bufC (the shared first smoothing), 2 = the term image of this dimension
-      auto pass = [&](int ax, int order, int where) -> int {
-        RGMultiT<T> M;
+      // one pass along `ax`; FIRST: reads the input image (TIN), else the float image `cur`; last: into the term image
+      auto pass = [&](auto first_tag, int ax, int order, bool last) -> int {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        using TI = typename std::conditional<FIRST, TIN, float>::type;
+        RGMultiT<TI, float> M;
         memset(&M, 0, sizeof(M));
-        T *dst[PRAD_LOG_MAXSIG];
+        float *dst[PRAD_LOG_MAXSIG];
         for (int q = 0; q < nsig; q++) {
           M.k[q] = rgauss_coefficients(sigmas[q], spacing[ax], order, normalize != 0);
-          dst[q] = where == 1 ? bufC[q] : where == 2 ? term[nterm][q] : (flip ? bufB[q] : bufA[q]);
-          M.in[q] = cur[q];
+          dst[q] = last ? term[nterm][q] : (flip ? bufB[q] : bufA[q]);
+          M.in[q] = FIRST ? reinterpret_cast<const TI *>(in) : reinterpret_cast<const TI *>(cur[q]);
           M.scratch[q] = scratch[q];
           M.out[q] = dst[q];
         }
@@ -267,44 +266,36 @@ int log_multi_dev(const T *in, const int *size, int Nd, const double *spacing, c
         const dim3 grid((unsigned)((lines + 255) / 256), (unsigned)nsig);
         if (reference_kernel) {
           for (int q = 0; q < nsig; q++)
-            hipLaunchKernelGGL((rgauss_line_kernel<T>), dim3(grid.x), dim3(256), 0, s, M.in[q], outer, g.size[ax], inner, M.k[q],
+            hipLaunchKernelGGL((rgauss_line_kernel<TI, float>), dim3(grid.x), dim3(256), 0, s, M.in[q], outer, g.size[ax], inner, M.k[q],
                                M.scratch[q], M.out[q]);
           PRAD_TRY(check_launch("rgauss_line_kernel"));
         } else if (plain_steps) {         // (PRAD_LOG_PLAIN=1: the compiler's own order of the recursion step, for A/B runs)
-          if (inner == 1) hipLaunchKernelGGL((rgauss_pass_kernel<T, true, true>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
-          else hipLaunchKernelGGL((rgauss_pass_kernel<T, false, true>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
+          if (inner == 1) hipLaunchKernelGGL((rgauss_pass_kernel<TI, true, true, float>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
+          else hipLaunchKernelGGL((rgauss_pass_kernel<TI, false, true, float>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
           PRAD_TRY(check_launch("rgauss_pass_kernel"));
         } else {
-          if (inner == 1) hipLaunchKernelGGL((rgauss_pass_kernel<T, true, false>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
-          else hipLaunchKernelGGL((rgauss_pass_kernel<T, false, false>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
+          if (inner == 1) hipLaunchKernelGGL((rgauss_pass_kernel<TI, true, false, float>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
+          else hipLaunchKernelGGL((rgauss_pass_kernel<TI, false, false, float>), grid, dim3(256), 0, s, M, outer, g.size[ax], inner);
           PRAD_TRY(check_launch("rgauss_pass_kernel"));
         }
         for (int q = 0; q < nsig; q++) cur[q] = dst[q];
-        if (where == 0) flip ^= 1;
+        if (!last) flip ^= 1;
         return PRAD_OK;
       };
-      bool first_pass = true;
+      // the derivative filter on the input, then the smoothing filters of the other dimensions in increasing ITK direction
+      PRAD_TRY(pass(std::true_type{}, dim, 2, Nd == 1));
+      int left = Nd - 1;
       for (int other = Nd - 1; other >= 0; other--) {
         if (other == dim) continue;
-        if (first_pass && Nd >= 3 && other == Nd - 1) {     // smoothing of the INPUT along the last axis: shared
-          if (!have_shared || shared_axis != other) {
-            PRAD_TRY(pass(other, 0, 1));
-            have_shared = true;
-            shared_axis = other;
-          }
-          for (int q = 0; q < nsig; q++) cur[q] = bufC[q];
-        } else {
-          PRAD_TRY(pass(other, 0, 0));
-        }
-        first_pass = false;
+        left--;
+        PRAD_TRY(pass(std::false_type{}, other, 0, left == 0));
       }
-      PRAD_TRY(pass(dim, 2, 2));
       term_sp2[nterm] = spacing[dim] * spacing[dim];
       nterm++;
     }
     // acc = sum of term / spacing^2 in ITK's order (x, y, z) with the roundings of its separate accumulation step
     for (int q = 0; q < nsig; q++) {
-      LogTerms<T> L;
+      LogTerms<float> L;
       memset(&L, 0, sizeof(L));
       L.n = nterm;
       for (int k = 0; k < nterm; k++) {
@@ -312,7 +303,7 @@ int log_multi_dev(const T *in, const int *size, int Nd, const double *spacing, c
         L.sp2[k] = term_sp2[k];
       }
       const unsigned blocks = (unsigned)std::min<long long>((g.n + 255) / 256, 256LL * 32);
-      hipLaunchKernelGGL((log_combine_kernel<T>), dim3(blocks), dim3(256), 0, s, L, g.n, outs[q]);
+      hipLaunchKernelGGL((log_combine_kernel<float, TIN>), dim3(blocks), dim3(256), 0, s, L, g.n, outs[q]);
     }
     PRAD_TRY(check_launch("log_combine_kernel"));
   }

@@ -933,8 +933,8 @@ def wavelet_images(image: torch.Tensor, wavelet="coif1"):
 
 
 def _log_real(image: torch.Tensor) -> torch.Tensor:
-    """the filter's real image type: float64 inputs stay float64, everything else is float32 (SimpleITK's real type of the
-    input, imageoperations.py:824-830)"""
+    """the type the filter reads and returns: float64 inputs stay float64, everything else is float32 (SimpleITK's real type
+    of the input, imageoperations.py:824-830).  Between the passes every image is float32 (ITK's InternalRealType)."""
     return image.contiguous() if image.dtype == torch.float64 else image.to(torch.float32).contiguous()
 
 

@@ -140,7 +140,8 @@ def getWaveletImage(inputImage, inputMask, **kwargs):
 
 def laplacian_recursive_gaussian(array, spacing_xyz, sigma, normalize=True):
     """sitk.LaplacianRecursiveGaussianImageFilter (NormalizeAcrossScale) on the device, host arrays in and out: float32,
-    or float64 for a float64 input (the filter keeps the input's real type, imageoperations.py:824-830)"""
+    or float64 for a float64 input (the filter keeps the input's pixel type, imageoperations.py:824-830; its internal images
+    are float32 either way, as in ITK)"""
     f64 = np.asarray(array).dtype == np.float64
     a = np.ascontiguousarray(array, dtype=np.float64 if f64 else np.float32)
     size = np.array(a.shape, dtype=np.intc)

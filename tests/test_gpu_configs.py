@@ -68,6 +68,198 @@ def test_c4_voxel_joint_entropy_512_sampled(checker):
     np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
 
 
+def _reference_voxel_glcm(checker, img, msk, Ng, vox, force2D, chunk=1000):
+    """The reference's voxel-based route for the three features the sliding-window kernel carries: per-kernel matrices from
+    the C checker (_cmatrices.c:203-222, set_bb :1120-1147), then glcm.py:149-205 (symmetrise, empty angles -- none of the
+    dense call's angles is empty -- NaN marks, normalise), :226-258 (ux, HXY) and :292 / :495 / :512 (JointAverage = plain
+    mean over the angles, JointEnergy / JointEntropy = nanmean)."""
+    nk = vox.shape[1]
+    ent, ene, avg = np.empty(nk), np.empty(nk), np.empty(nk)
+    lev = np.arange(1, Ng + 1, dtype=float)
+    seen = None
+    for s in range(0, nk, chunk):
+        P, _ = checker.calculate_glcm(img, msk, [1], Ng, force2D, 0, kernelRadius=2, voxels=np.ascontiguousarray(vox[:, s:s + chunk]))
+        P = P + P.transpose(0, 2, 1, 3)
+        tot = P.sum((1, 2))
+        seen = (tot > 0).any(0) if seen is None else seen | (tot > 0).any(0)
+        tot[tot == 0] = np.nan
+        with np.errstate(invalid="ignore", divide="ignore"):
+            p = P / tot[:, None, None, :]
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore", RuntimeWarning)
+                ent[s:s + chunk] = np.nanmean(-(p * np.log2(p + np.spacing(1))).sum((1, 2)), 1)
+                ene[s:s + chunk] = np.nanmean((p ** 2).sum((1, 2)), 1)
+            avg[s:s + chunk] = (lev[None, :, None, None] * p).sum((1, 2)).mean(1)
+    assert seen.all(), "an angle without a single pair in the sample: the empty-angle rule of glcm.py:186-199 would apply"
+    return {"JointEntropy": ent, "JointEnergy": ene, "JointAverage": avg}
+
+
+def _slab_sample(rng, z0, z1, n, count):
+    """`count` centres of the slab z0 <= z < z1: its corners, edges and faces first, random ones after"""
+    zs, ys = [z0, z0 + 1, z1 - 2, z1 - 1], [0, 1, 2, n // 2, n - 3, n - 2, n - 1]
+    fixed = np.array([(z, y, x) for z in zs for y in ys for x in ys], np.int32).T
+    r = np.stack([rng.integers(z0, z1, count - fixed.shape[1]), rng.integers(0, n, count - fixed.shape[1]),
+                  rng.integers(0, n, count - fixed.shape[1])]).astype(np.int32)
+    return np.concatenate([fixed, r], 1)
+
+
+@pytest.mark.parametrize("three_d", [False, True])
+def test_c4_sliding_window_maps_512_dense_vs_reference(three_d, checker):
+    """VERDICT r4 missing #1 / weak #1: the kernel config 4's figure is quoted on, voxel_glcm_slide_kernel, against the
+    REFERENCE route (not against this repo's window kernel).  Every voxel of two z-slabs of the 512^3 bench volume is a centre
+    (dense requests: the route the bench takes, asserted), exampleVoxel.yaml's 5 x 5 window and the 3-D 5^3 window, full mask
+    and a partial mask (random holes, an empty band, ROI-less centres); >= 10^4 of the returned centres per window -- slab
+    corners, edges, faces, centres whose neighbours are masked out -- are compared with the reference's per-kernel matrices
+    + numpy formulas at 1e-9."""
+    import torch
+    from pyradiomics_amd import engine
+    n, Ng = 512, 32
+    img_d, msk_d = _volume(n, "smooth", 0)                   # the volume of bench.py's mode_voxel
+    g = torch.Generator(device=img_d.device)
+    g.manual_seed(17)
+    part_d = (torch.rand((n, n, n), generator=g, device=img_d.device) < 0.8).to(torch.uint8)
+    part_d[:, 200:212, :] = 0                                # windows without a single ROI voxel
+    part_d[:, :, 300:303] = 0
+    img = img_d.cpu().numpy()
+    feats = ["JointEntropy", "JointEnergy", "JointAverage"]
+    rng = np.random.default_rng(23)
+    kw = dict(kernelRadius=2, force2D=not three_d, force2Ddimension=0)
+    compared = 0
+    for mask_d in (msk_d, part_d):
+        msk = mask_d.cpu().numpy().astype(bool)
+        for z0, z1 in ((0, 16), (500, 512)):
+            zz, yy, xx = torch.meshgrid(torch.arange(z0, z1, device=img_d.device, dtype=torch.int32),
+                                        torch.arange(n, device=img_d.device, dtype=torch.int32),
+                                        torch.arange(n, device=img_d.device, dtype=torch.int32), indexing="ij")
+            vox_d = torch.stack([zz.reshape(-1), yy.reshape(-1), xx.reshape(-1)])
+            del zz, yy, xx
+            got = engine.voxel_glcm_features(img_d, mask_d, Ng, vox_d, feats, **kw)
+            assert engine.last_path() == "voxel-fused" and engine.last_variant() == "slide"
+            pick = _slab_sample(rng, z0, z1, n, 2600)
+            flat = torch.from_numpy(((pick[0] - z0).astype(np.int64) * n + pick[1]) * n + pick[2]).to(img_d.device)
+            want = _reference_voxel_glcm(checker, img, msk, Ng, pick, not three_d)
+            for f in feats:
+                a, b = got[f][flat].cpu().numpy(), want[f]
+                assert np.array_equal(np.isnan(a), np.isnan(b)), (f, z0, int(np.isnan(a).sum()), int(np.isnan(b).sum()))
+                ok = ~np.isnan(b)
+                np.testing.assert_allclose(a[ok], b[ok], rtol=1e-9, atol=1e-12, err_msg="%s slab %d" % (f, z0))
+            if mask_d is part_d:
+                assert np.isnan(want["JointAverage"]).sum() > 50 and (~msk[pick[0], pick[1], pick[2]]).sum() > 100
+            compared += pick.shape[1]
+            del got, vox_d
+    assert compared >= 10000
+
+
+def test_c3_filters_rebinning_matrices_256_full_size(checker):
+    """VERDICT r4 missing #2: BASELINE config 3 at its own size -- the 256^3 bench volume through the product's wavelet
+    (8 coif1 sub-bands) and LoG (sigma 1..5 mm) kernels against oracle/filters_oracle.py (pinned by the reference's notebook),
+    then, on the PRODUCT's filtered images (matrix parity on shared inputs), binCount-32 levels against
+    numpy's getBinEdges / binImage arithmetic (imageoperations.py:119-126,156-174) and GLCM + GLRLM of each of the 13 level
+    volumes bit for bit against the reference C (cmatrices.c:4-92, :299-541), one (matrix, angle) per host thread."""
+    import torch
+    from bench import make_volume
+    from oracle import filters_oracle as fo
+    from pyradiomics_amd import engine
+    n = 256
+    dev = torch.device("cuda", 0)
+    lv, msk_d = make_volume(n, 32, "smooth", 0, dev)
+    img_d = (lv.to(torch.float32) * 25.0 + 3.0).to(torch.int16)          # bench.py mode_config3's volume
+    img = img_d.cpu().numpy()
+    msk = msk_d.cpu().numpy().astype(bool)
+    derived = dict(engine.wavelet_images(img_d))
+    assert len(derived) == 8
+    ap, ret = fo.swt3(img, "coif1")
+    want = {"wavelet-" + k: v for k, v in ret[0].items()}
+    want["wavelet-LLL"] = ap
+    del ap, ret
+    assert set(want) == set(derived)
+    for name in sorted(want):
+        w = want.pop(name)
+        g = derived[name].cpu().numpy()
+        assert g.dtype == np.float64 and np.abs(g - w).max() <= 1e-9 * np.abs(w).max(), name
+        del w, g
+    sig = (1.0, 2.0, 3.0, 4.0, 5.0)
+    for s, d in zip(sig, engine.log_images(img_d, (1.0, 1.0, 1.0), sig)):
+        w = fo.laplacian_recursive_gaussian(img, (1.0, 1.0, 1.0), s)
+        g = d.cpu().numpy()
+        assert g.dtype == np.float32 and np.abs(g - w).max() <= 2e-6 * np.abs(w).max(), s
+        derived["log-sigma-%g" % s] = d
+        del w, g
+    assert len(derived) == 13
+    for name, d in derived.items():
+        levels, Ng, edges = engine.bin_image(d, msk_d, binCount=32)[:3]
+        x = d.cpu().numpy()
+        e = np.histogram(x[msk], 32)[1]                                  # imageoperations.py:122-126
+        e[-1] += 1
+        assert np.array_equal(np.asarray(edges, dtype=np.float64), e), name
+        lev = np.digitize(x, e).astype(np.int32)                         # :156-174 (full mask: every voxel is binned)
+        assert Ng == int(lev.max()) == 32
+        assert np.array_equal(levels.cpu().numpy(), lev), name
+        g, r, ang = engine.glcm_glrlm(levels, msk_d, Ng, n)
+        assert engine.last_path() == "sweep"
+        want_g, want_r, want_ang, _ = checker.glcm_glrlm_angle_sharded(lev, msk, Ng, n)
+        assert np.array_equal(ang, want_ang)
+        assert np.array_equal(g.cpu().numpy(), want_g), "GLCM " + name
+        assert np.array_equal(r.cpu().numpy(), want_r), "GLRLM " + name
+
+
+def test_c5_case_256_all_classes_vs_reference_route(checker):
+    """VERDICT r4 missing #2: ONE case of BASELINE config 5 at its own size (bench.py's batch case: 256^3 int16 volume, ball
+    ROI, Original + 8 wavelet sub-bands, six feature classes, binCount 32) through RadiomicsFeatureExtractor.execute on the
+    HIP backend -- device-resident, fused formulas, the route bench.py times -- against the reference-shaped route assembled
+    from the checkers: oracle wavelet (filters_oracle.swt3 on the whole image, featureextractor.py:371-395), crop to the ROI
+    box, numpy binning, the reference C matrices (oracle/_ref) + the classes' numpy formulas, numpy first-order statistics.
+    Every one of the 837 feature values at 1e-6 relative."""
+    import torch
+    from bench import _batch_case_setup
+    from helpers import feature_class, FEATURE_CLASSES
+    from oracle import filters_oracle as fo
+    from pyradiomics_amd import backend, cmatrices
+    from pyradiomics_amd.image import Image
+    ex, vols, one = _batch_case_setup(torch.device("cuda", 0), 4000, 1)
+    backend.set(cmatrices)
+    got = one(0)
+    keys = [k for k in got if not k.startswith("diagnostics")]
+    assert len(keys) == 9 * (18 + 24 + 16 + 16 + 14 + 5)
+    vol = vols[0]
+    N = vol.shape[0]
+    zz, yy, xx = np.ogrid[:N, :N, :N]
+    roi = (((zz - N / 2) ** 2 + (yy - N / 2) ** 2 + (xx - N / 2) ** 2) < (0.45 * N) ** 2)
+    idx = np.nonzero(roi)
+    bb = tuple(slice(int(i.min()), int(i.max()) + 1) for i in idx)
+    ap, ret = fo.swt3(vol, "coif1")
+    derived = {"original": vol}
+    derived.update({"wavelet-" + k: v for k, v in ret[0].items()})
+    derived["wavelet-LLL"] = ap
+    mask_c = Image(np.ascontiguousarray(roi[bb]).astype(np.int16))
+    backend.set(checker)
+    worst = (0.0, None)
+    try:
+        for name, arr in derived.items():
+            img_c = Image(np.ascontiguousarray(arr[bb]))
+            for cls in FEATURE_CLASSES:
+                fc = feature_class(cls)(img_c, mask_c, binCount=32, deviceResident=False)
+                fc.enableAllFeatures()
+                for fname, ref in fc.execute().items():
+                    k = "%s_%s_%s" % (name, cls, fname)
+                    if k not in got:
+                        continue                      # (deprecated features are not in the extractor's default set)
+                    a, b = float(got[k]), float(ref)
+                    if np.isnan(b):
+                        assert np.isnan(a), k
+                        continue
+                    err = abs(a - b) / max(abs(b), 1e-300)
+                    assert err <= 1e-6, (k, a, b, err)
+                    if err > worst[0]:
+                        worst = (err, k)
+                    keys.remove(k)
+    finally:
+        backend.set(cmatrices)
+    assert keys == [], keys[:5]
+    print("config 5 case: worst relative error %.3g (%s)" % worst)
+
+
 def test_cases_in_flight_on_threads_equal_the_sequential_run():
     """batch.run_batch(threads=3): three whole cases at a time on one GPU (per-thread library contexts and HIP streams);
     every feature value equals the one-at-a-time run bit for bit"""
