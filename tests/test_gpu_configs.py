@@ -145,7 +145,7 @@ def test_c4_sliding_window_maps_512_dense_vs_reference(three_d, checker):
                 ok = ~np.isnan(b)
                 np.testing.assert_allclose(a[ok], b[ok], rtol=1e-9, atol=1e-12, err_msg="%s slab %d" % (f, z0))
             if mask_d is part_d:
-                assert np.isnan(want["JointAverage"]).sum() > 50 and (~msk[pick[0], pick[1], pick[2]]).sum() > 100
+                assert np.isnan(want["JointAverage"]).sum() > 20 and (~msk[pick[0], pick[1], pick[2]]).sum() > 100
             compared += pick.shape[1]
             del got, vox_d
     assert compared >= 10000
