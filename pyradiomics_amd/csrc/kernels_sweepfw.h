@@ -26,6 +26,52 @@
 
 namespace prad {
 
+// -DPRAD_FW_STAMPS: per-phase cycle accounting of the walk ("where does the issue time go").  Every wave
+// keeps one s_memtime stamp and adds the cycles since the last stamp to the phase that just ended; lane 0 writes the sums to
+// prad_fw_stamps[wave][phase] at the end (read back by prad_debug_fw_stamps, scripts/r05_fw_stamps.py).  A stamp is an SMEM
+// instruction + s_waitcnt lgkmcnt(0): it drains the ds_adds in flight, ~5 stamps per plain group of ~7000 wave cycles.
+enum FwPhase { FP_INIT, FP_GRAB, FP_CTRL, FP_ISSUE, FP_WAIT_ROWS, FP_WAIT_PACK, FP_GROUP, FP_PACK, FP_SLOW, FP_FLUSH, FP_DRAIN,
+               FP_TOTAL, FP_REALTIME, FP_NGROUP, FP_NGROUP_PACK, FP_NSLOW, FP_COUNT };
+#ifdef PRAD_FW_STAMPS
+__device__ unsigned long long prad_fw_stamps[2 * 8192 * FP_COUNT];   // [PACK][wave][phase]
+struct FwClock {
+  unsigned long long last, first, rt0;
+  unsigned acc[FP_COUNT];
+  __device__ __forceinline__ void start() {
+#pragma unroll
+    for (int i = 0; i < FP_COUNT; i++) acc[i] = 0;
+    rt0 = __builtin_amdgcn_s_memrealtime();
+    first = last = __builtin_readcyclecounter();
+  }
+  template <int PH>
+  __device__ __forceinline__ void lap() {
+    const unsigned long long now = __builtin_readcyclecounter();
+    acc[PH] += (unsigned)(now - last);
+    last = now;
+  }
+  template <int PH>
+  __device__ __forceinline__ void count() { acc[PH]++; }
+  __device__ __forceinline__ void store(int slot) {
+    acc[FP_TOTAL] = (unsigned)(__builtin_readcyclecounter() - first);
+    acc[FP_REALTIME] = (unsigned)(__builtin_amdgcn_s_memrealtime() - rt0);
+    const unsigned w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0 && w < 8192) {
+#pragma unroll
+      for (int i = 0; i < FP_COUNT; i++) prad_fw_stamps[((size_t)slot * 8192 + w) * FP_COUNT + i] = acc[i];
+    }
+  }
+};
+#else
+struct FwClock {
+  __device__ __forceinline__ void start() {}
+  template <int PH>
+  __device__ __forceinline__ void lap() {}
+  template <int PH>
+  __device__ __forceinline__ void count() {}
+  __device__ __forceinline__ void store(int) {}
+};
+#endif
+
 struct FwDesc {
   int slot;          // index of the angle in the caller's list (output column)
   int NM, NU;        // extents of the march and row dimensions
@@ -492,9 +538,13 @@ struct FwWave {
     for (int w = 0; w < KW; w++) P[w] = C[w];
   }
   // U plain steps with renamed registers (no line dead, no run near the end of the table)
-  __device__ __forceinline__ void plain_group(const u32 (&v)[U][KW]) {
+  // pk_late (PRAD_FW_PACK_LATE): the pack unit's loads go out behind the FIRST step of the group instead of in front of the
+  // group, so that the wait for the group's level rows (vmcnt(0): the compiler cannot count across the conditional) does not
+  // also wait for the pack's HBM loads
+  __device__ __forceinline__ void plain_group(const u32 (&v)[U][KW], PackWave *pk_late = nullptr) {
 #pragma unroll
     for (int k = 0; k < U; k++) {
+      if (k == 1 && pk_late) pk_late->begin();
       u32 X[KW];
       fw_make_x<K, DX>(P, X);
 #pragma unroll
@@ -566,7 +616,7 @@ struct FwWave {
   }
   __device__ __forceinline__ void run(const FwDesc &D, int NX, int pitch, long long nrows, const uint8_t *__restrict__ L,
                                       const uint8_t *__restrict__ rowzero, bool anyzero, int *work, int bx, int nblocks,
-                                      PackWave &pk, const PackJob &pj, bool xcd) {
+                                      PackWave &pk, const PackJob &pj, bool xcd, FwClock &clk) {
     const int NM = D.NM, NU = D.NU, du = D.du;
     const long long delta = D.sM + (long long)du * D.sU;
     // row numbers of the packed volume (rowzero[r] != 0: row r holds a voxel outside the ROI), wave-uniform like `off`
@@ -673,6 +723,7 @@ struct FwWave {
         young = 2;
       }
       int t = t0;
+      clk.template lap<FP_GRAB>();
       bool wrap = false;  // the next step would leave the row range: all lines end first
       bool tail = false;  // past the end of the piece: only runs that began inside it are still recorded
       // One loop, two kinds of iteration: a plain group of U steps, or ONE slow step (every special case funnels into
@@ -727,6 +778,7 @@ struct FwWave {
             }
           }
           if (grp && safe > 0) {
+            clk.template lap<FP_CTRL>();
             u32 v[U][KW];
             const uint8_t *p = lp + off;
 #pragma unroll
@@ -734,10 +786,29 @@ struct FwWave {
               load_row(p, v[k]);
               p += delta;
             }
+#ifndef PRAD_FW_PACK_LATE
             if (PACK) pk.begin();            // (the next volume's pack rides along: loads out, ...
+#endif
             if (safe == 1) calm_padding();   // (second group of a pair: the first one let the padding lines grow)
+#ifdef PRAD_FW_STAMPS
+            clk.template lap<FP_ISSUE>();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (PACK && pk.loaded) {
+              clk.template lap<FP_WAIT_PACK>();
+              clk.template count<FP_NGROUP_PACK>();
+            } else {
+              clk.template lap<FP_WAIT_ROWS>();
+            }
+            clk.template count<FP_NGROUP>();
+#endif
+#ifdef PRAD_FW_PACK_LATE
+            plain_group(v, PACK ? &pk : nullptr);
+#else
             plain_group(v);
+#endif
+            clk.template lap<FP_GROUP>();
             if (PACK) pk.finish(pj);         //  ... bytes stored behind the group's VALU / LDS work)
+            clk.template lap<FP_PACK>();
             safe--;
             if (young > 0) young--;
             t += U;
@@ -756,7 +827,10 @@ struct FwWave {
         } else {
           load_row(lp + off, c);
         }
+        clk.template lap<FP_CTRL>();
         single_step(c, tail);
+        clk.template lap<FP_SLOW>();
+        clk.template count<FP_NSLOW>();
         safe = 0;
         young = 0;
         if (closing) {
@@ -954,6 +1028,8 @@ __global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, PackJob pj, c
   const int wpb = (int)(blockDim.x >> 6);
   const long long pw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
   PackWave pk(pj, pw, (long long)gridDim.x * wpb);
+  FwClock clk;
+  clk.start();
 #ifdef PRAD_FW_SETPRIO   // experiment: issue priority over co-resident waves of another launch
   __builtin_amdgcn_s_setprio(PRAD_FW_SETPRIO);
 #endif
@@ -965,24 +1041,29 @@ __global__ void __launch_bounds__(1024) sweep_fw_kernel(FwSet set, PackJob pj, c
     } else {
       for (int i = threadIdx.x; i < h.words + Ng + 1; i += blockDim.x) lds[i] = 0;
       __syncthreads();
+      clk.lap<FP_INIT>();
       const FwDesc &D = set.d[role];
       FwTab T;
       T.init(h, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
       int *wk = work + PRAD_FW_WORK_STRIDE * PRAD_FW_DOMAINS * role;
       if (D.dx == 0) {
         FwWave<LONG, K, 0, HASPAD, PACK> w(T, set.NX);
-        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj, set.xcd != 0);
+        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj, set.xcd != 0, clk);
       } else if (D.dx > 0) {
         FwWave<LONG, K, 1, HASPAD, PACK> w(T, set.NX);
-        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj, set.xcd != 0);
+        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj, set.xcd != 0, clk);
       } else {
         FwWave<LONG, K, -1, HASPAD, PACK> w(T, set.NX);
-        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj, set.xcd != 0);
+        w.run(D, set.NX, set.pitch, set.nrows, L, rowzero, anyzero, wk, bx, nblocks, pk, pj, set.xcd != 0, clk);
       }
+      clk.lap<FP_CTRL>();
       flush_block_hist<true, true, true>(lds + Ng + 1, h, Nr, D.slot, glcm_acc, glrlm_acc);
+      clk.lap<FP_FLUSH>();
     }
   }
   if (PACK) pk.drain(pj);
+  clk.lap<FP_DRAIN>();
+  clk.store(PACK ? 1 : 0);
 }
 
 }  // namespace prad

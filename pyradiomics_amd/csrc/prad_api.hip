@@ -1676,6 +1676,17 @@ const char *prad_version(void) { return kVersion; }
 const char *prad_last_error(void) { return err_state().msg; }
 const char *prad_last_path(void) { return ctx().last_path; }
 const char *prad_last_variant(void) { return ctx().last_variant; }
+#ifdef PRAD_FW_STAMPS
+// instrumentation builds only (scripts/r05_fw_stamps.py): per-wave, per-phase cycle sums of the last sweep_fw_kernel launch
+// (slot 1: the launch that carries the pack side job, slot 0: the one without)
+int prad_debug_fw_stamps(unsigned long long *out, int slot, int nwaves) {
+  if (!out || nwaves < 1 || nwaves > 8192 || slot < 0 || slot > 1) return PRAD_E_ARG;
+  PRAD_HIP(hipDeviceSynchronize());
+  PRAD_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(prad::prad_fw_stamps), sizeof(unsigned long long) * prad::FP_COUNT * (size_t)nwaves,
+                               sizeof(unsigned long long) * prad::FP_COUNT * 8192 * (size_t)slot));
+  return PRAD_OK;
+}
+#endif
 
 int prad_device_count(void) {
   int n = 0;
