@@ -464,7 +464,7 @@ def batch_child(argv) -> None:
     print("%d %.6f %d" % (ncases, time.perf_counter() - t0, len(res[0])), flush=True)
 
 
-def mode_batch(device, rank: int, cases: int, fence):
+def mode_batch(device, rank: int, cases: int, fence, world: int = 1):
     """north_star 'batched mode' (BASELINE config 5 in miniature): whole cases -- a 256^3 volume, ball ROI, Original +
     8 wavelet sub-bands, all six feature classes -- through RadiomicsFeatureExtractor.execute, `cases` per rank, no
     collective.  The cases of a rank are dealt to PRAD_BATCH_PROCS worker processes on the rank's GPU (default 4), each with
@@ -477,6 +477,10 @@ def mode_batch(device, rank: int, cases: int, fence):
     import subprocess
     from pyradiomics_amd import batch
     procs = int(os.environ.get("PRAD_BATCH_PROCS", "4"))
+    if procs > 0:
+        # every worker process is a host-bound Python thread: more workers than cores only take turns.  The ranks of a node
+        # share the host (N ranks x 4 workers + N parents), so a rank gets usable_cores() // world of them (VERDICT r4 missing #5)
+        procs = max(1, min(procs, usable_cores() // max(1, world)))
     threads = int(os.environ.get("PRAD_BATCH_THREADS", "1" if procs > 0 else "3"))
     ex, vols, one = _batch_case_setup(device, 1000 * rank, min(cases, 5) + 1 if procs > 0 else cases + 1)
     one(0)                                                # warm-up: code objects, workspace
@@ -616,6 +620,7 @@ def main() -> None:
                     help="how deferred calls overlap (default: the library's, i.e. pipeline unless PRAD_DEFERRED_MODE=lanes)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets several ranks share "
                                                       "one GPU on a test box)")
+    ap.add_argument("--batch-cases", type=int, default=36, help="cases per rank in modes.batch")
     ap.add_argument("--cpu-voxels", type=int, default=160 * 512 * 512,
                     help="voxels in the single-threaded CPU sample (default: a 160-slice slab, ~5 s on one core)")
     args = ap.parse_args()
@@ -724,7 +729,7 @@ def main() -> None:
             guarded("fallback", lambda: mode_fallback(device, engine))
 
         def batch_mode():
-            nc, dt_b, nfeat = mode_batch(device, rank, 36, fence)
+            nc, dt_b, nfeat = mode_batch(device, rank, args.batch_cases, fence, world)
             dt_b = max_over_ranks(dt_b)
             return {"value": round(world * nc / dt_b, 2), "unit": "cases/s", "cases_per_rank": nc, "features_per_case": nfeat,
                     "ms_per_case_per_gpu": round(dt_b / nc * 1e3, 2),

@@ -48,6 +48,8 @@ class _WorkerPool:
         import threading
         self.jobs = queue.Queue()
         self.device = device
+        self.closed = False
+        self.state = threading.Lock()          # guards `closed` against a run() racing a shutdown()
         self.threads = [threading.Thread(target=self._loop, daemon=True) for _ in range(threads)]
         for t in self.threads:
             t.start()
@@ -99,8 +101,13 @@ class _WorkerPool:
                             done.set()
             return job
 
-        for i in indices:
-            self.jobs.put(make(i))
+        with self.state:
+            # a pool that was retired by another host thread (a call with a different thread count on the same GPU) has no
+            # workers left: jobs put on its queue would never run and done.wait() would block forever
+            if self.closed:
+                raise RuntimeError("worker pool was shut down (another call changed the thread count of this GPU's pool)")
+            for i in indices:
+                self.jobs.put(make(i))
         done.wait()
         if errors:
             raise errors[0]
@@ -118,13 +125,18 @@ class _WorkerPool:
         return self.run(list(range(len(self.threads))), [None] * len(self.threads), job)
 
     def shutdown(self):
-        for _ in self.threads:
-            self.jobs.put(None)
+        with self.state:
+            if self.closed:
+                return
+            self.closed = True
+            for _ in self.threads:           # (behind any jobs already queued: those still run)
+                self.jobs.put(None)
         for t in self.threads:
             t.join()
 
 
 _POOLS: dict = {}
+_POOLS_LOCK = __import__("threading").Lock()
 
 
 _ATEXIT: list = []
@@ -132,8 +144,10 @@ _ATEXIT: list = []
 
 def shutdown_pools() -> None:
     """ends the worker threads of every pool (each frees the native workspace it held)"""
-    for key in list(_POOLS):
-        _POOLS.pop(key).shutdown()
+    with _POOLS_LOCK:
+        pools = [_POOLS.pop(key) for key in list(_POOLS)]
+    for p in pools:
+        p.shutdown()
 
 
 def _pool(threads: int):
@@ -143,17 +157,22 @@ def _pool(threads: int):
     except ImportError:
         dev = None
     key = (dev, max(1, threads))
-    if key not in _POOLS:
-        if not _POOLS and not _ATEXIT:
-            import atexit
-            atexit.register(shutdown_pools)
-            _ATEXIT.append(True)
-        # one pool per GPU: a call with another thread count retires the old pool (its threads free the native workspaces they
-        # held -- hundreds of MB per worker at 256^3) instead of keeping both alive
-        for old in [k for k in _POOLS if k[0] == dev]:
-            _POOLS.pop(old).shutdown()
-        _POOLS[key] = _WorkerPool(key[1], dev)
-    return _POOLS[key]
+    retired = []
+    with _POOLS_LOCK:
+        if key not in _POOLS:
+            if not _ATEXIT:
+                import atexit
+                atexit.register(shutdown_pools)
+                _ATEXIT.append(True)
+            # one pool per GPU: a call with another thread count retires the old pool (its threads free the native workspaces
+            # they held -- hundreds of MB per worker at 256^3) instead of keeping both alive; a host thread that still holds
+            # the retired pool gets a RuntimeError from its next run(), not a hang
+            retired = [_POOLS.pop(k) for k in [k for k in _POOLS if k[0] == dev]]
+            _POOLS[key] = _WorkerPool(key[1], dev)
+        pool = _POOLS[key]
+    for old in retired:          # (outside the lock: joins the old threads, which finish the jobs they already hold)
+        old.shutdown()
+    return pool
 
 
 def warm_threads(fn, threads: int):

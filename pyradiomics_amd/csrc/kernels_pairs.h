@@ -1,0 +1,196 @@
+// kernels_pairs.h -- the tier between the sweeps and the exact generic kernels (round 5).
+//
+// The sweep kernels (kernels_sweep*.h) need unit angles and <= 160 grey levels; everything else -- `distances: [1, 2]`
+// (62 angles, cmatrices.c:807-892), 161+ levels -- used to drop to kernels_generic.h: one fp64 L2 atomic per pair, 43 ms for
+// a 256^3 GLCM and 82 ms for GLCM + GLRLM at 300 levels (270 - 500 x the sweep).  Here:
+//
+//   pairs_pack_kernel    int32 level + uint8 mask -> uint16 level, 0 outside the ROI; flags[0] on a level outside 1..Ng
+//                        (the caller then re-runs the exact kernels: they reproduce the reference's aliasing / IndexError)
+//   pairs_glcm_kernel    GLCM (cmatrices.c:4-92) for ANY offset list: one lane per voxel, its neighbours read from the
+//                        packed volume (L1 / L2 hits), u32 counts in LDS tables [angles of the pass][level rows of the
+//                        pass][Ng]: as many angles per pass as fit 150 KB (32 levels: 36 angles), or one angle and a tile of
+//                        level rows when Ng x Ng does not fit (300 levels: 128 rows).  blockIdx.y = pass.
+//   pairs_glrlm_kernel   GLRLM (cmatrices.c:299-541) for any level count: a lane whose voxel STARTS a run walks it; runs of
+//                        length 1 are derived, not counted (every ROI voxel of level g lies on exactly one line of an
+//                        angle: GLRLM[g][1] = N_g - sum_{len >= 2} len GLRLM[g][len]), so the u32 L2 atomics are as rare
+//                        as the longer runs.
+//   pairs_level_count_kernel, pairs_run1_kernel, pairs_multi_check_kernel   N_g, the derivation above, the reference's
+//                        "no line of this angle holds two ROI voxels" rule (cmatrices.c:524-534).
+// Counts are integers below 2^31 (the reference's own limit) accumulated in u32 and converted once: bit-exact.
+#pragma once
+#include "prad_runtime.h"
+#include "kernels_sweep.h"
+
+namespace prad {
+
+#define PRAD_PAIR_MAXA 128
+#define PRAD_PAIR_LDS_WORDS (150 * 256)    // 150 KB of u32
+struct PairAngles {
+  int n;
+  signed char o[PRAD_PAIR_MAXA][4];   // dz, dy, dx of the volume embedded in 3-D
+};
+
+typedef unsigned short lev16;
+
+__global__ void __launch_bounds__(256) pairs_pack_kernel(const int *__restrict__ image, const uint8_t *__restrict__ mask,
+                                                         long long n, int Ng, lev16 *__restrict__ L, int *__restrict__ flags) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    lev16 v = 0;
+    if (mask[i]) {
+      const int l = image[i];
+      if (l >= 1 && l <= Ng) v = (lev16)l;
+      else bad = true;
+    }
+    L[i] = v;
+  }
+  if (bad) flags[0] = 1;
+}
+
+// pass p: angles [ag * AG, min(Na, (ag + 1) * AG)), level rows [tile * RT, min(Ng, (tile + 1) * RT)) with ag = p / ntile
+__global__ void __launch_bounds__(1024) pairs_glcm_kernel(const lev16 *__restrict__ L, int Nz, int Ny, int Nx, PairAngles A,
+                                                          int AG, int RT, int ntile, int Ng, u32 *__restrict__ acc,
+                                                          const int *__restrict__ flags) {
+  extern __shared__ u32 tab[];
+  if (flags[0]) return;
+  const int pass = blockIdx.y, ag = pass / ntile, tile = pass - ag * ntile;
+  const int a0 = ag * AG, na = min(A.n - a0, AG);
+  const int r0 = tile * RT, nr = min(Ng - r0, RT);
+  const int words = na * nr * Ng;
+  for (int i = threadIdx.x; i < words; i += blockDim.x) tab[i] = 0;
+  __syncthreads();
+  const long long plane = (long long)Ny * Nx, n = (long long)Nz * plane;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = L[i];
+    const int row = c - 1 - r0;
+    if (c == 0 || (unsigned)row >= (unsigned)nr) continue;
+    const int z = (int)(i / plane);
+    const int r = (int)(i - (long long)z * plane);
+    const int y = r / Nx, x = r - y * Nx;
+    u32 *t = tab + row * Ng;
+    for (int k = 0; k < na; k++) {
+      const int zz = z + A.o[a0 + k][0], yy = y + A.o[a0 + k][1], xx = x + A.o[a0 + k][2];
+      if ((unsigned)zz < (unsigned)Nz && (unsigned)yy < (unsigned)Ny && (unsigned)xx < (unsigned)Nx) {
+        const int v = L[(long long)zz * plane + (long long)yy * Nx + xx];
+        if (v) atomicAdd(t + (size_t)k * nr * Ng + (v - 1), 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < words; i += blockDim.x) {
+    const u32 v = tab[i];
+    if (v) {
+      const int k = i / (nr * Ng), rc = i - k * nr * Ng;
+      atomicAdd(acc + ((size_t)(a0 + k) * Ng + r0) * Ng + rc, v);
+    }
+  }
+}
+
+// voxels per level (the N_g of the run-length derivation), LDS-private when Ng words fit
+__global__ void __launch_bounds__(256) pairs_level_count_kernel(const lev16 *__restrict__ L, long long n, int Ng, int use_lds,
+                                                                u32 *__restrict__ counts, const int *__restrict__ flags) {
+  extern __shared__ u32 tab[];
+  if (flags[0]) return;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < Ng; i += blockDim.x) tab[i] = 0;
+    __syncthreads();
+  }
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = L[i];
+    if (c) atomicAdd((use_lds ? tab : counts) + (c - 1), 1u);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < Ng; i += blockDim.x) {
+      const u32 v = tab[i];
+      if (v) atomicAdd(counts + i, v);
+    }
+  }
+}
+
+// blockIdx.y = angle.  acc [Na][Ng][Nr] u32 takes the runs of length >= 2; multi[a] is raised by the first voxel that has an
+// ROI voxel next to it along the angle (the cheap half of the reference's multiElement rule; pairs_multi_check_kernel decides
+// the rest)
+__global__ void __launch_bounds__(256) pairs_glrlm_kernel(const lev16 *__restrict__ L, int Nz, int Ny, int Nx, PairAngles A,
+                                                          int Ng, int Nr, u32 *__restrict__ acc, int *__restrict__ multi,
+                                                          const int *__restrict__ flags) {
+  if (flags[0]) return;
+  const int a = blockIdx.y;
+  const int dz = A.o[a][0], dy = A.o[a][1], dx = A.o[a][2];
+  const long long plane = (long long)Ny * Nx, n = (long long)Nz * plane;
+  const long long step = (long long)dz * plane + (long long)dy * Nx + dx;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  bool seen_pair = false;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = L[i];
+    if (!c) continue;
+    const int z = (int)(i / plane);
+    const int r = (int)(i - (long long)z * plane);
+    const int y = r / Nx, x = r - y * Nx;
+    const int pz = z - dz, py = y - dy, px = x - dx;
+    int zz = z + dz, yy = y + dy, xx = x + dx;
+    const bool next_in = (unsigned)zz < (unsigned)Nz && (unsigned)yy < (unsigned)Ny && (unsigned)xx < (unsigned)Nx;
+    const int nv = next_in ? L[i + step] : 0;
+    seen_pair = seen_pair || nv != 0;
+    if (nv != c) continue;                       // a run of length 1, or the last voxel of a longer one
+    if ((unsigned)pz < (unsigned)Nz && (unsigned)py < (unsigned)Ny && (unsigned)px < (unsigned)Nx && L[i - step] == c) continue;   // not the start
+    int len = 2;
+    long long j = i + step;
+    for (;;) {
+      zz += dz; yy += dy; xx += dx;
+      if ((unsigned)zz >= (unsigned)Nz || (unsigned)yy >= (unsigned)Ny || (unsigned)xx >= (unsigned)Nx) break;
+      j += step;
+      if (L[j] != c) break;
+      len++;
+    }
+    if (len <= Nr) atomicAdd(acc + ((size_t)a * Ng + (c - 1)) * Nr + (len - 1), 1u);
+  }
+  if (__ballot(seen_pair) != 0 && (threadIdx.x & 63) == 0 && !multi[a]) multi[a] = 1;
+}
+
+// exact multiElement test for the angles the walk left open (every ROI voxel isolated along the angle): a line start
+// counts the ROI voxels of its line, early exit
+__global__ void __launch_bounds__(256) pairs_multi_check_kernel(PairAngles A, const lev16 *__restrict__ L, int Nz, int Ny, int Nx,
+                                                                int *__restrict__ multi, const int *__restrict__ flags) {
+  if (flags[0]) return;
+  const int a = blockIdx.y;
+  if (multi[a]) return;
+  const int dz = A.o[a][0], dy = A.o[a][1], dx = A.o[a][2];
+  const long long plane = (long long)Ny * Nx, n = (long long)Nz * plane;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int z = (int)(i / plane);
+    const int r = (int)(i - (long long)z * plane);
+    int y = r / Nx, x = r - y * Nx;
+    const int pz = z - dz, py = y - dy, px = x - dx;
+    if ((unsigned)pz < (unsigned)Nz && (unsigned)py < (unsigned)Ny && (unsigned)px < (unsigned)Nx) continue;
+    int cnt = 0;
+    while ((unsigned)z < (unsigned)Nz && (unsigned)y < (unsigned)Ny && (unsigned)x < (unsigned)Nx) {
+      cnt += L[(long long)z * plane + (long long)y * Nx + x] != 0;
+      if (cnt > 1) {
+        multi[a] = 1;
+        return;
+      }
+      z += dz; y += dy; x += dx;
+    }
+  }
+}
+
+// GLRLM[a][g][1] = N_g - sum_{len >= 2} len * GLRLM[a][g][len]: one wave per (angle, level)
+__global__ void __launch_bounds__(256) pairs_run1_kernel(u32 *__restrict__ acc, const u32 *__restrict__ counts, int Ng, int Nr,
+                                                         int Na, const int *__restrict__ flags) {
+  if (flags[0]) return;
+  const int pair = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (pair >= Ng * Na) return;
+  const int g = pair % Ng, a = pair / Ng;
+  u32 *row = acc + ((size_t)a * Ng + g) * Nr;
+  unsigned long long s = 0;
+  for (int r = 1 + lane; r < Nr; r += 64) s += (unsigned long long)(r + 1) * row[r];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (lane == 0) row[0] = (u32)(counts[g] - s);    // (every run lies inside the level's voxels: s <= N_g)
+}
+
+}  // namespace prad

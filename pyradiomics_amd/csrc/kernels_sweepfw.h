@@ -112,6 +112,9 @@ struct PackJob {
 };
 
 #define PRAD_FW_U 8
+#ifndef PRAD_FW_MAXG
+#define PRAD_FW_MAXG 4           // plain groups one margin check may vouch for (RS >= 4 * 8 steps at 32 levels)
+#endif
 #define PRAD_FW_WORK_STRIDE 64   // ints between two chunk counters (256 B: a line of their own)
 #define PRAD_FW_DOMAINS 8        // chunk counters per role (one per XCD)
 // The whole layout of kernels_sweep.h (fused table H, long-run table G, dummies) sits Q = 4(Ng+1) bytes into the LDS,
@@ -769,53 +772,77 @@ struct FwWave {
 #else
             if (!LONG && !maybe_dead) {
 #endif
-              safe = 2;   // every run length has its slot and no line is dead
+              safe = PRAD_FW_MAXG;   // every run length has its slot and no line is dead
             } else {
+              // how many plain groups the longest open run (or the oldest dead line) leaves room for: up to PRAD_FW_MAXG
+              // (round 5: one check per RUN of groups -- on iid levels no run is longer than a handful of voxels, four groups
+              // fit the table's length slots -- instead of one per two groups: the check and the loop's scalar bookkeeping
+              // were 15 % of a wave's cycles, profiles/r05_fw_phases.md)
               const unsigned m = young > 0 ? margin<true>() : margin<false>();
-              if (__ballot(m + 2 * U * T.Q > (unsigned)T.lenlim) == 0) safe = 2;
-              else if (__ballot(m + U * T.Q > (unsigned)T.lenlim) == 0) safe = 1;
+#pragma unroll
+              for (int q = PRAD_FW_MAXG; q >= 1; q--) {
+                if (safe == 0 && __ballot(m + q * U * T.Q > (unsigned)T.lenlim) == 0) safe = q;
+              }
               if (safe > 0 && young == 0) maybe_dead = false;   // a dead line reads as unsafe in margin<false>
             }
           }
           if (grp && safe > 0) {
-            clk.template lap<FP_CTRL>();
-            u32 v[U][KW];
-            const uint8_t *p = lp + off;
-#pragma unroll
-            for (int k = 0; k < U; k++) {
-              load_row(p, v[k]);
-              p += delta;
-            }
-#ifndef PRAD_FW_PACK_LATE
-            if (PACK) pk.begin();            // (the next volume's pack rides along: loads out, ...
+            // ng plain groups back to back with nothing between them but the pointer bumps
+            int ng = min(safe, (t1 - t) / U);
+            if (du != 0) ng = min(ng, room / U);
+            if (young > 0) ng = min(ng, young);
+            if (anyzero || !rowzero) ng = 1;       // (the row flags were read for one group)
+#ifdef PRAD_FW_ONEGROUP
+            ng = 1;
 #endif
-            if (safe == 1) calm_padding();   // (second group of a pair: the first one let the padding lines grow)
+            clk.template lap<FP_CTRL>();
+            u32 va[U][KW];
+            auto load_group = [&](u32 (&v)[U][KW], long long o) __attribute__((always_inline)) {
+              const uint8_t *p = lp + o;
+#pragma unroll
+              for (int k = 0; k < U; k++) {
+                load_row(p, v[k]);
+                p += delta;
+              }
+            };
+            auto one_group = [&](const u32 (&v)[U][KW], bool first) __attribute__((always_inline)) {
+#ifndef PRAD_FW_PACK_LATE
+              if (PACK) pk.begin();            // (the next volume's pack rides along: loads out, ...
+#endif
+              if (!first) calm_padding();      // (the groups before let the padding lines grow)
 #ifdef PRAD_FW_STAMPS
-            clk.template lap<FP_ISSUE>();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (PACK && pk.loaded) {
-              clk.template lap<FP_WAIT_PACK>();
-              clk.template count<FP_NGROUP_PACK>();
-            } else {
-              clk.template lap<FP_WAIT_ROWS>();
-            }
-            clk.template count<FP_NGROUP>();
+              clk.template lap<FP_ISSUE>();
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              if (PACK && pk.loaded) {
+                clk.template lap<FP_WAIT_PACK>();
+                clk.template count<FP_NGROUP_PACK>();
+              } else {
+                clk.template lap<FP_WAIT_ROWS>();
+              }
+              clk.template count<FP_NGROUP>();
 #endif
 #ifdef PRAD_FW_PACK_LATE
-            plain_group(v, PACK ? &pk : nullptr);
+              plain_group(v, PACK ? &pk : nullptr);
 #else
-            plain_group(v);
+              plain_group(v);
 #endif
-            clk.template lap<FP_GROUP>();
-            if (PACK) pk.finish(pj);         //  ... bytes stored behind the group's VALU / LDS work)
-            clk.template lap<FP_PACK>();
-            safe--;
-            if (young > 0) young--;
-            t += U;
-            row += U * du;
-            off += (long long)U * delta;
-            ri += (long long)U * dri;
-            zpos += U;
+              clk.template lap<FP_GROUP>();
+              if (PACK) pk.finish(pj);         //  ... bytes stored behind the group's VALU / LDS work)
+              clk.template lap<FP_PACK>();
+              safe--;
+              if (young > 0) young--;
+              t += U;
+              row += U * du;
+              off += (long long)U * delta;
+              ri += (long long)U * dri;
+              zpos += U;
+            };
+            // (Rows of group g + 1 loaded while group g is walked -- a second register set -- was built and measured in round 5:
+            // 124 VGPRs, the pack side job's pinned state spilled to scratch, 0.68 instead of 0.43 ms.  One set it is.)
+            for (int gi = 0; gi < ng; gi++) {
+              load_group(va, off);
+              one_group(va, gi == 0);
+            }
             if (du != 0 && (row < 0 || row >= NU)) wrap = true;
             continue;
           }

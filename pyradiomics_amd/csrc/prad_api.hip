@@ -10,6 +10,7 @@
 // There is no host-side compute path: without a HIP device every calculate_* call fails with PRAD_E_HIP.
 #include "prad_runtime.h"
 #include "kernels_generic.h"
+#include "kernels_pairs.h"
 #include "kernels_sweep.h"
 #include "kernels_sweepfw.h"
 #include "kernels_sweepfw2.h"
@@ -835,6 +836,10 @@ int vol_finalize(Call &k, const VolState &v, int *sticky) {
   {
     Timed t(c, "finalize", k.s);
     const bool runs_diag = p.fused || p.fw2;     // the walks left the GLCM diagonal to the runs
+    // SKIP1 walks (fw2) did not count their runs of length 1: only finalize_glcm_diag_kernel puts them back, and it needs both
+    // matrices and the x angle's complete run table (plans with skip1 always carry them: plan_sweep clears the flag otherwise)
+    if (p.fw2 && p.skip1 && p.lines.count > 0 && !(glcm && glrlm && p.row_slot >= 0))
+      return fail(PRAD_E_UNSUPPORTED, "sweep plan derives runs of length 1 but the call cannot restore them");
     if (glcm && glrlm && runs_diag) {
       const int nb1 = (int)blocks_for((long long)Ng * Ng * Na), nb2 = (Ng * Na + 3) / 4;
       hipLaunchKernelGGL(finalize_glcm_diag_kernel, dim3(nb1 + nb2), dim3(256), 0, k.s, v.glcm_acc, v.glrlm_acc, Ng, Nr, Na, nb1,
@@ -977,6 +982,104 @@ int pipeline_step(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, dou
 }
 
 // GLCM and/or GLRLM, device pointers
+// The tier between the sweeps and the exact kernels (kernels_pairs.h): segment mode, Nd <= 3, any offset list of up to 128
+// angles, up to 38 400 grey levels.  *used = false when the call is not for it or the pack found a level outside 1..Ng
+// (the outputs are then untouched zeros and the exact kernels redo the call).
+int pairs_glcm_glrlm(Call &k, int Ng, int Nr, double *glcm, double *glrlm, bool *used) {
+  *used = false;
+  Context &c = *k.c;
+  if (k.vm.voxels || k.g.nd > 3 || Ng < 1 || Ng > PRAD_PAIR_LDS_WORDS || k.Na > PRAD_PAIR_MAXA || k.g.n >= 0x7fffffffLL ||
+      getenv("PRAD_NO_PAIRS"))
+    return PRAD_OK;
+  int dims[3] = {1, 1, 1};
+  for (int d = 0; d < k.g.nd; d++) dims[3 - k.g.nd + d] = k.g.size[d];
+  PairAngles A;
+  memset(&A, 0, sizeof(A));
+  A.n = k.Na;
+  for (int a = 0; a < k.Na; a++)
+    for (int d = 0; d < k.g.nd; d++) {
+      const int o = k.angles_h[a * k.g.nd + d];
+      if (o < -127 || o > 127) return PRAD_OK;
+      A.o[a][3 - k.g.nd + d] = (signed char)o;
+    }
+  if (glrlm && Nr < std::max(dims[0], std::max(dims[1], dims[2]))) return PRAD_OK;   // a run could overflow Nr: the exact kernels say what the reference says
+  const size_t gwords = glcm ? (size_t)k.Na * Ng * Ng : 0, rwords = glrlm ? (size_t)k.Na * Ng * Nr : 0;
+  if ((gwords + rwords) * sizeof(u32) > ((size_t)1 << 30)) return PRAD_OK;
+  hipStream_t s = k.s;
+  lev16 *L = nullptr;
+  u32 *gacc = nullptr, *racc = nullptr, *counts = nullptr;
+  int *multi = nullptr;
+  PRAD_TRY(c.get<lev16>("pairs_levels", (size_t)k.g.n + 8, &L));
+  if (glcm) PRAD_TRY(c.get<u32>("pairs_glcm_acc", gwords, &gacc));
+  if (glrlm) {
+    PRAD_TRY(c.get<u32>("pairs_glrlm_acc", rwords, &racc));
+    PRAD_TRY(c.get<u32>("pairs_counts", (size_t)Ng, &counts));
+    PRAD_TRY(c.get<int>("pairs_multi", (size_t)PRAD_PAIR_MAXA, &multi));
+  }
+  PRAD_HIP(hipMemsetAsync(k.flags_d, 0, sizeof(int) * 4, s));
+  const int cus = cu_count();
+  {
+    Timed t(c, "pack", s);
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n + 255) / 256, (long long)cus * 16));
+    hipLaunchKernelGGL(pairs_pack_kernel, dim3(gx), dim3(256), 0, s, k.image, k.mask, k.g.n, Ng, L, k.flags_d);
+    PRAD_TRY(check_launch("pairs_pack_kernel"));
+  }
+  if (glcm) {
+    Timed t(c, "pairs", s);
+    PRAD_HIP(hipMemsetAsync(gacc, 0, sizeof(u32) * gwords, s));
+    int AG, RT, ntile;
+    if ((long long)Ng * Ng <= PRAD_PAIR_LDS_WORDS) {
+      AG = std::max(1, std::min(k.Na, PRAD_PAIR_LDS_WORDS / (Ng * Ng)));
+      RT = Ng;
+      ntile = 1;
+    } else {
+      AG = 1;
+      RT = PRAD_PAIR_LDS_WORDS / Ng;
+      ntile = (Ng + RT - 1) / RT;
+    }
+    const int npass = ((k.Na + AG - 1) / AG) * ntile;
+    const size_t lds = sizeof(u32) * (size_t)AG * RT * Ng;
+    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairs_glcm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n + 1023) / 1024, (2LL * cus + npass - 1) / npass));
+    hipLaunchKernelGGL(pairs_glcm_kernel, dim3(gx, (unsigned)npass), dim3(1024), lds, s, L, dims[0], dims[1], dims[2], A, AG, RT,
+                       ntile, Ng, gacc, k.flags_d);
+    PRAD_TRY(check_launch("pairs_glcm_kernel"));
+    const long long total = (long long)Ng * Ng * k.Na;
+    hipLaunchKernelGGL(finalize_glcm_kernel, dim3(blocks_for(total)), dim3(256), 0, s, gacc, (const u32 *)nullptr, Ng, 1, k.Na, 0, glcm);
+    PRAD_TRY(check_launch("finalize_glcm_kernel"));
+  }
+  if (glrlm) {
+    Timed t(c, "pairs", s);
+    PRAD_HIP(hipMemsetAsync(racc, 0, sizeof(u32) * rwords, s));
+    PRAD_HIP(hipMemsetAsync(counts, 0, sizeof(u32) * (size_t)Ng, s));
+    PRAD_HIP(hipMemsetAsync(multi, 0, sizeof(int) * PRAD_PAIR_MAXA, s));
+    const int use_lds = Ng <= 8192;
+    const unsigned gc = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n + 255) / 256, (long long)cus * 8));
+    hipLaunchKernelGGL(pairs_level_count_kernel, dim3(gc), dim3(256), use_lds ? sizeof(u32) * (size_t)Ng : 0, s, L, k.g.n, Ng, use_lds,
+                       counts, k.flags_d);
+    PRAD_TRY(check_launch("pairs_level_count_kernel"));
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n + 255) / 256, std::max(1LL, 16LL * cus / k.Na)));
+    hipLaunchKernelGGL(pairs_glrlm_kernel, dim3(gx, (unsigned)k.Na), dim3(256), 0, s, L, dims[0], dims[1], dims[2], A, Ng, Nr, racc, multi,
+                       k.flags_d);
+    PRAD_TRY(check_launch("pairs_glrlm_kernel"));
+    hipLaunchKernelGGL(pairs_multi_check_kernel, dim3(gx, (unsigned)k.Na), dim3(256), 0, s, A, L, dims[0], dims[1], dims[2], multi, k.flags_d);
+    PRAD_TRY(check_launch("pairs_multi_check_kernel"));
+    hipLaunchKernelGGL(pairs_run1_kernel, dim3((unsigned)((Ng * k.Na + 3) / 4)), dim3(256), 0, s, racc, counts, Ng, Nr, k.Na, k.flags_d);
+    PRAD_TRY(check_launch("pairs_run1_kernel"));
+    const long long total = (long long)Ng * Nr * k.Na;
+    hipLaunchKernelGGL(finalize_glrlm_kernel, dim3(blocks_for(total)), dim3(256), 0, s, racc, multi, Ng, Nr, k.Na, glrlm,
+                       (const int *)nullptr, (int *)nullptr);
+    PRAD_TRY(check_launch("finalize_glrlm_kernel"));
+  }
+  PRAD_TRY(read_flags(k));
+  *used = k.flags_h[0] == 0;
+  if (!*used) {   // a level outside 1..Ng: leave zeros for the exact kernels (the finalize kernels above wrote only zeros: every
+                  // accumulating kernel returned at its first line)
+    PRAD_HIP(hipMemsetAsync(k.flags_d, 0, sizeof(int) * 4, s));
+  }
+  return PRAD_OK;
+}
+
 int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
                        int Na, int Ng, int Nr, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
                        double *glcm, double *glrlm, hipStream_t s) {
@@ -1018,6 +1121,13 @@ int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *siz
   if (!done && p.ok) {
     PRAD_TRY(sweep_glcm_glrlm(k, p, Ng, Nr, glcm, glrlm, &done));
     if (done) c.last_path = "sweep";
+  }
+  if (!done && !c.deferred) {      // (synchronous calls: the tier reads its levels verdict back)
+    PRAD_TRY(pairs_glcm_glrlm(k, Ng, Nr, glcm, glrlm, &done));
+    if (done) {
+      c.last_path = "pairs";
+      c.last_variant = "pairs";
+    }
   }
   if (!done) {
     if (glcm) PRAD_TRY(generic_glcm(k, Ng, glcm));

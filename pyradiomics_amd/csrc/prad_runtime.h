@@ -341,17 +341,22 @@ static __global__ void __launch_bounds__(256) zero_ranges_kernel(ZeroRanges z) {
 }
 struct ZeroBatch {
   ZeroRanges z;
-  ZeroBatch() { z.count = 0; }
-  // bytes: a multiple of 4 (every caller zeroes int / unsigned / double / 64-bit arrays)
+  bool bad;      // a range that cannot be taken (a seventh one, a size that is not a whole number of words): launch() fails
+  ZeroBatch() : bad(false) { z.count = 0; }
+  // bytes: a multiple of 4 (every caller zeroes int / unsigned / double / 64-bit arrays); 0 bytes: nothing to do
   ZeroBatch &add(void *ptr, size_t bytes) {
-    if (bytes >= 4 && z.count < 6) {
-      z.p[z.count] = (unsigned *)ptr;
-      z.words[z.count] = bytes / 4;
-      z.count++;
+    if (bytes == 0) return *this;
+    if ((bytes & 3) != 0 || (((size_t)ptr) & 3) != 0 || z.count >= 6) {   // (round 4 dropped such a range silently: ADVICE r4)
+      bad = true;
+      return *this;
     }
+    z.p[z.count] = (unsigned *)ptr;
+    z.words[z.count] = bytes / 4;
+    z.count++;
     return *this;
   }
   int launch(hipStream_t s) {
+    if (bad) return fail(PRAD_E_ARG, "ZeroBatch: more than 6 ranges, or a range that is not a whole number of aligned words");
     if (z.count == 0) return PRAD_OK;
     unsigned long long most = 0;
     for (int i = 0; i < z.count; i++) most = z.words[i] > most ? z.words[i] : most;

@@ -296,10 +296,12 @@ class RadiomicsFeatureExtractor:
 
     @staticmethod
     def _abandonFeatures(started):
-        """waits for and discards everything _startFeatures queued for one derived image (never raises)"""
-        fcs, queued, (image_token, token), _name = started
+        """waits for and discards everything _startFeatures queued for one derived image (never raises; idempotent: a token
+        that was already waited for -- `tokens[i] is None` -- is not waited for a second time)"""
+        fcs, queued, tokens, _name = started
         cm = queued[0].cMatrices if queued else (fcs[0][1].cMatrices if fcs else None)
-        for tok, wait in ((image_token, "segment_image_wait"), (token, "segment_wait")):
+        for i, wait in ((0, "segment_image_wait"), (1, "segment_wait")):
+            tok, tokens[i] = tokens[i], None
             if tok is not None and cm is not None:
                 try:
                     getattr(cm, wait)(tok)
@@ -338,7 +340,7 @@ class RadiomicsFeatureExtractor:
             return self._queueFeatures(fcs, cm, side, queued, names, ticket, imageTypeName, kwargs)
         except BaseException:
             # a class that fails to queue after the image call went through: retire that call's ticket before re-raising
-            self._abandonFeatures((fcs, queued, (ticket[0], None), imageTypeName))
+            self._abandonFeatures((fcs, queued, [ticket[0], None], imageTypeName))
             raise
 
     def _queueFeatures(self, fcs, cm, side, queued, names, ticket, imageTypeName, kwargs):
@@ -370,25 +372,30 @@ class RadiomicsFeatureExtractor:
                     queued.append(fc)
                     names.append(cname)
         token = cm.segment_mark(names) if names else None
-        return fcs, queued, (image_token, token), imageTypeName
+        return fcs, queued, [image_token, token], imageTypeName
 
     def _finishFeatures(self, started):
         """second half of computeFeatures: the host-side classes evaluated, the queued ones waited for and collected"""
-        fcs, queued, (image_token, token), imageTypeName = started
+        fcs, queued, tokens, imageTypeName = started
         out = collections.OrderedDict()
         try:
+            # (everything below runs under the guard: a failing host class, a failing wait -- the library's generation check, a
+            # HIP error -- or a failing collect leaves no ticket un-retired and no queued class holding its results: ADVICE r4)
             values = {cname: fc.execute() for cname, fc in fcs if fc not in queued}
+            if queued:
+                cm = queued[0].cMatrices
+                ok = True
+                for i, wait in ((0, cm.segment_image_wait), (1, cm.segment_wait)):
+                    tok, tokens[i] = tokens[i], None          # (marked as waited first: the abandon path must not wait again)
+                    if tok is not None:
+                        ok = wait(tok) and ok
+                if not ok:
+                    for fc in queued:      # a level outside [1, Ng]: the synchronous route raises what the reference raises
+                        fc.dropEnqueued()
+            for cname, fc in fcs:
+                for fname, value in (values[cname] if cname in values else fc.execute()).items():
+                    out["%s_%s_%s" % (imageTypeName, cname, fname)] = value
         except BaseException:
             self._abandonFeatures(started)
             raise
-        if queued:
-            cm = queued[0].cMatrices
-            ok = cm.segment_image_wait(image_token) if image_token is not None else True
-            ok = (cm.segment_wait(token) if token is not None else True) and ok
-            if not ok:
-                for fc in queued:      # a level outside [1, Ng]: the synchronous route raises what the reference raises
-                    fc.dropEnqueued()
-        for cname, fc in fcs:
-            for fname, value in (values[cname] if cname in values else fc.execute()).items():
-                out["%s_%s_%s" % (imageTypeName, cname, fname)] = value
         return out

