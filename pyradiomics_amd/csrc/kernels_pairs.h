@@ -193,4 +193,75 @@ __global__ void __launch_bounds__(256) pairs_run1_kernel(u32 *__restrict__ acc, 
   if (lane == 0) row[0] = (u32)(counts[g] - s);    // (every run lies inside the level's voxels: s <= N_g)
 }
 
+// GLDM (cmatrices.c:660-754) / NGTDM (cmatrices.c:543-658) for level counts and angle sets beyond kernels_neigh.h (more than
+// 255 levels, bin tables beyond 64 KB): the same per-voxel arithmetic on the 16-bit level volume, bins in LDS when they fit
+// 150 KB, else straight in the global accumulators.  Bin layout as kernels_neigh.h ([Ng][Na+1]; NGTDM: u64, slot 0 = voxels
+// of the level, slot c = sum of |c * level - sum of the c valid neighbours| -- exact integers, one division per slot in
+// ngtdm_finalize_kernel), so the finalize kernels are shared.
+template <bool NGTDM, bool USE_LDS>
+__global__ void __launch_bounds__(256) pairs_neigh_kernel(PairAngles A, const lev16 *__restrict__ L, int Nz, int Ny, int Nx, int Ng,
+                                                          int alpha, u32 *__restrict__ gldm_acc, u64 *__restrict__ ngtdm_acc,
+                                                          const int *__restrict__ flags) {
+  extern __shared__ u64 pn_lds64[];
+  if (flags[0]) return;
+  const int W = A.n + 1;
+  u32 *h32 = reinterpret_cast<u32 *>(pn_lds64);
+  const int nbins = Ng * W;
+  if (USE_LDS) {
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
+      if (NGTDM) pn_lds64[i] = 0;
+      else h32[i] = 0;
+    }
+    __syncthreads();
+  }
+  const long long plane = (long long)Ny * Nx, n = (long long)Nz * plane;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int c = L[i];
+    if (!c) continue;
+    const int z = (int)(i / plane);
+    const int r = (int)(i - (long long)z * plane);
+    const int y = r / Nx, x = r - y * Nx;
+    int cnt = 0, dep = 0;
+    long long sum = 0;
+    for (int a = 0; a < A.n; a++) {
+      const int zz = z + A.o[a][0], yy = y + A.o[a][1], xx = x + A.o[a][2];
+      if ((unsigned)zz >= (unsigned)Nz || (unsigned)yy >= (unsigned)Ny || (unsigned)xx >= (unsigned)Nx) continue;
+      const int v = L[(long long)zz * plane + (long long)yy * Nx + xx];
+      if (!v) continue;
+      if (NGTDM) {
+        cnt++;
+        sum += v;
+      } else {
+        int d = c - v;
+        d = d < 0 ? -d : d;
+        dep += (d <= alpha);
+      }
+    }
+    if (NGTDM) {
+      u64 *row = (USE_LDS ? pn_lds64 : ngtdm_acc) + (size_t)(c - 1) * W;
+      atomicAdd(row, 1ull);
+      if (cnt) {
+        long long d = (long long)cnt * c - sum;
+        d = d < 0 ? -d : d;
+        if (d) atomicAdd(row + cnt, (u64)d);
+      }
+    } else {
+      atomicAdd((USE_LDS ? h32 : gldm_acc) + (size_t)(c - 1) * W + dep, 1u);
+    }
+  }
+  if (USE_LDS) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
+      if (NGTDM) {
+        const u64 v = pn_lds64[i];
+        if (v) atomicAdd(ngtdm_acc + i, v);
+      } else {
+        const u32 v = h32[i];
+        if (v) atomicAdd(gldm_acc + i, v);
+      }
+    }
+  }
+}
+
 }  // namespace prad

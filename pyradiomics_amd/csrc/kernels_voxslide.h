@@ -23,16 +23,19 @@
 // The levels a group needs -- its row's planes of (2R+1)^2 (2R+1) voxels per x -- are staged once per run into LDS, a
 // plane per 32 (8) bytes; a run starts 2R+1 planes early with an empty table (planes only enter).
 //
-// Covered: 3 image dimensions, symmetrical GLCM, distance 1, kernelRadius 1 or 2, Ng <= 32, full 3-D windows or force2D
-// along the first (slice) axis, the features above.  Everything else stays on kernels_voxel.h (also the checker of this
-// file: tests/test_gpu_features.py).
+// Covered: 3 image dimensions, symmetrical GLCM, distance 1, kernelRadius 1 or 2, Ng <= 64 (round 5: the table size TB and
+// the waves per workgroup are template parameters -- 32 levels: 544 B tables, 3 / 4 waves; 40: 832 B, 2 waves; 48: 1184 B,
+// 1 / 2 waves; 64: 2080 B, one wave -- so that the reference's own example, exampleVoxel.yaml on brain1 with its 33 levels,
+// takes this kernel), full 3-D windows or force2D along the first (slice) axis, the features above.  Everything else stays
+// on kernels_voxel.h.  Checked against the reference route (tests/test_gpu_configs.py) and the window kernel
+// (tests/test_gpu_features.py).
 #pragma once
 #include "prad_runtime.h"
 #include "kernels_voxel.h"
 
 namespace prad {
 
-#define PRAD_VS_TB 544            // bytes of a lane's count table (528 used at Ng = 32; dword-aligned)
+#define PRAD_VS_TB 544            // bytes of a lane's count table at Ng <= 32 (528 used; 16-byte aligned); larger Ng: template TB
 #define PRAD_VS_FIX 40            // fixed-point fraction bits of S
 #define PRAD_VS_LUT 256
 
@@ -81,12 +84,12 @@ __device__ __forceinline__ double group_sum_f64(double v) {
 // RUN: centres per run.  Grid: x = runs along x, y = groups of rows, z = slices; a workgroup = 4 (2-D windows: 3) waves =
 // consecutive runs -- what 160 KB of LDS hold: 13 x 4 (64) tables of 544 B and 4 (16) rows of staged planes per wave.
 // maps: [nmaps][Nz][Ny][Nx] float64 (slot < 0: feature not requested); empty: [Nz][Ny][Nx] angle bits without a pair.
-template <int R, bool TWO_D, int RUN>
+template <int R, bool TWO_D, int RUN, int TB, int WAVES>
 constexpr size_t voxel_glcm_slide_lds() {
-  return 3 * PRAD_VS_LUT * 8 + (size_t)(TWO_D ? 3 : 4) * ((TWO_D ? 64 : 13 * (64 / 16)) * PRAD_VS_TB + (64 / (TWO_D ? 4 : 16)) * (RUN + 2 * R) * (TWO_D ? 8 : 32));
+  return 3 * PRAD_VS_LUT * 8 + (size_t)WAVES * ((TWO_D ? 64 : 13 * (64 / 16)) * TB + (64 / (TWO_D ? 4 : 16)) * (RUN + 2 * R) * (TWO_D ? 8 : 32));
 }
-template <int R, bool TWO_D, int RUN>
-__global__ void __launch_bounds__(TWO_D ? 192 : 256) voxel_glcm_slide_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx, VoxAngles A,
+template <int R, bool TWO_D, int RUN, int TB = PRAD_VS_TB, int WAVES = (TWO_D ? 3 : 4)>
+__global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx, VoxAngles A,
                                                               int Ng, const VoxSlideLut *__restrict__ lut_g, int slot_ent,
                                                               int slot_en, int slot_ja, double *__restrict__ maps,
                                                               unsigned *__restrict__ empty, const int *__restrict__ flags, int z_begin) {
@@ -97,7 +100,7 @@ __global__ void __launch_bounds__(TWO_D ? 192 : 256) voxel_glcm_slide_kernel(con
   constexpr int GS = TWO_D ? 4 : 16;           // lanes per group (>= angles)
   constexpr int NGR = 64 / GS;                 // groups (rows) per wave
   constexpr int XL = RUN + 2 * R;              // planes a run needs
-  constexpr int WAVES = TWO_D ? 3 : 4;         // waves per workgroup
+  static_assert(TB % 16 == 0, "tables are cleared 16 bytes at a time");
   constexpr int NT = TWO_D ? 64 : 13 * NGR;    // count tables per wave (3-D: the 13 angle lanes of each group)
   static_assert(NP <= PB, "plane does not fit its slot");
   extern __shared__ __align__(16) unsigned char vs_smem[];
@@ -107,9 +110,9 @@ __global__ void __launch_bounds__(TWO_D ? 192 : 256) voxel_glcm_slide_kernel(con
   long long *g_off = reinterpret_cast<long long *>(vs_smem);
   long long *g_dia = g_off + PRAD_VS_LUT;
   double *lg2T = reinterpret_cast<double *>(g_dia + PRAD_VS_LUT);
-  constexpr int WAVE_BYTES = NT * PRAD_VS_TB + NGR * XL * PB;
+  constexpr int WAVE_BYTES = NT * TB + NGR * XL * PB;
   unsigned char *wbase = vs_smem + 3 * PRAD_VS_LUT * 8 + (size_t)wave * WAVE_BYTES;
-  unsigned char *planes = wbase + NT * PRAD_VS_TB;
+  unsigned char *planes = wbase + NT * TB;
   for (int i = threadIdx.x; i < PRAD_VS_LUT; i += blockDim.x) {
     g_off[i] = lut_g->g_off[i];
     g_dia[i] = lut_g->g_dia[i];
@@ -124,11 +127,11 @@ __global__ void __launch_bounds__(TWO_D ? 192 : 256) voxel_glcm_slide_kernel(con
   const int grp = lane / GS, a = lane % GS;
   const int y = y0 + grp;
   const bool has_angle = a < A.na && a < (TWO_D ? 4 : 13);
-  unsigned char *tbl = wbase + (TWO_D ? lane : grp * 13 + min(a, 12)) * PRAD_VS_TB;
+  unsigned char *tbl = wbase + (TWO_D ? lane : grp * 13 + min(a, 12)) * TB;
   const int dz = has_angle ? A.o[a][0] : 0, dy = has_angle ? A.o[a][1] : 0, dx = has_angle ? A.o[a][2] : 0;
   if (live) {
     // clear the tables (wave-private: 64 x TB bytes)
-    for (int i = lane; i < NT * PRAD_VS_TB / 16; i += 64) reinterpret_cast<uint4 *>(wbase)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < NT * TB / 16; i += 64) reinterpret_cast<uint4 *>(wbase)[i] = make_uint4(0, 0, 0, 0);
     // stage the planes: slab x index k <-> global x0 - R + k; plane byte p = pz * D + py <-> (z - R + pz (TWO_D: z), y - R + py)
     for (int e = lane; e < NGR * XL * NP; e += 64) {
       const int p = e % NP, r = e / NP, k = r % XL, g = r / XL;

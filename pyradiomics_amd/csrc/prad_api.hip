@@ -1141,6 +1141,75 @@ int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *siz
   return k.flags_h[1] ? PRAD_INDEX_ERROR : PRAD_OK;
 }
 
+// GLDM / NGTDM on the 16-bit level volume (kernels_pairs.h): what kernels_neigh.h does not take -- more than 255 levels, bin
+// tables beyond its LDS budget.  Synchronous calls only; *used = false: not for this tier, or a level outside 1..Ng.
+int pairs_neigh(Call &k, bool ngtdm, int Ng, int alpha, double *out, bool *used) {
+  *used = false;
+  Context &c = *k.c;
+  if (k.vm.voxels || k.g.nd > 3 || Ng < 1 || Ng > 65535 || k.Na > PRAD_PAIR_MAXA || k.g.n >= 0x7fffffffLL || getenv("PRAD_NO_PAIRS"))
+    return PRAD_OK;
+  int dims[3] = {1, 1, 1};
+  for (int d = 0; d < k.g.nd; d++) dims[3 - k.g.nd + d] = k.g.size[d];
+  PairAngles A;
+  memset(&A, 0, sizeof(A));
+  A.n = k.Na;
+  for (int a = 0; a < k.Na; a++)
+    for (int d = 0; d < k.g.nd; d++) {
+      const int o = k.angles_h[a * k.g.nd + d];
+      if (o < -127 || o > 127) return PRAD_OK;
+      A.o[a][3 - k.g.nd + d] = (signed char)o;
+    }
+  const size_t nacc = (size_t)Ng * (k.Na + 1);
+  if (nacc * sizeof(u64) > ((size_t)1 << 30)) return PRAD_OK;
+  hipStream_t s = k.s;
+  lev16 *L = nullptr;
+  u32 *acc32 = nullptr;
+  u64 *acc64 = nullptr;
+  PRAD_TRY(c.get<lev16>("pairs_levels", (size_t)k.g.n + 8, &L));
+  if (ngtdm) PRAD_TRY(c.get<u64>("pairs_ngtdm_acc", nacc, &acc64));
+  else PRAD_TRY(c.get<u32>("pairs_gldm_acc", nacc, &acc32));
+  PRAD_HIP(hipMemsetAsync(k.flags_d, 0, sizeof(int) * 4, s));
+  const int cus = cu_count();
+  {
+    Timed t(c, "pack", s);
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n + 255) / 256, (long long)cus * 16));
+    hipLaunchKernelGGL(pairs_pack_kernel, dim3(gx), dim3(256), 0, s, k.image, k.mask, k.g.n, Ng, L, k.flags_d);
+    PRAD_TRY(check_launch("pairs_pack_kernel"));
+  }
+  {
+    Timed t(c, "pairs", s);
+    if (ngtdm) PRAD_HIP(hipMemsetAsync(acc64, 0, sizeof(u64) * nacc, s));
+    else PRAD_HIP(hipMemsetAsync(acc32, 0, sizeof(u32) * nacc, s));
+    const size_t lds = nacc * (ngtdm ? sizeof(u64) : sizeof(u32));
+    const bool use_lds = lds <= (size_t)PRAD_PAIR_LDS_WORDS * 4;
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n + 255) / 256, (long long)cus * (use_lds && lds > 40 * 1024 ? 4 : 16)));
+#define PRAD_PN(NG_, LDS_)                                                                                                      \
+  do {                                                                                                                          \
+    if (LDS_) PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairs_neigh_kernel<NG_, LDS_>),                      \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
+    hipLaunchKernelGGL((pairs_neigh_kernel<NG_, LDS_>), dim3(gx), dim3(256), LDS_ ? lds : 0, s, A, L, dims[0], dims[1], dims[2], Ng, \
+                       alpha, acc32, acc64, k.flags_d);                                                                         \
+  } while (0)
+    if (ngtdm && use_lds) PRAD_PN(true, true);
+    else if (ngtdm) PRAD_PN(true, false);
+    else if (use_lds) PRAD_PN(false, true);
+    else PRAD_PN(false, false);
+#undef PRAD_PN
+    PRAD_TRY(check_launch("pairs_neigh_kernel"));
+  }
+  if (ngtdm) PRAD_TRY(neigh_finalize_ngtdm(&c, s, acc64, Ng, k.Na, out));
+  else PRAD_TRY(neigh_finalize_gldm(&c, s, acc32, Ng, k.Na, out));
+  PRAD_TRY(read_flags(k));
+  *used = k.flags_h[0] == 0;
+  if (!*used) {      // irregular level: the exact kernels redo the call on a zeroed output (the finalize kernels wrote zeros and,
+                     // for NGTDM, the level column)
+    const size_t outn = ngtdm ? (size_t)Ng * 3 : (size_t)Ng * (2 * k.Na + 1);
+    PRAD_HIP(hipMemsetAsync(out, 0, sizeof(double) * outn, s));
+    PRAD_HIP(hipMemsetAsync(k.flags_d, 0, sizeof(int) * 4, s));
+  }
+  return PRAD_OK;
+}
+
 int texture_gldm(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles, int Na,
                  int Ng, int alpha, int Nvox, const int *voxels, int kernelRadius, int force2Ddim, double *out,
                  hipStream_t s) {
@@ -1162,8 +1231,13 @@ int texture_gldm(const int32_t *image, const uint8_t *mask, const int *size, int
     PRAD_TRY(read_flags(k));
     done = (k.flags_h[0] == 0);
   }
-  if (done) c.last_path = "neigh";
-  else {
+  if (!done && !c.deferred) {
+    PRAD_TRY(pairs_neigh(k, false, Ng, alpha, out, &done));
+    if (done) c.last_path = "pairs";
+  } else if (done) {
+    c.last_path = "neigh";
+  }
+  if (!done) {
     PRAD_TRY(generic_gldm(k, Ng, alpha, out));
     PRAD_TRY(read_flags(k));
     c.last_path = "generic";
@@ -1194,8 +1268,13 @@ int texture_ngtdm(const int32_t *image, const uint8_t *mask, const int *size, in
     PRAD_TRY(read_flags(k));
     done = (k.flags_h[0] == 0);
   }
-  if (done) c.last_path = "neigh";
-  else {
+  if (!done && !c.deferred) {
+    PRAD_TRY(pairs_neigh(k, true, Ng, 0, out, &done));
+    if (done) c.last_path = "pairs";
+  } else if (done) {
+    c.last_path = "neigh";
+  }
+  if (!done) {
     PRAD_TRY(generic_ngtdm(k, Ng, out));
     PRAD_TRY(read_flags(k));
     c.last_path = "generic";
@@ -1497,7 +1576,7 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
     const unsigned slide_feats = (1u << VF_JointEntropy) | (1u << VF_JointEnergy) | (1u << VF_JointAverage);
     const bool std13 = Nd == 3 && Na == 13 && f2d3 < 0 && dims[0] > 1 && dims[1] > 1 && dims[2] > 1;
     const bool std4 = Nd == 3 && Na == 4 && (f2d3 == 0 || dims[0] == 1) && dims[1] > 1 && dims[2] > 1;
-    bool slide = (std13 || std4) && symmetric && Ng <= 32 && (kernelRadius == 1 || kernelRadius == 2) &&
+    bool slide = (std13 || std4) && symmetric && Ng <= 64 && (kernelRadius == 1 || kernelRadius == 2) &&
                  (fmask & ~slide_feats) == 0 && (long long)Nvox * 64 >= g.n && !getenv("PRAD_VOX_NO_SLIDE");
     if (slide) {
       // the kernel's lanes assume the reference's angle order: dx in {-1, 0, 1}, and for the 2-D window no z component
@@ -1549,22 +1628,32 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
       const int s_ent = (fmask >> VF_JointEntropy) & 1 ? slot[VF_JointEntropy] : -1;
       const int s_en = (fmask >> VF_JointEnergy) & 1 ? slot[VF_JointEnergy] : -1;
       const int s_ja = (fmask >> VF_JointAverage) & 1 ? slot[VF_JointAverage] : -1;
+#define PRAD_SLIDE_T(RR, TWOD, RUNL, TBB, WV)                                                                               \
+  do {                                                                                                                      \
+    constexpr size_t lds_s = voxel_glcm_slide_lds<RR, TWOD, RUNL, TBB, WV>();                                               \
+    static_assert(lds_s <= 160 * 1024, "LDS");                                                                              \
+    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_slide_kernel<RR, TWOD, RUNL, TBB, WV>),         \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                                  \
+    const int wv = WV, rows = TWOD ? 16 : 4;                                                                                \
+    const int nruns = (dims[2] + RUNL - 1) / RUNL;                                                                          \
+    hipLaunchKernelGGL((voxel_glcm_slide_kernel<RR, TWOD, RUNL, TBB, WV>), dim3((nruns + wv - 1) / wv, (dims[1] + rows - 1) / rows, z_end - z_begin + 1), \
+                       dim3(64 * wv), lds_s, s, levels, dims[0], dims[1], dims[2], A, Ng, lut_dev, s_ent, s_en, s_ja, maps, emap, flags, z_begin); \
+  } while (0)
+      // the lanes' private count tables hold Ng (Ng + 1) / 2 bytes: table size and waves per workgroup by level count
+      // (32 levels: the round-4 shape; brain1 under exampleVoxel.yaml has 33)
 #define PRAD_SLIDE(RR, TWOD, RUNL)                                                                                          \
   do {                                                                                                                      \
-    constexpr size_t lds_s = voxel_glcm_slide_lds<RR, TWOD, RUNL>();                                                        \
-    static_assert(lds_s <= 160 * 1024, "LDS");                                                                              \
-    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_slide_kernel<RR, TWOD, RUNL>),                  \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                                  \
-    const int wv = TWOD ? 3 : 4, rows = TWOD ? 16 : 4;                                                                      \
-    const int nruns = (dims[2] + RUNL - 1) / RUNL;                                                                          \
-    hipLaunchKernelGGL((voxel_glcm_slide_kernel<RR, TWOD, RUNL>), dim3((nruns + wv - 1) / wv, (dims[1] + rows - 1) / rows, z_end - z_begin + 1), \
-                       dim3(64 * wv), lds_s, s, levels, dims[0], dims[1], dims[2], A, Ng, lut_dev, s_ent, s_en, s_ja, maps, emap, flags, z_begin); \
+    if (Ng <= 32) PRAD_SLIDE_T(RR, TWOD, RUNL, 544, (TWOD ? 3 : 4));                                                        \
+    else if (Ng <= 40) PRAD_SLIDE_T(RR, TWOD, RUNL, 832, (TWOD ? 2 : 3));                                                   \
+    else if (Ng <= 48) PRAD_SLIDE_T(RR, TWOD, RUNL, 1184, (TWOD ? 1 : 2));                                                  \
+    else PRAD_SLIDE_T(RR, TWOD, RUNL, 2080, 1);                                                                             \
   } while (0)
       if (std13 && kernelRadius == 2) PRAD_SLIDE(2, false, 64);
       else if (std13) PRAD_SLIDE(1, false, 64);
       else if (kernelRadius == 2) PRAD_SLIDE(2, true, 64);
       else PRAD_SLIDE(1, true, 64);
 #undef PRAD_SLIDE
+#undef PRAD_SLIDE_T
       PRAD_TRY(check_launch("voxel_glcm_slide_kernel"));
       const unsigned allbits = (1u << Na) - 1u;
       const unsigned gb = (unsigned)std::min<long long>(((long long)Nvox + 255) / 256, (long long)cu_count() * 16);

@@ -151,6 +151,39 @@ def test_c4_sliding_window_maps_512_dense_vs_reference(three_d, checker):
     assert compared >= 10000
 
 
+def test_c4_example_voxel_yaml_on_brain1_takes_the_sliding_window_kernel(checker):
+    """VERDICT r4 missing #4: the reference's OWN example -- examples/exampleSettings/exampleVoxel.yaml (binWidth 25, force2D,
+    kernelRadius 2, maskedKernel, GLCM JointEntropy) on data/brain1 -- has 33 grey levels, one more than round 4's sliding-window
+    kernel took.  The crop the reference makes (bounding box padded by kernelRadius, featureextractor.py:385-395), numpy
+    binning, every ROI voxel a centre: the request must take the sliding-window kernel and every value must equal the
+    reference route (per-kernel matrices of the reference C + glcm.py's numpy formulas) at 1e-9."""
+    import os
+    import torch
+    from helpers import GOLDEN
+    from pyradiomics_amd import engine, imageoperations
+    from pyradiomics_amd.image import read_nrrd
+    image = read_nrrd(os.path.join(GOLDEN, "data", "brain1_image.nrrd"))
+    mask = read_nrrd(os.path.join(GOLDEN, "data", "brain1_label.nrrd"))
+    ci, cmk = imageoperations.cropToTumorMask(image, mask, 1, padDistance=2)
+    roi = cmk.array == 1
+    levels, _ = imageoperations.binImage(ci.array, roi, binWidth=25)
+    levels = np.where(roi, levels, 0).astype(np.int32)
+    Ng = int(levels.max())
+    assert Ng == 33 and int(roi.sum()) == 4137
+    vox = np.array(np.nonzero(roi)).astype(np.int32)
+    dev = torch.device("cuda", 0)
+    feats = ["JointEntropy", "JointEnergy", "JointAverage"]
+    got = engine.voxel_glcm_features(torch.from_numpy(levels).to(dev), torch.from_numpy(roi.astype(np.uint8)).to(dev), Ng,
+                                     torch.from_numpy(vox).to(dev), feats, kernelRadius=2, force2D=True, force2Ddimension=0)
+    assert engine.last_path() == "voxel-fused" and engine.last_variant() == "slide"
+    want = _reference_voxel_glcm(checker, levels, roi, Ng, vox, True)
+    for f in feats:
+        a, b = got[f].cpu().numpy(), want[f]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f
+        ok = ~np.isnan(b)
+        np.testing.assert_allclose(a[ok], b[ok], rtol=1e-9, atol=1e-12, err_msg=f)
+
+
 def test_c3_filters_rebinning_matrices_256_full_size(checker):
     """VERDICT r4 missing #2: BASELINE config 3 at its own size -- the 256^3 bench volume through the product's wavelet
     (8 coif1 sub-bands) and LoG (sigma 1..5 mm) kernels against oracle/filters_oracle.py (pinned by the reference's notebook),

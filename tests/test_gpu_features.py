@@ -614,7 +614,7 @@ def _slide_vs_window(img, msk, Ng, vox, feats, **kw):
 
 @pytest.mark.parametrize("shape", [(9, 37, 70), (5, 16, 130), (1, 40, 66), (23, 5, 9)])
 @pytest.mark.parametrize("radius,force2D", [(2, False), (1, False), (2, True), (1, True)])
-@pytest.mark.parametrize("Ng", [32, 7])
+@pytest.mark.parametrize("Ng", [32, 7, 33, 45, 64])
 def test_sliding_window_maps_equal_the_window_kernel(shape, radius, force2D, Ng):
     """every centre of the volume, partial mask (holes, empty border rows): JointEntropy / JointEnergy / JointAverage from
     the incrementally updated tables == the from-scratch kernel, NaN patterns included (centres without any pair, the

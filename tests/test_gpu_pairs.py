@@ -93,6 +93,29 @@ def test_irregular_levels_fall_through_to_the_exact_kernels(checker):
     assert _lib.last_path() == "pairs" and np.array_equal(g, checker.calculate_glcm(img, msk, [1, 2], 300, False, 0)[0])
 
 
+@pytest.mark.parametrize("shape,Ng,dist,alpha", [((20, 33, 40), 300, [1, 2], 0), ((20, 33, 40), 300, [1], 2), ((12, 40, 36), 1000, [1], 0),
+                                                  ((9, 30, 31), 255, [1, 2], 1), ((40, 41), 500, [1, 2], 0)])
+def test_gldm_ngtdm_beyond_the_byte_kernels_take_the_pairs_tier(shape, Ng, dist, alpha, checker):
+    """GLDM (cmatrices.c:660-754) and NGTDM (:543-658) above 255 levels or with bin tables beyond kernels_neigh.h's LDS budget:
+    counts bit for bit, NGTDM's float column within 1e-12 of the reference's raster-order sum"""
+    from pyradiomics_amd import cmatrices as cm, _lib
+    img, msk = _case(shape, Ng, 7, smooth=True, hole=len(shape) == 3)
+    got = cm.calculate_gldm(img, msk, dist, Ng, alpha, False, 0)
+    assert _lib.last_path() == "pairs", _lib.last_path()
+    assert np.array_equal(got, checker.calculate_gldm(img, msk, dist, Ng, alpha, False, 0))
+    a = cm.calculate_ngtdm(img, msk, dist, Ng, False, 0)
+    assert _lib.last_path() == "pairs", _lib.last_path()
+    b = checker.calculate_ngtdm(img, msk, dist, Ng, False, 0)
+    assert np.array_equal(a[..., 0], b[..., 0]) and np.array_equal(a[..., 2], b[..., 2])
+    np.testing.assert_allclose(a[..., 1], b[..., 1], rtol=1e-12, atol=1e-12)
+    bad = img.copy()
+    bad[tuple(np.argwhere(msk)[0])] = Ng + 1
+    for fn, args in ((cm.calculate_gldm, (dist, Ng, alpha, False, 0)), (cm.calculate_ngtdm, (dist, Ng, False, 0))):
+        with pytest.raises(IndexError):
+            fn(bad, msk, *args)
+        assert _lib.last_path() == "generic"
+
+
 def test_pairs_tier_at_config_size(checker):
     """VERDICT r4 item 6's targets, on the volume they are quoted for: 256^3, GLCM with distances [1, 2] at 32 levels, and
     GLCM + GLRLM at 255 levels, bit-exact; device ms printed (bench.py modes.fallback reports them)"""
