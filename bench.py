@@ -314,16 +314,21 @@ def mode_config2(device, engine, size=256, levels=32):
 
 
 def mode_fallback(device, engine, size=256):
-    """the exact generic kernels the fast paths fall back to (kernels_generic.h, the int32 GLSZM path, the wrapped-lines
-    sweeps): distances [1, 2], 300 grey levels.  Parity of these paths is tested (tests/test_gpu_parity.py, test_gpu_fuzz.py);
-    this line gives them a number."""
+    """what the sweeps do not take: distances [1, 2], 161+ grey levels.  Until round 4 these calls ran on the exact generic
+    kernels (fp64 L2 atomics: 43 - 85 ms); round 5 put the pairs tier (kernels_pairs.h: LDS pair tables per angle group, run
+    starts walked, 16-bit levels) in between -- `path` says which one a call took.  Parity: tests/test_gpu_pairs.py,
+    test_gpu_parity.py, test_gpu_fuzz.py."""
     g = torch.Generator(device=device)
     g.manual_seed(11)
     shape = (size, size, size)
     img = torch.randint(1, 301, shape, generator=g, device=device, dtype=torch.int32)
     msk = torch.ones(shape, dtype=torch.uint8, device=device)
     n = img.numel()
-    jobs = {"glcm_d12_Ng300": lambda: engine.glcm(img, msk, 300, (1, 2)),
+    img32 = (img - 1) % 32 + 1
+    img255 = (img - 1) % 255 + 1
+    jobs = {"glcm_d12_Ng32": lambda: engine.glcm(img32, msk, 32, (1, 2)),
+            "glcm_glrlm_Ng255": lambda: engine.glcm_glrlm(img255, msk, 255, size),
+            "glcm_d12_Ng300": lambda: engine.glcm(img, msk, 300, (1, 2)),
             "glcm_glrlm_Ng300": lambda: engine.glcm_glrlm(img, msk, 300, size),
             "gldm_d12_Ng300": lambda: engine.gldm(img, msk, 300, 0, (1, 2)),
             "ngtdm_d12_Ng300": lambda: engine.ngtdm(img, msk, 300, (1, 2)),
@@ -573,6 +578,57 @@ def mode_voxel(device, rank: int, world: int, size: int, fence, three_d: bool = 
     return int(vox.shape[1]), max(dts), kms
 
 
+def mode_voxel_brain1(device, engine):
+    """the reference's own voxel example on the reference's own data: examples/exampleSettings/exampleVoxel.yaml (binWidth 25,
+    force2D, kernelRadius 2, GLCM JointEntropy) on data/brain1 (tests/golden/data: 256 x 256 x 25 int16, 4137 ROI voxels, 33 grey
+    levels after binning) -- the crop padded by kernelRadius, every ROI voxel a centre.  Wall ms of the map call (levels
+    resident) and which kernel took it; parity of exactly this request: tests/test_gpu_configs.py."""
+    from pyradiomics_amd import imageoperations
+    from pyradiomics_amd.image import read_nrrd
+    gd = os.path.join(ROOT, "tests", "golden", "data")
+    image, mask = read_nrrd(os.path.join(gd, "brain1_image.nrrd")), read_nrrd(os.path.join(gd, "brain1_label.nrrd"))
+    ci, cmk = imageoperations.cropToTumorMask(image, mask, 1, padDistance=2)
+    roi = cmk.array == 1
+    levels, _ = imageoperations.binImage(ci.array, roi, binWidth=25)
+    levels = np.where(roi, levels, 0).astype(np.int32)
+    Ng = int(levels.max())
+    vox = torch.from_numpy(np.array(np.nonzero(roi)).astype(np.int32)).to(device)
+    lv, mk = torch.from_numpy(levels).to(device), torch.from_numpy(roi.astype(np.uint8)).to(device)
+    kw = dict(kernelRadius=2, force2D=True, force2Ddimension=0)
+    engine.voxel_glcm_features(lv, mk, Ng, vox, ["JointEntropy"], **kw)
+    best = 1e9
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = engine.voxel_glcm_features(lv, mk, Ng, vox, ["JointEntropy"], **kw)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    assert bool(torch.isfinite(res["JointEntropy"]).all())
+    kms, variant = engine.last_kernel_ms("voxel"), engine.last_variant()
+    # cpu_baseline leg of this mode: the reference's route on one host core -- per-kernel matrices from the reference C
+    # (_cmatrices.c:203-222), then glcm.py:149-205 / :560-576 in numpy -- on the same 4137 kernels
+    from oracle import binding
+    cpu = binding.ref() if binding.have_ref() else binding.port()
+    vh = vox.cpu().numpy()
+    t0 = time.perf_counter()
+    ent = np.empty(vh.shape[1])
+    for lo in range(0, vh.shape[1], 1000):
+        P, _ = cpu.calculate_glcm(levels, roi, [1], Ng, True, 0, kernelRadius=2, voxels=np.ascontiguousarray(vh[:, lo:lo + 1000]))
+        P = P + P.transpose(0, 2, 1, 3)
+        tot = P.sum((1, 2))
+        tot[tot == 0] = np.nan
+        with np.errstate(invalid="ignore", divide="ignore"):
+            p = P / tot[:, None, None, :]
+            ent[lo:lo + 1000] = np.nanmean(-(p * np.log2(p + np.spacing(1))).sum((1, 2)), 1)
+    cpu_s = time.perf_counter() - t0
+    agree = bool(np.allclose(res["JointEntropy"].cpu().numpy(), ent, rtol=1e-9, atol=1e-12))
+    return {"case": "exampleVoxel.yaml on brain1: crop %s, %d centres, %d grey levels" % (tuple(levels.shape), int(vox.shape[1]), Ng),
+            "call_ms": round(best * 1e3, 4), "kernel_ms": round(kms, 4), "variant": variant,
+            "Mkernels_s": round(int(vox.shape[1]) / best / 1e6, 3),
+            "cpu_reference_route": {"kernels_s": round(vh.shape[1] / cpu_s, 1), "cores": 1, "seconds": round(cpu_s, 3),
+                                    "kind": "reference" if binding.have_ref() else "port", "agrees_1e-9": agree}}
+
+
 def host_boundary(image, mask, Ng: int, Nr: int):
     """the drop-in call itself: pageable host numpy arrays in, float64 matrices out (PCIe inclusive; never `value`)"""
     from pyradiomics_amd import cmatrices
@@ -727,6 +783,7 @@ def main() -> None:
             guarded("config2", lambda: mode_config2(device, engine))
             guarded("config3", lambda: mode_config3(device, engine))
             guarded("fallback", lambda: mode_fallback(device, engine))
+            guarded("voxel_brain1", lambda: mode_voxel_brain1(device, engine))
 
         def batch_mode():
             nc, dt_b, nfeat = mode_batch(device, rank, args.batch_cases, fence, world)
