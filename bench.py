@@ -38,9 +38,9 @@ ALG_BYTES_PER_VOXEL = 5.0       # int32 level + uint8 mask, read once (SURVEY.md
 # instruction every 2.65 cycles per SIMD (256 CUs x 4 SIMDs, 2.4 GHz).
 LDS_ATOMIC_PEAK = 256 * 2.4e9 / 4.1       # ds_add wave-instructions / s
 VALU_PEAK = 1024 * 2.4e9 / 2.65           # VALU wave-instructions / s
-# Counter figures that rocprofv3 collects (it cannot run inside bench.py): written by scripts/prof_r04.sh into this file
+# Counter figures that rocprofv3 collects (it cannot run inside bench.py): written by scripts/prof_r05.sh into this file
 # from --pmc passes over THIS bench command with the committed build; used only when the workload matches.
-PROFILED_FILE = os.path.join(ROOT, "profiles", "r04_counters.json")
+PROFILED_FILE = os.path.join(ROOT, "profiles", "r05_counters.json")
 
 
 def make_volume(size: int, levels: int, dist: str, seed: int, device) -> tuple[torch.Tensor, torch.Tensor]:
@@ -202,7 +202,7 @@ def headline_loop(engine, image, mask, Ng, Nr, steps, warmup, fence, outs, famil
     N-1; deferred_join flushes the last volume INSIDE the timed region), bracketed by fence().  Inside the timed region only
     the launches of the dominant kernel are bracketed by HIP events (family "sweep", on the stream they are launched on):
     every event record costs the stream 3 - 6 us, and ten records per step -- what the library's full timing keeps --
-    made a step 6 - 12 % slower than the product runs it (scripts/r04_event_cost.py).  The other families (pack, x angle,
+    made a step 6 - 12 % slower than the product runs it (scripts/archive/r04_event_cost.py).  The other families (pack, x angle,
     finalize, whole call) come from a second, fully instrumented pass of the same loop AFTER the timed region.
     Returns (seconds, per-family device ms per step, last outputs)."""
     state = {"n": 0, "g": None, "r": None}
@@ -476,8 +476,8 @@ def mode_batch(device, rank: int, cases: int, fence, world: int = 1):
     PRAD_BATCH_THREADS host threads (default 1) -- what `python -m pyradiomics_amd batch.csv --jobs N` does with N workers
     per GPU, and what the reference does with multiprocessing.Pool over cores (scripts/__init__.py:387-416).  A case is
     bound by its host thread (~870 HIP calls); host threads of ONE process share the runtime's locks and the GIL (the GPU
-    is busy 55 % of the time with three threads: scripts/r04_batch_busy.sh), worker processes do not: one process with
-    three threads 115 cases/s, four processes 128 (scripts/r04_batch_procs.py).  PRAD_BATCH_PROCS=0: threads of this
+    is busy 55 % of the time with three threads: scripts/archive/r04_batch_busy.sh), worker processes do not: one process with
+    three threads 115 cases/s, four processes 128 (scripts/archive/r04_batch_procs.py).  PRAD_BATCH_PROCS=0: threads of this
     process only (batch.run_batch(threads=), PRAD_BATCH_THREADS default 3 then).  Returns (cases, seconds, features per case)."""
     import subprocess
     from pyradiomics_amd import batch

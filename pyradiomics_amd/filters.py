@@ -28,6 +28,24 @@ _DEC_LO = {
     "db1": [0.7071067811865476, 0.7071067811865476],
     "db2": [-0.12940952255092145, 0.22414386804185735, 0.836516303737469, 0.48296291314469025],
     "sym2": [-0.12940952255092145, 0.22414386804185735, 0.836516303737469, 0.48296291314469025],
+    # round 5: more of PyWavelets' orthogonal families (the reference takes any pywt.Wavelet name, imageoperations.py:921).
+    # PyWavelets is not installed here: the digits are as recalled from its tables and CHECKED by the identities an
+    # orthonormal wavelet of that order must satisfy -- sum h = sqrt 2, sum h^2 = 1, double-shift orthogonality and the
+    # vanishing moments of the high-pass, all to <= 1e-11, the accuracy pywt's own tables have (tests/test_wavelet_tables.py)
+    "db3": [0.035226291882100656, -0.08544127388224149, -0.13501102001039084, 0.4598775021193313,
+            0.8068915093133388, 0.3326705529509569],
+    "sym3": [0.035226291882100656, -0.08544127388224149, -0.13501102001039084, 0.4598775021193313,
+             0.8068915093133388, 0.3326705529509569],
+    "db4": [-0.010597401784997278, 0.032883011666982945, 0.030841381835986965, -0.18703481171888114,
+            -0.02798376941698385, 0.6308807679295904, 0.7148465705525415, 0.23037781330885523],
+    "sym4": [-0.07576571478927333, -0.02963552764599851, 0.49761866763201545, 0.8037387518059161,
+             0.29785779560527736, -0.09921954357684722, -0.012603967262037833, 0.0322231006040427],
+    "db5": [0.003335725285001549, -0.012580751999015526, -0.006241490213011705, 0.07757149384006515,
+            -0.03224486958502952, -0.24229488706619015, 0.13842814590110342, 0.7243085284385744,
+            0.6038292697974729, 0.160102397974125],
+    "coif2": [-0.0007205494453645122, -0.0018232088707029932, 0.0056114348193944995, 0.023680171946334084,
+              -0.0594344186464569, -0.0764885990783064, 0.41700518442169254, 0.8127236354455423,
+              0.3861100668211622, -0.06737255472196302, -0.04146493678175915, 0.016387336463522112],
 }
 
 

@@ -24,7 +24,7 @@ rocprofv3 --kernel-trace --stats -d $O/stats_lanes -o s -- python $R/bench.py --
 rocprofv3 --kernel-trace --stats -d $O/stats_256 -o s -- python $R/bench.py --steps 20 --warmup 3 $BA --size 256 > $O/stats_256.log 2>&1
 { echo "## bench.py --size 256"; tail -1 $O/stats_256.log | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo; echo; python $R/scripts/rocpd_stats.py $O/stats_256/s_results.db | grep -E "prad|kernel \||---"; echo; } >> $O/kernel_stats.md
 rocprofv3 --kernel-trace --stats -d $O/stats_ng64 -o s -- python $R/bench.py --steps 20 --warmup 3 $BA --levels 64 > $O/stats_ng64.log 2>&1
-{ echo "## bench.py --levels 64 (two-table fixed-window kernel, 16-bit levels; deferred calls of this path run on two streams, so launches overlap and these durations are NOT kernel speeds: event-timed numbers in r05_probes.md section 16)"; tail -1 $O/stats_ng64.log | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo; echo; python $R/scripts/rocpd_stats.py $O/stats_ng64/s_results.db | grep -E "prad|kernel \||---"; echo; } >> $O/kernel_stats.md
+{ echo "## bench.py --levels 64 (two-table fixed-window kernel, 16-bit levels; deferred calls of this path run on two streams, so launches overlap and these durations are NOT kernel speeds: event-timed numbers in r04_probes.md section 16)"; tail -1 $O/stats_ng64.log | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"kernel_ms": [0-9.]*' | tr '\n' ' '; echo; echo; python $R/scripts/rocpd_stats.py $O/stats_ng64/s_results.db | grep -E "prad|kernel \||---"; echo; } >> $O/kernel_stats.md
 # the other kernels this round touched: LoG + wavelet (config 3 stages), voxel maps (config 4)
 cat > /tmp/r05_others.py <<PY
 import sys; sys.path.insert(0, "$R")
@@ -39,10 +39,19 @@ for _ in range(3):
     engine.log_images(img, (1.0, 1.0, 1.0), (1.0, 2.0, 3.0, 4.0, 5.0))
 for three_d in (False, True):
     bench.mode_voxel(dev, 0, 1, 512, torch.cuda.synchronize, three_d)
+# the pairs tier (kernels_pairs.h, round 5): GLCM distances [1, 2] at 32 levels, GLCM + GLRLM at 255 levels, GLDM / NGTDM at 300
+g = torch.Generator(device=dev); g.manual_seed(11)
+raw = torch.randint(1, 301, (256, 256, 256), generator=g, device=dev, dtype=torch.int32)
+ones = torch.ones((256, 256, 256), dtype=torch.uint8, device=dev)
+for _ in range(3):
+    engine.glcm((raw - 1) % 32 + 1, ones, 32, (1, 2))
+    engine.glcm_glrlm((raw - 1) % 255 + 1, ones, 255, 256)
+    engine.gldm(raw, ones, 300, 0, (1, 2))
+    engine.ngtdm(raw, ones, 300, (1, 2))
 torch.cuda.synchronize()
 PY
 rocprofv3 --kernel-trace --stats -d $O/stats_others -o s -- python /tmp/r05_others.py > $O/stats_others.log 2>&1
-{ echo "## filters at 256^3 (3 x wavelet_images + 3 x log_images of five sigmas) and voxel maps at 512^3 (5x5 and 5^3 windows, one map each)"; echo; python $R/scripts/rocpd_stats.py $O/stats_others/s_results.db | grep -E "prad|kernel \||---"; echo; } >> $O/kernel_stats.md
+{ echo "## filters at 256^3 (3 x wavelet_images + 3 x log_images of five sigmas) voxel maps at 512^3 (5x5 and 5^3 windows, three maps each) and the pairs tier at 256^3 (3 x GLCM d=[1,2] 32 levels, GLCM+GLRLM 255 levels, GLDM / NGTDM d=[1,2] 300 levels)"; echo; python $R/scripts/rocpd_stats.py $O/stats_others/s_results.db | grep -E "prad|kernel \||---"; echo; } >> $O/kernel_stats.md
 # PMC (separate passes, kernel-trace only)
 pass() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $O/pmc/$name -o $name -- python $R/bench.py --steps 4 --warmup 2 $BA > $O/pmc_$name.log 2>&1; }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU
