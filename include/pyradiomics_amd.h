@@ -463,7 +463,10 @@ int prad_swt_level1(const double *in, const int *size, int Nd, const double *dec
 int prad_swt_level1_dev(const double *in, const int *size, int Nd, const double *dec_lo, const double *dec_hi,
                         int flen, const int *axes, int naxes, double *out, void *stream);
 /* The same with the image in its own element type (dtype codes as prad_roi_minmax_dev: 0 float32, 1 float64, 2 int32,
- * 3 int16): the float64 copy the reference makes first (imageoperations.py:914-922) is folded into the fused 3-D kernel.
+ * 3 int16): the widening to float64 is folded into the fused 3-D kernel.  (The reference copies and pads the array,
+ * imageoperations.py:914-919, and pywt.swtn widens integer images to float64; it keeps FLOAT32 images in float32 arithmetic
+ * and returns float32 sub-bands -- here every input type is transformed in float64: for float32 images the sub-bands carry
+ * more precision than the reference's, a stated deviation)
  * PRAD_E_UNSUPPORTED when the call is not a 3-D transform over axes (2, 1, 0) with 2 / 4 / 6 taps: convert and use
  * prad_swt_level1_dev. */
 int prad_swt_level1_any_dev(const void *in, int dtype, const int *size, int Nd, const double *dec_lo,

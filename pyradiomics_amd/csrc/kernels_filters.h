@@ -98,8 +98,9 @@ __global__ void __launch_bounds__(256) swt_axis2_kernel(const double *__restrict
 // Output order as swt_level1_dev builds it for axes (2, 1, 0): band index = (bx * 2 + by) * 2 + bz.
 #define PRAD_SWT3_TY 8
 #define PRAD_SWT3_TX 32
-// TIN: the image as it is (int16 / int32 / float32 / float64): converted to float64 when staged (exact), which is what the
-// reference does before the transform (imageoperations.py:914-922 work on a float64 copy) without a pass of its own.
+// TIN: the image as it is (int16 / int32 / float32 / float64): converted to float64 when staged (exact).  pywt.swtn widens
+// integer images to float64 the same way; FLOAT32 images it transforms in float32 and returns float32 sub-bands, where this
+// kernel computes and returns float64 (more precision than the reference has: stated deviation).
 template <int F, typename TIN>
 __global__ void __launch_bounds__(256) swt3_fused_kernel(const TIN *__restrict__ x, int Nz, int Ny, int Nx, FilterTaps T,
                                                          int CZ, double *__restrict__ out) {

@@ -60,20 +60,22 @@ __global__ void __launch_bounds__(1024) pairs_glcm_kernel(const lev16 *__restric
   const int words = na * nr * Ng;
   for (int i = threadIdx.x; i < words; i += blockDim.x) tab[i] = 0;
   __syncthreads();
-  const long long plane = (long long)Ny * Nx, n = (long long)Nz * plane;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  // (the tier takes volumes below 2^31 voxels: 32-bit index arithmetic -- two 64-bit divisions per voxel visit were most of
+  // this kernel's instructions)
+  const unsigned plane = (unsigned)Ny * (unsigned)Nx, n = (unsigned)Nz * plane;
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int c = L[i];
     const int row = c - 1 - r0;
     if (c == 0 || (unsigned)row >= (unsigned)nr) continue;
-    const int z = (int)(i / plane);
-    const int r = (int)(i - (long long)z * plane);
-    const int y = r / Nx, x = r - y * Nx;
+    const unsigned zq = i / plane, r = i - zq * plane, yq = r / (unsigned)Nx;
+    const int z = (int)zq, y = (int)yq, x = (int)(r - yq * (unsigned)Nx);
     u32 *t = tab + row * Ng;
     for (int k = 0; k < na; k++) {
-      const int zz = z + A.o[a0 + k][0], yy = y + A.o[a0 + k][1], xx = x + A.o[a0 + k][2];
+      const int dz = A.o[a0 + k][0], dy = A.o[a0 + k][1], dx = A.o[a0 + k][2];
+      const int zz = z + dz, yy = y + dy, xx = x + dx;
       if ((unsigned)zz < (unsigned)Nz && (unsigned)yy < (unsigned)Ny && (unsigned)xx < (unsigned)Nx) {
-        const int v = L[(long long)zz * plane + (long long)yy * Nx + xx];
+        const int v = L[(int)i + dz * (int)plane + dy * Nx + dx];
         if (v) atomicAdd(t + (size_t)k * nr * Ng + (v - 1), 1u);
       }
     }
@@ -120,25 +122,24 @@ __global__ void __launch_bounds__(256) pairs_glrlm_kernel(const lev16 *__restric
   if (flags[0]) return;
   const int a = blockIdx.y;
   const int dz = A.o[a][0], dy = A.o[a][1], dx = A.o[a][2];
-  const long long plane = (long long)Ny * Nx, n = (long long)Nz * plane;
+  const unsigned plane = (unsigned)Ny * (unsigned)Nx, n = (unsigned)Nz * plane;      // (below 2^31 voxels: 32-bit index arithmetic)
   const long long step = (long long)dz * plane + (long long)dy * Nx + dx;
-  const long long stride = (long long)gridDim.x * blockDim.x;
+  const unsigned stride = gridDim.x * blockDim.x;
   bool seen_pair = false;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int c = L[i];
     if (!c) continue;
-    const int z = (int)(i / plane);
-    const int r = (int)(i - (long long)z * plane);
-    const int y = r / Nx, x = r - y * Nx;
+    const unsigned zq = i / plane, rq = i - zq * plane, yq = rq / (unsigned)Nx;
+    const int z = (int)zq, y = (int)yq, x = (int)(rq - yq * (unsigned)Nx);
     const int pz = z - dz, py = y - dy, px = x - dx;
     int zz = z + dz, yy = y + dy, xx = x + dx;
     const bool next_in = (unsigned)zz < (unsigned)Nz && (unsigned)yy < (unsigned)Ny && (unsigned)xx < (unsigned)Nx;
-    const int nv = next_in ? L[i + step] : 0;
+    const int nv = next_in ? L[(long long)i + step] : 0;
     seen_pair = seen_pair || nv != 0;
     if (nv != c) continue;                       // a run of length 1, or the last voxel of a longer one
-    if ((unsigned)pz < (unsigned)Nz && (unsigned)py < (unsigned)Ny && (unsigned)px < (unsigned)Nx && L[i - step] == c) continue;   // not the start
+    if ((unsigned)pz < (unsigned)Nz && (unsigned)py < (unsigned)Ny && (unsigned)px < (unsigned)Nx && L[(long long)i - step] == c) continue;   // not the start
     int len = 2;
-    long long j = i + step;
+    long long j = (long long)i + step;
     for (;;) {
       zz += dz; yy += dy; xx += dx;
       if ((unsigned)zz >= (unsigned)Nz || (unsigned)yy >= (unsigned)Ny || (unsigned)xx >= (unsigned)Nx) break;
@@ -198,36 +199,41 @@ __global__ void __launch_bounds__(256) pairs_run1_kernel(u32 *__restrict__ acc, 
 // 150 KB, else straight in the global accumulators.  Bin layout as kernels_neigh.h ([Ng][Na+1]; NGTDM: u64, slot 0 = voxels
 // of the level, slot c = sum of |c * level - sum of the c valid neighbours| -- exact integers, one division per slot in
 // ngtdm_finalize_kernel), so the finalize kernels are shared.
-template <bool NGTDM, bool USE_LDS>
-__global__ void __launch_bounds__(256) pairs_neigh_kernel(PairAngles A, const lev16 *__restrict__ L, int Nz, int Ny, int Nx, int Ng,
-                                                          int alpha, u32 *__restrict__ gldm_acc, u64 *__restrict__ ngtdm_acc,
-                                                          const int *__restrict__ flags) {
+// LDSMODE: 0 = bins in the global accumulators, 1 = bins in LDS in their own width (GLDM u32, NGTDM u64), 2 = NGTDM with u32
+// bins in LDS, widened in the flush: the caller sizes the grid so that a workgroup's sums stay below 2^32 (voxels per
+// workgroup x angles x Ng < 2^32), which halves the table (300 levels x 124 angles: 150 KB instead of 300)
+template <bool NGTDM, int LDSMODE>
+__global__ void __launch_bounds__(1024) pairs_neigh_kernel(PairAngles A, const lev16 *__restrict__ L, int Nz, int Ny, int Nx, int Ng,
+                                                           int alpha, u32 *__restrict__ gldm_acc, u64 *__restrict__ ngtdm_acc,
+                                                           const int *__restrict__ flags) {
   extern __shared__ u64 pn_lds64[];
+  constexpr bool USE_LDS = LDSMODE != 0;
+  constexpr bool BINS32 = !NGTDM || LDSMODE == 2;       // LDS bin width
   if (flags[0]) return;
   const int W = A.n + 1;
   u32 *h32 = reinterpret_cast<u32 *>(pn_lds64);
   const int nbins = Ng * W;
   if (USE_LDS) {
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
-      if (NGTDM) pn_lds64[i] = 0;
-      else h32[i] = 0;
+      if (BINS32) h32[i] = 0;
+      else pn_lds64[i] = 0;
     }
     __syncthreads();
   }
-  const long long plane = (long long)Ny * Nx, n = (long long)Nz * plane;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  const unsigned plane = (unsigned)Ny * (unsigned)Nx, n = (unsigned)Nz * plane;      // (below 2^31 voxels: 32-bit index arithmetic)
+  const unsigned stride = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int c = L[i];
     if (!c) continue;
-    const int z = (int)(i / plane);
-    const int r = (int)(i - (long long)z * plane);
-    const int y = r / Nx, x = r - y * Nx;
+    const unsigned zq = i / plane, r = i - zq * plane, yq = r / (unsigned)Nx;
+    const int z = (int)zq, y = (int)yq, x = (int)(r - yq * (unsigned)Nx);
     int cnt = 0, dep = 0;
     long long sum = 0;
     for (int a = 0; a < A.n; a++) {
-      const int zz = z + A.o[a][0], yy = y + A.o[a][1], xx = x + A.o[a][2];
+      const int dz = A.o[a][0], dy = A.o[a][1], dx = A.o[a][2];
+      const int zz = z + dz, yy = y + dy, xx = x + dx;
       if ((unsigned)zz >= (unsigned)Nz || (unsigned)yy >= (unsigned)Ny || (unsigned)xx >= (unsigned)Nx) continue;
-      const int v = L[(long long)zz * plane + (long long)yy * Nx + xx];
+      const int v = L[(int)i + dz * (int)plane + dy * Nx + dx];
       if (!v) continue;
       if (NGTDM) {
         cnt++;
@@ -239,12 +245,16 @@ __global__ void __launch_bounds__(256) pairs_neigh_kernel(PairAngles A, const le
       }
     }
     if (NGTDM) {
-      u64 *row = (USE_LDS ? pn_lds64 : ngtdm_acc) + (size_t)(c - 1) * W;
-      atomicAdd(row, 1ull);
-      if (cnt) {
-        long long d = (long long)cnt * c - sum;
-        d = d < 0 ? -d : d;
-        if (d) atomicAdd(row + cnt, (u64)d);
+      long long d = (long long)cnt * c - sum;
+      d = d < 0 ? -d : d;
+      if (USE_LDS && BINS32) {
+        u32 *row = h32 + (size_t)(c - 1) * W;
+        atomicAdd(row, 1u);
+        if (cnt && d) atomicAdd(row + cnt, (u32)d);
+      } else {
+        u64 *row = (USE_LDS ? pn_lds64 : ngtdm_acc) + (size_t)(c - 1) * W;
+        atomicAdd(row, 1ull);
+        if (cnt && d) atomicAdd(row + cnt, (u64)d);
       }
     } else {
       atomicAdd((USE_LDS ? h32 : gldm_acc) + (size_t)(c - 1) * W + dep, 1u);
@@ -254,7 +264,7 @@ __global__ void __launch_bounds__(256) pairs_neigh_kernel(PairAngles A, const le
     __syncthreads();
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
       if (NGTDM) {
-        const u64 v = pn_lds64[i];
+        const u64 v = BINS32 ? (u64)h32[i] : pn_lds64[i];
         if (v) atomicAdd(ngtdm_acc + i, v);
       } else {
         const u32 v = h32[i];

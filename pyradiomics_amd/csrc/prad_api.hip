@@ -1180,20 +1180,39 @@ int pairs_neigh(Call &k, bool ngtdm, int Ng, int alpha, double *out, bool *used)
     Timed t(c, "pairs", s);
     if (ngtdm) PRAD_HIP(hipMemsetAsync(acc64, 0, sizeof(u64) * nacc, s));
     else PRAD_HIP(hipMemsetAsync(acc32, 0, sizeof(u32) * nacc, s));
-    const size_t lds = nacc * (ngtdm ? sizeof(u64) : sizeof(u32));
-    const bool use_lds = lds <= (size_t)PRAD_PAIR_LDS_WORDS * 4;
-    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n + 255) / 256, (long long)cus * (use_lds && lds > 40 * 1024 ? 4 : 16)));
-#define PRAD_PN(NG_, LDS_)                                                                                                      \
+    // bins in LDS when they fit 150 KB: GLDM u32; NGTDM u64, or u32 with a grid fine enough that a workgroup's sums
+    // (voxels x angles x Ng at most) stay below 2^32
+    const size_t budget = (size_t)PRAD_PAIR_LDS_WORDS * 4;
+    int mode = 0;
+    size_t lds = 0;
+    if (!ngtdm) {
+      if (nacc * sizeof(u32) <= budget) { mode = 1; lds = nacc * sizeof(u32); }
+    } else if (nacc * sizeof(u64) <= budget) {
+      mode = 1; lds = nacc * sizeof(u64);
+    } else if (nacc * sizeof(u32) <= budget) {
+      mode = 2; lds = nacc * sizeof(u32);
+    }
+    // bins beyond 40 KB: one workgroup per CU, so make it a 16-wave one (4 waves per CU left the neighbour gathers
+    // latency-bound: GLDM at 300 levels x 124 angles took 7.8 ms)
+    const unsigned bt = (mode && lds > 40 * 1024) ? 1024u : 256u;
+    long long want = (long long)cus * (bt == 1024 ? 1 : 16);
+    if (mode == 2) {      // voxels per workgroup <= 2^32 / (Na * Ng) / 2
+      const long long cap = std::max<long long>(1, (1LL << 31) / ((long long)k.Na * Ng));
+      want = std::max(want, (k.g.n + cap - 1) / cap);
+    }
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n + bt - 1) / bt, want));
+#define PRAD_PN(NG_, MODE_)                                                                                                     \
   do {                                                                                                                          \
-    if (LDS_) PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairs_neigh_kernel<NG_, LDS_>),                      \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                              \
-    hipLaunchKernelGGL((pairs_neigh_kernel<NG_, LDS_>), dim3(gx), dim3(256), LDS_ ? lds : 0, s, A, L, dims[0], dims[1], dims[2], Ng, \
+    if (MODE_) PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairs_neigh_kernel<NG_, MODE_>),                    \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                             \
+    hipLaunchKernelGGL((pairs_neigh_kernel<NG_, MODE_>), dim3(gx), dim3(bt), lds, s, A, L, dims[0], dims[1], dims[2], Ng,       \
                        alpha, acc32, acc64, k.flags_d);                                                                         \
   } while (0)
-    if (ngtdm && use_lds) PRAD_PN(true, true);
-    else if (ngtdm) PRAD_PN(true, false);
-    else if (use_lds) PRAD_PN(false, true);
-    else PRAD_PN(false, false);
+    if (ngtdm && mode == 2) PRAD_PN(true, 2);
+    else if (ngtdm && mode == 1) PRAD_PN(true, 1);
+    else if (ngtdm) PRAD_PN(true, 0);
+    else if (mode == 1) PRAD_PN(false, 1);
+    else PRAD_PN(false, 0);
 #undef PRAD_PN
     PRAD_TRY(check_launch("pairs_neigh_kernel"));
   }

@@ -880,8 +880,9 @@ def voxel_firstorder(image: torch.Tensor, mask: torch.Tensor, levels, voxels: to
 
 def swt_level1(data: torch.Tensor, lo: np.ndarray, hi: np.ndarray, axes) -> torch.Tensor:
     """pywt.swtn(level=1) on the device: float64 tensor [2^len(axes), *data.shape], sub-bands in key order.  The image goes
-    in as it is when the fused 3-D kernel takes the call (its float64 copy is made while the planes are staged), as a
-    float64 copy otherwise"""
+    in as it is when the fused 3-D kernel takes the call (widened to float64 while the planes are staged), as a float64 copy
+    otherwise.  (pywt.swtn widens integer images the same way but keeps float32 images in float32: for those the sub-bands
+    here carry more precision than the reference's -- stated in DESIGN.md section 7.)"""
     lib = _lib.load()
     lib.prad_set_device(data.device.index or 0)
     size = np.array(data.shape, dtype=np.intc)

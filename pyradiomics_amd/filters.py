@@ -114,7 +114,7 @@ def _swt3_device(x, axes, **kwargs):
     start_level = kwargs.get("start_level", 0)
     shape = tuple(x.shape)
     from .engine import _DTYPE_CODES
-    data = x if x.dtype in _DTYPE_CODES else x.to(torch.float64)    # (engine.swt_level1 makes the float64 copy, or fuses it)
+    data = x if x.dtype in _DTYPE_CODES else x.to(torch.float64)    # (engine.swt_level1 widens to float64, in the fused kernel or as a copy)
     for d, n in enumerate(shape):                      # np.pad(..., 'wrap') by one sample on odd axes
         if n % 2:
             data = torch.cat([data, data.narrow(d, 0, 1)], dim=d)
