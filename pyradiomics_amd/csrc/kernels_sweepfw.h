@@ -583,7 +583,13 @@ struct FwWave {
     for (int j = 0; j < K; j++) {
       const int xj = FW_BYTE(X, j);
       unsigned a = (unsigned)(pl[j] - __mul24(xj, T.P4));   // len*Q
-      if (YOUNG) a = min(a, (unsigned)pl[j]);     // (a dead line: pl = age*Q, and a is huge)
+      // A dead line (state below alive0 although its previous level is a real one): its age in the dead zone while YOUNG,
+      // unsafe otherwise.  Said explicitly since round 5: until then a dead line read as "huge" only because the subtraction
+      // went negative -- not so for previous level 1 once the checked path has clamped the age at deadmax = 1 * P: a = 0, the
+      // line walked on on the plain path, grew into alive0 = (level 1, length 1) and its next change was recorded as a short
+      // run of level 1 (found by scripts/r05_stress.py: 138 x 58 x 300, runs of level 1 longer than RS + 1 across a piece
+      // boundary; fixture tests/golden/regress/fw_long_runs_138x58x300.npz)
+      if (pl[j] < T.alive0 && xj != 0) a = YOUNG ? (unsigned)pl[j] : 0x7fffffffu;   // (not ~0u: the callers add the groups' growth to it)
       m = max(m, a);
     }
     return m;
@@ -779,9 +785,16 @@ struct FwWave {
               // fit the table's length slots -- instead of one per two groups: the check and the loop's scalar bookkeeping
               // were 15 % of a wave's cycles, profiles/r05_fw_phases.md)
               const unsigned m = young > 0 ? margin<true>() : margin<false>();
+              // An event inside a run of n plain steps records at most len + n - 1 <= RS (the change is seen one step after
+              // the run's last voxel), but the line that LEAVES a window-filling row is closed by rotate_reg in the step of
+              // its last voxel: len + n.  Until round 5 the bound below was lenlim for both, so a run of exactly RS + 1
+              // voxels that ended at the x edge on the plain path landed in the slot of "longer than RS" -- which only the GLCM
+              // reads: lost for the GLRLM and the GLCM diagonal (found by scripts/r05_stress.py / r05_fw_bug_probe2.py on
+              // the 256- and 512-wide crops of tests/golden/regress/fw_long_runs_138x58x300.npz: two runs of level 21, length 26 = RS + 1)
+              const unsigned lim = (unsigned)T.lenlim - ((!haspad && DX != 0) ? (unsigned)T.Q : 0u);
 #pragma unroll
               for (int q = PRAD_FW_MAXG; q >= 1; q--) {
-                if (safe == 0 && __ballot(m + q * U * T.Q > (unsigned)T.lenlim) == 0) safe = q;
+                if (safe == 0 && __ballot(m + q * U * T.Q > lim) == 0) safe = q;
               }
               if (safe > 0 && young == 0) maybe_dead = false;   // a dead line reads as unsafe in margin<false>
             }
