@@ -38,3 +38,26 @@ def test_long_runs_across_pieces_and_at_the_row_edge(crop, env, checker, monkeyp
         assert np.array_equal(ang, wang)
         assert np.array_equal(r, wr), "GLRLM %s %s" % (vol.shape, env)
         assert np.array_equal(g, wg), "GLCM %s %s" % (vol.shape, env)
+
+
+def test_same_fixture_through_the_deferred_pipeline(checker):
+    """the launch bench.py times (PACK = true: volume N packed by the launch that walks volume N - 1) on the 512-wide tiling of
+    the fixture: every volume in flight bit-exact"""
+    import torch
+    from bench import headline_loop
+    from pyradiomics_amd import engine
+    d = np.load(FIX)
+    img = d["img"].astype(np.int32)[:, :, :256]
+    vol = np.ascontiguousarray(np.concatenate([img, img], axis=2))
+    Ng, Nr = int(d["Ng"]), 512
+    msk = np.ones(vol.shape, bool)
+    wg, _ = checker.calculate_glcm(vol, msk, [1], Ng, False, 0)
+    wr, _ = checker.calculate_glrlm(vol, msk, Ng, Nr, False, 0)
+    dev = torch.device("cuda", 0)
+    img_d, msk_d = torch.from_numpy(vol).to(dev), torch.from_numpy(msk.astype(np.uint8)).to(dev)
+    outs = [[None, None] for _ in range(4)]
+    headline_loop(engine, img_d, msk_d, Ng, Nr, 4, 2, torch.cuda.synchronize, outs, families=False)
+    assert engine.last_path() == "sweep"
+    for o in outs:
+        assert np.array_equal(o[0].cpu().numpy(), wg.reshape(o[0].shape)), "GLCM (deferred pipeline)"
+        assert np.array_equal(o[1].cpu().numpy(), wr.reshape(o[1].shape)), "GLRLM (deferred pipeline)"
