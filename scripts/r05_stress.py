@@ -64,7 +64,7 @@ def mask_of(shape, kind):
 t0 = time.time()
 while time.time() - t0 < budget * 0.6:
     Ng = int(rng.choice([8, 16, 32, 33, 44, 45, 64, 100, 160]))        # (45+: the two-table walk)
-    nx = int(rng.choice([128, 200, 256, 300, 511, 512]))
+    nx = int(rng.choice([128, 200, 256, 300, 511, 512, 512, 600, 1000, 1024]))        # (513..1024: the K = 16 window)
     shape = (int(rng.integers(20, 300)), int(rng.integers(9, 60)), nx)
     if rng.random() < 0.3:
         shape = (shape[1], shape[0], nx)
@@ -75,11 +75,13 @@ while time.time() - t0 < budget * 0.6:
     if not mask.any():
         mask[0, 0, 0] = True
     Nr = max(shape)
-    g, r, ang = cm.calculate_glcm_glrlm(img, mask, Ng, Nr, False, 0)
-    tag = "fw shape %s Ng %d variant %s" % (shape, Ng, _lib.last_variant() if hasattr(_lib, "last_variant") else "?")
-    assert _lib.last_path() == "sweep", tag
-    wg, wang = ck.calculate_glcm(img, mask, [1], Ng, False, 0)
-    wr, _ = ck.calculate_glrlm(img, mask, Ng, Nr, False, 0)
+    f2 = bool(rng.random() < 0.2)
+    dim = int(rng.integers(0, 3)) if f2 else 0
+    g, r, ang = cm.calculate_glcm_glrlm(img, mask, Ng, Nr, f2, dim)
+    tag = "fw shape %s Ng %d force2D %s/%d variant %s" % (shape, Ng, f2, dim, _lib.last_variant() if hasattr(_lib, "last_variant") else "?")
+    assert _lib.last_path() in ("sweep", "pairs"), tag      # (45+ levels on rows beyond 512 voxels: the pairs tier)
+    wg, wang = ck.calculate_glcm(img, mask, [1], Ng, f2, dim)
+    wr, _ = ck.calculate_glrlm(img, mask, Ng, Nr, f2, dim)
     okg, okr = np.array_equal(ang, wang) and np.array_equal(g, wg), np.array_equal(r, wr)
     if not (okg and okr):
         fails.append(tag)
