@@ -578,6 +578,32 @@ def mode_voxel(device, rank: int, world: int, size: int, fence, three_d: bool = 
     return int(vox.shape[1]), max(dts), kms
 
 
+def mode_voxel_wide(device, engine, size=256):
+    """the sliding-window kernel beyond JointEntropy (round 5): all seventeen features it carries as maps of a size^3 volume,
+    exampleVoxel.yaml window (force2D, kernelRadius 2), every voxel a centre; against the three-feature instantiation"""
+    from pyradiomics_amd.cmatrices import VOXEL_GLCM_FEATURES
+    img, msk = make_volume(size, 32, "smooth", 0, device)
+    idx = torch.arange(size, device=device, dtype=torch.int32)
+    zz, yy, xx = torch.meshgrid(idx, idx, idx, indexing="ij")
+    vox = torch.stack([zz.reshape(-1), yy.reshape(-1), xx.reshape(-1)])
+    del zz, yy, xx
+    kw = dict(kernelRadius=2, force2D=True, force2Ddimension=0)
+    not_carried = {"Correlation", "DifferenceEntropy", "SumEntropy", "Imc1", "Imc2", "MaximumProbability"}
+    wide = [f for f in VOXEL_GLCM_FEATURES if f not in not_carried]
+    out = {"case": "%d^3 volume, 5x5 window, every voxel a centre" % size}
+    for name, feats in (("three_features", ["JointEntropy", "JointEnergy", "JointAverage"]), ("seventeen_features", wide)):
+        engine.voxel_glcm_features(img, msk, 32, vox, feats, **kw)
+        assert engine.last_variant() == "slide", (name, engine.last_variant())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        engine.voxel_glcm_features(img, msk, 32, vox, feats, **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {"features": len(feats), "call_ms": round(dt * 1e3, 3), "kernel_ms": round(engine.last_kernel_ms("voxel"), 3),
+                     "Mkernels_s": round(vox.shape[1] / dt / 1e6, 1)}
+    return out
+
+
 def mode_voxel_brain1(device, engine):
     """the reference's own voxel example on the reference's own data: examples/exampleSettings/exampleVoxel.yaml (binWidth 25,
     force2D, kernelRadius 2, GLCM JointEntropy) on data/brain1 (tests/golden/data: 256 x 256 x 25 int16, 4137 ROI voxels, 33 grey
@@ -784,6 +810,7 @@ def main() -> None:
             guarded("config3", lambda: mode_config3(device, engine))
             guarded("fallback", lambda: mode_fallback(device, engine))
             guarded("voxel_brain1", lambda: mode_voxel_brain1(device, engine))
+            guarded("voxel_wide", lambda: mode_voxel_wide(device, engine))
 
         def batch_mode():
             nc, dt_b, nfeat = mode_batch(device, rank, args.batch_cases, fence, world)

@@ -39,6 +39,22 @@ namespace prad {
 #define PRAD_VS_FIX 40            // fixed-point fraction bits of S
 #define PRAD_VS_LUT 256
 
+// WIDE (round 5): fourteen more features whose sums update pair by pair -- Autocorrelation, ClusterProminence / Shade / Tendency,
+// Contrast, DifferenceAverage / Variance, Id, Idm, Idn, Idmn, InverseVariance, SumAverage, SumSquares (glcm.py:260-887).  A lane
+// additionally carries the integer sums A = sum ij, Q2 = sum (i^2 + j^2), D1 = sum |i - j|, S3 = sum (i + j)^3, S4 = sum (i + j)^4
+// over its angle's pairs and five 2^-40 fixed-point sums of g(|i - j|) (1 / (1 + k), 1 / (1 + k^2), 1 / (1 + k / Ng),
+// 1 / (1 + k^2 / Ng^2), 1 / k^2); the central moments come out of EXACT int64 expressions (P^3 S4 - 4 P^2 S1 S3 + ... fits: a
+// window of radius <= 2 holds at most 100 pairs per angle, levels <= 64), so there is no cancellation to lose digits in.
+// Not carried (they stay on kernels_voxel.h): Correlation (the reference's sigma == 0 test is a float accident), the entropies of
+// the sum / difference distributions, Imc1 / Imc2, MCC, MaximumProbability.
+#define PRAD_VS_KMAX 64
+struct VoxSlideLutK {            // g_f(k) * 2^40, f = Id, Idm, Idn, Idmn, InverseVariance (built per call: Idn / Idmn depend on Ng)
+  long long g[5][PRAD_VS_KMAX];
+};
+struct VoxSlideSlots {           // output slot of every VoxelGlcmFeature (kernels_voxel.h), -1 = not requested
+  int s[VF_COUNT];
+};
+
 struct VoxSlideLut {             // built once on the host (prad_api.hip), lives in global memory, copied to LDS per workgroup
   long long g_off[PRAD_VS_LUT];  // 2 (f(c+1) - f(c)),  f(c) = round(c log2 c * 2^40): an off-diagonal pair fills two entries
   long long g_dia[PRAD_VS_LUT];  // f(2c+2) - f(2c): a diagonal pair adds 2 to its entry
@@ -84,15 +100,18 @@ __device__ __forceinline__ double group_sum_f64(double v) {
 // RUN: centres per run.  Grid: x = runs along x, y = groups of rows, z = slices; a workgroup = 4 (2-D windows: 3) waves =
 // consecutive runs -- what 160 KB of LDS hold: 13 x 4 (64) tables of 544 B and 4 (16) rows of staged planes per wave.
 // maps: [nmaps][Nz][Ny][Nx] float64 (slot < 0: feature not requested); empty: [Nz][Ny][Nx] angle bits without a pair.
-template <int R, bool TWO_D, int RUN, int TB, int WAVES>
+template <int R, bool TWO_D, int RUN, int TB, int WAVES, bool WIDE = false>
 constexpr size_t voxel_glcm_slide_lds() {
-  return 3 * PRAD_VS_LUT * 8 + (size_t)WAVES * ((TWO_D ? 64 : 13 * (64 / 16)) * TB + (64 / (TWO_D ? 4 : 16)) * (RUN + 2 * R) * (TWO_D ? 8 : 32));
+  return 3 * PRAD_VS_LUT * 8 + (WIDE ? sizeof(VoxSlideLutK) : 0) +
+         (size_t)WAVES * ((TWO_D ? 64 : 13 * (64 / 16)) * TB + (64 / (TWO_D ? 4 : 16)) * (RUN + 2 * R) * (TWO_D ? 8 : 32));
 }
-template <int R, bool TWO_D, int RUN, int TB = PRAD_VS_TB, int WAVES = (TWO_D ? 3 : 4)>
+template <int R, bool TWO_D, int RUN, int TB = PRAD_VS_TB, int WAVES = (TWO_D ? 3 : 4), bool WIDE = false>
 __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx, VoxAngles A,
-                                                              int Ng, const VoxSlideLut *__restrict__ lut_g, int slot_ent,
-                                                              int slot_en, int slot_ja, double *__restrict__ maps,
+                                                              int Ng, const VoxSlideLut *__restrict__ lut_g,
+                                                              const VoxSlideLutK *__restrict__ lutk_g, VoxSlideSlots sl,
+                                                              double *__restrict__ maps,
                                                               unsigned *__restrict__ empty, const int *__restrict__ flags, int z_begin) {
+  const int slot_ent = sl.s[VF_JointEntropy], slot_en = sl.s[VF_JointEnergy], slot_ja = sl.s[VF_JointAverage];
   constexpr int D = 2 * R + 1;
   constexpr int PZ = TWO_D ? 1 : D;            // plane extent along z
   constexpr int NP = PZ * D;                   // voxels of a plane
@@ -111,12 +130,16 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   long long *g_dia = g_off + PRAD_VS_LUT;
   double *lg2T = reinterpret_cast<double *>(g_dia + PRAD_VS_LUT);
   constexpr int WAVE_BYTES = NT * TB + NGR * XL * PB;
-  unsigned char *wbase = vs_smem + 3 * PRAD_VS_LUT * 8 + (size_t)wave * WAVE_BYTES;
+  long long *gk = reinterpret_cast<long long *>(vs_smem + 3 * PRAD_VS_LUT * 8);      // WIDE: [5][PRAD_VS_KMAX]
+  unsigned char *wbase = vs_smem + 3 * PRAD_VS_LUT * 8 + (WIDE ? sizeof(VoxSlideLutK) : 0) + (size_t)wave * WAVE_BYTES;
   unsigned char *planes = wbase + NT * TB;
   for (int i = threadIdx.x; i < PRAD_VS_LUT; i += blockDim.x) {
     g_off[i] = lut_g->g_off[i];
     g_dia[i] = lut_g->g_dia[i];
     lg2T[i] = lut_g->lg2T[i];
+  }
+  if (WIDE) {
+    for (int i = threadIdx.x; i < 5 * PRAD_VS_KMAX; i += blockDim.x) gk[i] = lutk_g->g[i / PRAD_VS_KMAX][i % PRAD_VS_KMAX];
   }
   // this wave's run
   const int nruns = (Nx + RUN - 1) / RUN;
@@ -151,6 +174,9 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   const int qoff = dz * D + dy;                          // byte offset of q relative to p inside a plane
   long long S = 0;
   int nnz = 0, E2 = 0, P = 0, IJ = 0;
+  int wA = 0, wQ2 = 0, wD1 = 0, wS3 = 0;            // WIDE: sum ij, sum (i^2 + j^2), sum |i - j|, sum (i + j)^3
+  long long wS4 = 0, wF0 = 0, wF1 = 0, wF2 = 0, wF3 = 0, wF4 = 0;
+  const bool wantF = WIDE && (sl.s[VF_Id] >= 0 || sl.s[VF_Idm] >= 0 || sl.s[VF_Idn] >= 0 || sl.s[VF_Idmn] >= 0 || sl.s[VF_InverseVariance] >= 0);
   // The pairs between plane kp (the p side) and plane kq (the q side) enter (SIGN = +1) or leave (-1) this lane's table.
   // Straight-line code in four stages per chunk of positions -- level reads, table atomics, LUT reads, accumulation -- with
   // predication instead of branches: a pair at a time under its own branch left every LDS round trip exposed (three per
@@ -219,6 +245,21 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
           const int one = ok[k] ? 1 : 0, ij = ok[k] ? l1[k] + l2[k] : 0;
           if (SIGN > 0) { S += gg; E2 += e2; nnz += nz; P += one; IJ += ij; }
           else { S -= gg; E2 -= e2; nnz -= nz; P -= one; IJ -= ij; }
+          if (WIDE) {
+            const int i1 = ok[k] ? l1[k] : 0, j1 = ok[k] ? l2[k] : 0;
+            const int kd = i1 > j1 ? i1 - j1 : j1 - i1, sm = i1 + j1, sm2 = sm * sm;
+            const int a = i1 * j1, q2 = i1 * i1 + j1 * j1, s3 = sm2 * sm;
+            const long long s4 = (long long)sm2 * sm2;
+            if (SIGN > 0) { wA += a; wQ2 += q2; wD1 += kd; wS3 += s3; wS4 += s4; }
+            else { wA -= a; wQ2 -= q2; wD1 -= kd; wS3 -= s3; wS4 -= s4; }
+            if (wantF) {                                     // (wave-uniform)
+              const int kk = min(kd, PRAD_VS_KMAX - 1);
+              const long long f0 = ok[k] ? gk[kk] : 0, f1 = ok[k] ? gk[PRAD_VS_KMAX + kk] : 0, f2 = ok[k] ? gk[2 * PRAD_VS_KMAX + kk] : 0,
+                              f3 = ok[k] ? gk[3 * PRAD_VS_KMAX + kk] : 0, f4 = ok[k] ? gk[4 * PRAD_VS_KMAX + kk] : 0;
+              if (SIGN > 0) { wF0 += f0; wF1 += f1; wF2 += f2; wF3 += f3; wF4 += f4; }
+              else { wF0 -= f0; wF1 -= f1; wF2 -= f2; wF3 -= f3; wF4 -= f4; }
+            }
+          }
         }
       }
     }
@@ -255,12 +296,40 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
     if (slot_ent >= 0) h = group_sum_f64<GS>(h) * inv;
     if (slot_en >= 0) en = group_sum_f64<GS>(en) * inv;
     if (slot_ja >= 0) ja = group_sum_f64<GS>(ja) * inv;
-    if (a == 0 && y < Ny && gx < Nx) {
-      const long long vi = ((long long)z * Ny + y) * Nx + gx, n = (long long)Nz * Ny * Nx;
-      if (slot_ent >= 0) maps[(long long)slot_ent * n + vi] = h;
-      if (slot_en >= 0) maps[(long long)slot_en * n + vi] = en;
-      if (slot_ja >= 0) maps[(long long)slot_ja * n + vi] = ja;
+    const bool writer = a == 0 && y < Ny && gx < Nx;
+    const long long vi = ((long long)z * Ny + y) * Nx + gx, nmap = (long long)Nz * Ny * Nx;
+    if (writer) {
+      if (slot_ent >= 0) maps[(long long)slot_ent * nmap + vi] = h;
+      if (slot_en >= 0) maps[(long long)slot_en * nmap + vi] = en;
+      if (slot_ja >= 0) maps[(long long)slot_ja * nmap + vi] = ja;
       empty[vi] = (unsigned)em;
+    }
+    if (WIDE) {
+      // per angle (P pairs, T = 2 P entries, symmetric matrix): every expression below is the reference's sum over the
+      // normalised matrix written in the pair sums; integer numerators are exact
+      const double dP = (double)pc, iP = 1.0 / dP, iP2 = iP * iP;
+      const long long lP = pc, S1 = IJ, S2 = (long long)wQ2 + 2LL * wA, D2 = (long long)wQ2 - 2LL * wA;
+      auto put = [&](int f, double v) __attribute__((always_inline)) {
+        const int slot = sl.s[f];
+        if (slot < 0) return;                                   // (wave-uniform)
+        const double m = group_sum_f64<GS>(nonempty ? v : 0.0) * inv;
+        if (writer) maps[(long long)slot * nmap + vi] = m;
+      };
+      put(VF_Autocorrelation, (double)wA * iP);
+      put(VF_SumAverage, (double)IJ * iP);
+      put(VF_Contrast, (double)D2 * iP);
+      put(VF_DifferenceAverage, (double)wD1 * iP);
+      put(VF_DifferenceVariance, (double)(lP * D2 - (long long)wD1 * wD1) * iP2);
+      put(VF_SumSquares, (double)(2LL * lP * wQ2 - S1 * S1) * 0.25 * iP2);                 // (T Q2 - IJ^2) / T^2
+      put(VF_ClusterTendency, (double)(lP * S2 - S1 * S1) * iP2);
+      put(VF_ClusterShade, (double)(lP * lP * wS3 - 3LL * lP * S1 * S2 + 2LL * S1 * S1 * S1) * iP2 * iP);
+      put(VF_ClusterProminence,
+          (double)(lP * lP * lP * wS4 - 4LL * lP * lP * S1 * wS3 + 6LL * lP * S1 * S1 * S2 - 3LL * S1 * S1 * S1 * S1) * iP2 * iP2);
+      put(VF_Id, (double)wF0 * fix * iP);
+      put(VF_Idm, (double)wF1 * fix * iP);
+      put(VF_Idn, (double)wF2 * fix * iP);
+      put(VF_Idmn, (double)wF3 * fix * iP);
+      put(VF_InverseVariance, (double)wF4 * fix * iP);
     }
   }
 }

@@ -1592,7 +1592,14 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
       if (d != f2d3 && d >= 3 - Nd) wmax *= std::min(2 * kernelRadius + 1, dims[d]);
     // Sliding-window maps (kernels_voxslide.h): a dense map of the whole volume, the requested centres gathered from it.
     // Taken when the request is what that kernel covers and the centres are dense enough to pay for a whole-volume map.
-    const unsigned slide_feats = (1u << VF_JointEntropy) | (1u << VF_JointEnergy) | (1u << VF_JointAverage);
+    const unsigned slide_base = (1u << VF_JointEntropy) | (1u << VF_JointEnergy) | (1u << VF_JointAverage);
+    // round 5: fourteen more features with pair-by-pair sums (kernels_voxslide.h WIDE)
+    const unsigned slide_wide = (1u << VF_Autocorrelation) | (1u << VF_ClusterProminence) | (1u << VF_ClusterShade) |
+                                (1u << VF_ClusterTendency) | (1u << VF_Contrast) | (1u << VF_DifferenceAverage) |
+                                (1u << VF_DifferenceVariance) | (1u << VF_Id) | (1u << VF_Idm) | (1u << VF_Idn) | (1u << VF_Idmn) |
+                                (1u << VF_InverseVariance) | (1u << VF_SumAverage) | (1u << VF_SumSquares);
+    const unsigned slide_feats = slide_base | slide_wide;
+    const bool slide_is_wide = (fmask & slide_wide) != 0;
     const bool std13 = Nd == 3 && Na == 13 && f2d3 < 0 && dims[0] > 1 && dims[1] > 1 && dims[2] > 1;
     const bool std4 = Nd == 3 && Na == 4 && (f2d3 == 0 || dims[0] == 1) && dims[1] > 1 && dims[2] > 1;
     bool slide = (std13 || std4) && symmetric && Ng <= 64 && (kernelRadius == 1 || kernelRadius == 2) &&
@@ -1644,28 +1651,48 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
       unsigned *emap = nullptr;
       PRAD_TRY(c.get<double>("voxslide_maps", (size_t)nfeat * g.n, &maps));
       PRAD_TRY(c.get<unsigned>("voxslide_empty", (size_t)g.n, &emap));
-      const int s_ent = (fmask >> VF_JointEntropy) & 1 ? slot[VF_JointEntropy] : -1;
-      const int s_en = (fmask >> VF_JointEnergy) & 1 ? slot[VF_JointEnergy] : -1;
-      const int s_ja = (fmask >> VF_JointAverage) & 1 ? slot[VF_JointAverage] : -1;
-#define PRAD_SLIDE_T(RR, TWOD, RUNL, TBB, WV)                                                                               \
+      VoxSlideSlots sl;
+      for (int f = 0; f < VF_COUNT; f++) sl.s[f] = ((fmask >> f) & 1u) ? slot[f] : -1;
+      VoxSlideLutK *lutk_dev = nullptr;
+      VoxSlideLutK lutk_h;
+      if (slide_is_wide) {
+        const double sc = (double)(1LL << PRAD_VS_FIX), ng = (double)Ng;
+        for (int k = 0; k < PRAD_VS_KMAX; k++) {
+          const double kd = (double)k;
+          lutk_h.g[0][k] = std::llround(sc / (1.0 + kd));                       // Id      (glcm.py:741)
+          lutk_h.g[1][k] = std::llround(sc / (1.0 + kd * kd));                  // Idm     (:662)
+          lutk_h.g[2][k] = std::llround(sc / (1.0 + kd / ng));                  // Idn     (:759)
+          lutk_h.g[3][k] = std::llround(sc / (1.0 + (kd * kd) / (ng * ng)));    // Idmn    (:726)
+          lutk_h.g[4][k] = k ? std::llround(sc / (kd * kd)) : 0;                // InverseVariance (:773-776, k = 0 skipped)
+        }
+        PRAD_TRY(c.get<VoxSlideLutK>("voxslide_lutk", 1, &lutk_dev));
+        PRAD_HIP(hipMemcpyAsync(lutk_dev, &lutk_h, sizeof(lutk_h), hipMemcpyHostToDevice, s));
+      }
+#define PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WV, WD)                                                                           \
   do {                                                                                                                      \
-    constexpr size_t lds_s = voxel_glcm_slide_lds<RR, TWOD, RUNL, TBB, WV>();                                               \
+    constexpr size_t lds_s = voxel_glcm_slide_lds<RR, TWOD, RUNL, TBB, WV, WD>();                                           \
     static_assert(lds_s <= 160 * 1024, "LDS");                                                                              \
-    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_slide_kernel<RR, TWOD, RUNL, TBB, WV>),         \
+    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_slide_kernel<RR, TWOD, RUNL, TBB, WV, WD>),     \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                                  \
     const int wv = WV, rows = TWOD ? 16 : 4;                                                                                \
     const int nruns = (dims[2] + RUNL - 1) / RUNL;                                                                          \
-    hipLaunchKernelGGL((voxel_glcm_slide_kernel<RR, TWOD, RUNL, TBB, WV>), dim3((nruns + wv - 1) / wv, (dims[1] + rows - 1) / rows, z_end - z_begin + 1), \
-                       dim3(64 * wv), lds_s, s, levels, dims[0], dims[1], dims[2], A, Ng, lut_dev, s_ent, s_en, s_ja, maps, emap, flags, z_begin); \
+    hipLaunchKernelGGL((voxel_glcm_slide_kernel<RR, TWOD, RUNL, TBB, WV, WD>), dim3((nruns + wv - 1) / wv, (dims[1] + rows - 1) / rows, z_end - z_begin + 1), \
+                       dim3(64 * wv), lds_s, s, levels, dims[0], dims[1], dims[2], A, Ng, lut_dev, lutk_dev, sl, maps, emap, flags, z_begin); \
+  } while (0)
+      // (the WIDE instantiation carries 2.5 KB of g(k) tables in LDS: one wave less where the base shape fills the 160 KB)
+#define PRAD_SLIDE_T(RR, TWOD, RUNL, TBB, WV, WVW)                                                                          \
+  do {                                                                                                                      \
+    if (slide_is_wide) PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WVW, true);                                                       \
+    else PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WV, false);                                                                     \
   } while (0)
       // the lanes' private count tables hold Ng (Ng + 1) / 2 bytes: table size and waves per workgroup by level count
       // (32 levels: the round-4 shape; brain1 under exampleVoxel.yaml has 33)
 #define PRAD_SLIDE(RR, TWOD, RUNL)                                                                                          \
   do {                                                                                                                      \
-    if (Ng <= 32) PRAD_SLIDE_T(RR, TWOD, RUNL, 544, (TWOD ? 3 : 4));                                                        \
-    else if (Ng <= 40) PRAD_SLIDE_T(RR, TWOD, RUNL, 832, (TWOD ? 2 : 3));                                                   \
-    else if (Ng <= 48) PRAD_SLIDE_T(RR, TWOD, RUNL, 1184, (TWOD ? 1 : 2));                                                  \
-    else PRAD_SLIDE_T(RR, TWOD, RUNL, 2080, 1);                                                                             \
+    if (Ng <= 32) PRAD_SLIDE_T(RR, TWOD, RUNL, 544, (TWOD ? 3 : 4), (TWOD ? 3 : 4));                                        \
+    else if (Ng <= 40) PRAD_SLIDE_T(RR, TWOD, RUNL, 832, (TWOD ? 2 : 3), 2);                                                \
+    else if (Ng <= 48) PRAD_SLIDE_T(RR, TWOD, RUNL, 1184, (TWOD ? 1 : 2), (TWOD ? 1 : 2));                                  \
+    else PRAD_SLIDE_T(RR, TWOD, RUNL, 2080, 1, 1);                                                                          \
   } while (0)
       if (std13 && kernelRadius == 2) PRAD_SLIDE(2, false, 64);
       else if (std13) PRAD_SLIDE(1, false, 64);
@@ -1673,6 +1700,7 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
       else PRAD_SLIDE(1, true, 64);
 #undef PRAD_SLIDE
 #undef PRAD_SLIDE_T
+#undef PRAD_SLIDE_TW
       PRAD_TRY(check_launch("voxel_glcm_slide_kernel"));
       const unsigned allbits = (1u << Na) - 1u;
       const unsigned gb = (unsigned)std::min<long long>(((long long)Nvox + 255) / 256, (long long)cu_count() * 16);

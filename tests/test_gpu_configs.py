@@ -68,14 +68,23 @@ def test_c4_voxel_joint_entropy_512_sampled(checker):
     np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
 
 
-def _reference_voxel_glcm(checker, img, msk, Ng, vox, force2D, chunk=1000):
-    """The reference's voxel-based route for the three features the sliding-window kernel carries: per-kernel matrices from
+WIDE_FEATS = ["Autocorrelation", "ClusterProminence", "ClusterShade", "ClusterTendency", "Contrast", "DifferenceAverage",
+              "DifferenceVariance", "Id", "Idm", "Idn", "Idmn", "InverseVariance", "SumAverage", "SumSquares"]
+
+
+def _reference_voxel_glcm(checker, img, msk, Ng, vox, force2D, chunk=1000, wide=False):
+    """The reference's voxel-based route for the features the sliding-window kernel carries: per-kernel matrices from
     the C checker (_cmatrices.c:203-222, set_bb :1120-1147), then glcm.py:149-205 (symmetrise, empty angles -- none of the
-    dense call's angles is empty -- NaN marks, normalise), :226-258 (ux, HXY) and :292 / :495 / :512 (JointAverage = plain
-    mean over the angles, JointEnergy / JointEntropy = nanmean)."""
+    dense call's angles is empty -- NaN marks, normalise), :226-258 (ux, HXY) and the feature formulas (:260-887): JointAverage =
+    plain mean over the angles, everything else nanmean.  `wide`: also the fourteen features of the kernel's WIDE instantiation
+    (the sums over p_{x-y}(k) and p_{x+y}(k) written as weighted sums over p(i, j): the same numbers in another summation order)."""
+    import warnings
     nk = vox.shape[1]
-    ent, ene, avg = np.empty(nk), np.empty(nk), np.empty(nk)
+    names = ["JointEntropy", "JointEnergy", "JointAverage"] + (WIDE_FEATS if wide else [])
+    out = {f: np.empty(nk) for f in names}
     lev = np.arange(1, Ng + 1, dtype=float)
+    I, J = lev[None, :, None, None], lev[None, None, :, None]
+    K = np.abs(I - J)
     seen = None
     for s in range(0, nk, chunk):
         P, _ = checker.calculate_glcm(img, msk, [1], Ng, force2D, 0, kernelRadius=2, voxels=np.ascontiguousarray(vox[:, s:s + chunk]))
@@ -83,16 +92,35 @@ def _reference_voxel_glcm(checker, img, msk, Ng, vox, force2D, chunk=1000):
         tot = P.sum((1, 2))
         seen = (tot > 0).any(0) if seen is None else seen | (tot > 0).any(0)
         tot[tot == 0] = np.nan
-        with np.errstate(invalid="ignore", divide="ignore"):
+        sl = slice(s, s + chunk)
+        with np.errstate(invalid="ignore", divide="ignore"), warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
             p = P / tot[:, None, None, :]
-            import warnings
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore", RuntimeWarning)
-                ent[s:s + chunk] = np.nanmean(-(p * np.log2(p + np.spacing(1))).sum((1, 2)), 1)
-                ene[s:s + chunk] = np.nanmean((p ** 2).sum((1, 2)), 1)
-            avg[s:s + chunk] = (lev[None, :, None, None] * p).sum((1, 2)).mean(1)
+            out["JointEntropy"][sl] = np.nanmean(-(p * np.log2(p + np.spacing(1))).sum((1, 2)), 1)
+            out["JointEnergy"][sl] = np.nanmean((p ** 2).sum((1, 2)), 1)
+            ux = (I * p).sum((1, 2), keepdims=True)
+            out["JointAverage"][sl] = ux[:, 0, 0, :].mean(1)
+            if wide:
+                def nm(w):
+                    return np.nanmean((p * w).sum((1, 2)), 1)
+                c = I + J - 2 * ux                                                    # (symmetric matrix: uy = ux)
+                da = (p * K).sum((1, 2), keepdims=True)
+                out["Autocorrelation"][sl] = nm(I * J)
+                out["ClusterProminence"][sl] = nm(c ** 4)
+                out["ClusterShade"][sl] = nm(c ** 3)
+                out["ClusterTendency"][sl] = nm(c ** 2)
+                out["Contrast"][sl] = nm((I - J) ** 2)
+                out["DifferenceAverage"][sl] = np.nanmean(da[:, 0, 0, :], 1)
+                out["DifferenceVariance"][sl] = nm((K - da) ** 2)
+                out["Id"][sl] = nm(1.0 / (1.0 + K))
+                out["Idm"][sl] = nm(1.0 / (1.0 + K ** 2))
+                out["Idn"][sl] = nm(1.0 / (1.0 + K / Ng))
+                out["Idmn"][sl] = nm(1.0 / (1.0 + K ** 2 / Ng ** 2))
+                out["InverseVariance"][sl] = nm(np.where(K > 0, 1.0 / np.where(K > 0, K, 1.0) ** 2, 0.0))
+                out["SumAverage"][sl] = nm(I + J)
+                out["SumSquares"][sl] = nm((I - ux) ** 2)
     assert seen.all(), "an angle without a single pair in the sample: the empty-angle rule of glcm.py:186-199 would apply"
-    return {"JointEntropy": ent, "JointEnergy": ene, "JointAverage": avg}
+    return out
 
 
 def _slab_sample(rng, z0, z1, n, count):
@@ -144,6 +172,17 @@ def test_c4_sliding_window_maps_512_dense_vs_reference(three_d, checker):
                 assert np.array_equal(np.isnan(a), np.isnan(b)), (f, z0, int(np.isnan(a).sum()), int(np.isnan(b).sum()))
                 ok = ~np.isnan(b)
                 np.testing.assert_allclose(a[ok], b[ok], rtol=1e-9, atol=1e-12, err_msg="%s slab %d" % (f, z0))
+            if z0 == 0:          # the WIDE instantiation (fourteen more features) on the same slab and sample
+                gotw = engine.voxel_glcm_features(img_d, mask_d, Ng, vox_d, WIDE_FEATS, **kw)
+                assert engine.last_variant() == "slide"
+                sub = pick[:, :900]
+                wantw = _reference_voxel_glcm(checker, img, msk, Ng, sub, not three_d, wide=True)
+                for f in WIDE_FEATS:
+                    a, b = gotw[f][flat[:900]].cpu().numpy(), wantw[f]
+                    assert np.array_equal(np.isnan(a), np.isnan(b)), (f, z0)
+                    ok = ~np.isnan(b)
+                    np.testing.assert_allclose(a[ok], b[ok], rtol=1e-9, atol=1e-11, err_msg="%s slab %d" % (f, z0))
+                del gotw
             if mask_d is part_d:
                 assert np.isnan(want["JointAverage"]).sum() > 20 and (~msk[pick[0], pick[1], pick[2]]).sum() > 100
             compared += pick.shape[1]
@@ -176,12 +215,22 @@ def test_c4_example_voxel_yaml_on_brain1_takes_the_sliding_window_kernel(checker
     got = engine.voxel_glcm_features(torch.from_numpy(levels).to(dev), torch.from_numpy(roi.astype(np.uint8)).to(dev), Ng,
                                      torch.from_numpy(vox).to(dev), feats, kernelRadius=2, force2D=True, force2Ddimension=0)
     assert engine.last_path() == "voxel-fused" and engine.last_variant() == "slide"
-    want = _reference_voxel_glcm(checker, levels, roi, Ng, vox, True)
+    want = _reference_voxel_glcm(checker, levels, roi, Ng, vox, True, wide=True)
     for f in feats:
         a, b = got[f].cpu().numpy(), want[f]
         assert np.array_equal(np.isnan(a), np.isnan(b)), f
         ok = ~np.isnan(b)
         np.testing.assert_allclose(a[ok], b[ok], rtol=1e-9, atol=1e-12, err_msg=f)
+    # the fourteen features of the kernel's WIDE instantiation, alone and together with the three above
+    for req in (WIDE_FEATS, feats + WIDE_FEATS, ["Contrast"], ["Idmn", "ClusterProminence"]):
+        gw = engine.voxel_glcm_features(torch.from_numpy(levels).to(dev), torch.from_numpy(roi.astype(np.uint8)).to(dev), Ng,
+                                        torch.from_numpy(vox).to(dev), req, kernelRadius=2, force2D=True, force2Ddimension=0)
+        assert engine.last_variant() == "slide", req
+        for f in req:
+            a, b = gw[f].cpu().numpy(), want[f]
+            assert np.array_equal(np.isnan(a), np.isnan(b)), f
+            ok = ~np.isnan(b)
+            np.testing.assert_allclose(a[ok], b[ok], rtol=1e-9, atol=1e-11, err_msg=f)
 
 
 def test_c3_filters_rebinning_matrices_256_full_size(checker):

@@ -638,6 +638,30 @@ def test_sliding_window_maps_equal_the_window_kernel(shape, radius, force2D, Ng)
         np.testing.assert_allclose(a[ok], b[ok], rtol=1e-12 if f != "JointEntropy" else 1e-11, atol=1e-13, err_msg=f)
 
 
+@pytest.mark.parametrize("shape", [(9, 37, 70), (1, 40, 66), (23, 5, 9)])
+@pytest.mark.parametrize("radius,force2D", [(2, False), (1, False), (2, True)])
+@pytest.mark.parametrize("Ng", [32, 40, 64])
+def test_sliding_window_wide_features_equal_the_window_kernel(shape, radius, force2D, Ng):
+    """round 5: the fourteen features of the WIDE instantiation (integer pair sums, exact int64 central moments, fixed-point
+    g(|i - j|) sums) against the from-scratch kernel on every centre of a partially masked volume"""
+    rng = np.random.default_rng(hash((shape, radius, force2D, Ng, 5)) % (2 ** 32))
+    img = rng.integers(1, Ng + 1, size=shape).astype(np.int32)
+    img[:, : shape[1] // 2] = (img[:, : shape[1] // 2] + 3) // 4 + 1
+    msk = rng.random(shape) < 0.85
+    msk[:, -3:, :] = False
+    vox = np.array(np.nonzero(np.ones(shape, bool))).astype(np.int32)
+    feats = ["JointEntropy", "Autocorrelation", "ClusterProminence", "ClusterShade", "ClusterTendency", "Contrast", "DifferenceAverage",
+             "DifferenceVariance", "Id", "Idm", "Idn", "Idmn", "InverseVariance", "SumAverage", "SumSquares"]
+    new, old, variant = _slide_vs_window(img, msk, Ng, vox, feats, kernelRadius=radius, force2D=force2D, force2Ddimension=0)
+    assert variant == "slide"
+    for f in feats:
+        a, b = new[f], old[f]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f
+        ok = ~np.isnan(a)
+        assert ok.sum() > 0
+        np.testing.assert_allclose(a[ok], b[ok], rtol=1e-9, atol=1e-10, err_msg=f)
+
+
 def test_sliding_window_maps_are_only_taken_where_they_apply():
     rng = np.random.default_rng(3)
     shape = (8, 20, 40)
@@ -645,7 +669,8 @@ def test_sliding_window_maps_are_only_taken_where_they_apply():
     msk = np.ones(shape, bool)
     vox = np.array(np.nonzero(msk)).astype(np.int32)
     for feats, kw, want in ((["JointEntropy"], dict(kernelRadius=2), "slide"),
-                            (["JointEntropy", "Contrast"], dict(kernelRadius=2), "window"),        # a feature it does not carry
+                            (["JointEntropy", "Contrast"], dict(kernelRadius=2), "slide"),         # (carried since round 5: WIDE)
+                            (["JointEntropy", "Correlation"], dict(kernelRadius=2), "window"),     # a feature it does not carry
                             (["JointEntropy"], dict(kernelRadius=3), "window"),                    # counts beyond a byte
                             (["JointEntropy"], dict(kernelRadius=2, symmetrical=False), "window"),
                             (["JointEntropy"], dict(kernelRadius=2, force2D=True, force2Ddimension=1), "window")):
