@@ -104,7 +104,8 @@ struct PackJob {
   const int *image;
   const uint8_t *mask;
   uint8_t *levels;
-  uint8_t *rowzero;   // zeroed by the caller
+  uint8_t *levels16;  // two-table walk (kernels_sweepfw2.h PackWave16): 16-bit level*4 elements; `levels` then holds plain level bytes
+  uint8_t *rowzero;   // zeroed by the caller (fused-table walk only)
   int *flags;         // the packed volume's own flag words ([0] irregular level under the mask, [3] some voxel outside the ROI)
   long long n16;      // 16-voxel pieces
   int NX, Ng;

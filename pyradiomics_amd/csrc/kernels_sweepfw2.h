@@ -186,12 +186,157 @@ __device__ __forceinline__ void fw2_make_x(const u32 (&P)[K / 2], u32 (&X)[K / 2
   }
 }
 
+// The NEXT volume's pack for this path as a side job of the walking waves (round 5; PackJob / PackWave in kernels_sweepfw.h
+// have the reasons: the pack is HBM-bound, the walk is bound by its LDS atomics, so the pack's memory time disappears behind
+// the walk and only its VALU instructions remain -- as a launch of its own the pack costs 0.20 ms of a 0.85 ms step at
+// 512^3 x 64 levels, profiles/r05b_probe64.json).  A unit is 64 pieces of 16 voxels; a lane turns the 16 int32 levels + 16
+// mask bytes of its piece into 16 16-bit elements (level*4: two 16-byte stores into J.levels16) and 16 plain level bytes for
+// the rows kernel (one 16-byte store into J.levels).  Needs the linear layouts (pitch16 == 2 NX, pitch == NX: NX % 16 == 0)
+// and 16-byte aligned arrays.  Same results as pack_levels16_kernel for every input (tests/test_gpu_fw2_pack.py).
+struct PackWave16 {
+  unsigned long long img, msk;   // this lane's next piece: image + 64 t, mask + 16 t (byte addresses)
+  unsigned long long step16;     // pieces between two units of this wave
+  unsigned e;                    // first voxel of that piece (16 t; volumes stay below 2^31 voxels)
+  int units_left, last_lanes, tick, every, loaded, bad, lane;
+  int4 q0, q1, q2, q3;
+  uint4 m;
+  template <typename T>
+  static __device__ __forceinline__ void pin(T &x) { asm volatile("" : "+v"(x)); }
+  __device__ __forceinline__ PackWave16(const PackJob &J, long long pw, long long W) {
+    lane = threadIdx.x & 63;
+    const long long n16 = J.n16, first = pw * 64;
+    long long units = 0;
+    if (pw >= 0 && first < n16) units = (n16 - first + W * 64 - 1) / (W * 64);
+    units_left = (int)units;
+    const long long last_first = first + (units - 1) * W * 64;
+    last_lanes = units > 0 ? (int)((n16 - last_first) < 64 ? (n16 - last_first) : 64) : 0;
+    const unsigned long long t = (unsigned long long)(first + lane);
+    img = (unsigned long long)(size_t)J.image + 64ull * t;
+    msk = (unsigned long long)(size_t)J.mask + 16ull * t;
+    e = (unsigned)(16ull * t);
+    step16 = (unsigned long long)(W * 64);
+    tick = 0;
+    every = J.every;
+    loaded = 0;
+    bad = 0;
+    pin(img); pin(msk); pin(e); pin(step16); pin(units_left); pin(last_lanes); pin(tick); pin(every); pin(loaded); pin(bad);
+  }
+  __device__ __forceinline__ void load() {
+    q0 = q1 = q2 = q3 = make_int4(0, 0, 0, 0);
+    m = make_uint4(0, 0, 0, 0);
+    if (units_left > 1 || lane < last_lanes) {
+      const int4 *im4 = reinterpret_cast<const int4 *>((size_t)img);
+#ifdef PRAD_PACK16_NT     // A/B build: the image and the mask stream past the caches the walk's re-reads live in
+      m = __builtin_nontemporal_load(reinterpret_cast<const uint4 *>((size_t)msk));
+      q0 = __builtin_nontemporal_load(im4);
+      q1 = __builtin_nontemporal_load(im4 + 1);
+      q2 = __builtin_nontemporal_load(im4 + 2);
+      q3 = __builtin_nontemporal_load(im4 + 3);
+#else
+      m = *reinterpret_cast<const uint4 *>((size_t)msk);
+      q0 = im4[0];
+      q1 = im4[1];
+      q2 = im4[2];
+      q3 = im4[3];
+#endif
+    }
+    loaded = 1;
+    pin(loaded);
+  }
+  __device__ __forceinline__ void begin() {
+    if (units_left <= 0) return;
+    tick++;
+    pin(tick);
+    if (tick < every) return;
+    tick = 0;
+    pin(tick);
+    load();
+  }
+  __device__ __forceinline__ void finish(const PackJob &J) {
+    if (!loaded) return;
+    loaded = 0;
+    pin(loaded);
+    const bool mine = units_left > 1 || lane < last_lanes;
+    if (mine) {
+      const int lv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+      const u32 mw[4] = {m.x, m.y, m.z, m.w};
+      // Two voxels per dword (16-bit halves).  FAST PATH, decided once for the 16 voxels of the piece: every voxel lies inside
+      // the mask and every level is regular (1..Ng, no bits beyond the low half).  With q = h - 0x00010001 and
+      // r = q + (0x8000 - Ng) * 0x00010001, bit 15 of some half of h | q | r is set iff some half of h is 0 or > Ng (the lowest
+      // irregular half sees no borrow / carry from below; Ng <= 255 on this path).  SECOND FAST PATH: no voxel inside the mask.
+      const u32 K80 = 0x80808080u, K7F = 0x7f7f7f7fu, H1 = 0x00010001u, H80 = 0x80008000u;
+      const u32 radd = (0x8000u - (u32)J.Ng) * H1;
+      u32 h[8], badbits = 0, wideall = 0, nzall = K80, nzany = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const u32 l0 = (u32)lv[2 * i], l1 = (u32)lv[2 * i + 1];
+        wideall |= l0 | l1;
+        h[i] = __builtin_amdgcn_perm(l1, l0, 0x05040100u);     // low halves of the two levels
+        const u32 q = h[i] - H1;
+        badbits |= h[i] | q | (q + radd);
+      }
+#pragma unroll
+      for (int w = 0; w < 4; w++) {
+        const u32 nz = ((mw[w] & K7F) + K7F) | mw[w];           // bit 7 of every non-zero mask byte
+        nzall &= nz;
+        nzany |= nz;
+      }
+      u32 o16[8], o8[4];
+      if ((((~nzall) & K80) | (badbits & H80) | (wideall & 0xffff0000u)) == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) o16[i] = h[i] << PRAD_FUSED_SHIFT;
+#pragma unroll
+        for (int w = 0; w < 4; w++) o8[w] = __builtin_amdgcn_perm(h[2 * w + 1], h[2 * w], 0x06040200u);
+      } else if ((nzany & K80) == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) o16[i] = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) o8[w] = 0;
+      } else {
+        // the exact per-voxel form (pieces that straddle the ROI's surface, irregular levels): same results in every case
+#pragma unroll
+        for (int i = 0; i < 8; i++) o16[i] = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) o8[w] = 0;
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+          const bool in = (mw[b >> 2] >> (8 * (b & 3))) & 0xffu;
+          const int l = lv[b];
+          const bool regular = in && l >= 1 && l <= J.Ng;
+          bad |= in && !regular;
+          const u32 el = regular ? (u32)l : 0u;                 // (an irregular level packs as 0: never a table index)
+          o16[b >> 1] |= (el << PRAD_FUSED_SHIFT) << (16 * (b & 1));
+          o8[b >> 2] |= el << (8 * (b & 3));
+        }
+      }
+      uint4 *d16 = reinterpret_cast<uint4 *>(J.levels16 + 2ull * e);
+      d16[0] = make_uint4(o16[0], o16[1], o16[2], o16[3]);
+      d16[1] = make_uint4(o16[4], o16[5], o16[6], o16[7]);
+      *reinterpret_cast<uint4 *>(J.levels + e) = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+    }
+    img += 64ull * step16;
+    msk += 16ull * step16;
+    e += (unsigned)(16ull * step16);
+    units_left--;
+    pin(img); pin(msk); pin(e); pin(units_left); pin(bad);
+  }
+  // whatever the walk left over (a launch whose walk is much shorter than the pack, or no walk at all)
+  __device__ __forceinline__ void drain(const PackJob &J) {
+#pragma unroll 1
+    while (units_left > 0) {
+      load();
+      finish(J);
+    }
+    if (bad) J.flags[0] = 1;
+  }
+};
+
 #define FW2_EL(W, j) ((int)__builtin_amdgcn_ubfe((W)[(j) >> 1], 16 * ((j) & 1), 16))
 
 // SKIP1: runs of length 1 are not recorded by the walk.  Every ROI voxel lies on exactly one line of an angle, so
 // sum_len len * GLRLM_a[g][len] = N_g (the voxels of level g) for EVERY angle a; the x angle's kernel records all of its runs,
 // and the finalize step sets GLRLM_a[g][1] = N_g - sum_{len >= 2} len * GLRLM_a[g][len] (exact integers).
-template <bool LONG, int K, int DX, bool HASPAD, bool SKIP1>
+template <bool LONG, int K, int DX, bool HASPAD, bool SKIP1, bool PACK>
 struct Fw2Wave {
   static constexpr int KW = K / 2;
   static constexpr int U = PRAD_FW_U;
@@ -370,7 +515,7 @@ struct Fw2Wave {
     return __ballot(a) != 0;
   }
   __device__ __forceinline__ void run(const FwDesc &D, int NX, int pitch, long long nrows, const uint8_t *__restrict__ L,
-                                      int *work, int bx, int nblocks, bool xcd) {
+                                      int *work, int bx, int nblocks, bool xcd, PackWave16 &pk, const PackJob &pj) {
     const int NM = D.NM, NU = D.NU, du = D.du;
     const long long delta = D.sM + (long long)du * D.sU;
     const uint8_t *lpb = L + 2 * (long long)first_col(NX);
@@ -475,8 +620,10 @@ struct Fw2Wave {
               load_row(p, v[k]);
               p += delta;
             }
+            if (PACK) pk.begin();            // (the next volume's pack rides along: loads out, ...
             if (safe == 1) calm_padding();
             plain_group(v);
+            if (PACK) pk.finish(pj);         //  ... elements stored behind the group's VALU / LDS work)
             safe--;
             t += U;
             row += U * du;
@@ -533,37 +680,45 @@ __device__ __forceinline__ void fw2_flush(const u32 *lds, const Fw2Tab &T, int s
   }
 }
 
-template <bool LONG, int K, bool HASPAD, bool SKIP1>
-__global__ void __launch_bounds__(1024) sweep_fw2_kernel(FwSet set, const uint8_t *__restrict__ L, int Ng, int Nr, int RS2, int C,
-                                                         u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
+// PACK: the pack of the NEXT volume rides in this launch (PackWave16).  A volume whose pack found irregular levels (flags[0])
+// is skipped -- the generic kernels redo that call -- but the side job still runs.
+template <bool LONG, int K, bool HASPAD, bool SKIP1, bool PACK>
+__global__ void __launch_bounds__(1024) sweep_fw2_kernel(FwSet set, PackJob pj, const uint8_t *__restrict__ L, int Ng, int Nr, int RS2,
+                                                         int C, u32 *__restrict__ glcm_acc, u32 *__restrict__ glrlm_acc,
                                                          int *__restrict__ work, int *__restrict__ flags) {
   extern __shared__ u32 lds[];
-  if (flags[0]) return;  // irregular levels: the generic path will redo this call
-  if ((unsigned)(size_t)((lds_u32 *)lds) != 0u) {  // table offsets are used as LDS addresses
+  const int wpb = (int)(blockDim.x >> 6);
+  const long long pw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * wpb + (threadIdx.x >> 6)));
+  PackWave16 pk(pj, PACK ? pw : -1, (long long)gridDim.x * wpb);
+  bool walk = flags[0] == 0;   // (else: irregular levels, the generic path will redo this call)
+  if (walk && (unsigned)(size_t)((lds_u32 *)lds) != 0u) {  // table offsets are used as LDS addresses
     if (threadIdx.x == 0) atomicExch(flags + 2, 1);
-    return;
+    walk = false;
   }
-  int role = 0;
-  while (role + 1 < set.count && (int)blockIdx.x >= set.first_block[role + 1]) role++;
-  const int bx = (int)blockIdx.x - set.first_block[role], nblocks = set.first_block[role + 1] - set.first_block[role];
-  const int words = (int)fw2_table_words(Ng, RS2, C);
-  for (int i = threadIdx.x; i < words; i += blockDim.x) lds[i] = 0;
-  __syncthreads();
-  const FwDesc &D = set.d[role];
-  Fw2Tab T;
-  T.init(Ng, RS2, C, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
-  int *wk = work + PRAD_FW_WORK_STRIDE * PRAD_FW_DOMAINS * role;
-  if (D.dx == 0) {
-    Fw2Wave<LONG, K, 0, HASPAD, SKIP1> w(T, set.NX);
-    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0);
-  } else if (D.dx > 0) {
-    Fw2Wave<LONG, K, 1, HASPAD, SKIP1> w(T, set.NX);
-    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0);
-  } else {
-    Fw2Wave<LONG, K, -1, HASPAD, SKIP1> w(T, set.NX);
-    w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0);
+  if (walk) {
+    int role = 0;
+    while (role + 1 < set.count && (int)blockIdx.x >= set.first_block[role + 1]) role++;
+    const int bx = (int)blockIdx.x - set.first_block[role], nblocks = set.first_block[role + 1] - set.first_block[role];
+    const int words = (int)fw2_table_words(Ng, RS2, C);
+    for (int i = threadIdx.x; i < words; i += blockDim.x) lds[i] = 0;
+    __syncthreads();
+    const FwDesc &D = set.d[role];
+    Fw2Tab T;
+    T.init(Ng, RS2, C, Nr, glrlm_acc + (size_t)D.slot * Ng * Nr);
+    int *wk = work + PRAD_FW_WORK_STRIDE * PRAD_FW_DOMAINS * role;
+    if (D.dx == 0) {
+      Fw2Wave<LONG, K, 0, HASPAD, SKIP1, PACK> w(T, set.NX);
+      w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0, pk, pj);
+    } else if (D.dx > 0) {
+      Fw2Wave<LONG, K, 1, HASPAD, SKIP1, PACK> w(T, set.NX);
+      w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0, pk, pj);
+    } else {
+      Fw2Wave<LONG, K, -1, HASPAD, SKIP1, PACK> w(T, set.NX);
+      w.run(D, set.NX, set.pitch, set.nrows, L, wk, bx, nblocks, set.xcd != 0, pk, pj);
+    }
+    fw2_flush(lds, T, D.slot, glcm_acc, glrlm_acc);
   }
-  fw2_flush(lds, T, D.slot, glcm_acc, glrlm_acc);
+  if (PACK) pk.drain(pj);
 }
 
 // pack for this path: 16-bit level*4 elements (rows of pitch16 BYTES) and, for the rows kernel, plain 8-bit levels

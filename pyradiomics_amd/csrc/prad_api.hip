@@ -596,31 +596,38 @@ int launch_fw(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *lev
                     : launch_fw_k<false, 8>(k, p, pj, levels, rowzero, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
 }
 
-template <bool LNG, int K, bool HASPAD, bool SKIP1>
-int launch_fw2_khs(Call &k, const SweepPlan &p, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *work,
-                   int *flags_d) {
-  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw2_kernel<LNG, K, HASPAD, SKIP1>),
+template <bool LNG, int K, bool HASPAD, bool SKIP1, bool PACK>
+int launch_fw2_khsp(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
+                    int *work, int *flags_d) {
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw2_kernel<LNG, K, HASPAD, SKIP1, PACK>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw2));
-  hipLaunchKernelGGL((sweep_fw2_kernel<LNG, K, HASPAD, SKIP1>), dim3(p.fw_blocks), dim3(1024), p.lds_fw2, k.s, p.fwset, levels16, Ng,
-                     Nr, p.RS2, p.fw2_copies, glcm_acc, glrlm_acc, work, flags_d);
+  hipLaunchKernelGGL((sweep_fw2_kernel<LNG, K, HASPAD, SKIP1, PACK>), dim3(p.fw_blocks), dim3(1024), p.lds_fw2, k.s, p.fwset, pj, levels16,
+                     Ng, Nr, p.RS2, p.fw2_copies, glcm_acc, glrlm_acc, work, flags_d);
   return check_launch("sweep_fw2_kernel");
 }
+template <bool LNG, int K, bool HASPAD, bool SKIP1>
+int launch_fw2_khs(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
+                   int *work, int *flags_d) {
+  if (pj.n16 > 0) return launch_fw2_khsp<LNG, K, HASPAD, SKIP1, true>(k, p, pj, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d);
+  return launch_fw2_khsp<LNG, K, HASPAD, SKIP1, false>(k, p, pj, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d);
+}
 template <bool LNG, int K>
-int launch_fw2_k(Call &k, const SweepPlan &p, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *multi,
-                 int *flags_d) {
+int launch_fw2_k(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
+                 int *multi, int *flags_d) {
   int *work = multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE;
   if (p.Nx != 64 * K)
-    return p.skip1 ? launch_fw2_khs<LNG, K, true, true>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d)
-                   : launch_fw2_khs<LNG, K, true, false>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d);
-  return p.skip1 ? launch_fw2_khs<LNG, K, false, true>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d)
-                 : launch_fw2_khs<LNG, K, false, false>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d);
+    return p.skip1 ? launch_fw2_khs<LNG, K, true, true>(k, p, pj, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d)
+                   : launch_fw2_khs<LNG, K, true, false>(k, p, pj, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d);
+  return p.skip1 ? launch_fw2_khs<LNG, K, false, true>(k, p, pj, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d)
+                 : launch_fw2_khs<LNG, K, false, false>(k, p, pj, levels16, Ng, Nr, glcm_acc, glrlm_acc, work, flags_d);
 }
-int launch_fw2(Call &k, const SweepPlan &p, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *multi,
-               int *flags_d) {
-  if (p.LONGfw2) return p.fwK == 4 ? launch_fw2_k<true, 4>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
-                                 : launch_fw2_k<true, 8>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
-  return p.fwK == 4 ? launch_fw2_k<false, 4>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
-                    : launch_fw2_k<false, 8>(k, p, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
+// the two-table launch of one volume: every line angle and, optionally, the pack of the NEXT volume as a side job
+int launch_fw2(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
+               int *multi, int *flags_d) {
+  if (p.LONGfw2) return p.fwK == 4 ? launch_fw2_k<true, 4>(k, p, pj, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
+                                 : launch_fw2_k<true, 8>(k, p, pj, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
+  return p.fwK == 4 ? launch_fw2_k<false, 4>(k, p, pj, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d)
+                    : launch_fw2_k<false, 8>(k, p, pj, levels16, Ng, Nr, glcm_acc, glrlm_acc, multi, flags_d);
 }
 
 template <bool LNG>
@@ -714,9 +721,16 @@ int vol_prepare(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, doubl
 }
 
 // can this volume's pack ride in another volume's sweep launch?  (linear layout, vector loads)
+bool pipeline_volume(const SweepPlan &p, bool glcm, bool glrlm) {   // a volume the two-stage deferred pipeline takes
+  if (!(p.ok && p.lines.count > 0 && glcm && glrlm)) return false;
+  return (p.fw && p.fused) || (p.fw2 && !getenv("PRAD_FW2_LANES"));
+}
 bool pack_inline_ok(const Call &k, const VolState &v) {
-  return v.p.fw && v.glcm && v.glrlm && v.p.fused && v.p.pitch == v.p.Nx && v.p.padw == 0 && (k.g.n % 16) == 0 &&
-         ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)v.levels)) & 15) == 0;
+  if (!(v.glcm && v.glrlm && v.p.pitch == v.p.Nx && v.p.padw == 0 && (k.g.n % 16) == 0 &&
+        ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)v.levels)) & 15) == 0))
+    return false;
+  if (v.p.fw2) return v.levels16 && v.p.pitch16 == 2 * v.p.Nx && (((uintptr_t)v.levels16) & 15) == 0;
+  return v.p.fw && v.p.fused;
 }
 
 PackJob make_pack_job(const Call &k, const VolState &v, const VolState *host) {
@@ -725,6 +739,7 @@ PackJob make_pack_job(const Call &k, const VolState &v, const VolState *host) {
   j.image = k.image;
   j.mask = k.mask;
   j.levels = v.levels;
+  j.levels16 = v.p.fw2 ? v.levels16 : nullptr;
   j.rowzero = v.rowzero;
   j.flags = v.flags_d;
   j.n16 = k.g.n / 16;
@@ -780,7 +795,7 @@ int launch_sweeps(Call &k, const VolState &v, const PackJob &pj) {
   if (p.fw2 && G && R && !F && p.lines.count > 0) {
     {
       Timed t(*k.c, "sweep", k.s);
-      PRAD_TRY(launch_fw2(k, p, v.levels16, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi, v.flags_d));
+      PRAD_TRY(launch_fw2(k, p, pj, v.levels16, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi, v.flags_d));
     }
     if (p.row_slot >= 0) {
       Timed t(*k.c, "rows", k.s);
@@ -803,8 +818,10 @@ int launch_sweeps(Call &k, const VolState &v, const PackJob &pj) {
 
 // the sweeps of volume v; `pj` (n16 > 0) = the pack of another volume as a side job of the fixed-window launch
 int vol_sweep(Call &k, const VolState &v, const PackJob &pj) {
-  if (pj.n16 > 0 && !(v.p.fw && v.p.lines.count > 0 && v.glcm && v.glrlm && v.p.fused))
+  if (pj.n16 > 0 && !pipeline_volume(v.p, v.glcm != nullptr, v.glrlm != nullptr))
     return fail(PRAD_E_ARG, "internal: a pack job needs a fixed-window host launch");
+  if (pj.n16 > 0 && (pj.levels16 != nullptr) != v.p.fw2)
+    return fail(PRAD_E_ARG, "internal: the pack job's layout is not the host launch's");
   if (v.glcm && v.glrlm && v.p.fused) return launch_sweeps<true, true, true>(k, v, pj);
   if (v.glcm && v.glrlm) return launch_sweeps<true, true, false>(k, v, pj);
   if (v.glcm) return launch_sweeps<true, false, false>(k, v, pj);
@@ -962,14 +979,15 @@ int pipeline_step(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, dou
   Context &c = *k.c;
   PipeState &ps = pipe_state();
   *handled = false;
-  if (!(p.ok && p.fw && p.lines.count > 0 && glcm && glrlm && p.fused)) return pipeline_flush(c);
+  if (!pipeline_volume(p, glcm != nullptr, glrlm != nullptr)) return pipeline_flush(c);
   VolState v;
   PRAD_TRY(vol_prepare(k, p, Ng, Nr, glcm, glrlm, v));
   PackJob pj;
   memset(&pj, 0, sizeof(pj));
   bool inl = false;
   if (ps.pending.valid) {
-    inl = pack_inline_ok(k, v) && !getenv("PRAD_NO_INLINE_PACK");
+    // (the side job writes the layout of the launch it rides in: fused-table and two-table volumes do not mix)
+    inl = pack_inline_ok(k, v) && ps.pending.p.fw2 == v.p.fw2 && !getenv("PRAD_NO_INLINE_PACK");
     if (inl) pj = make_pack_job(k, v, &ps.pending);
     PRAD_TRY(pipeline_retire(c, k.s, pj));
   }
@@ -1097,10 +1115,10 @@ int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *siz
   Call k;
   PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, Nvox, voxels, kernelRadius, force2Ddim, s, false));
   SweepPlan p = plan_sweep(k, Ng, Nr, glcm != nullptr, glrlm != nullptr);
-  if (pipe && !(p.ok && p.fw && p.lines.count > 0 && glcm && glrlm && p.fused)) {
-    // Not a volume for the two-stage pipeline (the two-table kernel of 45+ grey levels, the wrapped-lines kernels): its pack
-    // is a launch of its own, so deal the call onto the lanes, where the pack of one volume runs under the walk of the
-    // previous one (64 levels, 256^3: 0.225 -> 0.179 ms per volume; 512^3: 1.10 -> 1.02)
+  if (pipe && !pipeline_volume(p, glcm != nullptr, glrlm != nullptr)) {
+    // Not a volume for the two-stage pipeline (the wrapped-lines kernels; PRAD_FW2_LANES: the two-table kernel of 45+ grey
+    // levels as until round 5): its pack is a launch of its own, so deal the call onto the lanes, where the pack of one
+    // volume runs under the walk of the previous one
     const hipStream_t user = s;
     PRAD_TRY(pipeline_flush(c));
     pipe = false;
