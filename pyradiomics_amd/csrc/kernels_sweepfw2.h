@@ -227,11 +227,17 @@ struct PackWave16 {
     if (units_left > 1 || lane < last_lanes) {
       const int4 *im4 = reinterpret_cast<const int4 *>((size_t)img);
 #ifdef PRAD_PACK16_NT     // A/B build: the image and the mask stream past the caches the walk's re-reads live in
-      m = __builtin_nontemporal_load(reinterpret_cast<const uint4 *>((size_t)msk));
-      q0 = __builtin_nontemporal_load(im4);
-      q1 = __builtin_nontemporal_load(im4 + 1);
-      q2 = __builtin_nontemporal_load(im4 + 2);
-      q3 = __builtin_nontemporal_load(im4 + 3);
+      typedef int v4i __attribute__((ext_vector_type(4)));
+      const v4i *iv = reinterpret_cast<const v4i *>((size_t)img);
+      const v4i mv = __builtin_nontemporal_load(reinterpret_cast<const v4i *>((size_t)msk));
+      const v4i a0 = __builtin_nontemporal_load(iv), a1 = __builtin_nontemporal_load(iv + 1),
+                a2 = __builtin_nontemporal_load(iv + 2), a3 = __builtin_nontemporal_load(iv + 3);
+      m = make_uint4((u32)mv.x, (u32)mv.y, (u32)mv.z, (u32)mv.w);
+      q0 = make_int4(a0.x, a0.y, a0.z, a0.w);
+      q1 = make_int4(a1.x, a1.y, a1.z, a1.w);
+      q2 = make_int4(a2.x, a2.y, a2.z, a2.w);
+      q3 = make_int4(a3.x, a3.y, a3.z, a3.w);
+      (void)im4;
 #else
       m = *reinterpret_cast<const uint4 *>((size_t)msk);
       q0 = im4[0];
@@ -719,6 +725,128 @@ __global__ void __launch_bounds__(1024) sweep_fw2_kernel(FwSet set, PackJob pj, 
     fw2_flush(lds, T, D.slot, glcm_acc, glrlm_acc);
   }
   if (PACK) pk.drain(pj);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The angle along x on the 16-bit level volume with the same exec-masked two-table step (round 5; until then the rows kernel
+// of kernels_sweep.h walked an 8-bit copy with the branch-free Walker: ~12 VALU and two unconditional ds_adds per voxel,
+// 0.11 / 0.17 ms per 512^3 volume of iid / smooth levels against 0.06 / 0.08 for the fused-table rows kernel at 32 levels).
+// A wave owns 64 rows (8 rows apart on large volumes, see fw_rows_role), stages 64 x 32-element tiles through LDS (16 B per
+// lane coalesced in, one row per lane out) and every lane walks its own row, two voxels (one staged dword) per asm block.
+// Table layout, state (p = A row, q = B cursor) and flush as in the line walk; this angle records ALL its runs (the SKIP1
+// restore of the line angles reads N_g off it).
+// ---------------------------------------------------------------------------------------------------------------
+#define PRAD_ROW16_EL 32      // elements of a row per staged tile (a tile = 64 rows x 32 elements: 5 KB per wave, so that 16 waves
+                              // and their tiles fit next to a 64-level table: the walk is a serial chain per lane, it needs the waves)
+#define PRAD_ROW16_PITCH 80    // bytes per staged row: 64 data + 16 pad => conflict-free ds_read_b128 per lane
+__device__ __forceinline__ void fw2_row_word(const Fw2Tab &T, int k1, u32 one, int &p, int &q, u32 c, u32 x) {
+  int t;
+#define PRAD_FW2_RCOL(J)                                                                                                 \
+  "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:WORD_" #J " src1_sel:WORD_" #J "\n\t"                                     \
+  "v_add_u32_sdwa %[t], %[p], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #J "\n\t"            \
+  "ds_add_u32 %[t], %[one]\n\t"                                                                                          \
+  "ds_add_u32 %[q], %[one]\n\t"                                                                                          \
+  "v_mul_u32_u24_sdwa %[p], %[S4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_" #J "\n\t"      \
+  "v_add_u32 %[q], %[K1], %[p]\n\t"                                                                                      \
+  "s_mov_b64 exec, -1\n\t"                                                                                               \
+  "v_add_u32 %[q], 4, %[q]\n\t"
+  asm volatile(PRAD_FW2_RCOL(0) PRAD_FW2_RCOL(1)
+               : [p] "+v"(p), [q] "+v"(q), [t] "=&v"(t)
+               : [c] "v"(c), [x] "v"(x), [one] "v"(one), [S4] "s"(T.S4), [K1] "v"(k1)
+               : "vcc", "memory");
+#undef PRAD_FW2_RCOL
+}
+
+template <bool LONG>
+__global__ void __launch_bounds__(1024) sweep_fw2_rows_kernel(const uint8_t *__restrict__ L16, long long nrows, int NX, int pitch16,
+                                                             int slot, int Ng, int Nr, int RS2, int C, u32 *__restrict__ glcm_acc,
+                                                             u32 *__restrict__ glrlm_acc, int *__restrict__ flags) {
+  extern __shared__ u32 lds[];
+  if (flags[0]) return;
+  if ((unsigned)(size_t)((lds_u32 *)lds) != 0u) {   // table offsets are used as LDS addresses
+    if (threadIdx.x == 0) atomicExch(flags + 2, 1);
+    return;
+  }
+  const int words = (int)fw2_table_words(Ng, RS2, C);
+  for (int i = threadIdx.x; i < words; i += blockDim.x) lds[i] = 0;
+  __syncthreads();
+  Fw2Tab T;
+  T.init(Ng, RS2, C, Nr, glrlm_acc + (size_t)slot * Ng * Nr);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+  const int dummy = 4 * lane;      // row 0 is scratch and at least 64 words long
+  u32 one = 1;
+  int k1v = T.K1 + (lane % T.C) * T.lenlim;
+  asm volatile("" : "+v"(one), "+v"(k1v));
+  uint8_t *tile = reinterpret_cast<uint8_t *>(lds) + ((4 * (size_t)words + 15) & ~(size_t)15) + (size_t)wave * 64 * PRAD_ROW16_PITCH;
+  const int RSTEP = nrows >= 4096 ? 8 : 1;
+  const long long ngroups = RSTEP == 8 ? ((nrows + 511) / 512) * 8 : (nrows + 63) / 64;
+  const long long nwaves = (long long)gridDim.x * wpb;
+  for (long long grp = (long long)blockIdx.x * wpb + wave; grp < ngroups; grp += nwaves) {
+    const long long r0 = RSTEP == 8 ? (grp >> 3) * 512 + (grp & 7) : grp * 64;     // row of tile slot i: r0 + RSTEP * i
+    int p = 0, q = k1v;   // level 0, no voxel seen
+    u32 pw = 0;           // previous staged dword (its high half is the previous voxel)
+    // lane -> (row j*16 + lane/4, 16-byte piece lane%4) of a tile; the pieces of the NEXT tile are loaded into registers before
+    // the current one is walked (the global-load latency of a wave's tiles was a third of this kernel's time)
+    uint4 nx4[4];
+    auto fetch = [&](int xc) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int rr = j * 16 + (lane >> 2);
+        const int cx = xc + (lane & 3) * 8;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r0 + (long long)RSTEP * rr < nrows && cx < NX) {
+          v = *reinterpret_cast<const uint4 *>(L16 + (r0 + (long long)RSTEP * rr) * pitch16 + 2 * cx);
+          const int valid = NX - cx;             // elements of this piece that belong to the row (the rest is the pad)
+          if (valid < 8) {
+            u32 *vw = reinterpret_cast<u32 *>(&v);
+#pragma unroll
+            for (int wd = 0; wd < 4; wd++) {
+              const int keep = valid - 2 * wd;
+              vw[wd] = keep >= 2 ? vw[wd] : (keep <= 0 ? 0u : (vw[wd] & 0xffffu));
+            }
+          }
+        }
+        nx4[j] = v;
+      }
+    };
+    fetch(0);
+    for (int xc = 0; xc < NX; xc += PRAD_ROW16_EL) {
+      // ---- stage rows r0 + RSTEP i (i = 0..63), elements xc..xc+31 ----
+#pragma unroll
+      for (int j = 0; j < 4; j++) *reinterpret_cast<uint4 *>(tile + (j * 16 + (lane >> 2)) * PRAD_ROW16_PITCH + (lane & 3) * 16) = nx4[j];
+      __builtin_amdgcn_wave_barrier();
+      if (xc + PRAD_ROW16_EL < NX) fetch(xc + PRAD_ROW16_EL);
+      // ---- each lane walks its own row (rows >= nrows and elements >= NX were staged as zeros) ----
+      const uint4 *row = reinterpret_cast<const uint4 *>(tile + lane * PRAD_ROW16_PITCH);
+#pragma unroll 2
+      for (int qd = 0; qd < PRAD_ROW16_EL / 8; qd++) {
+        const uint4 d = row[qd];
+        const u32 wds[4] = {d.x, d.y, d.z, d.w};
+        // a stretch outside the ROI is no run: its "length" restarts (the cursor must stay inside row 0's slots)
+        q = select_i32(p < T.S, k1v, q);
+        // 8 plain steps are safe while 4 len + 4 * 8 stays within the length slots (an event records at most len + 7)
+        if (LONG && __ballot((unsigned)(q - p - k1v) + 32u > (unsigned)T.lenlim) != 0) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const u32 c = wds[k], x = __builtin_amdgcn_alignbyte(c, pw, 2);
+#pragma unroll
+            for (int b = 0; b < 2; b++)
+              fw2_checked<LONG, false>(T, k1v, dummy, p, q, (int)((x >> (16 * b)) & 0xffffu), (int)((c >> (16 * b)) & 0xffffu), false);
+            pw = c;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            fw2_row_word(T, k1v, one, p, q, wds[k], __builtin_amdgcn_alignbyte(wds[k], pw, 2));
+            pw = wds[k];
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    fw2_checked<LONG, false>(T, k1v, dummy, p, q, (int)(pw >> 16), 0, false);   // the row ends: close its open run
+  }
+  fw2_flush(lds, T, slot, glcm_acc, glrlm_acc);
 }
 
 // pack for this path: 16-bit level*4 elements (rows of pitch16 BYTES) and, for the rows kernel, plain 8-bit levels

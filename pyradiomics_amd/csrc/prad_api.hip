@@ -279,6 +279,11 @@ struct SweepPlan {
   bool LONGfw2 = false;
   size_t lds_fw2 = 0;
   int pitch16 = 0;             // bytes per row of the 16-bit level volume
+  // the x angle of a two-table volume on the 16-bit levels (sweep_fw2_rows_kernel): table + one staging tile per wave
+  bool fw2_rows = false;
+  int RS2r = 0, fw2r_copies = 1, fw2r_waves = 16;
+  bool LONGfw2r = false;
+  size_t lds_fw2_rows = 0;
   FwSet fwset;
 };
 
@@ -365,6 +370,33 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
       p.lds_fw2 = 4 * fw2_table_words(Ng, p.RS2, copies);
       p.RS = 0;
       p.RSr = rsr;
+      // the x angle with the same two tables (round 5): as many waves (16, 8, 4 -- the walk is a serial chain per lane) as
+      // leave the table next to their 5 KB staging tiles >= 32 length slots (4 waves: >= 24); else the rows kernel of
+      // kernels_sweep.h on the 8-bit copy as before
+      for (int waves = 16; waves >= 4 && !p.fw2_rows && !getenv("PRAD_NO_FW2_ROWS"); waves >>= 1) {
+        if (const char *e = getenv("PRAD_FW2_ROWS_WAVES")) {   // tuning override
+          if (atoi(e) != waves) continue;
+        }
+        const long long mw = ((158 * 1024) - (long long)waves * 64 * PRAD_ROW16_PITCH) / 4;
+        const long long rm = mw / (Ng + 1) - (Ng + 1);
+        if (rm < std::min<long long>(waves > 4 ? 32 : 24, Nr)) continue;
+        int cc = 1;
+        long long r2 = std::min<long long>(std::min<long long>(rm, 64), Nr);
+        for (int c2 = 4; c2 >= 2; c2 >>= 1)
+          if (rm / c2 >= std::min<long long>(32, Nr)) {
+            cc = c2;
+            r2 = std::min<long long>(std::min<long long>(rm / c2, 64), Nr);
+            break;
+          }
+        if (r2 < Nr && ((Ng + 1 + cc * r2) & 1) == 0) r2--;      // odd row stride, as above
+        if (r2 < 1) continue;
+        p.fw2_rows = true;
+        p.RS2r = (int)r2;
+        p.fw2r_copies = cc;
+        p.fw2r_waves = waves;
+        p.LONGfw2r = r2 < Nr;
+        p.lds_fw2_rows = ((4 * fw2_table_words(Ng, p.RS2r, cc) + 15) & ~(size_t)15) + (size_t)waves * 64 * PRAD_ROW16_PITCH;
+      }
     }
   }
   if (!p.fused && !p.fw2) {
@@ -642,6 +674,18 @@ int launch_fw_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, i
   return check_launch("sweep_fw_rows_kernel");
 }
 
+template <bool LNG>
+int launch_fw2_rows(Call &k, const SweepPlan &p, const uint8_t *levels16, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *flags_d) {
+  const long long nrows = (long long)p.Nz * p.Ny, groups = nrows >= 4096 ? ((nrows + 511) / 512) * 8 : (nrows + 63) / 64;
+  const int wpb = p.fw2r_waves;
+  const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + wpb - 1) / wpb, (long long)cu_count()));
+  PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw2_rows_kernel<LNG>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw2_rows));
+  hipLaunchKernelGGL((sweep_fw2_rows_kernel<LNG>), dim3(gx), dim3(64 * wpb), p.lds_fw2_rows, k.s, levels16, nrows, p.Nx, p.pitch16,
+                     p.row_slot, Ng, Nr, p.RS2r, p.fw2r_copies, glcm_acc, glrlm_acc, flags_d);
+  return check_launch("sweep_fw2_rows_kernel");
+}
+
 template <bool G, bool R, bool LNG, bool F>
 int launch_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc,
                 int *multi) {
@@ -799,8 +843,14 @@ int launch_sweeps(Call &k, const VolState &v, const PackJob &pj) {
     }
     if (p.row_slot >= 0) {
       Timed t(*k.c, "rows", k.s);
-      if (p.LONGr) PRAD_TRY((launch_rows<G, R, true, F>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi)));
-      else PRAD_TRY((launch_rows<G, R, false, F>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi)));
+      if (p.fw2_rows) {
+        if (p.LONGfw2r) PRAD_TRY(launch_fw2_rows<true>(k, p, v.levels16, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.flags_d));
+        else PRAD_TRY(launch_fw2_rows<false>(k, p, v.levels16, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.flags_d));
+      } else if (p.LONGr) {
+        PRAD_TRY((launch_rows<G, R, true, F>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi)));
+      } else {
+        PRAD_TRY((launch_rows<G, R, false, F>(k, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi)));
+      }
     }
     return PRAD_OK;
   }

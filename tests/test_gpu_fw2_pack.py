@@ -177,3 +177,71 @@ def test_fw2_pipeline_equals_lanes_and_synchronous_512(cm, monkeypatch):
         for g, r, _ in got:
             assert torch.equal(g, g0) and torch.equal(r, r0), dist
         del im, mk
+
+
+# ---- the x angle of a two-table volume on the 16-bit levels (sweep_fw2_rows_kernel, round 5) ---------------------------------
+def _check_x(cm, checker, img, mask, Ng):
+    from pyradiomics_amd import _lib
+    Nr = int(max(img.shape))
+    g, r, ang = cm.calculate_glcm_glrlm(img, mask, Ng, Nr, False, 0)
+    assert _lib.last_path() == "sweep" and _lib.last_variant() == "fw2"
+    eg, eang = checker.calculate_glcm(img, mask, [1], Ng, False, 0)
+    er, _ = checker.calculate_glrlm(img, mask, Ng, Nr, False, 0)
+    assert np.array_equal(ang, eang)
+    bad = np.argwhere(g != eg)
+    assert bad.size == 0, "GLCM differs at %d entries, first (i, j, angle) = %s: %s vs %s; angle %s" % (
+        len(bad), bad[0], g[tuple(bad[0])], eg[tuple(bad[0])], ang[bad[0][-1]])
+    bad = np.argwhere(r != er)
+    assert bad.size == 0, "GLRLM differs at %d entries, first (i, len-1, angle) = %s: %s vs %s; angle %s" % (
+        len(bad), bad[0], r[tuple(bad[0])], er[tuple(bad[0])], ang[bad[0][-1]])
+
+
+@pytest.mark.parametrize("Ng", [64, 100, 128, 160, 45])
+@pytest.mark.parametrize("nx", [512, 300, 72])
+def test_fw2_rows_runs_around_the_last_length_slot(cm, checker, Ng, nx):
+    """runs along x of every length from 18 to 81 -- the table keeps 48 .. 63 length slots at these level counts (prad_api.hip
+    plan_sweep; PRAD_FW2_ROWS_WAVES moves them), so lengths below, at and above the last slot -- starting at every offset of
+    the 8-voxel blocks the plain path vouches for, ending inside the row, at the row's last voxel and at the ROI's edge; a
+    run longer than the slots goes to the global table"""
+    rng = np.random.default_rng(Ng + nx)
+    shape = (5, 46, nx)
+    img = rng.integers(1, Ng + 1, size=shape).astype(np.int32)
+    mask = np.ones(shape, bool)
+    row = 0
+    for z in range(shape[0]):
+        for y in range(shape[1]):
+            L = 18 + row % 64
+            x = row % 9
+            lv = 1 + row % Ng
+            while x + L <= nx:
+                img[z, y, x:x + L] = lv
+                lv = 1 + (lv + 6) % Ng
+                x += L
+            if row % 5 == 0:                      # the last run ends with the row
+                img[z, y, max(0, nx - L):] = 1 + (lv + 3) % Ng
+            if row % 7 == 0 and nx > L + 20:      # ... or at a voxel outside the ROI
+                mask[z, y, 10 + L] = False
+                img[z, y, 10:10 + L] = 2
+            row += 1
+    _check_x(cm, checker, img, mask, Ng)
+    _check_x(cm, checker, img, _mask(3, shape, "random"), Ng)
+
+
+@pytest.mark.parametrize("Ng", [64, 129, 160])
+def test_fw2_rows_kernel_equals_the_8_bit_rows_kernel(cm, Ng, monkeypatch):
+    """the new x-angle kernel against the one it replaces (PRAD_NO_FW2_ROWS=1: kernels_sweep.h on the 8-bit copy), on a volume
+    the CPU checker would take minutes for; more than 4096 rows (tile rows 8 apart) and fewer"""
+    import torch
+    from pyradiomics_amd import engine
+    for shape in ((96, 80, 512), (30, 40, 200)):
+        for kind, mkind in (("smooth", "ball"), ("uniform", "full"), ("blobs", "random")):
+            img = torch.from_numpy(_levels(31 + Ng, shape, Ng, kind)).cuda()
+            mask = torch.from_numpy(_mask(9, shape, mkind).astype(np.uint8)).cuda()
+            monkeypatch.delenv("PRAD_NO_FW2_ROWS", raising=False)
+            g1, r1, _ = engine.glcm_glrlm(img, mask, Ng, 512)
+            g1, r1 = g1.clone(), r1.clone()
+            assert engine.last_variant() == "fw2"
+            monkeypatch.setenv("PRAD_NO_FW2_ROWS", "1")
+            g0, r0, _ = engine.glcm_glrlm(img, mask, Ng, 512)
+            assert torch.equal(g0, g1) and torch.equal(r0, r1), (shape, kind, mkind)
+    monkeypatch.delenv("PRAD_NO_FW2_ROWS", raising=False)
