@@ -800,9 +800,11 @@ def main() -> None:
                     ms2 = el / args.steps * 1e3
                     out[d] = {"value": round(nvox * args.steps / el / 1e6, 1), "unit": "Mvoxels/s", "ms_per_step": round(ms2, 4),
                               "vs_32_levels": round(ms2 / (elapsed / args.steps * 1e3), 3) if d == "uniform" else None,
+                              "kernel_ms": round(f2["sweep"], 4), "rows_ms": round(f2["rows"], 4),
                               "variant": engine.last_variant()}
                     del im2, mk2
-                out["case"] = "the headline loop at 64 grey levels (same size / steps), deferred calls"
+                out["case"] = ("the headline loop at 64 grey levels (same size / steps), deferred calls: two-table walk with the next "
+                               "volume's pack as a side job (kernel_ms), x angle on the 16-bit levels (rows_ms)")
                 return out
             if args.levels == 32:
                 guarded("levels64", levels64)
