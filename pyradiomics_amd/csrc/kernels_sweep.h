@@ -809,7 +809,9 @@ struct AngleSet {
   int count;
   int off[PRAD_MAX_SWEEP][3];
 };
-__global__ void __launch_bounds__(256) multi_check_kernel(AngleSet A, const uint8_t *__restrict__ L, int Nz, int Ny,
+// T: element type of the packed volume (uint8_t, or the 16-bit elements of kernels_sweepfw2.h); pitch in ELEMENTS
+template <typename T>
+__global__ void __launch_bounds__(256) multi_check_kernel(AngleSet A, const T *__restrict__ L, int Nz, int Ny,
                                                           int Nx, int pitch, int *__restrict__ multi) {
   const int a = blockIdx.y;
   if (multi[a]) return;

@@ -190,8 +190,8 @@ __device__ __forceinline__ void fw2_make_x(const u32 (&P)[K / 2], u32 (&X)[K / 2
 // have the reasons: the pack is HBM-bound, the walk is bound by its LDS atomics, so the pack's memory time disappears behind
 // the walk and only its VALU instructions remain -- as a launch of its own the pack costs 0.20 ms of a 0.85 ms step at
 // 512^3 x 64 levels, profiles/r05b_probe64.json).  A unit is 64 pieces of 16 voxels; a lane turns the 16 int32 levels + 16
-// mask bytes of its piece into 16 16-bit elements (level*4: two 16-byte stores into J.levels16) and 16 plain level bytes for
-// the rows kernel (one 16-byte store into J.levels).  Needs the linear layouts (pitch16 == 2 NX, pitch == NX: NX % 16 == 0)
+// mask bytes of its piece into 16 16-bit elements (level*4: two 16-byte stores into J.levels16) and, when J.levels != NULL, 16
+// plain level bytes (one 16-byte store: only plans whose x angle still takes the rows kernel of kernels_sweep.h read them).  Needs the linear layouts (pitch16 == 2 NX, pitch == NX: NX % 16 == 0)
 // and 16-byte aligned arrays.  Same results as pack_levels16_kernel for every input (tests/test_gpu_fw2_pack.py).
 struct PackWave16 {
   unsigned long long img, msk;   // this lane's next piece: image + 64 t, mask + 16 t (byte addresses)
@@ -288,11 +288,14 @@ struct PackWave16 {
         nzany |= nz;
       }
       u32 o16[8], o8[4];
+      const bool want8 = J.levels != nullptr;      // (wave-uniform: the plain byte copy, only for plans that still read one)
       if ((((~nzall) & K80) | (badbits & H80) | (wideall & 0xffff0000u)) == 0) {
 #pragma unroll
         for (int i = 0; i < 8; i++) o16[i] = h[i] << PRAD_FUSED_SHIFT;
+        if (want8) {
 #pragma unroll
-        for (int w = 0; w < 4; w++) o8[w] = __builtin_amdgcn_perm(h[2 * w + 1], h[2 * w], 0x06040200u);
+          for (int w = 0; w < 4; w++) o8[w] = __builtin_amdgcn_perm(h[2 * w + 1], h[2 * w], 0x06040200u);
+        }
       } else if ((nzany & K80) == 0) {
 #pragma unroll
         for (int i = 0; i < 8; i++) o16[i] = 0;
@@ -318,7 +321,7 @@ struct PackWave16 {
       uint4 *d16 = reinterpret_cast<uint4 *>(J.levels16 + 2ull * e);
       d16[0] = make_uint4(o16[0], o16[1], o16[2], o16[3]);
       d16[1] = make_uint4(o16[4], o16[5], o16[6], o16[7]);
-      *reinterpret_cast<uint4 *>(J.levels + e) = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+      if (want8) *reinterpret_cast<uint4 *>(J.levels + e) = make_uint4(o8[0], o8[1], o8[2], o8[3]);
     }
     img += 64ull * step16;
     msk += 16ull * step16;
@@ -849,7 +852,8 @@ __global__ void __launch_bounds__(1024) sweep_fw2_rows_kernel(const uint8_t *__r
   fw2_flush(lds, T, slot, glcm_acc, glrlm_acc);
 }
 
-// pack for this path: 16-bit level*4 elements (rows of pitch16 BYTES) and, for the rows kernel, plain 8-bit levels
+// pack for this path: 16-bit level*4 elements (rows of pitch16 BYTES) and, when L8 != NULL (plans whose x angle still takes the
+// rows kernel of kernels_sweep.h), plain 8-bit levels
 __global__ void __launch_bounds__(256) pack_levels16_kernel(const int *__restrict__ image, const uint8_t *__restrict__ mask,
                                                             long long n, int NX, int pitch16, int pitch8, int Ng,
                                                             uint8_t *__restrict__ L16, uint8_t *__restrict__ L8,
@@ -877,7 +881,7 @@ __global__ void __launch_bounds__(256) pack_levels16_kernel(const int *__restric
       const int x = (int)(t - row * upr) << 2;
       *reinterpret_cast<uint2 *>(L16 + row * pitch16 + 2 * x) =
           make_uint2((e[0] << PRAD_FUSED_SHIFT) | (e[1] << (16 + PRAD_FUSED_SHIFT)), (e[2] << PRAD_FUSED_SHIFT) | (e[3] << (16 + PRAD_FUSED_SHIFT)));
-      *reinterpret_cast<u32 *>(L8 + row * pitch8 + x) = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
+      if (L8) *reinterpret_cast<u32 *>(L8 + row * pitch8 + x) = e[0] | (e[1] << 8) | (e[2] << 16) | (e[3] << 24);
     }
   } else {
     for (long long i = tid; i < n; i += nthreads) {
@@ -888,7 +892,7 @@ __global__ void __launch_bounds__(256) pack_levels16_kernel(const int *__restric
       const long long row = i / NX;
       const int x = (int)(i - row * NX);
       *reinterpret_cast<unsigned short *>(L16 + row * pitch16 + 2 * x) = (unsigned short)(regular ? (l << PRAD_FUSED_SHIFT) : 0);
-      L8[row * pitch8 + x] = (uint8_t)(regular ? l : 0);
+      if (L8) L8[row * pitch8 + x] = (uint8_t)(regular ? l : 0);
     }
   }
   if (bad) flags[0] = 1;

@@ -738,8 +738,12 @@ int vol_prepare(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, doubl
   v.glrlm = glrlm;
   v.flags_d = k.flags_d;
   const long long nrows = (long long)p.Nz * p.Ny;
-  PRAD_TRY(c.get<uint8_t>("levels", (size_t)nrows * p.pitch + 1024, &v.levels));
-  v.levels += 512;   // the fixed-window kernel reads (and masks) up to one window before the first and behind the last row
+  // (a two-table volume whose x angle walks the 16-bit elements keeps no byte copy: round 5b)
+  v.levels = nullptr;
+  if (!(p.fw2 && p.fw2_rows && p.lines.count > 0 && p.row_slot >= 0) || getenv("PRAD_FW2_KEEP8")) {
+    PRAD_TRY(c.get<uint8_t>("levels", (size_t)nrows * p.pitch + 1024, &v.levels));
+    v.levels += 512;   // the fixed-window kernel reads (and masks) up to one window before the first and behind the last row
+  }
   v.levels16 = nullptr;
   if (p.fw2) {
     PRAD_TRY(c.get<uint8_t>("levels16", (size_t)nrows * p.pitch16 + 4096, &v.levels16));
@@ -923,8 +927,12 @@ int vol_finalize(Call &k, const VolState &v, int *sticky) {
                            glcm, v.multi);
         PRAD_TRY(check_launch("glcm_diag_resolve_kernel"));
       }
-      hipLaunchKernelGGL(multi_check_kernel, dim3(128, Na), dim3(256), 0, k.s, p.aset, v.levels, p.Nz, p.Ny, p.Nx,
-                         p.pitch, v.multi);
+      if (v.levels)
+        hipLaunchKernelGGL(multi_check_kernel<uint8_t>, dim3(128, Na), dim3(256), 0, k.s, p.aset, (const uint8_t *)v.levels, p.Nz, p.Ny,
+                           p.Nx, p.pitch, v.multi);
+      else
+        hipLaunchKernelGGL(multi_check_kernel<unsigned short>, dim3(128, Na), dim3(256), 0, k.s, p.aset,
+                           reinterpret_cast<const unsigned short *>(v.levels16), p.Nz, p.Ny, p.Nx, p.pitch16 / 2, v.multi);
       PRAD_TRY(check_launch("multi_check_kernel"));
     }
     if (glrlm) {
