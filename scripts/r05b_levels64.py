@@ -35,8 +35,14 @@ for dist in ("uniform", "smooth"):
     out["64_%s_pipeline" % dist] = run(64, dist, [])
     out["64_%s_lanes" % dist] = run(64, dist, ["PRAD_FW2_LANES=1"])
 for e in extra:
+    lv = 64
+    if e.startswith("32:"):          # "32:ENV=VAL": the same at 32 levels
+        lv, e = 32, e[3:]
     env = e.split(",")
     for dist in ("uniform", "smooth"):
-        out["64_%s_%s" % (dist, e)] = run(64, dist, env)
+        key = "%d_%s_%s" % (lv, dist, e)
+        while key in out:
+            key += "_again"
+        out[key] = run(lv, dist, env)
 out["64_uniform_pipeline_again"] = run(64, "uniform", [])
 print(json.dumps(out, indent=1))
