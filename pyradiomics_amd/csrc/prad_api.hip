@@ -800,7 +800,10 @@ PackJob make_pack_job(const Call &k, const VolState &v, const VolState *host) {
     waves = 16.0 * std::max(1, host->p.fw_blocks);
   }
   const double units = (double)j.n16 / 64.0;
-  j.every = (int)std::max(1.0, std::min(64.0, std::floor(0.92 * groups / std::max(1.0, units))));
+  // (two-table walk: a unit every 3rd group instead of every 2nd at 512^3 -- 0.707 -> 0.698 ms per volume, smooth inside its run-to-run spread of 0.75 - 0.78;
+  //  the fused-table walk measures best at 2: 0.490 against 0.496 at 3, profiles/r05b_probes.md)
+  const double slack = v.p.fw2 ? 1.05 : 0.92;
+  j.every = (int)std::max(1.0, std::min(64.0, std::floor(slack * groups / std::max(1.0, units))));
   (void)waves;
   if (const char *e = getenv("PRAD_PACK_EVERY")) j.every = std::max(1, atoi(e));
   return j;
