@@ -515,8 +515,26 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
       const int nroles = p.lines.count;
       int total = cu_count();
       if (const char *e = getenv("PRAD_FW_BLOCKS")) total = std::max(nroles, atoi(e));   // tuning override: workgroups of the launch
+      // The remainder of the division goes to the roles that cost most per line (round 5b): the wave life by role of
+      // profiles/r05_fw_phases.md x the workgroups each role had gives 19.5 - 19.6 (lines that drift in x AND wrap in the row
+      // dimension), 18.8 - 19.2 (one of the two), 18.1 - 18.5 (neither); until then the first `total % nroles` roles of the
+      // angle list took it -- two of the light ones among them -- and the launch waited for role 6 (PRAD_FW_EXTRA_FIRST=1: as then)
+      int bonus[PRAD_MAX_SWEEP] = {0};
+      {
+        int left = total % nroles;
+        const bool as_listed = getenv("PRAD_FW_EXTRA_FIRST") != nullptr;
+        for (int cls = as_listed ? 0 : 2; cls >= 0 && left > 0; cls--)
+          for (int r = 0; r < nroles && left > 0; r++) {
+            const SweepDesc &S = p.lines.d[r];
+            const int c = (S.dx != 0 ? 1 : 0) + (S.du != 0 ? 1 : 0);
+            if ((as_listed || c == cls) && !bonus[r]) {
+              bonus[r] = 1;
+              left--;
+            }
+          }
+      }
       p.fwset.first_block[0] = 0;
-      for (int r = 0; r < nroles; r++) p.fwset.first_block[r + 1] = p.fwset.first_block[r] + total / nroles + (r < total % nroles ? 1 : 0);
+      for (int r = 0; r < nroles; r++) p.fwset.first_block[r + 1] = p.fwset.first_block[r] + total / nroles + bonus[r];
       for (int r = nroles + 1; r < PRAD_MAX_SWEEP + 1; r++) p.fwset.first_block[r] = p.fwset.first_block[nroles];
       p.fw_blocks = p.fwset.first_block[nroles];
     }

@@ -14,8 +14,14 @@ im, mk = bench.make_volume(512, 32, "uniform", seed=0, device=dev)
 torch.cuda.synchronize()
 t00 = time.perf_counter()
 rows = []
-for i in range(8):
+ab = len(sys.argv) > 3        # third argument: A/B of the remainder-workgroup allocation (PRAD_FW_EXTRA_FIRST=1 = as until round 5a)
+for i in range(16 if ab else 8):
+    if ab:
+        if (i // 4) % 2 == 1:
+            os.environ["PRAD_FW_EXTRA_FIRST"] = "1"
+        else:
+            os.environ.pop("PRAD_FW_EXTRA_FIRST", None)
     el, fam, _ = bench.headline_loop(engine, im, mk, 32, 512, steps, warm, torch.cuda.synchronize, [[None, None] for _ in range(4)], families=False)
     rows.append({"loop": i, "t_since_start_ms": round((time.perf_counter() - t00) * 1e3, 1), "ms_per_step": round(el / steps * 1e3, 4),
-                 "kernel_ms": round(fam["sweep"], 4)})
+                 "kernel_ms": round(fam["sweep"], 4), "extra_first": bool(os.environ.get("PRAD_FW_EXTRA_FIRST"))})
 print(json.dumps(rows, indent=1))
