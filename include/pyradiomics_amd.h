@@ -99,7 +99,10 @@ int prad_timing_end(void);
  * volume N-1 with the PACK of volume N riding in the same launch as a side job of the walking waves (the pack is
  * HBM-bound, the walk issue-bound: the pack's memory time disappears), then finalizes volume N-1.  Volume N is walked by
  * the next deferred call, or by prad_deferred_join / prad_deferred_status, which flush the pipeline.  As with the lanes,
- * inputs and outputs of a deferred call belong to the library until one of those two returns. */
+ * inputs and outputs of a deferred call belong to the library until one of those two returns.  The pipeline takes the
+ * volumes of the fixed-window kernels -- fused table (up to 44 levels) and, since round 5, two tables (45 .. 160 levels;
+ * a volume of the other kind than the one before it packs in a launch of its own) -- every other whole-volume call is
+ * dealt onto the lanes. */
 #define PRAD_E_DEFERRED (-6)
 int prad_set_deferred(int on);
 int prad_set_lanes(int n);                 /* 0 = default; returns PRAD_E_ARG outside [0, 4] */
