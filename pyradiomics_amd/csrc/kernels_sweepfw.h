@@ -208,6 +208,15 @@ __device__ __forceinline__ void fw_plain_word(const FwTab &T, int dummy, u32 one
 #else
 #define PRAD_FW_DSADD "ds_add_u32 %[t], %[one]\n\t"
 #endif
+#ifdef PRAD_FW_DSLATE   // A/B (round 6): the atomic behind the fresh-state instruction (one VALU between the address and its use)
+#define PRAD_FW_COL(J, PJ)                                                                                              \
+  "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:BYTE_" #J " src1_sel:BYTE_" #J "\n\t"                                    \
+  "v_add_u32_sdwa %[t], %[" PJ "], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t"      \
+  "v_mul_u32_u24_sdwa %[" PJ "], %[P4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t" \
+  PRAD_FW_DSADD                                                                                                          \
+  "s_mov_b64 exec, -1\n\t"                                                                                              \
+  "v_add_u32 %[" PJ "], %[Q], %[" PJ "]\n\t"
+#else
 #define PRAD_FW_COL(J, PJ)                                                                                              \
   "v_cmpx_ne_u32_sdwa vcc, %[c], %[x] src0_sel:BYTE_" #J " src1_sel:BYTE_" #J "\n\t"                                    \
   "v_add_u32_sdwa %[t], %[" PJ "], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t"      \
@@ -215,6 +224,7 @@ __device__ __forceinline__ void fw_plain_word(const FwTab &T, int dummy, u32 one
   "v_mul_u32_u24_sdwa %[" PJ "], %[P4], %[c] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_" #J "\n\t" \
   "s_mov_b64 exec, -1\n\t"                                                                                              \
   "v_add_u32 %[" PJ "], %[Q], %[" PJ "]\n\t"
+#endif
   asm volatile(PRAD_FW_COL(0, "p0") PRAD_FW_COL(1, "p1") PRAD_FW_COL(2, "p2") PRAD_FW_COL(3, "p3")
                : [p0] "+v"(p0), [p1] "+v"(p1), [p2] "+v"(p2), [p3] "+v"(p3), [t] "=&v"(t)
                : [c] "v"(c), [x] "v"(x), [one] "v"(one), [P4] "s"(T.P4), [Q] "s"(T.Q)
@@ -1045,7 +1055,7 @@ __device__ __forceinline__ void fw_rows_role(const HistLayout &h, const FwTab &T
 // the whole launch 0.477 ms against 0.38 + 0.055 for the two launches -- and its code made the line roles' kernel half as
 // large again (profiles/r03_probes.md), so it stays a kernel of its own.
 template <bool LONG>
-__global__ void __launch_bounds__(512) sweep_fw_rows_kernel(const uint8_t *__restrict__ L, long long nrows, int NX, int pitch,
+__global__ void __launch_bounds__(1024) sweep_fw_rows_kernel(const uint8_t *__restrict__ L, long long nrows, int NX, int pitch,
                                                             int slot, int Ng, int Nr, int RS, u32 *__restrict__ glcm_acc,
                                                             u32 *__restrict__ glrlm_acc, int *__restrict__ flags) {
   extern __shared__ u32 lds[];

@@ -267,6 +267,8 @@ struct SweepPlan {
   bool fw = false;
   int fwK = 8;                 // window columns per lane (4: rows up to 256, 8: up to 512)
   int fw_blocks = 1;           // workgroups per angle
+  int fw_threads = 1024;       // threads per workgroup of the fixed-window launch
+  int fw_rows_threads = 512;   // ... and of the x angle's launch (sweep_fw_rows_kernel: one staging tile per wave)
   int RSfw = 0;                // run-length slots of its table (one workgroup per CU: most of the 160 KB)
   bool LONGfw = false;
   size_t lds_fw = 0;
@@ -500,8 +502,9 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
     p.LONGfw = p.RSfw < Nr;
     p.lds_fw = fw_lds_bytes(hist_layout(true, true, true, Ng, p.RSfw));
     if (p.row_slot >= 0 && p.fw) {   // the x angle: a launch of its own, 8 waves + their staging tiles (sweep_fw_rows_kernel)
-      const size_t tiles = (size_t)(kRowsThreads / 64) * 64 * PRAD_ROW_PITCH;
-      int rs = fit_rs(true, true, true, Ng, Nr, 100 * 1024);
+      if (const char *e = getenv("PRAD_FW_ROWS_THREADS")) p.fw_rows_threads = std::max(64, std::min(1024, atoi(e) & ~63));   // tuning override
+      const size_t tiles = (size_t)(p.fw_rows_threads / 64) * 64 * PRAD_ROW_PITCH;
+      int rs = fit_rs(true, true, true, Ng, Nr, std::min<size_t>(100 * 1024, (size_t)160 * 1024 - 2048 - tiles));
       for (int r = rs; rs < Nr && r >= std::max(16, rs - 12); r--) {   // same bank-stride rule as above
         const int d = (((r + 1) * (Ng + 1)) % 32 + 1) % 32, dist = std::min(d, 32 - d);
         if ((d & 1) && dist >= 5 && dist <= 11) { rs = r; break; }
@@ -515,6 +518,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
       const int nroles = p.lines.count;
       int total = cu_count();
       if (const char *e = getenv("PRAD_FW_BLOCKS")) total = std::max(nroles, atoi(e));   // tuning override: workgroups of the launch
+      if (const char *e = getenv("PRAD_FW_THREADS")) p.fw_threads = std::max(64, std::min(1024, atoi(e) & ~63));   // ... and their size
       // The remainder of the division goes to the roles that cost most per line (round 5b): the wave life by role of
       // profiles/r05_fw_phases.md x the workgroups each role had gives 19.5 - 19.6 (lines that drift in x AND wrap in the row
       // dimension), 18.8 - 19.2 (one of the two), 18.1 - 18.5 (neither); until then the first `total % nroles` roles of the
@@ -558,7 +562,7 @@ SweepPlan plan_sweep(const Call &k, int Ng, int Nr, bool want_glcm, bool want_gl
         p.fwset.pitch = p.pitch16;
       }
       p.fwset.nrows = p.Nz * p.Ny;
-      const long long want = (long long)per_wave * (p.fwset.first_block[i + 1] - p.fwset.first_block[i]) * 16;
+      const long long want = (long long)per_wave * (p.fwset.first_block[i + 1] - p.fwset.first_block[i]) * (p.fw_threads / 64);
       int pieces = (int)std::max<long long>(1, (want + D.NU - 1) / D.NU);
       int CL = ((D.NM + pieces - 1) / pieces + 7) & ~7;
       CL = std::max(CL, D.NM >= 128 ? 64 : 16);   // (shorter pieces only multiply the piece start / tail overhead)
@@ -618,7 +622,7 @@ int launch_fw_kpp(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t 
                   u32 *glcm_acc, u32 *glrlm_acc, int *multi, int *flags_d) {
   PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_kernel<LNG, K, HASPAD, PACK>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw));
-  hipLaunchKernelGGL((sweep_fw_kernel<LNG, K, HASPAD, PACK>), dim3(p.fw_blocks), dim3(1024), p.lds_fw, k.s, p.fwset, pj,
+  hipLaunchKernelGGL((sweep_fw_kernel<LNG, K, HASPAD, PACK>), dim3(p.fw_blocks), dim3(p.fw_threads), p.lds_fw, k.s, p.fwset, pj,
                      levels, rowzero, Ng, Nr, p.RSfw, glcm_acc, glrlm_acc, multi + 2 * PRAD_MAX_SWEEP + PRAD_FW_WORK_STRIDE, flags_d);
   return check_launch("sweep_fw_kernel");
 }
@@ -683,11 +687,11 @@ int launch_fw2(Call &k, const SweepPlan &p, const PackJob &pj, const uint8_t *le
 template <bool LNG>
 int launch_fw_rows(Call &k, const SweepPlan &p, const uint8_t *levels, int Ng, int Nr, u32 *glcm_acc, u32 *glrlm_acc, int *flags_d) {
   const long long nrows = (long long)p.Nz * p.Ny, groups = nrows >= 4096 ? ((nrows + 511) / 512) * 8 : (nrows + 63) / 64;
-  const int wpb = kRowsThreads / 64;
+  const int wpb = p.fw_rows_threads / 64;
   const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((groups + wpb - 1) / wpb, (long long)cu_count()));
   PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sweep_fw_rows_kernel<LNG>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fw_rows));
-  hipLaunchKernelGGL((sweep_fw_rows_kernel<LNG>), dim3(gx), dim3(kRowsThreads), p.lds_fw_rows, k.s, levels, nrows, p.Nx,
+  hipLaunchKernelGGL((sweep_fw_rows_kernel<LNG>), dim3(gx), dim3(p.fw_rows_threads), p.lds_fw_rows, k.s, levels, nrows, p.Nx,
                      p.pitch, p.row_slot, Ng, Nr, p.RSfw_rows, glcm_acc, glrlm_acc, flags_d);
   return check_launch("sweep_fw_rows_kernel");
 }
