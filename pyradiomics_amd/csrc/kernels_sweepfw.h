@@ -600,7 +600,11 @@ struct FwWave {
       // line walked on on the plain path, grew into alive0 = (level 1, length 1) and its next change was recorded as a short
       // run of level 1 (found by scripts/r05_stress.py: 138 x 58 x 300, runs of level 1 longer than RS + 1 across a piece
       // boundary; fixture tests/golden/regress/fw_long_runs_138x58x300.npz)
+#ifdef PRAD_DBG_R5BUG1   // test build: the margin as it was until round 5 (tests/test_gpu_stress.py must find it)
+      if (YOUNG) a = min(a, (unsigned)pl[j]);
+#else
       if (pl[j] < T.alive0 && xj != 0) a = YOUNG ? (unsigned)pl[j] : 0x7fffffffu;   // (not ~0u: the callers add the groups' growth to it)
+#endif
       m = max(m, a);
     }
     return m;
@@ -802,7 +806,11 @@ struct FwWave {
               // voxels that ended at the x edge on the plain path landed in the slot of "longer than RS" -- which only the GLCM
               // reads: lost for the GLRLM and the GLCM diagonal (found by scripts/r05_stress.py / r05_fw_bug_probe2.py on
               // the 256- and 512-wide crops of tests/golden/regress/fw_long_runs_138x58x300.npz: two runs of level 21, length 26 = RS + 1)
+#ifdef PRAD_DBG_R5BUG2   // test build: the plain-path bound of edge roles as it was until round 5
+              const unsigned lim = (unsigned)T.lenlim;
+#else
               const unsigned lim = (unsigned)T.lenlim - ((!haspad && DX != 0) ? (unsigned)T.Q : 0u);
+#endif
 #pragma unroll
               for (int q = PRAD_FW_MAXG; q >= 1; q--) {
                 if (safe == 0 && __ballot(m + q * U * T.Q > lim) == 0) safe = q;

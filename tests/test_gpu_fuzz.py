@@ -11,12 +11,20 @@ NG_CHOICES = [1, 2, 3, 7, 16, 32, 33, 44, 45, 64, 128, 255, 256, 300]
 DIM_CHOICES = [1, 2, 3, 4, 5, 7, 8, 13, 15, 16, 17, 24, 31, 32, 33, 40, 48, 63, 64, 65]
 
 
-def _case(rng):
+def _case(rng, deep=False):
     nd = int(rng.choice([2, 3, 3, 3, 3]))
     shape = tuple(int(rng.choice(DIM_CHOICES)) for _ in range(nd))
     while np.prod(shape) > 70000:
         shape = tuple(max(1, s // 2) for s in shape)
     Ng = int(rng.choice(NG_CHOICES))
+    if deep:
+        # a volume the fixed-window walk takes and cuts into >= 2 pieces per line (a march of >= 128 steps): dead piece starts,
+        # tails, runs across piece boundaries -- the ground the two round-5 bugs of sweep_fw_kernel sat on for three rounds
+        nd = 3
+        shape = (int(rng.integers(130, 200)), int(rng.integers(9, 24)), int(rng.choice([96, 128, 200, 256])))
+        if rng.random() < 0.4:
+            shape = (shape[1], shape[0], shape[2])
+        Ng = int(rng.choice([8, 32, 32, 44, 45, 64]))
     frac = float(rng.choice([1.0, 1.0, 0.9, 0.5, 0.08]))
     smooth = bool(rng.random() < 0.5)
     f = rng.random(shape)
@@ -41,8 +49,12 @@ def _case(rng):
 def test_random_configurations_match_oracle(seed, checker):
     from pyradiomics_amd import cmatrices as cm
     rng = np.random.default_rng(1000 + seed)
+    from pyradiomics_amd import _lib
     for it in range(16):
-        shape, Ng, img, mask, force2D, f2d, dist, alpha = _case(rng)
+        deep = it >= 14
+        shape, Ng, img, mask, force2D, f2d, dist, alpha = _case(rng, deep)
+        if deep:
+            force2D, f2d, dist = False, 0, [1]
         tag = "seed %d it %d shape %s Ng %d force2D %s/%d dist %s alpha %d" % (seed, it, shape, Ng, force2D, f2d, dist, alpha)
         Nr = max(shape)
         try:
@@ -57,6 +69,8 @@ def test_random_configurations_match_oracle(seed, checker):
         got = cm.calculate_glrlm(img, mask, Ng, Nr, force2D, f2d)
         assert np.array_equal(got[1], want[1]) and np.array_equal(got[0], want[0]), "GLRLM " + tag
         g, r, _ = cm.calculate_glcm_glrlm(img, mask, Ng, Nr, force2D, f2d)
+        if deep:
+            assert _lib.last_path() == "sweep" and _lib.last_variant() in ("fw", "fw2"), (tag, _lib.last_variant())
         assert np.array_equal(r, want[0]), "fused GLRLM " + tag
         assert np.array_equal(g, checker.calculate_glcm(img, mask, [1], Ng, force2D, f2d)[0]), "fused GLCM " + tag
         want = checker.calculate_gldm(img, mask, dist, Ng, alpha, force2D, f2d)
