@@ -161,6 +161,22 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
                            int Nd, int Ng, long long Ns, int classes, int symmetric, int alpha, int force2Ddim,
                            double voxelArrayShift, double **results, int *layout, int *ticket, void *stream);
 int prad_image_wait(int ticket);
+/* prad_image_enqueue_dev issued from a LAUNCHER thread that belongs to the calling thread (created on first use; it has a
+ * workspace, result arena, side streams and tickets of its own).  One derived image is ~65 launches, copies and fills: 0.25 ms
+ * of host time per image on a path that is bound by its host thread (featureextractor.py:371-395 + base.py:181-198 in the
+ * reference are that thread too).  prad_image_submit copies the arguments and returns at once (*job: slot of up to four in
+ * flight per thread); the side streams wait for what was queued on `stream` by the time the launcher gets to the job, i.e.
+ * at least for everything the caller queued before the call.  prad_image_submit_result blocks until the launcher has ISSUED
+ * the job (not until the GPU has run it) and returns prad_image_enqueue_dev's code, result block and layout;
+ * prad_image_submit_wait waits for the image's GPU work like prad_image_wait and frees the slot (it must be called exactly
+ * once per job, also after a failed submit).  Jobs of one calling thread are issued in order.  prad_image_submit_release:
+ * prad_release_workspace on the launcher's context (nothing may be in flight). */
+int prad_image_submit(const int32_t *levels, const uint8_t *mask, const void *raw, int raw_dtype, const int *size, int Nd, int Ng,
+                      long long Ns, int classes, int symmetric, int alpha, int force2Ddim, double voxelArrayShift, void *stream,
+                      int *job);
+int prad_image_submit_result(int job, double **results, int *layout);
+int prad_image_submit_wait(int job);
+int prad_image_submit_release(void);
 
 /* ---- angles: cmatrices.h get_angle_count / build_angles (cmatrices.c:756-892) ------------------- */
 /* returns the number of angles, 0 on invalid distance (as the reference) */
@@ -399,6 +415,15 @@ int prad_digitize_counts_dev(const void *image, int dtype, const uint8_t *mask, 
  * non-finite ROI (np.histogram widens the range then): the two-call route with host-built edges serves those. */
 int prad_bincount_dev(const void *image, int dtype, const uint8_t *mask, long long n, int binCount, int32_t *levels,
                       double *minmax, double *edges, int *max_level, long long *counts, void *stream);
+/* prad_bincount_dev in two halves, for callers that have other host work between "queued" and "needed" (the case pipeline
+ * bins derived image i + 1 while the host still collects image i: imageoperations.py:67-174 + base.py:119-125 are one
+ * synchronous step per feature class in the reference).  prad_bincount_enqueue_dev queues the same kernels and the copy of
+ * their 8 x (2 binCount + 7) result bytes into a pinned block and returns a ticket (up to four in flight per host thread);
+ * prad_bincount_wait waits for THAT work only (an event behind the copy) and fills the host outputs of prad_bincount_dev,
+ * with its return codes.  A ticket is waited for exactly once; `levels` must stay allocated until then. */
+int prad_bincount_enqueue_dev(const void *image, int dtype, const uint8_t *mask, long long n, int binCount, int32_t *levels,
+                              int *ticket, void *stream);
+int prad_bincount_wait(int ticket, double *minmax, double *edges, int *max_level, long long *counts);
 
 /* ---- first-order statistics of the ROI intensities (radiomics/firstorder.py:33-474; device pointers) -----------
  * Segment mode.  The reference computes these with numpy on image[mask] (firstorder.py:96-101); here the ROI is

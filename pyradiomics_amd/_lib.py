@@ -46,6 +46,11 @@ SYMBOLS = {
     "prad_image_enqueue_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _ip, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
                                          C.c_int, C.c_double, C.POINTER(C.c_void_p), _ip, _ip, _vp]),
     "prad_image_wait": (C.c_int, [C.c_int]),
+    "prad_image_submit": (C.c_int, [_vp, _vp, _vp, C.c_int, _ip, C.c_int, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_double, _vp, _ip]),
+    "prad_image_submit_result": (C.c_int, [C.c_int, C.POINTER(C.c_void_p), _ip]),
+    "prad_image_submit_wait": (C.c_int, [C.c_int]),
+    "prad_image_submit_release": (C.c_int, []),
     "prad_deferred_status": (C.c_int, [C.c_void_p]),
     "prad_deferred_mark": (C.c_int, [C.POINTER(C.c_int), C.c_void_p]),
     "prad_get_angle_count": (C.c_int, [_ip, _ip, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -80,6 +85,9 @@ SYMBOLS = {
                                           C.POINTER(C.c_longlong), _vp]),
     "prad_bincount_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, _vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                         C.POINTER(C.c_int), C.POINTER(C.c_longlong), _vp]),
+    "prad_bincount_enqueue_dev": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong, C.c_int, _vp, _ip, _vp]),
+    "prad_bincount_wait": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_longlong)]),
     "prad_voxel_texture_features_dev": (C.c_int, [C.c_int, _vp, _vp, _ip, C.c_int, _ip, C.c_int, C.c_int, C.c_int, C.c_int,
                                                   _vp, C.c_int, C.c_int, _ip, C.c_int, _vp, _vp]),
     "prad_glcm_features_dev": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _ip, _vp]),

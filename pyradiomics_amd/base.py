@@ -100,8 +100,13 @@ class RadiomicsFeaturesBase:
         engine = _engine()
         key = ("levels", self.settings.get("binWidth", 25), self.settings.get("binCount"), id(self.maskArray))
         memo = self.inputImage._derived
-        if key not in memo:
-            levels, top, edges, counts = engine.bin_image(tensor, self.maskArray, with_counts=True, **self.settings)
+        pending = memo.get(key)
+        if pending is None or type(pending) is dict:
+            if pending is not None:       # queued by prebinDevice() while the host worked on the image before this one
+                del memo[key]
+                levels, top, edges, counts = engine.bin_image_collect(pending, with_counts=True)
+            else:
+                levels, top, edges, counts = engine.bin_image(tensor, self.maskArray, with_counts=True, **self.settings)
             levels._prad_memo = {"mask": self.maskArray}      # lets cMatrices serve GLCM and GLRLM from one sweep
             memo[key] = (levels, np.flatnonzero(counts[1:]) + 1, int(counts[1:].sum()), self.maskArray,
                          counts[1:][counts[1:] > 0])
@@ -111,6 +116,34 @@ class RadiomicsFeaturesBase:
         self.coefficients["Ng"] = int(grayLevels.max())
         self.coefficients["Ns"] = Ns
         return levels
+
+    @staticmethod
+    def prebinDevice(inputImage, inputMask, **settings):
+        """Queues the discretisation a feature class built on (inputImage, inputMask, settings) will ask for, without waiting
+        for it (engine.bin_image_enqueue); _applyBinningDevice collects it.  The case pipeline calls this for derived image
+        i + 1 before it collects image i, so the one host round trip of a binning (ROI min / max -> number of levels) has
+        passed by the time the classes of image i + 1 are constructed.  Returns True when something was queued."""
+        image, mask = as_image(inputImage), as_image(inputMask)
+        maskArray = imageoperations.roiTensor(mask, settings.get("label", 1))
+        key = ("levels", settings.get("binWidth", 25), settings.get("binCount"), id(maskArray))
+        if key in image._derived:
+            return False
+        token = _engine().bin_image_enqueue(image.device_tensor(), maskArray, **settings)
+        if token is None:
+            return False
+        image._derived[key] = token
+        return True
+
+    @staticmethod
+    def dropPrebinned(inputImage):
+        """waits for and discards what prebinDevice queued for an image that is not going to be evaluated (never raises)"""
+        memo = getattr(inputImage, "_derived", None) or {}
+        for key in [k for k, v in memo.items() if type(k) is tuple and k and k[0] == "levels" and type(v) is dict]:
+            token = memo.pop(key)
+            try:
+                _engine().bin_image_collect(token)
+            except Exception:      # noqa: BLE001
+                pass
 
     @property
     def cMatrices(self):

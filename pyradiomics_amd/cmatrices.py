@@ -365,9 +365,11 @@ def voxel_texture_features(cls, image, mask, distances, Ng, force2D, force2Ddime
 # ---- segment-mode features evaluated on the device matrices (prad_glcm_features_dev / prad_zone_matrix_features_dev)
 def _angle_mean(per_angle, empty):
     """np.nanmean over the angles the reference keeps (all-empty angles are deleted, e.g. glcm.py:186-198)"""
-    kept = per_angle[~empty]
+    kept = per_angle[~empty] if empty.any() else per_angle
     if kept.shape[0] == 0:
         return np.full(per_angle.shape[1], np.nan)
+    if not np.isnan(kept).any():
+        return kept.mean(0)          # (what nanmean computes without a NaN: sum over the angles / their number)
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", RuntimeWarning)
@@ -411,20 +413,32 @@ def segment_image_enqueue(levels, mask, Ng, Ns, requests, force2D=False, force2D
                                symmetric=take.get("glcm", {}).get("symmetrical", True), alpha=int(take.get("gldm", {}).get("alpha", 0)),
                                force2D=force2D, force2Ddimension=force2Ddimension,
                                voxelArrayShift=float(fo["shift"]) if fo else 0.0)
-    res, lay, Na = tok["res"], tok["layout"], tok["layout"][11]
-
+    # (with the image launcher the result block and its layout arrive with segment_image_wait: everything below reads them
+    #  from the token when it runs, i.e. after the wait; a class the device route declined -- layout -1 -- then says so)
     def flags(k, count):
+        res, lay = tok["res"], tok["layout"]
         return res[lay[k]:lay[k] + (count + 1) // 2 + 1].view(np.int32)[:count]
 
     def named(rq, vals):
-        return {f: float(vals[rq["table"].index(f)]) for f in rq["feats"]}
+        return dict(zip(rq["feats"], vals[rq["idx"]].tolist()))
 
+    def part(k, count):
+        res, lay = tok["res"], tok["layout"]
+        if lay[k] < 0:
+            raise NotImplementedError("declined by the device route")
+        return res[lay[k]:lay[k] + count]
+
+    for rq in take.values():
+        if "table" in rq:
+            rq["idx"] = np.array([rq["table"].index(f) for f in rq["feats"]], dtype=np.intp)
     out = {}
-    if "glcm" in take and lay[0] >= 0:
+    if "glcm" in take:
         rq = take["glcm"]
 
         def fin_glcm(rq=rq):
-            vals = res[lay[0]:lay[0] + Na * 23].reshape(Na, 23)
+            res, lay = tok["res"], tok["layout"]
+            Na = lay[11]
+            vals = part(0, Na * 23).reshape(Na, 23)
             r = named(rq, _angle_mean(vals, flags(1, Na) != 0)) if rq["feats"] else {}
             if rq["mcc"] and lay[2] >= 0 and res[lay[2] + Na] == 0:
                 import warnings
@@ -433,17 +447,19 @@ def segment_image_enqueue(levels, mask, Ng, Ns, requests, force2D=False, force2D
                     r["MCC"] = float(np.nanmean(res[lay[2]:lay[2] + Na]))
             return r
         out["glcm"] = fin_glcm
-    if "glrlm" in take and lay[3] >= 0:
-        out["glrlm"] = lambda rq=take["glrlm"]: named(rq, _angle_mean(res[lay[3]:lay[3] + Na * 16].reshape(Na, 16),
-                                                                       flags(4, Na) != 0))
-    if "gldm" in take and lay[5] >= 0:
-        out["gldm"] = lambda rq=take["gldm"]: named(rq, _angle_mean(res[lay[5]:lay[5] + 16].reshape(1, 16), flags(6, 1) != 0))
-    if "ngtdm" in take and lay[7] >= 0:
-        out["ngtdm"] = lambda rq=take["ngtdm"]: named(rq, res[lay[7]:lay[7] + 5])
-    if "glszm" in take and lay[8] >= 0:
+    if "glrlm" in take:
+        def fin_glrlm(rq=take["glrlm"]):
+            Na = tok["layout"][11]
+            return named(rq, _angle_mean(part(3, Na * 16).reshape(Na, 16), flags(4, Na) != 0))
+        out["glrlm"] = fin_glrlm
+    if "gldm" in take:
+        out["gldm"] = lambda rq=take["gldm"]: named(rq, _angle_mean(part(5, 16).reshape(1, 16), flags(6, 1) != 0))
+    if "ngtdm" in take:
+        out["ngtdm"] = lambda rq=take["ngtdm"]: named(rq, part(7, 5))
+    if "glszm" in take:
         def fin_glszm(rq=take["glszm"]):
-            vals = res[lay[8]:lay[8] + 17]
-            if vals[16] != 0:       # the device-side ranking declined / the reference's IndexError: the exact route
+            vals = part(8, 17) if tok["layout"][8] >= 0 else None
+            if vals is None or vals[16] != 0:       # the one-queue route or its device-side ranking declined / the reference's IndexError: the exact route
                 P, sizes = engine.glszm_compact(levels, mask, int(Ng), Ns, force2D, force2Ddimension)
                 if len(sizes) == 0:
                     raise NotImplementedError("no zones")
@@ -452,12 +468,13 @@ def segment_image_enqueue(levels, mask, Ng, Ns, requests, force2D=False, force2D
                 raise NotImplementedError("no zones")
             return named(rq, vals[:16])
         out["glszm"] = fin_glszm
-    if fo is not None and lay[10] >= 0:
+    if fo is not None:
         def fin_fo():
-            vals = res[lay[10]:lay[10] + 16]
-            if vals[15] != 0:
+            lay = tok["layout"]
+            vals = part(10, 16) if lay[10] >= 0 else None
+            if vals is None or vals[15] != 0:
                 return engine.firstorder_stats(_to_device(fo["raw"]), _to_device(mask), fo["shift"])
-            return dict(zip(engine.FIRSTORDER_FIELDS, (float(v) for v in vals[:15])))
+            return dict(zip(engine.FIRSTORDER_FIELDS, vals[:15].tolist()))
         out["firstorder"] = fin_fo
     return tok, out
 

@@ -26,7 +26,10 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
+#include <deque>
+#include <mutex>
 #include <thread>
 
 using namespace prad;
@@ -2693,25 +2696,37 @@ int prad_digitize_counts_dev(const void *image, int dtype, const uint8_t *mask, 
   return PRAD_OK;
 }
 
-int prad_bincount_dev(const void *image, int dtype, const uint8_t *mask, long long n, int binCount, int32_t *levels,
-                      double *minmax, double *edges, int *max_level, long long *counts, void *stream) {
-  Context &c = ctx();
-  PRAD_TRY(c.ensure_device());
-  if (!image || !mask || !levels || !minmax || n < 1) return fail(PRAD_E_ARG, "bincount: bad arguments");
-  if (dtype < 0 || dtype > 3) return fail(PRAD_E_ARG, "bincount: dtype %d", dtype);
-  if (binCount < 1 || binCount > 4096) return fail(PRAD_E_UNSUPPORTED, "bincount: binCount %d outside [1, 4096]", binCount);
-  hipStream_t s = (hipStream_t)stream;
+// the queueing half of prad_bincount_dev: slot in [0, PRAD_BIN_SLOTS) names the device block, the pinned block and the event
+namespace {
+constexpr int PRAD_BIN_SLOTS = 4;
+struct BinSlots {
+  int device = -1;
+  hipEvent_t done[PRAD_BIN_SLOTS] = {};
+  int nedges[PRAD_BIN_SLOTS] = {};
+  unsigned long long *host[PRAD_BIN_SLOTS] = {};
+  bool used[PRAD_BIN_SLOTS] = {};
+  unsigned seq = 0;
+};
+BinSlots &bin_slots() {
+  static thread_local BinSlots b;
+  return b;
+}
+int bincount_queue(Context &c, int slot, const void *image, int dtype, const uint8_t *mask, long long n, int binCount, int32_t *levels,
+                   hipStream_t s, unsigned long long **host_out) {
   const int nedges = binCount + 1;
   // one device block: [keys (2 u64) | info (8 B) | top (8 B) | counts (nedges + 1) | edges (nedges doubles)] -- one copy back
   unsigned long long *blk = nullptr;
   const size_t words = 2 + 1 + 1 + ((size_t)nedges + 1) + (size_t)nedges;
-  PRAD_TRY(c.get<unsigned long long>("bincount_blk", words, &blk));
+  char name_blk[32], name_pin[32];
+  snprintf(name_blk, sizeof(name_blk), "bincount_blk%d", slot);
+  snprintf(name_pin, sizeof(name_pin), "bincount_pin%d", slot);
+  PRAD_TRY(c.get<unsigned long long>(name_blk, words, &blk));
   unsigned long long *keys = blk;
   int *info = (int *)(blk + 2), *top = (int *)(blk + 3);
   unsigned long long *cnt_d = blk + 4;
   double *e_d = (double *)(blk + 4 + (size_t)nedges + 1);
   void *pin = nullptr;
-  PRAD_TRY(c.get_pinned("bincount_pin", sizeof(unsigned long long) * (words + 2), &pin));
+  PRAD_TRY(c.get_pinned(name_pin, sizeof(unsigned long long) * (words + 2), &pin));
   unsigned long long *h = (unsigned long long *)pin;
   PRAD_HIP(hipMemsetAsync(blk, 0, sizeof(unsigned long long) * words, s));
   h[words] = ~0ull;
@@ -2737,7 +2752,10 @@ int prad_bincount_dev(const void *image, int dtype, const uint8_t *mask, long lo
     default: PRAD_TRY(launch_digitize((const short *)image, mask, n, e_d, nedges, levels, top, cnt_d, s)); break;
   }
   PRAD_HIP(hipMemcpyAsync(h, blk, sizeof(unsigned long long) * words, hipMemcpyDeviceToHost, s));
-  PRAD_HIP(hipStreamSynchronize(s));
+  *host_out = h;
+  return PRAD_OK;
+}
+int bincount_collect(const unsigned long long *h, int nedges, double *minmax, double *edges, int *max_level, long long *counts) {
   if (h[1] == 0ull) return fail(PRAD_E_ARG, "roi_minmax: empty ROI");
   minmax[0] = f64_unkey(h[0]);
   minmax[1] = f64_unkey(h[1]);
@@ -2747,6 +2765,62 @@ int prad_bincount_dev(const void *image, int dtype, const uint8_t *mask, long lo
   if (counts) memcpy(counts, h + 4, sizeof(long long) * ((size_t)nedges + 1));
   if (edges) memcpy(edges, h + 4 + (size_t)nedges + 1, sizeof(double) * nedges);
   return PRAD_OK;
+}
+}  // namespace
+
+int prad_bincount_dev(const void *image, int dtype, const uint8_t *mask, long long n, int binCount, int32_t *levels,
+                      double *minmax, double *edges, int *max_level, long long *counts, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!image || !mask || !levels || !minmax || n < 1) return fail(PRAD_E_ARG, "bincount: bad arguments");
+  if (dtype < 0 || dtype > 3) return fail(PRAD_E_ARG, "bincount: dtype %d", dtype);
+  if (binCount < 1 || binCount > 4096) return fail(PRAD_E_UNSUPPORTED, "bincount: binCount %d outside [1, 4096]", binCount);
+  hipStream_t s = (hipStream_t)stream;
+  unsigned long long *h = nullptr;
+  PRAD_TRY(bincount_queue(c, PRAD_BIN_SLOTS, image, dtype, mask, n, binCount, levels, s, &h));   // (a block of its own: no ticket)
+  PRAD_HIP(hipStreamSynchronize(s));
+  return bincount_collect(h, binCount + 1, minmax, edges, max_level, counts);
+}
+
+// prad_bincount_dev in two halves (round 6: the case pipeline bins image i + 1 while the host still works on image i): the
+// queueing half returns a ticket, prad_bincount_wait(ticket, ...) waits for THAT work only (an event behind its copy) and hands
+// over what prad_bincount_dev returns.  Up to four tickets per thread; a ticket must be waited for exactly once.
+int prad_bincount_enqueue_dev(const void *image, int dtype, const uint8_t *mask, long long n, int binCount, int32_t *levels,
+                              int *ticket, void *stream) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!image || !mask || !levels || !ticket || n < 1) return fail(PRAD_E_ARG, "bincount_enqueue: bad arguments");
+  if (dtype < 0 || dtype > 3) return fail(PRAD_E_ARG, "bincount_enqueue: dtype %d", dtype);
+  if (binCount < 1 || binCount > 4096) return fail(PRAD_E_UNSUPPORTED, "bincount_enqueue: binCount %d outside [1, 4096]", binCount);
+  BinSlots &b = bin_slots();
+  if (b.device != c.device) {
+    for (int t = 0; t < PRAD_BIN_SLOTS; t++) {
+      if (b.done[t]) (void)hipEventDestroy(b.done[t]);
+      PRAD_HIP(hipEventCreateWithFlags(&b.done[t], hipEventDisableTiming));
+      b.used[t] = false;
+    }
+    b.device = c.device;
+  }
+  const int t = (int)(b.seq % PRAD_BIN_SLOTS);
+  if (b.used[t]) return fail(PRAD_E_ARG, "bincount_enqueue: %d binnings are in flight on this thread; prad_bincount_wait one first", PRAD_BIN_SLOTS);
+  hipStream_t s = (hipStream_t)stream;
+  PRAD_TRY(bincount_queue(c, t, image, dtype, mask, n, binCount, levels, s, &b.host[t]));
+  PRAD_HIP(hipEventRecord(b.done[t], s));
+  b.nedges[t] = binCount + 1;
+  b.used[t] = true;
+  b.seq++;
+  *ticket = t;
+  return PRAD_OK;
+}
+
+int prad_bincount_wait(int ticket, double *minmax, double *edges, int *max_level, long long *counts) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  BinSlots &b = bin_slots();
+  if (ticket < 0 || ticket >= PRAD_BIN_SLOTS || !b.used[ticket] || !minmax) return fail(PRAD_E_ARG, "bincount_wait: ticket %d", ticket);
+  b.used[ticket] = false;
+  PRAD_HIP(hipEventSynchronize(b.done[ticket]));
+  return bincount_collect(b.host[ticket], b.nedges[ticket], minmax, edges, max_level, counts);
 }
 
 int prad_digitize_dev(const void *image, int dtype, const uint8_t *mask, long long n, const double *edges, int nedges,
@@ -2999,6 +3073,177 @@ int prad_image_wait(int ticket) {
     for (int k = 0; k < 3; k++) (void)prad_deferred_status(q.s[k]);     // synchronises and clears the sticky word
     return fail(PRAD_E_DEFERRED, "a queued call of the image saw masked levels outside [1, Ng]; repeat it synchronously");
   }
+  return PRAD_OK;
+}
+
+}  // extern "C"
+
+// ---- the image launcher: prad_image_enqueue_dev issued from a helper thread (round 6) ----------------------------------
+// One derived image is ~65 kernel launches, copies and fills behind one C call: 0.25 ms of the calling thread, nine times
+// per case, on a path whose bound IS that thread (profiles/r06_probes.md section 6).  prad_image_submit hands the call to a
+// launcher thread that belongs to the calling thread (created on first use, with a Context -- workspace, result arena, side
+// streams, tickets -- of its own) and returns at once; the caller goes on with its own work (crop + binning of the next image,
+// collecting the one before) and asks for the outcome when it needs it.  Jobs of one caller run in the order they were given.
+namespace {
+struct ImgJob {
+  enum Kind { NONE, SUBMIT, WAIT, RELEASE } kind = NONE;
+  // SUBMIT arguments
+  const int32_t *levels = nullptr;
+  const uint8_t *mask = nullptr;
+  const void *raw = nullptr;
+  int raw_dtype = 0, size[PRAD_MAX_ND] = {0}, Nd = 0, Ng = 0, classes = 0, symmetric = 1, alpha = 0, force2Ddim = -1;
+  long long Ns = 0;
+  double shift = 0;
+  void *stream = nullptr;
+  int device = 0;
+  // outcome
+  int rc = PRAD_OK, wait_rc = PRAD_OK, ticket = -1, layout[16] = {0};
+  double *results = nullptr;
+  char msg[512] = {0};
+  bool submitted = false, waited = false, in_use = false;
+};
+constexpr int PRAD_IMG_JOBS = PRAD_IMG_TICKETS;     // (as many as the launcher's context has tickets: a fifth submit fails at once, like prad_image_enqueue_dev)
+struct ImgLauncher {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::deque<std::pair<int, int>> q;   // (job slot, kind)
+  ImgJob jobs[PRAD_IMG_JOBS];
+  unsigned seq = 0;
+  bool stop = false, started = false;
+  void run() {
+    for (;;) {
+      std::pair<int, int> w;
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv_work.wait(lk, [&] { return stop || !q.empty(); });
+        if (q.empty()) return;
+        w = q.front();
+        q.pop_front();
+      }
+      ImgJob &j = jobs[w.first];
+      if (w.second == ImgJob::SUBMIT) {
+        int rc = prad_set_device(j.device);
+        if (rc == PRAD_OK)
+          rc = prad_image_enqueue_dev(j.levels, j.mask, j.raw, j.raw_dtype, j.size, j.Nd, j.Ng, j.Ns, j.classes, j.symmetric, j.alpha,
+                                      j.force2Ddim, j.shift, &j.results, j.layout, &j.ticket, j.stream);
+        std::lock_guard<std::mutex> lk(m);
+        j.rc = rc;
+        if (rc != PRAD_OK) snprintf(j.msg, sizeof(j.msg), "%s", err_state().msg);
+        j.submitted = true;
+      } else if (w.second == ImgJob::WAIT) {
+        const int rc = j.rc == PRAD_OK ? prad_image_wait(j.ticket) : j.rc;
+        std::lock_guard<std::mutex> lk(m);
+        j.wait_rc = rc;
+        if (rc != PRAD_OK && j.rc == PRAD_OK) snprintf(j.msg, sizeof(j.msg), "%s", err_state().msg);
+        j.waited = true;
+      } else if (w.second == ImgJob::RELEASE) {
+        (void)prad_release_workspace();
+        std::lock_guard<std::mutex> lk(m);
+        j.waited = true;
+      }
+      cv_done.notify_all();
+    }
+  }
+  ~ImgLauncher() {
+    if (started) {
+      {
+        std::lock_guard<std::mutex> lk(m);
+        stop = true;
+      }
+      cv_work.notify_all();
+      if (th.joinable()) th.join();
+    }
+  }
+};
+ImgLauncher &img_launcher() {
+  static thread_local ImgLauncher L;
+  return L;
+}
+}  // namespace
+
+extern "C" {
+
+int prad_image_submit(const int32_t *levels, const uint8_t *mask, const void *raw, int raw_dtype, const int *size, int Nd, int Ng,
+                      long long Ns, int classes, int symmetric, int alpha, int force2Ddim, double voxelArrayShift, void *stream,
+                      int *job) {
+  Context &c = ctx();
+  PRAD_TRY(c.ensure_device());
+  if (!levels || !mask || !size || !job || Nd < 1 || Nd > PRAD_MAX_ND || Ng < 1) return fail(PRAD_E_ARG, "image_submit: bad arguments");
+  ImgLauncher &L = img_launcher();
+  std::unique_lock<std::mutex> lk(L.m);
+  const int slot = (int)(L.seq % PRAD_IMG_JOBS);
+  ImgJob &j = L.jobs[slot];
+  if (j.in_use) return fail(PRAD_E_ARG, "image_submit: %d images are in flight on this thread; prad_image_submit_wait one first", PRAD_IMG_JOBS);
+  j = ImgJob();
+  j.kind = ImgJob::SUBMIT;
+  j.levels = levels; j.mask = mask; j.raw = raw; j.raw_dtype = raw_dtype;
+  for (int d = 0; d < Nd; d++) j.size[d] = size[d];
+  j.Nd = Nd; j.Ng = Ng; j.Ns = Ns; j.classes = classes; j.symmetric = symmetric; j.alpha = alpha; j.force2Ddim = force2Ddim;
+  j.shift = voxelArrayShift; j.stream = stream; j.device = c.device;
+  j.in_use = true;
+  L.seq++;
+  L.q.emplace_back(slot, (int)ImgJob::SUBMIT);
+  if (!L.started) {
+    L.started = true;
+    L.th = std::thread([&L] { L.run(); });
+  }
+  lk.unlock();
+  L.cv_work.notify_one();
+  *job = slot;
+  return PRAD_OK;
+}
+
+int prad_image_submit_result(int job, double **results, int *layout) {
+  ImgLauncher &L = img_launcher();
+  if (job < 0 || job >= PRAD_IMG_JOBS || !results || !layout) return fail(PRAD_E_ARG, "image_submit_result: job %d", job);
+  std::unique_lock<std::mutex> lk(L.m);
+  ImgJob &j = L.jobs[job];
+  if (!j.in_use) return fail(PRAD_E_ARG, "image_submit_result: job %d is not in flight", job);
+  L.cv_done.wait(lk, [&] { return j.submitted; });
+  if (j.rc != PRAD_OK) return fail(j.rc, "%s", j.msg);
+  *results = j.results;
+  for (int k = 0; k < 16; k++) layout[k] = j.layout[k];
+  return PRAD_OK;
+}
+
+int prad_image_submit_wait(int job) {
+  ImgLauncher &L = img_launcher();
+  if (job < 0 || job >= PRAD_IMG_JOBS) return fail(PRAD_E_ARG, "image_submit_wait: job %d", job);
+  std::unique_lock<std::mutex> lk(L.m);
+  ImgJob &j = L.jobs[job];
+  if (!j.in_use) return fail(PRAD_E_ARG, "image_submit_wait: job %d is not in flight", job);
+  L.q.emplace_back(job, (int)ImgJob::WAIT);
+  lk.unlock();
+  L.cv_work.notify_one();
+  lk.lock();
+  L.cv_done.wait(lk, [&] { return j.waited; });
+  const int rc = j.wait_rc;
+  char msg[512];
+  snprintf(msg, sizeof(msg), "%s", j.msg);
+  j.in_use = false;
+  lk.unlock();
+  if (rc != PRAD_OK) return fail(rc, "%s", msg);
+  return PRAD_OK;
+}
+
+// frees the launcher thread's workspace and result arena (outstanding jobs must have been waited for)
+int prad_image_submit_release(void) {
+  ImgLauncher &L = img_launcher();
+  if (!L.started) return PRAD_OK;
+  std::unique_lock<std::mutex> lk(L.m);
+  for (int k = 0; k < PRAD_IMG_JOBS; k++)
+    if (L.jobs[k].in_use) return fail(PRAD_E_ARG, "image_submit_release: job %d is in flight", k);
+  ImgJob &j = L.jobs[L.seq % PRAD_IMG_JOBS];
+  j = ImgJob();
+  j.in_use = true;
+  const int slot = (int)(L.seq % PRAD_IMG_JOBS);
+  L.q.emplace_back(slot, (int)ImgJob::RELEASE);
+  lk.unlock();
+  L.cv_work.notify_one();
+  lk.lock();
+  L.cv_done.wait(lk, [&] { return j.waited; });
+  j.in_use = false;
   return PRAD_OK;
 }
 

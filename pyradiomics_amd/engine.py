@@ -192,6 +192,7 @@ def deferred_status() -> None:
 
 
 IMG_GLCM, IMG_GLRLM, IMG_GLDM, IMG_NGTDM, IMG_GLSZM, IMG_FIRSTORDER, IMG_MCC = 1, 2, 4, 8, 16, 32, 64
+_IMAGE_LAUNCHER = os.environ.get("PRAD_IMAGE_LAUNCHER", "1") != "0"     # (A/B switch: 0 = the calling thread issues the launches itself)
 
 
 def image_enqueue(levels: torch.Tensor, mask: torch.Tensor, raw, Ng: int, Ns: int, classes: int, symmetric: bool = True,
@@ -207,6 +208,16 @@ def image_enqueue(levels: torch.Tensor, mask: torch.Tensor, raw, Ng: int, Ns: in
             raw = raw.to(torch.float64)
         raw = raw.contiguous()
         code = _DTYPE_CODES[raw.dtype]
+    if _IMAGE_LAUNCHER:
+        # the ~65 launches of the image are issued by the calling thread's launcher thread (prad_image_submit): this thread goes
+        # on with the next image's crop + binning and the previous image's values; result block and layout arrive with image_wait
+        job = C.c_int(-1)
+        rc = lib.prad_image_submit(C.c_void_p(levels.data_ptr()), C.c_void_p(mask.data_ptr()),
+                                   C.c_void_p(raw.data_ptr()) if classes & IMG_FIRSTORDER else None, code, _iptr(size),
+                                   levels.dim(), int(Ng), int(Ns), int(classes), 1 if symmetric else 0, int(alpha),
+                                   int(force2Ddimension) if force2D else -1, float(voxelArrayShift), _stream_ptr(), C.byref(job))
+        _lib.raise_for(rc, "image submit")
+        return {"res": None, "layout": None, "job": int(job.value), "keep": (levels, mask, raw), "generation": _arena_gen.value}
     res_p = C.c_void_p()
     layout = (C.c_int * 16)()
     ticket = C.c_int(-1)
@@ -224,6 +235,24 @@ def image_enqueue(levels: torch.Tensor, mask: torch.Tensor, raw, Ng: int, Ns: in
 
 def image_wait(token) -> bool:
     """waits for the work of an image_enqueue() token only; False when a queued call saw levels outside [1, Ng] (void)"""
+    if token.get("job") is not None:
+        lib = _lib.load()
+        job, token["job"] = int(token["job"]), None
+        res_p = C.c_void_p()
+        layout = (C.c_int * 16)()
+        rc0 = lib.prad_image_submit_result(job, C.byref(res_p), layout)
+        rc = lib.prad_image_submit_wait(job)                  # (frees the slot, also after a failed submit: same code and message)
+        token["keep"] = None
+        if token.get("generation", _arena_gen.value) != _arena_gen.value:
+            raise RuntimeError("release_workspace() was called while this image was queued: its result block is gone")
+        _lib.raise_for(rc0, "image enqueue")
+        n = max(int(layout[12]), 8)
+        token["res"] = np.frombuffer((C.c_char * (8 * n)).from_address(res_p.value), dtype=np.float64, count=n)
+        token["layout"] = [int(v) for v in layout]
+        if rc == _lib.PRAD_E_DEFERRED:
+            return False
+        _lib.raise_for(rc, "image wait")
+        return True
     if token.get("generation", _arena_gen.value) != _arena_gen.value:
         token["keep"] = None
         raise RuntimeError("release_workspace() was called while this image was queued: its result block is gone")
@@ -477,6 +506,8 @@ def release_workspace() -> None:
     -- image_enqueue tokens, result_array views -- is void afterwards: image_wait() on such a token raises"""
     _arena_gen.value += 1
     _lib.raise_for(_lib.load().prad_release_workspace(), "release_workspace")
+    if _IMAGE_LAUNCHER:
+        _lib.raise_for(_lib.load().prad_image_submit_release(), "release_workspace (image launcher)")
 
 
 def last_device_ms() -> float:
@@ -788,6 +819,53 @@ def bin_image(image: torch.Tensor, mask: torch.Tensor, with_counts: bool = False
                                       C.byref(top), counts.ctypes.data_as(C.POINTER(C.c_longlong)) if with_counts else None,
                                       _stream_ptr())
     _lib.raise_for(rc, "digitize")
+    if with_counts:
+        return levels, int(top.value), edges, counts[:int(top.value) + 1]
+    return levels, int(top.value), edges
+
+
+def bin_image_enqueue(image: torch.Tensor, mask: torch.Tensor, **kwargs):
+    """the queueing half of bin_image for a fixed bin count (prad_bincount_enqueue_dev): the kernels and the copy of their few
+    result words are queued on the current stream, nothing is waited for.  Returns a token for bin_image_collect, or None when
+    the request needs the synchronous route (binWidth, a float32 image under NumPy 1.x, more than four binnings in flight)."""
+    lib = _lib.load()
+    binCount = kwargs.get("binCount")
+    if binCount is None or not (1 <= int(binCount) <= 4096) or os.environ.get("PRAD_BIN_TWO_CALLS") or os.environ.get("PRAD_BIN_SYNC"):
+        return None
+    if image.dtype not in _DTYPE_CODES:
+        image = image.to(torch.float64)
+    if image.dtype == torch.float32 and not _NUMPY2:
+        return None
+    image = image.contiguous()
+    mask8 = _mask_u8(mask)
+    lib.prad_set_device(image.device.index or 0)
+    levels = torch.empty(image.shape, dtype=torch.int32, device=image.device)
+    ticket = C.c_int(-1)
+    rc = lib.prad_bincount_enqueue_dev(C.c_void_p(image.data_ptr()), _DTYPE_CODES[image.dtype], C.c_void_p(mask8.data_ptr()),
+                                       image.numel(), int(binCount), C.c_void_p(levels.data_ptr()), C.byref(ticket), _stream_ptr())
+    if rc != _lib.PRAD_OK:
+        return None
+    return {"ticket": int(ticket.value), "levels": levels, "nb": int(binCount), "keep": (image, mask8), "args": (image, mask, kwargs)}
+
+
+def bin_image_collect(token, with_counts: bool = False):
+    """waits for a bin_image_enqueue() token and returns what bin_image returns (a constant or non-finite ROI takes the
+    synchronous two-call route, as there)"""
+    lib = _lib.load()
+    nb = token["nb"]
+    mm = (C.c_double * 2)()
+    edges = np.empty(nb + 1, dtype=np.float64)
+    counts = np.zeros(nb + 2, dtype=np.int64)
+    top = C.c_int(0)
+    rc = lib.prad_bincount_wait(int(token["ticket"]), mm, edges.ctypes.data_as(C.POINTER(C.c_double)), C.byref(top),
+                                counts.ctypes.data_as(C.POINTER(C.c_longlong)))
+    token["keep"] = None
+    image, mask, kwargs = token["args"]
+    token["args"] = None
+    if rc == _lib.PRAD_E_UNSUPPORTED:
+        return bin_image(image, mask, with_counts=with_counts, **kwargs)
+    _lib.raise_for(rc, "bincount")
+    levels = token["levels"]
     if with_counts:
         return levels, int(top.value), edges, counts[:int(top.value) + 1]
     return levels, int(top.value), edges

@@ -265,23 +265,43 @@ class RadiomicsFeatureExtractor:
             args = s.copy()
             args.update(custom)
             gens = chain(gens, _IMAGE_TYPES[imageType](image, mask, **args))
-        # One derived image of look-ahead: image i+1 is cropped, binned and its device classes QUEUED before the host
-        # collects image i, so the GPU works through a queue while the host does its round trips (first order) and its
-        # Python; results keep the reference's order (featureextractor.py:371-396 evaluates image after image).
-        pending = None
+        # Look-ahead: image i + 1 is cropped and its discretisation QUEUED (prebinDevice: no round trip) right behind the device
+        # classes of image i, and the host collects image i - 1 after that -- the GPU works through a queue while the host does
+        # its Python, and the one round trip of a binning (ROI min / max -> number of levels) has passed by the time the classes
+        # of image i + 1 are constructed; results keep the reference's order (featureextractor.py:371-396: image after image).
+        from .base import RadiomicsFeaturesBase
+        bins = on_dev and bool(self.enabledFeatures)      # (every class discretises: first order for its entropy / uniformity)
+        it = iter(gens)
+
+        def fetch():
+            try:
+                derived, typeName, kw = next(it)
+            except StopIteration:
+                return None
+            cimg, cmask = imageoperations.cropToTumorMask(derived, mask, label, padDistance=kernelRadius, deviceResident=on_dev)
+            if bins:
+                RadiomicsFeaturesBase.prebinDevice(cimg, cmask, **kw)
+            return cimg, cmask, typeName, kw
+
+        pending, nxt = None, None
         try:
-            for derived, typeName, kw in gens:
-                cimg, cmask = imageoperations.cropToTumorMask(derived, mask, label, padDistance=kernelRadius,
-                                                              deviceResident=on_dev)
-                started = self._startFeatures(cimg, cmask, typeName, **kw)
+            nxt = fetch()
+            while nxt is not None:
+                cur, nxt = nxt, None
+                try:
+                    started = self._startFeatures(cur[0], cur[1], cur[2], **cur[3])
+                except BaseException:
+                    RadiomicsFeaturesBase.dropPrebinned(cur[0])
+                    raise
                 prev, pending = pending, started
+                try:
+                    nxt = fetch()
+                except BaseException:
+                    if prev is not None:
+                        self._abandonFeatures(prev)
+                    raise
                 if prev is not None:
-                    try:
-                        out.update(self._finishFeatures(prev))
-                    except BaseException:
-                        self._abandonFeatures(pending)       # the look-ahead image was queued already
-                        pending = None
-                        raise
+                    out.update(self._finishFeatures(prev))      # (abandons `prev` itself when it fails)
             if pending is not None:
                 last, pending = pending, None
                 out.update(self._finishFeatures(last))
@@ -291,6 +311,8 @@ class RadiomicsFeatureExtractor:
             # tensors -- retire them, or every later case on this (persistent batch worker) thread fails
             if pending is not None:
                 self._abandonFeatures(pending)
+            if nxt is not None:
+                RadiomicsFeaturesBase.dropPrebinned(nxt[0])
             raise
         return out
 

@@ -94,6 +94,14 @@ def cropToTumorMask(image, mask, label=1, padDistance=0, deviceResident=False, a
     image of one case shares one cropped ROI.  `alignRows=False` keeps the device crop at the reference's exact extent
     (the preCrop stage: filters applied afterwards see the crop's borders, so its extent must match the reference's)."""
     img, msk = as_image(image), as_image(mask)
+    if deviceResident:
+        # every derived image of a case is cropped with the same box: slices, origin shift and the cropped mask are worked out
+        # once per (mask, box request) and per image geometry (0.1 ms of numpy per derived image otherwise)
+        gkey = ("cropgeo", label, padDistance, bool(alignRows), img.spacing, img.origin, img.direction)
+        geo = msk._derived.get(gkey)
+        if geo is not None:
+            sl, origin, cmask = geo
+            return Image(None, img.spacing, origin, img.direction, tensor=img.device_tensor()[sl].contiguous()), cmask
     bkey = ("bbox", label)
     if bkey not in msk._derived:
         msk._derived[bkey] = boundingBox(roiTensor(msk, label) if deviceResident else (msk.array == label))
@@ -122,6 +130,7 @@ def cropToTumorMask(image, mask, label=1, padDistance=0, deviceResident=False, a
     if ckey not in msk._derived:
         msk._derived[ckey] = Image(None, msk.spacing, origin, msk.direction,
                                    tensor=msk.device_tensor()[sl].contiguous())
+    msk._derived[gkey] = (sl, origin, msk._derived[ckey])
     return (Image(None, img.spacing, origin, img.direction, tensor=img.device_tensor()[sl].contiguous()),
             msk._derived[ckey])
 
