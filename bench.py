@@ -441,7 +441,10 @@ def _batch_case_setup(device, seed_base: int, ncases: int):
     roi[((zz - N / 2) ** 2 + (yy - N / 2) ** 2 + (xx - N / 2) ** 2) < (0.45 * N) ** 2] = 1
     ex = RadiomicsFeatureExtractor(params)
     vols = [(make_volume(N, 32, "smooth", seed_base + c, device)[0] * 25).cpu().numpy().astype(np.int16) for c in range(ncases)]
-    return ex, vols, lambda c: ex.execute(Image(vols[c]), Image(roi))
+    one = lambda c: ex.execute(Image(vols[c]), Image(roi))                                   # noqa: E731
+    # consecutive cases of one thread with one case of overlap (executeMany); PRAD_BATCH_PIPELINE=0: case after case
+    one.many = (lambda cs: ex.executeMany((Image(vols[c]), Image(roi)) for c in cs)) if os.environ.get("PRAD_BATCH_PIPELINE", "1") != "0" else None
+    return ex, vols, one
 
 
 def batch_child(argv) -> None:
@@ -461,12 +464,21 @@ def batch_child(argv) -> None:
     print("ready", flush=True)
     sys.stdin.readline()
     t0 = time.perf_counter()
-    if threads > 1:
-        res = batch._run_threaded(list(range(ncases)), list(range(1, ncases + 1)), one, threads)
-    else:
-        res = {i: one(i + 1) for i in range(ncases)}
+    res = _batch_run(batch, one, ncases, threads)
     torch.cuda.synchronize()
     print("%d %.6f %d" % (ncases, time.perf_counter() - t0, len(res[0])), flush=True)
+
+
+def _batch_run(batch, one, ncases: int, threads: int):
+    """cases 1 .. ncases of a worker (process or thread pool): {index: features}"""
+    ids = list(range(1, ncases + 1))
+    if one.many is not None:
+        if threads > 1:
+            return batch._pool(threads).run_many(list(range(ncases)), ids, one.many)
+        return dict(enumerate(one.many(ids)))
+    if threads > 1:
+        return batch._run_threaded(list(range(ncases)), ids, one, threads)
+    return {i: one(i + 1) for i in range(ncases)}
 
 
 def mode_batch(device, rank: int, cases: int, fence, world: int = 1):
@@ -520,20 +532,17 @@ def mode_batch(device, rank: int, cases: int, fence, world: int = 1):
                     except subprocess.TimeoutExpired:
                         k.kill()
         assert done == cases
-        mode_batch.how = "%d worker processes x %d thread(s) on the GPU" % (len(per), threads)
+        mode_batch.how = "%d worker processes x %d thread(s) on the GPU%s" % (len(per), threads, ", one case of overlap per thread (executeMany)" if one.many else "")
     else:
         if threads > 1:                                   # every worker thread warms its own workspace
             batch.warm_threads(lambda: one(0), threads)
         fence()
         t0 = time.perf_counter()
-        if threads > 1:
-            res = batch._run_threaded(list(range(cases)), list(range(1, cases + 1)), one, threads)
-        else:
-            res = {i: one(i + 1) for i in range(cases)}
+        res = _batch_run(batch, one, cases, threads)
         fence()
         dt = time.perf_counter() - t0
         nfeat = len(res[0])
-        mode_batch.how = "%d host thread(s) of one process (batch.run_batch(threads=))" % threads
+        mode_batch.how = "%d host thread(s) of one process (batch.run_batch(threads=%s))" % (threads, ", many=executeMany" if one.many else "")
     lat = []                                              # one case at a time on this thread (the case pipeline's latency)
     for c in range(1, min(cases, 5) + 1):
         fence()

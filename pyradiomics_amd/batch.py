@@ -113,6 +113,34 @@ class _WorkerPool:
             raise errors[0]
         return out
 
+    def run_many(self, indices, cases, many):
+        """like run(), for a worker that overlaps consecutive cases: `many(iterable of cases)` is a generator of their results
+        in order (RadiomicsFeatureExtractor.executeMany); every thread of the pool drives one such generator fed from a shared
+        queue of the indices, so each thread has one case of look-ahead of its own"""
+        import queue
+        todo = queue.SimpleQueue()
+        for i in indices:
+            todo.put(i)
+        out = {}
+
+        def job(_):
+            taken = []
+
+            def feed():
+                while True:
+                    try:
+                        i = todo.get_nowait()
+                    except queue.Empty:
+                        return
+                    taken.append(i)
+                    yield cases[i]
+            for k, result in enumerate(many(feed())):
+                out[taken[k]] = result
+
+        n = len(self.threads)
+        self.run(list(range(n)), [None] * n, job)
+        return out
+
     def each(self, fn):
         """runs fn() once on EVERY thread of the pool (warm-up: each thread allocates its own native workspace)"""
         import threading
@@ -188,13 +216,20 @@ def _run_threaded(indices, cases, worker, threads: int):
     return _pool(threads).run(list(indices), cases, worker)
 
 
-def run_batch(cases: Sequence, worker: Callable, gather: bool = True, threads: int = 1):
+def run_batch(cases: Sequence, worker: Callable, gather: bool = True, threads: int = 1, many: Callable = None):
     """Applies `worker(case)` to this rank's shard.  With gather=True rank 0 returns the results of ALL cases in
     input order (other ranks return None); with gather=False every rank returns {case_index: result} of its own.
-    threads > 1: that many cases of the shard at a time (host threads sharing the rank's GPU, see _run_threaded)."""
+    threads > 1: that many cases of the shard at a time (host threads sharing the rank's GPU, see _run_threaded).
+    `many(iterable of cases)` -> generator of their results in order, when given, replaces `worker`: a worker that overlaps
+    consecutive cases on one thread (RadiomicsFeatureExtractor.executeMany: case i + 1's upload and filters under case i's
+    last kernels), one such generator per host thread."""
     rank, world = rank_world()
     idx = shard_indices(len(cases), rank, world)
-    mine = _run_threaded(idx, cases, worker, threads) if threads > 1 else {i: worker(cases[i]) for i in idx}
+    if many is not None:
+        mine = (_pool(threads).run_many(list(idx), cases, many) if threads > 1
+                else dict(zip(idx, many(cases[i] for i in idx))))
+    else:
+        mine = _run_threaded(idx, cases, worker, threads) if threads > 1 else {i: worker(cases[i]) for i in idx}
     if not gather or world == 1:
         return [mine[i] for i in range(len(cases))] if (gather and world == 1) else mine
     import torch.distributed as dist

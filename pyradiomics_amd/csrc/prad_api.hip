@@ -2876,14 +2876,15 @@ long long prad_glszm_zones(int v, int *tempData, long long capacity_pairs) {
 // layer (15 - 25 us each) was a fifth of a 256^3 case.  The matrices live in workspace buffers (stream order recycles
 // them), the values land in one block of the result arena.
 #define PRAD_IMG_TICKETS 4
+#define PRAD_IMG_STREAMS 4   // side streams of an image: 0 sweeps (GLCM + GLRLM), 1 GLSZM, 2 first order, 3 neighbourhoods (GLDM + NGTDM)
 #define GF_FEATURES 23   // GF_COUNT of kernels_features.h
 }  // extern "C"
 namespace {
 struct ImageQueues {
-  hipStream_t s[3] = {};
+  hipStream_t s[PRAD_IMG_STREAMS] = {};
   hipEvent_t in = nullptr;
-  hipEvent_t done[PRAD_IMG_TICKETS][3] = {};
-  int *flag[PRAD_IMG_TICKETS][3] = {};
+  hipEvent_t done[PRAD_IMG_TICKETS][PRAD_IMG_STREAMS] = {};
+  int *flag[PRAD_IMG_TICKETS][PRAD_IMG_STREAMS] = {};
   unsigned used[PRAD_IMG_TICKETS] = {};
   unsigned long long seq = 0;
   int device = -1;
@@ -2898,11 +2899,11 @@ void release_image_queues() {
   for (int d = 0; d < 16; d++) {
     ImageQueues &q = tab[d];
     if (q.device < 0) continue;
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < PRAD_IMG_STREAMS; k++)
       if (q.s[k]) (void)hipStreamDestroy(q.s[k]);
     if (q.in) (void)hipEventDestroy(q.in);
     for (int t = 0; t < PRAD_IMG_TICKETS; t++)
-      for (int k = 0; k < 3; k++)
+      for (int k = 0; k < PRAD_IMG_STREAMS; k++)
         if (q.done[t][k]) (void)hipEventDestroy(q.done[t][k]);
     q = ImageQueues();
   }
@@ -2920,10 +2921,10 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   if ((classes & PRAD_IMG_FIRSTORDER) && !raw) return fail(PRAD_E_ARG, "image_enqueue: first order needs the undiscretised image");
   ImageQueues &q = image_queues();
   if (q.device != c.device) {
-    for (int k = 0; k < 3; k++) PRAD_HIP(hipStreamCreateWithFlags(&q.s[k], hipStreamNonBlocking));
+    for (int k = 0; k < PRAD_IMG_STREAMS; k++) PRAD_HIP(hipStreamCreateWithFlags(&q.s[k], hipStreamNonBlocking));
     PRAD_HIP(hipEventCreateWithFlags(&q.in, hipEventDisableTiming));
     for (int t = 0; t < PRAD_IMG_TICKETS; t++)
-      for (int k = 0; k < 3; k++) PRAD_HIP(hipEventCreateWithFlags(&q.done[t][k], hipEventDisableTiming));
+      for (int k = 0; k < PRAD_IMG_STREAMS; k++) PRAD_HIP(hipEventCreateWithFlags(&q.done[t][k], hipEventDisableTiming));
     q.device = c.device;
   }
   if (q.used[q.seq % PRAD_IMG_TICKETS] != 0)
@@ -2979,7 +2980,7 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   auto at = [&](int k) { return res + layout[k]; };
   // the side streams wait for everything queued on the caller's stream (binning produced the levels there)
   PRAD_HIP(hipEventRecord(q.in, (hipStream_t)stream));
-  for (int k = 0; k < 3; k++) PRAD_HIP(hipStreamWaitEvent(q.s[k], q.in, 0));
+  for (int k = 0; k < PRAD_IMG_STREAMS; k++) PRAD_HIP(hipStreamWaitEvent(q.s[k], q.in, 0));
   unsigned used = 0;
   // (workspace sets 4, 5, 6: sets 1 - 3 belong to callers that drive side streams of their own, engine.side_queue)
   // ---- side stream 0: GLCM + GLRLM (one sweep), GLDM + NGTDM (one pass over the neighbourhoods) ----
@@ -3007,19 +3008,25 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
     }
     used |= 1u;
   }
+  // ---- side stream 3: GLDM + NGTDM (one pass over the neighbourhoods) and their formulas.  Until round 6 they ran behind the
+  // sweeps on stream 0, whose chain of small formula kernels (~0.6 ms per 256^3 image) was then the longest of the image: the
+  // per-image critical path is the GLSZM's now (profiles/r06_probes.md section 6)
   if (classes & (PRAD_IMG_GLDM | PRAD_IMG_NGTDM)) {
+    static const bool own_stream = !getenv("PRAD_IMG_NEIGH_ON_SWEEP_STREAM");
+    const int ks = own_stream ? 3 : 0;
+    c.workspace = own_stream ? 7 : 4;
     const int W = 2 * Nab + 1;
     double *dm = nullptr, *nm = nullptr;
     PRAD_TRY(c.get<double>("img_gldm", (size_t)Ng * W, &dm));
     PRAD_TRY(c.get<double>("img_ngtdm", (size_t)Ng * 3, &nm));
-    PRAD_TRY(texture_gldm_ngtdm(levels, mask, size, Nd, angb.data(), Nab, Ng, alpha, dm, nm, q.s[0]));
-    c.workspace = 4;
+    PRAD_TRY(texture_gldm_ngtdm(levels, mask, size, Nd, angb.data(), Nab, Ng, alpha, dm, nm, q.s[ks]));
+    c.workspace = own_stream ? 7 : 4;
     c.deferred = true;
     if (classes & PRAD_IMG_GLDM) {
-      PRAD_TRY(prad_zone_matrix_features_dev(dm, Ng, W, 1, (long long)W, 1LL, 0LL, nullptr, at(5), (int *)at(6), q.s[0]));
+      PRAD_TRY(prad_zone_matrix_features_dev(dm, Ng, W, 1, (long long)W, 1LL, 0LL, nullptr, at(5), (int *)at(6), q.s[ks]));
     }
-    if (classes & PRAD_IMG_NGTDM) PRAD_TRY(prad_ngtdm_features_dev(nm, Ng, at(7), q.s[0]));
-    used |= 1u;
+    if (classes & PRAD_IMG_NGTDM) PRAD_TRY(prad_ngtdm_features_dev(nm, Ng, at(7), q.s[ks]));
+    used |= 1u << ks;
   }
   // ---- side stream 1: GLSZM ----
   if (classes & PRAD_IMG_GLSZM) {
@@ -3043,7 +3050,7 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   c.workspace = 0;
   // a verdict mark and an event behind the work of every side stream that got some
   const int t = (int)(q.seq++ % PRAD_IMG_TICKETS);
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < PRAD_IMG_STREAMS; k++) {
     if (!(used & (1u << k))) continue;
     void *f = nullptr;
     PRAD_TRY(c.arena_alloc(sizeof(int), &f));
@@ -3063,14 +3070,14 @@ int prad_image_wait(int ticket) {
   if (ticket < 0 || ticket >= PRAD_IMG_TICKETS) return fail(PRAD_E_ARG, "image_wait: ticket %d", ticket);
   ImageQueues &q = image_queues();
   bool bad = false;
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < PRAD_IMG_STREAMS; k++) {
     if (!(q.used[ticket] & (1u << k))) continue;
     PRAD_HIP(hipEventSynchronize(q.done[ticket][k]));
     bad = bad || *q.flag[ticket][k] != 0;
   }
   q.used[ticket] = 0;
   if (bad) {
-    for (int k = 0; k < 3; k++) (void)prad_deferred_status(q.s[k]);     // synchronises and clears the sticky word
+    for (int k = 0; k < PRAD_IMG_STREAMS; k++) (void)prad_deferred_status(q.s[k]);     // synchronises and clears the sticky word
     return fail(PRAD_E_DEFERRED, "a queued call of the image saw masked levels outside [1, Ng]; repeat it synchronously");
   }
   return PRAD_OK;
@@ -3086,7 +3093,7 @@ int prad_image_wait(int ticket) {
 // collecting the one before) and asks for the outcome when it needs it.  Jobs of one caller run in the order they were given.
 namespace {
 struct ImgJob {
-  enum Kind { NONE, SUBMIT, WAIT, RELEASE } kind = NONE;
+  enum Kind { NONE, SUBMIT, WAIT, RELEASE, RETIRE } kind = NONE;
   // SUBMIT arguments
   const int32_t *levels = nullptr;
   const uint8_t *mask = nullptr;
@@ -3100,7 +3107,11 @@ struct ImgJob {
   int rc = PRAD_OK, wait_rc = PRAD_OK, ticket = -1, layout[16] = {0};
   double *results = nullptr;
   char msg[512] = {0};
-  bool submitted = false, waited = false, in_use = false;
+  bool submitted = false, waited = false, in_use = false, retiring = false;
+  // what the caller needs to wait for the image's GPU work on its own thread: the launcher's events and verdict words
+  hipEvent_t ev[PRAD_IMG_STREAMS] = {};
+  int *flag[PRAD_IMG_STREAMS] = {};
+  unsigned used = 0;
 };
 constexpr int PRAD_IMG_JOBS = PRAD_IMG_TICKETS;     // (as many as the launcher's context has tickets: a fifth submit fails at once, like prad_image_enqueue_dev)
 struct ImgLauncher {
@@ -3130,7 +3141,20 @@ struct ImgLauncher {
         std::lock_guard<std::mutex> lk(m);
         j.rc = rc;
         if (rc != PRAD_OK) snprintf(j.msg, sizeof(j.msg), "%s", err_state().msg);
+        if (rc == PRAD_OK) {
+          ImageQueues &iq = image_queues();
+          j.used = iq.used[j.ticket];
+          for (int k = 0; k < PRAD_IMG_STREAMS; k++) {
+            j.ev[k] = iq.done[j.ticket][k];
+            j.flag[k] = iq.flag[j.ticket][k];
+          }
+        }
         j.submitted = true;
+      } else if (w.second == ImgJob::RETIRE) {      // the caller has waited for the image's events itself: free ticket and slot
+        if (prad_set_device(j.device) == PRAD_OK) image_queues().used[j.ticket] = 0;
+        std::lock_guard<std::mutex> lk(m);
+        j.in_use = false;
+        j.retiring = false;
       } else if (w.second == ImgJob::WAIT) {
         const int rc = j.rc == PRAD_OK ? prad_image_wait(j.ticket) : j.rc;
         std::lock_guard<std::mutex> lk(m);
@@ -3174,6 +3198,7 @@ int prad_image_submit(const int32_t *levels, const uint8_t *mask, const void *ra
   std::unique_lock<std::mutex> lk(L.m);
   const int slot = (int)(L.seq % PRAD_IMG_JOBS);
   ImgJob &j = L.jobs[slot];
+  if (j.in_use && j.retiring) L.cv_done.wait(lk, [&] { return !j.in_use; });     // (waited for already: the launcher is about to free it)
   if (j.in_use) return fail(PRAD_E_ARG, "image_submit: %d images are in flight on this thread; prad_image_submit_wait one first", PRAD_IMG_JOBS);
   j = ImgJob();
   j.kind = ImgJob::SUBMIT;
@@ -3212,7 +3237,34 @@ int prad_image_submit_wait(int job) {
   if (job < 0 || job >= PRAD_IMG_JOBS) return fail(PRAD_E_ARG, "image_submit_wait: job %d", job);
   std::unique_lock<std::mutex> lk(L.m);
   ImgJob &j = L.jobs[job];
-  if (!j.in_use) return fail(PRAD_E_ARG, "image_submit_wait: job %d is not in flight", job);
+  if (!j.in_use || j.retiring) return fail(PRAD_E_ARG, "image_submit_wait: job %d is not in flight", job);
+  // The image's GPU work is waited for HERE, on the calling thread (the launcher may be busy issuing the next image: a wait
+  // queued behind that would cost the caller those 0.25 ms per image); the launcher only frees the ticket afterwards.  A
+  // failed submit and a voided image (a level outside [1, Ng]: the sticky word has to be cleared on the launcher's
+  // streams) take the launcher's own prad_image_wait.
+  L.cv_done.wait(lk, [&] { return j.submitted; });
+  if (j.rc == PRAD_OK) {
+    hipEvent_t ev[PRAD_IMG_STREAMS];
+    int *flag[PRAD_IMG_STREAMS];
+    const unsigned used = j.used;
+    for (int k = 0; k < PRAD_IMG_STREAMS; k++) { ev[k] = j.ev[k]; flag[k] = j.flag[k]; }
+    lk.unlock();
+    bool bad = false;
+    hipError_t herr = hipSuccess;
+    for (int k = 0; k < PRAD_IMG_STREAMS && herr == hipSuccess; k++) {
+      if (!(used & (1u << k))) continue;
+      herr = hipEventSynchronize(ev[k]);
+      bad = bad || *flag[k] != 0;
+    }
+    lk.lock();
+    if (herr == hipSuccess && !bad) {
+      j.retiring = true;
+      L.q.emplace_back(job, (int)ImgJob::RETIRE);
+      lk.unlock();
+      L.cv_work.notify_one();
+      return PRAD_OK;
+    }
+  }
   L.q.emplace_back(job, (int)ImgJob::WAIT);
   lk.unlock();
   L.cv_work.notify_one();
@@ -3232,8 +3284,10 @@ int prad_image_submit_release(void) {
   ImgLauncher &L = img_launcher();
   if (!L.started) return PRAD_OK;
   std::unique_lock<std::mutex> lk(L.m);
-  for (int k = 0; k < PRAD_IMG_JOBS; k++)
+  for (int k = 0; k < PRAD_IMG_JOBS; k++) {
+    if (L.jobs[k].in_use && L.jobs[k].retiring) L.cv_done.wait(lk, [&] { return !L.jobs[k].in_use; });
     if (L.jobs[k].in_use) return fail(PRAD_E_ARG, "image_submit_release: job %d is in flight", k);
+  }
   ImgJob &j = L.jobs[L.seq % PRAD_IMG_JOBS];
   j = ImgJob();
   j.in_use = true;

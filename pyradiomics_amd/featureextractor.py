@@ -181,6 +181,64 @@ class RadiomicsFeatureExtractor:
         return image, mask
 
     def execute(self, imageFilepath, maskFilepath, label=None, label_channel=None, voxelBased=False):
+        """featureextractor.py:241-343: every enabled feature of every enabled image type for one (image, mask) pair"""
+        steps = self._executeSteps(imageFilepath, maskFilepath, label, label_channel, voxelBased)
+        try:
+            while True:
+                next(steps)
+        except StopIteration as done:
+            return done.value
+
+    def executeMany(self, cases, label=None, label_channel=None, voxelBased=False):
+        """Generator over the results of `cases` -- (image, mask) pairs, or (image, mask, label) -- in their order, with ONE CASE OF
+        OVERLAP on this thread: case i + 1 is loaded, uploaded, filtered and its first derived images queued before the values of
+        case i's last derived image are collected, so the GPU works through case i's tail while the host does case i + 1's head
+        (the upload of a 256^3 case alone is 1.3 ms in which nothing else of that case can run).  Results are those of
+        execute(), bit for bit (the same calls in the same order per case; only the collection of the last image moves).  The
+        reference's batch mode is a process pool over cases (scripts/__init__.py:387-416); this is its one-process form for a
+        GPU.  A case that raises is reported by re-raising at its position; the case in flight behind it is abandoned."""
+        prev, cur = None, None
+        try:
+            for case in cases:
+                lab = case[2] if len(case) > 2 else label
+                steps = self._executeSteps(case[0], case[1], lab, label_channel, voxelBased)
+                try:
+                    next(steps)                      # head of this case: loaded, uploaded, filtered, its FIRST derived image queued
+                    cur = (steps, None)
+                except StopIteration as done:        # (nothing was left pending: e.g. no derived image)
+                    cur = (None, done.value)
+                if prev is not None:
+                    last, prev = prev, None
+                    yield self._finishSteps(last)    # the previous case's last image: its kernels ran under this case's head
+                if cur[0] is not None:
+                    try:
+                        next(cur[0])                 # the body: every image but the last collected, the last one left queued
+                    except StopIteration as done:
+                        cur = (None, done.value)
+                prev, cur = cur, None
+            if prev is not None:
+                last, prev = prev, None
+                yield self._finishSteps(last)
+        finally:
+            for state in (prev, cur):
+                if state is not None and state[0] is not None:
+                    state[0].close()                 # (abandons what the unfinished case queued)
+
+    @staticmethod
+    def _finishSteps(state):
+        steps, value = state
+        if steps is None:
+            return value
+        try:
+            while True:
+                next(steps)
+        except StopIteration as done:
+            return done.value
+
+    def _executeSteps(self, imageFilepath, maskFilepath, label=None, label_channel=None, voxelBased=False):
+        """execute() as a generator that yields TWICE -- when the case's first derived image is queued (executeMany collects the
+        previous case's last image there: at most two images of two cases in flight, the library's tickets are a ring of four) and
+        when everything is queued or collected except the values of the last derived image -- and returns what execute() returns"""
         s = self.settings.copy()
         if label is not None:
             s["label"] = label
@@ -283,7 +341,7 @@ class RadiomicsFeatureExtractor:
                 RadiomicsFeaturesBase.prebinDevice(cimg, cmask, **kw)
             return cimg, cmask, typeName, kw
 
-        pending, nxt = None, None
+        pending, nxt, head_done = None, None, False
         try:
             nxt = fetch()
             while nxt is not None:
@@ -294,6 +352,9 @@ class RadiomicsFeatureExtractor:
                     RadiomicsFeaturesBase.dropPrebinned(cur[0])
                     raise
                 prev, pending = pending, started
+                if prev is None and not head_done:
+                    head_done = True
+                    yield                          # (executeMany: the previous case's last image is collected here)
                 try:
                     nxt = fetch()
                 except BaseException:
@@ -303,6 +364,7 @@ class RadiomicsFeatureExtractor:
                 if prev is not None:
                     out.update(self._finishFeatures(prev))      # (abandons `prev` itself when it fails)
             if pending is not None:
+                yield                              # (executeMany: the next case's head runs here; GeneratorExit abandons `pending`)
                 last, pending = pending, None
                 out.update(self._finishFeatures(last))
         except BaseException:

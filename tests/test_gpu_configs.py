@@ -20,6 +20,44 @@ def _volume(n, kind, seed):
     return img, msk
 
 
+def test_execute_many_overlaps_cases_and_equals_execute():
+    """RadiomicsFeatureExtractor.executeMany (case i + 1's head before case i's last image is collected, one thread) and
+    batch.run_batch(many=, threads=2): every value equals execute()'s bit for bit, in the order of the cases; a failing case
+    re-raises at its position and the cases behind it still run on a fresh call"""
+    import torch
+    from pyradiomics_amd import batch
+    from pyradiomics_amd.featureextractor import RadiomicsFeatureExtractor
+    from pyradiomics_amd.image import Image
+    rng = np.random.default_rng(5)
+    N = 56
+    zz, yy, xx = np.ogrid[:N, :N, :N]
+    roi = (((zz - N / 2) ** 2 + (yy - N / 2) ** 2 + (xx - N / 2) ** 2) < (0.42 * N) ** 2).astype(np.int16)
+    from scipy import ndimage
+    vols = [(ndimage.gaussian_filter(rng.standard_normal((N, N, N)), 1.2) * 400 + 800).astype(np.int16) for _ in range(6)]
+    ex = RadiomicsFeatureExtractor({"setting": {"binCount": 24, "additionalInfo": False},
+                                    "imageType": {"Original": {}, "Wavelet": {}, "LoG": {"sigma": [1.5]}}})
+    seq = [ex.execute(Image(v), Image(roi)) for v in vols]
+    many = list(ex.executeMany((Image(v), Image(roi)) for v in vols))
+    thr = batch.run_batch(vols, None, threads=2, many=lambda cs: ex.executeMany((Image(v), Image(roi)) for v in cs))
+    torch.cuda.synchronize()
+    assert len(seq) == len(many) == len(thr) == 6 and len(seq[0]) > 900
+    for a, b, c in zip(seq, many, thr):
+        assert list(a) == list(b) == list(c)
+        for k in a:
+            x, y, z = float(a[k]), float(b[k]), float(c[k])
+            assert (x == y == z) or (np.isnan(x) and np.isnan(y) and np.isnan(z)), k
+    # a case without its label in the middle: the cases in front of it arrive, the error surfaces, nothing is left in flight
+    empty = np.zeros_like(roi)
+    got = []
+    with pytest.raises(ValueError):
+        for r in ex.executeMany([(Image(vols[0]), Image(roi)), (Image(vols[1]), Image(empty)), (Image(vols[2]), Image(roi))]):
+            got.append(r)
+    assert len(got) <= 1
+    again = list(ex.executeMany((Image(v), Image(roi)) for v in vols[:3]))
+    for a, b in zip(seq[:3], again):
+        assert all(float(a[k]) == float(b[k]) or np.isnan(float(a[k])) for k in a)
+
+
 @pytest.mark.parametrize("kind", ["uniform", "smooth"])
 def test_c2_all_five_matrices_256(kind, checker):
     from pyradiomics_amd import cmatrices as cm, _lib
