@@ -483,17 +483,18 @@ def _batch_run(batch, one, ncases: int, threads: int):
 
 def mode_batch(device, rank: int, cases: int, fence, world: int = 1):
     """north_star 'batched mode' (BASELINE config 5 in miniature): whole cases -- a 256^3 volume, ball ROI, Original +
-    8 wavelet sub-bands, all six feature classes -- through RadiomicsFeatureExtractor.execute, `cases` per rank, no
-    collective.  The cases of a rank are dealt to PRAD_BATCH_PROCS worker processes on the rank's GPU (default 4), each with
-    PRAD_BATCH_THREADS host threads (default 1) -- what `python -m pyradiomics_amd batch.csv --jobs N` does with N workers
-    per GPU, and what the reference does with multiprocessing.Pool over cores (scripts/__init__.py:387-416).  A case is
-    bound by its host thread (~870 HIP calls); host threads of ONE process share the runtime's locks and the GIL (the GPU
-    is busy 55 % of the time with three threads: scripts/archive/r04_batch_busy.sh), worker processes do not: one process with
-    three threads 115 cases/s, four processes 128 (scripts/archive/r04_batch_procs.py).  PRAD_BATCH_PROCS=0: threads of this
-    process only (batch.run_batch(threads=), PRAD_BATCH_THREADS default 3 then).  Returns (cases, seconds, features per case)."""
+    8 wavelet sub-bands, all six feature classes -- through RadiomicsFeatureExtractor, `cases` per rank, no collective.
+    Default (round 6): PRAD_BATCH_THREADS = 3 host threads of THIS process (batch.run_batch(threads=3, many=executeMany)); each
+    thread has a launcher thread of its own for the ~65 launches of a derived image and one case of overlap.  PRAD_BATCH_PROCS = N
+    > 0 deals the cases to N worker processes on the rank's GPU instead (what rounds 3 - 5 reported with N = 4, and what the
+    reference does with multiprocessing.Pool over cores, scripts/__init__.py:387-416), capped at usable_cores() // world.
+    Returns (cases, seconds, features per case)."""
     import subprocess
     from pyradiomics_amd import batch
-    procs = int(os.environ.get("PRAD_BATCH_PROCS", "4"))
+    # round 6: ONE process per GPU by default -- three host threads, each with a launcher thread of its own (prad_image_submit) and
+    # one case of overlap (executeMany), reach what four worker processes reached until round 5 (the GPU's own 140 - 145 cases/s:
+    # profiles/r06_probes.md section 6), and eight ranks of them fit the 16 cores of the bench host
+    procs = int(os.environ.get("PRAD_BATCH_PROCS", "0"))
     if procs > 0:
         # every worker process is a host-bound Python thread: more workers than cores only take turns.  The ranks of a node
         # share the host (N ranks x 4 workers + N parents), so a rank gets usable_cores() // world of them (VERDICT r4 missing #5)

@@ -308,9 +308,39 @@ inline NeighPlan plan_neigh(const Geo &g, const VoxMode &vm, const int *angles_h
   return p;
 }
 
+// A packed copy of the WHOLE volume that somebody made already (prad_image_enqueue_dev, round 6: GLDM / NGTDM and the GLSZM of
+// one derived image each packed the same int32 levels + mask into the same bytes, 35 us each at 256^3): a neigh_pack() call
+// for the same (image, mask, voxel count, Ng) hands it out instead of packing again and ORs the pack's verdict word into the
+// caller's.  Thread local, set and cleared by the one caller that knows the consumers run behind the pack (same stream, or a
+// stream that waits for it).
+struct SharedPack {
+  const int32_t *image = nullptr;
+  const uint8_t *mask = nullptr;
+  long long n = 0;
+  int Ng = 0;
+  uint8_t *levels = nullptr;
+  const int *flags = nullptr;      // [0] != 0: a masked level outside [1, Ng]
+};
+inline SharedPack &shared_pack() {
+  static thread_local SharedPack p;
+  return p;
+}
+__global__ void or_flag_kernel(int *__restrict__ dst, const int *__restrict__ src) {
+  if (src[0]) dst[0] = 1;
+}
+inline bool take_shared_pack(hipStream_t s, const Geo &g, const int32_t *image, const uint8_t *mask, int Ng, int *flags_d,
+                             uint8_t **levels) {
+  const SharedPack &sp = shared_pack();
+  if (!sp.levels || sp.image != image || sp.mask != mask || sp.n != g.n || sp.Ng != Ng) return false;
+  *levels = sp.levels;
+  hipLaunchKernelGGL(or_flag_kernel, dim3(1), dim3(1), 0, s, flags_d, sp.flags);
+  return true;
+}
+
 // packs planes [plo, phi) of the 3-D-embedded volume (the rest of `levels` is not touched / not read)
 inline int neigh_pack(Context *c, hipStream_t s, const Geo &g, const NeighPlan &p, int plo, int phi,
                       const int32_t *image, const uint8_t *mask, int Ng, int *flags_d, uint8_t **levels) {
+  if (take_shared_pack(s, g, image, mask, Ng, flags_d, levels)) return check_launch("or_flag_kernel");
   PRAD_TRY(c->get<uint8_t>("levels", (size_t)g.n + 64, levels));
   Timed t(*c, "pack", s);
   const long long plane = (long long)p.Ny * p.Nx, off = plo * plane, n = (phi - plo) * plane;

@@ -2978,6 +2978,29 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   double *res = (double *)blk;
   *results = res;
   auto at = [&](int k) { return res + layout[k]; };
+  // ONE byte-packed copy of the volume for the neighbourhood pass and the GLSZM (each of them packed for itself until round 6),
+  // made on the caller's stream in front of the fork; a buffer per ticket: up to four images are in flight
+  struct ClearShared {
+    ~ClearShared() { shared_pack() = SharedPack(); }
+  } clear_shared;
+  if ((classes & (PRAD_IMG_GLDM | PRAD_IMG_NGTDM | PRAD_IMG_GLSZM)) && Nd <= 3 && Ng <= 255 && n < 0x7fffffffLL &&
+      !getenv("PRAD_IMG_NO_SHARED_PACK")) {
+    char name[32];
+    snprintf(name, sizeof(name), "img_pack%d", (int)(q.seq % PRAD_IMG_TICKETS));
+    uint8_t *pk = nullptr;
+    int *pf = nullptr;
+    c.workspace = 0;
+    PRAD_TRY(c.get<uint8_t>(name, (size_t)n + 64 + 16, &pk));
+    pf = (int *)(pk + (((size_t)n + 64 + 3) & ~(size_t)3));
+    PRAD_HIP(hipMemsetAsync(pf, 0, sizeof(int) * 2, (hipStream_t)stream));
+    const int vec_ok = ((((uintptr_t)levels) | ((uintptr_t)mask) | ((uintptr_t)pk)) & 15) == 0;
+    const int NX = size[Nd - 1];
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((n / 16 + 255) / 256, 4096));
+    hipLaunchKernelGGL(pack_levels_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, levels, mask, n, NX, NX, 0, Ng, pk, pf, vec_ok, 0);
+    PRAD_TRY(check_launch("pack_levels_kernel"));
+    SharedPack &sp = shared_pack();
+    sp.image = levels; sp.mask = mask; sp.n = n; sp.Ng = Ng; sp.levels = pk; sp.flags = pf;
+  }
   // the side streams wait for everything queued on the caller's stream (binning produced the levels there)
   PRAD_HIP(hipEventRecord(q.in, (hipStream_t)stream));
   for (int k = 0; k < PRAD_IMG_STREAMS; k++) PRAD_HIP(hipStreamWaitEvent(q.s[k], q.in, 0));
