@@ -1144,7 +1144,19 @@ int pairs_glcm_glrlm(Call &k, int Ng, int Nr, double *glcm, double *glrlm, bool 
     const int npass = ((k.Na + AG - 1) / AG) * ntile;
     const size_t lds = sizeof(u32) * (size_t)AG * RT * Ng;
     PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&pairs_glcm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n + 1023) / 1024, (2LL * cus + npass - 1) / npass));
+    // workgroups per pass: the count (2 .. 4 per CU over all passes) that leaves the fewest CUs idle in the last round -- one
+    // 150 KB table per CU at a time (186 passes at 300 levels x 3 workgroups were 2.2 rounds, billed as 3)
+    long long gbest = 1;
+    double ebest = 0;
+    for (long long gtry = std::max<long long>(1, 2LL * cus / npass); gtry <= std::max<long long>(1, (4LL * cus + npass - 1) / npass); gtry++) {
+      const long long total = gtry * npass, rounds = (total + cus - 1) / cus;
+      const double eff = (double)total / (double)(rounds * cus);
+      if (eff > ebest + 1e-9) {
+        ebest = eff;
+        gbest = gtry;
+      }
+    }
+    const unsigned gx = (unsigned)std::max<long long>(1, std::min<long long>((k.g.n / 8 + 1023) / 1024, gbest));
     hipLaunchKernelGGL(pairs_glcm_kernel, dim3(gx, (unsigned)npass), dim3(1024), lds, s, L, dims[0], dims[1], dims[2], A, AG, RT,
                        ntile, Ng, gacc, k.flags_d);
     PRAD_TRY(check_launch("pairs_glcm_kernel"));
