@@ -213,7 +213,12 @@ def _run_threaded(indices, cases, worker, threads: int):
     state) per host thread and its C calls release the GIL, so one case's Python / launch overhead (a third of a 256^3
     case) runs under another case's kernels.  Every thread works on a HIP stream of its own; the threads persist
     between calls (_WorkerPool)."""
-    return _pool(threads).run(list(indices), cases, worker)
+    for attempt in (0, 1):
+        try:
+            return _pool(threads).run(list(indices), cases, worker)
+        except RuntimeError as e:      # (another host thread changed the pool's thread count between _pool() and run(): ADVICE r5)
+            if attempt or "worker pool was shut down" not in str(e):
+                raise
 
 
 def run_batch(cases: Sequence, worker: Callable, gather: bool = True, threads: int = 1, many: Callable = None):

@@ -476,6 +476,13 @@ def segment_image_enqueue(levels, mask, Ng, Ns, requests, force2D=False, force2D
                 return engine.firstorder_stats(_to_device(fo["raw"]), _to_device(mask), fo["shift"])
             return dict(zip(engine.FIRSTORDER_FIELDS, vals[:15].tolist()))
         out["firstorder"] = fin_fo
+    lay = tok.get("layout")
+    if lay is not None:
+        # issued by this thread (no launcher): what the device route declined is known already -- those classes are left out
+        # and the caller queues them on its own; with the launcher the same is found out when the closure runs
+        for cls, k in (("glcm", 0), ("glrlm", 3), ("gldm", 5), ("ngtdm", 7), ("glszm", 8), ("firstorder", 10)):
+            if lay[k] < 0:
+                out.pop(cls, None)
     return tok, out
 
 

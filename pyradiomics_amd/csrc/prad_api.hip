@@ -802,6 +802,9 @@ bool pack_inline_ok(const Call &k, const VolState &v) {
   if (!(v.glcm && v.glrlm && v.p.pitch == v.p.Nx && v.p.padw == 0 && (k.g.n % 16) == 0 &&
         ((((uintptr_t)k.image) | ((uintptr_t)k.mask) | ((uintptr_t)v.levels)) & 15) == 0))
     return false;
+  // (PackWave16 keeps its piece's voxel index in 32 bits, PackWave its row-flag index: side-job packs stay below 2^31 voxels --
+  //  ADVICE r5; a larger volume packs in a launch of its own)
+  if (k.g.n >= (1LL << 31)) return false;
   if (v.p.fw2) return v.levels16 && v.p.pitch16 == 2 * v.p.Nx && (((uintptr_t)v.levels16) & 15) == 0;
   return v.p.fw && v.p.fused;
 }
@@ -1362,11 +1365,13 @@ int texture_gldm(const int32_t *image, const uint8_t *mask, const int *size, int
     c.last_path = "neigh";
     return c.end_call(s);
   }
+  bool irregular = false;      // the byte kernels' pack already saw a level outside [1, Ng]: the tier would only find it again
   if (done) {
     PRAD_TRY(read_flags(k));
     done = (k.flags_h[0] == 0);
+    irregular = !done;
   }
-  if (!done && !c.deferred) {
+  if (!done && !c.deferred && !irregular) {
     PRAD_TRY(pairs_neigh(k, false, Ng, alpha, out, &done));
     if (done) c.last_path = "pairs";
   } else if (done) {
@@ -1399,11 +1404,13 @@ int texture_ngtdm(const int32_t *image, const uint8_t *mask, const int *size, in
     c.last_path = "neigh";
     return c.end_call(s);
   }
+  bool irregular = false;      // the byte kernels' pack already saw a level outside [1, Ng]: the tier would only find it again
   if (done) {
     PRAD_TRY(read_flags(k));
     done = (k.flags_h[0] == 0);
+    irregular = !done;
   }
-  if (!done && !c.deferred) {
+  if (!done && !c.deferred && !irregular) {
     PRAD_TRY(pairs_neigh(k, true, Ng, 0, out, &done));
     if (done) c.last_path = "pairs";
   } else if (done) {

@@ -35,3 +35,15 @@ def test_product_table_equals_restatement_and_swt_preserves_energy(name):
     for ax in range(3):                                          # one undecimated level: |a|^2 + |d|^2 = 2 |x|^2 along every axis
         a, d = fo.swt_axis(x, lo, ax), fo.swt_axis(x, hi, ax)
         assert abs((a * a).sum() + (d * d).sum() - 2.0 * (x * x).sum()) < 1e-9 * (x * x).sum()
+
+
+@pytest.mark.parametrize("name", WAVELETS)
+def test_table_equals_pywavelets_when_it_is_installed(name):
+    """the identities above cannot tell a filter from its time reverse or a db phase from a sym phase; where
+    PyWavelets is importable the tables are compared with pywt.Wavelet(name).dec_lo / dec_hi digit for digit (skipped in
+    this image: pywt is not installed and there is no network)"""
+    pywt = pytest.importorskip("pywt")
+    w = pywt.Wavelet(name)
+    lo, hi = wavelet_filters(name)
+    np.testing.assert_allclose(lo, np.asarray(w.dec_lo), rtol=0, atol=5e-16)
+    np.testing.assert_allclose(hi, np.asarray(w.dec_hi), rtol=0, atol=5e-16)
