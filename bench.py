@@ -38,9 +38,9 @@ ALG_BYTES_PER_VOXEL = 5.0       # int32 level + uint8 mask, read once (SURVEY.md
 # instruction every 2.65 cycles per SIMD (256 CUs x 4 SIMDs, 2.4 GHz).
 LDS_ATOMIC_PEAK = 256 * 2.4e9 / 4.1       # ds_add wave-instructions / s
 VALU_PEAK = 1024 * 2.4e9 / 2.65           # VALU wave-instructions / s
-# Counter figures that rocprofv3 collects (it cannot run inside bench.py): written by scripts/prof_r05.sh into this file
+# Counter figures that rocprofv3 collects (it cannot run inside bench.py): written by scripts/prof_r06.sh into this file
 # from --pmc passes over THIS bench command with the committed build; used only when the workload matches.
-PROFILED_FILE = os.path.join(ROOT, "profiles", "r05_counters.json")
+PROFILED_FILE = os.path.join(ROOT, "profiles", "r06_counters.json")
 
 
 def make_volume(size: int, levels: int, dist: str, seed: int, device) -> tuple[torch.Tensor, torch.Tensor]:
