@@ -2900,7 +2900,7 @@ long long prad_glszm_zones(int v, int *tempData, long long capacity_pairs) {
 }  // extern "C"
 namespace {
 struct ImageQueues {
-  hipStream_t s[PRAD_IMG_STREAMS] = {};
+  hipStream_t sp[2][PRAD_IMG_STREAMS] = {};   // two sets of side streams: consecutive images alternate (round 6)
   hipEvent_t in = nullptr;
   hipEvent_t done[PRAD_IMG_TICKETS][PRAD_IMG_STREAMS] = {};
   int *flag[PRAD_IMG_TICKETS][PRAD_IMG_STREAMS] = {};
@@ -2919,7 +2919,8 @@ void release_image_queues() {
     ImageQueues &q = tab[d];
     if (q.device < 0) continue;
     for (int k = 0; k < PRAD_IMG_STREAMS; k++)
-      if (q.s[k]) (void)hipStreamDestroy(q.s[k]);
+      for (int h = 0; h < 2; h++)
+        if (q.sp[h][k]) (void)hipStreamDestroy(q.sp[h][k]);
     if (q.in) (void)hipEventDestroy(q.in);
     for (int t = 0; t < PRAD_IMG_TICKETS; t++)
       for (int k = 0; k < PRAD_IMG_STREAMS; k++)
@@ -2940,7 +2941,8 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   if ((classes & PRAD_IMG_FIRSTORDER) && !raw) return fail(PRAD_E_ARG, "image_enqueue: first order needs the undiscretised image");
   ImageQueues &q = image_queues();
   if (q.device != c.device) {
-    for (int k = 0; k < PRAD_IMG_STREAMS; k++) PRAD_HIP(hipStreamCreateWithFlags(&q.s[k], hipStreamNonBlocking));
+    for (int h = 0; h < 2; h++)
+      for (int k = 0; k < PRAD_IMG_STREAMS; k++) PRAD_HIP(hipStreamCreateWithFlags(&q.sp[h][k], hipStreamNonBlocking));
     PRAD_HIP(hipEventCreateWithFlags(&q.in, hipEventDisableTiming));
     for (int t = 0; t < PRAD_IMG_TICKETS; t++)
       for (int k = 0; k < PRAD_IMG_STREAMS; k++) PRAD_HIP(hipEventCreateWithFlags(&q.done[t][k], hipEventDisableTiming));
@@ -2949,6 +2951,13 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   if (q.used[q.seq % PRAD_IMG_TICKETS] != 0)
     return fail(PRAD_E_ARG, "image_enqueue: %d images are in flight on this thread; prad_image_wait one first", PRAD_IMG_TICKETS);
   PRAD_TRY(prad_set_deferred(1));     // (creates the sticky word on first use)
+  // Consecutive images alternate between two sets of side streams and workspace sets: the tail of image i on a stream -- its
+  // chain of small formula kernels, ~0.1 ms in which the GPU is nearly idle -- runs under the first kernels of image i + 1
+  // instead of in front of them (one stream per class serialised the images of a case class by class).  PRAD_IMG_ONE_SET=1: as before.
+  static const bool one_set = getenv("PRAD_IMG_ONE_SET") != nullptr;
+  const int par = one_set ? 0 : (int)(q.seq & 1);
+  hipStream_t *qs = q.sp[par];
+  const int wso = 4 * par;               // workspace sets 4..7 (even images), 8..11 (odd images)
   struct Restore {
     Context &c;
     ~Restore() {
@@ -3022,31 +3031,31 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   }
   // the side streams wait for everything queued on the caller's stream (binning produced the levels there)
   PRAD_HIP(hipEventRecord(q.in, (hipStream_t)stream));
-  for (int k = 0; k < PRAD_IMG_STREAMS; k++) PRAD_HIP(hipStreamWaitEvent(q.s[k], q.in, 0));
+  for (int k = 0; k < PRAD_IMG_STREAMS; k++) PRAD_HIP(hipStreamWaitEvent(qs[k], q.in, 0));
   unsigned used = 0;
   // (workspace sets 4, 5, 6: sets 1 - 3 belong to callers that drive side streams of their own, engine.side_queue)
   // ---- side stream 0: GLCM + GLRLM (one sweep), GLDM + NGTDM (one pass over the neighbourhoods) ----
-  c.workspace = 4;
+  c.workspace = 4 + wso;
   if (classes & (PRAD_IMG_GLCM | PRAD_IMG_GLRLM)) {
     double *gm = nullptr, *rm = nullptr;
     PRAD_TRY(c.get<double>("img_glcm", (size_t)Ng * Ng * Na, &gm));
     PRAD_TRY(c.get<double>("img_glrlm", (size_t)Ng * Nr * Na, &rm));
-    int rc = texture_pairs_runs(levels, mask, size, Nd, ang.data(), Na, Ng, Nr, 1, nullptr, 0, force2Ddim, gm, rm, q.s[0]);
+    int rc = texture_pairs_runs(levels, mask, size, Nd, ang.data(), Na, Ng, Nr, 1, nullptr, 0, force2Ddim, gm, rm, qs[0]);
     if (rc != PRAD_OK) return rc;
-    c.workspace = 4;     // (texture_pairs_runs leaves the lane guard's state)
+    c.workspace = 4 + wso;     // (texture_pairs_runs leaves the lane guard's state)
     c.deferred = true;
-    PRAD_TRY(prad_deferred_join(q.s[0]));
+    PRAD_TRY(prad_deferred_join(qs[0]));
     if (classes & PRAD_IMG_GLCM) {
-      PRAD_TRY(prad_glcm_features_dev(gm, Ng, Na, symmetric, at(0), (int *)at(1), q.s[0]));
+      PRAD_TRY(prad_glcm_features_dev(gm, Ng, Na, symmetric, at(0), (int *)at(1), qs[0]));
       if (layout[2] >= 0) {
-        rc = prad_glcm_mcc_dev(gm, Ng, Na, symmetric, at(2), q.s[0]);
+        rc = prad_glcm_mcc_dev(gm, Ng, Na, symmetric, at(2), qs[0]);
         if (rc == PRAD_E_UNSUPPORTED) layout[2] = -1;       // (too many grey levels for the device MCC: the caller's host route)
         else if (rc != PRAD_OK) return rc;
       }
     }
     if (classes & PRAD_IMG_GLRLM) {
       PRAD_TRY(prad_zone_matrix_features_dev(rm, Ng, Nr, Na, (long long)Nr * Na, (long long)Na, 1LL, nullptr, at(3),
-                                             (int *)at(4), q.s[0]));     // (size values 1 .. Nr: no table)
+                                             (int *)at(4), qs[0]));     // (size values 1 .. Nr: no table)
     }
     used |= 1u;
   }
@@ -3056,25 +3065,25 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   if (classes & (PRAD_IMG_GLDM | PRAD_IMG_NGTDM)) {
     static const bool own_stream = !getenv("PRAD_IMG_NEIGH_ON_SWEEP_STREAM");
     const int ks = own_stream ? 3 : 0;
-    c.workspace = own_stream ? 7 : 4;
+    c.workspace = (own_stream ? 7 : 4) + wso;
     const int W = 2 * Nab + 1;
     double *dm = nullptr, *nm = nullptr;
     PRAD_TRY(c.get<double>("img_gldm", (size_t)Ng * W, &dm));
     PRAD_TRY(c.get<double>("img_ngtdm", (size_t)Ng * 3, &nm));
-    PRAD_TRY(texture_gldm_ngtdm(levels, mask, size, Nd, angb.data(), Nab, Ng, alpha, dm, nm, q.s[ks]));
-    c.workspace = own_stream ? 7 : 4;
+    PRAD_TRY(texture_gldm_ngtdm(levels, mask, size, Nd, angb.data(), Nab, Ng, alpha, dm, nm, qs[ks]));
+    c.workspace = (own_stream ? 7 : 4) + wso;
     c.deferred = true;
     if (classes & PRAD_IMG_GLDM) {
-      PRAD_TRY(prad_zone_matrix_features_dev(dm, Ng, W, 1, (long long)W, 1LL, 0LL, nullptr, at(5), (int *)at(6), q.s[ks]));
+      PRAD_TRY(prad_zone_matrix_features_dev(dm, Ng, W, 1, (long long)W, 1LL, 0LL, nullptr, at(5), (int *)at(6), qs[ks]));
     }
-    if (classes & PRAD_IMG_NGTDM) PRAD_TRY(prad_ngtdm_features_dev(nm, Ng, at(7), q.s[ks]));
+    if (classes & PRAD_IMG_NGTDM) PRAD_TRY(prad_ngtdm_features_dev(nm, Ng, at(7), qs[ks]));
     used |= 1u << ks;
   }
   // ---- side stream 1: GLSZM ----
   if (classes & PRAD_IMG_GLSZM) {
-    c.workspace = 5;
+    c.workspace = 5 + wso;
     const int rc = prad_glszm_features_dev(levels, mask, size, Nd, angb.data(), Nab, Ng, (int)std::min<long long>(Ns, 2147483647LL),
-                                           at(8), (int *)at(9), q.s[1]);
+                                           at(8), (int *)at(9), qs[1]);
     if (rc == PRAD_E_UNSUPPORTED) layout[8] = layout[9] = -1;
     else if (rc != PRAD_OK) return rc;
     else used |= 2u;
@@ -3082,8 +3091,8 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   }
   // ---- side stream 2: first order ----
   if (classes & PRAD_IMG_FIRSTORDER) {
-    c.workspace = 6;
-    const int rc = prad_firstorder_queue_dev(raw, raw_dtype, mask, n, Ns, voxelArrayShift, at(10), q.s[2]);
+    c.workspace = 6 + wso;
+    const int rc = prad_firstorder_queue_dev(raw, raw_dtype, mask, n, Ns, voxelArrayShift, at(10), qs[2]);
     if (rc == PRAD_E_UNSUPPORTED) layout[10] = -1;
     else if (rc != PRAD_OK) return rc;
     else used |= 4u;
@@ -3098,8 +3107,8 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
     PRAD_TRY(c.arena_alloc(sizeof(int), &f));
     q.flag[t][k] = (int *)f;
     *q.flag[t][k] = 0;
-    PRAD_TRY(prad_deferred_mark(q.flag[t][k], q.s[k]));
-    PRAD_HIP(hipEventRecord(q.done[t][k], q.s[k]));
+    PRAD_TRY(prad_deferred_mark(q.flag[t][k], qs[k]));
+    PRAD_HIP(hipEventRecord(q.done[t][k], qs[k]));
   }
   q.used[t] = used | 0x80000000u;     // (in flight, even when every class was declined)
   *ticket = t;
@@ -3119,7 +3128,9 @@ int prad_image_wait(int ticket) {
   }
   q.used[ticket] = 0;
   if (bad) {
-    for (int k = 0; k < PRAD_IMG_STREAMS; k++) (void)prad_deferred_status(q.s[k]);     // synchronises and clears the sticky word
+    for (int h = 0; h < 2; h++)
+      for (int k = 0; k < PRAD_IMG_STREAMS; k++)
+        if (q.sp[h][k]) (void)prad_deferred_status(q.sp[h][k]);     // synchronises and clears the sticky word
     return fail(PRAD_E_DEFERRED, "a queued call of the image saw masked levels outside [1, Ng]; repeat it synchronously");
   }
   return PRAD_OK;
