@@ -860,6 +860,34 @@ template <bool G, bool R, bool F>
 int launch_sweeps(Call &k, const VolState &v, const PackJob &pj) {
   const SweepPlan &p = v.p;
   if (p.lines.count > 0 && p.fw && G && R && F) {
+    // PRAD_ROWS_STREAM=1 (round-6 experiment): the x angle's launch on a side stream, concurrent with the walk launch -- it only
+    // needs the packed levels, writes its own accumulator slots, and its 8-wave workgroups could take the CUs the walk's
+    // workgroups leave in the launch's last 10 % (roles finish up to 8 % apart)
+    static const bool rows_side = getenv("PRAD_ROWS_STREAM") != nullptr;
+    if (rows_side && p.row_slot >= 0) {
+      static thread_local hipStream_t side = nullptr;
+      static thread_local hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (!side) {
+        int lo = 0, hi = 0;
+        PRAD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // (lo = the numerically largest = least urgent)
+        PRAD_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, getenv("PRAD_ROWS_STREAM_PRIO") ? atoi(getenv("PRAD_ROWS_STREAM_PRIO")) : lo));
+        PRAD_HIP(hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        PRAD_HIP(hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+      }
+      PRAD_HIP(hipEventRecord(e0, k.s));
+      PRAD_HIP(hipStreamWaitEvent(side, e0, 0));
+      {
+        Timed t(*k.c, "sweep", k.s);
+        PRAD_TRY(launch_fw(k, p, pj, v.levels, v.rowzero, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi, v.flags_d));
+      }
+      Call k2 = k;
+      k2.s = side;
+      if (p.RSfw_rows < v.Nr) PRAD_TRY(launch_fw_rows<true>(k2, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.flags_d));
+      else PRAD_TRY(launch_fw_rows<false>(k2, p, v.levels, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.flags_d));
+      PRAD_HIP(hipEventRecord(e1, side));
+      PRAD_HIP(hipStreamWaitEvent(k.s, e1, 0));
+      return PRAD_OK;
+    }
     {
       Timed t(*k.c, "sweep", k.s);
       PRAD_TRY(launch_fw(k, p, pj, v.levels, v.rowzero, v.Ng, v.Nr, v.glcm_acc, v.glrlm_acc, v.multi, v.flags_d));
