@@ -116,6 +116,30 @@ def test_gldm_ngtdm_beyond_the_byte_kernels_take_the_pairs_tier(shape, Ng, dist,
         assert _lib.last_path() == "generic"
 
 
+@pytest.mark.parametrize("shape,Ng,dist,f2d", [((20, 33, 40), 32, [1, 2], None), ((14, 21, 30), 32, [1, 2, 3], None), ((9, 30, 31), 200, [1, 2, 3], None),
+                                              ((12, 40, 36), 64, [1, 2], 0), ((10, 25, 27), 500, [1, 2], 2), ((40, 41), 100, [1, 2, 3], None),
+                                              ((5, 6, 7), 12, [1, 2], None), ((16, 20, 24), 32, [2], None)])
+def test_ngtdm_over_full_boxes_of_neighbours_is_box_sums(shape, Ng, dist, f2d, checker):
+    """NGTDM (cmatrices.c:543-658) for distances [1, 2] / [1, 2, 3] -- every offset of a 5^3 / 7^3 cube, 124 / 342 neighbours --
+    as separable box sums (round 6), at any level count, with holes in the mask, force2D, volumes smaller than the box; a
+    neighbour set that is NOT a full box (distances [2]: a shell) keeps its kernel.  Counts bit for bit, the float column
+    within 1e-12 of the reference's raster-order sum; an irregular level raises what the reference raises"""
+    from pyradiomics_amd import cmatrices as cm, _lib
+    img, msk = _case(shape, Ng, 11, smooth=True, hole=len(shape) == 3)
+    force, dim = f2d is not None, (f2d or 0)
+    a = cm.calculate_ngtdm(img, msk, dist, Ng, force, dim)
+    nd = len(shape) - (1 if force else 0)
+    full_box = dist != [2] and (2 * max(dist) + 1) ** nd - 1 > 26      # (up to 26 neighbours the byte kernel keeps the call)
+    assert _lib.last_path() == ("pairs" if full_box or Ng > 255 else "neigh"), _lib.last_path()
+    b = checker.calculate_ngtdm(img, msk, dist, Ng, force, dim)
+    assert np.array_equal(a[..., 0], b[..., 0]) and np.array_equal(a[..., 2], b[..., 2])
+    np.testing.assert_allclose(a[..., 1], b[..., 1], rtol=1e-12, atol=1e-12)
+    bad = img.copy()
+    bad[tuple(np.argwhere(msk)[0])] = Ng + 1
+    with pytest.raises(IndexError):
+        cm.calculate_ngtdm(bad, msk, dist, Ng, force, dim)
+
+
 def test_pairs_tier_at_config_size(checker):
     """VERDICT r4 item 6's targets, on the volume they are quoted for: 256^3, GLCM with distances [1, 2] at 32 levels, and
     GLCM + GLRLM at 255 levels, bit-exact; device ms printed (bench.py modes.fallback reports them)"""
