@@ -552,6 +552,19 @@ def mode_batch(device, rank: int, cases: int, fence, world: int = 1):
         fence()
         lat.append((time.perf_counter() - t1) * 1e3)
     mode_batch.one_thread_ms = sorted(lat)[len(lat) // 2]
+    # ... and the same cases back to back on this one thread (no fence between them, one case of overlap when executeMany is on):
+    # what a single-threaded caller that loops over its cases gets per case
+    loop_cases = list(range(1, min(cases, 5) + 1)) * 2
+    fence()
+    t1 = time.perf_counter()
+    if one.many is not None:
+        for _ in one.many(loop_cases):
+            pass
+    else:
+        for c in loop_cases:
+            one(c)
+    fence()
+    mode_batch.one_thread_loop_ms = (time.perf_counter() - t1) / len(loop_cases) * 1e3
     return cases, dt, nfeat
 
 
@@ -847,6 +860,7 @@ def main() -> None:
             return {"value": round(world * nc / dt_b, 2), "unit": "cases/s", "cases_per_rank": nc, "features_per_case": nfeat,
                     "ms_per_case_per_gpu": round(dt_b / nc * 1e3, 2),
                     "one_thread_ms_per_case": round(mode_batch.one_thread_ms, 2),
+                    "one_thread_loop_ms_per_case": round(mode_batch.one_thread_loop_ms, 2),
                     "case": "256^3 int16 volume from host memory, ball ROI (38 %% of the box), Original + 8 wavelet "
                             "sub-bands, six feature classes; %s" % mode_batch.how}
 
