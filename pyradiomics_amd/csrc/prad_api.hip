@@ -749,11 +749,21 @@ struct VolState {
   int *multi = nullptr;
   int *flags_d = nullptr;
   bool packed_inline = false;   // the pack rides in the previous volume's sweep launch (PackJob)
+  int lane = -1;                // workspace set of the volume (pipeline mode)
 };
+
+// PRAD_FINALIZE_STREAM=1 (round-6 experiment): the finalize launches of a pipeline volume on a side stream, see pipeline_retire
+bool fin_side() {
+  static const bool on = getenv("PRAD_FINALIZE_STREAM") != nullptr && atoi(getenv("PRAD_FINALIZE_STREAM")) != 0;
+  return on;
+}
+int fin_wait_for_lane(hipStream_t s, int lane);      // `s` waits for the side-stream finalize that last read workspace set `lane`
 
 // workspace of a volume + the memsets that must precede its pack and its sweeps
 int vol_prepare(Call &k, const SweepPlan &p, int Ng, int Nr, double *glcm, double *glrlm, VolState &v) {
   Context &c = *k.c;
+  if (fin_side() && c.lane >= 0) PRAD_TRY(fin_wait_for_lane(k.s, c.lane));
+  v.lane = c.lane;
   v.valid = true;
   v.p = p;
   v.Ng = Ng;
@@ -1042,6 +1052,10 @@ struct PipeState {
   unsigned long long seq = 0;
   hipEvent_t ev = nullptr;
   int mode = -1;                // 1 pipeline, 0 lanes
+  // side stream of the finalize launches (fin_side()): fin_done[l] is recorded behind the finalize that read workspace set l
+  hipStream_t fin = nullptr;
+  hipEvent_t fin_in = nullptr, fin_all = nullptr, fin_done[4] = {};
+  bool fin_used[4] = {};
 };
 PipeState &pipe_state() {
   static thread_local PipeState p;
@@ -1073,8 +1087,46 @@ int pipeline_retire(Context &c, hipStream_t s, const PackJob &pj) {
   int *sticky = nullptr;
   PRAD_TRY(pipeline_sticky(c, &sticky));
   PRAD_TRY(vol_sweep(k, ps.pending, pj));
-  PRAD_TRY(vol_finalize(k, ps.pending, sticky));
+  if (fin_side() && ps.pending.lane >= 0 && ps.pending.lane < 4) {
+    // The three finalize launches (13 us + their launch gaps per 512^3 volume) need a handful of workgroups and no LDS: on a
+    // side stream they run under the next volume's walk launch instead of in front of it.  The accumulators they read belong to
+    // workspace set `lane`: with THREE alternating sets the next volume that zeroes this set is two steps away.
+    if (!ps.fin) {
+      PRAD_HIP(hipStreamCreateWithFlags(&ps.fin, hipStreamNonBlocking));
+      PRAD_HIP(hipEventCreateWithFlags(&ps.fin_in, hipEventDisableTiming));
+      PRAD_HIP(hipEventCreateWithFlags(&ps.fin_all, hipEventDisableTiming));
+      for (int l = 0; l < 4; l++) PRAD_HIP(hipEventCreateWithFlags(&ps.fin_done[l], hipEventDisableTiming));
+    }
+    PRAD_HIP(hipEventRecord(ps.fin_in, s));
+    PRAD_HIP(hipStreamWaitEvent(ps.fin, ps.fin_in, 0));
+    Call k2 = k;
+    k2.s = ps.fin;
+    PRAD_TRY(vol_finalize(k2, ps.pending, sticky));
+    PRAD_HIP(hipEventRecord(ps.fin_done[ps.pending.lane], ps.fin));
+    ps.fin_used[ps.pending.lane] = true;
+  } else {
+    PRAD_TRY(vol_finalize(k, ps.pending, sticky));
+  }
   ps.pending.valid = false;
+  return PRAD_OK;
+}
+
+int fin_wait_for_lane(hipStream_t s, int lane) {
+  PipeState &ps = pipe_state();
+  if (lane < 0 || lane >= 4 || !ps.fin || !ps.fin_used[lane]) return PRAD_OK;
+  PRAD_HIP(hipStreamWaitEvent(s, ps.fin_done[lane], 0));
+  return PRAD_OK;
+}
+// everything queued on the finalize side stream so far: `s` waits for it (s != nullptr) or the host does
+int fin_join(hipStream_t s, bool host) {
+  PipeState &ps = pipe_state();
+  if (!ps.fin) return PRAD_OK;
+  if (host) {
+    PRAD_HIP(hipStreamSynchronize(ps.fin));
+    return PRAD_OK;
+  }
+  PRAD_HIP(hipEventRecord(ps.fin_all, ps.fin));
+  PRAD_HIP(hipStreamWaitEvent(s, ps.fin_all, 0));
   return PRAD_OK;
 }
 
@@ -1240,7 +1292,7 @@ int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *siz
   } lane_guard{c};
   bool pipe = c.deferred && !voxels && pipeline_mode();
   if (c.deferred && !voxels && !pipe) PRAD_TRY(c.lane_begin(s, &s));   // lanes mode: whole-volume deferred calls alternate between lanes
-  if (pipe) c.lane = (int)(pipe_state().seq++ & 1);                    // pipeline mode: the workspace sets alternate, the stream is the caller's
+  if (pipe) c.lane = (int)(pipe_state().seq++ % (fin_side() ? 3u : 2u));   // pipeline mode: the workspace sets alternate (three with the finalize side stream), the stream is the caller's
   Call k;
   PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, Nvox, voxels, kernelRadius, force2Ddim, s, false));
   SweepPlan p = plan_sweep(k, Ng, Nr, glcm != nullptr, glrlm != nullptr);
@@ -1253,7 +1305,7 @@ int texture_pairs_runs(const int32_t *image, const uint8_t *mask, const int *siz
     pipe = false;
     c.lane = -1;
     PRAD_TRY(c.lane_begin(user, &s));
-    if (c.lane >= 0) c.lane += 2;      // (workspace sets of their own: #0 / #1 belong to the pipeline's alternating volumes)
+    if (c.lane >= 0) c.lane += fin_side() ? 3 : 2;      // (workspace sets of their own: #0 / #1 (/ #2) belong to the pipeline's alternating volumes)
     PRAD_TRY(setup_call(k, image, mask, size, Nd, angles, Na, Nvox, voxels, kernelRadius, force2Ddim, s, false));
     p = plan_sweep(k, Ng, Nr, glcm != nullptr, glrlm != nullptr);
   }
@@ -2167,10 +2219,13 @@ int prad_set_device(int device) {
     if (pipe_state().pending.valid && c.device_set && hipSetDevice(c.device) == hipSuccess) {
       (void)pipeline_flush(c);   // a volume still pending on the old device: retire it there
       if (pipe_state().s) (void)hipStreamSynchronize(pipe_state().s);
+      (void)fin_join(nullptr, true);
     }
     pipe_state().pending.valid = false;
     pipe_state().s = nullptr;
     pipe_state().ev = nullptr;
+    pipe_state().fin = nullptr;      // (the side stream and its events belonged to the old device)
+    for (int l = 0; l < 4; l++) pipe_state().fin_used[l] = false;
     c.own_stream = nullptr;  // streams belong to a device; new ones are created lazily
     for (int l = 0; l < PRAD_MAX_LANES; l++) {
       if (c.lane_stream[l]) (void)hipStreamSynchronize(c.lane_stream[l]);
@@ -2200,6 +2255,7 @@ int prad_release_workspace(void) {
   if (pipe_state().pending.valid) {        // the pending volume's buffers are about to go away: retire it first
     (void)pipeline_flush(c);
     if (pipe_state().s) (void)hipStreamSynchronize(pipe_state().s);
+    (void)fin_join(nullptr, true);
     pipe_state().pending.valid = false;
   }
   glszm_state().valid = false;            // its zone list lives in the workspace
@@ -2306,6 +2362,7 @@ int prad_set_deferred_mode(int mode) {
   PipeState &ps = pipe_state();
   PRAD_TRY(pipeline_flush(c));
   if (ps.s) PRAD_HIP(hipStreamSynchronize(ps.s));
+  PRAD_TRY(fin_join(nullptr, true));
   PRAD_TRY(c.lanes_sync());
   ps.mode = mode;
   return PRAD_OK;
@@ -2331,6 +2388,7 @@ int prad_deferred_join(void *stream) {
     PRAD_HIP(hipEventRecord(ps.ev, ps.s));
     PRAD_HIP(hipStreamWaitEvent((hipStream_t)stream, ps.ev, 0));
   }
+  PRAD_TRY(fin_join((hipStream_t)stream, false));
   return c.lanes_join((hipStream_t)stream);
 }
 int prad_deferred_mark(int *flag, void *stream) {
@@ -2338,6 +2396,7 @@ int prad_deferred_mark(int *flag, void *stream) {
   PRAD_TRY(c.ensure_device());
   if (!flag || !c.in_arena(flag, sizeof(int))) return fail(PRAD_E_ARG, "deferred_mark: flag must lie in the result arena");
   PRAD_TRY(pipeline_flush(c));
+  PRAD_TRY(fin_join((hipStream_t)stream, false));
   int *sticky = nullptr;
   PRAD_TRY(c.get<int>("deferred_sticky", 16, &sticky));
   PRAD_HIP(hipMemcpyAsync(flag, sticky, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -2348,6 +2407,7 @@ int prad_deferred_status(void *stream) {
   PRAD_TRY(c.ensure_device());
   PRAD_TRY(pipeline_flush(c));
   if (pipe_state().s) PRAD_HIP(hipStreamSynchronize(pipe_state().s));
+  PRAD_TRY(fin_join(nullptr, true));
   PRAD_HIP(hipStreamSynchronize((hipStream_t)stream));
   PRAD_TRY(c.lanes_sync());
   if (!c.has("deferred_sticky")) return PRAD_OK;  // no deferred call yet
