@@ -235,9 +235,12 @@ def image_enqueue(levels: torch.Tensor, mask: torch.Tensor, raw, Ng: int, Ns: in
 
 def image_wait(token) -> bool:
     """waits for the work of an image_enqueue() token only; False when a queued call saw levels outside [1, Ng] (void)"""
+    if "waited" in token:           # (a launcher token that was waited for already: its slot is free, the verdict is kept)
+        return token["waited"]
     if token.get("job") is not None:
         lib = _lib.load()
         job, token["job"] = int(token["job"]), None
+        token["waited"] = False
         res_p = C.c_void_p()
         layout = (C.c_int * 16)()
         rc0 = lib.prad_image_submit_result(job, C.byref(res_p), layout)
@@ -252,6 +255,7 @@ def image_wait(token) -> bool:
         if rc == _lib.PRAD_E_DEFERRED:
             return False
         _lib.raise_for(rc, "image wait")
+        token["waited"] = True
         return True
     if token.get("generation", _arena_gen.value) != _arena_gen.value:
         token["keep"] = None

@@ -681,3 +681,54 @@ def test_sliding_window_maps_are_only_taken_where_they_apply():
     few = vox[:, ::50]                                                               # sparse centres: not worth a whole map
     _, _, variant = _slide_vs_window(img, msk, 8, np.ascontiguousarray(few), ["JointEntropy"], kernelRadius=2)
     assert variant == "window"
+
+
+@pytest.mark.gpu
+def test_launcher_and_two_half_binning_equal_the_one_call_forms(monkeypatch):
+    """round 6: prad_image_submit / _result / _wait (the image's launches issued by the calling thread's launcher thread) against
+    prad_image_enqueue_dev issued by the caller itself -- same result block, value for value; a voided image (a masked level outside
+    [1, Ng]) comes back False from the wait and frees its slot; a fifth job in flight is refused at once.  prad_bincount_enqueue_dev
+    + prad_bincount_wait against prad_bincount_dev: levels, number of levels, edges and the level census bit for bit."""
+    import torch
+    from pyradiomics_amd import engine
+    rng = np.random.default_rng(8)
+    shape = (30, 44, 52)
+    dev = torch.device("cuda", 0)
+    f = rng.normal(size=shape).cumsum(1).cumsum(2)
+    raw = torch.from_numpy(f).to(dev)
+    msk = torch.from_numpy((rng.random(shape) < 0.85).astype(np.uint8)).to(dev)
+    # the two halves of the binning
+    lv1, top1, edges1, counts1 = engine.bin_image(raw, msk, with_counts=True, binCount=20)
+    tok = engine.bin_image_enqueue(raw, msk, binCount=20)
+    assert tok is not None
+    lv2, top2, edges2, counts2 = engine.bin_image_collect(tok, with_counts=True)
+    assert top1 == top2 and torch.equal(lv1, lv2) and np.array_equal(edges1, edges2) and np.array_equal(counts1, counts2)
+    assert engine.bin_image_enqueue(raw, msk, binWidth=0.5) is None                     # (binWidth: the synchronous route)
+    toks = [engine.bin_image_enqueue(raw, msk, binCount=8 + i) for i in range(4)]
+    assert all(t is not None for t in toks) and engine.bin_image_enqueue(raw, msk, binCount=5) is None    # four tickets per thread
+    for i, t in enumerate(toks):
+        assert engine.bin_image_collect(t)[1] == 8 + i
+    # the launcher against the caller's own launches
+    Ns = int(msk.sum().item())
+    allc = (engine.IMG_GLCM | engine.IMG_MCC | engine.IMG_GLRLM | engine.IMG_GLDM | engine.IMG_NGTDM | engine.IMG_GLSZM | engine.IMG_FIRSTORDER)
+    assert engine._IMAGE_LAUNCHER
+    a = engine.image_enqueue(lv1, msk, raw, top1, Ns, allc)
+    assert a.get("job") is not None and a["res"] is None
+    assert engine.image_wait(a) and engine.image_wait(a)                               # (a second wait returns the kept verdict)
+    monkeypatch.setattr(engine, "_IMAGE_LAUNCHER", False)
+    b = engine.image_enqueue(lv1, msk, raw, top1, Ns, allc)
+    assert b.get("job") is None and engine.image_wait(b)
+    monkeypatch.setattr(engine, "_IMAGE_LAUNCHER", True)
+    assert a["layout"] == b["layout"]
+    n = a["layout"][12]
+    assert np.array_equal(a["res"][:n], b["res"][:n], equal_nan=True)
+    # a voided image, then the slot is free again; five in flight are refused
+    bad = lv1.clone()
+    bad[tuple(torch.nonzero(msk)[0].tolist())] = top1 + 3
+    v = engine.image_enqueue(bad, msk, raw, top1, Ns, engine.IMG_GLCM | engine.IMG_GLRLM)
+    assert engine.image_wait(v) is False
+    jobs = [engine.image_enqueue(lv1, msk, raw, top1, Ns, engine.IMG_NGTDM) for _ in range(4)]
+    with pytest.raises(ValueError):
+        engine.image_enqueue(lv1, msk, raw, top1, Ns, engine.IMG_NGTDM)
+    assert all(engine.image_wait(t) for t in jobs)
+    assert engine.image_wait(engine.image_enqueue(lv1, msk, raw, top1, Ns, engine.IMG_NGTDM))
