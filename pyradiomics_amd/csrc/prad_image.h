@@ -6,8 +6,9 @@
 #pragma once
 
 // ---- one derived image, every class, one call (the case pipeline's enqueue half in native code) -------------------------
-// What pyradiomics_amd/featureextractor.py did with ~25 calls per derived image -- GLCM + GLRLM sweep and formulas, MCC,
-// GLDM + NGTDM pass and formulas on side stream 0, GLSZM on side stream 1, first order on side stream 2, each under its own
+// What pyradiomics_amd/featureextractor.py did with ~25 calls per derived image -- GLCM + GLRLM sweep, their formulas and the MCC
+// on side stream 0, GLSZM on side stream 1, first order on side stream 2, GLDM + NGTDM pass and formulas on side stream 3
+// (round 6; two alternating sets of these streams, one byte-packed copy of the volume shared in front of the fork), each under its own
 // workspace set, a verdict mark and an event behind each -- as one entry point: the per-call cost of the Python / ctypes
 // layer (15 - 25 us each) was a fifth of a 256^3 case.  The matrices live in workspace buffers (stream order recycles
 // them), the values land in one block of the result arena.
@@ -150,7 +151,7 @@ int prad_image_enqueue_dev(const int32_t *levels, const uint8_t *mask, const voi
   for (int k = 0; k < PRAD_IMG_STREAMS; k++) PRAD_HIP(hipStreamWaitEvent(qs[k], q.in, 0));
   unsigned used = 0;
   // (workspace sets 4, 5, 6: sets 1 - 3 belong to callers that drive side streams of their own, engine.side_queue)
-  // ---- side stream 0: GLCM + GLRLM (one sweep), GLDM + NGTDM (one pass over the neighbourhoods) ----
+  // ---- side stream 0: GLCM + GLRLM (one sweep) and their formulas ----
   c.workspace = 4 + wso;
   if (classes & (PRAD_IMG_GLCM | PRAD_IMG_GLRLM)) {
     double *gm = nullptr, *rm = nullptr;

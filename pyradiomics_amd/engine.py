@@ -198,7 +198,8 @@ _IMAGE_LAUNCHER = os.environ.get("PRAD_IMAGE_LAUNCHER", "1") != "0"     # (A/B s
 def image_enqueue(levels: torch.Tensor, mask: torch.Tensor, raw, Ng: int, Ns: int, classes: int, symmetric: bool = True,
                   alpha: int = 0, force2D: bool = False, force2Ddimension: int = 0, voxelArrayShift: float = 0.0):
     """every requested class (IMG_* bits) of ONE derived image queued by one library call (prad_image_enqueue_dev: sweeps,
-    neighbourhood pass, GLSZM, first order and all formula kernels on the library's three side streams).  Returns a token
+    neighbourhood pass, GLSZM, first order and all formula kernels on the library's four side streams, two alternating sets of them; issued by the calling
+    thread's launcher thread unless PRAD_IMAGE_LAUNCHER=0).  Returns a token
     {"res": float64 view of the result block, "layout": offsets (include/pyradiomics_amd.h), "ticket", "keep"}; the values
     are valid after image_wait(token)."""
     lib, levels, mask, size = _prep(levels, mask)
