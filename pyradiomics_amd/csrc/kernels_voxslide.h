@@ -37,7 +37,8 @@ namespace prad {
 
 #define PRAD_VS_TB 544            // bytes of a lane's count table at Ng <= 32 (528 used; 16-byte aligned); larger Ng: template TB
 #define PRAD_VS_FIX 40            // fixed-point fraction bits of S
-#define PRAD_VS_LUT 256
+#define PRAD_VS_LUT 128           // counts of a table entry <= 100 (pairs of one angle in a 5^3 window); entry 127: the absent pair
+#define PRAD_VS_NNZ_SHIFT 52      // S carries nnz above its 11 + 40 bits
 
 // WIDE (round 5): fourteen more features whose sums update pair by pair -- Autocorrelation, ClusterProminence / Shade / Tendency,
 // Contrast, DifferenceAverage / Variance, Id, Idm, Idn, Idmn, InverseVariance, SumAverage, SumSquares (glcm.py:260-887).  A lane
@@ -55,9 +56,18 @@ struct VoxSlideSlots {           // output slot of every VoxelGlcmFeature (kerne
   int s[VF_COUNT];
 };
 
+// What ONE pair adds to (takes from) a lane's sums when the count of its table entry goes c -> c + 1 (c + 1 -> c), one 16-byte
+// LDS read per pair (round 6; until then three sums were computed with selects per pair).  Entry PRAD_VS_LUT - 1 is all zero:
+// the read of an absent pair (a position outside the angle's plane overlap, a voxel outside the mask) lands there.
+struct VoxSlideLutE {
+  long long g;                   // off-diagonal: 2 (f(c+1) - f(c)), f(c) = round(c log2 c * 2^40) -- the pair fills two entries;
+                                 // diagonal: f(2c+2) - f(2c) -- it adds 2 to one; plus (c == 0 ? entries that become non-zero : 0) << 52
+  int e2;                        // change of sum n^2: 2 (2c + 1) / 4 (2c + 1)
+  int one;                       // 1: the pair itself
+};
 struct VoxSlideLut {             // built once on the host (prad_api.hip), lives in global memory, copied to LDS per workgroup
-  long long g_off[PRAD_VS_LUT];  // 2 (f(c+1) - f(c)),  f(c) = round(c log2 c * 2^40): an off-diagonal pair fills two entries
-  long long g_dia[PRAD_VS_LUT];  // f(2c+2) - f(2c): a diagonal pair adds 2 to its entry
+  VoxSlideLutE off[PRAD_VS_LUT];
+  VoxSlideLutE dia[PRAD_VS_LUT];
   double lg2T[PRAD_VS_LUT];      // log2(2 P) for P pairs
 };
 
@@ -102,10 +112,10 @@ __device__ __forceinline__ double group_sum_f64(double v) {
 // maps: [nmaps][Nz][Ny][Nx] float64 (slot < 0: feature not requested); empty: [Nz][Ny][Nx] angle bits without a pair.
 template <int R, bool TWO_D, int RUN, int TB, int WAVES, bool WIDE = false>
 constexpr size_t voxel_glcm_slide_lds() {
-  return 3 * PRAD_VS_LUT * 8 + (WIDE ? sizeof(VoxSlideLutK) : 0) +
-         (size_t)WAVES * ((TWO_D ? 64 : 13 * (64 / 16)) * TB + (64 / (TWO_D ? 4 : 16)) * (RUN + 2 * R) * (TWO_D ? 8 : 32));
+  return sizeof(VoxSlideLut) + (WIDE ? sizeof(VoxSlideLutK) : 0) +
+         (size_t)WAVES * ((TWO_D ? 64 : 13 * (64 / 16)) * TB + (64 / (TWO_D ? 4 : 16)) * (RUN + 2 * R) * (TWO_D ? 8 : 32) + 32);
 }
-template <int R, bool TWO_D, int RUN, int TB = PRAD_VS_TB, int WAVES = (TWO_D ? 3 : 4), bool WIDE = false>
+template <int R, bool TWO_D, int RUN, int TB = PRAD_VS_TB, int WAVES = (TWO_D ? 3 : 4), bool WIDE = false, bool JA = true>
 __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx, VoxAngles A,
                                                               int Ng, const VoxSlideLut *__restrict__ lut_g,
                                                               const VoxSlideLutK *__restrict__ lutk_g, VoxSlideSlots sl,
@@ -121,23 +131,21 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   constexpr int XL = RUN + 2 * R;              // planes a run needs
   static_assert(TB % 16 == 0, "tables are cleared 16 bytes at a time");
   constexpr int NT = TWO_D ? 64 : 13 * NGR;    // count tables per wave (3-D: the 13 angle lanes of each group)
-  static_assert(NP <= PB, "plane does not fit its slot");
+  static_assert(NP < PB, "a staged plane keeps a zero byte behind its voxels");
   extern __shared__ __align__(16) unsigned char vs_smem[];
   if (flags[0]) return;                        // a level outside [1, Ng]: the caller reruns on the matrix path
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // workgroup LDS: the LUTs, then per wave: tables [64][TB], planes [NGR][XL][PB]
-  long long *g_off = reinterpret_cast<long long *>(vs_smem);
-  long long *g_dia = g_off + PRAD_VS_LUT;
-  double *lg2T = reinterpret_cast<double *>(g_dia + PRAD_VS_LUT);
-  constexpr int WAVE_BYTES = NT * TB + NGR * XL * PB;
-  long long *gk = reinterpret_cast<long long *>(vs_smem + 3 * PRAD_VS_LUT * 8);      // WIDE: [5][PRAD_VS_KMAX]
-  unsigned char *wbase = vs_smem + 3 * PRAD_VS_LUT * 8 + (WIDE ? sizeof(VoxSlideLutK) : 0) + (size_t)wave * WAVE_BYTES;
+  // workgroup LDS: the LUTs, then per wave: tables [64][TB], planes [NGR][XL][PB], one plane of zeros
+  VoxSlideLut *lut = reinterpret_cast<VoxSlideLut *>(vs_smem);
+  const double *lg2T = lut->lg2T;
+  constexpr int WAVE_BYTES = NT * TB + NGR * XL * PB + 32;
+  static_assert(sizeof(VoxSlideLut) % 16 == 0 && sizeof(VoxSlideLutK) % 16 == 0 && WAVE_BYTES % 16 == 0, "16-byte clears and reads");
+  long long *gk = reinterpret_cast<long long *>(vs_smem + sizeof(VoxSlideLut));      // WIDE: [5][PRAD_VS_KMAX]
+  unsigned char *wbase = vs_smem + sizeof(VoxSlideLut) + (WIDE ? sizeof(VoxSlideLutK) : 0) + (size_t)wave * WAVE_BYTES;
   unsigned char *planes = wbase + NT * TB;
-  for (int i = threadIdx.x; i < PRAD_VS_LUT; i += blockDim.x) {
-    g_off[i] = lut_g->g_off[i];
-    g_dia[i] = lut_g->g_dia[i];
-    lg2T[i] = lut_g->lg2T[i];
-  }
+  const unsigned char *zplane = planes + NGR * XL * PB;
+  for (int i = threadIdx.x; i < (int)(sizeof(VoxSlideLut) / 16); i += blockDim.x)
+    reinterpret_cast<uint4 *>(vs_smem)[i] = reinterpret_cast<const uint4 *>(lut_g)[i];
   if (WIDE) {
     for (int i = threadIdx.x; i < 5 * PRAD_VS_KMAX; i += blockDim.x) gk[i] = lutk_g->g[i / PRAD_VS_KMAX][i % PRAD_VS_KMAX];
   }
@@ -153,8 +161,8 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   unsigned char *tbl = wbase + (TWO_D ? lane : grp * 13 + min(a, 12)) * TB;
   const int dz = has_angle ? A.o[a][0] : 0, dy = has_angle ? A.o[a][1] : 0, dx = has_angle ? A.o[a][2] : 0;
   if (live) {
-    // clear the tables (wave-private: 64 x TB bytes)
-    for (int i = lane; i < NT * TB / 16; i += 64) reinterpret_cast<uint4 *>(wbase)[i] = make_uint4(0, 0, 0, 0);
+    // clear the tables (wave-private: 64 x TB bytes), the planes' spare bytes and the plane of zeros
+    for (int i = lane; i < WAVE_BYTES / 16; i += 64) reinterpret_cast<uint4 *>(wbase)[i] = make_uint4(0, 0, 0, 0);
     // stage the planes: slab x index k <-> global x0 - R + k; plane byte p = pz * D + py <-> (z - R + pz (TWO_D: z), y - R + py)
     for (int e = lane; e < NGR * XL * NP; e += 64) {
       const int p = e % NP, r = e / NP, k = r % XL, g = r / XL;
@@ -173,78 +181,82 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   const int pz_lo = max(0, -dz), pz_hi = min(PZ, PZ - dz), py_lo = max(0, -dy), py_hi = min(D, D - dy);
   const int qoff = dz * D + dy;                          // byte offset of q relative to p inside a plane
   long long S = 0;
-  int nnz = 0, E2 = 0, P = 0, IJ = 0;
+  int E2 = 0, P = 0, IJ = 0;                        // (nnz: the bits of S from PRAD_VS_NNZ_SHIFT up)
   int wA = 0, wQ2 = 0, wD1 = 0, wS3 = 0;            // WIDE: sum ij, sum (i^2 + j^2), sum |i - j|, sum (i + j)^3
   long long wS4 = 0, wF0 = 0, wF1 = 0, wF2 = 0, wF3 = 0, wF4 = 0;
   const bool wantF = WIDE && (sl.s[VF_Id] >= 0 || sl.s[VF_Idm] >= 0 || sl.s[VF_Idn] >= 0 || sl.s[VF_Idmn] >= 0 || sl.s[VF_InverseVariance] >= 0);
   // The pairs between plane kp (the p side) and plane kq (the q side) enter (SIGN = +1) or leave (-1) this lane's table.
-  // Straight-line code in four stages per chunk of positions -- level reads, table atomics, LUT reads, accumulation -- with
-  // predication instead of branches: a pair at a time under its own branch left every LDS round trip exposed (three per
-  // pair, ~14 000 cycles per step of a 5^3 window; profiles/r04_probes.md).
-  unsigned vmask = 0;                                    // positions of the plane this lane's angle pairs up
+  // Straight-line code in four stages per chunk of positions -- level reads, table atomics, LUT reads, accumulation -- without
+  // branches: a pair at a time under its own branch left every LDS round trip exposed (three per pair, ~14 000 cycles per
+  // step of a 5^3 window; profiles/r04_probes.md).  Round 6: an absent pair costs no selects either -- its q read lands on a
+  // zero byte (the spare byte of a staged plane; the plane of zeros while the run has one plane only), so that its smaller
+  // level is 0; then its table update goes to the spare word behind the counts and its LUT read to the all-zero entry, and
+  // the sums take what the read returns.  52 -> 33 instructions per position (profiles/r06_probes.md section 12).
+  int qa[NP];                                            // byte of the q plane position p pairs up with (PB - 1: none)
 #pragma unroll
   for (int p = 0; p < NP; p++) {
     const int pz = p / D, py = p % D;
-    if (has_angle && pz >= pz_lo && pz < pz_hi && py >= py_lo && py < py_hi) vmask |= 1u << p;
+    qa[p] = has_angle && pz >= pz_lo && pz < pz_hi && py >= py_lo && py < py_hi ? p + qoff : PB - 1;
   }
   unsigned *tbl32 = reinterpret_cast<unsigned *>(tbl);
+  constexpr int TRASH = TB - 4;                          // (the byte index of) a word no level pair counts in
+  const VoxSlideLutE *lut_off = lut->off, *lut_dia = lut->dia;
   using Plus = std::integral_constant<int, 1>;
   using Minus = std::integral_constant<int, -1>;
   auto plane_pairs = [&](int kp, int kq, auto sign_tag, bool on) __attribute__((always_inline)) {
     constexpr int SIGN = decltype(sign_tag)::value;
-    constexpr int CH = NP > 9 ? 9 : NP;                  // positions in flight
-    const unsigned char *pp = gp + kp * PB, *pq = gp + kq * PB;
-    const unsigned vm = on ? vmask : 0u;
+#ifndef PRAD_VS_CH
+#define PRAD_VS_CH 9
+#endif
+    constexpr int CH = NP > PRAD_VS_CH ? PRAD_VS_CH : NP;   // positions in flight
+    const unsigned char *pp = gp + kp * PB, *pq = on ? gp + kq * PB : zplane;
 #pragma unroll
     for (int c0 = 0; c0 < NP; c0 += CH) {
       int l1[CH], l2[CH], shf[CH];
       unsigned old[CH];
       bool ok[CH], dg[CH];
-      long long g[CH];
-      // 1: levels (an invalid position reads its own p for q: any in-range address)
+      VoxSlideLutE e[CH];
+      // 1: levels
 #pragma unroll
       for (int k = 0; k < CH; k++) {
         const int p = c0 + k;
         if (p < NP) {
-          const bool v = (vm >> p) & 1u;
           l1[k] = pp[p];
-          l2[k] = pq[v ? p + qoff : p];
-          ok[k] = v;
+          l2[k] = pq[qa[p]];
         }
       }
-      // 2: table updates (an absent pair adds 0 to word 0)
+      // 2: table updates
 #pragma unroll
       for (int k = 0; k < CH; k++) {
         if (c0 + k < NP) {
-          ok[k] = ok[k] && l1[k] != 0 && l2[k] != 0;
-          const int lo = min(l1[k], l2[k]) - 1, hi = max(l1[k], l2[k]) - 1;
-          const int idx = ok[k] ? (hi * (hi + 1) >> 1) + lo : 0;
+          const int lo = min(l1[k], l2[k]), hi = max(l1[k], l2[k]);
+          ok[k] = lo != 0;
+          const int idx = ok[k] ? (hi * (hi - 1) >> 1) + lo - 1 : TRASH;
           dg[k] = lo == hi;
           shf[k] = (idx & 3) * 8;
-          const unsigned inc = ok[k] ? (SIGN > 0 ? (1u << shf[k]) : (0u - (1u << shf[k]))) : 0u;
+          const unsigned inc = SIGN > 0 ? (1u << shf[k]) : (0u - (1u << shf[k]));
           old[k] = __hip_atomic_fetch_add(tbl32 + (idx >> 2), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
-      // 3: g(c), c = the smaller of the counts before / after
+      // 3: what the pair changes, by c = the smaller of its entry's counts before / after
 #pragma unroll
       for (int k = 0; k < CH; k++) {
         if (c0 + k < NP) {
-          const int c = ok[k] ? (int)((old[k] >> shf[k]) & 255u) - (SIGN > 0 ? 0 : 1) : 0;
-          shf[k] = c;                                      // (reuse: the count)
-          g[k] = (dg[k] ? g_dia : g_off)[c];
+          const int c = ok[k] ? (int)((old[k] >> shf[k]) & 255u) - (SIGN > 0 ? 0 : 1) : PRAD_VS_LUT - 1;
+          e[k] = (dg[k] ? lut_dia : lut_off)[c];
         }
       }
       // 4: the lane's sums
 #pragma unroll
       for (int k = 0; k < CH; k++) {
         if (c0 + k < NP) {
-          const int c = shf[k];
-          const long long gg = ok[k] ? g[k] : 0;
-          const int e2 = ok[k] ? (dg[k] ? 4 : 2) * (2 * c + 1) : 0;
-          const int nz = ok[k] && c == 0 ? (dg[k] ? 1 : 2) : 0;
-          const int one = ok[k] ? 1 : 0, ij = ok[k] ? l1[k] + l2[k] : 0;
-          if (SIGN > 0) { S += gg; E2 += e2; nnz += nz; P += one; IJ += ij; }
-          else { S -= gg; E2 -= e2; nnz -= nz; P -= one; IJ -= ij; }
+          if (SIGN > 0) { S += e[k].g; E2 += e[k].e2; P += e[k].one; }
+          else { S -= e[k].g; E2 -= e[k].e2; P -= e[k].one; }
+          if (JA) {
+            const int ij = ok[k] ? l1[k] + l2[k] : 0;
+            if (SIGN > 0) IJ += ij;
+            else IJ -= ij;
+          }
           if (WIDE) {
             const int i1 = ok[k] ? l1[k] : 0, j1 = ok[k] ? l2[k] : 0;
             const int kd = i1 > j1 ? i1 - j1 : j1 - i1, sm = i1 + j1, sm2 = sm * sm;
@@ -286,7 +298,11 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
     const double T = (double)(2 * pc), iT = 1.0 / T;
     double h = 0, en = 0, ja = 0;
     if (nonempty) {
-      if (slot_ent >= 0) h = lg2T[pc] - ((double)S * fix) * iT - (double)nnz * eps_ln2;
+      if (slot_ent >= 0) {
+        const long long Sf = S & ((1LL << PRAD_VS_NNZ_SHIFT) - 1);
+        const int nnz = (int)(S >> PRAD_VS_NNZ_SHIFT);
+        h = lg2T[pc] - ((double)Sf * fix) * iT - (double)nnz * eps_ln2;
+      }
       if (slot_en >= 0) en = (double)E2 * iT * iT;
       if (slot_ja >= 0) ja = (double)IJ * iT;
     }
