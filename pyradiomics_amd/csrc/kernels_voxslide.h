@@ -37,7 +37,7 @@ namespace prad {
 
 #define PRAD_VS_TB 544            // bytes of a lane's count table at Ng <= 32 (528 used; 16-byte aligned); larger Ng: template TB
 #define PRAD_VS_FIX 40            // fixed-point fraction bits of S
-#define PRAD_VS_LUT 128           // counts of a table entry <= 100 (pairs of one angle in a 5^3 window); entry 127: the absent pair
+#define PRAD_VS_LUT 112           // counts of a table entry <= 100 (pairs of one angle in a 5^3 window); the last entry: the absent pair
 #define PRAD_VS_NNZ_SHIFT 52      // S carries nnz above its 11 + 40 bits
 
 // WIDE (round 5): fourteen more features whose sums update pair by pair -- Autocorrelation, ClusterProminence / Shade / Tendency,
@@ -62,8 +62,8 @@ struct VoxSlideSlots {           // output slot of every VoxelGlcmFeature (kerne
 struct VoxSlideLutE {
   long long g;                   // off-diagonal: 2 (f(c+1) - f(c)), f(c) = round(c log2 c * 2^40) -- the pair fills two entries;
                                  // diagonal: f(2c+2) - f(2c) -- it adds 2 to one; plus (c == 0 ? entries that become non-zero : 0) << 52
-  int e2;                        // change of sum n^2: 2 (2c + 1) / 4 (2c + 1)
-  int one;                       // 1: the pair itself
+  int ep;                        // 1 << 20 (the pair itself) | change of sum n^2: 2 (2c + 1) / 4 (2c + 1)   (sum n^2 <= 200^2 < 2^20)
+  int pad;
 };
 struct VoxSlideLut {             // built once on the host (prad_api.hip), lives in global memory, copied to LDS per workgroup
   VoxSlideLutE off[PRAD_VS_LUT];
@@ -106,6 +106,31 @@ __device__ __forceinline__ double group_sum_f64(double v) {
   return v;
 }
 
+// Lane-balanced schedule of a 3-D window (round 6).  An angle (dz, dy, dx) pairs up (D - |dz|) (D - |dy|) of the D^2 positions
+// of a plane: 25, 20 or 16 of 25 at radius 2, and three of a group's sixteen lanes have no angle at all -- with a lane per angle
+// walking all 25 positions, 40 % of the slots of a step were spent on absent pairs.  Instead every lane visits NSLOT = 16 pair
+// positions per entering (leaving) plane: an angle's lane takes the first 16 of its own, the three helper lanes take the
+// overflow (9 positions of the angle (0, 0, 1), 4 of each of the six angles with 20) in segments of SEG slots, one angle per segment, and
+// update THAT angle's table (LDS atomics: whose lane adds is immaterial).  Their sums stay apart per segment; once per centre a
+// helper leaves them in LDS records and the angle's lane adds the (at most MAXQ) records that belong to it.  The schedule is a
+// function of the 13 angles and the radius only; prad_api.hip builds it (voxslide_schedule).
+template <int R>
+struct VoxSlideBal {
+  static constexpr int NSLOT = R == 2 ? 16 : 5;    // pair positions a lane visits per entering (leaving) plane
+  static constexpr int SEG = R == 2 ? 4 : 1;       // slots of a helper lane that serve one angle
+  static constexpr int NSEG = NSLOT / SEG;
+  static constexpr int MAXQ = R == 2 ? 3 : 4;      // helper segments the overflow of one angle takes at most
+  static constexpr int NREC = 3 * NSEG + 1;        // records of a group: 3 helpers x NSEG segments, and one of zeros
+};
+struct VoxSlideSched {
+  unsigned slot[16][16];      // [lane of a group][k]: p | q << 8 | angle whose table it counts in << 16 | (dx + 1) << 20 | valid << 24
+  unsigned char rec[16][4];   // [angle lane][j]: the helper records that hold parts of its sums (255: none)
+};
+struct VoxSlideRec {          // a helper segment's sums (16 bytes)
+  long long S;
+  int EP, IJ;
+};
+
 // R: kernel radius (1, 2); TWO_D: the window has no extent along z (force2D on the slice axis, or a single slice)
 // RUN: centres per run.  Grid: x = runs along x, y = groups of rows, z = slices; a workgroup = 4 (2-D windows: 3) waves =
 // consecutive runs -- what 160 KB of LDS hold: 13 x 4 (64) tables of 544 B and 4 (16) rows of staged planes per wave.
@@ -113,12 +138,14 @@ __device__ __forceinline__ double group_sum_f64(double v) {
 template <int R, bool TWO_D, int RUN, int TB, int WAVES, bool WIDE = false>
 constexpr size_t voxel_glcm_slide_lds() {
   return sizeof(VoxSlideLut) + (WIDE ? sizeof(VoxSlideLutK) : 0) +
-         (size_t)WAVES * ((TWO_D ? 64 : 13 * (64 / 16)) * TB + (64 / (TWO_D ? 4 : 16)) * (RUN + 2 * R) * (TWO_D ? 8 : 32) + 32);
+         (size_t)WAVES * ((TWO_D ? 64 : 13 * (64 / 16)) * TB + (64 / (TWO_D ? 4 : 16)) * (RUN + 2 * R + 1) * (TWO_D ? 8 : 32) +
+                          (!TWO_D && !WIDE ? 4 * VoxSlideBal<R>::NREC * 16 : 0));
 }
 template <int R, bool TWO_D, int RUN, int TB = PRAD_VS_TB, int WAVES = (TWO_D ? 3 : 4), bool WIDE = false, bool JA = true>
 __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx, VoxAngles A,
                                                               int Ng, const VoxSlideLut *__restrict__ lut_g,
-                                                              const VoxSlideLutK *__restrict__ lutk_g, VoxSlideSlots sl,
+                                                              const VoxSlideLutK *__restrict__ lutk_g,
+                                                              const VoxSlideSched *__restrict__ sched, VoxSlideSlots sl,
                                                               double *__restrict__ maps,
                                                               unsigned *__restrict__ empty, const int *__restrict__ flags, int z_begin) {
   const int slot_ent = sl.s[VF_JointEntropy], slot_en = sl.s[VF_JointEnergy], slot_ja = sl.s[VF_JointAverage];
@@ -129,21 +156,26 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   constexpr int GS = TWO_D ? 4 : 16;           // lanes per group (>= angles)
   constexpr int NGR = 64 / GS;                 // groups (rows) per wave
   constexpr int XL = RUN + 2 * R;              // planes a run needs
+  constexpr int GSTR = (XL + 1) * PB;          // bytes of a group's planes: one of zeros, then the XL of the run (the odd count
+                                               // also spreads the groups over the LDS banks: XL planes put all four on the same)
+  constexpr bool BAL = !TWO_D && !WIDE;        // the lane-balanced schedule (above)
+  using BL = VoxSlideBal<R>;
   static_assert(TB % 16 == 0, "tables are cleared 16 bytes at a time");
   constexpr int NT = TWO_D ? 64 : 13 * NGR;    // count tables per wave (3-D: the 13 angle lanes of each group)
   static_assert(NP < PB, "a staged plane keeps a zero byte behind its voxels");
   extern __shared__ __align__(16) unsigned char vs_smem[];
   if (flags[0]) return;                        // a level outside [1, Ng]: the caller reruns on the matrix path
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // workgroup LDS: the LUTs, then per wave: tables [64][TB], planes [NGR][XL][PB], one plane of zeros
+  // workgroup LDS: the LUTs, then per wave: tables [64][TB], planes [NGR][1 + XL][PB], the helper records [NGR][NREC]
   VoxSlideLut *lut = reinterpret_cast<VoxSlideLut *>(vs_smem);
   const double *lg2T = lut->lg2T;
-  constexpr int WAVE_BYTES = NT * TB + NGR * XL * PB + 32;
-  static_assert(sizeof(VoxSlideLut) % 16 == 0 && sizeof(VoxSlideLutK) % 16 == 0 && WAVE_BYTES % 16 == 0, "16-byte clears and reads");
+  constexpr int WAVE_BYTES = NT * TB + NGR * GSTR + (BAL ? NGR * BL::NREC * 16 : 0);
+  static_assert(sizeof(VoxSlideLut) % 16 == 0 && sizeof(VoxSlideLutK) % 16 == 0 && WAVE_BYTES % 16 == 0 && (NGR * GSTR) % 16 == 0,
+                "16-byte clears and reads");
   long long *gk = reinterpret_cast<long long *>(vs_smem + sizeof(VoxSlideLut));      // WIDE: [5][PRAD_VS_KMAX]
   unsigned char *wbase = vs_smem + sizeof(VoxSlideLut) + (WIDE ? sizeof(VoxSlideLutK) : 0) + (size_t)wave * WAVE_BYTES;
   unsigned char *planes = wbase + NT * TB;
-  const unsigned char *zplane = planes + NGR * XL * PB;
+  VoxSlideRec *recs = reinterpret_cast<VoxSlideRec *>(planes + NGR * GSTR);
   for (int i = threadIdx.x; i < (int)(sizeof(VoxSlideLut) / 16); i += blockDim.x)
     reinterpret_cast<uint4 *>(vs_smem)[i] = reinterpret_cast<const uint4 *>(lut_g)[i];
   if (WIDE) {
@@ -161,7 +193,7 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   unsigned char *tbl = wbase + (TWO_D ? lane : grp * 13 + min(a, 12)) * TB;
   const int dz = has_angle ? A.o[a][0] : 0, dy = has_angle ? A.o[a][1] : 0, dx = has_angle ? A.o[a][2] : 0;
   if (live) {
-    // clear the tables (wave-private: 64 x TB bytes), the planes' spare bytes and the plane of zeros
+    // clear the tables (wave-private: 64 x TB bytes), the planes (their spare bytes and the planes of zeros stay 0), the records
     for (int i = lane; i < WAVE_BYTES / 16; i += 64) reinterpret_cast<uint4 *>(wbase)[i] = make_uint4(0, 0, 0, 0);
     // stage the planes: slab x index k <-> global x0 - R + k; plane byte p = pz * D + py <-> (z - R + pz (TWO_D: z), y - R + py)
     for (int e = lane; e < NGR * XL * NP; e += 64) {
@@ -171,128 +203,26 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
       unsigned char v = 0;
       if ((unsigned)gz < (unsigned)Nz && (unsigned)gy < (unsigned)Ny && (unsigned)gx < (unsigned)Nx)
         v = L[((long long)gz * Ny + gy) * Nx + gx];
-      planes[(g * XL + k) * PB + p] = v;
+      planes[g * GSTR + (k + 1) * PB + p] = v;
     }
   }
   __syncthreads();
   if (!live) return;
-  const unsigned char *gp = planes + grp * XL * PB;     // this group's planes
-  // the plane positions this lane's angle pairs up: p = (pz, py) with q = (pz + dz, py + dy) inside the plane
-  const int pz_lo = max(0, -dz), pz_hi = min(PZ, PZ - dz), py_lo = max(0, -dy), py_hi = min(D, D - dy);
-  const int qoff = dz * D + dy;                          // byte offset of q relative to p inside a plane
-  long long S = 0;
-  int E2 = 0, P = 0, IJ = 0;                        // (nnz: the bits of S from PRAD_VS_NNZ_SHIFT up)
-  int wA = 0, wQ2 = 0, wD1 = 0, wS3 = 0;            // WIDE: sum ij, sum (i^2 + j^2), sum |i - j|, sum (i + j)^3
-  long long wS4 = 0, wF0 = 0, wF1 = 0, wF2 = 0, wF3 = 0, wF4 = 0;
-  const bool wantF = WIDE && (sl.s[VF_Id] >= 0 || sl.s[VF_Idm] >= 0 || sl.s[VF_Idn] >= 0 || sl.s[VF_Idmn] >= 0 || sl.s[VF_InverseVariance] >= 0);
-  // The pairs between plane kp (the p side) and plane kq (the q side) enter (SIGN = +1) or leave (-1) this lane's table.
-  // Straight-line code in four stages per chunk of positions -- level reads, table atomics, LUT reads, accumulation -- without
-  // branches: a pair at a time under its own branch left every LDS round trip exposed (three per pair, ~14 000 cycles per
-  // step of a 5^3 window; profiles/r04_probes.md).  Round 6: an absent pair costs no selects either -- its q read lands on a
-  // zero byte (the spare byte of a staged plane; the plane of zeros while the run has one plane only), so that its smaller
-  // level is 0; then its table update goes to the spare word behind the counts and its LUT read to the all-zero entry, and
-  // the sums take what the read returns.  52 -> 33 instructions per position (profiles/r06_probes.md section 12).
-  int qa[NP];                                            // byte of the q plane position p pairs up with (PB - 1: none)
-#pragma unroll
-  for (int p = 0; p < NP; p++) {
-    const int pz = p / D, py = p % D;
-    qa[p] = has_angle && pz >= pz_lo && pz < pz_hi && py >= py_lo && py < py_hi ? p + qoff : PB - 1;
-  }
-  unsigned *tbl32 = reinterpret_cast<unsigned *>(tbl);
+  const unsigned char *gp = planes + grp * GSTR + PB;   // this group's planes of the run (gp - PB: the plane of zeros)
   constexpr int TRASH = TB - 4;                          // (the byte index of) a word no level pair counts in
   const VoxSlideLutE *lut_off = lut->off, *lut_dia = lut->dia;
   using Plus = std::integral_constant<int, 1>;
   using Minus = std::integral_constant<int, -1>;
-  auto plane_pairs = [&](int kp, int kq, auto sign_tag, bool on) __attribute__((always_inline)) {
-    constexpr int SIGN = decltype(sign_tag)::value;
-#ifndef PRAD_VS_CH
-#define PRAD_VS_CH 9
-#endif
-    constexpr int CH = NP > PRAD_VS_CH ? PRAD_VS_CH : NP;   // positions in flight
-    const unsigned char *pp = gp + kp * PB, *pq = on ? gp + kq * PB : zplane;
-#pragma unroll
-    for (int c0 = 0; c0 < NP; c0 += CH) {
-      int l1[CH], l2[CH], shf[CH];
-      unsigned old[CH];
-      bool ok[CH], dg[CH];
-      VoxSlideLutE e[CH];
-      // 1: levels
-#pragma unroll
-      for (int k = 0; k < CH; k++) {
-        const int p = c0 + k;
-        if (p < NP) {
-          l1[k] = pp[p];
-          l2[k] = pq[qa[p]];
-        }
-      }
-      // 2: table updates
-#pragma unroll
-      for (int k = 0; k < CH; k++) {
-        if (c0 + k < NP) {
-          const int lo = min(l1[k], l2[k]), hi = max(l1[k], l2[k]);
-          ok[k] = lo != 0;
-          const int idx = ok[k] ? (hi * (hi - 1) >> 1) + lo - 1 : TRASH;
-          dg[k] = lo == hi;
-          shf[k] = (idx & 3) * 8;
-          const unsigned inc = SIGN > 0 ? (1u << shf[k]) : (0u - (1u << shf[k]));
-          old[k] = __hip_atomic_fetch_add(tbl32 + (idx >> 2), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-      // 3: what the pair changes, by c = the smaller of its entry's counts before / after
-#pragma unroll
-      for (int k = 0; k < CH; k++) {
-        if (c0 + k < NP) {
-          const int c = ok[k] ? (int)((old[k] >> shf[k]) & 255u) - (SIGN > 0 ? 0 : 1) : PRAD_VS_LUT - 1;
-          e[k] = (dg[k] ? lut_dia : lut_off)[c];
-        }
-      }
-      // 4: the lane's sums
-#pragma unroll
-      for (int k = 0; k < CH; k++) {
-        if (c0 + k < NP) {
-          if (SIGN > 0) { S += e[k].g; E2 += e[k].e2; P += e[k].one; }
-          else { S -= e[k].g; E2 -= e[k].e2; P -= e[k].one; }
-          if (JA) {
-            const int ij = ok[k] ? l1[k] + l2[k] : 0;
-            if (SIGN > 0) IJ += ij;
-            else IJ -= ij;
-          }
-          if (WIDE) {
-            const int i1 = ok[k] ? l1[k] : 0, j1 = ok[k] ? l2[k] : 0;
-            const int kd = i1 > j1 ? i1 - j1 : j1 - i1, sm = i1 + j1, sm2 = sm * sm;
-            const int a = i1 * j1, q2 = i1 * i1 + j1 * j1, s3 = sm2 * sm;
-            const long long s4 = (long long)sm2 * sm2;
-            if (SIGN > 0) { wA += a; wQ2 += q2; wD1 += kd; wS3 += s3; wS4 += s4; }
-            else { wA -= a; wQ2 -= q2; wD1 -= kd; wS3 -= s3; wS4 -= s4; }
-            if (wantF) {                                     // (wave-uniform)
-              const int kk = min(kd, PRAD_VS_KMAX - 1);
-              const long long f0 = ok[k] ? gk[kk] : 0, f1 = ok[k] ? gk[PRAD_VS_KMAX + kk] : 0, f2 = ok[k] ? gk[2 * PRAD_VS_KMAX + kk] : 0,
-                              f3 = ok[k] ? gk[3 * PRAD_VS_KMAX + kk] : 0, f4 = ok[k] ? gk[4 * PRAD_VS_KMAX + kk] : 0;
-              if (SIGN > 0) { wF0 += f0; wF1 += f1; wF2 += f2; wF3 += f3; wF4 += f4; }
-              else { wF0 -= f0; wF1 -= f1; wF2 -= f2; wF3 -= f3; wF4 -= f4; }
-            }
-          }
-        }
-      }
-    }
-  };
+  int wA = 0, wQ2 = 0, wD1 = 0, wS3 = 0;            // WIDE: sum ij, sum (i^2 + j^2), sum |i - j|, sum (i + j)^3
+  long long wS4 = 0, wF0 = 0, wF1 = 0, wF2 = 0, wF3 = 0, wF4 = 0;
+  const bool wantF = WIDE && (sl.s[VF_Id] >= 0 || sl.s[VF_Idm] >= 0 || sl.s[VF_Idn] >= 0 || sl.s[VF_Idmn] >= 0 || sl.s[VF_InverseVariance] >= 0);
   const double eps_ln2 = 2.220446049250313e-16 / 0.6931471805599453;
   const double fix = 1.0 / (double)(1LL << PRAD_VS_FIX);
   const double nan = __longlong_as_double(0x7ff8000000000000LL);
-  for (int s = 0; s < XL; s++) {
-    {
-      // plane s enters: pairs inside it (dx = 0) or with plane s - 1 (p side for dx > 0, q side for dx < 0)
-      const int sm = max(s - 1, 0);
-      plane_pairs(dx > 0 ? sm : s, dx < 0 ? sm : s, Plus{}, dx == 0 || s >= 1);
-      // plane s - D leaves: pairs inside it or with plane s - D + 1
-      if (s >= D) {                                        // (wave-uniform)
-        const int o = s - D;
-        plane_pairs(dx < 0 ? o + 1 : o, dx > 0 ? o + 1 : o, Minus{}, true);
-      }
-    }
-    if (s < 2 * R) continue;
-    // centre: slab x index s - R
+  // the centre at slab x index s - R, from this lane's sums: S (nnz in its bits from PRAD_VS_NNZ_SHIFT up), EP = P << 20 | E2, IJ
+  auto emit = [&](int s, long long S, int EP, int IJ) __attribute__((always_inline)) {
     const int gx = x0 + s - 2 * R;
+    const int P = EP >> 20, E2 = EP & 0xfffff;
     const bool nonempty = has_angle && P > 0;
     const int pc = nonempty ? P : 1;
     const double T = (double)(2 * pc), iT = 1.0 / T;
@@ -347,7 +277,190 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
       put(VF_Idmn, (double)wF3 * fix * iP);
       put(VF_InverseVariance, (double)wF4 * fix * iP);
     }
+  };
+  // A pair enters (SIGN = +1) or leaves (-1) a count table.  Straight-line code in four stages per chunk of pair positions --
+  // level reads, table atomics, LUT reads, accumulation -- without branches: a pair at a time under its own branch left every LDS
+  // round trip exposed (three per pair, ~14 000 cycles per step of a 5^3 window; profiles/r04_probes.md).  Round 6: an absent
+  // pair costs no selects either -- its q read lands on a zero byte (the spare byte of a staged plane; the plane of zeros in
+  // front of the run), so that its smaller level is 0; then its table update goes to the spare word behind the counts and its
+  // LUT read to the all-zero entry, and the sums take what the read returns (profiles/r06_probes.md section 12).
+  //   l1, l2: the levels; tb: the table; returns through e / ok what stage 4 adds
+#define PRAD_VS_STAGE2(K, TBP)                                                                                       \
+  {                                                                                                                  \
+    const int lo = min(l1[K], l2[K]), hi = max(l1[K], l2[K]);                                                        \
+    ok[K] = lo != 0;                                                                                                 \
+    const int idx = ok[K] ? (hi * (hi - 1) >> 1) + lo - 1 : TRASH;                                                   \
+    dg[K] = lo == hi;                                                                                                \
+    shf[K] = (idx & 3) * 8;                                                                                          \
+    const unsigned inc = SIGN > 0 ? (1u << shf[K]) : (0u - (1u << shf[K]));                                          \
+    old[K] = __hip_atomic_fetch_add((TBP) + (idx >> 2), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);        \
   }
+  // (c = the smaller of the entry's counts before / after)
+#define PRAD_VS_STAGE3(K)                                                                                            \
+  {                                                                                                                  \
+    const int c = ok[K] ? (int)((old[K] >> shf[K]) & 255u) - (SIGN > 0 ? 0 : 1) : PRAD_VS_LUT - 1;                   \
+    e[K] = (dg[K] ? lut_dia : lut_off)[c];                                                                           \
+  }
+  if constexpr (BAL) {
+    constexpr int NSLOT = BL::NSLOT, SEG = BL::SEG, NSEG = BL::NSEG, MAXQ = BL::MAXQ, NREC = BL::NREC;
+    unsigned *tb[NSLOT];
+    int a1P[NSLOT], a2P[NSLOT], a1M[NSLOT], a2M[NSLOT];    // bytes of the p and q voxels relative to the entering (leaving) plane
+#pragma unroll
+    for (int k = 0; k < NSLOT; k++) {
+      const unsigned d = sched->slot[a][k];
+      const int p = d & 31, q = (d >> 8) & 31, t = (d >> 16) & 15, dxk = (int)((d >> 20) & 3) - 1;
+      const bool valid = (d >> 24) != 0;
+      tb[k] = reinterpret_cast<unsigned *>(wbase + (grp * 13 + t) * TB);
+      // entering plane s: pairs inside it (dx = 0) or with plane s - 1 (p side for dx > 0, q side for dx < 0);
+      // leaving plane o = s - D: pairs inside it or with plane o + 1
+      a1P[k] = p - (dxk > 0 ? PB : 0);
+      a2P[k] = valid ? q - (dxk < 0 ? PB : 0) : PB - 1;
+      a1M[k] = p + (dxk < 0 ? PB : 0);
+      a2M[k] = valid ? q + (dxk > 0 ? PB : 0) : PB - 1;
+    }
+    VoxSlideRec *grec = recs + grp * NREC;
+    const VoxSlideRec *mine[MAXQ];
+#pragma unroll
+    for (int j = 0; j < MAXQ; j++) {
+      const int r = sched->rec[a][j];
+      mine[j] = grec + (r == 255 ? NREC - 1 : r);
+    }
+    VoxSlideRec *hrec = grec + max(a - 13, 0) * NSEG;      // a helper's NSEG records
+    long long Sq[NSEG];
+    int EPq[NSEG], IJq[NSEG];
+#pragma unroll
+    for (int r = 0; r < NSEG; r++) { Sq[r] = 0; EPq[r] = 0; IJq[r] = 0; }
+    auto slots = [&](const unsigned char *base, const int(&a1)[NSLOT], const int(&a2)[NSLOT], auto sign_tag) __attribute__((always_inline)) {
+      constexpr int SIGN = decltype(sign_tag)::value;
+      constexpr int CH = NSLOT > 8 ? 8 : NSLOT;
+#pragma unroll
+      for (int c0 = 0; c0 < NSLOT; c0 += CH) {
+        int l1[CH], l2[CH], shf[CH];
+        unsigned old[CH];
+        bool ok[CH], dg[CH];
+        VoxSlideLutE e[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          l1[k] = base[a1[c0 + k]];
+          l2[k] = base[a2[c0 + k]];
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) PRAD_VS_STAGE2(k, tb[c0 + k])
+#pragma unroll
+        for (int k = 0; k < CH; k++) PRAD_VS_STAGE3(k)
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const int r = (c0 + k) / SEG;
+          const int ij = JA && ok[k] ? l1[k] + l2[k] : 0;
+          if (SIGN > 0) { Sq[r] += e[k].g; EPq[r] += e[k].ep; IJq[r] += ij; }
+          else { Sq[r] -= e[k].g; EPq[r] -= e[k].ep; IJq[r] -= ij; }
+        }
+      }
+    };
+    for (int s = 0; s < XL; s++) {
+      slots(gp + s * PB, a1P, a2P, Plus{});
+      if (s >= D) slots(gp + (s - D) * PB, a1M, a2M, Minus{});      // (wave-uniform)
+      if (s < 2 * R) continue;
+      if (a >= 13) {
+#pragma unroll
+        for (int r = 0; r < NSEG; r++) hrec[r] = VoxSlideRec{Sq[r], EPq[r], IJq[r]};
+      }
+      long long S = Sq[0];
+      int EP = EPq[0], IJ = IJq[0];
+#pragma unroll
+      for (int r = 1; r < NSEG; r++) { S += Sq[r]; EP += EPq[r]; IJ += IJq[r]; }
+#pragma unroll
+      for (int j = 0; j < MAXQ; j++) {
+        const VoxSlideRec rr = *mine[j];
+        S += rr.S;
+        EP += rr.EP;
+        IJ += rr.IJ;
+      }
+      emit(s, S, EP, IJ);
+    }
+  } else {
+    // a lane per angle walks the plane: position p = (pz, py) pairs up with q = (pz + dz, py + dy) where that lies inside
+    const int pz_lo = max(0, -dz), pz_hi = min(PZ, PZ - dz), py_lo = max(0, -dy), py_hi = min(D, D - dy);
+    const int qoff = dz * D + dy;                          // byte offset of q relative to p inside a plane
+    int qa[NP];                                            // byte of the q plane position p pairs up with (PB - 1: none)
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      const int pz = p / D, py = p % D;
+      qa[p] = has_angle && pz >= pz_lo && pz < pz_hi && py >= py_lo && py < py_hi ? p + qoff : PB - 1;
+    }
+    unsigned *tbl32 = reinterpret_cast<unsigned *>(tbl);
+    long long S = 0;
+    int EP = 0, IJ = 0;
+    // the pairs between plane kp (the p side) and plane kq (the q side; -1: the plane of zeros)
+    auto plane_pairs = [&](int kp, int kq, auto sign_tag) __attribute__((always_inline)) {
+      constexpr int SIGN = decltype(sign_tag)::value;
+#ifndef PRAD_VS_CH
+#define PRAD_VS_CH 9
+#endif
+      constexpr int CH = NP > PRAD_VS_CH ? PRAD_VS_CH : NP;   // positions in flight
+      const unsigned char *pp = gp + kp * PB, *pq = gp + kq * PB;
+#pragma unroll
+      for (int c0 = 0; c0 < NP; c0 += CH) {
+        int l1[CH], l2[CH], shf[CH];
+        unsigned old[CH];
+        bool ok[CH], dg[CH];
+        VoxSlideLutE e[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const int p = c0 + k;
+          if (p < NP) {
+            l1[k] = pp[p];
+            l2[k] = pq[qa[p]];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          if (c0 + k < NP) PRAD_VS_STAGE2(k, tbl32)
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          if (c0 + k < NP) PRAD_VS_STAGE3(k)
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          if (c0 + k < NP) {
+            const int ij = JA && ok[k] ? l1[k] + l2[k] : 0;
+            if (SIGN > 0) { S += e[k].g; EP += e[k].ep; IJ += ij; }
+            else { S -= e[k].g; EP -= e[k].ep; IJ -= ij; }
+            if (WIDE) {
+              const int i1 = ok[k] ? l1[k] : 0, j1 = ok[k] ? l2[k] : 0;
+              const int kd = i1 > j1 ? i1 - j1 : j1 - i1, sm = i1 + j1, sm2 = sm * sm;
+              const int a = i1 * j1, q2 = i1 * i1 + j1 * j1, s3 = sm2 * sm;
+              const long long s4 = (long long)sm2 * sm2;
+              if (SIGN > 0) { wA += a; wQ2 += q2; wD1 += kd; wS3 += s3; wS4 += s4; }
+              else { wA -= a; wQ2 -= q2; wD1 -= kd; wS3 -= s3; wS4 -= s4; }
+              if (wantF) {                                     // (wave-uniform)
+                const int kk = min(kd, PRAD_VS_KMAX - 1);
+                const long long f0 = ok[k] ? gk[kk] : 0, f1 = ok[k] ? gk[PRAD_VS_KMAX + kk] : 0, f2 = ok[k] ? gk[2 * PRAD_VS_KMAX + kk] : 0,
+                                f3 = ok[k] ? gk[3 * PRAD_VS_KMAX + kk] : 0, f4 = ok[k] ? gk[4 * PRAD_VS_KMAX + kk] : 0;
+                if (SIGN > 0) { wF0 += f0; wF1 += f1; wF2 += f2; wF3 += f3; wF4 += f4; }
+                else { wF0 -= f0; wF1 -= f1; wF2 -= f2; wF3 -= f3; wF4 -= f4; }
+              }
+            }
+          }
+        }
+      }
+    };
+    for (int s = 0; s < XL; s++) {
+      // plane s enters: pairs inside it (dx = 0) or with plane s - 1 (p side for dx > 0, q side for dx < 0; the run's first
+      // plane has the plane of zeros there: no pairs)
+      plane_pairs(dx > 0 ? s - 1 : s, dx < 0 ? s - 1 : s, Plus{});
+      // plane s - D leaves: pairs inside it or with plane s - D + 1
+      if (s >= D) {                                        // (wave-uniform)
+        const int o = s - D;
+        plane_pairs(dx < 0 ? o + 1 : o, dx > 0 ? o + 1 : o, Minus{});
+      }
+      if (s < 2 * R) continue;
+      emit(s, S, EP, IJ);
+    }
+  }
+#undef PRAD_VS_STAGE2
+#undef PRAD_VS_STAGE3
 }
 
 // smallest and largest slice index of the requested centres (the map is only built for those slices): zr[0] = min, zr[1] = max

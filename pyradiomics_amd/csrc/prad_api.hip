@@ -1804,6 +1804,44 @@ int copy_back(Context &c, double *host, const double *dev, size_t count) {
 // ------------------------------------------------------------------------------------------------
 // fused voxel-based GLCM features
 // ------------------------------------------------------------------------------------------------
+// The lane-balanced schedule of a 3-D sliding window (kernels_voxslide.h, VoxSlideBal): which pair positions of a plane each of a
+// group's sixteen lanes visits.  false: the angles' overflow does not fit the three helper lanes (never for the 13 angles of
+// distance 1; the caller then stays on the window kernel).
+template <int R>
+bool voxslide_schedule_r(const VoxAngles &A, VoxSlideSched *sc) {
+  using BL = VoxSlideBal<R>;
+  constexpr int D = 2 * R + 1;
+  memset(sc, 0, sizeof(*sc));
+  memset(sc->rec, 255, sizeof(sc->rec));
+  int seg = 0;                                            // helper segments handed out
+  for (int a = 0; a < A.na; a++) {
+    const int dz = A.o[a][0], dy = A.o[a][1], dx = A.o[a][2];
+    int n = 0, nq = 0;
+    for (int p = 0; p < D * D; p++) {
+      const int pz = p / D, py = p % D;
+      if (pz + dz < 0 || pz + dz >= D || py + dy < 0 || py + dy >= D) continue;
+      const unsigned d = (unsigned)p | (unsigned)(p + dz * D + dy) << 8 | (unsigned)a << 16 | (unsigned)(dx + 1) << 20 | 1u << 24;
+      if (n < BL::NSLOT) {
+        sc->slot[a][n] = d;
+      } else {
+        const int o = n - BL::NSLOT;                      // the o-th overflow position of this angle
+        if (o % BL::SEG == 0) {                           // opens a segment
+          if (seg >= 3 * BL::NSEG || nq >= BL::MAXQ) return false;
+          sc->rec[a][nq++] = (unsigned char)seg++;
+        }
+        const int sg = seg - 1;
+        sc->slot[13 + sg / BL::NSEG][(sg % BL::NSEG) * BL::SEG + o % BL::SEG] = d;
+      }
+      n++;
+    }
+  }
+  return true;
+}
+bool voxslide_schedule(const VoxAngles &A, int R, VoxSlideSched *sc) {
+  if (A.na != 13) return false;
+  return R == 2 ? voxslide_schedule_r<2>(A, sc) : R == 1 ? voxslide_schedule_r<1>(A, sc) : false;
+}
+
 int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int *size, int Nd, const int *angles,
                             int Na, int Ng, int Nvox, const int *voxels, int kernelRadius, int force2Ddim,
                             int symmetric, const int *feature_ids, int nfeat, double *out, uint32_t *empty_mask,
@@ -1880,6 +1918,9 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
       for (int a = 0; a < Na && slide; a++)
         slide = std::abs(A.o[a][0]) <= 1 && std::abs(A.o[a][1]) <= 1 && std::abs(A.o[a][2]) <= 1 && (std13 || A.o[a][0] == 0);
     }
+    VoxSlideSched sched_h;                                 // 3-D windows, the three base features: the lane-balanced schedule
+    const bool balanced = slide && std13 && !slide_is_wide;
+    if (balanced) slide = voxslide_schedule(A, kernelRadius, &sched_h);
     int z_begin = 0, z_end = -1;
     if (slide) {
       // the slices the centres lie in (one rank of a sharded map owns a z-slab of them: batch.voxel_maps_sharded)
@@ -1911,8 +1952,8 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
         for (int k = 0; k < PRAD_VS_LUT; k++) {
           const bool absent = k == PRAD_VS_LUT - 1;            // (a count never gets there: <= 100 pairs per angle)
           const long long nz = k == 0 ? 1LL << PRAD_VS_NNZ_SHIFT : 0;
-          t.off[k] = absent ? VoxSlideLutE{0, 0, 0} : VoxSlideLutE{2 * (f(k + 1) - f(k)) + 2 * nz, 2 * (2 * k + 1), 1};
-          t.dia[k] = absent ? VoxSlideLutE{0, 0, 0} : VoxSlideLutE{f(2 * k + 2) - f(2 * k) + nz, 4 * (2 * k + 1), 1};
+          t.off[k] = absent ? VoxSlideLutE{0, 0, 0} : VoxSlideLutE{2 * (f(k + 1) - f(k)) + 2 * nz, (1 << 20) | (2 * (2 * k + 1)), 0};
+          t.dia[k] = absent ? VoxSlideLutE{0, 0, 0} : VoxSlideLutE{f(2 * k + 2) - f(2 * k) + nz, (1 << 20) | (4 * (2 * k + 1)), 0};
           t.lg2T[k] = k ? std::log2(2.0 * k) : 0.0;
         }
         return t;
@@ -1926,6 +1967,14 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
       PRAD_TRY(c.get<unsigned>("voxslide_empty", (size_t)g.n, &emap));
       VoxSlideSlots sl;
       for (int f = 0; f < VF_COUNT; f++) sl.s[f] = ((fmask >> f) & 1u) ? slot[f] : -1;
+      VoxSlideSched *sched_dev = nullptr;
+      if (balanced) {
+        void *sc_h = nullptr;
+        PRAD_TRY(c.get<VoxSlideSched>("voxslide_sched", 1, &sched_dev));
+        PRAD_TRY(c.get_pinned("voxslide_sched_h", sizeof(sched_h), &sc_h));
+        memcpy(sc_h, &sched_h, sizeof(sched_h));
+        PRAD_HIP(hipMemcpyAsync(sched_dev, sc_h, sizeof(sched_h), hipMemcpyHostToDevice, s));
+      }
       VoxSlideLutK *lutk_dev = nullptr;
       VoxSlideLutK lutk_h;
       if (slide_is_wide) {
@@ -1950,7 +1999,7 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
     const int wv = WV, rows = TWOD ? 16 : 4;                                                                                \
     const int nruns = (dims[2] + RUNL - 1) / RUNL;                                                                          \
     hipLaunchKernelGGL((voxel_glcm_slide_kernel<RR, TWOD, RUNL, TBB, WV, WD, JJ>), dim3((nruns + wv - 1) / wv, (dims[1] + rows - 1) / rows, z_end - z_begin + 1), \
-                       dim3(64 * wv), lds_s, s, levels, dims[0], dims[1], dims[2], A, Ng, lut_dev, lutk_dev, sl, maps, emap, flags, z_begin); \
+                       dim3(64 * wv), lds_s, s, levels, dims[0], dims[1], dims[2], A, Ng, lut_dev, lutk_dev, sched_dev, sl, maps, emap, flags, z_begin); \
   } while (0)
       // (the WIDE instantiation carries 2.5 KB of g(k) tables in LDS: one wave less where the base shape fills the 160 KB)
 #define PRAD_SLIDE_T(RR, TWOD, RUNL, TBB, WV, WVW)                                                                          \
