@@ -35,7 +35,10 @@
 
 namespace prad {
 
-#define PRAD_VS_TB 544            // bytes of a lane's count table at Ng <= 32 (528 used; 16-byte aligned); larger Ng: template TB
+#define PRAD_VS_TB 532            // bytes of a count table at Ng <= 32: 528 of counts and a spare word; larger Ng: template TB.
+                                  // An ODD number of words: neighbouring voxels have neighbouring levels, the lanes of a wave
+                                  // update the same few entries of their tables at once, and with an even stride (544 B until
+                                  // round 6) every fourth table put that entry on the same LDS bank
 #define PRAD_VS_FIX 40            // fixed-point fraction bits of S
 #define PRAD_VS_LUT 112           // counts of a table entry <= 100 (pairs of one angle in a 5^3 window); the last entry: the absent pair
 #define PRAD_VS_NNZ_SHIFT 52      // S carries nnz above its 11 + 40 bits
@@ -69,7 +72,11 @@ struct VoxSlideLut {             // built once on the host (prad_api.hip), lives
   VoxSlideLutE off[PRAD_VS_LUT];
   VoxSlideLutE dia[PRAD_VS_LUT];
   double lg2T[PRAD_VS_LUT];      // log2(2 P) for P pairs
+  // LIGHT kernels (JointEntropy alone: no sum n^2) read 8 bytes per pair -- the g column of the entries above -- and count the
+  // pairs themselves; in LDS the two columns take the place of off / dia
+  long long g_off[PRAD_VS_LUT], g_dia[PRAD_VS_LUT];
 };
+#define PRAD_VS_LUT_LDS (sizeof(VoxSlideLutE) * 2 * PRAD_VS_LUT + 8 * PRAD_VS_LUT)      // bytes of LDS the LUTs take
 
 // sum over the lanes of a group of GS (4 or 16) neighbouring lanes, result in every lane of the group
 template <int GS>
@@ -137,11 +144,11 @@ struct VoxSlideRec {          // a helper segment's sums (16 bytes)
 // maps: [nmaps][Nz][Ny][Nx] float64 (slot < 0: feature not requested); empty: [Nz][Ny][Nx] angle bits without a pair.
 template <int R, bool TWO_D, int RUN, int TB, int WAVES, bool WIDE = false>
 constexpr size_t voxel_glcm_slide_lds() {
-  return sizeof(VoxSlideLut) + (WIDE ? sizeof(VoxSlideLutK) : 0) +
-         (size_t)WAVES * ((TWO_D ? 64 : 13 * (64 / 16)) * TB + (64 / (TWO_D ? 4 : 16)) * (RUN + 2 * R + 1) * (TWO_D ? 8 : 32) +
+  return PRAD_VS_LUT_LDS + (WIDE ? sizeof(VoxSlideLutK) : 0) +
+         (size_t)WAVES * ((TWO_D ? 64 : 13 * (64 / 16)) * TB + (64 / (TWO_D ? 4 : 16)) * (RUN + 2 * R + (TWO_D ? 1 : 2)) * (TWO_D ? 8 : 32) +
                           (!TWO_D && !WIDE ? 4 * VoxSlideBal<R>::NREC * 16 : 0));
 }
-template <int R, bool TWO_D, int RUN, int TB = PRAD_VS_TB, int WAVES = (TWO_D ? 3 : 4), bool WIDE = false, bool JA = true>
+template <int R, bool TWO_D, int RUN, int TB = PRAD_VS_TB, int WAVES = (TWO_D ? 3 : 4), bool WIDE = false, bool JA = true, bool LIGHT = false>
 __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint8_t *__restrict__ L, int Nz, int Ny, int Nx, VoxAngles A,
                                                               int Ng, const VoxSlideLut *__restrict__ lut_g,
                                                               const VoxSlideLutK *__restrict__ lutk_g,
@@ -156,28 +163,35 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   constexpr int GS = TWO_D ? 4 : 16;           // lanes per group (>= angles)
   constexpr int NGR = 64 / GS;                 // groups (rows) per wave
   constexpr int XL = RUN + 2 * R;              // planes a run needs
-  constexpr int GSTR = (XL + 1) * PB;          // bytes of a group's planes: one of zeros, then the XL of the run (the odd count
-                                               // also spreads the groups over the LDS banks: XL planes put all four on the same)
+  constexpr int GSTR = (XL + (TWO_D ? 1 : 2)) * PB;   // bytes of a group's planes: one of zeros, then the XL of the run; 3-D: and
+                                               // one to make the stride 16 banks (mod 32) -- the two groups of a half wave read
+                                               // two neighbouring planes = 16 banks each, side by side
   constexpr bool BAL = !TWO_D && !WIDE;        // the lane-balanced schedule (above)
   using BL = VoxSlideBal<R>;
-  static_assert(TB % 16 == 0, "tables are cleared 16 bytes at a time");
   constexpr int NT = TWO_D ? 64 : 13 * NGR;    // count tables per wave (3-D: the 13 angle lanes of each group)
+  static_assert(TB % 8 == 4 && (NT * TB) % 16 == 0, "tables: an odd number of words each, cleared 16 bytes at a time");
   static_assert(NP < PB, "a staged plane keeps a zero byte behind its voxels");
   extern __shared__ __align__(16) unsigned char vs_smem[];
   if (flags[0]) return;                        // a level outside [1, Ng]: the caller reruns on the matrix path
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // workgroup LDS: the LUTs, then per wave: tables [64][TB], planes [NGR][1 + XL][PB], the helper records [NGR][NREC]
-  VoxSlideLut *lut = reinterpret_cast<VoxSlideLut *>(vs_smem);
+  static_assert(!LIGHT || (!WIDE && !JA), "LIGHT: JointEntropy alone");
+  VoxSlideLut *lut = reinterpret_cast<VoxSlideLut *>(vs_smem);      // (off, dia, lg2T; LIGHT: g_off, g_dia at the place of off)
   const double *lg2T = lut->lg2T;
+  long long *lg_off = reinterpret_cast<long long *>(vs_smem), *lg_dia = lg_off + PRAD_VS_LUT;
   constexpr int WAVE_BYTES = NT * TB + NGR * GSTR + (BAL ? NGR * BL::NREC * 16 : 0);
-  static_assert(sizeof(VoxSlideLut) % 16 == 0 && sizeof(VoxSlideLutK) % 16 == 0 && WAVE_BYTES % 16 == 0 && (NGR * GSTR) % 16 == 0,
+  static_assert(PRAD_VS_LUT_LDS % 16 == 0 && sizeof(VoxSlideLutK) % 16 == 0 && WAVE_BYTES % 16 == 0 && (NGR * GSTR) % 16 == 0,
                 "16-byte clears and reads");
-  long long *gk = reinterpret_cast<long long *>(vs_smem + sizeof(VoxSlideLut));      // WIDE: [5][PRAD_VS_KMAX]
-  unsigned char *wbase = vs_smem + sizeof(VoxSlideLut) + (WIDE ? sizeof(VoxSlideLutK) : 0) + (size_t)wave * WAVE_BYTES;
+  long long *gk = reinterpret_cast<long long *>(vs_smem + PRAD_VS_LUT_LDS);      // WIDE: [5][PRAD_VS_KMAX]
+  unsigned char *wbase = vs_smem + PRAD_VS_LUT_LDS + (WIDE ? sizeof(VoxSlideLutK) : 0) + (size_t)wave * WAVE_BYTES;
   unsigned char *planes = wbase + NT * TB;
   VoxSlideRec *recs = reinterpret_cast<VoxSlideRec *>(planes + NGR * GSTR);
-  for (int i = threadIdx.x; i < (int)(sizeof(VoxSlideLut) / 16); i += blockDim.x)
+  for (int i = threadIdx.x; i < (int)(PRAD_VS_LUT_LDS / 16); i += blockDim.x)
     reinterpret_cast<uint4 *>(vs_smem)[i] = reinterpret_cast<const uint4 *>(lut_g)[i];
+  if (LIGHT) {
+    __syncthreads();                                             // (the copy above put off / dia there)
+    for (int i = threadIdx.x; i < 2 * PRAD_VS_LUT; i += blockDim.x) lg_off[i] = lut_g->g_off[i];      // (g_dia follows g_off)
+  }
   if (WIDE) {
     for (int i = threadIdx.x; i < 5 * PRAD_VS_KMAX; i += blockDim.x) gk[i] = lutk_g->g[i / PRAD_VS_KMAX][i % PRAD_VS_KMAX];
   }
@@ -289,17 +303,19 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   {                                                                                                                  \
     const int lo = min(l1[K], l2[K]), hi = max(l1[K], l2[K]);                                                        \
     ok[K] = lo != 0;                                                                                                 \
-    const int idx = ok[K] ? (hi * (hi - 1) >> 1) + lo - 1 : TRASH;                                                   \
+    const int real = (hi * (hi - 1) >> 1) + lo - 1;     /* (outside the select: one v_cndmask, not an exec-masked region) */ \
+    const int idx = ok[K] ? real : TRASH;                                                                            \
     dg[K] = lo == hi;                                                                                                \
-    shf[K] = (idx & 3) * 8;                                                                                          \
-    const unsigned inc = SIGN > 0 ? (1u << shf[K]) : (0u - (1u << shf[K]));                                          \
+    shf[K] = idx * 8;                                   /* (shifts and bit-field extracts take its low five bits) */ \
+    const unsigned inc = SIGN > 0 ? (1u << (shf[K] & 31)) : (0u - (1u << (shf[K] & 31)));                            \
     old[K] = __hip_atomic_fetch_add((TBP) + (idx >> 2), inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);        \
   }
   // (c = the smaller of the entry's counts before / after)
 #define PRAD_VS_STAGE3(K)                                                                                            \
   {                                                                                                                  \
-    const int c = ok[K] ? (int)((old[K] >> shf[K]) & 255u) - (SIGN > 0 ? 0 : 1) : PRAD_VS_LUT - 1;                   \
-    e[K] = (dg[K] ? lut_dia : lut_off)[c];                                                                           \
+    const int c = ok[K] ? (int)__builtin_amdgcn_ubfe(old[K], (unsigned)shf[K], 8u) - (SIGN > 0 ? 0 : 1) : PRAD_VS_LUT - 1; \
+    if (LIGHT) e[K].g = (dg[K] ? lg_dia : lg_off)[c];                                                                \
+    else e[K] = (dg[K] ? lut_dia : lut_off)[c];                                                                      \
   }
   if constexpr (BAL) {
     constexpr int NSLOT = BL::NSLOT, SEG = BL::SEG, NSEG = BL::NSEG, MAXQ = BL::MAXQ, NREC = BL::NREC;
@@ -330,36 +346,53 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
     int EPq[NSEG], IJq[NSEG];
 #pragma unroll
     for (int r = 0; r < NSEG; r++) { Sq[r] = 0; EPq[r] = 0; IJq[r] = 0; }
-    auto slots = [&](const unsigned char *base, const int(&a1)[NSLOT], const int(&a2)[NSLOT], auto sign_tag) __attribute__((always_inline)) {
-      constexpr int SIGN = decltype(sign_tag)::value;
-      constexpr int CH = NSLOT > 8 ? 8 : NSLOT;
+    // the pairs of entering plane s (base_p) and, with BOTH, of leaving plane s - D (base_m) in one straight line: the level
+    // reads of the leaving plane are under way while the entering plane's pairs are counted
+    auto slots = [&](const unsigned char *base_p, const unsigned char *base_m, auto both_tag) __attribute__((always_inline)) {
+      constexpr int T = decltype(both_tag)::value ? 2 * NSLOT : NSLOT;
+#ifndef PRAD_VS_CHB
+#define PRAD_VS_CHB 16
+#endif
+      constexpr int CH = T > PRAD_VS_CHB ? PRAD_VS_CHB : T;      // slots in flight
 #pragma unroll
-      for (int c0 = 0; c0 < NSLOT; c0 += CH) {
+      for (int c0 = 0; c0 < T; c0 += CH) {
         int l1[CH], l2[CH], shf[CH];
         unsigned old[CH];
         bool ok[CH], dg[CH];
         VoxSlideLutE e[CH];
 #pragma unroll
         for (int k = 0; k < CH; k++) {
-          l1[k] = base[a1[c0 + k]];
-          l2[k] = base[a2[c0 + k]];
+          const int j = c0 + k, jj = j % NSLOT;
+          if (j < T) {
+            l1[k] = j < NSLOT ? base_p[a1P[jj]] : base_m[a1M[jj]];
+            l2[k] = j < NSLOT ? base_p[a2P[jj]] : base_m[a2M[jj]];
+          }
         }
 #pragma unroll
-        for (int k = 0; k < CH; k++) PRAD_VS_STAGE2(k, tb[c0 + k])
-#pragma unroll
-        for (int k = 0; k < CH; k++) PRAD_VS_STAGE3(k)
+        for (int k = 0; k < CH; k++) {
+          const int j = c0 + k, SIGN = j < NSLOT ? 1 : -1;
+          if (j < T) PRAD_VS_STAGE2(k, tb[j % NSLOT])
+        }
 #pragma unroll
         for (int k = 0; k < CH; k++) {
-          const int r = (c0 + k) / SEG;
-          const int ij = JA && ok[k] ? l1[k] + l2[k] : 0;
-          if (SIGN > 0) { Sq[r] += e[k].g; EPq[r] += e[k].ep; IJq[r] += ij; }
-          else { Sq[r] -= e[k].g; EPq[r] -= e[k].ep; IJq[r] -= ij; }
+          const int j = c0 + k, SIGN = j < NSLOT ? 1 : -1;
+          if (j < T) PRAD_VS_STAGE3(k)
+        }
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const int j = c0 + k, r = (j % NSLOT) / SEG;
+          if (j < T) {
+            const int ij = JA && ok[k] ? l1[k] + l2[k] : 0;
+            const int ep = LIGHT ? (ok[k] ? 1 : 0) : e[k].ep;      // (LIGHT: EPq counts the pairs)
+            if (j < NSLOT) { Sq[r] += e[k].g; EPq[r] += ep; IJq[r] += ij; }
+            else { Sq[r] -= e[k].g; EPq[r] -= ep; IJq[r] -= ij; }
+          }
         }
       }
     };
     for (int s = 0; s < XL; s++) {
-      slots(gp + s * PB, a1P, a2P, Plus{});
-      if (s >= D) slots(gp + (s - D) * PB, a1M, a2M, Minus{});      // (wave-uniform)
+      if (s >= D) slots(gp + s * PB, gp + (s - D) * PB, std::true_type{});      // (wave-uniform)
+      else slots(gp + s * PB, gp, std::false_type{});
       if (s < 2 * R) continue;
       if (a >= 13) {
 #pragma unroll
@@ -376,7 +409,7 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
         EP += rr.EP;
         IJ += rr.IJ;
       }
-      emit(s, S, EP, IJ);
+      emit(s, S, LIGHT ? EP << 20 : EP, IJ);
     }
   } else {
     // a lane per angle walks the plane: position p = (pz, py) pairs up with q = (pz + dz, py + dy) where that lies inside
@@ -425,8 +458,9 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
         for (int k = 0; k < CH; k++) {
           if (c0 + k < NP) {
             const int ij = JA && ok[k] ? l1[k] + l2[k] : 0;
-            if (SIGN > 0) { S += e[k].g; EP += e[k].ep; IJ += ij; }
-            else { S -= e[k].g; EP -= e[k].ep; IJ -= ij; }
+            const int ep = LIGHT ? (ok[k] ? 1 : 0) : e[k].ep;      // (LIGHT: EP counts the pairs)
+            if (SIGN > 0) { S += e[k].g; EP += ep; IJ += ij; }
+            else { S -= e[k].g; EP -= ep; IJ -= ij; }
             if (WIDE) {
               const int i1 = ok[k] ? l1[k] : 0, j1 = ok[k] ? l2[k] : 0;
               const int kd = i1 > j1 ? i1 - j1 : j1 - i1, sm = i1 + j1, sm2 = sm * sm;
@@ -456,7 +490,7 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
         plane_pairs(dx < 0 ? o + 1 : o, dx > 0 ? o + 1 : o, Minus{});
       }
       if (s < 2 * R) continue;
-      emit(s, S, EP, IJ);
+      emit(s, S, LIGHT ? EP << 20 : EP, IJ);
     }
   }
 #undef PRAD_VS_STAGE2

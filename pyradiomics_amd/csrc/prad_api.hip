@@ -1955,6 +1955,8 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
           t.off[k] = absent ? VoxSlideLutE{0, 0, 0} : VoxSlideLutE{2 * (f(k + 1) - f(k)) + 2 * nz, (1 << 20) | (2 * (2 * k + 1)), 0};
           t.dia[k] = absent ? VoxSlideLutE{0, 0, 0} : VoxSlideLutE{f(2 * k + 2) - f(2 * k) + nz, (1 << 20) | (4 * (2 * k + 1)), 0};
           t.lg2T[k] = k ? std::log2(2.0 * k) : 0.0;
+          t.g_off[k] = t.off[k].g;
+          t.g_dia[k] = t.dia[k].g;
         }
         return t;
       }();
@@ -1990,32 +1992,33 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
         PRAD_TRY(c.get<VoxSlideLutK>("voxslide_lutk", 1, &lutk_dev));
         PRAD_HIP(hipMemcpyAsync(lutk_dev, &lutk_h, sizeof(lutk_h), hipMemcpyHostToDevice, s));
       }
-#define PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WV, WD, JJ)                                                                         \
+#define PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WV, WD, JJ, LT)                                                                         \
   do {                                                                                                                      \
     constexpr size_t lds_s = voxel_glcm_slide_lds<RR, TWOD, RUNL, TBB, WV, WD>();                                           \
     static_assert(lds_s <= 160 * 1024, "LDS");                                                                              \
-    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_slide_kernel<RR, TWOD, RUNL, TBB, WV, WD, JJ>),     \
+    PRAD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&voxel_glcm_slide_kernel<RR, TWOD, RUNL, TBB, WV, WD, JJ, LT>),     \
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));                                  \
     const int wv = WV, rows = TWOD ? 16 : 4;                                                                                \
     const int nruns = (dims[2] + RUNL - 1) / RUNL;                                                                          \
-    hipLaunchKernelGGL((voxel_glcm_slide_kernel<RR, TWOD, RUNL, TBB, WV, WD, JJ>), dim3((nruns + wv - 1) / wv, (dims[1] + rows - 1) / rows, z_end - z_begin + 1), \
+    hipLaunchKernelGGL((voxel_glcm_slide_kernel<RR, TWOD, RUNL, TBB, WV, WD, JJ, LT>), dim3((nruns + wv - 1) / wv, (dims[1] + rows - 1) / rows, z_end - z_begin + 1), \
                        dim3(64 * wv), lds_s, s, levels, dims[0], dims[1], dims[2], A, Ng, lut_dev, lutk_dev, sched_dev, sl, maps, emap, flags, z_begin); \
   } while (0)
       // (the WIDE instantiation carries 2.5 KB of g(k) tables in LDS: one wave less where the base shape fills the 160 KB)
 #define PRAD_SLIDE_T(RR, TWOD, RUNL, TBB, WV, WVW)                                                                          \
   do {                                                                                                                      \
-    if (slide_is_wide) PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WVW, true, true);                                                 \
-    else if (sl.s[VF_JointAverage] >= 0) PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WV, false, true);                               \
-    else PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WV, false, false);                                                              \
+    if (slide_is_wide) PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WVW, true, true, false);                                          \
+    else if (sl.s[VF_JointAverage] >= 0) PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WV, false, true, false);                        \
+    else if (sl.s[VF_JointEnergy] >= 0) PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WV, false, false, false);                        \
+    else PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WV, false, false, true);                                                        \
   } while (0)
       // the lanes' private count tables hold Ng (Ng + 1) / 2 bytes: table size and waves per workgroup by level count
       // (32 levels: the round-4 shape; brain1 under exampleVoxel.yaml has 33)
 #define PRAD_SLIDE(RR, TWOD, RUNL)                                                                                          \
   do {                                                                                                                      \
-    if (Ng <= 32) PRAD_SLIDE_T(RR, TWOD, RUNL, 544, (TWOD ? 3 : 4), (TWOD ? 3 : 4));                                        \
-    else if (Ng <= 40) PRAD_SLIDE_T(RR, TWOD, RUNL, 832, (TWOD ? 2 : 3), 2);                                                \
-    else if (Ng <= 48) PRAD_SLIDE_T(RR, TWOD, RUNL, 1184, (TWOD ? 1 : 2), (TWOD ? 1 : 2));                                  \
-    else PRAD_SLIDE_T(RR, TWOD, RUNL, 2096, 1, 1);                                                                          \
+    if (Ng <= 32) PRAD_SLIDE_T(RR, TWOD, RUNL, 532, (TWOD ? 3 : 4), (TWOD ? 3 : 4));                                        \
+    else if (Ng <= 40) PRAD_SLIDE_T(RR, TWOD, RUNL, 828, (TWOD ? 2 : 3), 2);                                                \
+    else if (Ng <= 48) PRAD_SLIDE_T(RR, TWOD, RUNL, 1180, (TWOD ? 1 : 2), (TWOD ? 1 : 2));                                  \
+    else PRAD_SLIDE_T(RR, TWOD, RUNL, 2084, 1, 1);                                                                          \
   } while (0)
       if (std13 && kernelRadius == 2) PRAD_SLIDE(2, false, 64);
       else if (std13) PRAD_SLIDE(1, false, 64);
