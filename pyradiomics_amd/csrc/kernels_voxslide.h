@@ -40,7 +40,7 @@ namespace prad {
                                   // update the same few entries of their tables at once, and with an even stride (544 B until
                                   // round 6) every fourth table put that entry on the same LDS bank
 #define PRAD_VS_FIX 40            // fixed-point fraction bits of S
-#define PRAD_VS_LUT 112           // counts of a table entry <= 100 (pairs of one angle in a 5^3 window); the last entry: the absent pair
+#define PRAD_VS_LUT 104           // counts of a table entry <= 100 (pairs of one angle in a 5^3 window); the last entry: the absent pair
 #define PRAD_VS_NNZ_SHIFT 52      // S carries nnz above its 11 + 40 bits
 
 // WIDE (round 5): fourteen more features whose sums update pair by pair -- Autocorrelation, ClusterProminence / Shade / Tendency,
@@ -71,12 +71,13 @@ struct VoxSlideLutE {
 struct VoxSlideLut {             // built once on the host (prad_api.hip), lives in global memory, copied to LDS per workgroup
   VoxSlideLutE off[PRAD_VS_LUT];
   VoxSlideLutE dia[PRAD_VS_LUT];
-  double lg2T[PRAD_VS_LUT];      // log2(2 P) for P pairs
+  struct PT { double lg2T, inv; } pt[PRAD_VS_LUT];      // log2(2 P) and 1 / (2 P) for P pairs (the quotient the division gives)
+  double inv_na[16];             // 1 / n for n non-empty angles (n = 0: NaN)
   // LIGHT kernels (JointEntropy alone: no sum n^2) read 8 bytes per pair -- the g column of the entries above -- and count the
   // pairs themselves; in LDS the two columns take the place of off / dia
   long long g_off[PRAD_VS_LUT], g_dia[PRAD_VS_LUT];
 };
-#define PRAD_VS_LUT_LDS (sizeof(VoxSlideLutE) * 2 * PRAD_VS_LUT + 8 * PRAD_VS_LUT)      // bytes of LDS the LUTs take
+#define PRAD_VS_LUT_LDS (sizeof(VoxSlideLutE) * 2 * PRAD_VS_LUT + 16 * PRAD_VS_LUT + 128)      // bytes of LDS the LUTs take
 
 // sum over the lanes of a group of GS (4 or 16) neighbouring lanes, result in every lane of the group
 template <int GS>
@@ -176,8 +177,7 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // workgroup LDS: the LUTs, then per wave: tables [64][TB], planes [NGR][1 + XL][PB], the helper records [NGR][NREC]
   static_assert(!LIGHT || (!WIDE && !JA), "LIGHT: JointEntropy alone");
-  VoxSlideLut *lut = reinterpret_cast<VoxSlideLut *>(vs_smem);      // (off, dia, lg2T; LIGHT: g_off, g_dia at the place of off)
-  const double *lg2T = lut->lg2T;
+  VoxSlideLut *lut = reinterpret_cast<VoxSlideLut *>(vs_smem);      // (off, dia, pt, inv_na; LIGHT: g_off, g_dia at the place of off)
   long long *lg_off = reinterpret_cast<long long *>(vs_smem), *lg_dia = lg_off + PRAD_VS_LUT;
   constexpr int WAVE_BYTES = NT * TB + NGR * GSTR + (BAL ? NGR * BL::NREC * 16 : 0);
   static_assert(PRAD_VS_LUT_LDS % 16 == 0 && sizeof(VoxSlideLutK) % 16 == 0 && WAVE_BYTES % 16 == 0 && (NGR * GSTR) % 16 == 0,
@@ -232,27 +232,27 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   const bool wantF = WIDE && (sl.s[VF_Id] >= 0 || sl.s[VF_Idm] >= 0 || sl.s[VF_Idn] >= 0 || sl.s[VF_Idmn] >= 0 || sl.s[VF_InverseVariance] >= 0);
   const double eps_ln2 = 2.220446049250313e-16 / 0.6931471805599453;
   const double fix = 1.0 / (double)(1LL << PRAD_VS_FIX);
-  const double nan = __longlong_as_double(0x7ff8000000000000LL);
   // the centre at slab x index s - R, from this lane's sums: S (nnz in its bits from PRAD_VS_NNZ_SHIFT up), EP = P << 20 | E2, IJ
   auto emit = [&](int s, long long S, int EP, int IJ) __attribute__((always_inline)) {
     const int gx = x0 + s - 2 * R;
     const int P = EP >> 20, E2 = EP & 0xfffff;
     const bool nonempty = has_angle && P > 0;
     const int pc = nonempty ? P : 1;
-    const double T = (double)(2 * pc), iT = 1.0 / T;
+    const VoxSlideLut::PT pt = lut->pt[pc];
+    const double iT = pt.inv;                              // 1 / T, T = 2 P
     double h = 0, en = 0, ja = 0;
     if (nonempty) {
       if (slot_ent >= 0) {
         const long long Sf = S & ((1LL << PRAD_VS_NNZ_SHIFT) - 1);
         const int nnz = (int)(S >> PRAD_VS_NNZ_SHIFT);
-        h = lg2T[pc] - ((double)Sf * fix) * iT - (double)nnz * eps_ln2;
+        h = pt.lg2T - ((double)Sf * fix) * iT - (double)nnz * eps_ln2;
       }
       if (slot_en >= 0) en = (double)E2 * iT * iT;
       if (slot_ja >= 0) ja = (double)IJ * iT;
     }
     const int na = group_sum_i32<GS>(nonempty ? 1 : 0);
     const int em = group_sum_i32<GS>(has_angle && !nonempty ? (1 << a) : 0);
-    const double inv = na ? 1.0 / (double)na : nan;
+    const double inv = lut->inv_na[na];
     if (slot_ent >= 0) h = group_sum_f64<GS>(h) * inv;
     if (slot_en >= 0) en = group_sum_f64<GS>(en) * inv;
     if (slot_ja >= 0) ja = group_sum_f64<GS>(ja) * inv;
@@ -390,10 +390,7 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
         }
       }
     };
-    for (int s = 0; s < XL; s++) {
-      if (s >= D) slots(gp + s * PB, gp + (s - D) * PB, std::true_type{});      // (wave-uniform)
-      else slots(gp + s * PB, gp, std::false_type{});
-      if (s < 2 * R) continue;
+    auto centre = [&](int s) __attribute__((always_inline)) {
       if (a >= 13) {
 #pragma unroll
         for (int r = 0; r < NSEG; r++) hrec[r] = VoxSlideRec{Sq[r], EPq[r], IJq[r]};
@@ -410,6 +407,23 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
         IJ += rr.IJ;
       }
       emit(s, S, LIGHT ? EP << 20 : EP, IJ);
+    };
+    // the window fills (planes enter only), then slides: XL - D = RUN - 1 steps (PRAD_VS_UNROLL steps to a loop body: the 64
+    // level addresses of a step could then be bumped once per body -- measured no gain at 3, profiles/r06_probes.md section 12)
+    for (int s = 0; s < D; s++) {
+      slots(gp + s * PB, gp, std::false_type{});
+      if (s >= 2 * R) centre(s);
+    }
+#ifndef PRAD_VS_UNROLL
+#define PRAD_VS_UNROLL 1
+#endif
+    static_assert((XL - D) % PRAD_VS_UNROLL == 0, "the sliding steps come in whole loop bodies");
+    for (int s = D; s < XL; s += PRAD_VS_UNROLL) {
+#pragma unroll
+      for (int u = 0; u < PRAD_VS_UNROLL; u++) {
+        slots(gp + (s + u) * PB, gp + (s + u - D) * PB, std::true_type{});
+        centre(s + u);
+      }
     }
   } else {
     // a lane per angle walks the plane: position p = (pz, py) pairs up with q = (pz + dz, py + dy) where that lies inside
@@ -424,39 +438,49 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
     unsigned *tbl32 = reinterpret_cast<unsigned *>(tbl);
     long long S = 0;
     int EP = 0, IJ = 0;
-    // the pairs between plane kp (the p side) and plane kq (the q side; -1: the plane of zeros)
-    auto plane_pairs = [&](int kp, int kq, auto sign_tag) __attribute__((always_inline)) {
-      constexpr int SIGN = decltype(sign_tag)::value;
+    // plane s enters -- pairs inside it (dx = 0) or with plane s - 1 (p side for dx > 0, q side for dx < 0; the run's first plane
+    // has the plane of zeros there: no pairs) -- and, with BOTH, plane o = s - D leaves -- pairs inside it or with plane o + 1 --
+    // in one straight line for the 2-D windows (the 5 x 5 window has 5 positions per plane: one sign at a time left four LDS
+    // round trips per five pairs exposed)
+    // (MODE 0: the entering plane, 1: both, 2: the leaving plane)
+    auto plane_pairs = [&](int s, auto mode_tag) __attribute__((always_inline)) {
+      constexpr int MODE = decltype(mode_tag)::value;
+      constexpr int J0 = MODE == 2 ? NP : 0, T = MODE == 0 ? NP : 2 * NP;
 #ifndef PRAD_VS_CH
 #define PRAD_VS_CH 9
 #endif
-      constexpr int CH = NP > PRAD_VS_CH ? PRAD_VS_CH : NP;   // positions in flight
-      const unsigned char *pp = gp + kp * PB, *pq = gp + kq * PB;
+      constexpr int CH = T - J0 <= 10 ? T - J0 : PRAD_VS_CH;         // positions in flight
+      const int o = s - D;
+      const unsigned char *pp_p = gp + (dx > 0 ? s - 1 : s) * PB, *pq_p = gp + (dx < 0 ? s - 1 : s) * PB;
+      const unsigned char *pp_m = gp + (dx < 0 ? o + 1 : o) * PB, *pq_m = gp + (dx > 0 ? o + 1 : o) * PB;
 #pragma unroll
-      for (int c0 = 0; c0 < NP; c0 += CH) {
+      for (int c0 = J0; c0 < T; c0 += CH) {
         int l1[CH], l2[CH], shf[CH];
         unsigned old[CH];
         bool ok[CH], dg[CH];
         VoxSlideLutE e[CH];
 #pragma unroll
         for (int k = 0; k < CH; k++) {
-          const int p = c0 + k;
-          if (p < NP) {
-            l1[k] = pp[p];
-            l2[k] = pq[qa[p]];
+          const int j = c0 + k, p = j % NP;
+          if (j < T) {
+            l1[k] = j < NP ? pp_p[p] : pp_m[p];
+            l2[k] = j < NP ? pq_p[qa[p]] : pq_m[qa[p]];
           }
         }
 #pragma unroll
         for (int k = 0; k < CH; k++) {
-          if (c0 + k < NP) PRAD_VS_STAGE2(k, tbl32)
+          const int j = c0 + k, SIGN = j < NP ? 1 : -1;
+          if (j < T) PRAD_VS_STAGE2(k, tbl32)
         }
 #pragma unroll
         for (int k = 0; k < CH; k++) {
-          if (c0 + k < NP) PRAD_VS_STAGE3(k)
+          const int j = c0 + k, SIGN = j < NP ? 1 : -1;
+          if (j < T) PRAD_VS_STAGE3(k)
         }
 #pragma unroll
         for (int k = 0; k < CH; k++) {
-          if (c0 + k < NP) {
+          const int j = c0 + k, SIGN = j < NP ? 1 : -1;
+          if (j < T) {
             const int ij = JA && ok[k] ? l1[k] + l2[k] : 0;
             const int ep = LIGHT ? (ok[k] ? 1 : 0) : e[k].ep;      // (LIGHT: EP counts the pairs)
             if (SIGN > 0) { S += e[k].g; EP += ep; IJ += ij; }
@@ -480,16 +504,17 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
         }
       }
     };
-    for (int s = 0; s < XL; s++) {
-      // plane s enters: pairs inside it (dx = 0) or with plane s - 1 (p side for dx > 0, q side for dx < 0; the run's first
-      // plane has the plane of zeros there: no pairs)
-      plane_pairs(dx > 0 ? s - 1 : s, dx < 0 ? s - 1 : s, Plus{});
-      // plane s - D leaves: pairs inside it or with plane s - D + 1
-      if (s >= D) {                                        // (wave-uniform)
-        const int o = s - D;
-        plane_pairs(dx < 0 ? o + 1 : o, dx > 0 ? o + 1 : o, Minus{});
+    for (int s = 0; s < D; s++) {                            // the window fills
+      plane_pairs(s, std::integral_constant<int, 0>{});
+      if (s >= 2 * R) emit(s, S, LIGHT ? EP << 20 : EP, IJ);
+    }
+    for (int s = D; s < XL; s++) {                           // and slides
+      if constexpr (TWO_D) {
+        plane_pairs(s, std::integral_constant<int, 1>{});
+      } else {                                               // (25 positions per plane and the WIDE sums: one sign at a time is faster)
+        plane_pairs(s, std::integral_constant<int, 0>{});
+        plane_pairs(s, std::integral_constant<int, 2>{});
       }
-      if (s < 2 * R) continue;
       emit(s, S, LIGHT ? EP << 20 : EP, IJ);
     }
   }

@@ -29,6 +29,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
+#include <limits>
 #include <mutex>
 #include <thread>
 
@@ -1954,10 +1955,12 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
           const long long nz = k == 0 ? 1LL << PRAD_VS_NNZ_SHIFT : 0;
           t.off[k] = absent ? VoxSlideLutE{0, 0, 0} : VoxSlideLutE{2 * (f(k + 1) - f(k)) + 2 * nz, (1 << 20) | (2 * (2 * k + 1)), 0};
           t.dia[k] = absent ? VoxSlideLutE{0, 0, 0} : VoxSlideLutE{f(2 * k + 2) - f(2 * k) + nz, (1 << 20) | (4 * (2 * k + 1)), 0};
-          t.lg2T[k] = k ? std::log2(2.0 * k) : 0.0;
+          t.pt[k].lg2T = k ? std::log2(2.0 * k) : 0.0;
+          t.pt[k].inv = k ? 1.0 / (2.0 * k) : 0.0;
           t.g_off[k] = t.off[k].g;
           t.g_dia[k] = t.dia[k].g;
         }
+        for (int n = 0; n < 16; n++) t.inv_na[n] = n ? 1.0 / (double)n : std::numeric_limits<double>::quiet_NaN();
         return t;
       }();
       VoxSlideLut *lut_dev = nullptr;
@@ -2012,10 +2015,11 @@ int voxel_glcm_features_dev(const int32_t *image, const uint8_t *mask, const int
     else PRAD_SLIDE_TW(RR, TWOD, RUNL, TBB, WV, false, false, true);                                                        \
   } while (0)
       // the lanes' private count tables hold Ng (Ng + 1) / 2 bytes: table size and waves per workgroup by level count
-      // (32 levels: the round-4 shape; brain1 under exampleVoxel.yaml has 33)
+      // (brain1 under exampleVoxel.yaml has 33 levels).  2-D windows at <= 32 levels: runs of 32 centres instead of 64 -- the
+      // staged planes of a wave halve, and FOUR waves' tables fit the 160 KB instead of three (a SIMD of every CU sat idle)
 #define PRAD_SLIDE(RR, TWOD, RUNL)                                                                                          \
   do {                                                                                                                      \
-    if (Ng <= 32) PRAD_SLIDE_T(RR, TWOD, RUNL, 532, (TWOD ? 3 : 4), (TWOD ? 3 : 4));                                        \
+    if (Ng <= 32) PRAD_SLIDE_T(RR, TWOD, (TWOD ? 32 : RUNL), 532, 4, 4);                                                    \
     else if (Ng <= 40) PRAD_SLIDE_T(RR, TWOD, RUNL, 828, (TWOD ? 2 : 3), 2);                                                \
     else if (Ng <= 48) PRAD_SLIDE_T(RR, TWOD, RUNL, 1180, (TWOD ? 1 : 2), (TWOD ? 1 : 2));                                  \
     else PRAD_SLIDE_T(RR, TWOD, RUNL, 2084, 1, 1);                                                                          \
