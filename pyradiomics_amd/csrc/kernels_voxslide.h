@@ -504,18 +504,23 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
         }
       }
     };
-    for (int s = 0; s < D; s++) {                            // the window fills
-      plane_pairs(s, std::integral_constant<int, 0>{});
-      if (s >= 2 * R) emit(s, S, LIGHT ? EP << 20 : EP, IJ);
-    }
-    for (int s = D; s < XL; s++) {                           // and slides
-      if constexpr (TWO_D) {
-        plane_pairs(s, std::integral_constant<int, 1>{});
-      } else {                                               // (25 positions per plane and the WIDE sums: one sign at a time is faster)
+    if constexpr (TWO_D) {
+      for (int s = 0; s < D; s++) {                          // the window fills
         plane_pairs(s, std::integral_constant<int, 0>{});
-        plane_pairs(s, std::integral_constant<int, 2>{});
+        if (s >= 2 * R) emit(s, S, LIGHT ? EP << 20 : EP, IJ);
       }
-      emit(s, S, LIGHT ? EP << 20 : EP, IJ);
+      for (int s = D; s < XL; s++) {                         // and slides
+        plane_pairs(s, std::integral_constant<int, 1>{});
+        emit(s, S, LIGHT ? EP << 20 : EP, IJ);
+      }
+    } else {
+      // (3-D windows come here with the WIDE sums only: 25 positions per plane at ~80 instructions each -- one sign at a time and
+      // one copy of the code measured 4 % faster than the merged / peeled form)
+      for (int s = 0; s < XL; s++) {
+        plane_pairs(s, std::integral_constant<int, 0>{});
+        if (s >= D) plane_pairs(s, std::integral_constant<int, 2>{});      // (wave-uniform)
+        if (s >= 2 * R) emit(s, S, LIGHT ? EP << 20 : EP, IJ);
+      }
     }
   }
 #undef PRAD_VS_STAGE2
