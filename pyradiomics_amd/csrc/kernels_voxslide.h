@@ -7,28 +7,30 @@
 // exampleVoxel.yaml).  The reference has no analogue: it materialises P[Nvox][Ng][Ng][Na] and evaluates the formulas with
 // numpy (glcm.py:145-205, base.py:200-245); the values produced here are the same features of the same matrices.
 //
-// Work decomposition: a LANE owns ONE ANGLE of one row of centres and keeps that angle's co-occurrence counts in a private
-// LDS table for the whole run of centres: symmetric counts m(lo, hi) of the unordered level pair, one byte each (a window
-// of radius <= 2 holds at most 100 pairs per angle), Ng (Ng + 1) / 2 <= 528 bytes.  Nothing is shared between lanes, so the
-// per-angle sums need no wave reduction: each lane carries
+// Work decomposition: the co-occurrence counts of one ANGLE of one row of centres live in an LDS table for the whole run of
+// centres: symmetric counts m(lo, hi) of the unordered level pair, one byte each (a window of radius <= 2 holds at most 100 pairs
+// per angle), Ng (Ng + 1) / 2 <= 528 bytes.  2-D windows: a lane per (row, angle) walks the plane's positions and owns the
+// table.  3-D windows: the sixteen lanes of a group share the work of its thirteen angles (VoxSlideBal below).  Per angle:
 //     S   = sum over matrix entries of n log2 n   (n = 2 m on the diagonal, m elsewhere and there twice), as a 2^-40
 //           fixed-point integer built from table DIFFERENCES g(c) = f(c + 1) - f(c): the sum telescopes, so S is exactly
 //           the sum of the rounded f over the current counts whatever the history of the window -- no drift along a run,
-//           results independent of where a run starts
-//     nnz = non-zero entries, E2 = sum of n^2, P = pairs, IJ = sum of (i + j) over the pairs
+//           results independent of where a run starts, of which lane applied a pair and of the order of the atomics
+//     nnz = non-zero entries (carried in the bits of S above its 51), E2 = sum of n^2, P = pairs (one word: P << 20 | E2),
+//     IJ = sum of (i + j) over the pairs
 // and JointEntropy = log2 T - S / T - nnz eps / ln 2 (the first-order expansion of -sum p log2(p + eps), p = n / T,
 // T = 2 P; the neglected term is < 1e-28), JointEnergy = E2 / T^2, JointAverage = IJ / T follow per angle; the mean over
 // the non-empty angles of a centre (np.nanmean, glcm.py:260-887) is a sum over the 16 (3-D, 13 angles) or 4 (2-D window,
 // 4 angles) lanes of a group.  A wave holds 4 (16) groups = 4 (16) neighbouring rows.
 // The levels a group needs -- its row's planes of (2R+1)^2 (2R+1) voxels per x -- are staged once per run into LDS, a
-// plane per 32 (8) bytes; a run starts 2R+1 planes early with an empty table (planes only enter).
+// plane per 32 (8) bytes behind one plane of zeros; a run starts 2R+1 planes early with an empty table (planes only enter).
 //
 // Covered: 3 image dimensions, symmetrical GLCM, distance 1, kernelRadius 1 or 2, Ng <= 64 (round 5: the table size TB and
-// the waves per workgroup are template parameters -- 32 levels: 544 B tables, 3 / 4 waves; 40: 832 B, 2 waves; 48: 1184 B,
-// 1 / 2 waves; 64: 2080 B, one wave -- so that the reference's own example, exampleVoxel.yaml on brain1 with its 33 levels,
+// the waves per workgroup are template parameters -- 32 levels: 532 B tables, 4 waves; 40: 828 B, 2 / 3 waves; 48: 1180 B,
+// 1 / 2 waves; 64: 2084 B, one wave -- so that the reference's own example, exampleVoxel.yaml on brain1 with its 33 levels,
 // takes this kernel), full 3-D windows or force2D along the first (slice) axis, the features above.  Everything else stays
-// on kernels_voxel.h.  Checked against the reference route (tests/test_gpu_configs.py) and the window kernel
-// (tests/test_gpu_features.py).
+// on kernels_voxel.h.  Checked against the reference route (tests/test_gpu_configs.py, tests/test_gpu_stress.py) and the
+// window kernel (tests/test_gpu_features.py).  Round 6 (profiles/r06_probes.md section 12): 5^3 window at 512^3 207 -> 91 ms,
+// 5 x 5 window 23.0 -> 12.2 ms, bit-identical maps.
 #pragma once
 #include "prad_runtime.h"
 #include "kernels_voxel.h"
@@ -140,8 +142,8 @@ struct VoxSlideRec {          // a helper segment's sums (16 bytes)
 };
 
 // R: kernel radius (1, 2); TWO_D: the window has no extent along z (force2D on the slice axis, or a single slice)
-// RUN: centres per run.  Grid: x = runs along x, y = groups of rows, z = slices; a workgroup = 4 (2-D windows: 3) waves =
-// consecutive runs -- what 160 KB of LDS hold: 13 x 4 (64) tables of 544 B and 4 (16) rows of staged planes per wave.
+// RUN: centres per run.  Grid: x = runs along x, y = groups of rows, z = slices; a workgroup = 4 waves (fewer above 32 levels) =
+// consecutive runs -- what 160 KB of LDS hold: 13 x 4 (64) tables of 532 B and 4 (16) rows of staged planes per wave.
 // maps: [nmaps][Nz][Ny][Nx] float64 (slot < 0: feature not requested); empty: [Nz][Ny][Nx] angle bits without a pair.
 template <int R, bool TWO_D, int RUN, int TB, int WAVES, bool WIDE = false>
 constexpr size_t voxel_glcm_slide_lds() {
