@@ -638,6 +638,33 @@ def test_sliding_window_maps_equal_the_window_kernel(shape, radius, force2D, Ng)
         np.testing.assert_allclose(a[ok], b[ok], rtol=1e-12 if f != "JointEntropy" else 1e-11, atol=1e-13, err_msg=f)
 
 
+@pytest.mark.parametrize("feats", [["JointEntropy"], ["JointEnergy"], ["JointAverage"], ["JointEntropy", "JointEnergy"]])
+@pytest.mark.parametrize("radius,force2D", [(2, False), (1, False), (2, True), (1, True)])
+@pytest.mark.parametrize("Ng", [32, 38, 64])
+def test_sliding_window_instantiations_by_request(feats, radius, force2D, Ng):
+    """round 6: the kernel is instantiated by what the request needs -- JointEntropy alone (LIGHT: 8-byte LUT entries, pairs
+    counted by the lanes), without / with the sum of i + j (JA) -- and 3-D windows run the lane-balanced schedule (helper
+    lanes, LDS records); a volume wider than two runs of 64 and of 32 centres, rows that are no whole group, every centre
+    against the from-scratch window kernel"""
+    shape = (7, 22, 150)
+    rng = np.random.default_rng(hash((tuple(feats), radius, force2D, Ng, 6)) % (2 ** 32))
+    img = rng.integers(1, Ng + 1, size=shape).astype(np.int32)
+    img[:, : shape[1] // 2] = (img[:, : shape[1] // 2] + 3) // 4 + 1          # repeated pairs: counts beyond 1
+    img[2:5, 4:9, 20:90] = Ng                                                 # a constant block: the largest counts a window has
+    msk = rng.random(shape) < 0.9
+    msk[:, -2:, :] = False
+    msk[3, 5:8, 30:60] = True
+    vox = np.array(np.nonzero(np.ones(shape, bool))).astype(np.int32)
+    new, old, variant = _slide_vs_window(img, msk, Ng, vox, feats, kernelRadius=radius, force2D=force2D, force2Ddimension=0)
+    assert variant == "slide"
+    for f in feats:
+        a, b = new[f], old[f]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f
+        ok = ~np.isnan(a)
+        assert ok.sum() > 0
+        np.testing.assert_allclose(a[ok], b[ok], rtol=1e-12 if f != "JointEntropy" else 1e-11, atol=1e-13, err_msg=f)
+
+
 @pytest.mark.parametrize("shape", [(9, 37, 70), (1, 40, 66), (23, 5, 9)])
 @pytest.mark.parametrize("radius,force2D", [(2, False), (1, False), (2, True)])
 @pytest.mark.parametrize("Ng", [32, 40, 64])
