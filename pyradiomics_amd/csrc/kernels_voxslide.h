@@ -237,6 +237,10 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   // the centre at slab x index s - R, from this lane's sums: S (nnz in its bits from PRAD_VS_NNZ_SHIFT up), EP = P << 20 | E2, IJ
   auto emit = [&](int s, long long S, int EP, int IJ) __attribute__((always_inline)) {
     const int gx = x0 + s - 2 * R;
+#ifdef PRAD_DBG_NOEMIT      // (timing probe, wrong maps: what the pair code alone costs)
+    if (a == 0 && y < Ny && gx < Nx) maps[((long long)z * Ny + y) * Nx + gx] = __longlong_as_double(S + EP + IJ);
+    return;
+#endif
     const int P = EP >> 20, E2 = EP & 0xfffff;
     const bool nonempty = has_angle && P > 0;
     const int pc = nonempty ? P : 1;
