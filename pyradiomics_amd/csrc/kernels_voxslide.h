@@ -169,7 +169,10 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   constexpr int GSTR = (XL + (TWO_D ? 1 : 2)) * PB;   // bytes of a group's planes: one of zeros, then the XL of the run; 3-D: and
                                                // one to make the stride 16 banks (mod 32) -- the two groups of a half wave read
                                                // two neighbouring planes = 16 banks each, side by side
-  constexpr bool BAL = !TWO_D && !WIDE;        // the lane-balanced schedule (above)
+#ifndef PRAD_VS_BAL_R1
+#define PRAD_VS_BAL_R1 1
+#endif
+  constexpr bool BAL = !TWO_D && !WIDE && (R == 2 || PRAD_VS_BAL_R1);        // the lane-balanced schedule (above)
   using BL = VoxSlideBal<R>;
   constexpr int NT = TWO_D ? 64 : 13 * NGR;    // count tables per wave (3-D: the 13 angle lanes of each group)
   static_assert(TB % 8 == 4 && (NT * TB) % 16 == 0, "tables: an odd number of words each, cleared 16 bytes at a time");
