@@ -114,6 +114,10 @@ out = {"workload": [512, 32, "uniform"], "deferred_mode": "pipeline",
                  "in pipeline mode: walks + inline pack + x-angle kernel + finalize; kernel_bytes: the fused launch alone)"}
 print(json.dumps(out, indent=1))
 PY
+# the sliding-window map kernels' SQ counters (two more passes, 256^3 maps)
+bash $R/scripts/r06_voxel_pmc.sh > /dev/null 2>&1
+{ echo; echo "## sliding-window map kernels (scripts/r06_voxel_pmc.sh: JointEntropy maps of a 256^3 volume, 5^3 and 5 x 5 windows)"; echo; cat $R/gpurun_out/r06_voxpmc/pmc.md; } >> $O/pmc.md
+rm -rf $R/gpurun_out/r06_voxpmc/pmc
 cd $R
 find $O -name "*.db" -delete
 find $O -name "*.csv" -size +200k -delete
