@@ -54,6 +54,19 @@ namespace prad {
 // Not carried (they stay on kernels_voxel.h): Correlation (the reference's sigma == 0 test is a float accident), the entropies of
 // the sum / difference distributions, Imc1 / Imc2, MCC, MaximumProbability.
 #define PRAD_VS_KMAX 64
+// Tuning knobs (the defaults are what profiles/r06_probes.md section 12 measured best; scripts/build_variant.sh builds others):
+#ifndef PRAD_VS_CH
+#define PRAD_VS_CH 9              // pair positions in flight per stage where a lane per angle walks a 3-D plane (the WIDE sums)
+#endif
+#ifndef PRAD_VS_CHB
+#define PRAD_VS_CHB 16            // ... on the lane-balanced schedule (16 entering, then 16 leaving)
+#endif
+#ifndef PRAD_VS_UNROLL
+#define PRAD_VS_UNROLL 1          // sliding steps per loop body of the balanced schedule (3: no gain)
+#endif
+#ifndef PRAD_VS_BAL_R1
+#define PRAD_VS_BAL_R1 1          // 3^3 windows on the balanced schedule too (0: a lane per angle, 51 instead of 43 ms at 512^3)
+#endif
 struct VoxSlideLutK {            // g_f(k) * 2^40, f = Id, Idm, Idn, Idmn, InverseVariance (built per call: Idn / Idmn depend on Ng)
   long long g[5][PRAD_VS_KMAX];
 };
@@ -169,9 +182,6 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   constexpr int GSTR = (XL + (TWO_D ? 1 : 2)) * PB;   // bytes of a group's planes: one of zeros, then the XL of the run; 3-D: and
                                                // one to make the stride 16 banks (mod 32) -- the two groups of a half wave read
                                                // two neighbouring planes = 16 banks each, side by side
-#ifndef PRAD_VS_BAL_R1
-#define PRAD_VS_BAL_R1 1
-#endif
   constexpr bool BAL = !TWO_D && !WIDE && (R == 2 || PRAD_VS_BAL_R1);        // the lane-balanced schedule (above)
   using BL = VoxSlideBal<R>;
   constexpr int NT = TWO_D ? 64 : 13 * NGR;    // count tables per wave (3-D: the 13 angle lanes of each group)
@@ -230,8 +240,6 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
   const unsigned char *gp = planes + grp * GSTR + PB;   // this group's planes of the run (gp - PB: the plane of zeros)
   constexpr int TRASH = TB - 4;                          // (the byte index of) a word no level pair counts in
   const VoxSlideLutE *lut_off = lut->off, *lut_dia = lut->dia;
-  using Plus = std::integral_constant<int, 1>;
-  using Minus = std::integral_constant<int, -1>;
   int wA = 0, wQ2 = 0, wD1 = 0, wS3 = 0;            // WIDE: sum ij, sum (i^2 + j^2), sum |i - j|, sum (i + j)^3
   long long wS4 = 0, wF0 = 0, wF1 = 0, wF2 = 0, wF3 = 0, wF4 = 0;
   const bool wantF = WIDE && (sl.s[VF_Id] >= 0 || sl.s[VF_Idm] >= 0 || sl.s[VF_Idn] >= 0 || sl.s[VF_Idmn] >= 0 || sl.s[VF_InverseVariance] >= 0);
@@ -359,9 +367,6 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
     // reads of the leaving plane are under way while the entering plane's pairs are counted
     auto slots = [&](const unsigned char *base_p, const unsigned char *base_m, auto both_tag) __attribute__((always_inline)) {
       constexpr int T = decltype(both_tag)::value ? 2 * NSLOT : NSLOT;
-#ifndef PRAD_VS_CHB
-#define PRAD_VS_CHB 16
-#endif
       constexpr int CH = T > PRAD_VS_CHB ? PRAD_VS_CHB : T;      // slots in flight
 #pragma unroll
       for (int c0 = 0; c0 < T; c0 += CH) {
@@ -423,9 +428,6 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
       slots(gp + s * PB, gp, std::false_type{});
       if (s >= 2 * R) centre(s);
     }
-#ifndef PRAD_VS_UNROLL
-#define PRAD_VS_UNROLL 1
-#endif
     static_assert((XL - D) % PRAD_VS_UNROLL == 0, "the sliding steps come in whole loop bodies");
     for (int s = D; s < XL; s += PRAD_VS_UNROLL) {
 #pragma unroll
@@ -455,9 +457,6 @@ __global__ void __launch_bounds__(64 * WAVES) voxel_glcm_slide_kernel(const uint
     auto plane_pairs = [&](int s, auto mode_tag) __attribute__((always_inline)) {
       constexpr int MODE = decltype(mode_tag)::value;
       constexpr int J0 = MODE == 2 ? NP : 0, T = MODE == 0 ? NP : 2 * NP;
-#ifndef PRAD_VS_CH
-#define PRAD_VS_CH 9
-#endif
       constexpr int CH = T - J0 <= 10 ? T - J0 : PRAD_VS_CH;         // positions in flight
       const int o = s - D;
       const unsigned char *pp_p = gp + (dx > 0 ? s - 1 : s) * PB, *pq_p = gp + (dx < 0 ? s - 1 : s) * PB;
